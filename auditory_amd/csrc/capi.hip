@@ -1,0 +1,499 @@
+// C ABI of libauditory_hip.so: context / plan management and the batch entry points.
+// See include/auditory_hip.h for the contract of every function.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+struct aud_ctx {
+    int device = -1;
+    std::string err = "";
+    hipStream_t stream = nullptr;  // used by the _host entry points
+    // grow-only device workspaces for the _host entry points
+    void* ws[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t ws_cap[4] = {0, 0, 0, 0};
+    // RCCL (loaded lazily)
+    void* rccl_lib = nullptr;
+    void* comm = nullptr;
+    int n_ranks = 0, rank = 0;
+};
+
+struct aud_plan {
+    aud_ctx* ctx = nullptr;
+    aud_plan_desc d{};
+    int H = 0, M = 0, ratio = 0;
+    int nfac = 0;
+    int fac[aud::kMaxFactors] = {0};
+    int F_generic = 0;
+    void* d_tw = nullptr;
+    void* d_filt = nullptr;
+    int32_t* d_bin_pts = nullptr;
+    void* d_gabor = nullptr;
+    const char* family = "generic";
+};
+
+namespace {
+
+int fail(aud_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+int hip_fail(aud_ctx* c, hipError_t e, const char* what) {
+    return fail(c, AUD_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define AUD_HIP(c, call)                                   \
+    do {                                                   \
+        hipError_t e__ = (call);                           \
+        if (e__ != hipSuccess) return hip_fail(c, e__, #call); \
+    } while (0)
+
+size_t tsize(int dt) { return dt == AUD_F64 ? 8 : 4; }
+
+int ensure_ws(aud_ctx* c, int slot, size_t bytes) {
+    if (c->ws_cap[slot] >= bytes) return AUD_OK;
+    if (c->ws[slot]) {
+        AUD_HIP(c, hipFree(c->ws[slot]));
+        c->ws[slot] = nullptr;
+        c->ws_cap[slot] = 0;
+    }
+    const size_t cap = bytes + bytes / 4 + 4096;
+    AUD_HIP(c, hipMalloc(&c->ws[slot], cap));
+    c->ws_cap[slot] = cap;
+    return AUD_OK;
+}
+
+template <typename TT>
+std::vector<TT> convert(const double* src, size_t n) {
+    std::vector<TT> v(n);
+    for (size_t i = 0; i < n; ++i) v[i] = TT(src[i]);
+    return v;
+}
+
+int upload(aud_ctx* c, void** dst, const void* src, size_t bytes) {
+    AUD_HIP(c, hipMalloc(dst, bytes ? bytes : 16));
+    if (bytes) AUD_HIP(c, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return AUD_OK;
+}
+
+int upload_real(aud_ctx* c, void** dst, const double* src, size_t n, int dt) {
+    if (dt == AUD_F64) return upload(c, dst, src, n * 8);
+    std::vector<float> v = convert<float>(src, n);
+    return upload(c, dst, v.data(), n * 4);
+}
+
+void factorize(int m, int* fac, int* nfac) {
+    int n = 0;
+    while (m % 4 == 0) { fac[n++] = 4; m /= 4; }
+    while (m % 2 == 0) { fac[n++] = 2; m /= 2; }
+    for (int p = 3; int64_t(p) * p <= m; p += 2)
+        while (m % p == 0) { fac[n++] = p; m /= p; }
+    if (m > 1) fac[n++] = m;
+    *nfac = n;
+}
+
+void fill_melspec_args(const aud_plan* p, aud::MelspecArgs* a) {
+    const aud_plan_desc& d = p->d;
+    std::memset(a, 0, sizeof(*a));
+    a->N = d.win_samples;
+    a->S = d.step_samples;
+    a->T = d.segment_steps;
+    a->border = d.border_steps;
+    a->H = p->H;
+    a->M = p->M;
+    a->ratio = p->ratio;
+    a->nfac = p->nfac;
+    for (int i = 0; i < p->nfac; ++i) a->fac[i] = p->fac[i];
+    a->tw = p->d_tw;
+    a->nf = d.mel.n_filters;
+    a->bin_pts = p->d_bin_pts;
+    a->filt = p->d_filt;
+    a->mel_log_off = d.mel.log_off;
+    a->mel_log_min = d.mel.log_min;
+    a->renorm = d.mel.renorm;
+    a->renorm_min = d.mel.renorm_min;
+    a->renorm_scale = d.mel.renorm_scale;
+    a->comp_log_pow = d.dft.comp_log_pow;
+    a->dft_log_min = d.dft.log_min;
+    a->dft_log_off = d.dft.log_offset;
+    a->F = p->F_generic;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aud_init(int device_id, aud_ctx** out) {
+    if (!out) return AUD_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return AUD_EHIP;
+    aud_ctx* c = new (std::nothrow) aud_ctx();
+    if (!c) return AUD_ENOMEM;
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return AUD_EHIP;
+    }
+    *out = c;
+    return AUD_OK;
+}
+
+int aud_shutdown(aud_ctx* c) {
+    if (!c) return AUD_EINVAL;
+    (void)hipSetDevice(c->device);
+    aud_comm_destroy(c);
+    for (int i = 0; i < 4; ++i)
+        if (c->ws[i]) (void)hipFree(c->ws[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->rccl_lib) dlclose(c->rccl_lib);
+    delete c;
+    return AUD_OK;
+}
+
+const char* aud_last_error(const aud_ctx* c) { return c ? c->err.c_str() : "null context"; }
+int aud_device_id(const aud_ctx* c) { return c ? c->device : -1; }
+
+int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
+    if (!c || !d || !out) return AUD_EINVAL;
+    *out = nullptr;
+    const int N = d->win_samples, nf = d->mel.n_filters;
+    if (N < 4 || d->step_samples < 1 || d->segment_steps < 1 || d->border_steps < 0)
+        return fail(c, AUD_EINVAL, "win_samples >= 4, step_samples >= 1, segment_steps >= 1 required");
+    if (nf < 1 || !d->bin_pts || !d->mel_filters) return fail(c, AUD_EINVAL, "mel table missing");
+    if (d->compute_dtype != AUD_F32 && d->compute_dtype != AUD_F64)
+        return fail(c, AUD_EINVAL, "compute_dtype must be AUD_F32 or AUD_F64");
+    if (d->dft.prev_smooth != 0.0)
+        return fail(c, AUD_EINVAL, "dft.PrevSmooth != 0 (sequential smoothing) is not supported yet");
+    const int H = N / 2 + 1;
+    // Envelope of mel.FilterDft (mel.go:128-131): every tap must stay inside Power [H] and
+    // inside the [nf, nf+2] table (flat offset); outside it the Go code panics.
+    const int64_t cells = int64_t(nf) * (nf + 2);
+    for (int f = 0; f < nf; ++f) {
+        const int lo = d->bin_pts[f], hi = d->bin_pts[f + 2];
+        if (lo < 0 || hi >= H) return fail(c, AUD_EINVAL, "mel BinPts outside the power spectrum (HiHz > Nyquist?)");
+        if (hi >= lo && int64_t(f) * (nf + 2) + (hi - lo) >= cells)
+            return fail(c, AUD_EINVAL, "mel triangle wider than the filter table (SURVEY Q4)");
+    }
+    if (d->n_gabor > 0) {
+        if (!d->gabor_filters || d->gabor.size_x < 1 || d->gabor.size_y < 1 || d->gabor.stride_x < 1 ||
+            d->gabor.stride_y < 1)
+            return fail(c, AUD_EINVAL, "gabor filter set incomplete");
+    }
+    AUD_HIP(c, hipSetDevice(c->device));
+
+    aud_plan* p = new (std::nothrow) aud_plan();
+    if (!p) return AUD_ENOMEM;
+    p->ctx = c;
+    p->d = *d;
+    p->d.bin_pts = nullptr;
+    p->d.mel_filters = nullptr;
+    p->d.gabor_filters = nullptr;
+    p->H = H;
+    p->ratio = (N % 2 == 0) ? 2 : 1;
+    p->M = N / p->ratio;
+    factorize(p->M, p->fac, &p->nfac);
+    p->F_generic = aud::melspec_generic_pick_F(p->M, d->compute_dtype);
+    if (p->F_generic < 1) {
+        delete p;
+        return fail(c, AUD_EINVAL, "win_samples too large for the LDS-resident FFT");
+    }
+
+    int rc = AUD_OK;
+    {  // twiddles exp(-2 pi i k / N), computed in long double
+        std::vector<double> tw(size_t(N) * 2);
+        const long double w = -2.0L * 3.14159265358979323846264338327950288L / (long double)N;
+        for (int k = 0; k < N; ++k) {
+            tw[2 * size_t(k)] = double(cosl(w * k));
+            tw[2 * size_t(k) + 1] = double(sinl(w * k));
+        }
+        rc = upload_real(c, &p->d_tw, tw.data(), tw.size(), d->compute_dtype);
+    }
+    if (rc == AUD_OK) rc = upload_real(c, &p->d_filt, d->mel_filters, size_t(cells), d->compute_dtype);
+    if (rc == AUD_OK)
+        rc = upload(c, reinterpret_cast<void**>(&p->d_bin_pts), d->bin_pts, sizeof(int32_t) * (nf + 2));
+    if (rc == AUD_OK && d->n_gabor > 0)
+        rc = upload_real(c, &p->d_gabor, d->gabor_filters,
+                         size_t(d->n_gabor) * d->gabor.size_x * d->gabor.size_y, d->compute_dtype);
+    if (rc != AUD_OK) {
+        aud_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return AUD_OK;
+}
+
+int aud_plan_destroy(aud_plan* p) {
+    if (!p) return AUD_EINVAL;
+    (void)hipSetDevice(p->ctx->device);
+    if (p->d_tw) (void)hipFree(p->d_tw);
+    if (p->d_filt) (void)hipFree(p->d_filt);
+    if (p->d_bin_pts) (void)hipFree(p->d_bin_pts);
+    if (p->d_gabor) (void)hipFree(p->d_gabor);
+    delete p;
+    return AUD_OK;
+}
+
+const char* aud_plan_kernel_name(const aud_plan* p) { return p ? p->family : ""; }
+
+int aud_melspec_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud_item* items,
+                          int n_items, float* mel, float* power, float* log_power, void* stream) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    if (n_items < 0 || (n_items > 0 && (!sig || !items || !mel)))
+        return fail(c, AUD_EINVAL, "null buffer");
+    if (sig_dtype != AUD_F32 && sig_dtype != AUD_F64 && sig_dtype != AUD_I16)
+        return fail(c, AUD_EINVAL, "bad sig_dtype");
+    if (log_power && !p->d.dft.comp_log_pow) return fail(c, AUD_EINVAL, "log_power needs CompLogPow");
+    if (n_items == 0) return AUD_OK;
+    AUD_HIP(c, hipSetDevice(c->device));
+    aud::MelspecArgs a;
+    fill_melspec_args(p, &a);
+    a.sig = sig;
+    a.sig_dtype = sig_dtype;
+    a.items = items;
+    a.n_items = n_items;
+    a.mel = mel;
+    a.power = power;
+    a.log_power = log_power;
+    AUD_HIP(c, aud::launch_melspec_generic(a, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
+    return AUD_OK;
+}
+
+int aud_gabor_batch_dev(aud_plan* p, const float* mel, int n_items, int rows, int cols, int out_rank,
+                        const int32_t* out_shape, int by_time, float* out, void* stream) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    if (p->d.n_gabor <= 0 || !p->d_gabor) return fail(c, AUD_EINVAL, "plan has no gabor filters");
+    if (n_items < 0 || rows < 1 || cols < 1 || !out_shape) return fail(c, AUD_EINVAL, "bad shape");
+    const aud_gabor_set& g = p->d.gabor;
+    int32_t nT = 0, nF = 0, strides = 1;
+    if (aud_gabor_iter_space(&g, rows, cols, out_rank, out_shape, &nT, &nF, &strides) != AUD_OK)
+        return fail(c, AUD_EINVAL, "Convolve rejects this shape (gabor.go:226-229, :259-262)");
+    if (n_items == 0 || nT == 0 || nF == 0) return AUD_OK;
+    if (!mel || !out) return fail(c, AUD_EINVAL, "null buffer");
+    const int nG = p->d.n_gabor;
+    // reads: the reference indexes melData by flat offset; past the end it panics
+    const int64_t last_read = int64_t((nF - 1) * g.stride_y + g.size_y - 1) * cols +
+                              int64_t(nT - 1) * g.stride_x + g.size_x - 1;
+    if (last_read >= int64_t(rows) * cols)
+        return fail(c, AUD_EINVAL, "gabor pools reach past the mel matrix (SURVEY Q10)");
+    aud::GaborArgs a;
+    std::memset(&a, 0, sizeof(a));
+    if (out_rank == 2) {
+        const int x_max = by_time ? (nT - 1) + strides * (nG - 1) : (nG - 1) + (nT - 1) * nG;
+        if (2 * nF > out_shape[0] || x_max >= out_shape[1])
+            return fail(c, AUD_EINVAL, "2-D gabor output too small");
+        a.d0 = out_shape[0];
+        a.d1 = out_shape[1];
+    } else {
+        if (nF > out_shape[0] || nT > out_shape[1] || out_shape[2] < 2 || out_shape[3] < nG)
+            return fail(c, AUD_EINVAL, "4-D gabor output too small");
+        a.d0 = out_shape[0];
+        a.d1 = out_shape[1];
+        a.d2 = out_shape[2];
+        a.d3 = out_shape[3];
+    }
+    AUD_HIP(c, hipSetDevice(c->device));
+    a.mel = mel;
+    a.n_items = n_items;
+    a.rows = rows;
+    a.cols = cols;
+    a.k = p->d_gabor;
+    a.nG = nG;
+    a.SX = g.size_x;
+    a.SY = g.size_y;
+    a.stx = g.stride_x;
+    a.sty = g.stride_y;
+    a.gain = g.gain;
+    a.rank = out_rank;
+    a.by_time = by_time;
+    a.nT = nT;
+    a.nF = nF;
+    a.t_max_strides = strides;
+    a.out = out;
+    AUD_HIP(c, aud::launch_gabor(a, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
+    return AUD_OK;
+}
+
+int aud_process_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud_item* items,
+                          int n_items, float* mel, int pools_y, int pools_x, float* gabor,
+                          void* stream) {
+    if (!p) return AUD_EINVAL;
+    int rc = aud_melspec_batch_dev(p, sig, sig_dtype, items, n_items, mel, nullptr, nullptr, stream);
+    if (rc != AUD_OK) return rc;
+    const int32_t shape[4] = {pools_y, pools_x, 2, p->d.n_gabor};
+    return aud_gabor_batch_dev(p, mel, n_items, p->d.mel.n_filters, p->d.segment_steps, 4, shape, 0,
+                               gabor, stream);
+}
+
+int aud_melspec_batch_host(aud_plan* p, const double* sig, int64_t sig_total, const aud_item* items,
+                           int n_items, double* mel, double* power, double* log_power) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    if (n_items < 0 || sig_total < 0 || (n_items > 0 && (!sig || !items || !mel)))
+        return fail(c, AUD_EINVAL, "null buffer");
+    if (n_items == 0) return AUD_OK;
+    for (int i = 0; i < n_items; ++i)
+        if (items[i].sig_off < 0 || items[i].sig_len < 0 || items[i].sig_off + items[i].sig_len > sig_total)
+            return fail(c, AUD_EINVAL, "item outside the signal buffer");
+    AUD_HIP(c, hipSetDevice(c->device));
+    const int nf = p->d.mel.n_filters, T = p->d.segment_steps, H = p->H;
+    const size_t n_mel = size_t(n_items) * nf * T, n_pow = size_t(n_items) * H * T;
+    const size_t sig_bytes = size_t(sig_total) * 8, item_bytes = size_t(n_items) * sizeof(aud_item);
+    const bool want_p = power != nullptr, want_lp = log_power != nullptr;
+    const size_t out_floats = n_mel + (want_p ? n_pow : 0) + (want_lp ? n_pow : 0);
+    int rc;
+    if ((rc = ensure_ws(c, 0, sig_bytes + 16)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 1, item_bytes)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 2, out_floats * 4)) != AUD_OK) return rc;
+    float* d_mel = static_cast<float*>(c->ws[2]);
+    float* d_pow = want_p ? d_mel + n_mel : nullptr;
+    float* d_lp = want_lp ? d_mel + n_mel + (want_p ? n_pow : 0) : nullptr;
+    AUD_HIP(c, hipMemcpyAsync(c->ws[0], sig, sig_bytes, hipMemcpyHostToDevice, c->stream));
+    AUD_HIP(c, hipMemcpyAsync(c->ws[1], items, item_bytes, hipMemcpyHostToDevice, c->stream));
+    rc = aud_melspec_batch_dev(p, c->ws[0], AUD_F64, static_cast<const aud_item*>(c->ws[1]), n_items,
+                               d_mel, d_pow, d_lp, c->stream);
+    if (rc != AUD_OK) return rc;
+    std::vector<float> h(out_floats);
+    AUD_HIP(c, hipMemcpyAsync(h.data(), d_mel, out_floats * 4, hipMemcpyDeviceToHost, c->stream));
+    AUD_HIP(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n_mel; ++i) mel[i] = double(h[i]);
+    size_t o = n_mel;
+    if (want_p) {
+        for (size_t i = 0; i < n_pow; ++i) power[i] = double(h[o + i]);
+        o += n_pow;
+    }
+    if (want_lp)
+        for (size_t i = 0; i < n_pow; ++i) log_power[i] = double(h[o + i]);
+    return AUD_OK;
+}
+
+int aud_gabor_batch_host(aud_plan* p, const double* mel, int n_items, int rows, int cols, int out_rank,
+                         const int32_t* out_shape, int by_time, float* out) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    if (n_items < 0 || rows < 1 || cols < 1 || !out_shape || (out_rank != 2 && out_rank != 4))
+        return fail(c, AUD_EINVAL, "bad shape");
+    if (n_items == 0) return AUD_OK;
+    if (!mel || !out) return fail(c, AUD_EINVAL, "null buffer");
+    AUD_HIP(c, hipSetDevice(c->device));
+    size_t out_cells = 1;
+    for (int i = 0; i < out_rank; ++i) out_cells *= size_t(out_shape[i] > 0 ? out_shape[i] : 0);
+    const size_t n_mel = size_t(n_items) * rows * cols, n_out = size_t(n_items) * out_cells;
+    int rc;
+    if ((rc = ensure_ws(c, 2, n_mel * 4)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 3, n_out * 4 + 16)) != AUD_OK) return rc;
+    std::vector<float> hm(n_mel);
+    for (size_t i = 0; i < n_mel; ++i) hm[i] = float(mel[i]);
+    AUD_HIP(c, hipMemcpyAsync(c->ws[2], hm.data(), n_mel * 4, hipMemcpyHostToDevice, c->stream));
+    // in/out semantics: cells the reference leaves alone keep the caller's values
+    AUD_HIP(c, hipMemcpyAsync(c->ws[3], out, n_out * 4, hipMemcpyHostToDevice, c->stream));
+    rc = aud_gabor_batch_dev(p, static_cast<const float*>(c->ws[2]), n_items, rows, cols, out_rank,
+                             out_shape, by_time, static_cast<float*>(c->ws[3]), c->stream);
+    if (rc != AUD_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        return rc;
+    }
+    AUD_HIP(c, hipMemcpyAsync(out, c->ws[3], n_out * 4, hipMemcpyDeviceToHost, c->stream));
+    AUD_HIP(c, hipStreamSynchronize(c->stream));
+    return AUD_OK;
+}
+
+}  // extern "C"
+
+// ---- RCCL, bound lazily so that single-GPU users never load it ---------------------
+
+namespace {
+struct uid128 {
+    char b[128];
+};
+typedef int (*rccl_get_uid_t)(uid128*);
+typedef int (*rccl_comm_init_t)(void**, int, uid128, int);
+typedef int (*rccl_comm_destroy_t)(void*);
+typedef int (*rccl_allgather_t)(const void*, void*, size_t, int /*dtype*/, void*, hipStream_t);
+typedef const char* (*rccl_errstr_t)(int);
+
+void* rccl_open() {
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    return h;
+}
+constexpr int kNcclFloat32 = 7;  // ncclFloat32 in nccl.h / rccl.h
+}  // namespace
+
+extern "C" {
+
+int aud_comm_unique_id(char id[128]) {
+    if (!id) return AUD_EINVAL;
+    void* h = rccl_open();
+    if (!h) return AUD_ERCCL;
+    auto get = reinterpret_cast<rccl_get_uid_t>(dlsym(h, "ncclGetUniqueId"));
+    if (!get) return AUD_ERCCL;
+    uid128 u;
+    std::memset(&u, 0, sizeof(u));
+    if (get(&u) != 0) return AUD_ERCCL;
+    std::memcpy(id, u.b, 128);
+    return AUD_OK;
+}
+
+int aud_comm_init(aud_ctx* c, int n_ranks, int rank, const char id[128]) {
+    if (!c || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return AUD_EINVAL;
+    if (c->comm) return fail(c, AUD_EINVAL, "communicator already initialised");
+    AUD_HIP(c, hipSetDevice(c->device));
+    if (!c->rccl_lib) c->rccl_lib = rccl_open();
+    if (!c->rccl_lib) return fail(c, AUD_ERCCL, "cannot load librccl.so");
+    auto init = reinterpret_cast<rccl_comm_init_t>(dlsym(c->rccl_lib, "ncclCommInitRank"));
+    if (!init) return fail(c, AUD_ERCCL, "ncclCommInitRank not found");
+    uid128 u;
+    std::memcpy(u.b, id, 128);
+    void* comm = nullptr;
+    const int r = init(&comm, n_ranks, u, rank);
+    if (r != 0) {
+        auto es = reinterpret_cast<rccl_errstr_t>(dlsym(c->rccl_lib, "ncclGetErrorString"));
+        return fail(c, AUD_ERCCL, std::string("ncclCommInitRank: ") + (es ? es(r) : "error"));
+    }
+    c->comm = comm;
+    c->n_ranks = n_ranks;
+    c->rank = rank;
+    return AUD_OK;
+}
+
+int aud_comm_destroy(aud_ctx* c) {
+    if (!c) return AUD_EINVAL;
+    if (c->comm && c->rccl_lib) {
+        auto destroy = reinterpret_cast<rccl_comm_destroy_t>(dlsym(c->rccl_lib, "ncclCommDestroy"));
+        if (destroy) destroy(c->comm);
+    }
+    c->comm = nullptr;
+    return AUD_OK;
+}
+
+int aud_allgather_dev(aud_ctx* c, const float* send, float* recv, int64_t count, void* stream) {
+    if (!c || count < 0) return AUD_EINVAL;
+    if (!c->comm) return fail(c, AUD_ERCCL, "aud_comm_init has not been called");
+    if (count == 0) return AUD_OK;
+    if (!send || !recv) return fail(c, AUD_EINVAL, "null buffer");
+    AUD_HIP(c, hipSetDevice(c->device));
+    auto ag = reinterpret_cast<rccl_allgather_t>(dlsym(c->rccl_lib, "ncclAllGather"));
+    if (!ag) return fail(c, AUD_ERCCL, "ncclAllGather not found");
+    const int r = ag(send, recv, size_t(count), kNcclFloat32, c->comm, static_cast<hipStream_t>(stream));
+    if (r != 0) {
+        auto es = reinterpret_cast<rccl_errstr_t>(dlsym(c->rccl_lib, "ncclGetErrorString"));
+        return fail(c, AUD_ERCCL, std::string("ncclAllGather: ") + (es ? es(r) : "error"));
+    }
+    return AUD_OK;
+}
+
+}  // extern "C"

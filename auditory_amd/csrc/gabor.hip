@@ -1,0 +1,91 @@
+// agabor.Convolve (agabor/gabor.go:225-315) for a batch of mel matrices.
+//
+// One thread owns one output position (item, fIdx, tIdx) and keeps up to 8 filter sums in
+// registers, so every mel sample it loads feeds 8 FMAs.  The filter taps are indexed only
+// by loop counters, i.e. wave-uniform, and come in through the scalar path.  The mel
+// matrix is addressed by the reference's flat offset (f+ff)*cols + (t+ft) (etensor has no
+// per-dimension bounds check), NaN inputs read as 0.5 (:278-280), and the result is
+// rectified into the on/off pair with the 2-D / 4-D index maps of :286-309.
+#include "kernels.h"
+
+namespace aud {
+namespace {
+
+constexpr int kChunk = 8;
+
+template <typename TT>
+__global__ __launch_bounds__(256) void k_gabor(const GaborArgs a) {
+    const int per_item = a.nF * a.nT;
+    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= int64_t(a.n_items) * per_item) return;
+    const int item = int(gid / per_item);
+    const int r = int(gid - int64_t(item) * per_item);
+    const int f_idx = r / a.nT, t_idx = r - f_idx * a.nT;
+    const int f = f_idx * a.sty, t = t_idx * a.stx;
+
+    const float* __restrict__ mel = a.mel + size_t(item) * a.rows * a.cols;
+    const TT* __restrict__ kf = static_cast<const TT*>(a.k);
+    const int area = a.SX * a.SY;
+    const TT gain = TT(a.gain);
+
+    size_t out_item;
+    if (a.rank == 2)
+        out_item = size_t(a.d0) * a.d1;
+    else
+        out_item = size_t(a.d0) * a.d1 * a.d2 * a.d3;
+    float* out = a.out + size_t(item) * out_item;
+
+    for (int g0 = 0; g0 < a.nG; g0 += kChunk) {
+        TT acc[kChunk];
+#pragma unroll
+        for (int c = 0; c < kChunk; ++c) acc[c] = TT(0);
+        const int gc = min(kChunk, a.nG - g0);
+        for (int ff = 0; ff < a.SY; ++ff) {
+            const float* row = mel + size_t(f + ff) * a.cols + t;
+            for (int ft = 0; ft < a.SX; ++ft) {
+                float mv = row[ft];
+                if (mv != mv) mv = 0.5f;  // math.IsNaN -> .5
+                const TT v = TT(mv);
+                const TT* tap = kf + size_t(g0) * area + ff * a.SX + ft;
+#pragma unroll
+                for (int c = 0; c < kChunk; ++c)
+                    if (c < gc) acc[c] += tap[size_t(c) * area] * v;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kChunk; ++c) {
+            if (c >= gc) break;
+            const int flt = g0 + c;
+            const bool pos = acc[c] >= TT(0);
+            const float act = float(gain * (acc[c] < TT(0) ? -acc[c] : acc[c]));
+            size_t o_on, o_off;
+            if (a.rank == 2) {
+                const int y = f_idx * 2;
+                const int x = a.by_time ? t_idx + a.t_max_strides * flt : flt + t_idx * a.nG;
+                o_on = size_t(y) * a.d1 + x;
+                o_off = size_t(y + 1) * a.d1 + x;
+            } else {
+                const size_t cell = (size_t(f_idx) * a.d1 + t_idx) * a.d2;
+                o_on = cell * a.d3 + flt;
+                o_off = (cell + 1) * a.d3 + flt;
+            }
+            out[o_on] = pos ? act : 0.f;
+            out[o_off] = pos ? 0.f : act;
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_gabor(const GaborArgs& a, int compute_dtype, hipStream_t st) {
+    const int64_t total = int64_t(a.n_items) * a.nF * a.nT;
+    if (total == 0) return hipSuccess;
+    const dim3 grid(unsigned((total + 255) / 256));
+    if (compute_dtype == AUD_F64)
+        hipLaunchKernelGGL(k_gabor<double>, grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(k_gabor<float>, grid, dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace aud

@@ -1,0 +1,59 @@
+// Internal launch descriptors shared between the C API (capi.hip) and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "auditory_hip.h"
+
+namespace aud {
+
+constexpr int kMaxFactors = 24;
+
+// Arguments of every frame->mel kernel family.  Doubles are converted to the compute
+// type inside the kernel; `tw` and `filt` are already stored in the compute type.
+struct MelspecArgs {
+    const void* sig;
+    int sig_dtype;
+    const aud_item* items;
+    int n_items;
+    int N, S, T, border, H;
+    int M;      // complex FFT length: N/2 for even N (packed real trick), N for odd N
+    int ratio;  // N / M
+    int nfac;
+    int fac[kMaxFactors];
+    const void* tw;  // [N] complex<TT>: exp(-2 pi i k / N)
+    int nf;
+    const int32_t* bin_pts;  // [nf+2]
+    const void* filt;        // [nf*(nf+2)] TT, the reference's table layout
+    double mel_log_off, mel_log_min;
+    int renorm;
+    double renorm_min, renorm_scale;
+    int comp_log_pow;
+    double dft_log_min, dft_log_off;
+    float* mel;        // [n_items, nf, T]
+    float* power;      // [n_items, H, T] or null
+    float* log_power;  // [n_items, H, T] or null
+    int F;             // frames per workgroup
+};
+
+struct GaborArgs {
+    const float* mel;  // [n_items, rows, cols]
+    int n_items, rows, cols;
+    const void* k;  // [nG, SY, SX] TT
+    int nG, SX, SY, stx, sty;
+    double gain;
+    int rank;  // 2 or 4
+    int d0, d1, d2, d3;
+    int by_time;
+    int nT, nF, t_max_strides;
+    float* out;
+};
+
+// generic any-N kernel (Stockham in LDS, radix 2/4 + per-output generic radix)
+size_t melspec_generic_lds_bytes(int M, int F, int compute_dtype);
+int melspec_generic_pick_F(int M, int compute_dtype);
+hipError_t launch_melspec_generic(const MelspecArgs& a, int compute_dtype, hipStream_t st);
+
+hipError_t launch_gabor(const GaborArgs& a, int compute_dtype, hipStream_t st);
+
+}  // namespace aud

@@ -1,0 +1,143 @@
+"""Device context and plan wrappers over the C ABI (one context per GPU, one process per GPU)."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+_CTX = {}
+
+
+def _check(lib, ctx, rc):
+    if rc != capi.AUD_OK:
+        msg = lib.aud_last_error(ctx).decode() if ctx else lib.aud_status_string(rc).decode()
+        raise capi.AuditoryError(rc, msg or lib.aud_status_string(rc).decode())
+
+
+class Context:
+    """aud_ctx: owns the device, a stream for host-buffer calls and the RCCL communicator."""
+
+    def __init__(self, device=0):
+        self.lib = capi.load()
+        h = C.c_void_p()
+        rc = self.lib.aud_init(int(device), C.byref(h))
+        if rc != capi.AUD_OK:
+            raise capi.AuditoryError(rc, "aud_init(%d): no usable HIP device -- this library has no "
+                                     "CPU fallback" % device)
+        self.handle = h
+        self.device = int(device)
+
+    def check(self, rc):
+        _check(self.lib, self.handle, rc)
+
+    def close(self):
+        if self.handle:
+            self.lib.aud_shutdown(self.handle)
+            self.handle = None
+
+
+def get_ctx(device=0):
+    if device not in _CTX:
+        _CTX[device] = Context(device)
+    return _CTX[device]
+
+
+def _dptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+class Plan:
+    """aud_plan: immutable tables (twiddles, mel triangles, gabor taps) resident on the device."""
+
+    def __init__(self, ctx, win_samples, step_samples, segment_steps, border_steps, dft, fbank,
+                 bin_pts, mel_filters, gabor_set=None, gabor_filters=None, compute_dtype=capi.AUD_F32):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.N, self.S, self.T, self.border = win_samples, step_samples, segment_steps, border_steps
+        self.H = win_samples // 2 + 1
+        self.nf = fbank.n_filters
+        self.compute_dtype = compute_dtype
+        bp = np.ascontiguousarray(bin_pts, np.int32)
+        mf = np.ascontiguousarray(mel_filters, np.float64)
+        d = capi.PlanDesc()
+        d.win_samples, d.step_samples = win_samples, step_samples
+        d.segment_steps, d.border_steps = segment_steps, border_steps
+        d.dft, d.mel = dft, fbank
+        d.bin_pts = _dptr(bp, C.c_int32)
+        d.mel_filters = _dptr(mf, C.c_double)
+        self.n_gabor = 0
+        if gabor_filters is not None and len(gabor_filters):
+            gk = np.ascontiguousarray(gabor_filters, np.float64)
+            d.n_gabor = gk.shape[0]
+            d.gabor = gabor_set
+            d.gabor_filters = _dptr(gk, C.c_double)
+            self.n_gabor = gk.shape[0]
+            self.gabor_set = gabor_set
+        d.compute_dtype = compute_dtype
+        h = C.c_void_p()
+        ctx.check(self.lib.aud_plan_create(ctx.handle, C.byref(d), C.byref(h)))
+        self.handle = h
+
+    @property
+    def kernel_name(self):
+        return self.lib.aud_plan_kernel_name(self.handle).decode()
+
+    # ---- device-pointer calls (ints are raw device addresses; stream is a hipStream_t) ----
+    def melspec_dev(self, sig_ptr, sig_dtype, items_ptr, n_items, mel_ptr, power_ptr=0,
+                    log_power_ptr=0, stream=0):
+        self.ctx.check(self.lib.aud_melspec_batch_dev(self.handle, sig_ptr, sig_dtype, items_ptr,
+                                                      n_items, mel_ptr, power_ptr or None,
+                                                      log_power_ptr or None, stream or None))
+
+    def gabor_dev(self, mel_ptr, n_items, rows, cols, out_shape, out_ptr, by_time=False, stream=0):
+        shp = (C.c_int32 * len(out_shape))(*out_shape)
+        self.ctx.check(self.lib.aud_gabor_batch_dev(self.handle, mel_ptr, n_items, rows, cols,
+                                                    len(out_shape), shp, int(by_time), out_ptr,
+                                                    stream or None))
+
+    def process_dev(self, sig_ptr, sig_dtype, items_ptr, n_items, mel_ptr, pools_y, pools_x,
+                    gabor_ptr, stream=0):
+        self.ctx.check(self.lib.aud_process_batch_dev(self.handle, sig_ptr, sig_dtype, items_ptr,
+                                                      n_items, mel_ptr, pools_y, pools_x, gabor_ptr,
+                                                      stream or None))
+
+    # ---- host-buffer calls (float64 in / float64+float32 out, like the Go tensors) ---------
+    def melspec_host(self, sig, items, want_power=False, want_log_power=False):
+        sig = np.ascontiguousarray(sig, np.float64)
+        items = np.ascontiguousarray(items, dtype=ITEM_DTYPE)
+        n = len(items)
+        mel = np.zeros((n, self.nf, self.T), np.float64)
+        power = np.zeros((n, self.H, self.T), np.float64) if want_power else None
+        logp = np.zeros((n, self.H, self.T), np.float64) if want_log_power else None
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        self.ctx.check(self.lib.aud_melspec_batch_host(self.handle, vp(sig), sig.size, vp(items), n,
+                                                       vp(mel), vp(power), vp(logp)))
+        return mel, power, logp
+
+    def gabor_host(self, mel, out, by_time=False):
+        """mel: f64 [n, rows, cols]; out: f32 [n, ...] modified in place"""
+        mel = np.ascontiguousarray(mel, np.float64)
+        assert out.dtype == np.float32 and out.flags.c_contiguous
+        n, rows, cols = mel.shape
+        shp = (C.c_int32 * (out.ndim - 1))(*out.shape[1:])
+        rc = self.lib.aud_gabor_batch_host(self.handle, mel.ctypes.data_as(C.c_void_p), n, rows,
+                                           cols, out.ndim - 1, shp, int(by_time),
+                                           out.ctypes.data_as(C.c_void_p))
+        self.ctx.check(rc)
+        return out
+
+    def close(self):
+        if self.handle:
+            self.lib.aud_plan_destroy(self.handle)
+            self.handle = None
+
+
+ITEM_DTYPE = np.dtype([("sig_off", np.int64), ("sig_len", np.int32), ("start0", np.int32)])
+assert ITEM_DTYPE.itemsize == C.sizeof(capi.Item)
+
+
+def make_items(sig_off, sig_len, start0):
+    n = len(sig_off)
+    it = np.zeros(n, ITEM_DTYPE)
+    it["sig_off"], it["sig_len"], it["start0"] = sig_off, sig_len, start0
+    return it

@@ -1,0 +1,160 @@
+"""Host-side mirror of the reference's orchestrator `sound.SndEnv` (sound/sndenv.go) for the
+hot path: Init -> ProcessSegment -> ApplyGabor.  The frame loop itself runs on the GPU as one
+batched launch per call; MFCC / energy / kwta stages of the reference are out of scope."""
+import numpy as np
+
+from . import agabor, capi, dft, mel, runtime
+
+
+def MSecToSamples(ms, rate):
+    """sound/sndenv.go:522-524"""
+    return capi.load().aud_msec_to_samples(float(ms), int(rate))
+
+
+class Params:
+    """sound.Params, sound/sndenv.go:24-61"""
+
+    def __init__(self):
+        self.WinMs = 0.0
+        self.StepMs = 0.0
+        self.SegmentMs = 0.0
+        self.StrideMs = 0.0
+        self.BorderSteps = 0
+        self.Channel = 0
+        self.WinSamples = 0
+        self.StepSamples = 0
+        self.SegmentSamples = 0
+        self.StrideSamples = 0
+        self.SegmentSteps = 0
+        self.Steps = []
+
+    def to_c(self):
+        c = capi.SoundParams()
+        c.win_ms, c.step_ms, c.segment_ms, c.stride_ms = self.WinMs, self.StepMs, self.SegmentMs, self.StrideMs
+        c.border_steps, c.channel = self.BorderSteps, self.Channel
+        return c
+
+
+class SndEnv:
+    """sound.SndEnv, sound/sndenv.go:73-182 (hot-path fields only)"""
+
+    def __init__(self, device=0, compute_dtype=capi.AUD_F32):
+        self.Params = Params()
+        self.SampleRate = 0                 # se.Sound.SampleRate()
+        self.Channels = 1                   # se.Sound.Channels(); mono streams only (SURVEY a-0)
+        self.Signal = np.zeros(0, np.float64)
+        self.SegCnt = 0
+        self.DFT = dft.Params()
+        self.Mel = mel.Params()
+        self.MelFilters = None
+        self.PowerSegment = None
+        self.LogPowerSegment = None
+        self.MelFBankSegment = None
+        self.GaborSpecs = []
+        self.GaborFilters = agabor.FilterSet()
+        self.GborOutPoolsX = 0
+        self.GborOutPoolsY = 0
+        self.GborOutUnitsX = 0
+        self.GborOutUnitsY = 0
+        self.GborOutput = None
+        self.ByTime = False
+        self._device = device
+        self._compute_dtype = compute_dtype
+        self._plan = None
+
+    def ParamDefaults(self):
+        """sound/sndenv.go:64-71"""
+        c = capi.SoundParams()
+        capi.load().aud_sound_params_defaults(c)
+        p = self.Params
+        p.WinMs, p.StepMs, p.SegmentMs, p.StrideMs = c.win_ms, c.step_ms, c.segment_ms, c.stride_ms
+        p.Channel, p.BorderSteps = c.channel, c.border_steps
+
+    def Defaults(self):
+        """sound/sndenv.go:185-192"""
+        self.ParamDefaults()
+        self.Mel.Defaults()
+        self.ByTime = False
+
+    def Init(self):
+        """sound/sndenv.go:195-267.  Returns None, or an error string like the Go `error`."""
+        lib = capi.load()
+        c = self.Params.to_c()
+        if lib.aud_sound_params_derive(c, int(self.SampleRate)) != capi.AUD_OK:
+            print("sample rate <= 0")
+            return "sample rate <= 0"
+        p = self.Params
+        p.WinSamples, p.StepSamples, p.SegmentSamples = c.win_samples, c.step_samples, c.segment_samples
+        p.SegmentSteps, p.StrideSamples = c.segment_steps, c.stride_samples
+
+        specs = agabor.Active(self.GaborSpecs)
+        if specs:
+            agabor.ToTensor(specs, self.GaborFilters)
+        if self.GborOutPoolsX == 0 and self.GborOutPoolsY == 0:
+            self.GborOutput = np.zeros((self.GborOutUnitsY, self.GborOutUnitsX), np.float32)
+        elif self.GborOutPoolsX > 0 and self.GborOutPoolsY > 0:
+            self.GborOutput = np.zeros((self.GborOutPoolsY, self.GborOutPoolsX, self.GborOutUnitsY,
+                                        self.GborOutUnitsX), np.float32)
+        else:
+            print("GborOutPoolsX & GborOutPoolsY must both be == 0 or > 0 (i.e. 2D or 4D)")
+            return None
+
+        H = p.WinSamples // 2 + 1
+        self.DFT.Defaults()
+        self.MelFilters = self.Mel.InitFilters(p.WinSamples, self.SampleRate)
+        self.PowerSegment = np.zeros((H, p.SegmentSteps))
+        self.LogPowerSegment = np.zeros((H, p.SegmentSteps))
+        p.Steps = [p.StepSamples * (i - p.BorderSteps) for i in range(p.SegmentSteps)]
+        self.MelFBankSegment = np.zeros((self.Mel.FBank.NFilters, p.SegmentSteps))
+        self.SegCnt = lib.aud_seg_cnt(len(self.Signal), p.SegmentSamples, p.StrideSamples,
+                                      self.Channels)
+        self._make_plan()
+        return None
+
+    def _make_plan(self):
+        if self._plan is not None:
+            self._plan.close()
+        p = self.Params
+        has_g = len(self.GaborFilters.Filters) > 0
+        self._plan = runtime.Plan(runtime.get_ctx(self._device), p.WinSamples, p.StepSamples,
+                                  p.SegmentSteps, p.BorderSteps, self.DFT.to_c(),
+                                  self.Mel.FBank.to_c(), self.Mel.BinPts, self.MelFilters,
+                                  self.GaborFilters.to_c() if has_g else None,
+                                  self.GaborFilters.Filters if has_g else None, self._compute_dtype)
+
+    def _item(self, segment, add):
+        start0 = segment * self.Params.StrideSamples + MSecToSamples(add, self.SampleRate)
+        return (0, len(self.Signal), start0)
+
+    def ProcessSegment(self, segment, add=0):
+        """sound/sndenv.go:342-359 (frame loop part): fills PowerSegment, LogPowerSegment and
+        MelFBankSegment for one segment."""
+        self.ProcessSegments([segment], add)
+
+    def ProcessSegments(self, segments, add=0):
+        """Batch extension: all requested segments in ONE launch.  Returns
+        (mel [n, nf, T], power [n, H, T], log_power [n, H, T]); the SndEnv tensors hold the last."""
+        its = [self._item(s, add) for s in segments]
+        items = runtime.make_items([i[0] for i in its], [i[1] for i in its], [i[2] for i in its])
+        m, pw, lp = self._plan.melspec_host(self.Signal, items, True, bool(self.DFT.CompLogPow))
+        self.MelFBankSegment = m[-1]
+        self.PowerSegment = pw[-1]
+        if lp is not None:
+            self.LogPowerSegment = lp[-1]
+        return m, pw, lp
+
+    def ApplyGabor(self):
+        """sound/sndenv.go:481-497 without NeighInhib / Kwta (both off by default, out of scope)"""
+        agabor.Convolve(self.MelFBankSegment, self.GaborFilters, self.GborOutput, self.ByTime,
+                        plan=self._plan)
+        return self.GborOutput
+
+    def Tail(self, signal):
+        """sound/sndenv.go:503-507"""
+        return capi.load().aud_tail(len(signal), self.Params.SegmentSamples, self.Params.StrideSamples)
+
+    def Pad(self, signal, value=0.0):
+        """sound/sndenv.go:510-519"""
+        n = capi.load().aud_pad_len(len(signal), self.Params.SegmentSamples,
+                                    self.Params.StrideSamples, self.Params.StepSamples)
+        return np.concatenate([np.asarray(signal, np.float64), np.full(n, value)])

@@ -1,0 +1,253 @@
+/*
+ * auditory_hip.h -- C ABI of libauditory_hip.so: the MI355X (gfx950) implementation of
+ * emer/auditory's signal -> framed FFT -> power/log-power -> mel filterbank -> 2-D gabor
+ * hot path.  This is the drop-in boundary: the reference has no FFI of its own (it is
+ * pure Go), so each entry point names the exported Go symbol (file:line, relative to the
+ * reference root) whose body a cgo shim routes here.  See INTEGRATION.md for the shim.
+ *
+ * Conventions
+ *  - extern "C", plain C types, explicit sizes; every function returns an int status
+ *    (AUD_OK == 0) unless documented otherwise.  No C++ exceptions cross the boundary.
+ *  - "_dev" entry points take DEVICE pointers and a hipStream_t passed as void*; they
+ *    only enqueue work (no allocation, no synchronisation: they are graph-capturable).
+ *  - "_host" entry points take HOST pointers (float64 in, float64/float32 out, matching
+ *    the reference's etensor.Float64 / etensor.Float32 buffers), stage through a
+ *    ctx-owned workspace, and return after the result is in the caller's buffer.  The
+ *    library never keeps a caller pointer after return (cgo rule).
+ *  - There is NO CPU fallback anywhere in this library: without a usable HIP device
+ *    aud_init fails with AUD_EHIP and nothing else can be called.
+ *  - One aud_ctx per device; one process per GPU is the intended deployment.
+ */
+#ifndef AUDITORY_HIP_H
+#define AUDITORY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AUD_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+#define AUD_OK 0
+#define AUD_EINVAL 1 /* bad argument / shape outside the supported envelope */
+#define AUD_EHIP 2   /* HIP runtime error (see aud_last_error) */
+#define AUD_ERCCL 3  /* RCCL error */
+#define AUD_ENOMEM 4
+#define AUD_ESHORT 5 /* sndenv.go:458-460 "end beyond signal length" (per-step API only) */
+
+/* element types of signal buffers / compute */
+#define AUD_F32 0
+#define AUD_F64 1
+#define AUD_I16 2 /* raw 16-bit PCM; normalised on device by /0x7FFF (sound.go:138) */
+
+typedef struct aud_ctx aud_ctx;
+typedef struct aud_plan aud_plan;
+
+/* ---- parameter blocks (field-for-field mirrors of the Go structs) ---------------- */
+
+/* sound.Params, sound/sndenv.go:24-61 */
+typedef struct {
+    double win_ms;           /* WinMs */
+    double step_ms;          /* StepMs */
+    double segment_ms;       /* SegmentMs */
+    double stride_ms;        /* StrideMs */
+    int32_t border_steps;    /* BorderSteps */
+    int32_t channel;         /* Channel */
+    int32_t win_samples;     /* WinSamples     (derived) */
+    int32_t step_samples;    /* StepSamples    (derived) */
+    int32_t segment_samples; /* SegmentSamples (derived) */
+    int32_t stride_samples;  /* StrideSamples  (derived) */
+    int32_t segment_steps;   /* SegmentSteps   (derived) */
+} aud_sound_params;
+
+/* dft.Params, dft/dft.go:15-31 */
+typedef struct {
+    int32_t comp_log_pow; /* CompLogPow */
+    double log_min;       /* LogMin */
+    double log_offset;    /* LogOffSet */
+    double prev_smooth;   /* PrevSmooth */
+    double cur_smooth;    /* CurSmooth */
+} aud_dft_params;
+
+/* mel.FilterBank, mel/mel.go:16-44 */
+typedef struct {
+    int32_t n_filters;   /* NFilters */
+    double lo_hz;        /* LoHz */
+    double hi_hz;        /* HiHz */
+    double log_off;      /* LogOff */
+    double log_min;      /* LogMin */
+    int32_t renorm;      /* Renorm */
+    double renorm_min;   /* RenormMin */
+    double renorm_max;   /* RenormMax */
+    double renorm_scale; /* RenormScale */
+} aud_mel_fbank;
+
+/* agabor.Filter, agabor/gabor.go:17-42 */
+typedef struct {
+    int32_t off;         /* Off */
+    double wave_len;     /* WaveLen */
+    double orientation;  /* Orientation */
+    double sigma_width;  /* SigmaWidth */
+    double sigma_length; /* SigmaLength */
+    double phase_offset; /* PhaseOffset */
+    int32_t circle_edge; /* CircleEdge */
+    int32_t circular;    /* Circular */
+} aud_gabor_spec;
+
+/* agabor.FilterSet (scalar part), agabor/gabor.go:45-70 */
+typedef struct {
+    int32_t size_x;     /* SizeX */
+    int32_t size_y;     /* SizeY */
+    int32_t stride_x;   /* StrideX */
+    int32_t stride_y;   /* StrideY */
+    double gain;        /* Gain */
+    int32_t distribute; /* Distribute */
+} aud_gabor_set;
+
+/* One work item of a batch = one segment of one mono stream.
+ * Frame s (0 <= s < segment_steps) covers samples
+ *   [start0 + step_samples*(s - border_steps), ... + win_samples)
+ * of the stream that begins at element sig_off of the signal buffer and is sig_len
+ * samples long.  start0 = segment*StrideSamples + MSecToSamples(add) (sndenv.go:440-441).
+ * Negative positions read as zero; a frame whose end exceeds sig_len is masked to zero,
+ * as are all later frames of the segment (sndenv.go:354-358, :458-460). */
+typedef struct {
+    int64_t sig_off;
+    int32_t sig_len;
+    int32_t start0;
+} aud_item;
+
+/* Everything a plan needs.  Tables are built host-side (aud_mel_init_filters,
+ * aud_gabor_to_tensor) so device code never re-derives them. */
+typedef struct {
+    int32_t win_samples;         /* N: FFT length = window length, no taper (sndenv.go:470) */
+    int32_t step_samples;        /* S */
+    int32_t segment_steps;       /* T */
+    int32_t border_steps;
+    aud_dft_params dft;
+    aud_mel_fbank mel;
+    const int32_t* bin_pts;      /* [n_filters+2]           mel.Params.BinPts */
+    const double* mel_filters;   /* [n_filters, n_filters+2] SndEnv.MelFilters */
+    int32_t n_gabor;             /* 0 = no gabor stage */
+    aud_gabor_set gabor;
+    const double* gabor_filters; /* [n_gabor, size_y, size_x] FilterSet.Filters, or NULL */
+    int32_t compute_dtype;       /* AUD_F32 (default) or AUD_F64 */
+} aud_plan_desc;
+
+/* ---- host-side setup: no GPU needed --------------------------------------------- */
+
+int aud_version(void);
+const char* aud_status_string(int status);
+
+/* sound.MSecToSamples, sound/sndenv.go:522-524 */
+int aud_msec_to_samples(double ms, int rate);
+/* SndEnv.ParamDefaults, sound/sndenv.go:64-71 */
+void aud_sound_params_defaults(aud_sound_params* p);
+/* the derivations of SndEnv.Init, sound/sndenv.go:202-207; AUD_EINVAL if sample_rate <= 0 (:196-201) */
+int aud_sound_params_derive(aud_sound_params* p, int sample_rate);
+/* SndEnv.Init's SegCnt, sound/sndenv.go:263-265 */
+int aud_seg_cnt(int signal_len, int segment_samples, int stride_samples, int channels);
+/* SndEnv.Tail / SndEnv.Pad length, sound/sndenv.go:503-519 */
+int aud_tail(int signal_len, int segment_samples, int stride_samples);
+int aud_pad_len(int signal_len, int segment_samples, int stride_samples, int step_samples);
+/* Wave.GetFloatAtIdx, sound/sound.go:130-141 */
+double aud_pcm_to_float(int value, int bit_depth);
+
+/* dft.Params.Defaults, dft/dft.go:33-39 */
+void aud_dft_defaults(aud_dft_params* d);
+/* mel.FilterBank.Defaults, mel/mel.go:171-180 */
+void aud_mel_defaults(aud_mel_fbank* m);
+/* mel.FreqToMel / MelToFreq / FreqToBin, mel/mel.go:156-168 */
+double aud_freq_to_mel(double freq);
+double aud_mel_to_freq(double mel);
+int aud_freq_to_bin(double freq, double n_fft, double sample_rate);
+/* mel.Params.InitFilters, mel/mel.go:77-117.  bin_pts [nf+2], hz_pts [nf+2] (may be NULL),
+ * filters [nf, nf+2].  Sets m->renorm = 0 as mel.go:80 does.  AUD_EINVAL where the Go
+ * code would index past the end of the filter tensor (panic). */
+int aud_mel_init_filters(aud_mel_fbank* m, int dft_size, int sample_rate, int32_t* bin_pts,
+                         double* hz_pts, double* filters);
+
+/* agabor.Active, agabor/gabor.go:329-336: compacts the !Off specs into `active`, returns the count */
+int aud_gabor_active(const aud_gabor_spec* specs, int n, aud_gabor_spec* active);
+/* agabor.ToTensor, agabor/gabor.go:89-222 (applies Filter.Defaults :73-86 to each active spec).
+ * specs: ALL specs (Off ones are skipped); out: [n_active, size_y, size_x].  Returns n_active via *n_out. */
+int aud_gabor_to_tensor(const aud_gabor_spec* specs, int n, const aud_gabor_set* set, double* out,
+                        int* n_out);
+/* Iteration space of agabor.Convolve, agabor/gabor.go:231-262: number of time / frequency
+ * positions visited for a [mel_rows, mel_cols] input and an output of the given rank/shape.
+ * AUD_EINVAL for the shapes Convolve rejects (cols < SizeX, rank not 2 or 4). */
+int aud_gabor_iter_space(const aud_gabor_set* set, int mel_rows, int mel_cols, int out_rank,
+                         const int32_t* out_shape, int32_t* n_t, int32_t* n_f,
+                         int32_t* t_max_strides);
+
+/* ---- device context / plans ------------------------------------------------------ */
+
+int aud_init(int device_id, aud_ctx** ctx);
+int aud_shutdown(aud_ctx* ctx);
+const char* aud_last_error(const aud_ctx* ctx); /* never NULL */
+int aud_device_id(const aud_ctx* ctx);
+
+int aud_plan_create(aud_ctx* ctx, const aud_plan_desc* desc, aud_plan** plan);
+int aud_plan_destroy(aud_plan* plan);
+/* which frame->mel kernel family the plan selected: "generic", "r16x16", ... (diagnostic) */
+const char* aud_plan_kernel_name(const aud_plan* plan);
+
+/* ---- hot path, device-resident (what bench.py times) ----------------------------- */
+
+/* The SndEnv.ProcessSegment frame loop (sound/sndenv.go:342-359 -> :438-478) fused with
+ * dft.Params.Filter (dft/dft.go:42-85) and mel.Params.FilterDft (mel/mel.go:120-153)
+ * for n_items segments at once.
+ *   sig        device, element type sig_dtype (AUD_F32 / AUD_F64 / AUD_I16)
+ *   items      device, [n_items]
+ *   mel        device, float32 [n_items, n_filters, T]   (MelFBankSegment per item)
+ *   power      device, float32 [n_items, H, T] or NULL   (PowerSegment;    H = N/2+1)
+ *   log_power  device, float32 [n_items, H, T] or NULL   (LogPowerSegment; needs CompLogPow)
+ * Every cell of every output is written (masked frames as zero). */
+int aud_melspec_batch_dev(aud_plan* plan, const void* sig, int sig_dtype, const aud_item* items,
+                          int n_items, float* mel, float* power, float* log_power, void* stream);
+
+/* agabor.Convolve (agabor/gabor.go:225-315) for n_items mel matrices at once.
+ *   mel   device float32 [n_items, mel_rows, mel_cols]
+ *   out   device float32 [n_items, out_shape...]; rank 2 ([2*nFy, nFx*nG], gbv.go:800-813) or
+ *         rank 4 ([PoolsY, PoolsX, UnitsY, UnitsX], sndenv.go:218-220).  Only the cells the
+ *         reference writes are written; the rest keep their contents.
+ * AUD_EINVAL (nothing written) for the shapes Convolve rejects and for shapes where the
+ * Go code would index out of range. */
+int aud_gabor_batch_dev(aud_plan* plan, const float* mel, int n_items, int mel_rows, int mel_cols,
+                        int out_rank, const int32_t* out_shape, int by_time, float* out,
+                        void* stream);
+
+/* ProcessSegment + ApplyGabor (sound/sndenv.go:481-497, 4-D pooled output) in one call:
+ * mel as above, gabor float32 [n_items, pools_y, pools_x, 2, n_gabor]. */
+int aud_process_batch_dev(aud_plan* plan, const void* sig, int sig_dtype, const aud_item* items,
+                          int n_items, float* mel, int pools_y, int pools_x, float* gabor,
+                          void* stream);
+
+/* ---- hot path, host buffers (what the cgo shim binds) ---------------------------- */
+
+/* Same as aud_melspec_batch_dev on host memory: sig float64 (SndEnv.Signal values), items on
+ * the host, outputs float64 [n_items, nf, T] / [n_items, H, T] (NULL to skip). */
+int aud_melspec_batch_host(aud_plan* plan, const double* sig, int64_t sig_total,
+                           const aud_item* items, int n_items, double* mel, double* power,
+                           double* log_power);
+
+/* agabor.Convolve on host memory: mel float64 [n_items, rows, cols], out float32 in/out. */
+int aud_gabor_batch_host(aud_plan* plan, const double* mel, int n_items, int mel_rows,
+                         int mel_cols, int out_rank, const int32_t* out_shape, int by_time,
+                         float* out);
+
+/* ---- multi-GPU reassembly (one process per GPU, RCCL over xGMI) ------------------ */
+
+/* 128-byte RCCL unique id, created on rank 0 and distributed by the host program */
+int aud_comm_unique_id(char id[128]);
+int aud_comm_init(aud_ctx* ctx, int n_ranks, int rank, const char id[128]);
+int aud_comm_destroy(aud_ctx* ctx);
+/* in-place capable all-gather of `count` float32 per rank: recv[rank*count ...] <- send */
+int aud_allgather_dev(aud_ctx* ctx, const float* send, float* recv, int64_t count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUDITORY_HIP_H */

@@ -1,0 +1,160 @@
+"""CPU-only checks of the shipped library: it loads, exports every symbol the header declares,
+and its host-side setup (parameter derivation, mel table, gabor taps) is bit-identical to the
+oracle's independent restatement.  No compute entry point is called here (no GPU)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from auditory_amd import agabor, capi, mel, sound
+import workloads as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "auditory_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(aud_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load()
+    declared = _header_symbols()
+    assert len(declared) >= 30
+    assert sorted(capi.SYMBOLS) == declared
+    nm = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (aud_[a-z0-9_]+)", nm))
+    assert set(declared) <= exported
+    assert lib.aud_version() == 100
+    assert lib.aud_status_string(capi.AUD_EINVAL).decode().startswith("invalid")
+
+
+def test_library_carries_gfx950_code_object():
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", capi.LIB_PATH],
+                         capture_output=True, text=True, cwd="/tmp")
+    if out.returncode != 0:
+        pytest.skip("llvm-objdump unavailable")
+    assert "gfx950" in out.stdout
+
+
+def test_no_oracle_in_product():
+    """the product must not reach into oracle/ (tier rule 3)"""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "auditory_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in src.lower().replace("no oracle", ""), f
+
+
+def test_init_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    assert capi.load().aud_init(0, C.byref(h)) == capi.AUD_EHIP
+    from auditory_amd import runtime
+    with pytest.raises(capi.AuditoryError):
+        runtime.Context(0)
+
+
+def test_param_derivation_matches_oracle(orc):
+    lib = capi.load()
+    for ms, sr in [(25, 16000), (32, 16000), (25, 44100), (10, 44100), (46.44, 44100), (12.5, 22050),
+                   (0.03, 16000), (-25, 16000)]:
+        assert lib.aud_msec_to_samples(ms, sr) == orc.msec_to_samples(ms, sr)
+    se = sound.SndEnv()
+    se.Defaults()
+    p = se.Params
+    assert (p.WinMs, p.StepMs, p.SegmentMs, p.StrideMs, p.BorderSteps) == (25.0, 10.0, 100.0, 100.0, 2)
+    c = p.to_c()
+    assert lib.aud_sound_params_derive(c, 0) == capi.AUD_EINVAL
+    assert lib.aud_sound_params_derive(c, 44100) == 0
+    o = orc.sound_params(25, 10, 100, 100, 2, 44100)
+    assert (c.win_samples, c.step_samples, c.segment_samples, c.stride_samples, c.segment_steps) == \
+        (o.win_samples, o.step_samples, o.segment_samples, o.stride_samples, o.segment_steps)
+    assert lib.aud_seg_cnt(48000, 1600, 1600, 1) == orc.lib().orc_seg_cnt(48000, 1600, 1600, 1)
+    for v, bd in [(32767, 16), (-32768, 16), (1234, 16), (127, 8), (8388607, 24), (2147483647, 32), (5, 12)]:
+        assert lib.aud_pcm_to_float(v, bd) == orc.lib().orc_pcm_to_float(v, bd)
+    d = capi.DftParams()
+    lib.aud_dft_defaults(d)
+    od = orc.dft_defaults()
+    assert (d.comp_log_pow, d.log_min, d.log_offset, d.prev_smooth, d.cur_smooth) == \
+        (od.comp_log_pow, od.log_min, od.log_offset, od.prev_smooth, od.cur_smooth) == (1, -100.0, 1.0, 0.0, 1.0)
+
+
+@pytest.mark.parametrize("name", list(W.CONFIGS))
+def test_mel_table_bit_identical_to_oracle(orc, name):
+    oc = W.OracleCfg(orc, name)
+    sr, win, step, seg, stride, border, nf, lo, hi = W.CONFIGS[name]
+    mp = mel.Params()
+    mp.Defaults()
+    assert mp.FBank.Renorm and mp.MFCC and mp.NCoefs == 13
+    mp.FBank.NFilters, mp.FBank.LoHz, mp.FBank.HiHz = nf, lo, hi
+    filt = mp.InitFilters(oc.N, sr)
+    assert mp.FBank.Renorm is False
+    assert np.array_equal(mp.BinPts, oc.bins)
+    assert np.array_equal(mp.HzPts, oc.hz)
+    assert np.array_equal(filt, oc.filt, equal_nan=True)
+    assert mel.FreqToBin(1000.0, 400, 16000) == orc.lib().orc_freq_to_bin(1000.0, 400.0, 16000.0)
+    assert mel.FreqToMel(440.0) == orc.lib().orc_freq_to_mel(440.0)
+    assert mel.MelToFreq(1234.5) == orc.lib().orc_mel_to_freq(1234.5)
+
+
+def test_mel_table_overflow_is_an_error():
+    mp = mel.Params()
+    mp.Defaults()
+    mp.FBank.NFilters = 4            # triangles far wider than nf+2 -> the Go code panics
+    with pytest.raises(capi.AuditoryError):
+        mp.InitFilters(512, 16000)
+
+
+@pytest.mark.parametrize("sx,sy,distribute", [(9, 9, False), (8, 8, False), (7, 11, True)])
+def test_gabor_taps_bit_identical_to_oracle(orc, sx, sy, distribute):
+    dicts = list(W.DEFAULT_GABOR_SPECS) + [
+        dict(off=1, wave_len=2.0, orientation=30, sigma_width=0.5, sigma_length=0.5),
+        dict(orientation=0, circle_edge=1),                       # zero fields -> Defaults
+        dict(wave_len=1.5, sigma_width=0.4, circular=1),
+        dict(wave_len=2.5, orientation=90, sigma_width=0.6, sigma_length=0.3, phase_offset=0.7)]
+    ref = orc.gabor_to_tensor(dicts, sx, sy, distribute)
+    fs = agabor.FilterSet()
+    fs.SizeX, fs.SizeY, fs.Distribute = sx, sy, distribute
+    specs = [agabor.Filter(WaveLen=d.get("wave_len", 0.0), Orientation=d.get("orientation", 0.0),
+                           SigmaWidth=d.get("sigma_width", 0.0), SigmaLength=d.get("sigma_length", 0.0),
+                           PhaseOffset=d.get("phase_offset", 0.0), CircleEdge=bool(d.get("circle_edge", 0)),
+                           Circular=bool(d.get("circular", 0)), Off=bool(d.get("off", 0))) for d in dicts]
+    agabor.ToTensor(specs, fs)
+    assert fs.Filters.shape == ref.shape == (11, sy, sx)
+    assert np.array_equal(fs.Filters, ref)
+
+
+def test_gabor_iter_space():
+    lib = capi.load()
+    gs = capi.GaborSet(9, 9, 3, 3, 2.0, 0)
+    nt, nf_, st = C.c_int32(), C.c_int32(), C.c_int32()
+    shp = (C.c_int32 * 4)(11, 32, 2, 8)
+    assert lib.aud_gabor_iter_space(gs, 40, 104, 4, shp, nt, nf_, st) == 0
+    assert (nt.value, nf_.value) == (32, 11)               # tMax=min(96,101), fMax=min(33,37)
+    shp = (C.c_int32 * 4)(20, 50, 2, 8)
+    assert lib.aud_gabor_iter_space(gs, 40, 104, 4, shp, nt, nf_, st) == 0
+    assert (nt.value, nf_.value) == (34, 13)               # tMax=101, fMax=37
+    g2 = capi.GaborSet(8, 8, 6, 3, 1.5, 0)
+    shp2 = (C.c_int32 * 2)(22, 68)
+    assert lib.aud_gabor_iter_space(g2, 40, 104, 2, shp2, nt, nf_, st) == 0
+    assert (nt.value, nf_.value, st.value) == (17, 11, 17)
+    assert lib.aud_gabor_iter_space(g2, 40, 8, 2, shp2, nt, nf_, st) == 0 and nt.value == 1
+    assert lib.aud_gabor_iter_space(g2, 40, 7, 2, shp2, nt, nf_, st) == capi.AUD_EINVAL
+    assert lib.aud_gabor_iter_space(g2, 40, 104, 5, shp2, nt, nf_, st) == capi.AUD_EINVAL
+    assert lib.aud_gabor_iter_space(g2, 40, 104, 3, shp2, nt, nf_, st) == capi.AUD_EINVAL
+
+
+def test_sndenv_pad_tail():
+    se = sound.SndEnv()
+    se.Defaults()
+    se.Params.SegmentSamples, se.Params.StrideSamples, se.Params.StepSamples = 1600, 1600, 160
+    sig = np.zeros(10000)
+    assert se.Tail(sig) == (10000 - 1600) % 1600
+    assert len(se.Pad(sig)) == 10000 + 1600 - 160 - se.Tail(sig) % 160
