@@ -114,18 +114,20 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
                 const int q = b / s, k = b - q * s;
                 const C2<TT>* x = src + size_t(f) * M + k + s * q;
                 const int sm = s * m;
-                TT ar = TT(0), ai = TT(0);
+                // p-term direct sum: accumulate in float64 even in the f32 build, so a long
+                // prime pass (p = 1103) does not pile up sqrt(p) f32 roundings
+                double ar = 0.0, ai = 0.0;
                 int e = 0;
                 for (int i = 0; i < p; ++i) {
                     const C2<TT> v = x[i * sm];
                     const C2<TT> c = tw[e * wp];
-                    ar += v.x * c.x - v.y * c.y;
-                    ai += v.x * c.y + v.y * c.x;
+                    ar += double(v.x) * double(c.x) - double(v.y) * double(c.y);
+                    ai += double(v.x) * double(c.y) + double(v.y) * double(c.x);
                     e += j;
                     if (e >= p) e -= p;
                 }
                 const C2<TT> t = tw[int((int64_t(q) * j * s * a.ratio) % N)];
-                dst[size_t(f) * M + k + s * (p * q + j)] = cmul<TT>({ar, ai}, t);
+                dst[size_t(f) * M + k + s * (p * q + j)] = cmul<TT>({TT(ar), TT(ai)}, t);
             }
         }
         __syncthreads();

@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- audio-seconds/sec of the frame->FFT->power->mel hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): batch = 256 synthetic 16 kHz mono utterances of 1 s per GPU,
+WinMs 32 (N = 512-point FFT, no taper), StepMs 10 (S = 160), one segment per utterance with
+BorderSteps 2 (T = 104 frames), 40 mel filters 0-8000 Hz, mel output only.  A "step" is one pass
+of the hot path over one such batch, inputs already resident in HBM.  Multi-GPU: one process per
+GPU, each rank owns its own 256-utterance shard (weak scaling, no data-path collective in the
+timed region); the RCCL all-gather that reassembles the feature tensor is measured in a second
+region and reported under "allgather".
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(oc, sig64, L, target_s=12.0, max_threads=16, chunk=8):
+    """The oracle (C float64 restatement, FFT plan cached per segment) timed on this box's host
+    cores, one utterance per thread at a time (ctypes releases the GIL).
+
+    Memory is bounded by construction: every call hands the oracle `chunk` utterances that are
+    VIEWS of the resident batch (no per-thread copies), the thread count is capped at the box's
+    CPU share (16 per GPU), and the sample size is capped.  (An earlier version copied
+    ~1 GB per thread and took a GPU box down by exhausting host RAM.)"""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(avail, max_threads))
+    n_rows = len(sig64)
+    chunk = min(chunk, n_rows)
+    flat = sig64.reshape(-1)                       # view of the resident [B, L] batch
+
+    def run_chunk(first, faithful=False):
+        first = first % (n_rows - chunk + 1)
+        view = flat[first * L:(first + chunk) * L]  # contiguous view, no copy
+        rc, mel, _ = orc.process_batch(oc.sp, oc.d, oc.m, oc.bins, oc.filt, view,
+                                       np.arange(chunk) * L, np.full(chunk, L), np.zeros(chunk),
+                                       faithful=faithful)
+        assert rc == 0
+        return chunk
+
+    t0 = time.perf_counter()
+    run_chunk(0)
+    per_utt = (time.perf_counter() - t0) / chunk
+    t0 = time.perf_counter()
+    run_chunk(0, faithful=True)
+    per_utt_faithful = (time.perf_counter() - t0) / chunk
+    calls_per_thread = int(min(2000, max(1, target_s / (per_utt * chunk))))
+
+    def worker(t):
+        done = 0
+        for c in range(calls_per_thread):
+            done += run_chunk((t * 131 + c * chunk))
+        return done
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        n = sum(ex.map(worker, range(cores)))
+    dt = time.perf_counter() - t0
+    return {"value": round(n * 1.0 / dt, 2), "unit": "audio-seconds/sec", "cores": cores,
+            "kind": "port",
+            "sample": "%d synthetic 1 s utterances (the bench batch, re-used), oracle/auditory_oracle.c "
+                      "float64, %d threads x %d calls x %d utterances, FFT plan cached per segment"
+                      % (n, cores, calls_per_thread, chunk),
+            "one_thread_cached": round(1.0 / per_utt, 2),
+            "one_thread_plan_per_frame": round(1.0 / per_utt_faithful, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
+    ap.add_argument("--win-ms", type=float, default=32.0, help="32 -> N=512 (headline), 25 -> N=400")
+    ap.add_argument("--compute", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-allgather", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import workloads as W
+    from auditory_amd import capi, runtime, synth
+    from auditory_amd.batch import BatchProcessor, allgather_features
+    from oracle import oracle as orc  # cpu_baseline leg + table cross-check only
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    name = "cfg2_16k_n512_nf40" if args.win_ms == 32.0 else "cfg2_16k_n400_nf40"
+    assert args.win_ms in (32.0, 25.0)
+    oc = W.OracleCfg(orc, name)
+    B, sr, dur = args.batch, oc.sr, 16000
+    L = (oc.full_len() + 63) // 64 * 64          # zero tail so every frame is in bounds, 64-sample pitch
+    sig64, _ = synth.batch(2, B, dur, sr, row_len=L, first_idx=rank * B)
+    cdt = capi.AUD_F32 if args.compute == "f32" else capi.AUD_F64
+    plan = W.product_plan(oc, cdt, device=local_rank)
+    bp = BatchProcessor(plan, dev)
+    dsig = torch.from_numpy(sig64.astype(np.float32)).to(dev).view(-1)
+    items = bp.upload_items(runtime.make_items(np.arange(B) * L, [L] * B, [0] * B))
+    mel = torch.empty((B, oc.nf, oc.T), dtype=torch.float32, device=dev)
+
+    def step():
+        bp.melspec(dsig, items, B, mel=mel)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                                  # same stream the kernel is launched on
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the timed output is the real thing (spot-check utterance 0 against the oracle)
+    o = orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig64[0])
+    ok, msg = W.close_enough(mel[0].cpu().numpy(), o["mel_seg"], 1e-5 if cdt == capi.AUD_F32 else 3e-7)
+    if not ok:
+        print("WARNING: spot check vs oracle: " + msg, file=sys.stderr)
+
+    # second region: the same step followed by the RCCL all-gather of the mel slabs
+    ag = None
+    if world > 1 and not args.no_allgather:
+        for _ in range(3):
+            step()
+            allgather_features(mel, world)
+        sync_all()
+        k2 = max(10, args.steps // 4)
+        t0 = time.perf_counter()
+        for _ in range(k2):
+            step()
+            full = allgather_features(mel, world)
+        sync_all()
+        e2 = time.perf_counter() - t0
+        t = torch.tensor([e2], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        e2 = float(t.item())
+        ag = {"value": round(B * world * k2 / e2, 1), "unit": "audio-seconds/sec", "steps": k2,
+              "ms_per_step": round(1e3 * e2 / k2, 4), "gathered_shape": list(full.shape),
+              "note": "step + one ncclAllGather (RCCL) of the [B, 40, 104] f32 mel slab per rank"}
+
+    audio_s_per_step = B * world * (dur / float(sr))
+    alg_bytes = B * (4 * dur + 4 * oc.nf * oc.T)  # each sample read once + each mel value written once
+    kern_ms = dev_ms / args.steps
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    line = {
+        "metric": "audio-seconds/sec (16 kHz, 25 ms/10 ms, 40 mel) at 1/2/4/8 MI355X",
+        "value": round(audio_s_per_step * args.steps / elapsed, 1),
+        "unit": "audio-seconds/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.compute, "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: batch=%d synthetic 16 kHz 1 s mono utterances per GPU, "
+                               "%d-pt FFT (WinMs %g), step 160, T=104 frames, 40 mel, mel only"
+                               % (B, oc.N, args.win_ms),
+                   "batch_per_gpu": B, "win_samples": oc.N, "step_samples": oc.S,
+                   "segment_steps": oc.T, "n_mel": oc.nf, "kernel": plan.kernel_name,
+                   "sharding": "utterances, contiguous block per rank"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                     "kernel": "frame->FFT->power->mel (%s)" % plan.kernel_name,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "avg_launch_us": round(kern_ms * 1e3, 3)},
+    }
+    if ag:
+        line["allgather"] = ag
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(oc, sig64, L)
+    if rank == 0:
+        print(json.dumps(line))
+    plan.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

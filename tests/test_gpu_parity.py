@@ -110,8 +110,14 @@ def test_zero_signal_and_empty_batch(orc, torch_cuda):
     mel, _, _ = plan.melspec_host(np.zeros(8), runtime.make_items([], [], []))
     assert mel.shape == (0, 32, 14)
     # signal shorter than one window: every frame masked -> all zero
-    mel, pw, _ = plan.melspec_host(np.ones(100), runtime.make_items([0], [100], [0]), True)
+    mel, pw, _ = plan.melspec_host(np.ones(50), runtime.make_items([0], [50], [0]), True)
     assert np.all(mel == 0) and np.all(pw == 0)
+    # 100 samples: only frame 0 (start -320, end 80) fits; it sees 320 zeros + 80 ones
+    mel, pw, _ = plan.melspec_host(np.ones(100), runtime.make_items([0], [100], [0]), True)
+    o = orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, np.ones(100))
+    assert o["done"] == 1 and np.all(mel[0, :, 1:] == 0)
+    ok, msg = W.close_enough(mel[0], o["mel_seg"], TOL_F32)
+    assert ok, msg
     plan.close()
 
 
@@ -152,17 +158,29 @@ def test_gabor_4d_and_2d_vs_oracle(orc, torch_cuda, cdt):
     plan.gabor_host(mel, out)
     ok, msg = W.close_enough(out, ref, tol)
     assert ok, msg
-    # smaller pool grid than the mel allows: untouched cells keep their contents
-    out = np.full((5, 12, 40, 2, 8), 7.0, np.float32)
+    # wider units than the kernel fills + fewer pools than the mel allows:
+    # untouched cells keep their contents (the reference never zeroes rawOut)
+    out = np.full((5, 9, 20, 3, 10), 7.0, np.float32)
     ref = np.full_like(out, 7.0)
     for i in range(5):
-        assert orc.gabor_convolve(mel[i], k, 3, 3, 2.0, ref[i]) in (0,)
+        assert orc.gabor_convolve(mel[i], k, 3, 3, 2.0, ref[i]) == 0
     plan.gabor_host(mel, out)
     ok, msg = W.close_enough(out, ref, tol)
     assert ok, msg
-    assert (out[:, 11:, :, :, :] == 7.0).all()
-    # pools that reach past the mel matrix: the Go code would panic -> AUD_EINVAL, nothing written
-    big = np.full((5, 14, 40, 2, 8), 7.0, np.float32)
+    assert (out[:, :, :, 2, :] == 7.0).all() and (out[:, :, :, :, 8:] == 7.0).all()
+    # PoolsX = 33: the last time position reads t+ft = 104 = first sample of the NEXT mel row
+    # (etensor has no per-dimension bounds check) -- reproduced through flat indexing
+    out = np.zeros((5, 11, 33, 2, 8), np.float32)
+    ref = np.zeros_like(out)
+    for i in range(5):
+        assert orc.gabor_convolve(mel[i], k, 3, 3, 2.0, ref[i]) == 0
+    plan.gabor_host(mel, out)
+    ok, msg = W.close_enough(out, ref, tol)
+    assert ok, msg
+    assert np.abs(ref[:, :, 32]).max() > 0
+    # pools that reach past the mel matrix: the Go code panics -> AUD_EINVAL, nothing written
+    big = np.full((5, 12, 40, 2, 8), 7.0, np.float32)
+    assert orc.gabor_convolve(mel[0], k, 3, 3, 2.0, big[0].copy()) == orc.ORC_EPANIC
     with pytest.raises(capi.AuditoryError):
         plan.gabor_host(mel, big)
     assert (big == 7.0).all()
