@@ -9,6 +9,13 @@ namespace aud {
 
 constexpr int kMaxFactors = 24;
 
+// All LDS scratch lives in the dynamic region (keeps its base 16-byte aligned; every carve
+// offset below is a multiple of 16).
+__device__ __forceinline__ unsigned char* dyn_lds() {
+    extern __shared__ __attribute__((aligned(16))) unsigned char aud_dyn_lds[];
+    return aud_dyn_lds;
+}
+
 // Arguments of every frame->mel kernel family.  Doubles are converted to the compute
 // type inside the kernel; `tw` and `filt` are already stored in the compute type.
 struct MelspecArgs {

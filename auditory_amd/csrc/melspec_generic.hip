@@ -39,7 +39,7 @@ __device__ __forceinline__ double dev_log(double v) { return log(v); }
 
 template <typename TT>
 __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* smem = dyn_lds();
     const int tid = threadIdx.x;
     const int F = a.F, M = a.M, N = a.N, H = a.H, T = a.T;
     C2<TT>* src = reinterpret_cast<C2<TT>*>(smem);

@@ -1,0 +1,47 @@
+"""TEST INFRASTRUCTURE ONLY: compiles the product's HIP sources, unchanged, with g++ against the
+host stand-in for the HIP runtime (tests/emul/hip/hip_runtime.h) into tests/emul/libauditory_emul*.so.
+Variants: plain (-O2), asan (AddressSanitizer + UBSan), tsan (ThreadSanitizer)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from auditory_amd import build as product_build  # noqa: E402  (source list only)
+
+FLAGS = {
+    "plain": ["-O2"],
+    "asan": ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+             "-fno-sanitize-recover=undefined"],
+    "tsan": ["-O1", "-g", "-fsanitize=thread"],
+}
+
+
+def lib_path(variant="plain"):
+    return os.path.join(HERE, "libauditory_emul%s.so" % ("" if variant == "plain" else "_" + variant))
+
+
+def build(variant="plain", force=False):
+    out = lib_path(variant)
+    srcs = product_build.sources() + [os.path.join(HERE, "emul_runtime.cpp")]
+    deps = srcs + [os.path.join(HERE, "hip", "hip_runtime.h"),
+                   os.path.join(product_build.CSRC, "kernels.h"),
+                   os.path.join(product_build.INCLUDE, "auditory_hip.h")]
+    deps += [os.path.join(product_build.CSRC, f) for f in os.listdir(product_build.CSRC)
+             if f.endswith((".h", ".hpp", ".inc"))]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    cmd = ["g++", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
+           "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-function", "-Wno-attributes"] + FLAGS[variant] + [
+           "-I" + HERE, "-I" + product_build.INCLUDE, "-I" + product_build.CSRC, "-o", out]
+    for s in srcs:
+        cmd += ["-x", "c++", s]
+    cmd += ["-ldl"]
+    subprocess.check_call(cmd)
+    return out
+
+
+if __name__ == "__main__":
+    for v in sys.argv[1:] or ["plain"]:
+        print(build(v, force=True))

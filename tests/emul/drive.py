@@ -1,0 +1,36 @@
+"""TEST INFRASTRUCTURE ONLY: runs parity cases against a sanitizer build of the emulated kernels.
+Invoked as a subprocess (the sanitizer runtime has to be LD_PRELOADed into python):
+    LD_PRELOAD=$(gcc -print-file-name=libasan.so) python tests/emul/drive.py asan quick
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), HERE]
+
+import backend  # noqa: E402
+import parity_cases as PC  # noqa: E402
+from auditory_amd import capi  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+def main():
+    variant, which = sys.argv[1], sys.argv[2]
+    by_name = {c[0]: c for c in PC.CASES}
+    with backend.emulated(variant):
+        if which == "quick":
+            # small shapes: every kernel family, both compute types, every control path
+            PC.case_melspec_vs_oracle(orc, ("sndenv_16k_n400_nf32", 0.25, 1, [0, 2]), capi.AUD_F32)
+            PC.case_melspec_vs_oracle(orc, ("cfg2_16k_n512_nf40", 0.2, 1, [0]), capi.AUD_F32, seg_ms=100.0)
+            PC.case_melspec_vs_oracle(orc, ("cfg2_16k_n512_nf40", 0.2, 1, [0]), capi.AUD_F64, seg_ms=100.0)
+            PC.case_melspec_vs_oracle(orc, ("odd_15k_n375_nf32", 0.2, 1, [0]), capi.AUD_F32)
+            PC.case_zero_signal_and_empty_batch(orc)
+            PC.case_gabor_4d_and_2d_vs_oracle(orc, capi.AUD_F32)
+        else:
+            PC.case_melspec_vs_oracle(orc, by_name[which], capi.AUD_F32)
+    print("DRIVE-OK", variant, which)
+
+
+if __name__ == "__main__":
+    main()

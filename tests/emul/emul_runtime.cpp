@@ -1,0 +1,160 @@
+// TEST INFRASTRUCTURE ONLY -- runtime behind tests/emul/hip/hip_runtime.h (see its header).
+// One OS thread per GPU thread of the running workgroup; workgroups run one after another.
+#include <hip/hip_runtime.h>
+
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/asan_interface.h>
+#define EMUL_POISON(p, n) ASAN_POISON_MEMORY_REGION(p, n)
+#define EMUL_UNPOISON(p, n) ASAN_UNPOISON_MEMORY_REGION(p, n)
+#else
+#define EMUL_POISON(p, n) ((void)0)
+#define EMUL_UNPOISON(p, n) ((void)0)
+#endif
+
+#include <condition_variable>
+#include <cstdio>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace aud {
+// the one dynamic-LDS allocation of the running workgroup (160 KiB per CU on MI355X)
+alignas(16) unsigned char aud_dyn_lds[160 * 1024];
+}  // namespace aud
+
+namespace {
+
+// barrier whose participant count can shrink when threads leave the kernel early
+struct Barrier {
+    std::mutex m;
+    std::condition_variable cv;
+    int waiting = 0, live = 0;
+    unsigned long gen = 0;
+    void reset(int n) {
+        waiting = 0;
+        live = n;
+    }
+    void arrive_and_wait() {
+        std::unique_lock<std::mutex> lk(m);
+        const unsigned long g = gen;
+        if (++waiting >= live) {
+            waiting = 0;
+            ++gen;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return gen != g; });
+        }
+    }
+    void drop() {
+        std::unique_lock<std::mutex> lk(m);
+        --live;
+        if (live > 0 && waiting >= live) {
+            waiting = 0;
+            ++gen;
+            cv.notify_all();
+        }
+    }
+};
+
+constexpr int kMaxThreads = 1024;
+Barrier g_block;
+Barrier g_wave[kMaxThreads / 64];
+uint64_t g_xchg[kMaxThreads];
+size_t g_lds_bytes = 0;
+hipError_t g_last = hipSuccess;
+
+}  // namespace
+
+namespace aud_emul {
+
+void sync_block() { g_block.arrive_and_wait(); }
+
+uint64_t wave_exchange(uint64_t mine, int src_lane) {
+    const int tid = int(threadIdx.x);
+    const int w = tid >> 6;
+    g_xchg[tid] = mine;
+    g_wave[w].arrive_and_wait();
+    const uint64_t got = g_xchg[(w << 6) | (src_lane & 63)];
+    g_wave[w].arrive_and_wait();
+    return got;
+}
+
+void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body) {
+    const int nthr = int(block.x * block.y * block.z);
+    if (nthr < 1 || nthr > kMaxThreads || lds_bytes > sizeof(aud::aud_dyn_lds)) {
+        g_last = hipErrorInvalidValue;
+        return;
+    }
+    g_lds_bytes = lds_bytes;
+    const unsigned long nblocks = (unsigned long)grid.x * grid.y * grid.z;
+    for (unsigned long b = 0; b < nblocks; ++b) {
+        // poison LDS so that reads of never-written shared memory show up as NaNs / garbage
+        EMUL_UNPOISON(aud::aud_dyn_lds, sizeof(aud::aud_dyn_lds));
+        std::memset(aud::aud_dyn_lds, 0xFF, sizeof(aud::aud_dyn_lds));
+        // LDS beyond what the launch asked for is off limits (ASan build traps the access)
+        const size_t used = (lds_bytes + 7) & ~size_t(7);
+        if (used < sizeof(aud::aud_dyn_lds))
+            EMUL_POISON(aud::aud_dyn_lds + used, sizeof(aud::aud_dyn_lds) - used);
+        g_block.reset(nthr);
+        for (int w = 0; w * 64 < nthr; ++w) g_wave[w].reset(std::min(64, nthr - w * 64));
+        std::vector<std::thread> pool;
+        pool.reserve(size_t(nthr));
+        for (int t = 0; t < nthr; ++t) {
+            pool.emplace_back([&, t, b]() {
+                threadIdx = dim3(unsigned(t) % block.x, (unsigned(t) / block.x) % block.y,
+                                 unsigned(t) / (block.x * block.y));
+                blockIdx = dim3(unsigned(b % grid.x), unsigned((b / grid.x) % grid.y),
+                                unsigned(b / ((unsigned long)grid.x * grid.y)));
+                blockDim = block;
+                gridDim = grid;
+                body();
+                g_wave[t >> 6].drop();
+                g_block.drop();
+            });
+        }
+        for (auto& th : pool) th.join();
+    }
+    EMUL_UNPOISON(aud::aud_dyn_lds, sizeof(aud::aud_dyn_lds));
+}
+
+}  // namespace aud_emul
+
+hipError_t hipGetDeviceCount(int* n) {
+    *n = 1;
+    return hipSuccess;
+}
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipMalloc(void** p, size_t bytes) {
+    *p = std::malloc(bytes ? bytes : 1);  // exact size: ASan sees device-buffer overruns
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipFree(void* p) {
+    std::free(p);
+    return hipSuccess;
+}
+hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind) {
+    std::memcpy(dst, src, bytes);
+    return hipSuccess;
+}
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind, hipStream_t) {
+    std::memcpy(dst, src, bytes);
+    return hipSuccess;
+}
+hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t) {
+    std::memset(dst, value, bytes);
+    return hipSuccess;
+}
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
+    *s = nullptr;
+    return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipGetLastError() {
+    const hipError_t e = g_last;
+    g_last = hipSuccess;
+    return e;
+}
+const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emulated HIP error"; }

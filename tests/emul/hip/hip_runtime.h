@@ -1,0 +1,101 @@
+// TEST INFRASTRUCTURE ONLY -- a host stand-in for <hip/hip_runtime.h>.
+//
+// Lets the product's .hip sources be compiled UNCHANGED with g++ so that their indexing,
+// barriers and arithmetic can be exercised on the CPU under AddressSanitizer / UBSan /
+// ThreadSanitizer (GPU sanitizers are not available on this pool).  Every GPU thread is a real
+// OS thread; __syncthreads() and the wave shuffles are real barriers, so a missing barrier is a
+// data race TSan can see and a divergent barrier is a detected deadlock.
+//
+// This is NOT a CPU fallback of the product: libauditory_hip.so never contains or loads it;
+// only tests/ builds tests/emul/libauditory_emul*.so and only `-m "not gpu"` tests load it.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+typedef int hipError_t;
+typedef struct emul_stream* hipStream_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+enum { hipStreamNonBlocking = 1 };
+
+hipError_t hipGetDeviceCount(int* n);
+hipError_t hipSetDevice(int d);
+hipError_t hipMalloc(void** p, size_t bytes);
+hipError_t hipFree(void* p);
+hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind k);
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind k, hipStream_t s);
+hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t s);
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipGetLastError();
+const char* hipGetErrorString(hipError_t e);
+
+namespace aud_emul {
+void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body);
+void sync_block();
+// exchange one 8-byte payload between the lanes of the calling thread's wave
+uint64_t wave_exchange(uint64_t mine, int src_lane);
+}  // namespace aud_emul
+
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+    aud_emul::launch((grid), (block), (lds), [=]() { kernel(__VA_ARGS__); })
+
+inline void __syncthreads() { aud_emul::sync_block(); }
+
+template <typename T>
+inline T emul_shfl_any(T v, int src_lane) {
+    static_assert(sizeof(T) <= 8, "shuffle payload");
+    uint64_t raw = 0;
+    std::memcpy(&raw, &v, sizeof(T));
+    raw = aud_emul::wave_exchange(raw, src_lane);
+    T out;
+    std::memcpy(&out, &raw, sizeof(T));
+    return out;
+}
+inline int emul_lane() { return int(threadIdx.x & 63u); }
+template <typename T>
+inline T __shfl(T v, int src, int width = 64) {
+    const int lane = emul_lane();
+    return emul_shfl_any(v, (lane & ~(width - 1)) | (src & (width - 1)));
+}
+template <typename T>
+inline T __shfl_xor(T v, int mask, int width = 64) {
+    const int lane = emul_lane();
+    const int src = lane ^ mask;
+    return emul_shfl_any(v, (src & ~(width - 1)) == (lane & ~(width - 1)) ? src : lane);
+}
+template <typename T>
+inline T __shfl_down(T v, unsigned d, int width = 64) {
+    const int lane = emul_lane();
+    const int src = lane + int(d);
+    return emul_shfl_any(v, (src & ~(width - 1)) == (lane & ~(width - 1)) ? src : lane);
+}
+template <typename T>
+inline T __shfl_up(T v, unsigned d, int width = 64) {
+    const int lane = emul_lane();
+    const int src = lane - int(d);
+    return emul_shfl_any(v, (src >= 0 && (src & ~(width - 1)) == (lane & ~(width - 1))) ? src : lane);
+}
+
+using std::max;
+using std::min;

@@ -1,0 +1,219 @@
+"""Parity cases that go through the HOST-buffer C ABI only (no torch): shared between
+tests/test_gpu_parity.py (the real library on the MI355X) and tests/test_emul_parity.py (the same
+kernel sources compiled for the CPU thread emulator, for sanitizer coverage without a GPU).
+Tolerances (BASELINE.json north_star: 1e-5 relative on the float32 tensors):
+  f32 compute : |got - ref| <= 1e-5 * max(1, |ref|)  on broadband inputs
+  f64 compute : |got - ref| <= 3e-7 * max(1, |ref|)  (float32 output rounding only)
+"""
+import numpy as np
+import pytest
+
+import workloads as W
+from auditory_amd import capi, runtime, synth
+
+TOL_F32 = 1e-5
+TOL_F64 = 3e-7
+
+
+def oracle_items(orc, oc, sig2d, segs):
+    """oracle outputs for items (row r of sig2d, segment s)"""
+    mel, pw, lp = [], [], []
+    for r, s in segs:
+        o = orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig2d[r], segment=s)
+        mel.append(o["mel_seg"]); pw.append(o["power_seg"]); lp.append(o["log_power_seg"])
+    return np.stack(mel), np.stack(pw), np.stack(lp)
+
+
+def make_items(oc, L, segs):
+    return runtime.make_items([r * L for r, s in segs], [L] * len(segs),
+                              [s * oc.sp.stride_samples for r, s in segs])
+
+CASES = [  # config, seconds of audio, rows, segments to process per row
+    ("sndenv_16k_n400_nf32", 0.5, 2, [0, 1, 2, 3]),      # seg 3: later frames run off the end (Q7)
+    ("cfg2_16k_n400_nf40", 1.0, 3, [0]),
+    ("cfg2_16k_n512_nf40", 1.0, 3, [0]),
+    ("cfg1_44k_n1103_nf32", 0.3, 1, [0, 1]),             # prime N
+    ("cfg5_44k_n2048_nf128", 0.25, 2, [0]),              # NaN mel row (Q3), T=504 mostly masked
+    ("odd_15k_n375_nf32", 0.3, 1, [0, 1]),
+    ("mixed_16k_n480_nf32", 0.5, 1, [0, 1]),
+]
+
+GABOR_DEFAULT = dict(size=(9, 9), stride=(3, 3), gain=2.0, specs=W.DEFAULT_GABOR_SPECS)
+GABOR_VIEW = dict(size=(8, 8), stride=(6, 3), gain=1.5, specs=W.DEFAULT_GABOR_SPECS[::2])   # gbv.go:334-357
+
+
+def case_melspec_vs_oracle(orc, case, cdt, seg_ms=None):
+    name, dur, rows, seg_list = case
+    oc = W.OracleCfg(orc, name, seg_ms)
+    L = int(dur * oc.sr)
+    sig, pcm = synth.batch(11, rows, L, oc.sr)
+    segs = [(r, s) for r in range(rows) for s in seg_list]
+    ref_mel, ref_pw, ref_lp = oracle_items(orc, oc, sig, segs)
+    plan = W.product_plan(oc, cdt)
+    try:
+        mel, pw, lp = plan.melspec_host(sig.ravel(), make_items(oc, L, segs), True, True)
+    finally:
+        plan.close()
+    tol = TOL_F32 if cdt == capi.AUD_F32 else TOL_F64
+    ok, msg = W.close_enough(mel, ref_mel, tol)
+    assert ok, "mel " + msg
+    ok, msg = W.close_enough(lp, ref_lp, tol)
+    assert ok, "log_power " + msg
+    # power spans ~10 decades: judge it relative to the frame's largest bin
+    scale = np.maximum(ref_pw.max(axis=1, keepdims=True), 1.0)
+    assert np.abs(pw - ref_pw).max() <= (2e-6 if cdt == capi.AUD_F32 else 3e-7) * scale.max()
+    assert (np.abs(pw - ref_pw) / scale).max() <= (2e-6 if cdt == capi.AUD_F32 else 3e-7)
+    # masked frames are exactly zero, not LogMin (Q7)
+    dead = (ref_pw == 0).all(axis=1) & (ref_mel == 0).all(axis=1)
+    assert np.all(mel.transpose(0, 2, 1)[dead] == 0)
+    if name == "cfg5_44k_n2048_nf128":
+        assert np.isnan(mel[:, 0, :3]).all()
+
+
+def case_zero_signal_and_empty_batch(orc):
+    oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
+    plan = W.product_plan(oc)
+    mel, pw, lp = plan.melspec_host(np.zeros(4000), runtime.make_items([0], [4000], [0]), True, True)
+    assert np.all(mel == -10.0) and np.all(pw == 0) and np.all(lp == 0)        # Q2
+    mel, _, _ = plan.melspec_host(np.zeros(8), runtime.make_items([], [], []))
+    assert mel.shape == (0, 32, 14)
+    # signal shorter than one window: every frame masked -> all zero
+    mel, pw, _ = plan.melspec_host(np.ones(50), runtime.make_items([0], [50], [0]), True)
+    assert np.all(mel == 0) and np.all(pw == 0)
+    # 100 samples: only frame 0 (start -320, end 80) fits; it sees 320 zeros + 80 ones
+    mel, pw, _ = plan.melspec_host(np.ones(100), runtime.make_items([0], [100], [0]), True)
+    o = orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, np.ones(100))
+    assert o["done"] == 1 and np.all(mel[0, :, 1:] == 0)
+    ok, msg = W.close_enough(mel[0], o["mel_seg"], TOL_F32)
+    assert ok, msg
+    plan.close()
+
+
+def case_plan_rejects_unsupported(orc):
+    from auditory_amd import mel
+    oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
+    ctx = runtime.get_ctx(0)
+    dftp = capi.DftParams(1, -100.0, 1.0, 0.0, 1.0)
+    fb = capi.MelFBank(32, 0.0, 8000.0, 0.0, -10.0, 0, -6.0, 4.0, 0.0)
+    bad_bins = oc.bins.copy()
+    bad_bins[-1] = 300                                  # past Power[H]: Go panics
+    with pytest.raises(capi.AuditoryError):
+        runtime.Plan(ctx, 400, 160, 14, 2, dftp, fb, bad_bins, oc.filt)
+    with pytest.raises(capi.AuditoryError):
+        runtime.Plan(ctx, 2, 160, 14, 2, dftp, fb, oc.bins, oc.filt)
+
+
+def case_gabor_4d_and_2d_vs_oracle(orc, cdt):
+    oc = W.OracleCfg(orc, "cfg2_16k_n512_nf40")
+    rng = np.random.default_rng(3)
+    mel = rng.normal(2.0, 2.5, size=(5, 40, 104))
+    mel[1, 0, :] = np.nan                               # NaN -> 0.5
+    mel[2] = 3.25                                       # constant -> fSum ~ 0
+    mel = mel.astype(np.float32).astype(np.float64)     # what the GPU mel stage hands over
+    tol = 1e-5 if cdt == capi.AUD_F32 else 3e-7
+    # 4-D pooled output, processspeech default filter set
+    k = orc.gabor_to_tensor(W.DEFAULT_GABOR_SPECS, 9, 9)
+    plan = W.product_plan(oc, cdt, GABOR_DEFAULT)
+    out = np.full((5, 11, 32, 2, 8), 7.0, np.float32)
+    ref = np.full_like(out, 7.0)
+    for i in range(5):
+        assert orc.gabor_convolve(mel[i], k, 3, 3, 2.0, ref[i]) == 0
+    plan.gabor_host(mel, out)
+    ok, msg = W.close_enough(out, ref, tol)
+    assert ok, msg
+    # wider units than the kernel fills + fewer pools than the mel allows:
+    # untouched cells keep their contents (the reference never zeroes rawOut)
+    out = np.full((5, 9, 20, 3, 10), 7.0, np.float32)
+    ref = np.full_like(out, 7.0)
+    for i in range(5):
+        assert orc.gabor_convolve(mel[i], k, 3, 3, 2.0, ref[i]) == 0
+    plan.gabor_host(mel, out)
+    ok, msg = W.close_enough(out, ref, tol)
+    assert ok, msg
+    assert (out[:, :, :, 2, :] == 7.0).all() and (out[:, :, :, :, 8:] == 7.0).all()
+    # PoolsX = 33: the last time position reads t+ft = 104 = first sample of the NEXT mel row
+    # (etensor has no per-dimension bounds check) -- reproduced through flat indexing
+    out = np.zeros((5, 11, 33, 2, 8), np.float32)
+    ref = np.zeros_like(out)
+    for i in range(5):
+        assert orc.gabor_convolve(mel[i], k, 3, 3, 2.0, ref[i]) == 0
+    plan.gabor_host(mel, out)
+    ok, msg = W.close_enough(out, ref, tol)
+    assert ok, msg
+    assert np.abs(ref[:, :, 32]).max() > 0
+    # pools that reach past the mel matrix: the Go code panics -> AUD_EINVAL, nothing written
+    big = np.full((5, 12, 40, 2, 8), 7.0, np.float32)
+    assert orc.gabor_convolve(mel[0], k, 3, 3, 2.0, big[0].copy()) == orc.ORC_EPANIC
+    with pytest.raises(capi.AuditoryError):
+        plan.gabor_host(mel, big)
+    assert (big == 7.0).all()
+    plan.close()
+    # 2-D output, gaborview sizing, both orders
+    k4 = orc.gabor_to_tensor(W.DEFAULT_GABOR_SPECS[::2], 8, 8)
+    plan = W.product_plan(oc, cdt, GABOR_VIEW)
+    nfy, nfx = (40 - 8) // 3 + 1, (104 - 8) // 6 + 1
+    for by_time in (True, False):
+        out = np.zeros((5, 2 * nfy, nfx * 4), np.float32)
+        ref = np.zeros_like(out)
+        for i in range(5):
+            assert orc.gabor_convolve(mel[i], k4, 6, 3, 1.5, ref[i], by_time=by_time) == 0
+        plan.gabor_host(mel, out, by_time)
+        ok, msg = W.close_enough(out, ref, tol)
+        assert ok, msg
+    plan.close()
+
+
+def case_sndenv_mirror_reads_like_the_reference(orc):
+    """drive the host-side SndEnv mirror the way an emergent sim drives sound.SndEnv"""
+    from auditory_amd import agabor, sound
+    sig, _ = synth.batch(5, 1, 8000, 16000)
+    se = sound.SndEnv()
+    se.Defaults()
+    se.SampleRate, se.Signal = 16000, sig[0]
+    se.GaborSpecs = [agabor.Filter(WaveLen=2.0, Orientation=o, SigmaWidth=0.5, SigmaLength=0.5,
+                                   PhaseOffset=ph, CircleEdge=True)
+                     for o in (0, 45, 90, 135) for ph in (0, 1.5708)]
+    gf = se.GaborFilters
+    gf.SizeX = gf.SizeY = 9
+    gf.StrideX = gf.StrideY = 3
+    gf.Gain = 2
+    se.GborOutPoolsX, se.GborOutPoolsY, se.GborOutUnitsX, se.GborOutUnitsY = 2, 8, 8, 2
+    assert se.Init() is None
+    assert (se.Params.WinSamples, se.Params.SegmentSteps, se.SegCnt) == (400, 14, 5)
+    oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
+    k = orc.gabor_to_tensor(W.DEFAULT_GABOR_SPECS, 9, 9)
+    for seg in range(se.SegCnt):
+        se.ProcessSegment(seg, 0)
+        tsr = se.ApplyGabor()
+        o = orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig[0], segment=seg)
+        ok, msg = W.close_enough(se.MelFBankSegment, o["mel_seg"], TOL_F32)
+        assert ok, msg
+        ok, msg = W.close_enough(se.LogPowerSegment, o["log_power_seg"], TOL_F32)
+        assert ok, msg
+        ref = np.zeros((8, 2, 2, 8), np.float32)
+        assert orc.gabor_convolve(o["mel_seg"], k, 3, 3, 2.0, ref) == 0
+        ok, msg = W.close_enough(tsr, ref, TOL_F32)
+        assert ok, "gabor " + msg
+
+
+def case_recreated_tone_fixtures_f64(orc):
+    """Synthetic re-creation of the reference's pure-tone WAV designs (44.1 kHz, amp 0.8, 0.5 s,
+    int16), processspeech parameters (N=1103, nf=32).  Bins span >10 decades of power, so this
+    runs in the float64 compute mode where 1e-5 relative holds on every mel value."""
+    oc = W.OracleCfg(orc, "cfg1_44k_n1103_nf32")
+    n = int(0.5 * 44100)
+    t = np.arange(n) / 44100.0
+    rows = []
+    for hz in (800.0, 2000.0, 5000.0, 7000.0):
+        rows.append(np.round(0.8 * np.sin(2 * np.pi * hz * t) * 32767.0).astype(np.int16))
+    sig = synth.pcm_to_float64(np.stack(rows))
+    segs = [(r, s) for r in range(4) for s in (0, 2)]
+    ref_mel, _, _ = oracle_items(orc, oc, sig, segs)
+    plan = W.product_plan(oc, capi.AUD_F64)
+    mel, _, _ = plan.melspec_host(sig.ravel(), make_items(oc, n, segs))
+    plan.close()
+    err = np.abs(mel - ref_mel) / np.maximum(np.abs(ref_mel), 1e-30)
+    assert err.max() <= 1e-5, err.max()
+    for r, pk in enumerate((20, 50, 125, 175)):
+        hot = int(np.argmax(mel[2 * r, :, 5]))
+        assert oc.bins[hot] <= pk <= oc.bins[hot + 2]

@@ -1,0 +1,82 @@
+"""CPU-only coverage of the HIP kernel sources themselves.
+
+The product's .hip files are compiled unchanged against a host stand-in for the HIP runtime
+(tests/emul/, one OS thread per GPU thread, real barriers) and driven through the same C ABI and
+the same parity cases as on the GPU.  This is how indexing, barrier placement and arithmetic are
+checked when no GPU is at hand, and how the kernels get AddressSanitizer / UBSan / ThreadSanitizer
+coverage (GPU sanitizers are not available on this pool).  It is test infrastructure: the shipped
+library has no CPU path (tests/test_capi_host.py::test_init_without_gpu_fails_loudly)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import parity_cases as PC
+from auditory_amd import capi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "emul"))
+import backend  # noqa: E402
+import build_emul  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def emu():
+    with backend.emulated("plain") as lib:
+        yield lib
+
+
+EMU_CASES = [c for c in PC.CASES if c[0] != "cfg5_44k_n2048_nf128"]
+
+
+@pytest.mark.parametrize("case", EMU_CASES, ids=[c[0] for c in EMU_CASES])
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_emul_melspec_vs_oracle(orc, emu, case, cdt):
+    PC.case_melspec_vs_oracle(orc, case, cdt)
+
+
+def test_emul_melspec_nan_row_config(orc, emu):
+    # cfg 5 parameters (N=2048, 128 mel, NaN row) on a short segment to keep the thread count sane
+    PC.case_melspec_vs_oracle(orc, ("cfg5_44k_n2048_nf128", 0.25, 1, [0]), capi.AUD_F32, seg_ms=200.0)
+
+
+def test_emul_zero_signal_and_empty_batch(orc, emu):
+    PC.case_zero_signal_and_empty_batch(orc)
+
+
+def test_emul_plan_rejects_unsupported(orc, emu):
+    PC.case_plan_rejects_unsupported(orc)
+
+
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_emul_gabor_4d_and_2d_vs_oracle(orc, emu, cdt):
+    PC.case_gabor_4d_and_2d_vs_oracle(orc, cdt)
+
+
+def test_emul_sndenv_mirror(orc, emu):
+    PC.case_sndenv_mirror_reads_like_the_reference(orc)
+
+
+def test_emul_recreated_tone_fixtures_f64(orc, emu):
+    PC.case_recreated_tone_fixtures_f64(orc)
+
+
+def _sanitizer_run(variant, which, timeout=900):
+    build_emul.build(variant)
+    rt = {"asan": "libasan.so", "tsan": "libtsan.so"}[variant]
+    pre = subprocess.check_output(["gcc", "-print-file-name=" + rt]).decode().strip()
+    env = dict(os.environ, LD_PRELOAD=pre, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               TSAN_OPTIONS="halt_on_error=1:report_signal_unsafe=0", OMP_NUM_THREADS="1",
+               OPENBLAS_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "emul", "drive.py"), variant, which],
+                       capture_output=True, text=True, env=env, timeout=timeout)
+    assert r.returncode == 0 and "DRIVE-OK" in r.stdout, (r.stdout[-2000:] + "\n" + r.stderr[-6000:])
+
+
+def test_emul_kernels_under_asan_ubsan():
+    _sanitizer_run("asan", "quick")
+
+
+def test_emul_kernels_under_tsan():
+    _sanitizer_run("tsan", "quick")
