@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -32,6 +33,9 @@ struct aud_plan {
     int nfac = 0;
     int fac[aud::kMaxFactors] = {0};
     int F_generic = 0;
+    bool use_r16 = false;
+    aud::R16Args r16{};
+    int* d_grp = nullptr;  // [17 + nf]: group offsets then filter ids
     void* d_tw = nullptr;
     void* d_filt = nullptr;
     int32_t* d_bin_pts = nullptr;
@@ -225,6 +229,42 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
     if (rc == AUD_OK && d->n_gabor > 0)
         rc = upload_real(c, &p->d_gabor, d->gabor_filters,
                          size_t(d->n_gabor) * d->gabor.size_x * d->gabor.size_y, d->compute_dtype);
+    // kernel family: the in-register 16 x 16 kernel for 512-sample windows, else the generic one
+    size_t r16_lds = 0;
+    int r16_xch = 0;
+    if (rc == AUD_OK && aud::melspec_r16_supported(N, d->step_samples, d->compute_dtype, &r16_lds, &r16_xch)) {
+        // balance the mel filters over 16 thread groups by tap count (longest first, LPT)
+        std::vector<int> order(nf), load(16, 0), owner(nf);
+        for (int f = 0; f < nf; ++f) order[f] = f;
+        auto taps = [&](int f) { return std::max(0, d->bin_pts[f + 2] - d->bin_pts[f] + 1) + 12; };
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return taps(x) > taps(y); });
+        for (int f : order) {
+            int g = 0;
+            for (int c = 1; c < 16; ++c)
+                if (load[c] < load[g]) g = c;
+            owner[f] = g;
+            load[g] += taps(f);
+        }
+        std::vector<int> tab(17 + nf, 0);
+        int pos = 0;
+        for (int g = 0; g < 16; ++g) {
+            tab[g] = pos;
+            for (int f = 0; f < nf; ++f)
+                if (owner[f] == g) tab[17 + pos++] = f;
+        }
+        tab[16] = pos;
+        rc = upload(c, reinterpret_cast<void**>(&p->d_grp), tab.data(), tab.size() * sizeof(int));
+        if (rc == AUD_OK && aud::melspec_r16_prepare() != hipSuccess)
+            rc = fail(c, AUD_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        if (rc == AUD_OK) {
+            p->use_r16 = true;
+            p->family = "r16x16";
+            p->r16.xch_off = r16_xch;
+            p->r16.lds_bytes = unsigned(r16_lds);
+            p->r16.grp_off = p->d_grp;
+            p->r16.grp_flt = p->d_grp + 17;
+        }
+    }
     if (rc != AUD_OK) {
         aud_plan_destroy(p);
         return rc;
@@ -240,6 +280,7 @@ int aud_plan_destroy(aud_plan* p) {
     if (p->d_filt) (void)hipFree(p->d_filt);
     if (p->d_bin_pts) (void)hipFree(p->d_bin_pts);
     if (p->d_gabor) (void)hipFree(p->d_gabor);
+    if (p->d_grp) (void)hipFree(p->d_grp);
     delete p;
     return AUD_OK;
 }
@@ -266,7 +307,10 @@ int aud_melspec_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
     a.mel = mel;
     a.power = power;
     a.log_power = log_power;
-    AUD_HIP(c, aud::launch_melspec_generic(a, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
+    if (p->use_r16)
+        AUD_HIP(c, aud::launch_melspec_r16(a, p->r16, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
+    else
+        AUD_HIP(c, aud::launch_melspec_generic(a, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
     return AUD_OK;
 }
 

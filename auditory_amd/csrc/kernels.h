@@ -56,10 +56,23 @@ struct GaborArgs {
     float* out;
 };
 
+// extra arguments of the 512-point (16 x 16 in registers) kernel
+struct R16Args {
+    int xch_off;           // byte offset of the transpose buffer inside dynamic LDS
+    unsigned lds_bytes;    // dynamic LDS of the launch
+    const int* grp_off;    // [17] device: filter-group boundaries into grp_flt
+    const int* grp_flt;    // [nf] device: filter ids, grouped so that groups carry equal tap counts
+};
+
 // generic any-N kernel (Stockham in LDS, radix 2/4 + per-output generic radix)
 size_t melspec_generic_lds_bytes(int M, int F, int compute_dtype);
 int melspec_generic_pick_F(int M, int compute_dtype);
 hipError_t launch_melspec_generic(const MelspecArgs& a, int compute_dtype, hipStream_t st);
+
+// N = 512 fast path
+bool melspec_r16_supported(int N, int S, int compute_dtype, size_t* lds_bytes, int* xch_off);
+hipError_t melspec_r16_prepare();
+hipError_t launch_melspec_r16(const MelspecArgs& a, const R16Args& e, int compute_dtype, hipStream_t st);
 
 hipError_t launch_gabor(const GaborArgs& a, int compute_dtype, hipStream_t st);
 

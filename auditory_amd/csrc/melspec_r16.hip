@@ -1,0 +1,332 @@
+// Fast frame -> FFT -> power -> mel -> log kernel for win_samples = 512 (the "512-pt" BASELINE
+// configuration): the packed-real trick turns each frame into one 256-point complex FFT,
+// computed as 16 x 16 with both radix-16 passes held entirely in registers.
+//
+// Geometry (wave64, 256 threads = 4 waves per workgroup):
+//   * one workgroup = one tile of 16 consecutive frames of one work item;
+//   * 16 lanes cooperate on a frame, each lane owns 16 complex points, so a wave carries
+//     4 frames and every butterfly is straight-line VALU code on registers;
+//   * the tile's contiguous sample span (15*S + N samples; every sample is used by N/S = 3.2
+//     frames) is fetched from HBM once with 16-byte loads and shared through LDS;
+//   * the single 16x16 transpose between the two passes goes through LDS in rows of
+//     16 + pad complex so that both the 8-byte column writes and the 16-byte row reads are
+//     bank-conflict free (row pitch = 4 * odd dwords; frame pitch = a multiple of 256 B);
+//   * Z[k] / Z[256-k] pairs for the real-FFT split live in lanes j and 16-j of the same
+//     16-lane group and are exchanged with wave shuffles (no LDS round trip);
+//   * the power spectrum is parked in LDS (the sample span is dead by then) and the mel
+//     triangles are reduced by 16 filter groups x 16 frames; the host balances the groups
+//     so that all 256 threads carry about the same number of taps.
+//
+// Reference semantics: sound/sndenv.go:438-478, dft/dft.go:53-85, mel/mel.go:120-153.
+#include "kernels.h"
+
+namespace aud {
+namespace {
+
+template <typename TT>
+struct alignas(2 * sizeof(TT)) C2 {
+    TT x, y;
+};
+// two complex values moved as one 16-byte (f32) LDS access
+template <typename TT>
+struct alignas(16) C2x2 {
+    C2<TT> a, b;
+};
+
+template <typename TT>
+__device__ __forceinline__ C2<TT> cadd(C2<TT> a, C2<TT> b) { return {a.x + b.x, a.y + b.y}; }
+template <typename TT>
+__device__ __forceinline__ C2<TT> csub(C2<TT> a, C2<TT> b) { return {a.x - b.x, a.y - b.y}; }
+template <typename TT>
+__device__ __forceinline__ C2<TT> cmul(C2<TT> a, C2<TT> b) {
+    return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+// multiply by -i and by +i
+template <typename TT>
+__device__ __forceinline__ C2<TT> mul_mi(C2<TT> a) { return {a.y, -a.x}; }
+template <typename TT>
+__device__ __forceinline__ C2<TT> mul_pi(C2<TT> a) { return {-a.y, a.x}; }
+
+// forward 4-point DFT in place: u[k] = sum_n u[n] exp(-2 pi i n k / 4)
+template <typename TT>
+__device__ __forceinline__ void dft4(C2<TT>& u0, C2<TT>& u1, C2<TT>& u2, C2<TT>& u3) {
+    const C2<TT> s0 = cadd(u0, u2), d0 = csub(u0, u2);
+    const C2<TT> s1 = cadd(u1, u3), d1 = csub(u1, u3);
+    u0 = cadd(s0, s1);
+    u2 = csub(s0, s1);
+    u1 = cadd(d0, mul_mi(d1));
+    u3 = cadd(d0, mul_pi(d1));
+}
+
+// forward 16-point DFT of v[0..15] (natural order in, natural order out), as 4 x 4:
+// X[k1 + 4 k2] = sum_b W16^(b k1) W4^(b k2) sum_a v[4a + b] W4^(a k1)
+template <typename TT>
+__device__ __forceinline__ void dft16(C2<TT> (&v)[16]) {
+    const TT c1 = TT(0.92387953251128675613L);  // cos(pi/8)
+    const TT s1 = TT(0.38268343236508977173L);  // sin(pi/8)
+    const TT r2 = TT(0.70710678118654752440L);  // sqrt(1/2)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);
+    // now v[4*k1 + b] = t[b][k1]; twiddle by W16^(b*k1)
+    // b = 1: W^1, W^2, W^3
+    v[4 + 1] = cmul(v[4 + 1], C2<TT>{c1, -s1});
+    v[8 + 1] = C2<TT>{(v[8 + 1].x + v[8 + 1].y) * r2, (v[8 + 1].y - v[8 + 1].x) * r2};
+    v[12 + 1] = cmul(v[12 + 1], C2<TT>{s1, -c1});
+    // b = 2: W^2, W^4 = -i, W^6
+    v[4 + 2] = C2<TT>{(v[4 + 2].x + v[4 + 2].y) * r2, (v[4 + 2].y - v[4 + 2].x) * r2};
+    v[8 + 2] = mul_mi(v[8 + 2]);
+    v[12 + 2] = C2<TT>{(v[12 + 2].y - v[12 + 2].x) * r2, -(v[12 + 2].x + v[12 + 2].y) * r2};
+    // b = 3: W^3, W^6, W^9
+    v[4 + 3] = cmul(v[4 + 3], C2<TT>{s1, -c1});
+    v[8 + 3] = C2<TT>{(v[8 + 3].y - v[8 + 3].x) * r2, -(v[8 + 3].x + v[8 + 3].y) * r2};
+    v[12 + 3] = cmul(v[12 + 3], C2<TT>{-c1, s1});
+    // second layer: for each k1, a 4-point DFT over b; outputs X[k1 + 4 k2] land in v[4*k1 + k2]
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft4(v[4 * k1 + 0], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+    // v[4*k1 + k2] holds X[k1 + 4*k2]: transpose the 4x4 register tile into natural order
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a + 1; b < 4; ++b) {
+            const C2<TT> t = v[4 * a + b];
+            v[4 * a + b] = v[4 * b + a];
+            v[4 * b + a] = t;
+        }
+}
+
+__device__ __forceinline__ float dev_log(float v) { return logf(v); }
+__device__ __forceinline__ double dev_log(double v) { return log(v); }
+
+template <typename TT>
+__device__ __forceinline__ TT load_sample(const void* sig, int dtype, int64_t i) {
+    if (dtype == AUD_F32) return TT(static_cast<const float*>(sig)[i]);
+    if (dtype == AUD_F64) return TT(static_cast<const double*>(sig)[i]);
+    return TT(static_cast<const int16_t*>(sig)[i]) / TT(0x7FFF);  // sound.go:138
+}
+
+constexpr int kF = 16;    // frames per workgroup
+constexpr int kM = 256;   // complex FFT length
+constexpr int kN = 512;   // window length
+constexpr int kH = 257;   // power bins
+constexpr int kHp = 257;  // P row pitch in elements (odd: frames map to distinct banks)
+
+template <typename TT>
+struct Layout {
+    // transpose rows: 16 + pad complex; pitch in dwords must be 4 * odd
+    static constexpr int kRowC = (sizeof(TT) == 4) ? 18 : 17;
+    static constexpr int kFrameC = 16 * kRowC;
+};
+
+template <typename TT>
+__global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const R16Args e) {
+    unsigned char* smem = dyn_lds();
+    TT* sigbuf = reinterpret_cast<TT*>(smem);                       // [span] then reused as P
+    C2<TT>* xch = reinterpret_cast<C2<TT>*>(smem + e.xch_off);      // [16][16][kRowC]
+    const int tid = threadIdx.x;
+    const int f = tid >> 4;   // frame within the tile
+    const int j = tid & 15;   // lane within the frame's 16-lane group
+    const int T = a.T, S = a.S;
+
+    const int tiles = (T + kF - 1) / kF;
+    const int item = blockIdx.x / tiles;
+    const int t0 = (blockIdx.x - item * tiles) * kF;
+    const aud_item it = a.items[item];
+    const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_512^k
+
+    // ---- stage the tile's sample span: positions g0 .. g0 + span of the item's stream ------
+    const int64_t g0 = int64_t(it.start0) + int64_t(S) * (t0 - a.border);
+    const int span = (kF - 1) * S + kN;
+    const int64_t lim = it.sig_len;
+    if (a.sig_dtype == AUD_F32 && sizeof(TT) == 4 && ((it.sig_off + g0) & 3) == 0 &&
+        (reinterpret_cast<uintptr_t>(a.sig) & 15) == 0) {
+        const float* __restrict__ src = static_cast<const float*>(a.sig) + it.sig_off;
+        for (int c = tid; c * 4 < span; c += 256) {
+            const int64_t p = g0 + 4 * c;
+            float4 v;
+            if (p >= 0 && p + 3 < lim) {
+                v = *reinterpret_cast<const float4*>(src + p);
+            } else {
+                v.x = (p >= 0 && p < lim) ? src[p] : 0.f;
+                v.y = (p + 1 >= 0 && p + 1 < lim) ? src[p + 1] : 0.f;
+                v.z = (p + 2 >= 0 && p + 2 < lim) ? src[p + 2] : 0.f;
+                v.w = (p + 3 >= 0 && p + 3 < lim) ? src[p + 3] : 0.f;
+            }
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(sigbuf) + 4 * c) = v;
+        }
+    } else {
+        for (int c = tid; c < span; c += 256) {
+            const int64_t p = g0 + c;
+            sigbuf[c] = (p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p) : TT(0);
+        }
+    }
+
+    // per-lane constants, fetched while the span lands: W_256^(j*k1) = W_512^(2 j k1)
+    C2<TT> tw1[16];
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) tw1[k1] = tw[2 * j * k1];
+    __syncthreads();
+
+    // ---- pass 1: z[16 n1 + j] (z[m] = x[2m] + i x[2m+1]) -> 16-point DFT over n1 --------------
+    C2<TT> v[16];
+    {
+        // S is even on this path (checked by the host), so every frame starts on an 8-byte
+        // boundary and each point is one ds_read_b64
+        const C2<TT>* fr = reinterpret_cast<const C2<TT>*>(sigbuf) + (f * (S >> 1) + j);
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = fr[16 * n1];
+    }
+    dft16(v);
+    {
+        C2<TT>* col = xch + f * Layout<TT>::kFrameC + j;  // row k1, column n2 = j
+        col[0] = v[0];
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) col[k1 * Layout<TT>::kRowC] = cmul(v[k1], tw1[k1]);
+    }
+    __syncthreads();
+
+    // ---- pass 2: row k1 = j: 16-point DFT over n2 -> Z[j + 16 k2] in v[k2] --------------------
+    {
+        // row pitch and frame pitch are multiples of 16 B, so the row is read as 16-byte pieces
+        const C2<TT>* row = xch + f * Layout<TT>::kFrameC + j * Layout<TT>::kRowC;
+        if (sizeof(TT) == 4) {
+            const C2x2<TT>* row2 = reinterpret_cast<const C2x2<TT>*>(row);
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) {
+                const C2x2<TT> pr = row2[n2];
+                v[2 * n2] = pr.a;
+                v[2 * n2 + 1] = pr.b;
+            }
+        } else {
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) v[n2] = row[n2];
+        }
+    }
+    dft16(v);
+
+    // ---- real-FFT split + power ------------------------------------------------------------
+    // For k = j + 16 q (q = 0..7) the partner Z[256 - k] sits in lane (16 - j) & 15, register
+    // 15 - q (lane 0 pairs with itself: register (16 - q) & 15).  X[k] = (E + T)/2,
+    // X[256-k] = conj(E - T)/2 with E = Z[k] + conj Z[256-k], T = -i W_512^k (Z[k] - conj Z[256-k]).
+    TT* P = sigbuf + f * kHp;  // sample span is dead: every lane passed the barrier above
+    {
+        const int lane = tid & 63;
+        const int partner = (lane & 48) | ((16 - j) & 15);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const C2<TT> mine_up = (j == 0) ? v[(16 - q) & 15] : v[15 - q];  // what my partner needs
+            C2<TT> B;
+            B.x = __shfl(mine_up.x, partner, 64);
+            B.y = __shfl(mine_up.y, partner, 64);
+            const C2<TT> A = v[q];
+            const int k = j + 16 * q;
+            const C2<TT> w = tw[k];                     // W_512^k
+            const C2<TT> E = {A.x + B.x, A.y - B.y};    // A + conj(B)
+            const C2<TT> D = {A.x - B.x, A.y + B.y};    // A - conj(B)
+            const C2<TT> mD = {D.y, -D.x};              // -i D
+            const C2<TT> Tm = cmul(mD, w);
+            const TT xr = E.x + Tm.x, xi = E.y + Tm.y;  // 2 X[k]
+            const TT yr = E.x - Tm.x, yi = E.y - Tm.y;  // 2 conj X[256-k]
+            P[k] = TT(0.25) * (xr * xr + xi * xi);
+            if (k != 0) P[kM - k] = TT(0.25) * (yr * yr + yi * yi);
+            else P[kM] = TT(0.25) * (yr * yr + yi * yi);  // k = 0 also yields the Nyquist bin
+        }
+        // k = 128 (lane 0, register 8) pairs with itself: X[128] = conj(Z[128])
+        if (j == 0) P[128] = v[8].x * v[8].x + v[8].y * v[8].y;
+    }
+    __syncthreads();
+
+    // ---- optional PowerSegment / LogPowerSegment (dft.go:70-83) -------------------------------
+    if (a.power || a.log_power) {
+        const TT off = TT(a.dft_log_off), lmin = TT(a.dft_log_min);
+        for (int w = tid; w < kF * kH; w += 256) {
+            const int k = w >> 4, ff = w & 15;
+            const int sstep = t0 + ff;
+            if (sstep >= T) continue;
+            const int64_t start = int64_t(it.start0) + int64_t(S) * (sstep - a.border);
+            const bool live = start + kN <= lim;
+            const TT pw = sigbuf[ff * kHp + k];
+            const size_t o = (size_t(item) * kH + k) * T + sstep;
+            if (a.power) a.power[o] = live ? float(pw) : 0.f;
+            if (a.log_power) {
+                float lp = 0.f;
+                if (live && a.comp_log_pow) {
+                    const TT vv = pw + off;
+                    lp = float(vv == TT(0) ? lmin : dev_log(vv));
+                }
+                a.log_power[o] = lp;
+            }
+        }
+    }
+
+    // ---- mel triangles + log (mel.go:120-153): 16 balanced filter groups x 16 frames ----------
+    {
+        const int ff = tid & 15, grp = tid >> 4;
+        const int sstep = t0 + ff;
+        if (sstep < T) {
+            const int64_t start = int64_t(it.start0) + int64_t(S) * (sstep - a.border);
+            const bool live = start + kN <= lim;
+            const TT* __restrict__ filt = static_cast<const TT*>(a.filt);
+            const TT* prow = sigbuf + ff * kHp;
+            const int cols = a.nf + 2;
+            const TT loff = TT(a.mel_log_off), lmin = TT(a.mel_log_min);
+            for (int idx = e.grp_off[grp]; idx < e.grp_off[grp + 1]; ++idx) {
+                const int flt = e.grp_flt[idx];
+                float res = 0.f;
+                if (live) {
+                    const int lo = a.bin_pts[flt], hi = a.bin_pts[flt + 2];
+                    const TT* wrow = filt + size_t(flt) * cols;
+                    TT sum = TT(0);
+                    for (int bin = lo; bin <= hi; ++bin) sum += wrow[bin - lo] * prow[bin];
+                    sum += loff;
+                    TT val = (sum == TT(0)) ? lmin : dev_log(sum);
+                    if (a.renorm) {
+                        val -= TT(a.renorm_min);
+                        if (val < TT(0)) val = TT(0);
+                        val *= TT(a.renorm_scale);
+                        if (val > TT(1)) val = TT(1);
+                    }
+                    res = float(val);
+                }
+                a.mel[(size_t(item) * a.nf + flt) * T + sstep] = res;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool melspec_r16_supported(int N, int S, int compute_dtype, size_t* lds_bytes, int* xch_off) {
+    if (N != kN || S < 1 || (S & 1)) return false;  // odd steps go to the generic kernel
+    const size_t tsz = compute_dtype == AUD_F64 ? 8 : 4;
+    const size_t span = size_t(kF - 1) * S + kN;
+    size_t first = span > size_t(kF) * kHp ? span : size_t(kF) * kHp;  // sample span, later P
+    first = (first * tsz + 15) & ~size_t(15);
+    const size_t rowc = compute_dtype == AUD_F64 ? 17 : 18;
+    const size_t xch = size_t(kF) * 16 * rowc * 2 * tsz;
+    const size_t total = first + xch;
+    if (total > 160 * 1024) return false;
+    if (lds_bytes) *lds_bytes = total;
+    if (xch_off) *xch_off = int(first);
+    return true;
+}
+
+hipError_t melspec_r16_prepare() {
+    // more than 64 KiB of dynamic LDS has to be requested explicitly
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_melspec_r16<double>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_melspec_r16<float>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t launch_melspec_r16(const MelspecArgs& a, const R16Args& e, int compute_dtype, hipStream_t st) {
+    const int tiles = (a.T + kF - 1) / kF;
+    const dim3 grid(unsigned(a.n_items) * unsigned(tiles));
+    if (compute_dtype == AUD_F64)
+        hipLaunchKernelGGL(k_melspec_r16<double>, grid, dim3(256), e.lds_bytes, st, a, e);
+    else
+        hipLaunchKernelGGL(k_melspec_r16<float>, grid, dim3(256), e.lds_bytes, st, a, e);
+    return hipGetLastError();
+}
+
+}  // namespace aud

@@ -31,11 +31,20 @@ struct dim3 {
 };
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
+struct alignas(16) float4 {
+    float x, y, z, w;
+};
+struct alignas(8) float2 {
+    float x, y;
+};
+
 typedef int hipError_t;
 typedef struct emul_stream* hipStream_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 enum { hipStreamNonBlocking = 1 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return 0; }
 
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipSetDevice(int d);

@@ -1,7 +1,7 @@
 """prints error statistics of the GPU mel output vs the oracle for cfg2 (diagnostic)"""
 import sys, os
 import numpy as np, torch
-sys.path.insert(0, "tests")
+sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")]
 import workloads as W
 from auditory_amd import capi, runtime, synth
 from auditory_amd.batch import BatchProcessor
