@@ -62,15 +62,30 @@ class BatchProcessor:
         return mel, gabor
 
 
-def allgather_features(local, world_size, group=None):
-    """The one collective of the path: reassemble [B/G, ...] slabs into [B, ...] on every rank
-    (torch.distributed all_gather_into_tensor == ncclAllGather; RCCL on ROCm, gloo on CPU)."""
+def allgather_features(local, world_size, group=None, n_total=None):
+    """The one collective of the path: reassemble the per-rank [B_r, ...] slabs into [B, ...] on
+    every rank (torch.distributed all_gather_into_tensor == ncclAllGather; RCCL on ROCm, gloo on
+    CPU).  Shards follow shard_range(); when B does not divide evenly the short shards are padded
+    to the longest one for the collective and the padding is dropped afterwards."""
     import torch.distributed as dist
-    out = torch.empty((local.shape[0] * world_size,) + tuple(local.shape[1:]), dtype=local.dtype,
+    if n_total is None:
+        n_total = local.shape[0] * world_size
+    counts = [shard_range(n_total, r, world_size) for r in range(world_size)]
+    longest = max(hi - lo for lo, hi in counts)
+    rank = dist.get_rank(group)
+    assert local.shape[0] == counts[rank][1] - counts[rank][0], "local slab does not match shard_range"
+    send = local.contiguous()
+    if send.shape[0] < longest:
+        pad = torch.zeros((longest - send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype,
+                          device=send.device)
+        send = torch.cat([send, pad], 0)
+    out = torch.empty((longest * world_size,) + tuple(local.shape[1:]), dtype=local.dtype,
                       device=local.device)
     if dist.get_backend(group) == "gloo":
-        parts = list(out.chunk(world_size, 0))
-        dist.all_gather(parts, local.contiguous(), group=group)
+        dist.all_gather(list(out.chunk(world_size, 0)), send, group=group)
     else:
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-    return out
+        dist.all_gather_into_tensor(out, send, group=group)
+    if longest * world_size == n_total:
+        return out
+    parts = [out[r * longest:r * longest + (hi - lo)] for r, (lo, hi) in enumerate(counts)]
+    return torch.cat(parts, 0)

@@ -151,7 +151,7 @@ def main():
 
     # sanity: the timed output is the real thing (spot-check utterance 0 against the oracle)
     o = orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig64[0])
-    ok, msg = W.close_enough(mel[0].cpu().numpy(), o["mel_seg"], 1e-5 if cdt == capi.AUD_F32 else 3e-7)
+    ok, msg = W.feature_close(mel[0].cpu().numpy(), o["mel_seg"], cdt, lin_axis=0)
     if not ok:
         print("WARNING: spot check vs oracle: " + msg, file=sys.stderr)
 

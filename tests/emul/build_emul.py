@@ -15,6 +15,8 @@ FLAGS = {
     "asan": ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
              "-fno-sanitize-recover=undefined"],
     "tsan": ["-O1", "-g", "-fsanitize=thread"],
+    # contracted multiply-adds, closer to what hipcc emits for the device (fp-contract=fast)
+    "fma": ["-O2", "-mfma", "-ffp-contract=fast"],
 }
 
 

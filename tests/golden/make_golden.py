@@ -1,0 +1,65 @@
+"""Generates tests/golden/*.npz from the CPU oracle (oracle/auditory_oracle.c).
+
+The reference (Go) cannot run in this pipeline and ships no vectors of its own, so these
+fixtures are REGRESSION vectors of the oracle, not reference outputs: they freeze today's oracle
+(itself pinned by the KATs and the numpy cross-check of tests/test_oracle.py) so that later edits
+to oracle/ or to the kernels cannot drift silently.  Inputs are regenerated from the seeds;
+expected outputs are stored.  Run:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+
+import workloads as W  # noqa: E402
+from auditory_amd import synth  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+# name -> (config, segment_ms override, seconds of audio, rows, segments, seed id, gabor?)
+FIXTURES = {
+    "sndenv_16k_n400_nf32": ("sndenv_16k_n400_nf32", None, 0.45, 2, [0, 1, 3], 21, "pool8x2"),
+    "cfg2_16k_n400_nf40": ("cfg2_16k_n400_nf40", None, 1.0, 2, [0], 22, "pool11x32"),
+    "cfg2_16k_n512_nf40": ("cfg2_16k_n512_nf40", None, 1.0, 2, [0], 23, "pool11x32"),
+    "cfg1_44k_n1103_nf32": ("cfg1_44k_n1103_nf32", None, 0.3, 1, [0, 1], 24, "pool8x2"),
+    "cfg5_44k_n2048_nf128": ("cfg5_44k_n2048_nf128", 300.0, 0.4, 2, [0], 25, None),
+}
+GABOR = {"pool8x2": (8, 2), "pool11x32": (11, 32)}
+
+
+def inputs(name):
+    cfg, seg_ms, dur, rows, segs, seed, gab = FIXTURES[name]
+    oc = W.OracleCfg(orc, cfg, seg_ms)
+    L = int(dur * oc.sr)
+    sig, pcm = synth.batch(seed, rows, L, oc.sr)
+    return oc, sig, pcm, [(r, s) for r in range(rows) for s in segs], gab
+
+
+def compute(name):
+    oc, sig, pcm, items, gab = inputs(name)
+    mel, lp = [], []
+    for r, s in items:
+        o = orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig[r], segment=s)
+        mel.append(o["mel_seg"])
+        lp.append(o["log_power_seg"])
+    out = dict(mel=np.stack(mel), log_power=np.stack(lp).astype(np.float32),
+               bin_pts=oc.bins, pcm_crc=np.array([int(pcm.astype(np.int64).sum())]))
+    if gab:
+        py, px = GABOR[gab]
+        k = orc.gabor_to_tensor(W.DEFAULT_GABOR_SPECS, 9, 9)
+        g = np.zeros((len(items), py, px, 2, 8), np.float32)
+        for i in range(len(items)):
+            assert orc.gabor_convolve(out["mel"][i], k, 3, 3, 2.0, g[i]) == 0
+        out["gabor"] = g
+        out["gabor_k"] = k
+    return out
+
+
+if __name__ == "__main__":
+    for name in FIXTURES:
+        d = compute(name)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+        print(name, {k: v.shape for k, v in d.items()})

@@ -1,0 +1,54 @@
+"""Golden-fixture checks shared by the CPU (oracle, emulator) and GPU test files."""
+import os
+import sys
+
+import numpy as np
+
+import workloads as W
+from auditory_amd import capi, runtime
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as G  # noqa: E402
+
+NAMES = list(G.FIXTURES)
+
+
+def load(name):
+    return np.load(os.path.join(HERE, "golden", name + ".npz"))
+
+
+def check_oracle_reproduces(name):
+    """oracle today == oracle when the fixture was written (bit for bit)"""
+    gold, now = load(name), G.compute(name)
+    for k in gold.files:
+        assert np.array_equal(gold[k], now[k], equal_nan=True), (name, k)
+
+
+def check_library_against_golden(name, compute_dtype):
+    """the shipped C ABI (GPU, or the emulator build in CPU tests) against the stored outputs"""
+    gold = load(name)
+    oc, sig, pcm, items, gab = G.inputs(name)
+    assert int(pcm.astype(np.int64).sum()) == int(gold["pcm_crc"][0]), "seeded input drifted"
+    L = sig.shape[1]
+    its = runtime.make_items([r * L for r, s in items], [L] * len(items),
+                             [s * oc.sp.stride_samples for r, s in items])
+    gspec = dict(size=(9, 9), stride=(3, 3), gain=2.0, specs=W.DEFAULT_GABOR_SPECS) if gab else None
+    plan = W.product_plan(oc, compute_dtype, gspec)
+    try:
+        mel, _, lp = plan.melspec_host(sig.ravel(), its, False, True)
+        ok, msg = W.feature_close(mel, gold["mel"], compute_dtype, lin_axis=1)
+        assert ok, (name, "mel", msg)
+        if compute_dtype == capi.AUD_F64:
+            ok, msg = W.close_enough(lp, gold["log_power"], 3e-7)
+        else:  # f32 FFT: bins are accurate relative to the frame's peak bin (see spectrum_close)
+            ok, msg = W.spectrum_close(lp, gold["log_power"], 4e-6, log_offset=1.0)
+        assert ok, (name, "log_power", msg)
+        if gab:
+            py, px = G.GABOR[gab]
+            out = np.zeros((len(items), py, px, 2, 8), np.float32)
+            plan.gabor_host(mel, out)            # gabor of the library's own mel, as SndEnv does
+            ok, msg = W.feature_close(out, gold["gabor"], compute_dtype)
+            assert ok, (name, "gabor", msg)
+    finally:
+        plan.close()

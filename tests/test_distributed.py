@@ -1,0 +1,51 @@
+"""N>1 path on the CPU: world_size-2 (and 3, uneven shards) gloo jobs; see dist_worker.py."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from auditory_amd.batch import shard_range
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 256, 4096, 4099):
+        for w in (1, 2, 3, 4, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 6), (3, 7)])
+def test_sharded_melspec_allgather_gloo(world, n_total):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(n_total)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    for rc, o, e in outs:
+        assert rc == 0 and "RANK-OK" in o, e[-3000:]

