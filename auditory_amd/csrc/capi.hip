@@ -177,8 +177,6 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
     if (nf < 1 || !d->bin_pts || !d->mel_filters) return fail(c, AUD_EINVAL, "mel table missing");
     if (d->compute_dtype != AUD_F32 && d->compute_dtype != AUD_F64)
         return fail(c, AUD_EINVAL, "compute_dtype must be AUD_F32 or AUD_F64");
-    if (d->dft.prev_smooth != 0.0)
-        return fail(c, AUD_EINVAL, "dft.PrevSmooth != 0 (sequential smoothing) is not supported yet");
     const int H = N / 2 + 1;
     // Envelope of mel.FilterDft (mel.go:128-131): every tap must stay inside Power [H] and
     // inside the [nf, nf+2] table (flat offset); outside it the Go code panics.
@@ -296,6 +294,9 @@ int aud_melspec_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
     if (sig_dtype != AUD_F32 && sig_dtype != AUD_F64 && sig_dtype != AUD_I16)
         return fail(c, AUD_EINVAL, "bad sig_dtype");
     if (log_power && !p->d.dft.comp_log_pow) return fail(c, AUD_EINVAL, "log_power needs CompLogPow");
+    const bool smooth = p->d.dft.prev_smooth != 0.0;
+    if (smooth && !power)
+        return fail(c, AUD_EINVAL, "dft.PrevSmooth != 0 needs the power buffer (the scan runs on it)");
     if (n_items == 0) return AUD_OK;
     AUD_HIP(c, hipSetDevice(c->device));
     aud::MelspecArgs a;
@@ -311,6 +312,27 @@ int aud_melspec_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
         AUD_HIP(c, aud::launch_melspec_r16(a, p->r16, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
     else
         AUD_HIP(c, aud::launch_melspec_generic(a, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
+    if (smooth) {
+        // dft.go:67-69: p_s = Prev*p_{s-1} + Cur*raw_s along the steps, then log-power and mel from it
+        aud::SmoothArgs sa;
+        std::memset(&sa, 0, sizeof(sa));
+        sa.items = items;
+        sa.n_items = n_items;
+        sa.H = p->H;
+        sa.T = p->d.segment_steps;
+        sa.N = p->d.win_samples;
+        sa.S = p->d.step_samples;
+        sa.border = p->d.border_steps;
+        sa.power = power;
+        sa.log_power = log_power;
+        sa.prev_smooth = p->d.dft.prev_smooth;
+        sa.cur_smooth = p->d.dft.cur_smooth;
+        sa.log_off = p->d.dft.log_offset;
+        sa.log_min = p->d.dft.log_min;
+        sa.comp_log_pow = p->d.dft.comp_log_pow;
+        AUD_HIP(c, aud::launch_power_smooth(sa, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
+        AUD_HIP(c, aud::launch_mel_from_power(a, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
+    }
     return AUD_OK;
 }
 
@@ -395,7 +417,8 @@ int aud_melspec_batch_host(aud_plan* p, const double* sig, int64_t sig_total, co
     const int nf = p->d.mel.n_filters, T = p->d.segment_steps, H = p->H;
     const size_t n_mel = size_t(n_items) * nf * T, n_pow = size_t(n_items) * H * T;
     const size_t sig_bytes = size_t(sig_total) * 8, item_bytes = size_t(n_items) * sizeof(aud_item);
-    const bool want_p = power != nullptr, want_lp = log_power != nullptr;
+    const bool smooth = p->d.dft.prev_smooth != 0.0;  // the scan needs a device power buffer
+    const bool want_p = power != nullptr || smooth, want_lp = log_power != nullptr;
     const size_t out_floats = n_mel + (want_p ? n_pow : 0) + (want_lp ? n_pow : 0);
     int rc;
     if ((rc = ensure_ws(c, 0, sig_bytes + 16)) != AUD_OK) return rc;
@@ -415,7 +438,8 @@ int aud_melspec_batch_host(aud_plan* p, const double* sig, int64_t sig_total, co
     for (size_t i = 0; i < n_mel; ++i) mel[i] = double(h[i]);
     size_t o = n_mel;
     if (want_p) {
-        for (size_t i = 0; i < n_pow; ++i) power[i] = double(h[o + i]);
+        if (power)
+            for (size_t i = 0; i < n_pow; ++i) power[i] = double(h[o + i]);
         o += n_pow;
     }
     if (want_lp)

@@ -64,6 +64,18 @@ struct R16Args {
     const int* grp_flt;    // [nf] device: filter ids, grouped so that groups carry equal tap counts
 };
 
+// PrevSmooth != 0 mode: scan along the steps of a stored power tensor
+struct SmoothArgs {
+    const aud_item* items;
+    int n_items, H, T, N, S, border;
+    float* power;      // [n_items, H, T] in/out
+    float* log_power;  // [n_items, H, T] or null
+    double prev_smooth, cur_smooth, log_off, log_min;
+    int comp_log_pow;
+};
+hipError_t launch_power_smooth(const SmoothArgs& a, int compute_dtype, hipStream_t st);
+hipError_t launch_mel_from_power(const MelspecArgs& a, int compute_dtype, hipStream_t st);
+
 // generic any-N kernel (Stockham in LDS, radix 2/4 + per-output generic radix)
 size_t melspec_generic_lds_bytes(int M, int F, int compute_dtype);
 int melspec_generic_pick_F(int M, int compute_dtype);

@@ -1,0 +1,107 @@
+// dft.Params.PrevSmooth != 0: the reference blends each step's power with the previous
+// step's (dft/dft.go:67-69), which makes the frames of a segment sequentially dependent:
+//     p_0 = raw_0;   p_s = PrevSmooth * p_{s-1} + CurSmooth * raw_s   (s > 0)
+// and everything downstream (log-power, mel) is computed from the smoothed p_s.  The frame->FFT
+// kernels are frame-parallel, so this mode runs as three launches: raw power [item, H, T] from
+// the FFT kernel, the scan below along T (one thread per (item, bin)), then mel from the smoothed
+// power.  The default PrevSmooth = 0 never comes here.
+#include "kernels.h"
+
+namespace aud {
+namespace {
+
+__device__ __forceinline__ float dev_log(float v) { return logf(v); }
+__device__ __forceinline__ double dev_log(double v) { return log(v); }
+
+// number of leading live frames of an item: frame s is live iff start0 + S (s - border) + N <= sig_len
+__device__ __forceinline__ int live_frames(const aud_item& it, int N, int S, int T, int border) {
+    int n = 0;
+    for (int s = 0; s < T; ++s) {
+        const int64_t start = int64_t(it.start0) + int64_t(S) * (s - border);
+        if (start + N <= int64_t(it.sig_len)) ++n;
+        else break;
+    }
+    return n;
+}
+
+template <typename TT>
+__global__ __launch_bounds__(256) void k_power_smooth(const SmoothArgs a) {
+    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= int64_t(a.n_items) * a.H) return;
+    const int item = int(gid / a.H);
+    const int nlive = live_frames(a.items[item], a.N, a.S, a.T, a.border);
+    float* prow = a.power + size_t(gid) * a.T;
+    float* lrow = a.log_power ? a.log_power + size_t(gid) * a.T : nullptr;
+    const TT prev = TT(a.prev_smooth), cur = TT(a.cur_smooth);
+    const TT off = TT(a.log_off), lmin = TT(a.log_min);
+    TT carry = TT(0);
+    for (int s = 0; s < nlive; ++s) {
+        TT p = TT(prow[s]);
+        if (s > 0) p = prev * carry + cur * p;  // dft.go:67-69
+        carry = p;
+        prow[s] = float(p);
+        if (lrow) {
+            const TT v = p + off;
+            lrow[s] = a.comp_log_pow ? float(v == TT(0) ? lmin : dev_log(v)) : 0.f;
+        }
+    }
+}
+
+// mel.Params.FilterDft (mel/mel.go:120-153) applied to a stored power tensor [item, H, T]
+template <typename TT>
+__global__ __launch_bounds__(256) void k_mel_from_power(const MelspecArgs a) {
+    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int per_item = a.nf * a.T;
+    if (gid >= int64_t(a.n_items) * per_item) return;
+    const int item = int(gid / per_item);
+    const int r = int(gid - int64_t(item) * per_item);
+    const int flt = r / a.T, s = r - flt * a.T;  // consecutive threads = consecutive steps: coalesced
+    const aud_item it = a.items[item];
+    const int64_t start = int64_t(it.start0) + int64_t(a.S) * (s - a.border);
+    const bool live = start + a.N <= int64_t(it.sig_len);
+    float res = 0.f;
+    if (live) {
+        const TT* __restrict__ filt = static_cast<const TT*>(a.filt);
+        const int lo = a.bin_pts[flt], hi = a.bin_pts[flt + 2];
+        const TT* wrow = filt + size_t(flt) * (a.nf + 2);
+        const float* pcol = a.power + size_t(item) * a.H * a.T + s;
+        TT sum = TT(0);
+        for (int bin = lo; bin <= hi; ++bin) sum += wrow[bin - lo] * TT(pcol[size_t(bin) * a.T]);
+        sum += TT(a.mel_log_off);
+        TT val = (sum == TT(0)) ? TT(a.mel_log_min) : dev_log(sum);
+        if (a.renorm) {
+            val -= TT(a.renorm_min);
+            if (val < TT(0)) val = TT(0);
+            val *= TT(a.renorm_scale);
+            if (val > TT(1)) val = TT(1);
+        }
+        res = float(val);
+    }
+    a.mel[gid] = res;
+}
+
+}  // namespace
+
+hipError_t launch_power_smooth(const SmoothArgs& a, int compute_dtype, hipStream_t st) {
+    const int64_t total = int64_t(a.n_items) * a.H;
+    if (total == 0) return hipSuccess;
+    const dim3 grid(unsigned((total + 255) / 256));
+    if (compute_dtype == AUD_F64)
+        hipLaunchKernelGGL(k_power_smooth<double>, grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(k_power_smooth<float>, grid, dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mel_from_power(const MelspecArgs& a, int compute_dtype, hipStream_t st) {
+    const int64_t total = int64_t(a.n_items) * a.nf * a.T;
+    if (total == 0) return hipSuccess;
+    const dim3 grid(unsigned((total + 255) / 256));
+    if (compute_dtype == AUD_F64)
+        hipLaunchKernelGGL(k_mel_from_power<double>, grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(k_mel_from_power<float>, grid, dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace aud

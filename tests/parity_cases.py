@@ -221,3 +221,34 @@ def case_recreated_tone_fixtures_f64(orc):
     for r, pk in enumerate((20, 50, 125, 175)):
         hot = int(np.argmax(mel[2 * r, :, 5]))
         assert oc.bins[hot] <= pk <= oc.bins[hot + 2]
+
+
+def case_prev_smooth(orc, name, cdt):
+    """dft.PrevSmooth != 0 (dft.go:67-69): the scan along the steps, log-power and mel from it"""
+    oc = W.OracleCfg(orc, name)
+    oc.d.prev_smooth, oc.d.cur_smooth = 0.35, 0.65
+    L = int(0.5 * oc.sr)
+    sig, _ = synth.batch(13, 2, L, oc.sr)
+    segs = [(r, s) for r in range(2) for s in (0, 1, 3)]
+    ref_mel, ref_pw, ref_lp = oracle_items(orc, oc, sig, segs)
+    plan = W.product_plan(oc, cdt, dft_override=(0.35, 0.65))
+    try:
+        mel, pw, lp = plan.melspec_host(sig.ravel(), make_items(oc, L, segs), True, True)
+        mel2, _, _ = plan.melspec_host(sig.ravel(), make_items(oc, L, segs))      # no power requested
+    finally:
+        plan.close()
+    assert np.array_equal(mel, mel2)
+    ok, msg = W.feature_close(mel, ref_mel, cdt, lin_axis=1)
+    assert ok, "mel " + msg
+    tol = 4e-6 if cdt == capi.AUD_F32 else 3e-7
+    ok, msg = W.spectrum_close(pw, ref_pw, tol)
+    assert ok, "power " + msg
+    if cdt == capi.AUD_F64:
+        ok, msg = W.close_enough(lp, ref_lp, 3e-7)
+    else:
+        ok, msg = W.spectrum_close(lp, ref_lp, tol, log_offset=1.0)
+    assert ok, "log_power " + msg
+    # smoothing really happened: differs from the unsmoothed run
+    oc0 = W.OracleCfg(orc, name)
+    raw, _, _ = oracle_items(orc, oc0, sig, segs[:1])
+    assert np.abs(raw[0] - ref_mel[0]).max() > 1e-3

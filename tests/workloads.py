@@ -41,7 +41,7 @@ class OracleCfg:
         return self.S * (self.T - 1 - self.border) + self.N
 
 
-def product_plan(ocfg, compute_dtype=0, gabor=None, device=0):  # noqa: C901
+def product_plan(ocfg, compute_dtype=0, gabor=None, device=0, dft_override=None):  # noqa: C901
     """runtime.Plan built from the PRODUCT's own host setup for the same configuration"""
     from auditory_amd import agabor, capi, mel, runtime
     sr, win, step, seg, stride, border, nf, lo, hi = CONFIGS[ocfg.name]
@@ -51,6 +51,8 @@ def product_plan(ocfg, compute_dtype=0, gabor=None, device=0):  # noqa: C901
     filt = mp.InitFilters(ocfg.N, sr)
     dftp = capi.DftParams()
     capi.load().aud_dft_defaults(dftp)
+    if dft_override is not None:
+        dftp.prev_smooth, dftp.cur_smooth = dft_override
     gset = gk = None
     if gabor is not None:
         fs = agabor.FilterSet()
