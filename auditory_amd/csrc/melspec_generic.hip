@@ -5,8 +5,8 @@
 // between two LDS buffers, turned into a power spectrum, and reduced through the mel
 // triangle table.  Even N uses the packed-real trick (an N/2-point complex FFT plus one
 // split pass); odd N (e.g. the prime 1103 that 25 ms @ 44.1 kHz produces) runs a full
-// N-point complex FFT.  Radix 2 and 4 have dedicated butterflies; any other prime factor
-// p goes through an O(p) per-output pass, so every N is supported.  This is the
+// N-point complex FFT.  Radix 2, 3, 4 and 5 have dedicated butterflies; any other prime
+// factor p goes through an O(p) per-output pass, so every N is supported.  This is the
 // universal path; the common power-of-two sizes have faster specialised kernels.
 //
 // Reference semantics implemented here: sound/sndenv.go:438-478 (window extraction,
@@ -101,6 +101,46 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
                 y[s] = cmul<TT>({e1.x + o1.y, e1.y - o1.x}, tw[tq]);  // a0 - i a1 - a2 + i a3
                 y[2 * s] = cmul<TT>({e0.x - o0.x, e0.y - o0.y}, tw[2 * tq]);
                 y[3 * s] = cmul<TT>({e1.x - o1.y, e1.y + o1.x}, tw[3 * tq]);
+            }
+        } else if (p == 3) {
+            const TT hs = TT(0.86602540378443864676L);  // sin(2 pi / 3)
+            for (int w = tid; w < F * nb; w += blockDim.x) {
+                const int f = w / nb, b = w - f * nb;
+                const int q = b / s, k = b - q * s;
+                const C2<TT>* x = src + size_t(f) * M + k + s * q;
+                C2<TT>* y = dst + size_t(f) * M + k + s * 3 * q;
+                const int sm = s * m;
+                const C2<TT> a0 = x[0], a1 = x[sm], a2 = x[2 * sm];
+                const C2<TT> t = {a1.x + a2.x, a1.y + a2.y};
+                const C2<TT> mm = {a0.x - TT(0.5) * t.x, a0.y - TT(0.5) * t.y};
+                const C2<TT> n = {hs * (a1.x - a2.x), hs * (a1.y - a2.y)};
+                const int tq = q * s * a.ratio;
+                y[0] = {a0.x + t.x, a0.y + t.y};
+                y[s] = cmul<TT>({mm.x + n.y, mm.y - n.x}, tw[tq]);          // m - i n
+                y[2 * s] = cmul<TT>({mm.x - n.y, mm.y + n.x}, tw[2 * tq]);  // m + i n
+            }
+        } else if (p == 5) {
+            const TT c1 = TT(0.30901699437494742410L), c2 = TT(-0.80901699437494742410L);
+            const TT s1 = TT(0.95105651629515357212L), s2 = TT(0.58778525229247312917L);
+            for (int w = tid; w < F * nb; w += blockDim.x) {
+                const int f = w / nb, b = w - f * nb;
+                const int q = b / s, k = b - q * s;
+                const C2<TT>* x = src + size_t(f) * M + k + s * q;
+                C2<TT>* y = dst + size_t(f) * M + k + s * 5 * q;
+                const int sm = s * m;
+                const C2<TT> a0 = x[0], a1 = x[sm], a2 = x[2 * sm], a3 = x[3 * sm], a4 = x[4 * sm];
+                const C2<TT> t1 = {a1.x + a4.x, a1.y + a4.y}, t2 = {a2.x + a3.x, a2.y + a3.y};
+                const C2<TT> t3 = {a1.x - a4.x, a1.y - a4.y}, t4 = {a2.x - a3.x, a2.y - a3.y};
+                const C2<TT> m1 = {a0.x + c1 * t1.x + c2 * t2.x, a0.y + c1 * t1.y + c2 * t2.y};
+                const C2<TT> m2 = {a0.x + c2 * t1.x + c1 * t2.x, a0.y + c2 * t1.y + c1 * t2.y};
+                const C2<TT> n1 = {s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y};
+                const C2<TT> n2 = {s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y};
+                const int tq = q * s * a.ratio;
+                y[0] = {a0.x + t1.x + t2.x, a0.y + t1.y + t2.y};
+                y[s] = cmul<TT>({m1.x + n1.y, m1.y - n1.x}, tw[tq]);          // m1 - i n1
+                y[2 * s] = cmul<TT>({m2.x + n2.y, m2.y - n2.x}, tw[2 * tq]);  // m2 - i n2
+                y[3 * s] = cmul<TT>({m2.x - n2.y, m2.y + n2.x}, tw[3 * tq]);  // m2 + i n2
+                y[4 * s] = cmul<TT>({m1.x - n1.y, m1.y + n1.x}, tw[4 * tq]);  // m1 + i n1
             }
         } else {
             // one thread per output j of each radix-p butterfly
