@@ -35,7 +35,8 @@ struct aud_plan {
     int F_generic = 0;
     bool use_r16 = false;
     aud::R16Args r16{};
-    int* d_grp = nullptr;  // [17 + nf]: group offsets then filter ids
+    int* d_grp = nullptr;  // [17 + nf + 3 nf]: group offsets, filter ids, per-filter chunk info
+    void* d_w4 = nullptr;  // chunked triangle weights
     void* d_tw = nullptr;
     void* d_filt = nullptr;
     int32_t* d_bin_pts = nullptr;
@@ -229,12 +230,21 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
                          size_t(d->n_gabor) * d->gabor.size_x * d->gabor.size_y, d->compute_dtype);
     // kernel family: the in-register 16 x 16 kernel for 512-sample windows, else the generic one
     size_t r16_lds = 0;
-    int r16_xch = 0;
-    if (rc == AUD_OK && aud::melspec_r16_supported(N, d->step_samples, d->compute_dtype, &r16_lds, &r16_xch)) {
+    int r16_xch = 0, r16_w4 = 0, r16_chunks = 0;
+    for (int f = 0; f < nf; ++f) {
+        const int lo = d->bin_pts[f], hi = d->bin_pts[f + 2];
+        if (hi >= lo) r16_chunks += (hi >> 2) - (lo >> 2) + 1;
+    }
+    if (r16_chunks == 0) r16_chunks = 1;
+    if (rc == AUD_OK && aud::melspec_r16_supported(N, d->step_samples, d->compute_dtype, r16_chunks, &r16_lds,
+                                                  &r16_xch, &r16_w4)) {
         // balance the mel filters over 16 thread groups by tap count (longest first, LPT)
         std::vector<int> order(nf), load(16, 0), owner(nf);
         for (int f = 0; f < nf; ++f) order[f] = f;
-        auto taps = [&](int f) { return std::max(0, d->bin_pts[f + 2] - d->bin_pts[f] + 1) + 12; };
+        auto taps = [&](int f) {  // cost model: 4-bin chunks + a fixed per-filter epilogue (log, store)
+            const int lo = d->bin_pts[f], hi = d->bin_pts[f + 2];
+            return (hi >= lo ? (hi >> 2) - (lo >> 2) + 1 : 0) * 6 + 30;
+        };
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return taps(x) > taps(y); });
         for (int f : order) {
             int g = 0;
@@ -243,7 +253,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
             owner[f] = g;
             load[g] += taps(f);
         }
-        std::vector<int> tab(17 + nf, 0);
+        std::vector<int> tab(17 + nf + 3 * nf, 0);
         int pos = 0;
         for (int g = 0; g < 16; ++g) {
             tab[g] = pos;
@@ -251,7 +261,24 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
                 if (owner[f] == g) tab[17 + pos++] = f;
         }
         tab[16] = pos;
+        // triangles as 4-bin chunks aligned to bins 0, 4, 8, ...; table cells are addressed by the
+        // reference's flat offset f*(nf+2) + (bin - lo), weights outside [lo, hi] are zero
+        std::vector<double> w4;
+        for (int f = 0; f < nf; ++f) {
+            const int lo = d->bin_pts[f], hi = d->bin_pts[f + 2];
+            int* ci = &tab[17 + nf + 3 * f];
+            ci[0] = lo >> 2;
+            ci[1] = hi >= lo ? (hi >> 2) - (lo >> 2) + 1 : 0;
+            ci[2] = int(w4.size() / 4);
+            for (int cidx = 0; cidx < ci[1]; ++cidx)
+                for (int el = 0; el < 4; ++el) {
+                    const int bin = 4 * (ci[0] + cidx) + el;
+                    w4.push_back(bin >= lo && bin <= hi ? d->mel_filters[int64_t(f) * (nf + 2) + (bin - lo)] : 0.0);
+                }
+        }
+        if (w4.empty()) w4.assign(4, 0.0);
         rc = upload(c, reinterpret_cast<void**>(&p->d_grp), tab.data(), tab.size() * sizeof(int));
+        if (rc == AUD_OK) rc = upload_real(c, &p->d_w4, w4.data(), w4.size(), d->compute_dtype);
         if (rc == AUD_OK && aud::melspec_r16_prepare() != hipSuccess)
             rc = fail(c, AUD_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
         if (rc == AUD_OK) {
@@ -261,6 +288,10 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
             p->r16.lds_bytes = unsigned(r16_lds);
             p->r16.grp_off = p->d_grp;
             p->r16.grp_flt = p->d_grp + 17;
+            p->r16.chunk = p->d_grp + 17 + nf;
+            p->r16.w4 = p->d_w4;
+            p->r16.n_chunks = r16_chunks;
+            p->r16.w4_off = r16_w4;
         }
     }
     if (rc != AUD_OK) {
@@ -279,6 +310,7 @@ int aud_plan_destroy(aud_plan* p) {
     if (p->d_bin_pts) (void)hipFree(p->d_bin_pts);
     if (p->d_gabor) (void)hipFree(p->d_gabor);
     if (p->d_grp) (void)hipFree(p->d_grp);
+    if (p->d_w4) (void)hipFree(p->d_w4);
     delete p;
     return AUD_OK;
 }

@@ -62,6 +62,10 @@ struct R16Args {
     unsigned lds_bytes;    // dynamic LDS of the launch
     const int* grp_off;    // [17] device: filter-group boundaries into grp_flt
     const int* grp_flt;    // [nf] device: filter ids, grouped so that groups carry equal tap counts
+    const int* chunk;      // [nf][3] device: first 4-bin chunk, chunk count, offset into w4
+    const void* w4;        // device: triangle weights as aligned 4-bin chunks (compute type)
+    int n_chunks;          // number of 4-element chunks in w4
+    int w4_off;            // byte offset of their LDS copy
 };
 
 // PrevSmooth != 0 mode: scan along the steps of a stored power tensor
@@ -82,7 +86,8 @@ int melspec_generic_pick_F(int M, int compute_dtype);
 hipError_t launch_melspec_generic(const MelspecArgs& a, int compute_dtype, hipStream_t st);
 
 // N = 512 fast path
-bool melspec_r16_supported(int N, int S, int compute_dtype, size_t* lds_bytes, int* xch_off);
+bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, size_t* lds_bytes, int* xch_off,
+                           int* w4_off);
 hipError_t melspec_r16_prepare();
 hipError_t launch_melspec_r16(const MelspecArgs& a, const R16Args& e, int compute_dtype, hipStream_t st);
 

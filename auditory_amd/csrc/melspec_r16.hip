@@ -27,6 +27,11 @@ template <typename TT>
 struct alignas(2 * sizeof(TT)) C2 {
     TT x, y;
 };
+// four consecutive bins / weights moved as one 16-byte (f32) or 32-byte (f64) access
+template <typename TT>
+struct alignas(4 * sizeof(TT)) Q4 {
+    TT x, y, z, w;
+};
 // two complex values moved as one 16-byte (f32) LDS access
 template <typename TT>
 struct alignas(16) C2x2 {
@@ -108,7 +113,8 @@ constexpr int kF = 16;    // frames per workgroup
 constexpr int kM = 256;   // complex FFT length
 constexpr int kN = 512;   // window length
 constexpr int kH = 257;   // power bins
-constexpr int kHp = 257;  // P row pitch in elements (odd: frames map to distinct banks)
+constexpr int kHp = 260;  // P row pitch: 4 * 65 elements, so 4-bin (16-byte) chunks stay aligned and the
+                          // 16 frames of a tile land on 16 distinct 4-bank groups
 
 template <typename TT>
 struct Layout {
@@ -158,6 +164,14 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
             const int64_t p = g0 + c;
             sigbuf[c] = (p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p) : TT(0);
         }
+    }
+
+    // the chunked mel weights (a few KB) ride along into LDS; first used after the last barrier
+    {
+        typedef Q4<TT> quad_t;
+        const quad_t* __restrict__ gw = static_cast<const quad_t*>(e.w4);
+        quad_t* lw = reinterpret_cast<quad_t*>(smem + e.w4_off);
+        for (int c = tid; c < e.n_chunks; c += 256) lw[c] = gw[c];
     }
 
     // per-lane constants, fetched while the span lands: W_256^(j*k1) = W_512^(2 j k1)
@@ -232,6 +246,8 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
         }
         // k = 128 (lane 0, register 8) pairs with itself: X[128] = conj(Z[128])
         if (j == 0) P[128] = v[8].x * v[8].x + v[8].y * v[8].y;
+        // bins 257..259 only pad the last 4-bin chunk; their weights are zero but 0 * garbage must stay 0
+        if (j >= 13) P[kH + (j - 13)] = TT(0);
     }
     __syncthreads();
 
@@ -259,24 +275,33 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
     }
 
     // ---- mel triangles + log (mel.go:120-153): 16 balanced filter groups x 16 frames ----------
+    // Each triangle is stored as 4-bin chunks aligned to bins 0, 4, 8, ... (zero weights outside
+    // the triangle), so one 16-byte LDS read + one 16-byte table read feed four FMAs, in bin order.
     {
         const int ff = tid & 15, grp = tid >> 4;
         const int sstep = t0 + ff;
         if (sstep < T) {
             const int64_t start = int64_t(it.start0) + int64_t(S) * (sstep - a.border);
             const bool live = start + kN <= lim;
-            const TT* __restrict__ filt = static_cast<const TT*>(a.filt);
-            const TT* prow = sigbuf + ff * kHp;
-            const int cols = a.nf + 2;
+            typedef Q4<TT> quad_t;
+            const quad_t* w4 = reinterpret_cast<const quad_t*>(smem + e.w4_off);
+            const quad_t* prow = reinterpret_cast<const quad_t*>(sigbuf + ff * kHp);
             const TT loff = TT(a.mel_log_off), lmin = TT(a.mel_log_min);
             for (int idx = e.grp_off[grp]; idx < e.grp_off[grp + 1]; ++idx) {
                 const int flt = e.grp_flt[idx];
                 float res = 0.f;
                 if (live) {
-                    const int lo = a.bin_pts[flt], hi = a.bin_pts[flt + 2];
-                    const TT* wrow = filt + size_t(flt) * cols;
+                    const int c0 = e.chunk[3 * flt], nc = e.chunk[3 * flt + 1], wo = e.chunk[3 * flt + 2];
                     TT sum = TT(0);
-                    for (int bin = lo; bin <= hi; ++bin) sum += wrow[bin - lo] * prow[bin];
+#pragma unroll 4
+                    for (int c = 0; c < nc; ++c) {
+                        const quad_t pw = prow[c0 + c];
+                        const quad_t ww = w4[wo + c];
+                        sum += ww.x * pw.x;
+                        sum += ww.y * pw.y;
+                        sum += ww.z * pw.z;
+                        sum += ww.w * pw.w;
+                    }
                     sum += loff;
                     TT val = (sum == TT(0)) ? lmin : dev_log(sum);
                     if (a.renorm) {
@@ -295,18 +320,21 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
 
 }  // namespace
 
-bool melspec_r16_supported(int N, int S, int compute_dtype, size_t* lds_bytes, int* xch_off) {
+bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, size_t* lds_bytes, int* xch_off,
+                           int* w4_off) {
     if (N != kN || S < 1 || (S & 1)) return false;  // odd steps go to the generic kernel
     const size_t tsz = compute_dtype == AUD_F64 ? 8 : 4;
     const size_t span = size_t(kF - 1) * S + kN;
     size_t first = span > size_t(kF) * kHp ? span : size_t(kF) * kHp;  // sample span, later P
-    first = (first * tsz + 15) & ~size_t(15);
+    first = (first * tsz + 31) & ~size_t(31);
     const size_t rowc = compute_dtype == AUD_F64 ? 17 : 18;
     const size_t xch = size_t(kF) * 16 * rowc * 2 * tsz;
-    const size_t total = first + xch;
+    const size_t w4 = (size_t(n_chunks) * 4 * tsz + 31) & ~size_t(31);
+    const size_t total = first + xch + w4;
     if (total > 160 * 1024) return false;
     if (lds_bytes) *lds_bytes = total;
     if (xch_off) *xch_off = int(first);
+    if (w4_off) *w4_off = int(first + xch);
     return true;
 }
 
