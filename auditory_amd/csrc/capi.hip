@@ -61,7 +61,14 @@ int hip_fail(aud_ctx* c, hipError_t e, const char* what) {
         if (e__ != hipSuccess) return hip_fail(c, e__, #call); \
     } while (0)
 
-size_t tsize(int dt) { return dt == AUD_F64 ? 8 : 4; }
+// Goroutines / Python threads migrate between OS threads, so every entry point makes its device
+// current -- but only when it is not already (the device entry points may run under stream
+// capture, where needless runtime calls are best avoided).
+hipError_t make_current(const aud_ctx* c) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == c->device) return hipSuccess;
+    return hipSetDevice(c->device);
+}
 
 int ensure_ws(aud_ctx* c, int slot, size_t bytes) {
     if (c->ws_cap[slot] >= bytes) return AUD_OK;
@@ -193,7 +200,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
             d->gabor.stride_y < 1)
             return fail(c, AUD_EINVAL, "gabor filter set incomplete");
     }
-    AUD_HIP(c, hipSetDevice(c->device));
+    AUD_HIP(c, make_current(c));
 
     aud_plan* p = new (std::nothrow) aud_plan();
     if (!p) return AUD_ENOMEM;
@@ -330,7 +337,7 @@ int aud_melspec_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
     if (smooth && !power)
         return fail(c, AUD_EINVAL, "dft.PrevSmooth != 0 needs the power buffer (the scan runs on it)");
     if (n_items == 0) return AUD_OK;
-    AUD_HIP(c, hipSetDevice(c->device));
+    AUD_HIP(c, make_current(c));
     aud::MelspecArgs a;
     fill_melspec_args(p, &a);
     a.sig = sig;
@@ -402,7 +409,7 @@ int aud_gabor_batch_dev(aud_plan* p, const float* mel, int n_items, int rows, in
         a.d2 = out_shape[2];
         a.d3 = out_shape[3];
     }
-    AUD_HIP(c, hipSetDevice(c->device));
+    AUD_HIP(c, make_current(c));
     a.mel = mel;
     a.n_items = n_items;
     a.rows = rows;
@@ -445,7 +452,7 @@ int aud_melspec_batch_host(aud_plan* p, const double* sig, int64_t sig_total, co
     for (int i = 0; i < n_items; ++i)
         if (items[i].sig_off < 0 || items[i].sig_len < 0 || items[i].sig_off + items[i].sig_len > sig_total)
             return fail(c, AUD_EINVAL, "item outside the signal buffer");
-    AUD_HIP(c, hipSetDevice(c->device));
+    AUD_HIP(c, make_current(c));
     const int nf = p->d.mel.n_filters, T = p->d.segment_steps, H = p->H;
     const size_t n_mel = size_t(n_items) * nf * T, n_pow = size_t(n_items) * H * T;
     const size_t sig_bytes = size_t(sig_total) * 8, item_bytes = size_t(n_items) * sizeof(aud_item);
@@ -487,7 +494,7 @@ int aud_gabor_batch_host(aud_plan* p, const double* mel, int n_items, int rows, 
         return fail(c, AUD_EINVAL, "bad shape");
     if (n_items == 0) return AUD_OK;
     if (!mel || !out) return fail(c, AUD_EINVAL, "null buffer");
-    AUD_HIP(c, hipSetDevice(c->device));
+    AUD_HIP(c, make_current(c));
     size_t out_cells = 1;
     for (int i = 0; i < out_rank; ++i) out_cells *= size_t(out_shape[i] > 0 ? out_shape[i] : 0);
     const size_t n_mel = size_t(n_items) * rows * cols, n_out = size_t(n_items) * out_cells;
@@ -551,7 +558,7 @@ int aud_comm_unique_id(char id[128]) {
 int aud_comm_init(aud_ctx* c, int n_ranks, int rank, const char id[128]) {
     if (!c || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return AUD_EINVAL;
     if (c->comm) return fail(c, AUD_EINVAL, "communicator already initialised");
-    AUD_HIP(c, hipSetDevice(c->device));
+    AUD_HIP(c, make_current(c));
     if (!c->rccl_lib) c->rccl_lib = rccl_open();
     if (!c->rccl_lib) return fail(c, AUD_ERCCL, "cannot load librccl.so");
     auto init = reinterpret_cast<rccl_comm_init_t>(dlsym(c->rccl_lib, "ncclCommInitRank"));
@@ -585,7 +592,7 @@ int aud_allgather_dev(aud_ctx* c, const float* send, float* recv, int64_t count,
     if (!c->comm) return fail(c, AUD_ERCCL, "aud_comm_init has not been called");
     if (count == 0) return AUD_OK;
     if (!send || !recv) return fail(c, AUD_EINVAL, "null buffer");
-    AUD_HIP(c, hipSetDevice(c->device));
+    AUD_HIP(c, make_current(c));
     auto ag = reinterpret_cast<rccl_allgather_t>(dlsym(c->rccl_lib, "ncclAllGather"));
     if (!ag) return fail(c, AUD_ERCCL, "ncclAllGather not found");
     const int r = ag(send, recv, size_t(count), kNcclFloat32, c->comm, static_cast<hipStream_t>(stream));

@@ -126,6 +126,10 @@ hipError_t hipGetDeviceCount(int* n) {
     return hipSuccess;
 }
 hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetDevice(int* d) {
+    *d = 0;
+    return hipSuccess;
+}
 hipError_t hipMalloc(void** p, size_t bytes) {
     *p = std::malloc(bytes ? bytes : 1);  // exact size: ASan sees device-buffer overruns
     return *p ? hipSuccess : hipErrorOutOfMemory;

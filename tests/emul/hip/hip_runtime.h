@@ -48,6 +48,7 @@ inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { retu
 
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipSetDevice(int d);
+hipError_t hipGetDevice(int* d);
 hipError_t hipMalloc(void** p, size_t bytes);
 hipError_t hipFree(void* p);
 hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind k);
