@@ -1,0 +1,285 @@
+// auditory.hpp -- C++ host-side mirror of the reference's Go packages for the hot path, over the
+// C ABI of auditory_hip.h.  Header-only; link with -lauditory_hip.
+//
+// The reference is compiled Go with no FFI; a Go toolchain is not available in this pipeline, so the
+// host layer a Go maintainer would write with cgo (go/auditoryhip) is provided here in
+// C++ with the reference's package / type / field / method names:
+//
+//   namespace dft    { struct Params }                       dft/dft.go:15-39
+//   namespace mel    { struct FilterBank, struct Params }    mel/mel.go:16-117, :156-180
+//   namespace agabor { struct Filter, struct FilterSet, Active, ToTensor, Convolve }   agabor/gabor.go
+//   namespace sound  { MSecToSamples, struct Params, struct SndEnv }                   sound/sndenv.go
+//
+// Tensors are etensor-like: row-major `Values` plus `Shape`.  Error behaviour follows the Go code:
+// Init returns an error string ("" = nil); ProcessSegment / ApplyGabor / Convolve print and carry on.
+#ifndef AUDITORY_HPP
+#define AUDITORY_HPP
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "auditory_hip.h"
+
+namespace auditory {
+
+// minimal etensor.Float64 / Float32: row-major values + shape
+template <typename T>
+struct Tensor {
+    std::vector<int> Shape;
+    std::vector<T> Values;
+    void SetShape(std::vector<int> shp) {
+        Shape = std::move(shp);
+        size_t n = 1;
+        for (int d : Shape) n *= size_t(d);
+        Values.assign(n, T(0));  // etensor.SetShape zero-fills
+    }
+    int NumDims() const { return int(Shape.size()); }
+    int Dim(int i) const { return Shape[size_t(i)]; }
+    void SetZeros() { Values.assign(Values.size(), T(0)); }
+};
+using Float64 = Tensor<double>;
+using Float32 = Tensor<float>;
+
+// one device context shared by the mirrors (one process per GPU)
+inline aud_ctx*& default_ctx() {
+    static aud_ctx* ctx = nullptr;
+    return ctx;
+}
+inline int ensure_ctx(int device = 0) {
+    if (default_ctx()) return AUD_OK;
+    return aud_init(device, &default_ctx());  // AUD_EHIP without a GPU: there is no CPU fallback
+}
+
+namespace dft {
+struct Params {  // dft/dft.go:15-31
+    bool CompLogPow = false;
+    double LogMin = 0, LogOffSet = 0, PrevSmooth = 0, CurSmooth = 0;
+    void Defaults() {  // dft/dft.go:33-39
+        aud_dft_params c{};
+        c.prev_smooth = PrevSmooth;
+        aud_dft_defaults(&c);
+        CompLogPow = c.comp_log_pow != 0;
+        LogMin = c.log_min;
+        LogOffSet = c.log_offset;
+        PrevSmooth = c.prev_smooth;
+        CurSmooth = c.cur_smooth;
+    }
+    aud_dft_params c() const { return aud_dft_params{CompLogPow ? 1 : 0, LogMin, LogOffSet, PrevSmooth, CurSmooth}; }
+};
+}  // namespace dft
+
+namespace mel {
+inline double FreqToMel(double f) { return aud_freq_to_mel(f); }                                  // mel.go:156
+inline double MelToFreq(double m) { return aud_mel_to_freq(m); }                                  // mel.go:161
+inline int FreqToBin(double f, double nFft, double sr) { return aud_freq_to_bin(f, nFft, sr); }   // mel.go:166
+
+struct FilterBank {  // mel/mel.go:16-44
+    int NFilters = 0;
+    double LoHz = 0, HiHz = 0, LogOff = 0, LogMin = 0;
+    bool Renorm = false;
+    double RenormMin = 0, RenormMax = 0, RenormScale = 0;
+    void Defaults() {  // mel/mel.go:171-180
+        aud_mel_fbank c{};
+        aud_mel_defaults(&c);
+        from(c);
+    }
+    aud_mel_fbank c() const {
+        return aud_mel_fbank{NFilters, LoHz, HiHz, LogOff, LogMin, Renorm ? 1 : 0, RenormMin, RenormMax, RenormScale};
+    }
+    void from(const aud_mel_fbank& c) {
+        NFilters = c.n_filters; LoHz = c.lo_hz; HiHz = c.hi_hz; LogOff = c.log_off; LogMin = c.log_min;
+        Renorm = c.renorm != 0; RenormMin = c.renorm_min; RenormMax = c.renorm_max; RenormScale = c.renorm_scale;
+    }
+};
+
+struct Params {  // mel/mel.go:47-66
+    FilterBank FBank;
+    std::vector<int32_t> BinPts;
+    std::vector<double> HzPts;
+    bool MFCC = false, Deltas = false;
+    int NCoefs = 0;
+    void Defaults() {  // mel/mel.go:69-74
+        FBank.Defaults();
+        MFCC = true;
+        NCoefs = 13;
+        Deltas = true;
+    }
+    // mel/mel.go:77-117.  Returns false where the Go code would panic (triangle past the end of the tensor).
+    bool InitFilters(int dftSize, int sampleRate, Float64* filters) {
+        const int nf = FBank.NFilters;
+        BinPts.assign(size_t(nf) + 2, 0);
+        HzPts.assign(size_t(nf) + 2, 0.0);
+        filters->SetShape({nf, nf + 2});
+        aud_mel_fbank c = FBank.c();
+        const int rc = aud_mel_init_filters(&c, dftSize, sampleRate, BinPts.data(), HzPts.data(), filters->Values.data());
+        FBank.from(c);
+        return rc == AUD_OK;
+    }
+};
+}  // namespace mel
+
+namespace agabor {
+struct Filter {  // agabor/gabor.go:17-42
+    bool Off = false;
+    double WaveLen = 0, Orientation = 0, SigmaWidth = 0, SigmaLength = 0, PhaseOffset = 0;
+    bool CircleEdge = false, Circular = false;
+    aud_gabor_spec c() const {
+        return aud_gabor_spec{Off ? 1 : 0, WaveLen, Orientation, SigmaWidth, SigmaLength, PhaseOffset,
+                              CircleEdge ? 1 : 0, Circular ? 1 : 0};
+    }
+};
+
+struct FilterSet {  // agabor/gabor.go:45-70
+    int SizeX = 0, SizeY = 0, StrideX = 0, StrideY = 0;
+    double Gain = 0;
+    bool Distribute = false;
+    Float64 Filters;
+    aud_gabor_set c() const { return aud_gabor_set{SizeX, SizeY, StrideX, StrideY, Gain, Distribute ? 1 : 0}; }
+};
+
+inline std::vector<Filter> Active(const std::vector<Filter>& specs) {  // gabor.go:329-336
+    std::vector<Filter> a;
+    for (const Filter& s : specs)
+        if (!s.Off) a.push_back(s);
+    return a;
+}
+
+inline void ToTensor(const std::vector<Filter>& specs, FilterSet* set) {  // gabor.go:89-222
+    std::vector<aud_gabor_spec> cs;
+    for (const Filter& s : specs) cs.push_back(s.c());
+    const int n_act = int(Active(specs).size());
+    set->Filters.SetShape({n_act, set->SizeY, set->SizeX});
+    if (cs.empty()) return;
+    aud_gabor_set g = set->c();
+    int n_out = 0;
+    aud_gabor_to_tensor(cs.data(), int(cs.size()), &g, set->Filters.Values.data(), &n_out);
+}
+}  // namespace agabor
+
+// a plan bound to one (window, step, segment, mel table, gabor set) parameter set
+struct PlanHandle {
+    aud_plan* p = nullptr;
+    ~PlanHandle() {
+        if (p) aud_plan_destroy(p);
+    }
+    PlanHandle() = default;
+    PlanHandle(const PlanHandle&) = delete;
+    PlanHandle& operator=(const PlanHandle&) = delete;
+};
+
+namespace agabor {
+// gabor.go:225-315 on the GPU through an existing plan; logs and returns on rejected shapes, like the Go code
+inline void Convolve(aud_plan* plan, const Float64& melData, const FilterSet&, Float32* rawOut, bool byTime) {
+    std::vector<int32_t> shp(rawOut->Shape.begin(), rawOut->Shape.end());
+    const int rc = aud_gabor_batch_host(plan, melData.Values.data(), 1, melData.Dim(0), melData.Dim(1),
+                                        int(shp.size()), shp.data(), byTime ? 1 : 0, rawOut->Values.data());
+    if (rc != AUD_OK) std::fprintf(stderr, "agabor.Convolve: %s\n", aud_status_string(rc));
+}
+}  // namespace agabor
+
+namespace sound {
+inline int MSecToSamples(double ms, int rate) { return aud_msec_to_samples(ms, rate); }  // sndenv.go:522-524
+
+struct Params {  // sound/sndenv.go:24-61
+    double WinMs = 0, StepMs = 0, SegmentMs = 0, StrideMs = 0;
+    int BorderSteps = 0, Channel = 0;
+    int WinSamples = 0, StepSamples = 0, SegmentSamples = 0, StrideSamples = 0, SegmentSteps = 0;
+    std::vector<int> Steps;
+};
+
+struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
+    Params Params_;  // `Params` in Go; renamed only because C++ cannot reuse the type name
+    int SampleRate = 0, Channels = 1;  // se.Sound.SampleRate() / Channels()
+    Float64 Signal;
+    int SegCnt = 0;
+    dft::Params DFT;
+    mel::Params Mel;
+    Float64 MelFilters, PowerSegment, LogPowerSegment, MelFBankSegment;
+    std::vector<agabor::Filter> GaborSpecs;
+    agabor::FilterSet GaborFilters;
+    int GborOutPoolsX = 0, GborOutPoolsY = 0, GborOutUnitsX = 0, GborOutUnitsY = 0;
+    Float32 GborOutput;
+    bool ByTime = false;
+    int ComputeDtype = AUD_F32;
+    PlanHandle plan;
+
+    void ParamDefaults() {  // sndenv.go:64-71
+        aud_sound_params c{};
+        aud_sound_params_defaults(&c);
+        Params_.WinMs = c.win_ms; Params_.StepMs = c.step_ms; Params_.SegmentMs = c.segment_ms;
+        Params_.StrideMs = c.stride_ms; Params_.Channel = c.channel; Params_.BorderSteps = c.border_steps;
+    }
+    void Defaults() {  // sndenv.go:185-192
+        ParamDefaults();
+        Mel.Defaults();
+        ByTime = false;
+    }
+
+    // sndenv.go:195-267.  "" = nil error.
+    std::string Init() {
+        aud_sound_params c{};
+        c.win_ms = Params_.WinMs; c.step_ms = Params_.StepMs; c.segment_ms = Params_.SegmentMs;
+        c.stride_ms = Params_.StrideMs; c.border_steps = Params_.BorderSteps; c.channel = Params_.Channel;
+        if (aud_sound_params_derive(&c, SampleRate) != AUD_OK) {
+            std::printf("sample rate <= 0\n");
+            return "sample rate <= 0";
+        }
+        Params_.WinSamples = c.win_samples; Params_.StepSamples = c.step_samples;
+        Params_.SegmentSamples = c.segment_samples; Params_.SegmentSteps = c.segment_steps;
+        Params_.StrideSamples = c.stride_samples;
+
+        agabor::ToTensor(agabor::Active(GaborSpecs), &GaborFilters);
+        if (GborOutPoolsX == 0 && GborOutPoolsY == 0) GborOutput.SetShape({GborOutUnitsY, GborOutUnitsX});
+        else if (GborOutPoolsX > 0 && GborOutPoolsY > 0)
+            GborOutput.SetShape({GborOutPoolsY, GborOutPoolsX, GborOutUnitsY, GborOutUnitsX});
+        else {
+            std::fprintf(stderr, "GborOutPoolsX & GborOutPoolsY must both be == 0 or > 0 (i.e. 2D or 4D)\n");
+            return "";
+        }
+        const int H = Params_.WinSamples / 2 + 1;
+        DFT.Defaults();
+        if (!Mel.InitFilters(Params_.WinSamples, SampleRate, &MelFilters)) return "mel filter table overflow";
+        PowerSegment.SetShape({H, Params_.SegmentSteps});
+        LogPowerSegment.SetShape({H, Params_.SegmentSteps});
+        Params_.Steps.clear();
+        for (int i = 0; i < Params_.SegmentSteps; ++i) Params_.Steps.push_back(Params_.StepSamples * (i - Params_.BorderSteps));
+        MelFBankSegment.SetShape({Mel.FBank.NFilters, Params_.SegmentSteps});
+        SegCnt = aud_seg_cnt(int(Signal.Values.size()), Params_.SegmentSamples, Params_.StrideSamples, Channels);
+
+        if (ensure_ctx() != AUD_OK) return "no HIP device (libauditory_hip has no CPU fallback)";
+        aud_plan_desc d{};
+        d.win_samples = Params_.WinSamples; d.step_samples = Params_.StepSamples;
+        d.segment_steps = Params_.SegmentSteps; d.border_steps = Params_.BorderSteps;
+        d.dft = DFT.c(); d.mel = Mel.FBank.c();
+        d.bin_pts = Mel.BinPts.data(); d.mel_filters = MelFilters.Values.data();
+        d.n_gabor = GaborFilters.Filters.NumDims() == 3 ? GaborFilters.Filters.Dim(0) : 0;
+        d.gabor = GaborFilters.c();
+        d.gabor_filters = d.n_gabor ? GaborFilters.Filters.Values.data() : nullptr;
+        d.compute_dtype = ComputeDtype;
+        if (plan.p) { aud_plan_destroy(plan.p); plan.p = nullptr; }
+        if (aud_plan_create(default_ctx(), &d, &plan.p) != AUD_OK) return aud_last_error(default_ctx());
+        return "";
+    }
+
+    // sndenv.go:342-359 (frame loop): PowerSegment, LogPowerSegment, MelFBankSegment of one segment
+    void ProcessSegment(int segment, int add) {
+        aud_item it{0, int32_t(Signal.Values.size()),
+                    int32_t(segment * Params_.StrideSamples + MSecToSamples(double(add), SampleRate))};  // :440-441
+        const int rc = aud_melspec_batch_host(plan.p, Signal.Values.data(), int64_t(Signal.Values.size()), &it, 1,
+                                              MelFBankSegment.Values.data(), PowerSegment.Values.data(),
+                                              DFT.CompLogPow ? LogPowerSegment.Values.data() : nullptr);
+        if (rc != AUD_OK) std::printf("%s\n", aud_last_error(default_ctx()));  // fmt.Println(err), sndenv.go:356
+    }
+
+    // sndenv.go:481-497 without NeighInhib / Kwta (off by default; out of scope)
+    Float32* ApplyGabor() {
+        agabor::Convolve(plan.p, MelFBankSegment, GaborFilters, &GborOutput, ByTime);
+        return &GborOutput;
+    }
+};
+}  // namespace sound
+
+}  // namespace auditory
+#endif  // AUDITORY_HPP

@@ -1,0 +1,60 @@
+// Drives include/auditory.hpp the way an emergent simulation drives sound.SndEnv:
+//   Defaults -> set fields -> Init -> for each segment { ProcessSegment; ApplyGabor }
+// argv: <signal.f64> <sample_rate> <out.bin>.  Output: for every segment, float64 mel [nf*T],
+// float64 log-power [H*T], float32 gabor [8*2*2*8], preceded by one int32 header {SegCnt, nf, T, H}.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "auditory.hpp"
+
+using namespace auditory;
+
+int main(int argc, char** argv) {
+    if (argc < 4) return 2;
+    std::FILE* f = std::fopen(argv[1], "rb");
+    if (!f) return 3;
+    std::fseek(f, 0, SEEK_END);
+    const long bytes = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    sound::SndEnv se;
+    se.Defaults();
+    se.Signal.SetShape({int(bytes / 8)});
+    if (std::fread(se.Signal.Values.data(), 8, se.Signal.Values.size(), f) != se.Signal.Values.size()) return 4;
+    std::fclose(f);
+    se.SampleRate = std::atoi(argv[2]);
+
+    // the processspeech filter set (examples/processspeech/processspeech.go:226-253)
+    const double orient[] = {0, 45, 90, 135}, phase[] = {0, 1.5708};
+    for (double o : orient)
+        for (double ph : phase) {
+            agabor::Filter g;
+            g.WaveLen = 2.0; g.Orientation = o; g.SigmaWidth = 0.5; g.SigmaLength = 0.5;
+            g.PhaseOffset = ph; g.CircleEdge = true;
+            se.GaborSpecs.push_back(g);
+        }
+    se.GaborFilters.SizeX = se.GaborFilters.SizeY = 9;
+    se.GaborFilters.StrideX = se.GaborFilters.StrideY = 3;
+    se.GaborFilters.Gain = 2;
+    se.GborOutPoolsX = 2; se.GborOutPoolsY = 8; se.GborOutUnitsX = 8; se.GborOutUnitsY = 2;
+
+    const std::string err = se.Init();
+    if (!err.empty()) {
+        std::fprintf(stderr, "Init: %s\n", err.c_str());
+        return 5;
+    }
+    std::FILE* o = std::fopen(argv[3], "wb");
+    const int32_t hdr[4] = {se.SegCnt, se.Mel.FBank.NFilters, se.Params_.SegmentSteps, se.Params_.WinSamples / 2 + 1};
+    std::fwrite(hdr, 4, 4, o);
+    for (int seg = 0; seg < se.SegCnt; ++seg) {
+        se.ProcessSegment(seg, 0);
+        Float32* g = se.ApplyGabor();
+        std::fwrite(se.MelFBankSegment.Values.data(), 8, se.MelFBankSegment.Values.size(), o);
+        std::fwrite(se.LogPowerSegment.Values.data(), 8, se.LogPowerSegment.Values.size(), o);
+        std::fwrite(g->Values.data(), 4, g->Values.size(), o);
+    }
+    std::fclose(o);
+    aud_shutdown(default_ctx());
+    std::printf("CPP-DRIVER-OK %d segments\n", se.SegCnt);
+    return 0;
+}

@@ -1,0 +1,61 @@
+"""include/auditory.hpp (the C++ host mirror of the reference's Go packages) driven like an
+emergent sim drives sound.SndEnv, against the oracle.  CPU tier: linked with the emulator build
+of the kernels; GPU tier: linked with the shipped libauditory_hip.so."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import workloads as W
+from auditory_amd import capi, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "emul"))
+
+
+def _run_driver(lib_path, tmp_path, orc):
+    exe = str(tmp_path / "sndenv_driver")
+    libdir, libname = os.path.dirname(lib_path), os.path.basename(lib_path)[3:-3]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(HERE, "cpp", "sndenv_driver.cpp"), "-o", exe,
+                           "-L" + libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-pthread"])
+    sig, _ = synth.batch(6, 1, 8000, 16000)
+    sig_path, out_path = str(tmp_path / "sig.f64"), str(tmp_path / "out.bin")
+    sig[0].tofile(sig_path)
+    r = subprocess.run([exe, sig_path, "16000", out_path], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CPP-DRIVER-OK" in r.stdout, r.stdout + r.stderr
+    raw = open(out_path, "rb").read()
+    segcnt, nf, T, H = np.frombuffer(raw[:16], np.int32)
+    assert (segcnt, nf, T, H) == (5, 32, 14, 201)
+    oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
+    k = orc.gabor_to_tensor(W.DEFAULT_GABOR_SPECS, 9, 9)
+    pos = 16
+    for seg in range(segcnt):
+        mel = np.frombuffer(raw, np.float64, nf * T, pos).reshape(nf, T); pos += 8 * nf * T
+        lp = np.frombuffer(raw, np.float64, H * T, pos).reshape(H, T); pos += 8 * H * T
+        gab = np.frombuffer(raw, np.float32, 8 * 2 * 2 * 8, pos).reshape(8, 2, 2, 8); pos += 4 * 256
+        o = orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig[0], segment=seg)
+        ok, msg = W.feature_close(mel, o["mel_seg"], capi.AUD_F32, lin_axis=0)
+        assert ok, (seg, msg)
+        ok, msg = W.spectrum_close(lp[None], o["log_power_seg"][None], 4e-6, log_offset=1.0)
+        assert ok, (seg, msg)
+        ref = np.zeros((8, 2, 2, 8), np.float32)
+        assert orc.gabor_convolve(o["mel_seg"], k, 3, 3, 2.0, ref) == 0
+        ok, msg = W.feature_close(gab, ref, capi.AUD_F32)
+        assert ok, (seg, msg)
+    assert pos == len(raw)
+
+
+def test_cpp_mirror_on_emulated_kernels(orc, tmp_path):
+    import build_emul
+    _run_driver(build_emul.build("plain"), tmp_path, orc)
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_on_gpu(orc, tmp_path):
+    import torch
+    assert torch.cuda.is_available()
+    _run_driver(capi.LIB_PATH, tmp_path, orc)
