@@ -102,11 +102,18 @@ int upload_real(aud_ctx* c, void** dst, const double* src, size_t n, int dt) {
     return upload(c, dst, v.data(), n * 4);
 }
 
+// as few Stockham stages as possible out of the radices the kernel has in registers
+// (16, 8, 4, 2 | 25, 5 | 3), then whatever primes are left
 void factorize(int m, int* fac, int* nfac) {
     int n = 0;
+    while (m % 16 == 0) { fac[n++] = 16; m /= 16; }
+    while (m % 8 == 0) { fac[n++] = 8; m /= 8; }
     while (m % 4 == 0) { fac[n++] = 4; m /= 4; }
     while (m % 2 == 0) { fac[n++] = 2; m /= 2; }
-    for (int p = 3; int64_t(p) * p <= m; p += 2)
+    while (m % 25 == 0) { fac[n++] = 25; m /= 25; }
+    while (m % 5 == 0) { fac[n++] = 5; m /= 5; }
+    while (m % 3 == 0) { fac[n++] = 3; m /= 3; }
+    for (int p = 7; int64_t(p) * p <= m; p += 2)
         while (m % p == 0) { fac[n++] = p; m /= p; }
     if (m > 1) fac[n++] = m;
     *nfac = n;
