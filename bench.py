@@ -80,6 +80,9 @@ def cpu_baseline(oc, sig64, L, target_s=12.0, max_threads=16, chunk=8):
             "one_thread_plan_per_frame": round(1.0 / per_utt_faithful, 2)}
 
 
+_real_cpu_baseline = cpu_baseline
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +90,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
     ap.add_argument("--win-ms", type=float, default=32.0, help="32 -> N=512 (headline), 25 -> N=400")
+    ap.add_argument("--workload", choices=["cfg2", "cfg4", "cfg5"], default="cfg2",
+                    help="cfg2: BASELINE configs[1] (the judged line).  Secondary lines for BASELINE.md's table: "
+                         "cfg4 = cfg2 + agabor.Convolve (default FilterSet, 4-D [11,32,2,8] pools); "
+                         "cfg5 = 44.1 kHz 5 s streams, N=2048, 128 mel (use --batch 128)")
     ap.add_argument("--compute", choices=["f32", "f64"], default="f32")
     ap.add_argument("--launch", choices=["graph", "eager"], default="graph",
                     help="graph: the K steps are replayed from hipGraphs of up to 50 captured steps each "
@@ -116,12 +123,16 @@ def main():
 
     name = "cfg2_16k_n512_nf40" if args.win_ms == 32.0 else "cfg2_16k_n400_nf40"
     assert args.win_ms in (32.0, 25.0)
+    if args.workload == "cfg5":
+        name = "cfg5_44k_n2048_nf128"
     oc = W.OracleCfg(orc, name)
-    B, sr, dur = args.batch, oc.sr, 16000
+    B, sr = args.batch, oc.sr
+    dur = 5 * sr if args.workload == "cfg5" else 16000        # samples of real audio per stream
     L = (oc.full_len() + 63) // 64 * 64          # zero tail so every frame is in bounds, 64-sample pitch
     sig64, _ = synth.batch(2, B, dur, sr, row_len=L, first_idx=rank * B)
     cdt = capi.AUD_F32 if args.compute == "f32" else capi.AUD_F64
-    plan = W.product_plan(oc, cdt, device=local_rank)
+    gab = dict(size=(9, 9), stride=(3, 3), gain=2.0, specs=W.DEFAULT_GABOR_SPECS) if args.workload == "cfg4" else None
+    plan = W.product_plan(oc, cdt, gab, device=local_rank)
     bp = BatchProcessor(plan, dev)
     dsig = torch.from_numpy(sig64.astype(np.float32)).to(dev).view(-1)
     items = bp.upload_items(runtime.make_items(np.arange(B) * L, [L] * B, [0] * B))
@@ -130,11 +141,18 @@ def main():
     # one step = one launch of the fused frame->mel kernel over the resident batch, through the C ABI
     lib, plan_h = plan.lib, plan.handle
     call_args = (plan_h, dsig.data_ptr(), capi.AUD_F32, items.data_ptr(), B, mel.data_ptr(), None, None)
+    gout = torch.zeros((B, 11, 32, 2, 8), dtype=torch.float32, device=dev) if gab else None
+    gab_args = (plan_h, dsig.data_ptr(), capi.AUD_F32, items.data_ptr(), B, mel.data_ptr(), 11, 32,
+                gout.data_ptr()) if gab else None
 
     def step():
-        rc = lib.aud_melspec_batch_dev(*call_args, torch.cuda.current_stream(dev).cuda_stream)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        if gab:
+            rc = lib.aud_process_batch_dev(*gab_args, st)
+        else:
+            rc = lib.aud_melspec_batch_dev(*call_args, st)
         if rc != 0:
-            raise RuntimeError("aud_melspec_batch_dev: %d %s" % (rc, lib.aud_last_error(plan.ctx.handle)))
+            raise RuntimeError("hot path launch: %d %s" % (rc, lib.aud_last_error(plan.ctx.handle)))
 
     def sync_all():
         if world > 1:
@@ -210,6 +228,8 @@ def main():
 
     audio_s_per_step = B * world * (dur / float(sr))
     alg_bytes = B * (4 * dur + 4 * oc.nf * oc.T)  # each sample read once + each mel value written once
+    if gab:  # unfused gabor: re-read the mel tensor, write the pooled on/off pairs
+        alg_bytes += B * (4 * oc.nf * oc.T + 4 * 11 * 32 * 2 * 8)
     kern_ms = dev_ms / args.steps
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     line = {
@@ -220,9 +240,13 @@ def main():
         "ms_per_step": round(1e3 * elapsed / args.steps, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.compute, "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: batch=%d synthetic 16 kHz 1 s mono utterances per GPU, "
-                               "%d-pt FFT (WinMs %g), step 160, T=104 frames, 40 mel, mel only"
-                               % (B, oc.N, args.win_ms),
+        "config": {"workload": {"cfg2": "BASELINE configs[1]: batch=%d synthetic 16 kHz 1 s mono utterances per GPU, "
+                                        "%d-pt FFT (WinMs %g), step 160, T=104 frames, 40 mel, mel only"
+                                        % (B, oc.N, args.win_ms),
+                                "cfg4": "BASELINE configs[3]: configs[1] (batch=%d, %d-pt FFT) + agabor.Convolve, "
+                                        "default FilterSet 9x9/3 x 8 filters, [11,32,2,8] pools" % (B, oc.N),
+                                "cfg5": "BASELINE configs[4]: %d mono streams of 5 s @44.1 kHz, 2048-pt FFT, step 441, "
+                                        "T=504 frames, 128 mel" % B}[args.workload],
                    "batch_per_gpu": B, "win_samples": oc.N, "step_samples": oc.S,
                    "segment_steps": oc.T, "n_mel": oc.nf, "kernel": plan.kernel_name, "launch": launch_mode,
                    "sharding": "utterances, contiguous block per rank"},

@@ -1,0 +1,69 @@
+"""Dry run of bench.py's control flow on the CPU (no timing claims): torch.cuda is replaced by a
+stub and the C ABI by the emulator build, so that argument plumbing, the JSON contract and the
+cpu_baseline leg are exercised before any GPU minute is spent on them."""
+import json
+import os
+import sys
+import types
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "emul"))
+
+
+class _Stream:
+    cuda_stream = 0
+
+
+class _Event:
+    def __init__(self, enable_timing=False):
+        import time
+        self._t = None
+        self._time = time
+
+    def record(self):
+        self._t = self._time.perf_counter()
+
+    def elapsed_time(self, other):
+        return max(1e-6, (other._t - self._t) * 1e3)
+
+
+class _Graph:
+    def __init__(self):
+        raise RuntimeError("no hipGraph in the dry run")
+
+
+@pytest.mark.parametrize("extra", [[], ["--win-ms", "25"], ["--workload", "cfg4"], ["--compute", "f64", "--launch", "eager"]])
+def test_bench_dry_run(monkeypatch, capsys, extra):
+    import backend
+    import bench
+    real_device = torch.device
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda d=None: None)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda d=None: _Stream())
+    monkeypatch.setattr(torch.cuda, "Event", _Event)
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", _Graph)
+    monkeypatch.setattr(torch, "device", lambda *a, **k: real_device("cpu"))
+    monkeypatch.setattr(bench, "cpu_baseline",
+                        lambda oc, sig, L: bench.__dict__["_real_cpu_baseline"](oc, sig, L, target_s=0.2))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--batch", "2"] + extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    with backend.emulated("plain"):
+        bench.main()
+    out = capsys.readouterr().out.strip().splitlines()
+    line = json.loads(out[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["unit"] == "audio-seconds/sec" and line["n_gpus"] == 1 and line["steps"] == 2
+    assert line["vs_baseline"] is None and line["scaling"] == "weak" and line["data"] == "synthetic"
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert line["cpu_baseline"]["cores"] <= 16 and line["cpu_baseline"]["kind"] == "port"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert line["value"] > 0 and line["roofline"]["achieved"] >= 0
