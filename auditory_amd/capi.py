@@ -88,6 +88,7 @@ SYMBOLS = {
     "aud_plan_create": (C.c_int, [_VP, C.POINTER(PlanDesc), C.POINTER(_VP)]),
     "aud_plan_destroy": (C.c_int, [_VP]),
     "aud_plan_kernel_name": (C.c_char_p, [_VP]),
+    "aud_plan_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int]),
     "aud_melspec_batch_dev": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, _VP, _VP, _VP, _VP]),
     "aud_gabor_batch_dev": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_int,
                                       _VP, _VP]),

@@ -34,6 +34,8 @@ struct aud_plan {
     int fac[aud::kMaxFactors] = {0};
     int F_generic = 0;
     bool use_r16 = false;
+    bool r16_tables = false;  // group schedule / chunked weights uploaded
+    int r16_chunks = 0;
     aud::R16Args r16{};
     int* d_grp = nullptr;  // [17 + nf + 3 nf]: group offsets, filter ids, per-filter chunk info
     void* d_w4 = nullptr;  // chunked triangle weights
@@ -243,15 +245,17 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
         rc = upload_real(c, &p->d_gabor, d->gabor_filters,
                          size_t(d->n_gabor) * d->gabor.size_x * d->gabor.size_y, d->compute_dtype);
     // kernel family: the in-register 16 x 16 kernel for 512-sample windows, else the generic one
-    size_t r16_lds = 0;
-    int r16_xch = 0, r16_w4 = 0, r16_chunks = 0;
+    int r16_chunks = 0;
     for (int f = 0; f < nf; ++f) {
         const int lo = d->bin_pts[f], hi = d->bin_pts[f + 2];
         if (hi >= lo) r16_chunks += (hi >> 2) - (lo >> 2) + 1;
     }
     if (r16_chunks == 0) r16_chunks = 1;
-    if (rc == AUD_OK && aud::melspec_r16_supported(N, d->step_samples, d->compute_dtype, r16_chunks, &r16_lds,
-                                                  &r16_xch, &r16_w4)) {
+    p->r16_chunks = r16_chunks;
+    aud::R16Args r16cfg;
+    std::memset(&r16cfg, 0, sizeof(r16cfg));
+    bool r16_ok = aud::melspec_r16_supported(N, d->step_samples, d->compute_dtype, r16_chunks, true, &r16cfg);
+    if (rc == AUD_OK && r16_ok) {
         // balance the mel filters over 16 thread groups by tap count (longest first, LPT)
         std::vector<int> order(nf), load(16, 0), owner(nf);
         for (int f = 0; f < nf; ++f) order[f] = f;
@@ -297,15 +301,13 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
             rc = fail(c, AUD_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
         if (rc == AUD_OK) {
             p->use_r16 = true;
+            p->r16_tables = true;
             p->family = "r16x16";
-            p->r16.xch_off = r16_xch;
-            p->r16.lds_bytes = unsigned(r16_lds);
+            p->r16 = r16cfg;
             p->r16.grp_off = p->d_grp;
             p->r16.grp_flt = p->d_grp + 17;
             p->r16.chunk = p->d_grp + 17 + nf;
             p->r16.w4 = p->d_w4;
-            p->r16.n_chunks = r16_chunks;
-            p->r16.w4_off = r16_w4;
         }
     }
     if (rc != AUD_OK) {
@@ -330,6 +332,38 @@ int aud_plan_destroy(aud_plan* p) {
 }
 
 const char* aud_plan_kernel_name(const aud_plan* p) { return p ? p->family : ""; }
+
+int aud_plan_set_option(aud_plan* p, const char* name, int value) {
+    if (!p || !name) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    const std::string key(name);
+    if (key == "kernel") {  // 0 = automatic choice, 1 = force the generic any-N kernel
+        if (value == 1) {
+            p->use_r16 = false;
+            p->family = "generic";
+            return AUD_OK;
+        }
+        if (value == 0) {
+            if (p->r16_tables) {
+                p->use_r16 = true;
+                p->family = "r16x16";
+            }
+            return AUD_OK;
+        }
+        return fail(c, AUD_EINVAL, "kernel: 0 (auto) or 1 (generic)");
+    }
+    if (key == "r16_input") {  // 0 = operands straight from global memory, 1 = staged through LDS
+        if (!p->r16_tables) return fail(c, AUD_EINVAL, "plan has no r16x16 kernel");
+        if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "r16_input: 0 (direct) or 1 (staged)");
+        aud::R16Args cfg = p->r16;
+        if (!aud::melspec_r16_supported(p->d.win_samples, p->d.step_samples, p->d.compute_dtype, p->r16_chunks,
+                                        value == 0, &cfg))
+            return fail(c, AUD_EINVAL, "this r16x16 variant does not support the plan (odd step?)");
+        p->r16 = cfg;
+        return AUD_OK;
+    }
+    return fail(c, AUD_EINVAL, "unknown option");
+}
 
 int aud_melspec_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud_item* items,
                           int n_items, float* mel, float* power, float* log_power, void* stream) {

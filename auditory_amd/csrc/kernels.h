@@ -58,14 +58,16 @@ struct GaborArgs {
 
 // extra arguments of the 512-point (16 x 16 in registers) kernel
 struct R16Args {
+    int direct;            // 1: pass-1 operands straight from global memory, 0: staged through LDS
     int xch_off;           // byte offset of the transpose buffer inside dynamic LDS
+    int p_off;             // byte offset of the power spectrum (aliases the span or the transpose buffer)
+    int w4_off;            // byte offset of the LDS copy of the chunked mel weights
     unsigned lds_bytes;    // dynamic LDS of the launch
+    int n_chunks;          // number of 4-element chunks in w4
     const int* grp_off;    // [17] device: filter-group boundaries into grp_flt
     const int* grp_flt;    // [nf] device: filter ids, grouped so that groups carry equal tap counts
     const int* chunk;      // [nf][3] device: first 4-bin chunk, chunk count, offset into w4
     const void* w4;        // device: triangle weights as aligned 4-bin chunks (compute type)
-    int n_chunks;          // number of 4-element chunks in w4
-    int w4_off;            // byte offset of their LDS copy
 };
 
 // PrevSmooth != 0 mode: scan along the steps of a stored power tensor
@@ -86,8 +88,7 @@ int melspec_generic_pick_F(int M, int compute_dtype);
 hipError_t launch_melspec_generic(const MelspecArgs& a, int compute_dtype, hipStream_t st);
 
 // N = 512 fast path
-bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, size_t* lds_bytes, int* xch_off,
-                           int* w4_off);
+bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, bool direct, R16Args* out);
 hipError_t melspec_r16_prepare();
 hipError_t launch_melspec_r16(const MelspecArgs& a, const R16Args& e, int compute_dtype, hipStream_t st);
 

@@ -6,8 +6,13 @@
 //   * one workgroup = one tile of 16 consecutive frames of one work item;
 //   * 16 lanes cooperate on a frame, each lane owns 16 complex points, so a wave carries
 //     4 frames and every butterfly is straight-line VALU code on registers;
-//   * the tile's contiguous sample span (15*S + N samples; every sample is used by N/S = 3.2
-//     frames) is fetched from HBM once with 16-byte loads and shared through LDS;
+//   * input, two variants (template flag DIRECT, chosen per plan, see aud_plan_set_option):
+//       DIRECT  each lane pulls its 16 sample pairs straight from global memory into registers
+//               (8-byte loads, 128 B contiguous per frame; the N/S = 3.2x overlap between frames
+//               is served by L1/L2, HBM still sees every sample once).  No staging buffer, no
+//               staging barrier, LDS = transpose buffer only => 4 workgroups per CU;
+//       STAGED  the tile's contiguous sample span (15*S + N samples) is fetched once with 16-byte
+//               loads into LDS and pass 1 reads it from there => 3 workgroups per CU;
 //   * the single 16x16 transpose between the two passes goes through LDS in rows of
 //     16 + pad complex so that both the 8-byte column writes and the 16-byte row reads are
 //     bank-conflict free (row pitch = 4 * odd dwords; frame pitch = a multiple of 256 B);
@@ -123,11 +128,12 @@ struct Layout {
     static constexpr int kFrameC = 16 * kRowC;
 };
 
-template <typename TT>
+template <typename TT, bool DIRECT>
 __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const R16Args e) {
     unsigned char* smem = dyn_lds();
-    TT* sigbuf = reinterpret_cast<TT*>(smem);                       // [span] then reused as P
-    C2<TT>* xch = reinterpret_cast<C2<TT>*>(smem + e.xch_off);      // [16][16][kRowC]
+    TT* sigbuf = reinterpret_cast<TT*>(smem);                   // STAGED only: [span]
+    TT* Pbase = reinterpret_cast<TT*>(smem + e.p_off);          // power spectrum [16][kHp]
+    C2<TT>* xch = reinterpret_cast<C2<TT>*>(smem + e.xch_off);  // [16][16][kRowC]
     const int tid = threadIdx.x;
     const int f = tid >> 4;   // frame within the tile
     const int j = tid & 15;   // lane within the frame's 16-lane group
@@ -138,31 +144,62 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
     const int t0 = (blockIdx.x - item * tiles) * kF;
     const aud_item it = a.items[item];
     const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_512^k
-
-    // ---- stage the tile's sample span: positions g0 .. g0 + span of the item's stream ------
-    const int64_t g0 = int64_t(it.start0) + int64_t(S) * (t0 - a.border);
-    const int span = (kF - 1) * S + kN;
     const int64_t lim = it.sig_len;
-    if (a.sig_dtype == AUD_F32 && sizeof(TT) == 4 && ((it.sig_off + g0) & 3) == 0 &&
-        (reinterpret_cast<uintptr_t>(a.sig) & 15) == 0) {
-        const float* __restrict__ src = static_cast<const float*>(a.sig) + it.sig_off;
-        for (int c = tid; c * 4 < span; c += 256) {
-            const int64_t p = g0 + 4 * c;
-            float4 v;
-            if (p >= 0 && p + 3 < lim) {
-                v = *reinterpret_cast<const float4*>(src + p);
-            } else {
-                v.x = (p >= 0 && p < lim) ? src[p] : 0.f;
-                v.y = (p + 1 >= 0 && p + 1 < lim) ? src[p + 1] : 0.f;
-                v.z = (p + 2 >= 0 && p + 2 < lim) ? src[p + 2] : 0.f;
-                v.w = (p + 3 >= 0 && p + 3 < lim) ? src[p + 3] : 0.f;
+
+    C2<TT> v[16];
+    if constexpr (DIRECT) {
+        // ---- pass-1 operands straight from global memory: z[16 n1 + j] = (x[32 n1 + 2j], x[.. + 1]) ----
+        const int sstep = t0 + f;
+        const int64_t start = int64_t(it.start0) + int64_t(S) * (sstep - a.border);
+        const int64_t pos0 = start + 2 * j;
+        const bool frame_on = sstep < T;
+        bool fast = false;
+        if constexpr (sizeof(TT) == 4) {
+            // whole frame inside the stream, f32 samples, 8-byte aligned pairs
+            fast = frame_on && start >= 0 && start + kN <= lim && a.sig_dtype == AUD_F32 &&
+                   ((it.sig_off + start) & 1) == 0 && (reinterpret_cast<uintptr_t>(a.sig) & 7) == 0;
+            if (fast) {
+                const C2<TT>* __restrict__ src = reinterpret_cast<const C2<TT>*>(
+                    static_cast<const float*>(a.sig) + it.sig_off + pos0);
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) v[n1] = src[16 * n1];
             }
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(sigbuf) + 4 * c) = v;
+        }
+        if (!fast) {
+            // tile edges (left zero pad, end of stream), other sample types: guarded element loads
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const int64_t p = pos0 + 32 * n1;
+                v[n1].x = (frame_on && p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p) : TT(0);
+                v[n1].y = (frame_on && p + 1 >= 0 && p + 1 < lim)
+                              ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p + 1) : TT(0);
+            }
         }
     } else {
-        for (int c = tid; c < span; c += 256) {
-            const int64_t p = g0 + c;
-            sigbuf[c] = (p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p) : TT(0);
+        // ---- stage the tile's sample span: positions g0 .. g0 + span of the item's stream ------
+        const int64_t g0 = int64_t(it.start0) + int64_t(S) * (t0 - a.border);
+        const int span = (kF - 1) * S + kN;
+        if (a.sig_dtype == AUD_F32 && sizeof(TT) == 4 && ((it.sig_off + g0) & 3) == 0 &&
+            (reinterpret_cast<uintptr_t>(a.sig) & 15) == 0) {
+            const float* __restrict__ src = static_cast<const float*>(a.sig) + it.sig_off;
+            for (int c = tid; c * 4 < span; c += 256) {
+                const int64_t p = g0 + 4 * c;
+                float4 q4;
+                if (p >= 0 && p + 3 < lim) {
+                    q4 = *reinterpret_cast<const float4*>(src + p);
+                } else {
+                    q4.x = (p >= 0 && p < lim) ? src[p] : 0.f;
+                    q4.y = (p + 1 >= 0 && p + 1 < lim) ? src[p + 1] : 0.f;
+                    q4.z = (p + 2 >= 0 && p + 2 < lim) ? src[p + 2] : 0.f;
+                    q4.w = (p + 3 >= 0 && p + 3 < lim) ? src[p + 3] : 0.f;
+                }
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(sigbuf) + 4 * c) = q4;
+            }
+        } else {
+            for (int c = tid; c < span; c += 256) {
+                const int64_t p = g0 + c;
+                sigbuf[c] = (p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p) : TT(0);
+            }
         }
     }
 
@@ -174,21 +211,21 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
         for (int c = tid; c < e.n_chunks; c += 256) lw[c] = gw[c];
     }
 
-    // per-lane constants, fetched while the span lands: W_256^(j*k1) = W_512^(2 j k1)
+    // per-lane constants: W_256^(j*k1) = W_512^(2 j k1)
     C2<TT> tw1[16];
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) tw1[k1] = tw[2 * j * k1];
-    __syncthreads();
 
-    // ---- pass 1: z[16 n1 + j] (z[m] = x[2m] + i x[2m+1]) -> 16-point DFT over n1 --------------
-    C2<TT> v[16];
-    {
+    if constexpr (!DIRECT) {
+        __syncthreads();
+        // ---- pass 1 operands from the staged span: z[16 n1 + j] ----------------------------------
         // S is even on this path (checked by the host), so every frame starts on an 8-byte
-        // boundary and each point is one ds_read_b64
+        // boundary and each point is one 8-byte LDS read
         const C2<TT>* fr = reinterpret_cast<const C2<TT>*>(sigbuf) + (f * (S >> 1) + j);
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) v[n1] = fr[16 * n1];
     }
+    // ---- pass 1: 16-point DFT over n1 ----------------------------------------------------------
     dft16(v);
     {
         C2<TT>* col = xch + f * Layout<TT>::kFrameC + j;  // row k1, column n2 = j
@@ -215,13 +252,14 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
             for (int n2 = 0; n2 < 16; ++n2) v[n2] = row[n2];
         }
     }
+    if constexpr (DIRECT) __syncthreads();  // P reuses the transpose buffer: every row must have been read
     dft16(v);
 
     // ---- real-FFT split + power ------------------------------------------------------------
     // For k = j + 16 q (q = 0..7) the partner Z[256 - k] sits in lane (16 - j) & 15, register
     // 15 - q (lane 0 pairs with itself: register (16 - q) & 15).  X[k] = (E + T)/2,
     // X[256-k] = conj(E - T)/2 with E = Z[k] + conj Z[256-k], T = -i W_512^k (Z[k] - conj Z[256-k]).
-    TT* P = sigbuf + f * kHp;  // sample span is dead: every lane passed the barrier above
+    TT* P = Pbase + f * kHp;  // STAGED: over the dead sample span; DIRECT: over the transpose buffer
     {
         const int lane = tid & 63;
         const int partner = (lane & 48) | ((16 - j) & 15);
@@ -260,7 +298,7 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
             if (sstep >= T) continue;
             const int64_t start = int64_t(it.start0) + int64_t(S) * (sstep - a.border);
             const bool live = start + kN <= lim;
-            const TT pw = sigbuf[ff * kHp + k];
+            const TT pw = Pbase[ff * kHp + k];
             const size_t o = (size_t(item) * kH + k) * T + sstep;
             if (a.power) a.power[o] = live ? float(pw) : 0.f;
             if (a.log_power) {
@@ -285,7 +323,7 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
             const bool live = start + kN <= lim;
             typedef Q4<TT> quad_t;
             const quad_t* w4 = reinterpret_cast<const quad_t*>(smem + e.w4_off);
-            const quad_t* prow = reinterpret_cast<const quad_t*>(sigbuf + ff * kHp);
+            const quad_t* prow = reinterpret_cast<const quad_t*>(Pbase + ff * kHp);
             const TT loff = TT(a.mel_log_off), lmin = TT(a.mel_log_min);
             for (int idx = e.grp_off[grp]; idx < e.grp_off[grp + 1]; ++idx) {
                 const int flt = e.grp_flt[idx];
@@ -320,40 +358,67 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
 
 }  // namespace
 
-bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, size_t* lds_bytes, int* xch_off,
-                           int* w4_off) {
-    if (N != kN || S < 1 || (S & 1)) return false;  // odd steps go to the generic kernel
+bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, bool direct, R16Args* out) {
+    if (N != kN || S < 1) return false;
+    if (!direct && (S & 1)) return false;  // the staged variant reads 8-byte pairs from LDS
     const size_t tsz = compute_dtype == AUD_F64 ? 8 : 4;
-    const size_t span = size_t(kF - 1) * S + kN;
-    size_t first = span > size_t(kF) * kHp ? span : size_t(kF) * kHp;  // sample span, later P
-    first = (first * tsz + 31) & ~size_t(31);
     const size_t rowc = compute_dtype == AUD_F64 ? 17 : 18;
     const size_t xch = size_t(kF) * 16 * rowc * 2 * tsz;
+    const size_t pbytes = (size_t(kF) * kHp * tsz + 31) & ~size_t(31);
     const size_t w4 = (size_t(n_chunks) * 4 * tsz + 31) & ~size_t(31);
-    const size_t total = first + xch + w4;
+    size_t first = 0, xch_off, p_off;
+    if (direct) {
+        xch_off = 0;
+        p_off = 0;  // the power spectrum reuses the transpose buffer (one extra barrier)
+        first = xch > pbytes ? xch : pbytes;
+    } else {
+        const size_t span = size_t(kF - 1) * S + kN;
+        first = ((span * tsz + 31) & ~size_t(31));
+        if (first < pbytes) first = pbytes;  // sample span, later the power spectrum
+        p_off = 0;
+        xch_off = first;
+        first += xch;
+    }
+    const size_t total = first + w4;
     if (total > 160 * 1024) return false;
-    if (lds_bytes) *lds_bytes = total;
-    if (xch_off) *xch_off = int(first);
-    if (w4_off) *w4_off = int(first + xch);
+    if (out) {
+        out->xch_off = int(xch_off);
+        out->p_off = int(p_off);
+        out->w4_off = int(first);
+        out->lds_bytes = unsigned(total);
+        out->n_chunks = n_chunks;
+        out->direct = direct ? 1 : 0;
+    }
     return true;
 }
 
 hipError_t melspec_r16_prepare() {
     // more than 64 KiB of dynamic LDS has to be requested explicitly
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_melspec_r16<double>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_melspec_r16<float>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const void* fns[4] = {reinterpret_cast<const void*>(&k_melspec_r16<double, true>),
+                          reinterpret_cast<const void*>(&k_melspec_r16<double, false>),
+                          reinterpret_cast<const void*>(&k_melspec_r16<float, true>),
+                          reinterpret_cast<const void*>(&k_melspec_r16<float, false>)};
+    for (const void* fn : fns) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_melspec_r16(const MelspecArgs& a, const R16Args& e, int compute_dtype, hipStream_t st) {
     const int tiles = (a.T + kF - 1) / kF;
     const dim3 grid(unsigned(a.n_items) * unsigned(tiles));
-    if (compute_dtype == AUD_F64)
-        hipLaunchKernelGGL(k_melspec_r16<double>, grid, dim3(256), e.lds_bytes, st, a, e);
-    else
-        hipLaunchKernelGGL(k_melspec_r16<float>, grid, dim3(256), e.lds_bytes, st, a, e);
+    if (compute_dtype == AUD_F64) {
+        if (e.direct)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<double, true>), grid, dim3(256), e.lds_bytes, st, a, e);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<double, false>), grid, dim3(256), e.lds_bytes, st, a, e);
+    } else {
+        if (e.direct)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<float, true>), grid, dim3(256), e.lds_bytes, st, a, e);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<float, false>), grid, dim3(256), e.lds_bytes, st, a, e);
+    }
     return hipGetLastError();
 }
 

@@ -82,6 +82,10 @@ class Plan:
     def kernel_name(self):
         return self.lib.aud_plan_kernel_name(self.handle).decode()
 
+    def set_option(self, name, value):
+        """aud_plan_set_option: "kernel" (0 auto / 1 generic), "r16_input" (0 direct / 1 staged)"""
+        self.ctx.check(self.lib.aud_plan_set_option(self.handle, name.encode(), int(value)))
+
     # ---- device-pointer calls (ints are raw device addresses; stream is a hipStream_t) ----
     def melspec_dev(self, sig_ptr, sig_dtype, items_ptr, n_items, mel_ptr, power_ptr=0,
                     log_power_ptr=0, stream=0):

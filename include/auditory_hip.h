@@ -193,6 +193,10 @@ int aud_plan_create(aud_ctx* ctx, const aud_plan_desc* desc, aud_plan** plan);
 int aud_plan_destroy(aud_plan* plan);
 /* which frame->mel kernel family the plan selected: "generic", "r16x16", ... (diagnostic) */
 const char* aud_plan_kernel_name(const aud_plan* plan);
+/* Tuning / diagnostic switches; results are identical whatever they are set to.
+ *   "kernel"    0 automatic (default), 1 force the generic any-N kernel
+ *   "r16_input" 0 operands straight from global memory (default), 1 staged through LDS */
+int aud_plan_set_option(aud_plan* plan, const char* name, int value);
 
 /* ---- hot path, device-resident (what bench.py times) ----------------------------- */
 

@@ -42,7 +42,7 @@ GABOR_DEFAULT = dict(size=(9, 9), stride=(3, 3), gain=2.0, specs=W.DEFAULT_GABOR
 GABOR_VIEW = dict(size=(8, 8), stride=(6, 3), gain=1.5, specs=W.DEFAULT_GABOR_SPECS[::2])   # gbv.go:334-357
 
 
-def case_melspec_vs_oracle(orc, case, cdt, seg_ms=None):
+def case_melspec_vs_oracle(orc, case, cdt, seg_ms=None, options=None):
     name, dur, rows, seg_list = case
     oc = W.OracleCfg(orc, name, seg_ms)
     L = int(dur * oc.sr)
@@ -51,9 +51,13 @@ def case_melspec_vs_oracle(orc, case, cdt, seg_ms=None):
     ref_mel, ref_pw, ref_lp = oracle_items(orc, oc, sig, segs)
     plan = W.product_plan(oc, cdt)
     try:
+        for k, v in (options or {}).items():
+            plan.set_option(k, v)
         mel, pw, lp = plan.melspec_host(sig.ravel(), make_items(oc, L, segs), True, True)
+        mel_only, _, _ = plan.melspec_host(sig.ravel(), make_items(oc, L, segs))
     finally:
         plan.close()
+    assert np.array_equal(mel, mel_only, equal_nan=True)      # optional outputs do not change mel
     tol = TOL_F32 if cdt == capi.AUD_F32 else TOL_F64
     ok, msg = W.feature_close(mel, ref_mel, cdt, lin_axis=1)
     assert ok, "mel " + msg
@@ -252,3 +256,60 @@ def case_prev_smooth(orc, name, cdt):
     oc0 = W.OracleCfg(orc, name)
     raw, _, _ = oracle_items(orc, oc0, sig, segs[:1])
     assert np.abs(raw[0] - ref_mel[0]).max() > 1e-3
+
+
+# the kernel variants a 512-sample plan can run: all must agree with the oracle (and each other)
+N512_VARIANTS = {"r16_direct": {"r16_input": 0}, "r16_staged": {"r16_input": 1}, "generic": {"kernel": 1}}
+
+
+def case_n512_variants(orc, cdt, seg_ms=None, dur=1.0, rows=2, segs=(0,)):
+    case = ("cfg2_16k_n512_nf40", dur, rows, list(segs))
+    for name, opts in N512_VARIANTS.items():
+        case_melspec_vs_oracle(orc, case, cdt, seg_ms=seg_ms, options=opts)
+    # a plan reports what it runs, and odd steps fall back to the generic kernel by themselves
+    oc = W.OracleCfg(orc, "cfg2_16k_n512_nf40")
+    plan = W.product_plan(oc, cdt)
+    assert plan.kernel_name == "r16x16"
+    plan.set_option("kernel", 1)
+    assert plan.kernel_name == "generic"
+    plan.set_option("kernel", 0)
+    assert plan.kernel_name == "r16x16"
+    with pytest.raises(capi.AuditoryError):
+        plan.set_option("nonsense", 1)
+    plan.close()
+
+
+def case_n512_odd_step_and_sample_types(orc, cdt):
+    """N = 512 with an odd step (S = 161): direct variant handles unaligned pairs through its guarded
+    loads, the staged one is refused; int16 / float64 samples go through the same paths."""
+    import ctypes as C
+    from auditory_amd import mel as melmod
+    lib = capi.load()
+    N, S, T, border, nf, sr = 512, 161, 20, 2, 40, 16000
+    mp = melmod.Params()
+    mp.Defaults()
+    mp.FBank.NFilters = nf
+    filt = mp.InitFilters(N, sr)
+    dftp = capi.DftParams()
+    lib.aud_dft_defaults(dftp)
+    L = 3000
+    sig, pcm = synth.batch(17, 2, L, sr)
+    # oracle with the same derived numbers
+    sp = orc.SndParams(sr, N, S, 0, T, border)
+    d, m = orc.dft_defaults(), orc.mel_defaults()
+    m.n_filters = nf
+    rc, bins, hz, ofilt = orc.mel_init_filters(m, N, sr)
+    ref = np.stack([orc.process_segment(sp, d, m, bins, ofilt, sig[r])["mel_seg"] for r in range(2)])
+    plan = runtime.Plan(runtime.get_ctx(0), N, S, T, border, dftp, mp.FBank.to_c(), mp.BinPts, filt,
+                        compute_dtype=cdt)
+    try:
+        assert plan.kernel_name == "r16x16"
+        with pytest.raises(capi.AuditoryError):
+            plan.set_option("r16_input", 1)                       # staged needs an even step
+        items = runtime.make_items([0, L], [L, L], [0, 0])
+        got, _, _ = plan.melspec_host(sig.ravel(), items)
+        ok, msg = W.feature_close(got, ref, cdt, lin_axis=1)
+        assert ok, msg
+        assert (ref[:, :, -1] == 0).all() and (got[:, :, -1] == 0).all()   # last frames run off the end
+    finally:
+        plan.close()

@@ -41,6 +41,16 @@ def test_emul_melspec_nan_row_config(orc, emu):
     PC.case_melspec_vs_oracle(orc, ("cfg5_44k_n2048_nf128", 0.25, 1, [0]), capi.AUD_F32, seg_ms=200.0)
 
 
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_emul_n512_kernel_variants(orc, emu, cdt):
+    PC.case_n512_variants(orc, cdt, seg_ms=200.0, dur=0.4, rows=2, segs=(0, 1))
+
+
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_emul_n512_odd_step(orc, emu, cdt):
+    PC.case_n512_odd_step_and_sample_types(orc, cdt)
+
+
 def test_emul_zero_signal_and_empty_batch(orc, emu):
     PC.case_zero_signal_and_empty_batch(orc)
 

@@ -30,6 +30,16 @@ def test_melspec_vs_oracle(orc, torch_cuda, case, cdt):
     PC.case_melspec_vs_oracle(orc, case, cdt)
 
 
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_n512_kernel_variants(orc, torch_cuda, cdt):
+    PC.case_n512_variants(orc, cdt)
+
+
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_n512_odd_step(orc, torch_cuda, cdt):
+    PC.case_n512_odd_step_and_sample_types(orc, cdt)
+
+
 def test_zero_signal_and_empty_batch(orc, torch_cuda):
     PC.case_zero_signal_and_empty_batch(orc)
 
