@@ -36,7 +36,7 @@ struct aud_plan {
     bool use_r16 = false;
     bool r16_tables = false;  // group schedule / chunked weights uploaded
     int r16_chunks = 0;
-    aud::R16Args r16{};
+    aud::FastArgs r16{};
     int* d_grp = nullptr;  // [17 + nf + 3 nf]: group offsets, filter ids, per-filter chunk info
     void* d_w4 = nullptr;  // chunked triangle weights
     void* d_tw = nullptr;
@@ -252,7 +252,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
     }
     if (r16_chunks == 0) r16_chunks = 1;
     p->r16_chunks = r16_chunks;
-    aud::R16Args r16cfg;
+    aud::FastArgs r16cfg;
     std::memset(&r16cfg, 0, sizeof(r16cfg));
     bool r16_ok = aud::melspec_r16_supported(N, d->step_samples, d->compute_dtype, r16_chunks, true, &r16cfg);
     if (rc == AUD_OK && r16_ok) {
@@ -355,7 +355,7 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
     if (key == "r16_input") {  // 0 = operands straight from global memory, 1 = staged through LDS
         if (!p->r16_tables) return fail(c, AUD_EINVAL, "plan has no r16x16 kernel");
         if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "r16_input: 0 (direct) or 1 (staged)");
-        aud::R16Args cfg = p->r16;
+        aud::FastArgs cfg = p->r16;
         if (!aud::melspec_r16_supported(p->d.win_samples, p->d.step_samples, p->d.compute_dtype, p->r16_chunks,
                                         value == 0, &cfg))
             return fail(c, AUD_EINVAL, "this r16x16 variant does not support the plan (odd step?)");

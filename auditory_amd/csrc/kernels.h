@@ -56,8 +56,8 @@ struct GaborArgs {
     float* out;
 };
 
-// extra arguments of the 512-point (16 x 16 in registers) kernel
-struct R16Args {
+// extra arguments of the register-resident two-pass kernels (r16x16 for N = 512, r25x8 for N = 400)
+struct FastArgs {
     int direct;            // 1: pass-1 operands straight from global memory, 0: staged through LDS
     int xch_off;           // byte offset of the transpose buffer inside dynamic LDS
     int p_off;             // byte offset of the power spectrum (aliases the span or the transpose buffer)
@@ -88,9 +88,9 @@ int melspec_generic_pick_F(int M, int compute_dtype);
 hipError_t launch_melspec_generic(const MelspecArgs& a, int compute_dtype, hipStream_t st);
 
 // N = 512 fast path
-bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, bool direct, R16Args* out);
+bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, bool direct, FastArgs* out);
 hipError_t melspec_r16_prepare();
-hipError_t launch_melspec_r16(const MelspecArgs& a, const R16Args& e, int compute_dtype, hipStream_t st);
+hipError_t launch_melspec_r16(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
 
 hipError_t launch_gabor(const GaborArgs& a, int compute_dtype, hipStream_t st);
 

@@ -23,96 +23,14 @@
 //     so that all 256 threads carry about the same number of taps.
 //
 // Reference semantics: sound/sndenv.go:438-478, dft/dft.go:53-85, mel/mel.go:120-153.
-#include "kernels.h"
+#include "device_common.h"
 
 namespace aud {
 namespace {
 
+// forward 16-point DFT of v[0..15], natural order in and out
 template <typename TT>
-struct alignas(2 * sizeof(TT)) C2 {
-    TT x, y;
-};
-// four consecutive bins / weights moved as one 16-byte (f32) or 32-byte (f64) access
-template <typename TT>
-struct alignas(4 * sizeof(TT)) Q4 {
-    TT x, y, z, w;
-};
-// two complex values moved as one 16-byte (f32) LDS access
-template <typename TT>
-struct alignas(16) C2x2 {
-    C2<TT> a, b;
-};
-
-template <typename TT>
-__device__ __forceinline__ C2<TT> cadd(C2<TT> a, C2<TT> b) { return {a.x + b.x, a.y + b.y}; }
-template <typename TT>
-__device__ __forceinline__ C2<TT> csub(C2<TT> a, C2<TT> b) { return {a.x - b.x, a.y - b.y}; }
-template <typename TT>
-__device__ __forceinline__ C2<TT> cmul(C2<TT> a, C2<TT> b) {
-    return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
-}
-// multiply by -i and by +i
-template <typename TT>
-__device__ __forceinline__ C2<TT> mul_mi(C2<TT> a) { return {a.y, -a.x}; }
-template <typename TT>
-__device__ __forceinline__ C2<TT> mul_pi(C2<TT> a) { return {-a.y, a.x}; }
-
-// forward 4-point DFT in place: u[k] = sum_n u[n] exp(-2 pi i n k / 4)
-template <typename TT>
-__device__ __forceinline__ void dft4(C2<TT>& u0, C2<TT>& u1, C2<TT>& u2, C2<TT>& u3) {
-    const C2<TT> s0 = cadd(u0, u2), d0 = csub(u0, u2);
-    const C2<TT> s1 = cadd(u1, u3), d1 = csub(u1, u3);
-    u0 = cadd(s0, s1);
-    u2 = csub(s0, s1);
-    u1 = cadd(d0, mul_mi(d1));
-    u3 = cadd(d0, mul_pi(d1));
-}
-
-// forward 16-point DFT of v[0..15] (natural order in, natural order out), as 4 x 4:
-// X[k1 + 4 k2] = sum_b W16^(b k1) W4^(b k2) sum_a v[4a + b] W4^(a k1)
-template <typename TT>
-__device__ __forceinline__ void dft16(C2<TT> (&v)[16]) {
-    const TT c1 = TT(0.92387953251128675613L);  // cos(pi/8)
-    const TT s1 = TT(0.38268343236508977173L);  // sin(pi/8)
-    const TT r2 = TT(0.70710678118654752440L);  // sqrt(1/2)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);
-    // now v[4*k1 + b] = t[b][k1]; twiddle by W16^(b*k1)
-    // b = 1: W^1, W^2, W^3
-    v[4 + 1] = cmul(v[4 + 1], C2<TT>{c1, -s1});
-    v[8 + 1] = C2<TT>{(v[8 + 1].x + v[8 + 1].y) * r2, (v[8 + 1].y - v[8 + 1].x) * r2};
-    v[12 + 1] = cmul(v[12 + 1], C2<TT>{s1, -c1});
-    // b = 2: W^2, W^4 = -i, W^6
-    v[4 + 2] = C2<TT>{(v[4 + 2].x + v[4 + 2].y) * r2, (v[4 + 2].y - v[4 + 2].x) * r2};
-    v[8 + 2] = mul_mi(v[8 + 2]);
-    v[12 + 2] = C2<TT>{(v[12 + 2].y - v[12 + 2].x) * r2, -(v[12 + 2].x + v[12 + 2].y) * r2};
-    // b = 3: W^3, W^6, W^9
-    v[4 + 3] = cmul(v[4 + 3], C2<TT>{s1, -c1});
-    v[8 + 3] = C2<TT>{(v[8 + 3].y - v[8 + 3].x) * r2, -(v[8 + 3].x + v[8 + 3].y) * r2};
-    v[12 + 3] = cmul(v[12 + 3], C2<TT>{-c1, s1});
-    // second layer: for each k1, a 4-point DFT over b; outputs X[k1 + 4 k2] land in v[4*k1 + k2]
-#pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1) dft4(v[4 * k1 + 0], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
-    // v[4*k1 + k2] holds X[k1 + 4*k2]: transpose the 4x4 register tile into natural order
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = a + 1; b < 4; ++b) {
-            const C2<TT> t = v[4 * a + b];
-            v[4 * a + b] = v[4 * b + a];
-            v[4 * b + a] = t;
-        }
-}
-
-__device__ __forceinline__ float dev_log(float v) { return logf(v); }
-__device__ __forceinline__ double dev_log(double v) { return log(v); }
-
-template <typename TT>
-__device__ __forceinline__ TT load_sample(const void* sig, int dtype, int64_t i) {
-    if (dtype == AUD_F32) return TT(static_cast<const float*>(sig)[i]);
-    if (dtype == AUD_F64) return TT(static_cast<const double*>(sig)[i]);
-    return TT(static_cast<const int16_t*>(sig)[i]) / TT(0x7FFF);  // sound.go:138
-}
+__device__ __forceinline__ void dft16(C2<TT> (&v)[16]) { SmallDft<TT, 16>::run(v, nullptr, 0); }
 
 constexpr int kF = 16;    // frames per workgroup
 constexpr int kM = 256;   // complex FFT length
@@ -129,7 +47,7 @@ struct Layout {
 };
 
 template <typename TT, bool DIRECT>
-__global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const R16Args e) {
+__global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const FastArgs e) {
     unsigned char* smem = dyn_lds();
     TT* sigbuf = reinterpret_cast<TT*>(smem);                   // STAGED only: [span]
     TT* Pbase = reinterpret_cast<TT*>(smem + e.p_off);          // power spectrum [16][kHp]
@@ -204,12 +122,7 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
     }
 
     // the chunked mel weights (a few KB) ride along into LDS; first used after the last barrier
-    {
-        typedef Q4<TT> quad_t;
-        const quad_t* __restrict__ gw = static_cast<const quad_t*>(e.w4);
-        quad_t* lw = reinterpret_cast<quad_t*>(smem + e.w4_off);
-        for (int c = tid; c < e.n_chunks; c += 256) lw[c] = gw[c];
-    }
+    stage_mel_weights<TT, 256>(e, smem, tid);
 
     // per-lane constants: W_256^(j*k1) = W_512^(2 j k1)
     C2<TT> tw1[16];
@@ -289,76 +202,12 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
     }
     __syncthreads();
 
-    // ---- optional PowerSegment / LogPowerSegment (dft.go:70-83) -------------------------------
-    if (a.power || a.log_power) {
-        const TT off = TT(a.dft_log_off), lmin = TT(a.dft_log_min);
-        for (int w = tid; w < kF * kH; w += 256) {
-            const int k = w >> 4, ff = w & 15;
-            const int sstep = t0 + ff;
-            if (sstep >= T) continue;
-            const int64_t start = int64_t(it.start0) + int64_t(S) * (sstep - a.border);
-            const bool live = start + kN <= lim;
-            const TT pw = Pbase[ff * kHp + k];
-            const size_t o = (size_t(item) * kH + k) * T + sstep;
-            if (a.power) a.power[o] = live ? float(pw) : 0.f;
-            if (a.log_power) {
-                float lp = 0.f;
-                if (live && a.comp_log_pow) {
-                    const TT vv = pw + off;
-                    lp = float(vv == TT(0) ? lmin : dev_log(vv));
-                }
-                a.log_power[o] = lp;
-            }
-        }
-    }
-
-    // ---- mel triangles + log (mel.go:120-153): 16 balanced filter groups x 16 frames ----------
-    // Each triangle is stored as 4-bin chunks aligned to bins 0, 4, 8, ... (zero weights outside
-    // the triangle), so one 16-byte LDS read + one 16-byte table read feed four FMAs, in bin order.
-    {
-        const int ff = tid & 15, grp = tid >> 4;
-        const int sstep = t0 + ff;
-        if (sstep < T) {
-            const int64_t start = int64_t(it.start0) + int64_t(S) * (sstep - a.border);
-            const bool live = start + kN <= lim;
-            typedef Q4<TT> quad_t;
-            const quad_t* w4 = reinterpret_cast<const quad_t*>(smem + e.w4_off);
-            const quad_t* prow = reinterpret_cast<const quad_t*>(Pbase + ff * kHp);
-            const TT loff = TT(a.mel_log_off), lmin = TT(a.mel_log_min);
-            for (int idx = e.grp_off[grp]; idx < e.grp_off[grp + 1]; ++idx) {
-                const int flt = e.grp_flt[idx];
-                float res = 0.f;
-                if (live) {
-                    const int c0 = e.chunk[3 * flt], nc = e.chunk[3 * flt + 1], wo = e.chunk[3 * flt + 2];
-                    TT sum = TT(0);
-#pragma unroll 4
-                    for (int c = 0; c < nc; ++c) {
-                        const quad_t pw = prow[c0 + c];
-                        const quad_t ww = w4[wo + c];
-                        sum += ww.x * pw.x;
-                        sum += ww.y * pw.y;
-                        sum += ww.z * pw.z;
-                        sum += ww.w * pw.w;
-                    }
-                    sum += loff;
-                    TT val = (sum == TT(0)) ? lmin : dev_log(sum);
-                    if (a.renorm) {
-                        val -= TT(a.renorm_min);
-                        if (val < TT(0)) val = TT(0);
-                        val *= TT(a.renorm_scale);
-                        if (val > TT(1)) val = TT(1);
-                    }
-                    res = float(val);
-                }
-                a.mel[(size_t(item) * a.nf + flt) * T + sstep] = res;
-            }
-        }
-    }
+    tile_epilogue<TT, 256, kF>(a, e, Pbase, kHp, smem, it, item, t0, tid);
 }
 
 }  // namespace
 
-bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, bool direct, R16Args* out) {
+bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, bool direct, FastArgs* out) {
     if (N != kN || S < 1) return false;
     if (!direct && (S & 1)) return false;  // the staged variant reads 8-byte pairs from LDS
     const size_t tsz = compute_dtype == AUD_F64 ? 8 : 4;
@@ -405,7 +254,7 @@ hipError_t melspec_r16_prepare() {
     return hipSuccess;
 }
 
-hipError_t launch_melspec_r16(const MelspecArgs& a, const R16Args& e, int compute_dtype, hipStream_t st) {
+hipError_t launch_melspec_r16(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st) {
     const int tiles = (a.T + kF - 1) / kF;
     const dim3 grid(unsigned(a.n_items) * unsigned(tiles));
     if (compute_dtype == AUD_F64) {

@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--launch", choices=["graph", "eager"], default="graph",
                     help="graph: the K steps are replayed from hipGraphs of up to 50 captured steps each "
                          "(a ~5 us kernel is otherwise bound by the Python/ctypes launch path)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="aud_plan_set_option switches for A/B runs, e.g. r16_input=1 (staged) or kernel=1 (generic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
     args = ap.parse_args()
@@ -133,6 +135,9 @@ def main():
     cdt = capi.AUD_F32 if args.compute == "f32" else capi.AUD_F64
     gab = dict(size=(9, 9), stride=(3, 3), gain=2.0, specs=W.DEFAULT_GABOR_SPECS) if args.workload == "cfg4" else None
     plan = W.product_plan(oc, cdt, gab, device=local_rank)
+    for kv in args.option:
+        k, v = kv.split("=")
+        plan.set_option(k, int(v))
     bp = BatchProcessor(plan, dev)
     dsig = torch.from_numpy(sig64.astype(np.float32)).to(dev).view(-1)
     items = bp.upload_items(runtime.make_items(np.arange(B) * L, [L] * B, [0] * B))
@@ -249,6 +254,7 @@ def main():
                                         "T=504 frames, 128 mel" % B}[args.workload],
                    "batch_per_gpu": B, "win_samples": oc.N, "step_samples": oc.S,
                    "segment_steps": oc.T, "n_mel": oc.nf, "kernel": plan.kernel_name, "launch": launch_mode,
+                   "options": args.option,
                    "sharding": "utterances, contiguous block per rank"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
