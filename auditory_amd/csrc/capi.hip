@@ -33,8 +33,10 @@ struct aud_plan {
     int nfac = 0;
     int fac[aud::kMaxFactors] = {0};
     int F_generic = 0;
-    bool use_r16 = false;
-    bool r16_tables = false;  // group schedule / chunked weights uploaded
+    // register-resident kernel of this plan, if its window length has one
+    enum Fast { kNoFast = 0, kR16 = 1, kR25 = 2 };
+    int fast_kind = kNoFast;   // which family the tables below were built for
+    bool use_fast = false;     // false: generic kernel (no fast family, or forced by an option)
     int r16_chunks = 0;
     aud::FastArgs r16{};
     int* d_grp = nullptr;  // [17 + nf + 3 nf]: group offsets, filter ids, per-filter chunk info
@@ -252,12 +254,22 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
     }
     if (r16_chunks == 0) r16_chunks = 1;
     p->r16_chunks = r16_chunks;
-    aud::FastArgs r16cfg;
-    std::memset(&r16cfg, 0, sizeof(r16cfg));
-    bool r16_ok = aud::melspec_r16_supported(N, d->step_samples, d->compute_dtype, r16_chunks, true, &r16cfg);
-    if (rc == AUD_OK && r16_ok) {
-        // balance the mel filters over 16 thread groups by tap count (longest first, LPT)
-        std::vector<int> order(nf), load(16, 0), owner(nf);
+    aud::FastArgs fastcfg;
+    std::memset(&fastcfg, 0, sizeof(fastcfg));
+    int fast_kind = aud_plan::kNoFast, n_groups = 0;
+    const char* fast_name = "generic";
+    if (aud::melspec_r16_supported(N, d->step_samples, d->compute_dtype, r16_chunks, true, &fastcfg)) {
+        fast_kind = aud_plan::kR16;
+        n_groups = 16;  // 256 threads = 16 frames x 16 filter groups
+        fast_name = "r16x16";
+    } else if (aud::melspec_r25_supported(N, d->step_samples, d->compute_dtype, r16_chunks, &fastcfg)) {
+        fast_kind = aud_plan::kR25;
+        n_groups = 8;  // 128 threads = 16 frames x 8 filter groups
+        fast_name = "r25x8";
+    }
+    if (rc == AUD_OK && fast_kind != aud_plan::kNoFast) {
+        // balance the mel filters over the thread groups by tap count (longest first, LPT)
+        std::vector<int> order(nf), load(n_groups, 0), owner(nf);
         for (int f = 0; f < nf; ++f) order[f] = f;
         auto taps = [&](int f) {  // cost model: 4-bin chunks + a fixed per-filter epilogue (log, store)
             const int lo = d->bin_pts[f], hi = d->bin_pts[f + 2];
@@ -266,17 +278,17 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return taps(x) > taps(y); });
         for (int f : order) {
             int g = 0;
-            for (int c = 1; c < 16; ++c)
-                if (load[c] < load[g]) g = c;
+            for (int cnd = 1; cnd < n_groups; ++cnd)
+                if (load[cnd] < load[g]) g = cnd;
             owner[f] = g;
             load[g] += taps(f);
         }
         std::vector<int> tab(17 + nf + 3 * nf, 0);
         int pos = 0;
-        for (int g = 0; g < 16; ++g) {
+        for (int g = 0; g < 16; ++g) {  // groups past n_groups stay empty
             tab[g] = pos;
             for (int f = 0; f < nf; ++f)
-                if (owner[f] == g) tab[17 + pos++] = f;
+                if (g < n_groups && owner[f] == g) tab[17 + pos++] = f;
         }
         tab[16] = pos;
         // triangles as 4-bin chunks aligned to bins 0, 4, 8, ...; table cells are addressed by the
@@ -297,13 +309,15 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
         if (w4.empty()) w4.assign(4, 0.0);
         rc = upload(c, reinterpret_cast<void**>(&p->d_grp), tab.data(), tab.size() * sizeof(int));
         if (rc == AUD_OK) rc = upload_real(c, &p->d_w4, w4.data(), w4.size(), d->compute_dtype);
-        if (rc == AUD_OK && aud::melspec_r16_prepare() != hipSuccess)
-            rc = fail(c, AUD_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
         if (rc == AUD_OK) {
-            p->use_r16 = true;
-            p->r16_tables = true;
-            p->family = "r16x16";
-            p->r16 = r16cfg;
+            const hipError_t pe = fast_kind == aud_plan::kR16 ? aud::melspec_r16_prepare() : aud::melspec_r25_prepare();
+            if (pe != hipSuccess) rc = fail(c, AUD_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        }
+        if (rc == AUD_OK) {
+            p->fast_kind = fast_kind;
+            p->use_fast = true;
+            p->family = fast_name;
+            p->r16 = fastcfg;
             p->r16.grp_off = p->d_grp;
             p->r16.grp_flt = p->d_grp + 17;
             p->r16.chunk = p->d_grp + 17 + nf;
@@ -339,21 +353,21 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
     const std::string key(name);
     if (key == "kernel") {  // 0 = automatic choice, 1 = force the generic any-N kernel
         if (value == 1) {
-            p->use_r16 = false;
+            p->use_fast = false;
             p->family = "generic";
             return AUD_OK;
         }
         if (value == 0) {
-            if (p->r16_tables) {
-                p->use_r16 = true;
-                p->family = "r16x16";
+            if (p->fast_kind != aud_plan::kNoFast) {
+                p->use_fast = true;
+                p->family = p->fast_kind == aud_plan::kR16 ? "r16x16" : "r25x8";
             }
             return AUD_OK;
         }
         return fail(c, AUD_EINVAL, "kernel: 0 (auto) or 1 (generic)");
     }
     if (key == "r16_input") {  // 0 = operands straight from global memory, 1 = staged through LDS
-        if (!p->r16_tables) return fail(c, AUD_EINVAL, "plan has no r16x16 kernel");
+        if (p->fast_kind != aud_plan::kR16) return fail(c, AUD_EINVAL, "plan has no r16x16 kernel");
         if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "r16_input: 0 (direct) or 1 (staged)");
         aud::FastArgs cfg = p->r16;
         if (!aud::melspec_r16_supported(p->d.win_samples, p->d.step_samples, p->d.compute_dtype, p->r16_chunks,
@@ -388,8 +402,10 @@ int aud_melspec_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
     a.mel = mel;
     a.power = power;
     a.log_power = log_power;
-    if (p->use_r16)
+    if (p->use_fast && p->fast_kind == aud_plan::kR16)
         AUD_HIP(c, aud::launch_melspec_r16(a, p->r16, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
+    else if (p->use_fast && p->fast_kind == aud_plan::kR25)
+        AUD_HIP(c, aud::launch_melspec_r25(a, p->r16, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
     else
         AUD_HIP(c, aud::launch_melspec_generic(a, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
     if (smooth) {

@@ -92,6 +92,11 @@ bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, bool d
 hipError_t melspec_r16_prepare();
 hipError_t launch_melspec_r16(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
 
+// N = 400 fast path
+bool melspec_r25_supported(int N, int S, int compute_dtype, int n_chunks, FastArgs* out);
+hipError_t melspec_r25_prepare();
+hipError_t launch_melspec_r25(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
+
 hipError_t launch_gabor(const GaborArgs& a, int compute_dtype, hipStream_t st);
 
 }  // namespace aud

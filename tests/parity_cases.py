@@ -313,3 +313,14 @@ def case_n512_odd_step_and_sample_types(orc, cdt):
         assert (ref[:, :, -1] == 0).all() and (got[:, :, -1] == 0).all()   # last frames run off the end
     finally:
         plan.close()
+
+
+def case_n400_variants(orc, cdt, seg_ms=None, dur=1.0, rows=2, segs=(0,)):
+    """25 ms @ 16 kHz (N = 400): the r25x8 kernel and the generic kernel, both against the oracle"""
+    for name in ("cfg2_16k_n400_nf40", "sndenv_16k_n400_nf32"):
+        oc = W.OracleCfg(orc, name, seg_ms)
+        plan = W.product_plan(oc, cdt)
+        assert plan.kernel_name == "r25x8"
+        plan.close()
+        for opts in ({}, {"kernel": 1}):
+            case_melspec_vs_oracle(orc, (name, dur, rows, list(segs)), cdt, seg_ms=seg_ms, options=opts)

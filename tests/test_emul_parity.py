@@ -47,6 +47,11 @@ def test_emul_n512_kernel_variants(orc, emu, cdt):
 
 
 @pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_emul_n400_kernel_variants(orc, emu, cdt):
+    PC.case_n400_variants(orc, cdt, seg_ms=200.0, dur=0.45, rows=2, segs=(0, 1, 2))
+
+
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
 def test_emul_n512_odd_step(orc, emu, cdt):
     PC.case_n512_odd_step_and_sample_types(orc, cdt)
 
