@@ -34,7 +34,7 @@ struct aud_plan {
     int fac[aud::kMaxFactors] = {0};
     int F_generic = 0;
     // register-resident kernel of this plan, if its window length has one
-    enum Fast { kNoFast = 0, kR16 = 1, kR25 = 2 };
+    enum Fast { kNoFast = 0, kR16 = 1, kR25 = 2, kR1024 = 3 };
     int fast_kind = kNoFast;   // which family the tables below were built for
     bool use_fast = false;     // false: generic kernel (no fast family, or forced by an option)
     int r16_chunks = 0;
@@ -266,6 +266,10 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
         fast_kind = aud_plan::kR25;
         n_groups = 8;  // 128 threads = 16 frames x 8 filter groups
         fast_name = "r25x8";
+    } else if (aud::melspec_r1024_supported(N, d->step_samples, d->compute_dtype, r16_chunks, &fastcfg)) {
+        fast_kind = aud_plan::kR1024;
+        n_groups = 64;  // 256 threads = 4 frames x 64 filter groups
+        fast_name = "r16x16x4";
     }
     if (rc == AUD_OK && fast_kind != aud_plan::kNoFast) {
         // balance the mel filters over the thread groups by tap count (longest first, LPT)
@@ -283,20 +287,21 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
             owner[f] = g;
             load[g] += taps(f);
         }
-        std::vector<int> tab(17 + nf + 3 * nf, 0);
+        const int goff = n_groups + 1;  // table: [n_groups + 1 offsets][nf filter ids][nf x 3 chunk info]
+        std::vector<int> tab(goff + nf + 3 * nf, 0);
         int pos = 0;
-        for (int g = 0; g < 16; ++g) {  // groups past n_groups stay empty
+        for (int g = 0; g < n_groups; ++g) {
             tab[g] = pos;
             for (int f = 0; f < nf; ++f)
-                if (g < n_groups && owner[f] == g) tab[17 + pos++] = f;
+                if (owner[f] == g) tab[goff + pos++] = f;
         }
-        tab[16] = pos;
+        tab[n_groups] = pos;
         // triangles as 4-bin chunks aligned to bins 0, 4, 8, ...; table cells are addressed by the
         // reference's flat offset f*(nf+2) + (bin - lo), weights outside [lo, hi] are zero
         std::vector<double> w4;
         for (int f = 0; f < nf; ++f) {
             const int lo = d->bin_pts[f], hi = d->bin_pts[f + 2];
-            int* ci = &tab[17 + nf + 3 * f];
+            int* ci = &tab[goff + nf + 3 * f];
             ci[0] = lo >> 2;
             ci[1] = hi >= lo ? (hi >> 2) - (lo >> 2) + 1 : 0;
             ci[2] = int(w4.size() / 4);
@@ -310,7 +315,9 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
         rc = upload(c, reinterpret_cast<void**>(&p->d_grp), tab.data(), tab.size() * sizeof(int));
         if (rc == AUD_OK) rc = upload_real(c, &p->d_w4, w4.data(), w4.size(), d->compute_dtype);
         if (rc == AUD_OK) {
-            const hipError_t pe = fast_kind == aud_plan::kR16 ? aud::melspec_r16_prepare() : aud::melspec_r25_prepare();
+            const hipError_t pe = fast_kind == aud_plan::kR16   ? aud::melspec_r16_prepare()
+                                  : fast_kind == aud_plan::kR25 ? aud::melspec_r25_prepare()
+                                                                : aud::melspec_r1024_prepare();
             if (pe != hipSuccess) rc = fail(c, AUD_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
         }
         if (rc == AUD_OK) {
@@ -319,8 +326,8 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
             p->family = fast_name;
             p->r16 = fastcfg;
             p->r16.grp_off = p->d_grp;
-            p->r16.grp_flt = p->d_grp + 17;
-            p->r16.chunk = p->d_grp + 17 + nf;
+            p->r16.grp_flt = p->d_grp + goff;
+            p->r16.chunk = p->d_grp + goff + nf;
             p->r16.w4 = p->d_w4;
         }
     }
@@ -360,7 +367,9 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
         if (value == 0) {
             if (p->fast_kind != aud_plan::kNoFast) {
                 p->use_fast = true;
-                p->family = p->fast_kind == aud_plan::kR16 ? "r16x16" : "r25x8";
+                p->family = p->fast_kind == aud_plan::kR16   ? "r16x16"
+                            : p->fast_kind == aud_plan::kR25 ? "r25x8"
+                                                             : "r16x16x4";
             }
             return AUD_OK;
         }
@@ -406,6 +415,8 @@ int aud_melspec_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
         AUD_HIP(c, aud::launch_melspec_r16(a, p->r16, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
     else if (p->use_fast && p->fast_kind == aud_plan::kR25)
         AUD_HIP(c, aud::launch_melspec_r25(a, p->r16, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
+    else if (p->use_fast && p->fast_kind == aud_plan::kR1024)
+        AUD_HIP(c, aud::launch_melspec_r1024(a, p->r16, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
     else
         AUD_HIP(c, aud::launch_melspec_generic(a, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
     if (smooth) {

@@ -64,7 +64,7 @@ struct FastArgs {
     int w4_off;            // byte offset of the LDS copy of the chunked mel weights
     unsigned lds_bytes;    // dynamic LDS of the launch
     int n_chunks;          // number of 4-element chunks in w4
-    const int* grp_off;    // [17] device: filter-group boundaries into grp_flt
+    const int* grp_off;    // [groups + 1] device: filter-group boundaries into grp_flt
     const int* grp_flt;    // [nf] device: filter ids, grouped so that groups carry equal tap counts
     const int* chunk;      // [nf][3] device: first 4-bin chunk, chunk count, offset into w4
     const void* w4;        // device: triangle weights as aligned 4-bin chunks (compute type)
@@ -96,6 +96,11 @@ hipError_t launch_melspec_r16(const MelspecArgs& a, const FastArgs& e, int compu
 bool melspec_r25_supported(int N, int S, int compute_dtype, int n_chunks, FastArgs* out);
 hipError_t melspec_r25_prepare();
 hipError_t launch_melspec_r25(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
+
+// N = 2048 fast path (one wave per frame, 16 x 16 x 4)
+bool melspec_r1024_supported(int N, int S, int compute_dtype, int n_chunks, FastArgs* out);
+hipError_t melspec_r1024_prepare();
+hipError_t launch_melspec_r1024(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
 
 hipError_t launch_gabor(const GaborArgs& a, int compute_dtype, hipStream_t st);
 

@@ -26,6 +26,7 @@ def main():
             PC.case_melspec_vs_oracle(orc, ("cfg2_16k_n512_nf40", 0.2, 1, [0]), capi.AUD_F64, seg_ms=100.0)
             PC.case_n512_odd_step_and_sample_types(orc, capi.AUD_F32)
             PC.case_n400_variants(orc, capi.AUD_F32, seg_ms=100.0, dur=0.25, rows=1, segs=(0, 1))
+            PC.case_n2048_variants(orc, capi.AUD_F32, seg_ms=60.0, dur=0.12, rows=1)
             PC.case_melspec_vs_oracle(orc, ("odd_15k_n375_nf32", 0.2, 1, [0]), capi.AUD_F32)
             PC.case_zero_signal_and_empty_batch(orc)
             PC.case_prev_smooth(orc, "sndenv_16k_n400_nf32", capi.AUD_F32)

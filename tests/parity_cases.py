@@ -324,3 +324,14 @@ def case_n400_variants(orc, cdt, seg_ms=None, dur=1.0, rows=2, segs=(0,)):
         plan.close()
         for opts in ({}, {"kernel": 1}):
             case_melspec_vs_oracle(orc, (name, dur, rows, list(segs)), cdt, seg_ms=seg_ms, options=opts)
+
+
+def case_n2048_variants(orc, cdt, seg_ms=300.0, dur=0.4, rows=2):
+    """BASELINE config 5 parameters (44.1 kHz, N = 2048, 128 mel, NaN row): r16x16x4 and generic"""
+    name = "cfg5_44k_n2048_nf128"
+    oc = W.OracleCfg(orc, name, seg_ms)
+    plan = W.product_plan(oc, cdt)
+    assert plan.kernel_name == "r16x16x4"
+    plan.close()
+    for opts in ({}, {"kernel": 1}):
+        case_melspec_vs_oracle(orc, (name, dur, rows, [0, 1]), cdt, seg_ms=seg_ms, options=opts)

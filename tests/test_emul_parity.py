@@ -52,6 +52,11 @@ def test_emul_n400_kernel_variants(orc, emu, cdt):
 
 
 @pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_emul_n2048_kernel_variants(orc, emu, cdt):
+    PC.case_n2048_variants(orc, cdt, seg_ms=100.0, dur=0.25, rows=1)
+
+
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
 def test_emul_n512_odd_step(orc, emu, cdt):
     PC.case_n512_odd_step_and_sample_types(orc, cdt)
 

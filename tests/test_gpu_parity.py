@@ -41,6 +41,11 @@ def test_n400_kernel_variants(orc, torch_cuda, cdt):
 
 
 @pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_n2048_kernel_variants(orc, torch_cuda, cdt):
+    PC.case_n2048_variants(orc, cdt)
+
+
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
 def test_n512_odd_step(orc, torch_cuda, cdt):
     PC.case_n512_odd_step_and_sample_types(orc, cdt)
 
