@@ -266,7 +266,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
         fast_kind = aud_plan::kR25;
         n_groups = 8;  // 128 threads = 16 frames x 8 filter groups
         fast_name = "r25x8";
-    } else if (aud::melspec_r1024_supported(N, d->step_samples, d->compute_dtype, r16_chunks, &fastcfg)) {
+    } else if (aud::melspec_r1024_supported(N, d->step_samples, d->compute_dtype, r16_chunks, nf, &fastcfg)) {
         fast_kind = aud_plan::kR1024;
         n_groups = 64;  // 256 threads = 4 frames x 64 filter groups
         fast_name = "r16x16x4";

@@ -184,10 +184,13 @@ __device__ __forceinline__ double dev_log(double v) { return log(v); }
 //   * dft/dft.go:70-83: PowerSegment / LogPowerSegment [item, H, T] (optional)
 //   * mel/mel.go:120-153: triangle sums (as aligned 4-bin chunks, bin order kept), + LogOff,
 //     ln / LogMin, optional renorm, MelFBankSegment [item, nf, T]
+// With lds_out set, mel values go to lds_out[flt * lds_pitch + lds_col0 + frame] instead of global memory
+// (kernels whose tiles are narrower than a 64-byte output run collect several tiles there first).
 template <typename TT, int NT, int F>
 __device__ __forceinline__ void tile_epilogue(const MelspecArgs& a, const FastArgs& e, const TT* P, int Hp,
                                               const unsigned char* smem, const aud_item& it, int item, int t0,
-                                              int tid) {
+                                              int tid, float* lds_out = nullptr, int lds_pitch = 0,
+                                              int lds_col0 = 0) {
     const int T = a.T, H = a.H, N = a.N;
     const int64_t lim = it.sig_len;
     if (a.power || a.log_power) {
@@ -245,7 +248,10 @@ __device__ __forceinline__ void tile_epilogue(const MelspecArgs& a, const FastAr
             }
             res = float(val);
         }
-        a.mel[(size_t(item) * a.nf + flt) * T + sstep] = res;
+        if (lds_out)
+            lds_out[flt * lds_pitch + lds_col0 + ff] = res;
+        else
+            a.mel[(size_t(item) * a.nf + flt) * T + sstep] = res;
     }
 }
 

@@ -62,6 +62,7 @@ struct FastArgs {
     int xch_off;           // byte offset of the transpose buffer inside dynamic LDS
     int p_off;             // byte offset of the power spectrum (aliases the span or the transpose buffer)
     int w4_off;            // byte offset of the LDS copy of the chunked mel weights
+    int out_off;           // byte offset of the LDS mel tile (kernels that collect several frame groups)
     unsigned lds_bytes;    // dynamic LDS of the launch
     int n_chunks;          // number of 4-element chunks in w4
     const int* grp_off;    // [groups + 1] device: filter-group boundaries into grp_flt
@@ -98,7 +99,7 @@ hipError_t melspec_r25_prepare();
 hipError_t launch_melspec_r25(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
 
 // N = 2048 fast path (one wave per frame, 16 x 16 x 4)
-bool melspec_r1024_supported(int N, int S, int compute_dtype, int n_chunks, FastArgs* out);
+bool melspec_r1024_supported(int N, int S, int compute_dtype, int n_chunks, int nf, FastArgs* out);
 hipError_t melspec_r1024_prepare();
 hipError_t launch_melspec_r1024(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
 

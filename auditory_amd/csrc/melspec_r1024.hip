@@ -14,14 +14,18 @@
 //            read back with consecutive lanes on consecutive addresses --
 //   split + power, power spectrum to LDS, shared tile epilogue (64 filter groups x 4 frames).
 //
-// 256 threads = 4 frames per workgroup; every LDS phase reuses the same 8.7 KB per frame.
+// 256 threads = 4 frames at a time; a workgroup walks 4 such groups (16 consecutive frames) so that
+// the mel weights are copied to LDS once per 16 frames and the mel values leave in 64-byte runs
+// (collected in an 8 KB LDS tile first).  Every LDS phase reuses the same 8.7 KB per frame.
 // Reference semantics: sound/sndenv.go:438-478, dft/dft.go:53-85, mel/mel.go:120-153.
 #include "device_common.h"
 
 namespace aud {
 namespace {
 
-constexpr int kF = 4;      // frames per workgroup (one wave each)
+constexpr int kF = 4;      // frames in flight (one wave each)
+constexpr int kSub = 4;    // groups of kF frames per workgroup
+constexpr int kTile = kF * kSub;  // 16 frames per workgroup
 constexpr int kNT = 256;
 constexpr int kM = 1024;   // complex FFT length
 constexpr int kN = 2048;   // window length
@@ -43,15 +47,20 @@ __global__ __launch_bounds__(256) void k_melspec_r1024(const MelspecArgs a, cons
     const int l = tid & 63;  // lane
     const int T = a.T, S = a.S;
 
-    const int tiles = (T + kF - 1) / kF;
+    const int tiles = (T + kTile - 1) / kTile;
     const int item = blockIdx.x / tiles;
-    const int t0 = (blockIdx.x - item * tiles) * kF;
+    const int tile0 = (blockIdx.x - item * tiles) * kTile;
     const aud_item it = a.items[item];
     const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_2048^k
     const int64_t lim = it.sig_len;
     C2<TT>* fr = xch + f * kFrameC;  // this frame's LDS region
+    float* melbuf = reinterpret_cast<float*>(smem + e.out_off);  // [nf][kTile]
 
     stage_mel_weights<TT, kNT>(e, smem, tid);
+
+  for (int sub = 0; sub < kSub; ++sub) {
+    const int t0 = tile0 + sub * kF;
+    if (t0 >= T) break;  // uniform: nothing left in this item
 
     // ---- stage 1 operands: z[64 n1 + l] = (x[128 n1 + 2 l], x[128 n1 + 2 l + 1]) ------------------
     C2<TT> v[16];
@@ -165,24 +174,35 @@ __global__ __launch_bounds__(256) void k_melspec_r1024(const MelspecArgs a, cons
     }
     __syncthreads();
 
-    tile_epilogue<TT, kNT, kF>(a, e, Pbase, kHp, smem, it, item, t0, tid);
+    tile_epilogue<TT, kNT, kF>(a, e, Pbase, kHp, smem, it, item, t0, tid, melbuf, kTile, sub * kF);
+    __syncthreads();  // the power spectrum is consumed: the next group may reuse the frame regions
+  }
+
+    // ---- the 16-frame mel tile leaves in 64-byte runs ---------------------------------------------------
+    for (int w = tid; w < a.nf * kTile; w += kNT) {
+        const int flt = w / kTile, c = w - flt * kTile;
+        const int sstep = tile0 + c;
+        if (sstep < T) a.mel[(size_t(item) * a.nf + flt) * T + sstep] = melbuf[flt * kTile + c];
+    }
 }
 
 }  // namespace
 
-bool melspec_r1024_supported(int N, int S, int compute_dtype, int n_chunks, FastArgs* out) {
-    if (N != kN || S < 1) return false;
+bool melspec_r1024_supported(int N, int S, int compute_dtype, int n_chunks, int nf, FastArgs* out) {
+    if (N != kN || S < 1 || nf < 1) return false;
     const size_t tsz = compute_dtype == AUD_F64 ? 8 : 4;
     const size_t frames = size_t(kF) * kFrameC * 2 * tsz;  // also covers P: 4 * 1028 * tsz
     const size_t w4 = (size_t(n_chunks) * 4 * tsz + 31) & ~size_t(31);
     const size_t first = (frames + 31) & ~size_t(31);
-    const size_t total = first + w4;
+    const size_t outb = size_t(nf) * kTile * sizeof(float);  // the 16-frame mel tile
+    const size_t total = first + w4 + outb;
     if (total > 160 * 1024) return false;
     if (out) {
         out->direct = 1;
         out->xch_off = 0;
         out->p_off = 0;
         out->w4_off = int(first);
+        out->out_off = int(first + w4);
         out->lds_bytes = unsigned(total);
         out->n_chunks = n_chunks;
     }
@@ -200,7 +220,7 @@ hipError_t melspec_r1024_prepare() {
 }
 
 hipError_t launch_melspec_r1024(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st) {
-    const int tiles = (a.T + kF - 1) / kF;
+    const int tiles = (a.T + kTile - 1) / kTile;
     const dim3 grid(unsigned(a.n_items) * unsigned(tiles));
     if (compute_dtype == AUD_F64)
         hipLaunchKernelGGL(k_melspec_r1024<double>, grid, dim3(kNT), e.lds_bytes, st, a, e);
