@@ -171,3 +171,24 @@ def test_full_size_properties_cfg2(orc, torch_cuda):
     assert np.abs(mel2 - (mel + np.log(4.0))).max() <= 2e-6 * np.abs(mel).max() + 1e-6
     plan.close()
 
+
+
+def test_rccl_allgather_single_rank(torch_cuda):
+    """aud_comm_* / aud_allgather_dev (the non-Python route to the path's one collective): with a
+    1-rank communicator the gather must hand the slab back unchanged."""
+    import ctypes as C
+    torch = torch_cuda
+    lib = capi.load()
+    ctx = runtime.get_ctx(0)
+    uid = C.create_string_buffer(128)
+    assert lib.aud_comm_unique_id(uid) == 0
+    ctx.check(lib.aud_comm_init(ctx.handle, 1, 0, uid))
+    try:
+        send = torch.arange(40 * 104 * 3, dtype=torch.float32, device="cuda")
+        recv = torch.zeros_like(send)
+        ctx.check(lib.aud_allgather_dev(ctx.handle, send.data_ptr(), recv.data_ptr(), send.numel(),
+                                        torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert torch.equal(send, recv)
+    finally:
+        lib.aud_comm_destroy(ctx.handle)
