@@ -54,7 +54,8 @@ class PlanDesc(C.Structure):
                 ("dft", DftParams), ("mel", MelFBank),
                 ("bin_pts", C.POINTER(C.c_int32)), ("mel_filters", C.POINTER(C.c_double)),
                 ("n_gabor", C.c_int32), ("gabor", GaborSet),
-                ("gabor_filters", C.POINTER(C.c_double)), ("compute_dtype", C.c_int32)]
+                ("gabor_filters", C.POINTER(C.c_double)), ("compute_dtype", C.c_int32),
+                ("mfcc_coefs", C.c_int32)]
 
 
 # every symbol include/auditory_hip.h declares: name -> (restype, argtypes)
@@ -90,6 +91,8 @@ SYMBOLS = {
     "aud_plan_kernel_name": (C.c_char_p, [_VP]),
     "aud_plan_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int]),
     "aud_melspec_batch_dev": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, _VP, _VP, _VP, _VP]),
+    "aud_mfcc_batch_dev": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "aud_melspec_mfcc_batch_host": (C.c_int, [_VP, _VP, C.c_int64, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "aud_gabor_batch_dev": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_int,
                                       _VP, _VP]),
     "aud_process_batch_dev": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, _VP, C.c_int, C.c_int,

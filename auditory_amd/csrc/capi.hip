@@ -45,6 +45,7 @@ struct aud_plan {
     void* d_filt = nullptr;
     int32_t* d_bin_pts = nullptr;
     void* d_gabor = nullptr;
+    void* d_dct = nullptr;  // [mfcc_coefs][nf] DCT-I rows
     const char* family = "generic";
 };
 
@@ -206,6 +207,8 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
         if (hi >= lo && int64_t(f) * (nf + 2) + (hi - lo) >= cells)
             return fail(c, AUD_EINVAL, "mel triangle wider than the filter table (SURVEY Q4)");
     }
+    if (d->mfcc_coefs < 0 || d->mfcc_coefs > nf || (d->mfcc_coefs > 0 && nf < 2))
+        return fail(c, AUD_EINVAL, "mfcc_coefs must be 0..n_filters (and n_filters >= 2: fourier.NewDCT panics)");
     if (d->n_gabor > 0) {
         if (!d->gabor_filters || d->gabor.size_x < 1 || d->gabor.size_y < 1 || d->gabor.stride_x < 1 ||
             d->gabor.stride_y < 1)
@@ -246,6 +249,21 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
     if (rc == AUD_OK && d->n_gabor > 0)
         rc = upload_real(c, &p->d_gabor, d->gabor_filters,
                          size_t(d->n_gabor) * d->gabor.size_x * d->gabor.size_y, d->compute_dtype);
+    if (rc == AUD_OK && d->mfcc_coefs > 0) {
+        // rows of the unnormalised DCT-I (FFTPACK cost / gonum fourier.DCT):
+        // y[k] = x[0] + (-1)^k x[n-1] + 2 sum_{j=1}^{n-2} x[j] cos(pi j k / (n-1))
+        std::vector<double> dct(size_t(d->mfcc_coefs) * nf);
+        const long double pi = 3.14159265358979323846264338327950288L;
+        for (int k = 0; k < d->mfcc_coefs; ++k)
+            for (int j = 0; j < nf; ++j) {
+                double v;
+                if (j == 0) v = 1.0;
+                else if (j == nf - 1) v = (k & 1) ? -1.0 : 1.0;
+                else v = double(2.0L * cosl(pi * (long double)j * (long double)k / (long double)(nf - 1)));
+                dct[size_t(k) * nf + j] = v;
+            }
+        rc = upload_real(c, &p->d_dct, dct.data(), dct.size(), d->compute_dtype);
+    }
     // kernel family: the in-register 16 x 16 kernel for 512-sample windows, else the generic one
     int r16_chunks = 0;
     for (int f = 0; f < nf; ++f) {
@@ -346,6 +364,7 @@ int aud_plan_destroy(aud_plan* p) {
     if (p->d_filt) (void)hipFree(p->d_filt);
     if (p->d_bin_pts) (void)hipFree(p->d_bin_pts);
     if (p->d_gabor) (void)hipFree(p->d_gabor);
+    if (p->d_dct) (void)hipFree(p->d_dct);
     if (p->d_grp) (void)hipFree(p->d_grp);
     if (p->d_w4) (void)hipFree(p->d_w4);
     delete p;
@@ -440,6 +459,40 @@ int aud_melspec_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
         AUD_HIP(c, aud::launch_power_smooth(sa, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
         AUD_HIP(c, aud::launch_mel_from_power(a, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
     }
+    return AUD_OK;
+}
+
+int aud_mfcc_batch_dev(aud_plan* p, const aud_item* items, int n_items, const float* mel, const float* log_power,
+                       float* mfcc, float* deltas, float* delta_deltas, float* energy, void* stream) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    if (p->d.mfcc_coefs <= 0 || !p->d_dct) return fail(c, AUD_EINVAL, "plan was created without mfcc_coefs");
+    if (n_items < 0) return fail(c, AUD_EINVAL, "bad n_items");
+    if (p->d.segment_steps > p->H)
+        return fail(c, AUD_EINVAL, "Energy reads LogPowerSegment row s < SegmentSteps: needs SegmentSteps <= bins (Go panics)");
+    if (delta_deltas && !deltas) return fail(c, AUD_EINVAL, "delta_deltas needs deltas");
+    if (n_items == 0) return AUD_OK;
+    if (!items || !mel || !log_power || !mfcc) return fail(c, AUD_EINVAL, "null buffer");
+    AUD_HIP(c, make_current(c));
+    aud::MfccArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.items = items;
+    a.n_items = n_items;
+    a.N = p->d.win_samples;
+    a.S = p->d.step_samples;
+    a.T = p->d.segment_steps;
+    a.border = p->d.border_steps;
+    a.H = p->H;
+    a.nf = p->d.mel.n_filters;
+    a.n_coefs = p->d.mfcc_coefs;
+    a.dct = p->d_dct;
+    a.mel = mel;
+    a.log_power = log_power;
+    a.mfcc = mfcc;
+    a.deltas = deltas;
+    a.delta_deltas = delta_deltas;
+    a.energy = energy;
+    AUD_HIP(c, aud::launch_mfcc(a, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
     return AUD_OK;
 }
 
@@ -551,6 +604,67 @@ int aud_melspec_batch_host(aud_plan* p, const double* sig, int64_t sig_total, co
     }
     if (want_lp)
         for (size_t i = 0; i < n_pow; ++i) log_power[i] = double(h[o + i]);
+    return AUD_OK;
+}
+
+int aud_melspec_mfcc_batch_host(aud_plan* p, const double* sig, int64_t sig_total, const aud_item* items,
+                                int n_items, double* mel, double* power, double* log_power, double* mfcc,
+                                double* deltas, double* delta_deltas, double* energy) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    if (p->d.mfcc_coefs <= 0) return fail(c, AUD_EINVAL, "plan was created without mfcc_coefs");
+    if (!p->d.dft.comp_log_pow) return fail(c, AUD_EINVAL, "the MFCC tail reads LogPowerSegment: needs CompLogPow");
+    if (n_items < 0 || sig_total < 0 || (n_items > 0 && (!sig || !items || !mel || !mfcc)))
+        return fail(c, AUD_EINVAL, "null buffer");
+    if (delta_deltas && !deltas) return fail(c, AUD_EINVAL, "delta_deltas needs deltas");
+    if (n_items == 0) return AUD_OK;
+    for (int i = 0; i < n_items; ++i)
+        if (items[i].sig_off < 0 || items[i].sig_len < 0 || items[i].sig_off + items[i].sig_len > sig_total)
+            return fail(c, AUD_EINVAL, "item outside the signal buffer");
+    AUD_HIP(c, make_current(c));
+    const int nf = p->d.mel.n_filters, T = p->d.segment_steps, H = p->H, nc = p->d.mfcc_coefs;
+    const size_t n_mel = size_t(n_items) * nf * T, n_pow = size_t(n_items) * H * T;
+    const size_t n_cc = size_t(n_items) * nc * T, n_en = size_t(n_items) * T;
+    // device layout: mel | power | log_power | mfcc | deltas | delta_deltas | energy
+    const size_t total = n_mel + 2 * n_pow + 3 * n_cc + n_en;
+    const size_t sig_bytes = size_t(sig_total) * 8, item_bytes = size_t(n_items) * sizeof(aud_item);
+    int rc;
+    if ((rc = ensure_ws(c, 0, sig_bytes + 16)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 1, item_bytes)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 2, total * 4)) != AUD_OK) return rc;
+    float* d_mel = static_cast<float*>(c->ws[2]);
+    float* d_pow = d_mel + n_mel;
+    float* d_lp = d_pow + n_pow;
+    float* d_cc = d_lp + n_pow;
+    float* d_dl = d_cc + n_cc;
+    float* d_ddl = d_dl + n_cc;
+    float* d_en = d_ddl + n_cc;
+    AUD_HIP(c, hipMemcpyAsync(c->ws[0], sig, sig_bytes, hipMemcpyHostToDevice, c->stream));
+    AUD_HIP(c, hipMemcpyAsync(c->ws[1], items, item_bytes, hipMemcpyHostToDevice, c->stream));
+    const aud_item* d_items = static_cast<const aud_item*>(c->ws[1]);
+    rc = aud_melspec_batch_dev(p, c->ws[0], AUD_F64, d_items, n_items, d_mel, d_pow, d_lp, c->stream);
+    if (rc == AUD_OK)
+        rc = aud_mfcc_batch_dev(p, d_items, n_items, d_mel, d_lp, d_cc, deltas ? d_dl : nullptr,
+                                delta_deltas ? d_ddl : nullptr, d_en, c->stream);
+    if (rc != AUD_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        return rc;
+    }
+    std::vector<float> h(total);
+    AUD_HIP(c, hipMemcpyAsync(h.data(), d_mel, total * 4, hipMemcpyDeviceToHost, c->stream));
+    AUD_HIP(c, hipStreamSynchronize(c->stream));
+    auto widen = [&](double* dst, const float* src, size_t n) {
+        if (dst)
+            for (size_t i = 0; i < n; ++i) dst[i] = double(src[i]);
+    };
+    const float* hp = h.data();
+    widen(mel, hp, n_mel);
+    widen(power, hp + n_mel, n_pow);
+    widen(log_power, hp + n_mel + n_pow, n_pow);
+    widen(mfcc, hp + n_mel + 2 * n_pow, n_cc);
+    widen(deltas, hp + n_mel + 2 * n_pow + n_cc, n_cc);
+    widen(delta_deltas, hp + n_mel + 2 * n_pow + 2 * n_cc, n_cc);
+    widen(energy, hp + n_mel + 2 * n_pow + 3 * n_cc, n_en);
     return AUD_OK;
 }
 

@@ -83,6 +83,20 @@ struct SmoothArgs {
 hipError_t launch_power_smooth(const SmoothArgs& a, int compute_dtype, hipStream_t st);
 hipError_t launch_mel_from_power(const MelspecArgs& a, int compute_dtype, hipStream_t st);
 
+// MFCC tail (mel.CepstrumDct + Energy / deltas of SndEnv.ProcessSegment)
+struct MfccArgs {
+    const aud_item* items;
+    int n_items, N, S, T, border, H, nf, n_coefs;
+    const void* dct;         // [n_coefs][nf] DCT-I rows (compute type)
+    const float* mel;        // [n_items, nf, T]
+    const float* log_power;  // [n_items, H, T]
+    float* mfcc;             // [n_items, n_coefs, T]
+    float* deltas;           // [n_items, n_coefs, T] or null
+    float* delta_deltas;     // [n_items, n_coefs, T] or null
+    float* energy;           // [n_items, T] or null
+};
+hipError_t launch_mfcc(const MfccArgs& a, int compute_dtype, hipStream_t st);
+
 // generic any-N kernel (Stockham in LDS, radix 2/4 + per-output generic radix)
 size_t melspec_generic_lds_bytes(int M, int F, int compute_dtype);
 int melspec_generic_pick_F(int M, int compute_dtype);

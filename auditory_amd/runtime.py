@@ -50,7 +50,8 @@ class Plan:
     """aud_plan: immutable tables (twiddles, mel triangles, gabor taps) resident on the device."""
 
     def __init__(self, ctx, win_samples, step_samples, segment_steps, border_steps, dft, fbank,
-                 bin_pts, mel_filters, gabor_set=None, gabor_filters=None, compute_dtype=capi.AUD_F32):
+                 bin_pts, mel_filters, gabor_set=None, gabor_filters=None, compute_dtype=capi.AUD_F32,
+                 mfcc_coefs=0):
         self.ctx = ctx
         self.lib = ctx.lib
         self.N, self.S, self.T, self.border = win_samples, step_samples, segment_steps, border_steps
@@ -74,6 +75,8 @@ class Plan:
             self.n_gabor = gk.shape[0]
             self.gabor_set = gabor_set
         d.compute_dtype = compute_dtype
+        d.mfcc_coefs = int(mfcc_coefs)
+        self.mfcc_coefs = int(mfcc_coefs)
         h = C.c_void_p()
         ctx.check(self.lib.aud_plan_create(ctx.handle, C.byref(d), C.byref(h)))
         self.handle = h
@@ -117,6 +120,22 @@ class Plan:
         self.ctx.check(self.lib.aud_melspec_batch_host(self.handle, vp(sig), sig.size, vp(items), n,
                                                        vp(mel), vp(power), vp(logp)))
         return mel, power, logp
+
+    def melspec_mfcc_host(self, sig, items, deltas=True):
+        """ProcessSegment with Mel.MFCC on, for all items at once.  Returns a dict of float64 arrays:
+        mel [n, nf, T], power / log_power [n, H, T], mfcc / deltas / delta_deltas [n, NCoefs, T], energy [n, T]"""
+        sig = np.ascontiguousarray(sig, np.float64)
+        items = np.ascontiguousarray(items, dtype=ITEM_DTYPE)
+        n, nc = len(items), self.mfcc_coefs
+        out = dict(mel=np.zeros((n, self.nf, self.T)), power=np.zeros((n, self.H, self.T)),
+                   log_power=np.zeros((n, self.H, self.T)), mfcc=np.zeros((n, nc, self.T)),
+                   deltas=np.zeros((n, nc, self.T)) if deltas else None,
+                   delta_deltas=np.zeros((n, nc, self.T)) if deltas else None, energy=np.zeros((n, self.T)))
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        self.ctx.check(self.lib.aud_melspec_mfcc_batch_host(
+            self.handle, vp(sig), sig.size, vp(items), n, vp(out["mel"]), vp(out["power"]), vp(out["log_power"]),
+            vp(out["mfcc"]), vp(out["deltas"]), vp(out["delta_deltas"]), vp(out["energy"])))
+        return out
 
     def gabor_host(self, mel, out, by_time=False):
         """mel: f64 [n, rows, cols]; out: f32 [n, ...] modified in place"""

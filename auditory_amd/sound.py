@@ -1,6 +1,7 @@
 """Host-side mirror of the reference's orchestrator `sound.SndEnv` (sound/sndenv.go) for the
 hot path: Init -> ProcessSegment -> ApplyGabor.  The frame loop itself runs on the GPU as one
-batched launch per call; MFCC / energy / kwta stages of the reference are out of scope."""
+batched launch per call; the MFCC tail (CepstrumDct, Energy, deltas) runs as three small kernels
+behind it; the kwta stage of the reference is out of scope."""
 import numpy as np
 
 from . import agabor, capi, dft, mel, runtime
@@ -50,6 +51,10 @@ class SndEnv:
         self.PowerSegment = None
         self.LogPowerSegment = None
         self.MelFBankSegment = None
+        self.Energy = None
+        self.MFCCSegment = None
+        self.MFCCDeltas = None
+        self.MFCCDeltaDeltas = None
         self.GaborSpecs = []
         self.GaborFilters = agabor.FilterSet()
         self.GborOutPoolsX = 0
@@ -106,6 +111,11 @@ class SndEnv:
         self.LogPowerSegment = np.zeros((H, p.SegmentSteps))
         p.Steps = [p.StepSamples * (i - p.BorderSteps) for i in range(p.SegmentSteps)]
         self.MelFBankSegment = np.zeros((self.Mel.FBank.NFilters, p.SegmentSteps))
+        self.Energy = np.zeros(p.SegmentSteps)
+        if self.Mel.MFCC:
+            self.MFCCSegment = np.zeros((self.Mel.NCoefs, p.SegmentSteps))
+            self.MFCCDeltas = np.zeros((self.Mel.NCoefs, p.SegmentSteps))
+            self.MFCCDeltaDeltas = np.zeros((self.Mel.NCoefs, p.SegmentSteps))
         self.SegCnt = lib.aud_seg_cnt(len(self.Signal), p.SegmentSamples, p.StrideSamples,
                                       self.Channels)
         self._make_plan()
@@ -120,7 +130,8 @@ class SndEnv:
                                   p.SegmentSteps, p.BorderSteps, self.DFT.to_c(),
                                   self.Mel.FBank.to_c(), self.Mel.BinPts, self.MelFilters,
                                   self.GaborFilters.to_c() if has_g else None,
-                                  self.GaborFilters.Filters if has_g else None, self._compute_dtype)
+                                  self.GaborFilters.Filters if has_g else None, self._compute_dtype,
+                                  mfcc_coefs=self.Mel.NCoefs if self.Mel.MFCC else 0)
 
     def _item(self, segment, add):
         start0 = segment * self.Params.StrideSamples + MSecToSamples(add, self.SampleRate)
@@ -132,11 +143,21 @@ class SndEnv:
         self.ProcessSegments([segment], add)
 
     def ProcessSegments(self, segments, add=0):
-        """Batch extension: all requested segments in ONE launch.  Returns
-        (mel [n, nf, T], power [n, H, T], log_power [n, H, T]); the SndEnv tensors hold the last."""
+        """Batch extension: all requested segments in ONE call.  Returns
+        (mel [n, nf, T], power [n, H, T], log_power [n, H, T]); the SndEnv tensors hold the last.
+        With Mel.MFCC (the default) the MFCC tail of sndenv.go:360-432 runs too and fills
+        MFCCSegment / MFCCDeltas / MFCCDeltaDeltas / Energy."""
         its = [self._item(s, add) for s in segments]
         items = runtime.make_items([i[0] for i in its], [i[1] for i in its], [i[2] for i in its])
-        m, pw, lp = self._plan.melspec_host(self.Signal, items, True, bool(self.DFT.CompLogPow))
+        if self.Mel.MFCC and self.DFT.CompLogPow:
+            o = self._plan.melspec_mfcc_host(self.Signal, items, deltas=bool(self.Mel.Deltas))
+            m, pw, lp = o["mel"], o["power"], o["log_power"]
+            self.MFCCSegment, self.Energy = o["mfcc"][-1], o["energy"][-1]
+            if self.Mel.Deltas:
+                self.MFCCDeltas, self.MFCCDeltaDeltas = o["deltas"][-1], o["delta_deltas"][-1]
+            self._last_mfcc = o
+        else:
+            m, pw, lp = self._plan.melspec_host(self.Signal, items, True, bool(self.DFT.CompLogPow))
         self.MelFBankSegment = m[-1]
         self.PowerSegment = pw[-1]
         if lp is not None:

@@ -134,6 +134,7 @@ typedef struct {
     aud_gabor_set gabor;
     const double* gabor_filters; /* [n_gabor, size_y, size_x] FilterSet.Filters, or NULL */
     int32_t compute_dtype;       /* AUD_F32 (default) or AUD_F64 */
+    int32_t mfcc_coefs;          /* mel.Params.NCoefs if the MFCC tail is wanted (Mel.MFCC), else 0 */
 } aud_plan_desc;
 
 /* ---- host-side setup: no GPU needed --------------------------------------------- */
@@ -229,6 +230,17 @@ int aud_process_batch_dev(aud_plan* plan, const void* sig, int sig_dtype, const 
                           int n_items, float* mel, int pools_y, int pools_x, float* gabor,
                           void* stream);
 
+/* The MFCC tail of SndEnv.ProcessSegment on stored tensors (needs desc.mfcc_coefs > 0):
+ * mel.Params.CepstrumDct (mel/mel.go:192-212) per processed step, Energy and the row-0 overwrite
+ * (sound/sndenv.go:360-372, with the reference's axis quirk), deltas and delta-deltas
+ * (sound/sndenv.go:378-431, running sums carried across coefficients as in the reference).
+ *   mel [n_items, nf, T] and log_power [n_items, H, T] as written by aud_melspec_batch_dev;
+ *   mfcc [n_items, NCoefs, T]; deltas / delta_deltas [n_items, NCoefs, T] or NULL (delta_deltas
+ *   needs deltas); energy [n_items, T] or NULL.  AUD_EINVAL if T > H (the Go code indexes out of range). */
+int aud_mfcc_batch_dev(aud_plan* plan, const aud_item* items, int n_items, const float* mel,
+                       const float* log_power, float* mfcc, float* deltas, float* delta_deltas,
+                       float* energy, void* stream);
+
 /* ---- hot path, host buffers (what the cgo shim binds) ---------------------------- */
 
 /* Same as aud_melspec_batch_dev on host memory: sig float64 (SndEnv.Signal values), items on
@@ -236,6 +248,12 @@ int aud_process_batch_dev(aud_plan* plan, const void* sig, int sig_dtype, const 
 int aud_melspec_batch_host(aud_plan* plan, const double* sig, int64_t sig_total,
                            const aud_item* items, int n_items, double* mel, double* power,
                            double* log_power);
+
+/* aud_melspec_batch_host + aud_mfcc_batch_dev in one call (SndEnv.ProcessSegment with Mel.MFCC on):
+ * outputs float64; power / log_power / deltas / delta_deltas / energy may be NULL. */
+int aud_melspec_mfcc_batch_host(aud_plan* plan, const double* sig, int64_t sig_total, const aud_item* items,
+                                int n_items, double* mel, double* power, double* log_power, double* mfcc,
+                                double* deltas, double* delta_deltas, double* energy);
 
 /* agabor.Convolve on host memory: mel float64 [n_items, rows, cols], out float32 in/out. */
 int aud_gabor_batch_host(aud_plan* plan, const double* mel, int n_items, int mel_rows,

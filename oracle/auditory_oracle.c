@@ -699,6 +699,119 @@ int orc_process_segment(const orc_snd_params* sp, const orc_dft_params* dp,
     return done;
 }
 
+/* ------------------------------------------------------------------ */
+/* MFCC tail of the segment loop                         */
+/* ------------------------------------------------------------------ */
+
+/* gonum v0.11.0 dsp/fourier DCT.Transform (FFTPACK `cost`, not vendored in the reference; contract
+ * restated): unnormalised DCT-I,
+ *   y[k] = x[0] + (-1)^k x[n-1] + 2 sum_{j=1}^{n-2} x[j] cos(pi j k / (n-1)),  n > 1.        */
+void orc_dct1(const double* x, double* y, int n) {
+    for (int k = 0; k < n; k++) {
+        long double s = (long double)x[0] + ((k & 1) ? -(long double)x[n - 1] : (long double)x[n - 1]);
+        for (int j = 1; j < n - 1; j++)
+            s += 2.0L * (long double)x[j] * cosl(3.14159265358979323846264338327950288L * (long double)j * (long double)k /
+                                                 (long double)(n - 1));
+        y[k] = (double)s;
+    }
+}
+
+/* mel/mel.go:192-212 CepstrumDct: DCT of the nf log-mel values of one step, c0 <- ln(1 + c0^2),
+ * first n_coefs into mfcc_seg[n_coefs, T] column `step`. */
+void orc_cepstrum_dct(int step, const double* fbank, int nf, double* mfcc_seg, int n_coefs, int T) {
+    double* out = (double*)malloc(sizeof(double) * (size_t)nf);
+    orc_dct1(fbank, out, nf);          /* mel.go:198-202 */
+    double el0 = out[0];
+    out[0] = log(1.0 + el0 * el0);     /* mel.go:203-204 */
+    for (int i = 0; i < n_coefs; i++) mfcc_seg[(size_t)i * T + step] = out[i]; /* :207-209 */
+    free(out);
+}
+
+/* sound/sndenv.go:360-432: Energy (with the reference's axis quirk, SURVEY Q8: Energy[s] sums
+ * LogPowerSegment.FloatValRowCell(s, f) = Values[s*T + f] over f < T, i.e. the log-power of BIN s
+ * over the steps), the row-0 overwrite, and the delta / delta-delta passes whose running sums are
+ * not reset per coefficient.  Returns ORC_EPANIC where the Go code would index out of range. */
+int orc_mfcc_tail(const double* log_power_seg, int H, int T, double* energy, double* mfcc_seg,
+                  int n_coefs, int deltas, double* mfcc_deltas, double* mfcc_delta_deltas) {
+    for (int s = 0; s < T; s++) {                     /* :360-366 */
+        double e = 0.0;
+        for (int f = 0; f < T; f++) {
+            long idx = (long)s * T + f;
+            if (idx >= (long)H * T) return ORC_EPANIC;
+            e += log_power_seg[idx];
+        }
+        energy[s] = e;
+    }
+    for (int s = 0; s < T; s++) mfcc_seg[s] = energy[s]; /* :368-372 SetFloatRowCell(0, s, e) */
+    if (!deltas) return ORC_OK;
+    const int npn = 2;
+    for (int pass = 0; pass < 2; pass++) {            /* :378-404 deltas, :407-431 delta-deltas */
+        const double* src = pass == 0 ? mfcc_seg : mfcc_deltas;
+        double* dst = pass == 0 ? mfcc_deltas : mfcc_delta_deltas;
+        for (int s = 0; s < T; s++) {
+            double prv = 0.0, nxt = 0.0;
+            for (int i = 0; i < n_coefs; i++) {
+                double nume = 0.0;
+                for (int n = 1; n <= npn; n++) {
+                    int sprv = s - n, snxt = s + n;
+                    if (sprv < 0) sprv = 0;
+                    if (snxt > T - 1) snxt = T - 1;
+                    prv += src[(size_t)i * T + sprv];
+                    nxt += src[(size_t)i * T + snxt];
+                    nume += (double)n * (nxt - prv);
+                    double denom = (double)(2 * n * n);
+                    dst[(size_t)i * T + s] = nume / denom;
+                }
+            }
+        }
+    }
+    return ORC_OK;
+}
+
+/* ProcessSegment with the MFCC tail on (mel.Params.MFCC = true, the SndEnv default):
+ * the loop of orc_process_segment plus CepstrumDct per processed step (sndenv.go:447-449)
+ * and orc_mfcc_tail.  mfcc_seg / deltas / delta_deltas: [n_coefs, T]; energy: [T]. */
+int orc_process_segment_mfcc(const orc_snd_params* sp, const orc_dft_params* dp,
+                             const orc_mel_fbank* mp, const int32_t* bin_pts, const double* filters,
+                             const double* signal, long sig_len, int segment, int add_ms,
+                             double* power, double* log_power, double* power_seg,
+                             double* log_power_seg, double* mel_seg, double* fbank, int n_coefs,
+                             int deltas, double* energy, double* mfcc_seg, double* mfcc_deltas,
+                             double* mfcc_delta_deltas) {
+    const int N = sp->win_samples, T = sp->segment_steps, H = N / 2 + 1, nf = mp->n_filters;
+    memset(power, 0, sizeof(double) * H);
+    memset(log_power, 0, sizeof(double) * H);
+    memset(power_seg, 0, sizeof(double) * (size_t)H * T);
+    memset(log_power_seg, 0, sizeof(double) * (size_t)H * T);
+    memset(mel_seg, 0, sizeof(double) * (size_t)nf * T);
+    memset(energy, 0, sizeof(double) * T);
+    memset(mfcc_seg, 0, sizeof(double) * (size_t)n_coefs * T); /* :349-351 */
+    /* MFCCDeltas / MFCCDeltaDeltas are NOT zeroed per segment by the reference; every cell is rewritten */
+    double* window = (double*)malloc(sizeof(double) * N);
+    orc_fft_plan* plan = orc_fft_plan_create(N);
+    int done = 0;
+    for (int s = 0; s < T; s++) {
+        long offset = (long)sp->step_samples * (s - sp->border_steps) +
+                      orc_msec_to_samples((double)add_ms, sp->sample_rate);
+        long start = (long)segment * sp->stride_samples + offset;
+        if (orc_snd_to_window(signal, sig_len, start, N, window) != ORC_OK) break;
+        orc_dft_filter(dp, plan, s, window, N, power, log_power, power_seg, log_power_seg, T);
+        int err = orc_mel_filter_dft(mp, bin_pts, s, power, H, mel_seg, T, fbank, filters);
+        if (err != ORC_OK) {
+            done = -err;
+            break;
+        }
+        orc_cepstrum_dct(s, fbank, nf, mfcc_seg, n_coefs, T);
+        done++;
+    }
+    orc_fft_plan_destroy(plan);
+    free(window);
+    if (done < 0) return done;
+    int rc = orc_mfcc_tail(log_power_seg, H, T, energy, mfcc_seg, n_coefs, deltas, mfcc_deltas,
+                           mfcc_delta_deltas);
+    return rc == ORC_OK ? done : -rc;
+}
+
 /* Batch driver for the CPU baseline (bench.py cpu_baseline leg) and for
  * batch-level parity tests: n_items independent (signal, segment) pairs, each
  * through orc_process_segment and optionally orc_gabor_convolve (4-D).

@@ -76,6 +76,8 @@ def lib():
         L.orc_process_segment.restype = C.c_int
         L.orc_process_batch.restype = C.c_int
         L.orc_snd_to_window.restype = C.c_int
+        L.orc_mfcc_tail.restype = C.c_int
+        L.orc_process_segment_mfcc.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -242,3 +244,30 @@ def process_batch(sp, d, m, bin_pts, filters, sig, sig_off, sig_len, seg, faithf
                                  _p(sig), _p(sig_off), _p(sig_len), _p(seg), C.c_int(n),
                                  C.c_int(int(faithful)), _p(mel), *gargs)
     return rc, mel, gout
+
+
+def dct1(x):
+    """gonum fourier.DCT.Transform (FFTPACK cost): unnormalised DCT-I"""
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.zeros_like(x)
+    lib().orc_dct1(_p(x), _p(y), C.c_int(len(x)))
+    return y
+
+
+def process_segment_mfcc(sp, d, m, bin_pts, filters, signal, segment=0, add_ms=0, n_coefs=13, deltas=True):
+    """sndenv.go:342-432 with Mel.MFCC on: mel + MFCCSegment / Energy / deltas / delta-deltas"""
+    N, T, nf = sp.win_samples, sp.segment_steps, m.n_filters
+    H = N // 2 + 1
+    signal = np.ascontiguousarray(signal, np.float64)
+    power, log_power = np.zeros(H), np.zeros(H)
+    power_seg, log_power_seg = np.zeros((H, T)), np.zeros((H, T))
+    mel_seg, fbank = np.zeros((nf, T)), np.zeros(nf)
+    energy = np.zeros(T)
+    mfcc, dl, ddl = np.zeros((n_coefs, T)), np.zeros((n_coefs, T)), np.zeros((n_coefs, T))
+    done = lib().orc_process_segment_mfcc(C.byref(sp), C.byref(d), C.byref(m), _p(bin_pts), _p(filters),
+                                          _p(signal), C.c_long(len(signal)), C.c_int(segment),
+                                          C.c_int(add_ms), _p(power), _p(log_power), _p(power_seg),
+                                          _p(log_power_seg), _p(mel_seg), _p(fbank), C.c_int(n_coefs),
+                                          C.c_int(int(deltas)), _p(energy), _p(mfcc), _p(dl), _p(ddl))
+    return dict(done=done, mel_seg=mel_seg, log_power_seg=log_power_seg, power_seg=power_seg, energy=energy,
+                mfcc=mfcc, deltas=dl, delta_deltas=ddl)

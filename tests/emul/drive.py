@@ -30,6 +30,7 @@ def main():
             PC.case_melspec_vs_oracle(orc, ("odd_15k_n375_nf32", 0.2, 1, [0]), capi.AUD_F32)
             PC.case_zero_signal_and_empty_batch(orc)
             PC.case_prev_smooth(orc, "sndenv_16k_n400_nf32", capi.AUD_F32)
+            PC.case_mfcc_tail(orc, "sndenv_16k_n400_nf32", capi.AUD_F32)
             PC.case_gabor_4d_and_2d_vs_oracle(orc, capi.AUD_F32)
         else:
             PC.case_melspec_vs_oracle(orc, by_name[which], capi.AUD_F32)

@@ -335,3 +335,39 @@ def case_n2048_variants(orc, cdt, seg_ms=300.0, dur=0.4, rows=2):
     plan.close()
     for opts in ({}, {"kernel": 1}):
         case_melspec_vs_oracle(orc, (name, dur, rows, [0, 1]), cdt, seg_ms=seg_ms, options=opts)
+
+
+def case_mfcc_tail(orc, name, cdt):
+    """CepstrumDct + Energy (axis quirk Q8) + deltas (carried sums) vs the oracle"""
+    oc = W.OracleCfg(orc, name)
+    L = int(0.5 * oc.sr)
+    sig, _ = synth.batch(19, 2, L, oc.sr)
+    segs = [(r, s) for r in range(2) for s in (0, 1, 3)]
+    plan = W.product_plan(oc, cdt, mfcc_coefs=13)
+    try:
+        got = plan.melspec_mfcc_host(sig.ravel(), make_items(oc, L, segs))
+        plain, _, _ = plan.melspec_host(sig.ravel(), make_items(oc, L, segs))
+    finally:
+        plan.close()
+    assert np.array_equal(got["mel"], plain, equal_nan=True)
+    for i, (r, sg) in enumerate(segs):
+        o = orc.process_segment_mfcc(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig[r], segment=sg)
+        ok, msg = W.feature_close(got["mel"][i], o["mel_seg"], cdt, lin_axis=0)
+        assert ok, "mel " + msg
+        if cdt == capi.AUD_F64:
+            # the DCT sums ~nf float32-STORED mel values (the tensors at the boundary are float32): 3e-6
+            ok, msg = W.close_enough(got["mfcc"][i], o["mfcc"], 3e-6)
+        else:
+            ok, msg = W.feature_close(got["mfcc"][i], o["mfcc"], cdt)
+        assert ok, "mfcc item %d: %s" % (i, msg)
+        # deltas are differences of running sums of MFCC values (the Energy row alone is ~T*5), stored in
+        # float32: they are accurate relative to the size of what is being differenced, not to their own
+        scale = max(1.0, float(np.nanmax(np.abs(o["mfcc"]))))
+        for key in ("deltas", "delta_deltas"):
+            err = float(np.nanmax(np.abs(got[key][i] - o[key]))) / scale
+            assert err <= (1e-5 if cdt == capi.AUD_F32 else 1e-6), "%s item %d: %.3g of the MFCC scale" % (key, i, err)
+        ok, msg = W.close_enough(got["energy"][i], o["energy"], 1e-5 if cdt == capi.AUD_F32 else 1e-6)
+        assert ok, "energy " + msg
+        assert np.array_equal(got["mfcc"][i][0], got["energy"][i])          # row 0 is the Energy row
+        dead = o["done"]
+        assert np.all(got["mfcc"][i][1:, dead:] == 0)                       # unprocessed steps stay zero

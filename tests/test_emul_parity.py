@@ -88,6 +88,12 @@ def test_emul_prev_smooth(orc, emu, name, cdt):
     PC.case_prev_smooth(orc, name, cdt)
 
 
+@pytest.mark.parametrize("name", ["sndenv_16k_n400_nf32", "cfg2_16k_n512_nf40"])
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_emul_mfcc_tail(orc, emu, name, cdt):
+    PC.case_mfcc_tail(orc, name, cdt)
+
+
 def _sanitizer_run(variant, which, timeout=900):
     build_emul.build(variant)
     rt = {"asan": "libasan.so", "tsan": "libtsan.so"}[variant]

@@ -73,6 +73,12 @@ def test_prev_smooth(orc, torch_cuda, name, cdt):
     PC.case_prev_smooth(orc, name, cdt)
 
 
+@pytest.mark.parametrize("name", ["sndenv_16k_n400_nf32", "cfg2_16k_n512_nf40"])
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_mfcc_tail(orc, torch_cuda, name, cdt):
+    PC.case_mfcc_tail(orc, name, cdt)
+
+
 def test_recreated_tone_fixtures_f64(orc, torch_cuda):
     PC.case_recreated_tone_fixtures_f64(orc)
 

@@ -41,7 +41,7 @@ class OracleCfg:
         return self.S * (self.T - 1 - self.border) + self.N
 
 
-def product_plan(ocfg, compute_dtype=0, gabor=None, device=0, dft_override=None):  # noqa: C901
+def product_plan(ocfg, compute_dtype=0, gabor=None, device=0, dft_override=None, mfcc_coefs=0):  # noqa: C901
     """runtime.Plan built from the PRODUCT's own host setup for the same configuration"""
     from auditory_amd import agabor, capi, mel, runtime
     sr, win, step, seg, stride, border, nf, lo, hi = CONFIGS[ocfg.name]
@@ -64,7 +64,7 @@ def product_plan(ocfg, compute_dtype=0, gabor=None, device=0, dft_override=None)
         agabor.ToTensor(specs, fs)
         gset, gk = fs.to_c(), fs.Filters
     return runtime.Plan(runtime.get_ctx(device), ocfg.N, ocfg.S, ocfg.T, ocfg.border, dftp,
-                        mp.FBank.to_c(), mp.BinPts, filt, gset, gk, compute_dtype)
+                        mp.FBank.to_c(), mp.BinPts, filt, gset, gk, compute_dtype, mfcc_coefs=mfcc_coefs)
 
 
 def close_enough(got, ref, tol):
