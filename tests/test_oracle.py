@@ -303,3 +303,49 @@ def test_reference_tone_fixtures(orc, hz, peak_bin):
     assert int(np.argmax(r["power_seg"][:, 5])) == peak_bin
     hot = int(np.argmax(r["mel_seg"][:, 5]))
     assert bins[hot] <= peak_bin <= bins[hot + 2]
+
+
+# ---------------- MFCC tail -----------------------------------
+def test_dct1_matches_scipy_and_fftpack_contract(orc):
+    from scipy.fft import dct
+    rng = np.random.default_rng(4)
+    for n in (2, 3, 13, 32, 40):
+        x = rng.normal(size=n)
+        y = orc.dct1(x)
+        assert np.abs(y - dct(x, type=1)).max() < 1e-12 * n       # unnormalised DCT-I
+        assert np.abs(orc.dct1(y) - 2 * (n - 1) * x).max() < 1e-11 * n   # gonum: twice => x * 2(n-1)
+
+
+def test_mfcc_tail_semantics(orc):
+    sp = orc.sound_params(25, 10, 100, 100, 2, 16000)
+    d, m = orc.dft_defaults(), orc.mel_defaults()
+    rc, bins, hz, filt = orc.mel_init_filters(m, 400, 16000)
+    sig, _ = synth.batch(8, 1, 3000, 16000)
+    o = orc.process_segment_mfcc(sp, d, m, bins, filt, sig[0], segment=1)
+    T, nc = 14, 13
+    assert o["done"] == 14
+    plain = orc.process_segment(sp, d, m, bins, filt, sig[0], segment=1)
+    assert np.array_equal(o["mel_seg"], plain["mel_seg"])
+    # Energy[s] = sum over the steps of the log-power of BIN s (the axis quirk, sndenv.go:360-366)
+    np.testing.assert_allclose(o["energy"], o["log_power_seg"][:T, :].sum(axis=1), rtol=1e-13)
+    assert np.array_equal(o["mfcc"][0], o["energy"])                     # row 0 overwritten (:368-372)
+    # rows 1.. are the DCT-I of the log-mel column
+    for s in (0, 5, 13):
+        c = orc.dct1(o["mel_seg"][:, s])
+        np.testing.assert_allclose(o["mfcc"][1:, s], c[1:nc], rtol=1e-12)
+    # deltas: running sums carried across coefficients (sndenv.go:378-404), restated naively here
+    M = o["mfcc"]
+    exp = np.zeros_like(M)
+    for s in range(T):
+        prv = nxt = 0.0
+        for i in range(nc):
+            nume = 0.0
+            for n in (1, 2):
+                prv += M[i, max(s - n, 0)]
+                nxt += M[i, min(s + n, T - 1)]
+                nume += n * (nxt - prv)
+                exp[i, s] = nume / (2 * n * n)
+    np.testing.assert_allclose(o["deltas"], exp, rtol=1e-12, atol=1e-12)
+    # a short signal: unprocessed steps keep MFCC rows 1.. at zero, row 0 still gets Energy
+    o2 = orc.process_segment_mfcc(sp, d, m, bins, filt, sig[0][:1900], segment=0)
+    assert o2["done"] == 12 and np.all(o2["mfcc"][1:, 12:] == 0)
