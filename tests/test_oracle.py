@@ -320,7 +320,7 @@ def test_mfcc_tail_semantics(orc):
     sp = orc.sound_params(25, 10, 100, 100, 2, 16000)
     d, m = orc.dft_defaults(), orc.mel_defaults()
     rc, bins, hz, filt = orc.mel_init_filters(m, 400, 16000)
-    sig, _ = synth.batch(8, 1, 3000, 16000)
+    sig, _ = synth.batch(8, 1, 4000, 16000)
     o = orc.process_segment_mfcc(sp, d, m, bins, filt, sig[0], segment=1)
     T, nc = 14, 13
     assert o["done"] == 14
