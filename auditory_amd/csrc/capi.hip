@@ -332,13 +332,20 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
         if (w4.empty()) w4.assign(4, 0.0);
         rc = upload(c, reinterpret_cast<void**>(&p->d_grp), tab.data(), tab.size() * sizeof(int));
         if (rc == AUD_OK) rc = upload_real(c, &p->d_w4, w4.data(), w4.size(), d->compute_dtype);
-        if (rc == AUD_OK) {
-            const hipError_t pe = fast_kind == aud_plan::kR16   ? aud::melspec_r16_prepare()
-                                  : fast_kind == aud_plan::kR25 ? aud::melspec_r25_prepare()
-                                                                : aud::melspec_r1024_prepare();
-            if (pe != hipSuccess) rc = fail(c, AUD_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        // Launches above the 64 KB default of dynamic LDS must be requested per kernel.  If the runtime
+        // refuses, the plan quietly keeps the generic kernel (same results, fits 64 KB by construction).
+        bool fast_usable = true;
+        if (rc == AUD_OK && fastcfg.lds_bytes > 64u * 1024u) {
+            const hipError_t pe = fast_kind == aud_plan::kR16   ? aud::melspec_r16_prepare(fastcfg.lds_bytes)
+                                  : fast_kind == aud_plan::kR25 ? aud::melspec_r25_prepare(fastcfg.lds_bytes)
+                                                                : aud::melspec_r1024_prepare(fastcfg.lds_bytes);
+            if (pe != hipSuccess) {
+                (void)hipGetLastError();
+                fast_usable = false;
+            }
         }
-        if (rc == AUD_OK) {
+        if (rc == AUD_OK && !fast_usable) fast_kind = aud_plan::kNoFast;
+        if (rc == AUD_OK && fast_kind != aud_plan::kNoFast) {
             p->fast_kind = fast_kind;
             p->use_fast = true;
             p->family = fast_name;

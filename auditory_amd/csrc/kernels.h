@@ -104,17 +104,17 @@ hipError_t launch_melspec_generic(const MelspecArgs& a, int compute_dtype, hipSt
 
 // N = 512 fast path
 bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, bool direct, FastArgs* out);
-hipError_t melspec_r16_prepare();
+hipError_t melspec_r16_prepare(unsigned lds_bytes);
 hipError_t launch_melspec_r16(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
 
 // N = 400 fast path
 bool melspec_r25_supported(int N, int S, int compute_dtype, int n_chunks, FastArgs* out);
-hipError_t melspec_r25_prepare();
+hipError_t melspec_r25_prepare(unsigned lds_bytes);
 hipError_t launch_melspec_r25(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
 
 // N = 2048 fast path (one wave per frame, 16 x 16 x 4)
 bool melspec_r1024_supported(int N, int S, int compute_dtype, int n_chunks, int nf, FastArgs* out);
-hipError_t melspec_r1024_prepare();
+hipError_t melspec_r1024_prepare(unsigned lds_bytes);
 hipError_t launch_melspec_r1024(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
 
 hipError_t launch_gabor(const GaborArgs& a, int compute_dtype, hipStream_t st);

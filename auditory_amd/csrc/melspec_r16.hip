@@ -241,14 +241,14 @@ bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, bool d
     return true;
 }
 
-hipError_t melspec_r16_prepare() {
+hipError_t melspec_r16_prepare(unsigned lds_bytes) {
     // more than 64 KiB of dynamic LDS has to be requested explicitly
     const void* fns[4] = {reinterpret_cast<const void*>(&k_melspec_r16<double, true>),
                           reinterpret_cast<const void*>(&k_melspec_r16<double, false>),
                           reinterpret_cast<const void*>(&k_melspec_r16<float, true>),
                           reinterpret_cast<const void*>(&k_melspec_r16<float, false>)};
     for (const void* fn : fns) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -187,11 +187,11 @@ bool melspec_r25_supported(int N, int S, int compute_dtype, int n_chunks, FastAr
     return true;
 }
 
-hipError_t melspec_r25_prepare() {
+hipError_t melspec_r25_prepare(unsigned lds_bytes) {
     const void* fns[2] = {reinterpret_cast<const void*>(&k_melspec_r25<double>),
                           reinterpret_cast<const void*>(&k_melspec_r25<float>)};
     for (const void* fn : fns) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
