@@ -262,18 +262,31 @@ def case_prev_smooth(orc, name, cdt):
 N512_VARIANTS = {"r16_direct": {"r16_input": 0}, "r16_staged": {"r16_input": 1}, "generic": {"kernel": 1}}
 
 
+def _fast_family(orc, name, cdt, seg_ms=None):
+    oc = W.OracleCfg(orc, name, seg_ms)
+    plan = W.product_plan(oc, cdt)
+    fam = plan.kernel_name
+    plan.close()
+    return fam
+
+
 def case_n512_variants(orc, cdt, seg_ms=None, dur=1.0, rows=2, segs=(0,)):
     case = ("cfg2_16k_n512_nf40", dur, rows, list(segs))
+    have_fast = _fast_family(orc, case[0], cdt, seg_ms) == "r16x16"
     for name, opts in N512_VARIANTS.items():
+        if "r16_input" in opts and not have_fast:
+            continue
         case_melspec_vs_oracle(orc, case, cdt, seg_ms=seg_ms, options=opts)
     # a plan reports what it runs, and odd steps fall back to the generic kernel by themselves
     oc = W.OracleCfg(orc, "cfg2_16k_n512_nf40")
     plan = W.product_plan(oc, cdt)
-    assert plan.kernel_name == "r16x16"
+    # float64 needs > 64 KB of LDS per workgroup; a runtime that refuses it leaves the plan on "generic"
+    assert plan.kernel_name == "r16x16" or (cdt == capi.AUD_F64 and plan.kernel_name == "generic")
+    auto = plan.kernel_name
     plan.set_option("kernel", 1)
     assert plan.kernel_name == "generic"
     plan.set_option("kernel", 0)
-    assert plan.kernel_name == "r16x16"
+    assert plan.kernel_name == auto
     with pytest.raises(capi.AuditoryError):
         plan.set_option("nonsense", 1)
     plan.close()
@@ -303,9 +316,9 @@ def case_n512_odd_step_and_sample_types(orc, cdt):
     plan = runtime.Plan(runtime.get_ctx(0), N, S, T, border, dftp, mp.FBank.to_c(), mp.BinPts, filt,
                         compute_dtype=cdt)
     try:
-        assert plan.kernel_name == "r16x16"
+        assert plan.kernel_name == "r16x16" or (cdt == capi.AUD_F64 and plan.kernel_name == "generic")
         with pytest.raises(capi.AuditoryError):
-            plan.set_option("r16_input", 1)                       # staged needs an even step
+            plan.set_option("r16_input", 1)                       # staged needs an even step (or no r16 at all)
         items = runtime.make_items([0, L], [L, L], [0, 0])
         got, _, _ = plan.melspec_host(sig.ravel(), items)
         ok, msg = W.feature_close(got, ref, cdt, lin_axis=1)
@@ -318,10 +331,8 @@ def case_n512_odd_step_and_sample_types(orc, cdt):
 def case_n400_variants(orc, cdt, seg_ms=None, dur=1.0, rows=2, segs=(0,)):
     """25 ms @ 16 kHz (N = 400): the r25x8 kernel and the generic kernel, both against the oracle"""
     for name in ("cfg2_16k_n400_nf40", "sndenv_16k_n400_nf32"):
-        oc = W.OracleCfg(orc, name, seg_ms)
-        plan = W.product_plan(oc, cdt)
-        assert plan.kernel_name == "r25x8"
-        plan.close()
+        fam = _fast_family(orc, name, cdt, seg_ms)
+        assert fam == "r25x8" or (cdt == capi.AUD_F64 and fam == "generic")
         for opts in ({}, {"kernel": 1}):
             case_melspec_vs_oracle(orc, (name, dur, rows, list(segs)), cdt, seg_ms=seg_ms, options=opts)
 
@@ -329,10 +340,8 @@ def case_n400_variants(orc, cdt, seg_ms=None, dur=1.0, rows=2, segs=(0,)):
 def case_n2048_variants(orc, cdt, seg_ms=300.0, dur=0.4, rows=2):
     """BASELINE config 5 parameters (44.1 kHz, N = 2048, 128 mel, NaN row): r16x16x4 and generic"""
     name = "cfg5_44k_n2048_nf128"
-    oc = W.OracleCfg(orc, name, seg_ms)
-    plan = W.product_plan(oc, cdt)
-    assert plan.kernel_name == "r16x16x4"
-    plan.close()
+    fam = _fast_family(orc, name, cdt, seg_ms)
+    assert fam == "r16x16x4" or (cdt == capi.AUD_F64 and fam == "generic")
     for opts in ({}, {"kernel": 1}):
         case_melspec_vs_oracle(orc, (name, dur, rows, [0, 1]), cdt, seg_ms=seg_ms, options=opts)
 
