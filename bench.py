@@ -100,6 +100,7 @@ def main():
                          "(a ~5 us kernel is otherwise bound by the Python/ctypes launch path)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="aud_plan_set_option switches for A/B runs, e.g. r16_input=1 (staged) or kernel=1 (generic)")
+    ap.add_argument("--prewarm-s", type=float, default=0.3, help="untimed seconds of steady launches before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
     args = ap.parse_args()
@@ -187,7 +188,7 @@ def main():
     n_rep = args.steps // per_graph
     # untimed: keep the device busy for ~0.3 s so that the timed region starts at steady clocks
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.3:
+    while time.perf_counter() - t_pre < args.prewarm_s:
         if graph is not None:
             graph.replay()
         else:

@@ -50,7 +50,7 @@ def test_bench_dry_run(monkeypatch, capsys, extra):
     monkeypatch.setattr(torch, "device", lambda *a, **k: real_device("cpu"))
     monkeypatch.setattr(bench, "cpu_baseline",
                         lambda oc, sig, L: bench.__dict__["_real_cpu_baseline"](oc, sig, L, target_s=0.2))
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--batch", "2"] + extra)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--batch", "2", "--prewarm-s", "0"] + extra)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
     with backend.emulated("plain"):
