@@ -34,7 +34,10 @@ def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> libauditory_hip.so.  Returns the path."""
     if not force and not stale():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # -fno-slp-vectorize: hipcc otherwise packs neighbouring f32 adds/muls of the butterflies into
+    # v_pk_* instructions, which on gfx950 issue no faster than two scalar ops and cost ~90 extra
+    # v_mov per wave to pair registers up (and 20 more VGPRs) -- see DESIGN.md 4.1
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared",
            "-Xarch_host", "-ffp-contract=off", "-I" + INCLUDE, "-I" + CSRC, "-o", LIB] + sources() + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
