@@ -241,6 +241,16 @@ def main():
               "ms_per_step": round(1e3 * e2 / k2, 4), "gathered_shape": list(full.shape),
               "note": "step + one ncclAllGather (RCCL) of the [B, 40, 104] f32 mel slab per rank"}
 
+    # roofline.traffic: HBM bytes per launch from the PMC passes (tools/profile_bench.sh), if they were
+    # taken for this kernel family and batch; null otherwise (it cannot be measured inside this process)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        if args.workload == "cfg2" and B == 256 and ("r16" in pmc.get("kernel", "")) == (plan.kernel_name == "r16x16"):
+            traffic = round(float(pmc["hbm_bytes_per_launch"]), 1)
+    except (OSError, ValueError, KeyError):
+        pass
     audio_s_per_step = B * world * (dur / float(sr))
     alg_bytes = B * (4 * dur + 4 * oc.nf * oc.T)  # each sample read once + each mel value written once
     if gab:  # unfused gabor: re-read the mel tensor, write the pooled on/off pairs
@@ -267,7 +277,7 @@ def main():
                    "options": args.option,
                    "sharding": "utterances, contiguous block per rank"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                      "kernel": "frame->FFT->power->mel (%s)" % plan.kernel_name,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "avg_launch_us": round(kern_ms * 1e3, 3)},

@@ -16,7 +16,9 @@ def rows(pattern):
 
 
 def main():
+    import json
     out, tag = sys.argv[1], sys.argv[2]
+    traffic = {}
     print("# rocprofv3 summary %s" % tag)
     stats = list(rows(os.path.join(out, "stats", "**", "*kernel_stats.csv")))
     print("## kernel stats (name, calls, avg ns, total ns, %)")
@@ -40,9 +42,23 @@ def main():
             note = ""
             if n == "FETCH_SIZE":
                 note = "  => HBM read  ~ %.3f MB/launch (x2 gfx950 correction, KB units)" % (2 * mean * 1024 / 1e6)
+                if "melspec" in k:
+                    traffic.setdefault(k, {})["read_bytes"] = 2 * mean * 1024
             if n == "WRITE_SIZE":
                 note = "  => HBM write ~ %.3f MB/launch (KB units)" % (mean * 1024 / 1e6)
+                if "melspec" in k:
+                    traffic.setdefault(k, {})["write_bytes"] = mean * 1024
             print("%-70s %-12s %7d %14.1f%s" % (k[:70], n, cnt, mean, note))
+    # what bench.py reports as roofline.traffic: HBM bytes per launch of the frame->mel kernel
+    best = None
+    for k, v in traffic.items():
+        if "read_bytes" in v and "write_bytes" in v:
+            best = {"kernel": k, "hbm_bytes_per_launch": v["read_bytes"] + v["write_bytes"], "tag": tag, **v}
+    if best:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        with open(os.path.join(root, "profiles", "pmc_traffic.json"), "w") as fh:
+            json.dump(best, fh, indent=1)
+        print("## wrote profiles/pmc_traffic.json:", best)
 
 
 if __name__ == "__main__":
