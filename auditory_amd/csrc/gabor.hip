@@ -13,7 +13,9 @@ namespace {
 
 constexpr int kChunk = 8;
 
-template <typename TT>
+// KSX, KSY, KNG > 0: compile-time filter geometry (the reference's default 9 x 9 x 8 set gets fully
+// unrolled taps and no group loop); 0: taken from the arguments at run time.
+template <typename TT, int KSX, int KSY, int KNG>
 __global__ __launch_bounds__(256) void k_gabor(const GaborArgs a) {
     const int per_item = a.nF * a.nT;
     const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -22,10 +24,11 @@ __global__ __launch_bounds__(256) void k_gabor(const GaborArgs a) {
     const int r = int(gid - int64_t(item) * per_item);
     const int f_idx = r / a.nT, t_idx = r - f_idx * a.nT;
     const int f = f_idx * a.sty, t = t_idx * a.stx;
+    const int SX = KSX > 0 ? KSX : a.SX, SY = KSY > 0 ? KSY : a.SY, NG = KNG > 0 ? KNG : a.nG;
 
     const float* __restrict__ mel = a.mel + size_t(item) * a.rows * a.cols;
     const TT* __restrict__ kf = static_cast<const TT*>(a.k);
-    const int area = a.SX * a.SY;
+    const int area = SX * SY;
     const TT gain = TT(a.gain);
 
     size_t out_item;
@@ -35,21 +38,27 @@ __global__ __launch_bounds__(256) void k_gabor(const GaborArgs a) {
         out_item = size_t(a.d0) * a.d1 * a.d2 * a.d3;
     float* out = a.out + size_t(item) * out_item;
 
-    for (int g0 = 0; g0 < a.nG; g0 += kChunk) {
+    for (int g0 = 0; g0 < NG; g0 += kChunk) {
         TT acc[kChunk];
 #pragma unroll
         for (int c = 0; c < kChunk; ++c) acc[c] = TT(0);
-        const int gc = min(kChunk, a.nG - g0);
-        for (int ff = 0; ff < a.SY; ++ff) {
-            const float* row = mel + size_t(f + ff) * a.cols + t;
-            for (int ft = 0; ft < a.SX; ++ft) {
-                float mv = row[ft];
-                if (mv != mv) mv = 0.5f;  // math.IsNaN -> .5
-                const TT v = TT(mv);
-                const TT* tap = kf + size_t(g0) * area + ff * a.SX + ft;
+        const int gc = min(kChunk, NG - g0);
+        auto tap_row = [&](const float* row, int ff, int ft) {
+            float mv = row[ft];
+            if (mv != mv) mv = 0.5f;  // math.IsNaN -> .5
+            const TT v = TT(mv);
+            const TT* tap = kf + size_t(g0) * area + ff * SX + ft;
 #pragma unroll
-                for (int c = 0; c < kChunk; ++c)
-                    if (c < gc) acc[c] += tap[size_t(c) * area] * v;
+            for (int c = 0; c < kChunk; ++c)
+                if (c < gc) acc[c] += tap[size_t(c) * area] * v;
+        };
+        for (int ff = 0; ff < SY; ++ff) {
+            const float* row = mel + size_t(f + ff) * a.cols + t;
+            if constexpr (KSX > 0) {
+#pragma unroll
+                for (int ft = 0; ft < KSX; ++ft) tap_row(row, ff, ft);
+            } else {
+                for (int ft = 0; ft < SX; ++ft) tap_row(row, ff, ft);
             }
         }
 #pragma unroll
@@ -61,7 +70,7 @@ __global__ __launch_bounds__(256) void k_gabor(const GaborArgs a) {
             size_t o_on, o_off;
             if (a.rank == 2) {
                 const int y = f_idx * 2;
-                const int x = a.by_time ? t_idx + a.t_max_strides * flt : flt + t_idx * a.nG;
+                const int x = a.by_time ? t_idx + a.t_max_strides * flt : flt + t_idx * NG;
                 o_on = size_t(y) * a.d1 + x;
                 o_off = size_t(y + 1) * a.d1 + x;
             } else {
@@ -81,10 +90,14 @@ hipError_t launch_gabor(const GaborArgs& a, int compute_dtype, hipStream_t st) {
     const int64_t total = int64_t(a.n_items) * a.nF * a.nT;
     if (total == 0) return hipSuccess;
     const dim3 grid(unsigned((total + 255) / 256));
-    if (compute_dtype == AUD_F64)
-        hipLaunchKernelGGL(k_gabor<double>, grid, dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL(k_gabor<float>, grid, dim3(256), 0, st, a);
+    const bool dflt = a.SX == 9 && a.SY == 9 && a.nG == 8;  // processspeech.go:226-253
+    if (compute_dtype == AUD_F64) {
+        if (dflt) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor<double, 9, 9, 8>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor<double, 0, 0, 0>), grid, dim3(256), 0, st, a);
+    } else {
+        if (dflt) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor<float, 9, 9, 8>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor<float, 0, 0, 0>), grid, dim3(256), 0, st, a);
+    }
     return hipGetLastError();
 }
 
