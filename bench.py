@@ -100,6 +100,7 @@ def main():
                          "(a ~5 us kernel is otherwise bound by the Python/ctypes launch path)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="aud_plan_set_option switches for A/B runs, e.g. r16_input=1 (staged) or kernel=1 (generic)")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for CPU dry runs)")
     ap.add_argument("--prewarm-s", type=float, default=0.3, help="untimed seconds of steady launches before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
@@ -122,7 +123,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     name = "cfg2_16k_n512_nf40" if args.win_ms == 32.0 else "cfg2_16k_n400_nf40"
     assert args.win_ms in (32.0, 25.0)

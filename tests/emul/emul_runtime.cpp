@@ -122,7 +122,7 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
 }  // namespace aud_emul
 
 hipError_t hipGetDeviceCount(int* n) {
-    *n = 1;
+    *n = 8;  // one emulated node
     return hipSuccess;
 }
 hipError_t hipSetDevice(int) { return hipSuccess; }

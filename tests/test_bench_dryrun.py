@@ -36,10 +36,7 @@ class _Graph:
         raise RuntimeError("no hipGraph in the dry run")
 
 
-@pytest.mark.parametrize("extra", [[], ["--win-ms", "25"], ["--workload", "cfg4"], ["--compute", "f64", "--launch", "eager"]])
-def test_bench_dry_run(monkeypatch, capsys, extra):
-    import backend
-    import bench
+def _patch(monkeypatch):
     real_device = torch.device
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
@@ -48,6 +45,37 @@ def test_bench_dry_run(monkeypatch, capsys, extra):
     monkeypatch.setattr(torch.cuda, "Event", _Event)
     monkeypatch.setattr(torch.cuda, "CUDAGraph", _Graph)
     monkeypatch.setattr(torch, "device", lambda *a, **k: real_device("cpu"))
+
+
+def test_bench_dry_run_two_ranks(tmp_path):
+    """the --gpus 2 control flow (sharded batches, max-over-ranks timing, the all-gather region) on gloo"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = os.path.join(HERE, "bench_dry_worker.py")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, worker, "--gpus", "2", "--steps", "4", "--warmup", "1",
+                                       "--batch", "2", "--prewarm-s", "0", "--dist-backend", "gloo"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][1][-2000:] + outs[1][1][-2000:]
+    line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    assert outs[1][0].strip() == ""                       # only rank 0 prints
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "cpu_baseline" not in line
+    assert line["allgather"]["gathered_shape"] == [4, 40, 104]
+
+
+@pytest.mark.parametrize("extra", [[], ["--win-ms", "25"], ["--workload", "cfg4"], ["--compute", "f64", "--launch", "eager"]])
+def test_bench_dry_run(monkeypatch, capsys, extra):
+    import backend
+    import bench
+    _patch(monkeypatch)
     monkeypatch.setattr(bench, "cpu_baseline",
                         lambda oc, sig, L: bench.__dict__["_real_cpu_baseline"](oc, sig, L, target_s=0.2))
     monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--batch", "2", "--prewarm-s", "0"] + extra)
