@@ -66,7 +66,7 @@ def test_bench_dry_run_two_ranks(tmp_path):
     outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs[0][1][-2000:] + outs[1][1][-2000:]
     line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
-    assert outs[1][0].strip() == ""                       # only rank 0 prints
+    assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]   # only rank 0 prints the JSON line
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "cpu_baseline" not in line
     assert line["allgather"]["gathered_shape"] == [4, 40, 104]
 
