@@ -27,7 +27,7 @@ def main():
         print("%-90s %8s %12s %14s %6s" % (name, r.get("Calls", "?"), r.get("AverageNs", r.get("Average", "?")),
                                              r.get("TotalDurationNs", r.get("TotalDuration", "?")),
                                              r.get("Percentage", "?")))
-    for ctr in ("fetch", "write"):
+    for ctr in ("fetch", "write", "sqa", "sqb"):
         per = {}
         for r in rows(os.path.join(out, ctr, "**", "*counter_collection.csv")):
             k = r.get("Kernel_Name", r.get("Kernel Name", "?"))
