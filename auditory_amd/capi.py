@@ -98,6 +98,9 @@ SYMBOLS = {
     "aud_process_batch_dev": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, _VP, C.c_int, C.c_int,
                                         _VP, _VP]),
     "aud_melspec_batch_host": (C.c_int, [_VP, _VP, C.c_int64, _VP, C.c_int, _VP, _VP, _VP]),
+    "aud_snd_to_window": (C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int, _VP]),
+    "aud_dft_filter_host": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, _VP, _VP]),
+    "aud_mel_filter_dft_host": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),
     "aud_gabor_batch_host": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_int,
                                        _VP]),
     "aud_comm_unique_id": (C.c_int, [_VP]),

@@ -151,6 +151,15 @@ void fill_melspec_args(const aud_plan* p, aud::MelspecArgs* a) {
     a->F = p->F_generic;
 }
 
+// the plan's frame -> power -> mel kernel (whatever family it selected), raw power, no smoothing
+hipError_t launch_frames(const aud_plan* p, const aud::MelspecArgs& a, hipStream_t st) {
+    if (p->use_fast && p->fast_kind == aud_plan::kR16) return aud::launch_melspec_r16(a, p->r16, p->d.compute_dtype, st);
+    if (p->use_fast && p->fast_kind == aud_plan::kR25) return aud::launch_melspec_r25(a, p->r16, p->d.compute_dtype, st);
+    if (p->use_fast && p->fast_kind == aud_plan::kR1024)
+        return aud::launch_melspec_r1024(a, p->r16, p->d.compute_dtype, st);
+    return aud::launch_melspec_generic(a, p->d.compute_dtype, st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -437,14 +446,7 @@ int aud_melspec_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
     a.mel = mel;
     a.power = power;
     a.log_power = log_power;
-    if (p->use_fast && p->fast_kind == aud_plan::kR16)
-        AUD_HIP(c, aud::launch_melspec_r16(a, p->r16, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
-    else if (p->use_fast && p->fast_kind == aud_plan::kR25)
-        AUD_HIP(c, aud::launch_melspec_r25(a, p->r16, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
-    else if (p->use_fast && p->fast_kind == aud_plan::kR1024)
-        AUD_HIP(c, aud::launch_melspec_r1024(a, p->r16, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
-    else
-        AUD_HIP(c, aud::launch_melspec_generic(a, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
+    AUD_HIP(c, launch_frames(p, a, static_cast<hipStream_t>(stream)));
     if (smooth) {
         // dft.go:67-69: p_s = Prev*p_{s-1} + Cur*raw_s along the steps, then log-power and mel from it
         aud::SmoothArgs sa;
@@ -611,6 +613,101 @@ int aud_melspec_batch_host(aud_plan* p, const double* sig, int64_t sig_total, co
     }
     if (want_lp)
         for (size_t i = 0; i < n_pow; ++i) log_power[i] = double(h[o + i]);
+    return AUD_OK;
+}
+
+int aud_snd_to_window(const double* signal, int64_t sig_len, int64_t start, int win_samples, double* window) {
+    if (!signal || !window || win_samples < 1 || sig_len < 0) return AUD_EINVAL;
+    const int64_t end = start + win_samples;
+    if (end > sig_len) return AUD_ESHORT;  // "SndToWindow: end beyond signal length!!"
+    for (int64_t i = 0; i < win_samples; ++i) {
+        const int64_t pos = start + i;
+        window[i] = pos < 0 ? 0.0 : signal[pos];
+    }
+    return AUD_OK;
+}
+
+int aud_dft_filter_host(aud_plan* p, int step, const double* window, double* power, double* log_power,
+                        double* power_seg, double* log_power_seg) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    const int N = p->d.win_samples, T = p->d.segment_steps, H = p->H, nf = p->d.mel.n_filters;
+    if (!window || !power || !power_seg || step < 0 || step >= T) return fail(c, AUD_EINVAL, "bad argument");
+    AUD_HIP(c, make_current(c));
+    // the window becomes a one-frame stream: frame 0 of the item covers [0, N), every later frame is dead
+    const aud_item it{0, N, p->d.step_samples * p->d.border_steps};
+    const size_t n_mel = size_t(nf) * T, n_pow = size_t(H) * T;
+    int rc;
+    if ((rc = ensure_ws(c, 0, size_t(N) * 8 + 16)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 1, sizeof(aud_item) + size_t(H) * 8 * 3)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 2, (n_mel + n_pow) * 4)) != AUD_OK) return rc;
+    unsigned char* w1 = static_cast<unsigned char*>(c->ws[1]);
+    double* d_carry = reinterpret_cast<double*>(w1 + sizeof(aud_item));
+    double* d_p = d_carry + H;
+    double* d_lp = d_p + H;
+    float* d_mel = static_cast<float*>(c->ws[2]);
+    float* d_pow = d_mel + n_mel;
+    AUD_HIP(c, hipMemcpyAsync(c->ws[0], window, size_t(N) * 8, hipMemcpyHostToDevice, c->stream));
+    AUD_HIP(c, hipMemcpyAsync(w1, &it, sizeof(it), hipMemcpyHostToDevice, c->stream));
+    AUD_HIP(c, hipMemcpyAsync(d_carry, power, size_t(H) * 8, hipMemcpyHostToDevice, c->stream));
+    aud::MelspecArgs a;
+    fill_melspec_args(p, &a);
+    a.sig = c->ws[0];
+    a.sig_dtype = AUD_F64;
+    a.items = reinterpret_cast<const aud_item*>(w1);
+    a.n_items = 1;
+    a.mel = d_mel;
+    a.power = d_pow;
+    AUD_HIP(c, launch_frames(p, a, c->stream));
+    AUD_HIP(c, aud::launch_frame_blend(d_pow, T, d_carry, H, step, p->d.dft.prev_smooth, p->d.dft.cur_smooth,
+                                       p->d.dft.comp_log_pow, p->d.dft.log_offset, p->d.dft.log_min, d_p, d_lp,
+                                       p->d.compute_dtype, c->stream));
+    std::vector<double> hp(size_t(H) * 2);
+    AUD_HIP(c, hipMemcpyAsync(hp.data(), d_p, size_t(H) * 16, hipMemcpyDeviceToHost, c->stream));
+    AUD_HIP(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < H; ++k) {  // the tensor stores of dft.go:70-83
+        power[k] = hp[k];
+        power_seg[size_t(k) * T + step] = hp[k];
+        if (p->d.dft.comp_log_pow) {
+            if (log_power) log_power[k] = hp[size_t(H) + k];
+            if (log_power_seg) log_power_seg[size_t(k) * T + step] = hp[size_t(H) + k];
+        }
+    }
+    return AUD_OK;
+}
+
+int aud_mel_filter_dft_host(aud_plan* p, int step, const double* power, double* segment, double* fbank) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    const int N = p->d.win_samples, T = p->d.segment_steps, H = p->H, nf = p->d.mel.n_filters;
+    if (!power || !segment || step < 0 || step >= T) return fail(c, AUD_EINVAL, "bad argument");
+    AUD_HIP(c, make_current(c));
+    const aud_item it{0, N, p->d.step_samples * p->d.border_steps};  // only column 0 is live
+    const size_t n_mel = size_t(nf) * T, n_pow = size_t(H) * T;
+    int rc;
+    if ((rc = ensure_ws(c, 1, sizeof(aud_item))) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 2, (n_mel + n_pow) * 4)) != AUD_OK) return rc;
+    float* d_mel = static_cast<float*>(c->ws[2]);
+    float* d_pow = d_mel + n_mel;
+    std::vector<float> hpow(n_pow, 0.f);
+    for (int k = 0; k < H; ++k) hpow[size_t(k) * T] = float(power[k]);
+    AUD_HIP(c, hipMemcpyAsync(c->ws[1], &it, sizeof(it), hipMemcpyHostToDevice, c->stream));
+    AUD_HIP(c, hipMemcpyAsync(d_pow, hpow.data(), n_pow * 4, hipMemcpyHostToDevice, c->stream));
+    aud::MelspecArgs a;
+    fill_melspec_args(p, &a);
+    a.items = static_cast<const aud_item*>(c->ws[1]);
+    a.n_items = 1;
+    a.mel = d_mel;
+    a.power = d_pow;
+    AUD_HIP(c, aud::launch_mel_from_power(a, p->d.compute_dtype, c->stream));
+    std::vector<float> hm(n_mel);
+    AUD_HIP(c, hipMemcpyAsync(hm.data(), d_mel, n_mel * 4, hipMemcpyDeviceToHost, c->stream));
+    AUD_HIP(c, hipStreamSynchronize(c->stream));
+    for (int f = 0; f < nf; ++f) {  // mel.go:150-151
+        const double v = double(hm[size_t(f) * T]);
+        if (fbank) fbank[f] = v;
+        segment[size_t(f) * T + step] = v;
+    }
     return AUD_OK;
 }
 

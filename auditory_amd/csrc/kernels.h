@@ -82,6 +82,9 @@ struct SmoothArgs {
 };
 hipError_t launch_power_smooth(const SmoothArgs& a, int compute_dtype, hipStream_t st);
 hipError_t launch_mel_from_power(const MelspecArgs& a, int compute_dtype, hipStream_t st);
+hipError_t launch_frame_blend(const float* raw, int raw_stride, const double* carry, int H, int step,
+                              double prev, double cur, int comp_log_pow, double log_off, double log_min,
+                              double* out_p, double* out_lp, int compute_dtype, hipStream_t st);
 
 // MFCC tail (mel.CepstrumDct + Energy / deltas of SndEnv.ProcessSegment)
 struct MfccArgs {

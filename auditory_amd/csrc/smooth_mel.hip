@@ -47,6 +47,25 @@ __global__ __launch_bounds__(256) void k_power_smooth(const SmoothArgs a) {
     }
 }
 
+// dft.Params.Power for ONE step with the caller's carry (dft/dft.go:62-85): raw[k] is this step's
+// re^2+im^2, carry[k] the caller's `power` tensor from the previous step
+template <typename TT>
+__global__ __launch_bounds__(256) void k_frame_blend(const float* raw, int raw_stride, const double* carry, int H,
+                                                      int step, double prev, double cur, int comp_log_pow,
+                                                      double log_off, double log_min, double* out_p, double* out_lp) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= H) return;
+    TT p = TT(raw[size_t(k) * raw_stride]);
+    if (step > 0) p = TT(prev) * TT(carry[k]) + TT(cur) * p;  // dft.go:67-69
+    out_p[k] = double(p);
+    if (comp_log_pow) {
+        const TT v = p + TT(log_off);
+        out_lp[k] = double(v == TT(0) ? TT(log_min) : dev_log(v));
+    } else {
+        out_lp[k] = 0.0;
+    }
+}
+
 // mel.Params.FilterDft (mel/mel.go:120-153) applied to a stored power tensor [item, H, T]
 template <typename TT>
 __global__ __launch_bounds__(256) void k_mel_from_power(const MelspecArgs a) {
@@ -90,6 +109,19 @@ hipError_t launch_power_smooth(const SmoothArgs& a, int compute_dtype, hipStream
         hipLaunchKernelGGL(k_power_smooth<double>, grid, dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL(k_power_smooth<float>, grid, dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_frame_blend(const float* raw, int raw_stride, const double* carry, int H, int step,
+                              double prev, double cur, int comp_log_pow, double log_off, double log_min,
+                              double* out_p, double* out_lp, int compute_dtype, hipStream_t st) {
+    const dim3 grid(unsigned((H + 255) / 256));
+    if (compute_dtype == AUD_F64)
+        hipLaunchKernelGGL(k_frame_blend<double>, grid, dim3(256), 0, st, raw, raw_stride, carry, H, step, prev, cur,
+                           comp_log_pow, log_off, log_min, out_p, out_lp);
+    else
+        hipLaunchKernelGGL(k_frame_blend<float>, grid, dim3(256), 0, st, raw, raw_stride, carry, H, step, prev, cur,
+                           comp_log_pow, log_off, log_min, out_p, out_lp);
     return hipGetLastError();
 }
 

@@ -20,6 +20,18 @@ class Params:
         self.PrevSmooth, self.CurSmooth = c.prev_smooth, c.cur_smooth
         self.CompLogPow, self.LogOffSet, self.LogMin = bool(c.comp_log_pow), c.log_offset, c.log_min
 
+    def Filter(self, step, windowIn, winSamples, power, logPower, powerForSegment, logPowerForSegment, plan):
+        """dft/dft.go:42-85 for ONE step on the GPU (one launch per frame: correct, never fast -- batch at
+        ProcessSegment level).  Arrays are float64 and written in place like the Go tensors; `power` is the
+        previous step's carry on entry.  `plan` is the runtime.Plan of these parameters (SndEnv keeps one)."""
+        import ctypes as C
+        import numpy as np
+        w = np.ascontiguousarray(windowIn, np.float64)
+        assert len(w) == winSamples == plan.N
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        plan.ctx.check(plan.lib.aud_dft_filter_host(plan.handle, int(step), vp(w), vp(power), vp(logPower),
+                                                    vp(powerForSegment), vp(logPowerForSegment)))
+
     def to_c(self):
         return capi.DftParams(int(self.CompLogPow), self.LogMin, self.LogOffSet, self.PrevSmooth,
                               self.CurSmooth)

@@ -70,6 +70,14 @@ class Params:
         self.NCoefs = 13
         self.Deltas = True
 
+    def FilterDft(self, step, dftPowerOut, segmentData, fBankData, filters, plan):
+        """mel/mel.go:120-153 for ONE step on the GPU (see dft.Params.Filter about per-frame launches).
+        `filters` is accepted for signature parity; the plan already holds the table on the device."""
+        import ctypes as C
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        pw = np.ascontiguousarray(dftPowerOut, np.float64)
+        plan.ctx.check(plan.lib.aud_mel_filter_dft_host(plan.handle, int(step), vp(pw), vp(segmentData), vp(fBankData)))
+
     def InitFilters(self, dftSize, sampleRate):
         """mel/mel.go:77-117.  Returns the [NFilters, NFilters+2] float64 filter tensor (the Go
         code fills the tensor passed by the caller); sets BinPts / HzPts and clears FBank.Renorm."""

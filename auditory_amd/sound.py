@@ -51,6 +51,10 @@ class SndEnv:
         self.PowerSegment = None
         self.LogPowerSegment = None
         self.MelFBankSegment = None
+        self.Window = None
+        self.Power = None
+        self.LogPower = None
+        self.MelFBank = None
         self.Energy = None
         self.MFCCSegment = None
         self.MFCCDeltas = None
@@ -136,6 +140,29 @@ class SndEnv:
     def _item(self, segment, add):
         start0 = segment * self.Params.StrideSamples + MSecToSamples(add, self.SampleRate)
         return (0, len(self.Signal), start0)
+
+    def SndToWindow(self, start):
+        """sound/sndenv.go:455-478.  Returns None or the Go error text; fills self.Window."""
+        import ctypes as C
+        self.Window = np.zeros(self.Params.WinSamples)
+        rc = capi.load().aud_snd_to_window(self.Signal.ctypes.data_as(C.c_void_p), len(self.Signal), int(start),
+                                           self.Params.WinSamples, self.Window.ctypes.data_as(C.c_void_p))
+        return None if rc == capi.AUD_OK else "SndToWindow: end beyond signal length!!"
+
+    def ProcessStep(self, segment, step, add=0):
+        """sound/sndenv.go:438-452: one step through dft.Filter and mel.FilterDft (a GPU round trip per
+        frame; ProcessSegment is the batched way).  Returns None or the error text."""
+        p = self.Params
+        if self.Power is None:
+            H = p.WinSamples // 2 + 1
+            self.Power, self.LogPower, self.MelFBank = np.zeros(H), np.zeros(H), np.zeros(self.Mel.FBank.NFilters)
+        offset = p.Steps[step] + MSecToSamples(add, self.SampleRate)
+        err = self.SndToWindow(segment * p.StrideSamples + offset)
+        if err is None:
+            self.DFT.Filter(step, self.Window, p.WinSamples, self.Power, self.LogPower, self.PowerSegment,
+                            self.LogPowerSegment, self._plan)
+            self.Mel.FilterDft(step, self.Power, self.MelFBankSegment, self.MelFBank, self.MelFilters, self._plan)
+        return err
 
     def ProcessSegment(self, segment, add=0):
         """sound/sndenv.go:342-359 (frame loop part): fills PowerSegment, LogPowerSegment and

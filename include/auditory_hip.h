@@ -255,6 +255,25 @@ int aud_melspec_mfcc_batch_host(aud_plan* plan, const double* sig, int64_t sig_t
                                 int n_items, double* mel, double* power, double* log_power, double* mfcc,
                                 double* deltas, double* delta_deltas, double* energy);
 
+/* ---- the reference's per-step API, one frame per call ---------------------------------------
+ * Kept so that code written against dft.Params.Filter / mel.Params.FilterDft / SndEnv.ProcessStep
+ * keeps working unchanged.  Each call is a GPU round trip for a single frame (hundreds of
+ * microseconds for microseconds of work): correct, never fast -- batch at ProcessSegment level. */
+
+/* SndEnv.SndToWindow, sound/sndenv.go:455-478: window[N] <- signal[start, start+N) with left zero pad;
+ * AUD_ESHORT ("end beyond signal length") if start + N > sig_len.  Host-side, no arithmetic. */
+int aud_snd_to_window(const double* signal, int64_t sig_len, int64_t start, int win_samples, double* window);
+
+/* dft.Params.Filter (+FftReal, Power), dft/dft.go:42-85, for one step: window [N]; power [H] is the
+ * carry of the previous step on entry (used when step > 0 and PrevSmooth != 0) and this step's power on
+ * return; log_power [H]; power_seg / log_power_seg [H, T] get column `step` (log_* may be NULL). */
+int aud_dft_filter_host(aud_plan* plan, int step, const double* window, double* power, double* log_power,
+                        double* power_seg, double* log_power_seg);
+
+/* mel.Params.FilterDft, mel/mel.go:120-153, for one step: power [H]; segment [nf, T] gets column `step`,
+ * fbank [nf] the same values. */
+int aud_mel_filter_dft_host(aud_plan* plan, int step, const double* power, double* segment, double* fbank);
+
 /* agabor.Convolve on host memory: mel float64 [n_items, rows, cols], out float32 in/out. */
 int aud_gabor_batch_host(aud_plan* plan, const double* mel, int n_items, int mel_rows,
                          int mel_cols, int out_rank, const int32_t* out_shape, int by_time,

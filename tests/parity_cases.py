@@ -380,3 +380,47 @@ def case_mfcc_tail(orc, name, cdt):
         assert np.array_equal(got["mfcc"][i][0], got["energy"][i])          # row 0 is the Energy row
         dead = o["done"]
         assert np.all(got["mfcc"][i][1:, dead:] == 0)                       # unprocessed steps stay zero
+
+
+def case_per_step_api(orc, cdt):
+    """The reference's per-step calls (SndToWindow -> dft.Filter -> mel.FilterDft, sndenv.go:438-452), one
+    frame per call, incl. the PrevSmooth carry through the caller's `power` tensor and the short-signal error."""
+    from auditory_amd import sound
+    sig, _ = synth.batch(23, 1, 2100, 16000)
+    for prev in (0.0, 0.4):
+        se = sound.SndEnv(compute_dtype=cdt)
+        se.Defaults()
+        se.Mel.MFCC = False
+        se.SampleRate, se.Signal = 16000, sig[0]
+        se.GborOutUnitsX = se.GborOutUnitsY = 1
+        assert se.Init() is None
+        if prev:
+            se.DFT.PrevSmooth, se.DFT.CurSmooth = prev, 1.0 - prev
+            se._make_plan()
+        oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
+        oc.d.prev_smooth, oc.d.cur_smooth = prev, 1.0 - prev
+        ref = orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig[0], segment=0)
+        # the Go loop: zero the tensors, step until the first error (sndenv.go:343-359)
+        for t in (se.PowerSegment, se.LogPowerSegment, se.MelFBankSegment):
+            t[:] = 0
+        se.Power = se.LogPower = None
+        done = 0
+        for s in range(se.Params.SegmentSteps):
+            err = se.ProcessStep(0, s, 0)
+            if err is not None:
+                assert err.startswith("SndToWindow")
+                break
+            done += 1
+        assert done == ref["done"] == 13
+        ok, msg = W.feature_close(se.MelFBankSegment, ref["mel_seg"], cdt, lin_axis=0)
+        assert ok, "prev=%g mel %s" % (prev, msg)
+        tol = 4e-6 if cdt == capi.AUD_F32 else 3e-7
+        ok, msg = W.spectrum_close(se.PowerSegment[None], ref["power_seg"][None], tol)
+        assert ok, "prev=%g power %s" % (prev, msg)
+        assert np.all(se.MelFBankSegment[:, done:] == 0)
+        # and the batched ProcessSegment gives the same tensors
+        se2_mel = se.MelFBankSegment.copy()
+        se.ProcessSegment(0, 0)
+        ok, msg = W.feature_close(se.MelFBankSegment, se2_mel, cdt, lin_axis=0)
+        assert ok, "batched vs per-step " + msg
+        se._plan.close()

@@ -94,6 +94,11 @@ def test_emul_mfcc_tail(orc, emu, name, cdt):
     PC.case_mfcc_tail(orc, name, cdt)
 
 
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_emul_per_step_api(orc, emu, cdt):
+    PC.case_per_step_api(orc, cdt)
+
+
 def _sanitizer_run(variant, which, timeout=900):
     build_emul.build(variant)
     rt = {"asan": "libasan.so", "tsan": "libtsan.so"}[variant]

@@ -79,6 +79,11 @@ def test_mfcc_tail(orc, torch_cuda, name, cdt):
     PC.case_mfcc_tail(orc, name, cdt)
 
 
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_per_step_api(orc, torch_cuda, cdt):
+    PC.case_per_step_api(orc, cdt)
+
+
 def test_recreated_tone_fixtures_f64(orc, torch_cuda):
     PC.case_recreated_tone_fixtures_f64(orc)
 
