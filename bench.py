@@ -28,7 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def cpu_baseline(oc, sig64, L, target_s=12.0, max_threads=16, chunk=8):
+def cpu_baseline(oc, sig64, L, target_s=12.0, max_threads=16, chunk=8, audio_s=1.0):
     """The oracle (C float64 restatement, FFT plan cached per segment) timed on this box's host
     cores, one utterance per thread at a time (ctypes releases the GIL).
 
@@ -71,13 +71,13 @@ def cpu_baseline(oc, sig64, L, target_s=12.0, max_threads=16, chunk=8):
     with ThreadPoolExecutor(cores) as ex:
         n = sum(ex.map(worker, range(cores)))
     dt = time.perf_counter() - t0
-    return {"value": round(n * 1.0 / dt, 2), "unit": "audio-seconds/sec", "cores": cores,
+    return {"value": round(n * audio_s / dt, 2), "unit": "audio-seconds/sec", "cores": cores,
             "kind": "port",
-            "sample": "%d synthetic 1 s utterances (the bench batch, re-used), oracle/auditory_oracle.c "
+            "sample": "%d synthetic %g s utterances (the bench batch, re-used), oracle/auditory_oracle.c "
                       "float64, %d threads x %d calls x %d utterances, FFT plan cached per segment"
-                      % (n, cores, calls_per_thread, chunk),
-            "one_thread_cached": round(1.0 / per_utt, 2),
-            "one_thread_plan_per_frame": round(1.0 / per_utt_faithful, 2)}
+                      % (n, audio_s, cores, calls_per_thread, chunk),
+            "one_thread_cached": round(audio_s / per_utt, 2),
+            "one_thread_plan_per_frame": round(audio_s / per_utt_faithful, 2)}
 
 
 _real_cpu_baseline = cpu_baseline
@@ -289,7 +289,7 @@ def main():
     if ag:
         line["allgather"] = ag
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(oc, sig64, L)
+        line["cpu_baseline"] = cpu_baseline(oc, sig64, L, audio_s=dur / float(sr))
     if rank == 0:
         print(json.dumps(line))
     plan.close()

@@ -77,7 +77,8 @@ def test_bench_dry_run(monkeypatch, capsys, extra):
     import bench
     _patch(monkeypatch)
     monkeypatch.setattr(bench, "cpu_baseline",
-                        lambda oc, sig, L: bench.__dict__["_real_cpu_baseline"](oc, sig, L, target_s=0.2))
+                        lambda oc, sig, L, audio_s=1.0: bench.__dict__["_real_cpu_baseline"](oc, sig, L, target_s=0.2,
+                                                                                          audio_s=audio_s))
     monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--batch", "2", "--prewarm-s", "0"] + extra)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
