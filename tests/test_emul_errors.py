@@ -1,0 +1,99 @@
+"""Error behaviour of the C ABI (emulator build, CPU): every misuse returns a status code and a message,
+writes nothing, and never crashes -- the contract the cgo shim relies on."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import workloads as W
+from auditory_amd import capi, runtime
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "emul"))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import backend
+    with backend.emulated("plain") as lib:
+        yield lib
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_melspec_argument_errors(orc, emu):
+    oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
+    plan = W.product_plan(oc)
+    lib, h = plan.lib, plan.handle
+    sig = np.zeros(4000)
+    items = runtime.make_items([0], [4000], [0])
+    mel = np.full((1, 32, 14), 7.0)
+    # null buffers
+    assert lib.aud_melspec_batch_host(h, None, 4000, _vp(items), 1, _vp(mel), None, None) == capi.AUD_EINVAL
+    assert lib.aud_melspec_batch_host(h, _vp(sig), 4000, None, 1, _vp(mel), None, None) == capi.AUD_EINVAL
+    assert lib.aud_melspec_batch_host(h, _vp(sig), 4000, _vp(items), 1, None, None, None) == capi.AUD_EINVAL
+    assert lib.aud_melspec_batch_host(h, _vp(sig), 4000, _vp(items), -1, _vp(mel), None, None) == capi.AUD_EINVAL
+    # item outside the signal buffer
+    bad = runtime.make_items([100], [4000], [0])
+    assert lib.aud_melspec_batch_host(h, _vp(sig), 4000, _vp(bad), 1, _vp(mel), None, None) == capi.AUD_EINVAL
+    assert b"outside" in lib.aud_last_error(plan.ctx.handle)
+    assert (mel == 7.0).all()                                   # nothing was written
+    # bad sample type on the device entry point
+    assert lib.aud_melspec_batch_dev(h, _vp(sig), 9, _vp(items), 1, _vp(mel), None, None, None) == capi.AUD_EINVAL
+    # null plan
+    assert lib.aud_melspec_batch_host(None, _vp(sig), 4000, _vp(items), 1, _vp(mel), None, None) == capi.AUD_EINVAL
+    # MFCC entry points on a plan created without mfcc_coefs
+    assert lib.aud_mfcc_batch_dev(h, _vp(items), 1, _vp(mel), _vp(mel), _vp(mel), None, None, None, None) == capi.AUD_EINVAL
+    # gabor on a plan without gabor filters
+    out = np.ones((1, 8, 2, 2, 8), np.float32)
+    shp = (C.c_int32 * 4)(8, 2, 2, 8)
+    assert lib.aud_gabor_batch_host(h, _vp(mel), 1, 32, 14, 4, shp, 0, _vp(out)) == capi.AUD_EINVAL
+    assert (out == 1).all()
+    plan.close()
+
+
+def test_plan_argument_errors(orc, emu):
+    oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
+    ctx = runtime.get_ctx(0)
+    lib = ctx.lib
+    d = capi.PlanDesc()
+    h = C.c_void_p()
+    assert lib.aud_plan_create(ctx.handle, None, C.byref(h)) == capi.AUD_EINVAL
+    assert lib.aud_plan_create(None, C.byref(d), C.byref(h)) == capi.AUD_EINVAL
+    d.win_samples, d.step_samples, d.segment_steps = 400, 160, 14
+    d.mel.n_filters = 32
+    assert lib.aud_plan_create(ctx.handle, C.byref(d), C.byref(h)) == capi.AUD_EINVAL      # no tables
+    dftp = capi.DftParams(1, -100.0, 1.0, 0.0, 1.0)
+    fb = capi.MelFBank(32, 0.0, 8000.0, 0.0, -10.0, 0, -6.0, 4.0, 0.0)
+    for kw in (dict(compute_dtype=7), dict(mfcc_coefs=33), dict(mfcc_coefs=-1)):
+        with pytest.raises(capi.AuditoryError):
+            runtime.Plan(ctx, 400, 160, 14, 2, dftp, fb, oc.bins, oc.filt, **kw)
+    with pytest.raises(capi.AuditoryError):                                                 # bad step
+        runtime.Plan(ctx, 400, 0, 14, 2, dftp, fb, oc.bins, oc.filt)
+    assert lib.aud_plan_destroy(None) == capi.AUD_EINVAL
+    assert lib.aud_plan_set_option(None, b"kernel", 1) == capi.AUD_EINVAL
+    assert lib.aud_last_error(None) == b"null context"
+    assert lib.aud_shutdown(None) == capi.AUD_EINVAL
+
+
+def test_per_step_and_comm_errors(orc, emu):
+    oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
+    plan = W.product_plan(oc)
+    lib, h = plan.lib, plan.handle
+    win, pw = np.zeros(400), np.zeros(201)
+    seg = np.zeros((201, 14))
+    assert lib.aud_dft_filter_host(h, 14, _vp(win), _vp(pw), _vp(pw), _vp(seg), _vp(seg)) == capi.AUD_EINVAL   # step >= T
+    assert lib.aud_dft_filter_host(h, 0, None, _vp(pw), _vp(pw), _vp(seg), _vp(seg)) == capi.AUD_EINVAL
+    assert lib.aud_mel_filter_dft_host(h, -1, _vp(pw), _vp(seg), None) == capi.AUD_EINVAL
+    sig = np.arange(10.0)
+    assert lib.aud_snd_to_window(_vp(sig), 10, 8, 4, _vp(win)) == capi.AUD_ESHORT          # end beyond signal
+    assert lib.aud_snd_to_window(_vp(sig), 10, -2, 4, _vp(win)) == 0 and list(win[:4]) == [0, 0, 0, 1]
+    # the all-gather needs a communicator
+    assert lib.aud_allgather_dev(plan.ctx.handle, _vp(win), _vp(win), 4, None) == capi.AUD_ERCCL
+    assert lib.aud_comm_init(plan.ctx.handle, 2, 5, _vp(win)) == capi.AUD_EINVAL            # rank >= n_ranks
+    assert lib.aud_comm_destroy(plan.ctx.handle) == 0
+    plan.close()
