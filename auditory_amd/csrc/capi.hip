@@ -359,6 +359,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
             p->use_fast = true;
             p->family = fast_name;
             p->r16 = fastcfg;
+            p->r16.ntile = 1;
             p->r16.grp_off = p->d_grp;
             p->r16.grp_flt = p->d_grp + goff;
             p->r16.chunk = p->d_grp + goff + nf;
@@ -417,7 +418,15 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
         if (!aud::melspec_r16_supported(p->d.win_samples, p->d.step_samples, p->d.compute_dtype, p->r16_chunks,
                                         value == 0, &cfg))
             return fail(c, AUD_EINVAL, "this r16x16 variant does not support the plan (odd step?)");
+        cfg.ntile = value == 0 ? p->r16.ntile : 1;
         p->r16 = cfg;
+        return AUD_OK;
+    }
+    if (key == "r16_tiles") {  // 16-frame tiles per workgroup of the direct r16x16 kernel: 1 or 2 (second prefetched)
+        if (p->fast_kind != aud_plan::kR16) return fail(c, AUD_EINVAL, "plan has no r16x16 kernel");
+        if (value != 1 && value != 2) return fail(c, AUD_EINVAL, "r16_tiles: 1 or 2");
+        if (value == 2 && !p->r16.direct) return fail(c, AUD_EINVAL, "r16_tiles = 2 needs the direct input variant");
+        p->r16.ntile = value;
         return AUD_OK;
     }
     return fail(c, AUD_EINVAL, "unknown option");

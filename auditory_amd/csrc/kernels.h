@@ -59,6 +59,7 @@ struct GaborArgs {
 // extra arguments of the register-resident two-pass kernels (r16x16 for N = 512, r25x8 for N = 400)
 struct FastArgs {
     int direct;            // 1: pass-1 operands straight from global memory, 0: staged through LDS
+    int ntile;             // r16x16 direct: 16-frame tiles per workgroup (1, or 2 with the second prefetched)
     int xch_off;           // byte offset of the transpose buffer inside dynamic LDS
     int p_off;             // byte offset of the power spectrum (aliases the span or the transpose buffer)
     int w4_off;            // byte offset of the LDS copy of the chunked mel weights

@@ -46,98 +46,51 @@ struct Layout {
     static constexpr int kFrameC = 16 * kRowC;
 };
 
-template <typename TT, bool DIRECT>
-__global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const FastArgs e) {
-    unsigned char* smem = dyn_lds();
-    TT* sigbuf = reinterpret_cast<TT*>(smem);                   // STAGED only: [span]
-    TT* Pbase = reinterpret_cast<TT*>(smem + e.p_off);          // power spectrum [16][kHp]
-    C2<TT>* xch = reinterpret_cast<C2<TT>*>(smem + e.xch_off);  // [16][16][kRowC]
-    const int tid = threadIdx.x;
-    const int f = tid >> 4;   // frame within the tile
-    const int j = tid & 15;   // lane within the frame's 16-lane group
+// pass-1 operands of frame (t0 + f) straight from global memory: z[16 n1 + j] = (x[32 n1 + 2j], x[.. + 1])
+template <typename TT>
+__device__ __forceinline__ void r16_load_direct(const MelspecArgs& a, const aud_item& it, int t0, int f, int j,
+                                                C2<TT> (&v)[16]) {
     const int T = a.T, S = a.S;
-
-    const int tiles = (T + kF - 1) / kF;
-    const int item = blockIdx.x / tiles;
-    const int t0 = (blockIdx.x - item * tiles) * kF;
-    const aud_item it = a.items[item];
-    const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_512^k
     const int64_t lim = it.sig_len;
-
-    C2<TT> v[16];
-    if constexpr (DIRECT) {
-        // ---- pass-1 operands straight from global memory: z[16 n1 + j] = (x[32 n1 + 2j], x[.. + 1]) ----
-        const int sstep = t0 + f;
-        const int64_t start = int64_t(it.start0) + int64_t(S) * (sstep - a.border);
-        const int64_t pos0 = start + 2 * j;
-        const bool frame_on = sstep < T;
-        bool fast = false;
-        if constexpr (sizeof(TT) == 4) {
-            // whole frame inside the stream, f32 samples, 8-byte aligned pairs
-            fast = frame_on && start >= 0 && start + kN <= lim && a.sig_dtype == AUD_F32 &&
-                   ((it.sig_off + start) & 1) == 0 && (reinterpret_cast<uintptr_t>(a.sig) & 7) == 0;
-            if (fast) {
-                const C2<TT>* __restrict__ src = reinterpret_cast<const C2<TT>*>(
-                    static_cast<const float*>(a.sig) + it.sig_off + pos0);
+    const int sstep = t0 + f;
+    const int64_t start = int64_t(it.start0) + int64_t(S) * (sstep - a.border);
+    const int64_t pos0 = start + 2 * j;
+    const bool frame_on = sstep < T;
+    bool fast = false;
+    if constexpr (sizeof(TT) == 4) {
+        // whole frame inside the stream, f32 samples, 8-byte aligned pairs
+        fast = frame_on && start >= 0 && start + kN <= lim && a.sig_dtype == AUD_F32 &&
+               ((it.sig_off + start) & 1) == 0 && (reinterpret_cast<uintptr_t>(a.sig) & 7) == 0;
+        if (fast) {
+            const C2<TT>* __restrict__ src = reinterpret_cast<const C2<TT>*>(
+                static_cast<const float*>(a.sig) + it.sig_off + pos0);
 #pragma unroll
-                for (int n1 = 0; n1 < 16; ++n1) v[n1] = src[16 * n1];
-            }
-        }
-        if (!fast) {
-            // tile edges (left zero pad, end of stream), other sample types: guarded element loads
-#pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                const int64_t p = pos0 + 32 * n1;
-                v[n1].x = (frame_on && p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p) : TT(0);
-                v[n1].y = (frame_on && p + 1 >= 0 && p + 1 < lim)
-                              ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p + 1) : TT(0);
-            }
-        }
-    } else {
-        // ---- stage the tile's sample span: positions g0 .. g0 + span of the item's stream ------
-        const int64_t g0 = int64_t(it.start0) + int64_t(S) * (t0 - a.border);
-        const int span = (kF - 1) * S + kN;
-        if (a.sig_dtype == AUD_F32 && sizeof(TT) == 4 && ((it.sig_off + g0) & 3) == 0 &&
-            (reinterpret_cast<uintptr_t>(a.sig) & 15) == 0) {
-            const float* __restrict__ src = static_cast<const float*>(a.sig) + it.sig_off;
-            for (int c = tid; c * 4 < span; c += 256) {
-                const int64_t p = g0 + 4 * c;
-                float4 q4;
-                if (p >= 0 && p + 3 < lim) {
-                    q4 = *reinterpret_cast<const float4*>(src + p);
-                } else {
-                    q4.x = (p >= 0 && p < lim) ? src[p] : 0.f;
-                    q4.y = (p + 1 >= 0 && p + 1 < lim) ? src[p + 1] : 0.f;
-                    q4.z = (p + 2 >= 0 && p + 2 < lim) ? src[p + 2] : 0.f;
-                    q4.w = (p + 3 >= 0 && p + 3 < lim) ? src[p + 3] : 0.f;
-                }
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(sigbuf) + 4 * c) = q4;
-            }
-        } else {
-            for (int c = tid; c < span; c += 256) {
-                const int64_t p = g0 + c;
-                sigbuf[c] = (p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p) : TT(0);
-            }
+            for (int n1 = 0; n1 < 16; ++n1) v[n1] = src[16 * n1];
         }
     }
+    if (!fast) {
+        // tile edges (left zero pad, end of stream), other sample types: guarded element loads
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const int64_t p = pos0 + 32 * n1;
+            v[n1].x = (frame_on && p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p) : TT(0);
+            v[n1].y = (frame_on && p + 1 >= 0 && p + 1 < lim)
+                          ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p + 1) : TT(0);
+        }
+    }
+}
 
-    // the chunked mel weights (a few KB) ride along into LDS; first used after the last barrier
-    stage_mel_weights<TT, 256>(e, smem, tid);
-
-    // per-lane constants: W_256^(j*k1) = W_512^(2 j k1)
+// everything after the pass-1 operands are in registers: both DFT passes, the transpose, the split, the
+// power spectrum and the tile epilogue, for the 16 frames t0 .. t0 + 15
+template <typename TT, bool DIRECT>
+__device__ __forceinline__ void r16_tile(const MelspecArgs& a, const FastArgs& e, unsigned char* smem, C2<TT>* xch,
+                                         TT* Pbase, const C2<TT>* __restrict__ tw, const aud_item& it, int item,
+                                         int t0, int tid, int f, int j, C2<TT> (&v)[16]) {
+    // per-lane twiddles W_256^(j*k1) = W_512^(2 j k1): 15 L1-resident loads, issued ahead of the first DFT
     C2<TT> tw1[16];
+    tw1[0] = C2<TT>{TT(1), TT(0)};
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) tw1[k1] = tw[2 * j * k1];
-
-    if constexpr (!DIRECT) {
-        __syncthreads();
-        // ---- pass 1 operands from the staged span: z[16 n1 + j] ----------------------------------
-        // S is even on this path (checked by the host), so every frame starts on an 8-byte
-        // boundary and each point is one 8-byte LDS read
-        const C2<TT>* fr = reinterpret_cast<const C2<TT>*>(sigbuf) + (f * (S >> 1) + j);
-#pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) v[n1] = fr[16 * n1];
-    }
     // ---- pass 1: 16-point DFT over n1 ----------------------------------------------------------
     dft16(v);
     {
@@ -178,10 +131,13 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
         const int partner = (lane & 48) | ((16 - j) & 15);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const C2<TT> mine_up = (j == 0) ? v[(16 - q) & 15] : v[15 - q];  // what my partner needs
+            // what my partner needs from me (selected by value: a pointer select would pin v[] in scratch)
+            const TT up0x = v[(16 - q) & 15].x, up0y = v[(16 - q) & 15].y;
+            const TT up1x = v[15 - q].x, up1y = v[15 - q].y;
+            const TT mine_x = (j == 0) ? up0x : up1x, mine_y = (j == 0) ? up0y : up1y;
             C2<TT> B;
-            B.x = __shfl(mine_up.x, partner, 64);
-            B.y = __shfl(mine_up.y, partner, 64);
+            B.x = __shfl(mine_x, partner, 64);
+            B.y = __shfl(mine_y, partner, 64);
             const C2<TT> A = v[q];
             const int k = j + 16 * q;
             const C2<TT> w = tw[k];                     // W_512^k
@@ -204,6 +160,83 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
 
     tile_epilogue<TT, 256, kF>(a, e, Pbase, kHp, smem, it, item, t0, tid);
 }
+
+// NTILE tiles of 16 frames per workgroup.  With NTILE = 2 (DIRECT only) the operands of the second tile are
+// requested before the first tile is computed, so their memory latency hides behind a whole tile of work,
+// and the grid shrinks to one residency round at the bench size.
+template <typename TT, bool DIRECT, int NTILE>
+__global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const FastArgs e) {
+    unsigned char* smem = dyn_lds();
+    TT* sigbuf = reinterpret_cast<TT*>(smem);                   // STAGED only: [span]
+    TT* Pbase = reinterpret_cast<TT*>(smem + e.p_off);          // power spectrum [16][kHp]
+    C2<TT>* xch = reinterpret_cast<C2<TT>*>(smem + e.xch_off);  // [16][16][kRowC]
+    const int tid = threadIdx.x;
+    const int f = tid >> 4;   // frame within the tile
+    const int j = tid & 15;   // lane within the frame's 16-lane group
+    const int T = a.T, S = a.S;
+
+    const int tiles = (T + kF * NTILE - 1) / (kF * NTILE);
+    const int item = blockIdx.x / tiles;
+    const int t0 = (blockIdx.x - item * tiles) * kF * NTILE;
+    const aud_item it = a.items[item];
+    const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_512^k
+    const int64_t lim = it.sig_len;
+    (void)sigbuf; (void)lim; (void)S;
+
+    C2<TT> v[16];
+    C2<TT> v2[NTILE > 1 ? 16 : 1];
+    if constexpr (DIRECT) {
+        r16_load_direct<TT>(a, it, t0, f, j, v);
+        if constexpr (NTILE > 1) r16_load_direct<TT>(a, it, t0 + kF, f, j, v2);  // in flight during tile 1
+    } else {
+        // ---- stage the tile's sample span: positions g0 .. g0 + span of the item's stream ------
+        const int64_t g0 = int64_t(it.start0) + int64_t(S) * (t0 - a.border);
+        const int span = (kF - 1) * S + kN;
+        if (a.sig_dtype == AUD_F32 && sizeof(TT) == 4 && ((it.sig_off + g0) & 3) == 0 &&
+            (reinterpret_cast<uintptr_t>(a.sig) & 15) == 0) {
+            const float* __restrict__ src = static_cast<const float*>(a.sig) + it.sig_off;
+            for (int c = tid; c * 4 < span; c += 256) {
+                const int64_t p = g0 + 4 * c;
+                float4 q4;
+                if (p >= 0 && p + 3 < lim) {
+                    q4 = *reinterpret_cast<const float4*>(src + p);
+                } else {
+                    q4.x = (p >= 0 && p < lim) ? src[p] : 0.f;
+                    q4.y = (p + 1 >= 0 && p + 1 < lim) ? src[p + 1] : 0.f;
+                    q4.z = (p + 2 >= 0 && p + 2 < lim) ? src[p + 2] : 0.f;
+                    q4.w = (p + 3 >= 0 && p + 3 < lim) ? src[p + 3] : 0.f;
+                }
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(sigbuf) + 4 * c) = q4;
+            }
+        } else {
+            for (int c = tid; c < span; c += 256) {
+                const int64_t p = g0 + c;
+                sigbuf[c] = (p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p) : TT(0);
+            }
+        }
+    }
+
+    // the chunked mel weights (a few KB) ride along into LDS; first used after the last barrier
+    stage_mel_weights<TT, 256>(e, smem, tid);
+
+    if constexpr (!DIRECT) {
+        __syncthreads();
+        // ---- pass 1 operands from the staged span: z[16 n1 + j] ----------------------------------
+        // S is even on this path (checked by the host), so every frame starts on an 8-byte
+        // boundary and each point is one 8-byte LDS read
+        const C2<TT>* fr = reinterpret_cast<const C2<TT>*>(sigbuf) + (f * (S >> 1) + j);
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = fr[16 * n1];
+    }
+    r16_tile<TT, DIRECT>(a, e, smem, xch, Pbase, tw, it, item, t0, tid, f, j, v);
+    if constexpr (NTILE > 1) {
+        if (t0 + kF < T) {          // uniform: the item has a second tile for this workgroup
+            __syncthreads();        // the power spectrum of tile 1 is consumed: the buffers are free again
+            r16_tile<TT, DIRECT>(a, e, smem, xch, Pbase, tw, it, item, t0 + kF, tid, f, j, v2);
+        }
+    }
+}
+
 
 }  // namespace
 
@@ -237,16 +270,19 @@ bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, bool d
         out->lds_bytes = unsigned(total);
         out->n_chunks = n_chunks;
         out->direct = direct ? 1 : 0;
+        if (!direct) out->ntile = 1;
     }
     return true;
 }
 
 hipError_t melspec_r16_prepare(unsigned lds_bytes) {
     // more than 64 KiB of dynamic LDS has to be requested explicitly
-    const void* fns[4] = {reinterpret_cast<const void*>(&k_melspec_r16<double, true>),
-                          reinterpret_cast<const void*>(&k_melspec_r16<double, false>),
-                          reinterpret_cast<const void*>(&k_melspec_r16<float, true>),
-                          reinterpret_cast<const void*>(&k_melspec_r16<float, false>)};
+    const void* fns[6] = {reinterpret_cast<const void*>(&k_melspec_r16<double, true, 1>),
+                          reinterpret_cast<const void*>(&k_melspec_r16<double, true, 2>),
+                          reinterpret_cast<const void*>(&k_melspec_r16<double, false, 1>),
+                          reinterpret_cast<const void*>(&k_melspec_r16<float, true, 1>),
+                          reinterpret_cast<const void*>(&k_melspec_r16<float, true, 2>),
+                          reinterpret_cast<const void*>(&k_melspec_r16<float, false, 1>)};
     for (const void* fn : fns) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
         if (e != hipSuccess) return e;
@@ -255,18 +291,24 @@ hipError_t melspec_r16_prepare(unsigned lds_bytes) {
 }
 
 hipError_t launch_melspec_r16(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st) {
-    const int tiles = (a.T + kF - 1) / kF;
-    const dim3 grid(unsigned(a.n_items) * unsigned(tiles));
+    const int ntile = (e.direct && e.ntile == 2) ? 2 : 1;
+    const int tiles = (a.T + kF * ntile - 1) / (kF * ntile);
+    const dim3 grid(unsigned(a.n_items) * unsigned(tiles)), blk(256);
+    const unsigned lds = e.lds_bytes;
     if (compute_dtype == AUD_F64) {
-        if (e.direct)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<double, true>), grid, dim3(256), e.lds_bytes, st, a, e);
+        if (e.direct && ntile == 2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<double, true, 2>), grid, blk, lds, st, a, e);
+        else if (e.direct)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<double, true, 1>), grid, blk, lds, st, a, e);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<double, false>), grid, dim3(256), e.lds_bytes, st, a, e);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<double, false, 1>), grid, blk, lds, st, a, e);
     } else {
-        if (e.direct)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<float, true>), grid, dim3(256), e.lds_bytes, st, a, e);
+        if (e.direct && ntile == 2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<float, true, 2>), grid, blk, lds, st, a, e);
+        else if (e.direct)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<float, true, 1>), grid, blk, lds, st, a, e);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<float, false>), grid, dim3(256), e.lds_bytes, st, a, e);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<float, false, 1>), grid, blk, lds, st, a, e);
     }
     return hipGetLastError();
 }

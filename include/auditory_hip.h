@@ -196,7 +196,8 @@ int aud_plan_destroy(aud_plan* plan);
 const char* aud_plan_kernel_name(const aud_plan* plan);
 /* Tuning / diagnostic switches; results are identical whatever they are set to.
  *   "kernel"    0 automatic (default), 1 force the generic any-N kernel
- *   "r16_input" 0 operands straight from global memory (default), 1 staged through LDS */
+ *   "r16_input" 0 operands straight from global memory (default), 1 staged through LDS
+ *   "r16_tiles" 1 (default) or 2 sixteen-frame tiles per workgroup, the second one's operands prefetched */
 int aud_plan_set_option(aud_plan* plan, const char* name, int value);
 
 /* ---- hot path, device-resident (what bench.py times) ----------------------------- */

@@ -259,7 +259,8 @@ def case_prev_smooth(orc, name, cdt):
 
 
 # the kernel variants a 512-sample plan can run: all must agree with the oracle (and each other)
-N512_VARIANTS = {"r16_direct": {"r16_input": 0}, "r16_staged": {"r16_input": 1}, "generic": {"kernel": 1}}
+N512_VARIANTS = {"r16_direct": {"r16_input": 0}, "r16_direct_2tiles": {"r16_input": 0, "r16_tiles": 2},
+                 "r16_staged": {"r16_input": 1}, "generic": {"kernel": 1}}
 
 
 def _fast_family(orc, name, cdt, seg_ms=None):

@@ -158,3 +158,38 @@ def test_sndenv_pad_tail():
     sig = np.zeros(10000)
     assert se.Tail(sig) == (10000 - 1600) % 1600
     assert len(se.Pad(sig)) == 10000 + 1600 - 160 - se.Tail(sig) % 160
+
+
+def test_kernels_use_no_scratch_and_fit_their_occupancy():
+    """hipcc's own resource report for every frame->mel kernel: no scratch (a register array that falls into
+    scratch memory costs 5x, and it happens silently: a pointer select on a register array did it once), and the
+    float32 kernels stay within the VGPR budget their LDS-limited occupancy assumes."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not installed")
+    from auditory_amd import build as B
+    budget = {"k_melspec_r16IfLb1ELi1": 128, "k_melspec_r16IfLb1ELi2": 128, "k_melspec_r16IfLb0ELi1": 168,
+              "k_melspec_r25If": 168, "k_melspec_r1024If": 168, "k_melspec_genericIf": 256}
+    seen = {}
+    for src in ("melspec_r16.hip", "melspec_r25.hip", "melspec_r1024.hip", "melspec_generic.hip"):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17",
+                            "-I" + B.INCLUDE, "-I" + B.CSRC, "-c", os.path.join(B.CSRC, src), "-o", "/dev/null",
+                            "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd="/tmp")
+        assert r.returncode == 0, r.stderr[-2000:]
+        name = None
+        for line in r.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.search(r"VGPRs: (\d+)", line)
+            if m and name:
+                seen.setdefault(name, {})["vgpr"] = int(m.group(1))
+            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+            if m and name:
+                seen.setdefault(name, {})["scratch"] = int(m.group(1))
+    assert len(seen) >= 12
+    for name, res in seen.items():
+        assert res["scratch"] == 0, (name, res)
+        for key, lim in budget.items():
+            if key in name:
+                assert res["vgpr"] <= lim, (name, res, lim)

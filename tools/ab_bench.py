@@ -49,7 +49,8 @@ def main():
     cdt = capi.AUD_F32 if args.compute == "f32" else capi.AUD_F64
     variants = {"auto": {}, "generic": {"kernel": 1}}
     if args.win_ms == 32.0:
-        variants = {"r16 direct": {"r16_input": 0}, "r16 staged": {"r16_input": 1}, "generic": {"kernel": 1}}
+        variants = {"r16 direct": {"r16_input": 0}, "r16 direct x2": {"r16_input": 0, "r16_tiles": 2},
+                    "r16 staged": {"r16_input": 1}, "generic": {"kernel": 1}}
     plans = {}
     for vname, opts in variants.items():
         p = W.product_plan(oc, cdt)
