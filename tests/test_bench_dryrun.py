@@ -96,3 +96,14 @@ def test_bench_dry_run(monkeypatch, capsys, extra):
     assert line["cpu_baseline"]["cores"] <= 16 and line["cpu_baseline"]["kind"] == "port"
     assert "workload" in line["config"] and "model" not in line["config"]
     assert line["value"] > 0 and line["roofline"]["achieved"] >= 0
+
+
+def test_smoke_dry_run(monkeypatch, capsys):
+    """__graft_entry__.smoke() end to end on the CPU (emulator build, torch.cuda stubbed)"""
+    import backend
+    import __graft_entry__ as G
+    _patch(monkeypatch)
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    with backend.emulated("plain"):
+        G.smoke()
+    assert "smoke ok: kernel=r16x16" in capsys.readouterr().out
