@@ -107,3 +107,19 @@ def test_smoke_dry_run(monkeypatch, capsys):
     with backend.emulated("plain"):
         G.smoke()
     assert "smoke ok: kernel=r16x16" in capsys.readouterr().out
+
+
+def test_device_api_tests_dry_run(monkeypatch, orc):
+    """the torch-tensor based -m gpu tests (BatchProcessor plumbing, sample types, fused mel+gabor, the
+    size-independent properties at a small batch) on the CPU: emulator build, torch.cuda stubbed"""
+    import backend
+    import test_gpu_parity as G
+    _patch(monkeypatch)
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    real_empty, real_zeros = torch.empty, torch.zeros
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: real_empty(*a, **{**k, "device": "cpu"}))
+    monkeypatch.setattr(torch, "zeros", lambda *a, **k: real_zeros(*a, **{**k, "device": "cpu"}))
+    with backend.emulated("plain"):
+        G.test_input_dtypes_agree(orc, torch)
+        G.test_process_batch_mel_plus_gabor(orc, torch)
+        G.test_full_size_properties_cfg2(orc, torch, B=4)
