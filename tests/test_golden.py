@@ -18,11 +18,12 @@ def test_oracle_reproduces_golden(orc, name):
     GC.check_oracle_reproduces(name)
 
 
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
 @pytest.mark.parametrize("name", GC.NAMES)
-def test_emulated_kernels_match_golden(orc, name):
+def test_emulated_kernels_match_golden(orc, name, cdt):
     import backend
     with backend.emulated("plain"):
-        GC.check_library_against_golden(name, capi.AUD_F32)
+        GC.check_library_against_golden(name, cdt)
 
 
 @pytest.mark.gpu
