@@ -70,6 +70,7 @@ SYMBOLS = {
     "aud_tail": (C.c_int, [C.c_int] * 3),
     "aud_pad_len": (C.c_int, [C.c_int] * 4),
     "aud_pcm_to_float": (C.c_double, [C.c_int, C.c_int]),
+    "aud_adjust_for_silence": (C.c_int, [C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int)]),
     "aud_dft_defaults": (None, [C.POINTER(DftParams)]),
     "aud_mel_defaults": (None, [C.POINTER(MelFBank)]),
     "aud_freq_to_mel": (C.c_double, [C.c_double]),

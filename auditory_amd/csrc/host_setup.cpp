@@ -72,6 +72,23 @@ int aud_pad_len(int signal_len, int segment_samples, int stride_samples, int ste
     return segment_samples - step_samples - tail % step_samples;
 }
 
+// sound/sndenv.go:274-294
+int aud_adjust_for_silence(double add_ms, double existing_ms, int sample_rate, int* delta_samples) {
+    if (delta_samples) *delta_samples = 0;
+    if (sample_rate <= 0) return -1;  // "sample rate <= 0"
+    int offset = 0;
+    if (add_ms >= 0) {
+        if (add_ms < existing_ms) {
+            offset = static_cast<int>(existing_ms - add_ms);  // Go int(): truncation
+            if (delta_samples) *delta_samples = -aud_msec_to_samples(double(offset), sample_rate);
+        } else if (add_ms > existing_ms) {
+            offset = static_cast<int>(add_ms - existing_ms);
+            if (delta_samples) *delta_samples = aud_msec_to_samples(double(offset), sample_rate);
+        }
+    }
+    return offset;
+}
+
 // sound/sound.go:130-141
 double aud_pcm_to_float(int value, int bit_depth) {
     switch (bit_depth) {

@@ -197,6 +197,20 @@ class SndEnv:
                         plan=self._plan)
         return self.GborOutput
 
+    def AdjustForSilence(self, add, existing):
+        """sound/sndenv.go:274-294: trims or prepends silence at the start of Signal; returns the offset (ms)"""
+        import ctypes as C
+        delta = C.c_int(0)
+        off = capi.load().aud_adjust_for_silence(float(add), float(existing), int(self.SampleRate), C.byref(delta))
+        if off < 0:
+            print("sample rate <= 0")
+            return -1
+        if delta.value < 0:
+            self.Signal = self.Signal[-delta.value:]
+        elif delta.value > 0:
+            self.Signal = np.concatenate([np.zeros(delta.value), self.Signal])
+        return off
+
     def Tail(self, signal):
         """sound/sndenv.go:503-507"""
         return capi.load().aud_tail(len(signal), self.Params.SegmentSamples, self.Params.StrideSamples)

@@ -153,6 +153,10 @@ int aud_seg_cnt(int signal_len, int segment_samples, int stride_samples, int cha
 /* SndEnv.Tail / SndEnv.Pad length, sound/sndenv.go:503-519 */
 int aud_tail(int signal_len, int segment_samples, int stride_samples);
 int aud_pad_len(int signal_len, int segment_samples, int stride_samples, int step_samples);
+/* SndEnv.AdjustForSilence, sound/sndenv.go:274-294: returns the Go function's `offset` (ms, truncated toward
+ * zero; -1 if sample_rate <= 0) and in *delta_samples what happens to the front of the signal:
+ * < 0 trim that many samples, > 0 prepend that many zeros, 0 leave it alone. */
+int aud_adjust_for_silence(double add_ms, double existing_ms, int sample_rate, int* delta_samples);
 /* Wave.GetFloatAtIdx, sound/sound.go:130-141 */
 double aud_pcm_to_float(int value, int bit_depth);
 

@@ -151,6 +151,17 @@ def test_gabor_iter_space():
     assert lib.aud_gabor_iter_space(g2, 40, 104, 3, shp2, nt, nf_, st) == capi.AUD_EINVAL
 
 
+def test_adjust_for_silence():
+    se = sound.SndEnv()
+    se.Defaults()
+    se.SampleRate, se.Signal = 16000, np.arange(16000.0)
+    assert se.AdjustForSilence(30.0, 100.0) == 70 and len(se.Signal) == 16000 - 1120 and se.Signal[0] == 1120
+    assert se.AdjustForSilence(100.5, 30.0) == 70 and len(se.Signal) == 16000 and np.all(se.Signal[:1120] == 0)
+    assert se.AdjustForSilence(50.0, 50.0) == 0 and se.AdjustForSilence(-1.0, 50.0) == 0 and len(se.Signal) == 16000
+    se.SampleRate = 0
+    assert se.AdjustForSilence(10, 20) == -1
+
+
 def test_sndenv_pad_tail():
     se = sound.SndEnv()
     se.Defaults()
