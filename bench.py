@@ -98,6 +98,10 @@ def main():
     ap.add_argument("--launch", choices=["graph", "eager"], default="graph",
                     help="graph: the K steps are replayed from hipGraphs of up to 50 captured steps each "
                          "(a ~5 us kernel is otherwise bound by the Python/ctypes launch path)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the steps are dealt over round-robin (each with its own output buffer). 1 = every "
+                         "step waits for the previous one (default, what roofline.avg_launch_us is defined on); 2 lets "
+                         "consecutive, independent batches overlap the way a double-buffered pipeline would")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="aud_plan_set_option switches for A/B runs, e.g. r16_input=1 (staged) or kernel=1 (generic)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for CPU dry runs)")
@@ -150,19 +154,39 @@ def main():
 
     # one step = one launch of the fused frame->mel kernel over the resident batch, through the C ABI
     lib, plan_h = plan.lib, plan.handle
-    call_args = (plan_h, dsig.data_ptr(), capi.AUD_F32, items.data_ptr(), B, mel.data_ptr(), None, None)
-    gout = torch.zeros((B, 11, 32, 2, 8), dtype=torch.float32, device=dev) if gab else None
-    gab_args = (plan_h, dsig.data_ptr(), capi.AUD_F32, items.data_ptr(), B, mel.data_ptr(), 11, 32,
-                gout.data_ptr()) if gab else None
+    n_streams = max(1, args.streams)
+    mels = [mel] + [torch.empty_like(mel) for _ in range(n_streams - 1)]
+    gouts = [torch.zeros((B, 11, 32, 2, 8), dtype=torch.float32, device=dev) if gab else None for _ in range(n_streams)]
+    gout = gouts[0]
+    side = [None] + [torch.cuda.Stream(dev) for _ in range(n_streams - 1)] if n_streams > 1 else [None]
+    step_no = [0]
 
-    def step():
-        st = torch.cuda.current_stream(dev).cuda_stream
+    def launch(buf, st):
         if gab:
-            rc = lib.aud_process_batch_dev(*gab_args, st)
+            rc = lib.aud_process_batch_dev(plan_h, dsig.data_ptr(), capi.AUD_F32, items.data_ptr(), B,
+                                           mels[buf].data_ptr(), 11, 32, gouts[buf].data_ptr(), st)
         else:
-            rc = lib.aud_melspec_batch_dev(*call_args, st)
+            rc = lib.aud_melspec_batch_dev(plan_h, dsig.data_ptr(), capi.AUD_F32, items.data_ptr(), B,
+                                           mels[buf].data_ptr(), None, None, st)
         if rc != 0:
             raise RuntimeError("hot path launch: %d %s" % (rc, lib.aud_last_error(plan.ctx.handle)))
+
+    def step():
+        """one batch; with --streams > 1 consecutive steps go to different streams / output buffers"""
+        buf = step_no[0] % n_streams
+        step_no[0] += 1
+        if buf == 0:
+            launch(0, torch.cuda.current_stream(dev).cuda_stream)
+        else:
+            launch(buf, side[buf].cuda_stream)
+
+    def fork():
+        for sst in side[1:]:
+            sst.wait_stream(torch.cuda.current_stream(dev))
+
+    def join():
+        for sst in side[1:]:
+            torch.cuda.current_stream(dev).wait_stream(sst)
 
     def sync_all():
         if world > 1:
@@ -180,8 +204,10 @@ def main():
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
+                fork()
                 for _ in range(per_graph):
                     step()
+                join()
             graph.replay()
             torch.cuda.synchronize(dev)
             launch_mode = "hipGraph x%d" % per_graph
@@ -202,13 +228,15 @@ def main():
     sync_all()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()                                  # same stream the kernels run on
+    ev0.record()                                  # same stream the kernels run on (side streams fork from / join it)
     if graph is not None:
         for _ in range(n_rep):
             graph.replay()
     else:
+        fork()
         for _ in range(args.steps):
             step()
+        join()
     ev1.record()
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -227,14 +255,17 @@ def main():
     # second region: the same step followed by the RCCL all-gather of the mel slabs
     ag = None
     if world > 1 and not args.no_allgather:
+        def step0():
+            launch(0, torch.cuda.current_stream(dev).cuda_stream)
+
         for _ in range(3):
-            step()
+            step0()
             allgather_features(mel, world)
         sync_all()
         k2 = max(10, args.steps // 4)
         t0 = time.perf_counter()
         for _ in range(k2):
-            step()
+            step0()
             full = allgather_features(mel, world)
         sync_all()
         e2 = time.perf_counter() - t0
@@ -277,7 +308,7 @@ def main():
                                 "cfg5": "BASELINE configs[4]: %d mono streams of 5 s @44.1 kHz, 2048-pt FFT, step 441, "
                                         "T=504 frames, 128 mel" % B}[args.workload],
                    "batch_per_gpu": B, "win_samples": oc.N, "step_samples": oc.S,
-                   "segment_steps": oc.T, "n_mel": oc.nf, "kernel": plan.kernel_name, "launch": launch_mode,
+                   "segment_steps": oc.T, "n_mel": oc.nf, "kernel": plan.kernel_name, "launch": launch_mode, "streams": n_streams,
                    "options": args.option,
                    "sharding": "utterances, contiguous block per rank"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,

@@ -44,6 +44,8 @@ def _patch(monkeypatch):
     monkeypatch.setattr(torch.cuda, "current_stream", lambda d=None: _Stream())
     monkeypatch.setattr(torch.cuda, "Event", _Event)
     monkeypatch.setattr(torch.cuda, "CUDAGraph", _Graph)
+    monkeypatch.setattr(torch.cuda, "Stream", _SideStream)
+    monkeypatch.setattr(_Stream, "wait_stream", lambda self, other: None, raising=False)
     monkeypatch.setattr(torch, "device", lambda *a, **k: real_device("cpu"))
 
 
@@ -71,7 +73,15 @@ def test_bench_dry_run_two_ranks(tmp_path):
     assert line["allgather"]["gathered_shape"] == [4, 40, 104]
 
 
-@pytest.mark.parametrize("extra", [[], ["--win-ms", "25"], ["--workload", "cfg4"], ["--compute", "f64", "--launch", "eager"]])
+class _SideStream(_Stream):
+    def __init__(self, dev=None):
+        pass
+
+    def wait_stream(self, other):
+        pass
+
+
+@pytest.mark.parametrize("extra", [[], ["--streams", "2"], ["--win-ms", "25"], ["--workload", "cfg4"], ["--compute", "f64", "--launch", "eager"]])
 def test_bench_dry_run(monkeypatch, capsys, extra):
     import backend
     import bench
