@@ -445,6 +445,9 @@ int aud_melspec_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
     if (smooth && !power)
         return fail(c, AUD_EINVAL, "dft.PrevSmooth != 0 needs the power buffer (the scan runs on it)");
     if (n_items == 0) return AUD_OK;
+    // one workgroup per (item, frame tile): keep the 1-D grid inside what a launch accepts
+    if (int64_t(n_items) * int64_t(p->d.segment_steps) > (int64_t(1) << 30))
+        return fail(c, AUD_EINVAL, "n_items x segment_steps too large for one launch; split the batch");
     AUD_HIP(c, make_current(c));
     aud::MelspecArgs a;
     fill_melspec_args(p, &a);
