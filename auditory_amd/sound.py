@@ -12,6 +12,72 @@ def MSecToSamples(ms, rate):
     return capi.load().aud_msec_to_samples(float(ms), int(rate))
 
 
+class Wave:
+    """sound.Wave, sound/sound.go:32-141 (PCM WAV in, normalised float64 out).  Host I/O: the RIFF parsing
+    replaces go-audio's decoder; the int -> float rule is Wave.GetFloatAtIdx (sound.go:130-141)."""
+
+    def __init__(self):
+        self.Data = np.zeros(0, np.int64)     # interleaved samples, like audio.IntBuffer.Data
+        self.SourceBitDepth = 0
+        self._rate = 0
+        self._channels = 0
+
+    def Load(self, fn):
+        """sound.go:37-51: decode a PCM WAV file (8/16/24/32-bit integer samples)"""
+        import struct
+        raw = open(fn, "rb").read()
+        if raw[:4] != b"RIFF" or raw[8:12] != b"WAVE":
+            raise ValueError("not a RIFF/WAVE file: %s" % fn)
+        pos, fmt, data = 12, None, None
+        while pos + 8 <= len(raw):
+            cid, size = raw[pos:pos + 4], struct.unpack("<I", raw[pos + 4:pos + 8])[0]
+            if cid == b"fmt ":
+                fmt = struct.unpack("<HHIIHH", raw[pos + 8:pos + 24])
+            elif cid == b"data":
+                data = raw[pos + 8:pos + 8 + size]
+            pos += 8 + size + (size & 1)
+        if fmt is None or data is None or fmt[0] != 1:
+            raise ValueError("only integer PCM WAV is supported")
+        self._channels, self._rate, self.SourceBitDepth = fmt[1], fmt[2], fmt[5]
+        if self.SourceBitDepth == 8:
+            self.Data = np.frombuffer(data, np.uint8).astype(np.int64) - 128
+        elif self.SourceBitDepth == 16:
+            self.Data = np.frombuffer(data, "<i2").astype(np.int64)
+        elif self.SourceBitDepth == 24:
+            b = np.frombuffer(data[:len(data) // 3 * 3], np.uint8).reshape(-1, 3).astype(np.int64)
+            v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+            self.Data = np.where(v >= 1 << 23, v - (1 << 24), v)
+        elif self.SourceBitDepth == 32:
+            self.Data = np.frombuffer(data, "<i4").astype(np.int64)
+        else:
+            raise ValueError("unsupported bit depth %d" % self.SourceBitDepth)
+        return None
+
+    def SampleRate(self):
+        """sound.go:79-90"""
+        return self._rate
+
+    def Channels(self):
+        """sound.go:93-103"""
+        return self._channels
+
+    def NumFrames(self):
+        return len(self.Data) // max(self._channels, 1)
+
+    def SoundToTensor(self):
+        """sound.go:116-127: the first NumFrames() entries of the INTERLEAVED buffer, normalised by
+        GetFloatAtIdx -- for stereo that is L,R,L,R... of the first half of the clip (SURVEY a-0 quirk);
+        mono is what the hot path supports."""
+        lib = capi.load()
+        n = self.NumFrames()
+        scale = {8: 0x7F, 16: 0x7FFF, 24: 0x7FFFFF, 32: 0x7FFFFFFF}.get(self.SourceBitDepth)
+        if scale is None:
+            return np.zeros(n)
+        out = self.Data[:n].astype(np.float64) / float(scale)
+        assert n == 0 or out[0] == lib.aud_pcm_to_float(int(self.Data[0]), self.SourceBitDepth)
+        return out
+
+
 class Params:
     """sound.Params, sound/sndenv.go:24-61"""
 
@@ -41,6 +107,7 @@ class SndEnv:
 
     def __init__(self, device=0, compute_dtype=capi.AUD_F32):
         self.Params = Params()
+        self.Sound = Wave()
         self.SampleRate = 0                 # se.Sound.SampleRate()
         self.Channels = 1                   # se.Sound.Channels(); mono streams only (SURVEY a-0)
         self.Signal = np.zeros(0, np.float64)
@@ -70,6 +137,12 @@ class SndEnv:
         self._device = device
         self._compute_dtype = compute_dtype
         self._plan = None
+
+    def ToTensor(self):
+        """sound/sndenv.go:297-300: Signal <- Sound.SoundToTensor()"""
+        self.Signal = self.Sound.SoundToTensor()
+        self.SampleRate, self.Channels = self.Sound.SampleRate(), self.Sound.Channels()
+        return True
 
     def ParamDefaults(self):
         """sound/sndenv.go:64-71"""

@@ -425,3 +425,36 @@ def case_per_step_api(orc, cdt):
         ok, msg = W.feature_close(se.MelFBankSegment, se2_mel, cdt, lin_axis=0)
         assert ok, "batched vs per-step " + msg
         se._plan.close()
+
+
+REF_SOUNDS = "/root/reference/examples/processspeech/sounds"
+
+
+def case_reference_wav(orc, cdt, wav="bug.wav"):
+    """One of the reference's own WAV files (44.1 kHz mono, only where the reference tree is mounted) through
+    Sound.Load -> ToTensor -> Init -> ProcessSegment (processspeech parameters: N = 1103, prime) vs the oracle."""
+    import os
+    from auditory_amd import sound
+    path = os.path.join(REF_SOUNDS, wav)
+    if not os.path.exists(path):
+        pytest.skip("reference WAV fixtures are not on this machine")
+    se = sound.SndEnv(compute_dtype=cdt)
+    se.Defaults()
+    se.Mel.MFCC = False
+    se.Sound.Load(path)
+    se.ToTensor()
+    se.GborOutUnitsX = se.GborOutUnitsY = 1
+    assert se.Init() is None
+    assert se.SampleRate == 44100 and se.Params.WinSamples == 1103 and se._plan.kernel_name == "generic"
+    sp = orc.sound_params(25, 10, 100, 100, 2, 44100)
+    d, m = orc.dft_defaults(), orc.mel_defaults()
+    rc, bins, hz, filt = orc.mel_init_filters(m, 1103, 44100)
+    segs = list(range(min(se.SegCnt, 4)))
+    mel, _, _ = se.ProcessSegments(segs)
+    for i, sg in enumerate(segs):
+        ref = orc.process_segment(sp, d, m, bins, filt, se.Signal, segment=sg)
+        if cdt == capi.AUD_F64:
+            ok, msg = W.close_enough(mel[i], ref["mel_seg"], 1e-5)      # real speech: full dynamic range
+        else:
+            ok, msg = W.feature_close(mel[i], ref["mel_seg"], cdt, lin_axis=0)
+        assert ok, "%s segment %d: %s" % (wav, sg, msg)

@@ -99,6 +99,11 @@ def test_emul_per_step_api(orc, emu, cdt):
     PC.case_per_step_api(orc, cdt)
 
 
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_emul_reference_wav(orc, emu, cdt):
+    PC.case_reference_wav(orc, cdt)
+
+
 def _sanitizer_run(variant, which, timeout=900):
     build_emul.build(variant)
     rt = {"asan": "libasan.so", "tsan": "libtsan.so"}[variant]
