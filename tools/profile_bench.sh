@@ -11,13 +11,21 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT" "$ROOT/profiles"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --launch eager $*"
-echo "[profile] stats pass";  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/stats.log" 2>&1 || echo "stats pass rc=$?"
-echo "[profile] FETCH_SIZE pass"; timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $BENCH > "$OUT/fetch.log" 2>&1 || echo "fetch pass rc=$?"
-echo "[profile] WRITE_SIZE pass"; timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $BENCH > "$OUT/write.log" 2>&1 || echo "write pass rc=$?"
+BENCH="python3 $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --launch eager --prewarm-s 0 $*"
+pass() {  # pass <name> <rocprofv3 args...>: a timeout or a death by signal ends the script (no GPU step after it)
+    local name=$1; shift
+    echo "[profile] $name pass"
+    timeout -k 10 300 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/$name.log" 2>&1
+    local rc=$?
+    if [ $rc -ne 0 ]; then echo "[profile] $name pass rc=$rc"; fi
+    if [ $rc -eq 124 ] || [ $rc -ge 128 ]; then echo "[profile] stopping after a timeout/crash"; exit $rc; fi
+}
+pass stats --kernel-trace --stats
+pass fetch --kernel-trace --pmc FETCH_SIZE
+pass write --kernel-trace --pmc WRITE_SIZE
 # optional SQ passes (8 SQ slots per pass; a pass with a counter this ROCm does not know simply fails and is skipped)
-echo "[profile] SQ pass A"; timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d "$OUT/sqa" -- $BENCH > "$OUT/sqa.log" 2>&1 || echo "SQ pass A rc=$?"
-echo "[profile] SQ pass B"; timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS --output-format csv -d "$OUT/sqb" -- $BENCH > "$OUT/sqb.log" 2>&1 || echo "SQ pass B rc=$?"
+pass sqa --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
+pass sqb --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS
 python3 "$ROOT/tools/rocprof_summary.py" "$OUT" "$TAG" > "$ROOT/profiles/${TAG}_summary.txt" 2>&1
 cat "$ROOT/profiles/${TAG}_summary.txt"
 for f in $(find "$OUT/stats" -name "*kernel_stats.csv" | head -1); do cp "$f" "$ROOT/profiles/${TAG}_kernel_stats.csv"; done
