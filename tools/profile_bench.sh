@@ -29,4 +29,6 @@ pass sqb --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNAL
 python3 "$ROOT/tools/rocprof_summary.py" "$OUT" "$TAG" > "$ROOT/profiles/${TAG}_summary.txt" 2>&1
 cat "$ROOT/profiles/${TAG}_summary.txt"
 for f in $(find "$OUT/stats" -name "*kernel_stats.csv" | head -1); do cp "$f" "$ROOT/profiles/${TAG}_kernel_stats.csv"; done
-cp "$ROOT/profiles/${TAG}_summary.txt" "$ROOT/profiles/${TAG}_kernel_stats.csv" "$ROOT/gpurun_out/" 2>/dev/null
+# only gpurun_out/ travels back from the GPU box: copy what has to be committed under profiles/
+cp "$ROOT/profiles/${TAG}_summary.txt" "$ROOT/profiles/${TAG}_kernel_stats.csv" "$ROOT/profiles/pmc_traffic.json" "$ROOT/gpurun_out/" 2>/dev/null
+true
