@@ -204,3 +204,32 @@ def test_kernels_use_no_scratch_and_fit_their_occupancy():
         for key, lim in budget.items():
             if key in name:
                 assert res["vgpr"] <= lim, (name, res, lim)
+
+
+def test_header_is_plain_c(tmp_path):
+    """the boundary is a C ABI: the header must compile as C99 (what cgo feeds it to), and a C caller must link"""
+    src = tmp_path / "use_abi.c"
+    src.write_text("""
+#include <stdio.h>
+#include "auditory_hip.h"
+int main(void) {
+    aud_sound_params p;
+    aud_mel_fbank m;
+    int32_t bins[34];
+    double hz[34], filt[32 * 34];
+    aud_sound_params_defaults(&p);
+    if (aud_sound_params_derive(&p, 16000) != AUD_OK || p.win_samples != 400) return 1;
+    aud_mel_defaults(&m);
+    if (aud_mel_init_filters(&m, 400, 16000, bins, hz, filt) != AUD_OK || m.renorm != 0) return 2;
+    printf("C-ABI-OK %d %d ", aud_version(), (int)bins[33]);
+    return 0;
+}
+""")
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + inc, "-fsyntax-only", str(src)])
+    exe = str(tmp_path / "use_abi")
+    subprocess.check_call(["gcc", "-std=c99", "-I" + inc, str(src), "-o", exe, "-L" + libdir, "-lauditory_hip",
+                           "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("C-ABI-OK 100 200"), out.stdout + out.stderr
