@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <climits>
 #include <cstring>
 #include <new>
 #include <string>
@@ -41,6 +42,9 @@ struct aud_plan {
     aud::FastArgs r16{};
     int* d_grp = nullptr;  // [17 + nf + 3 nf]: group offsets, filter ids, per-filter chunk info
     void* d_w4 = nullptr;  // chunked triangle weights
+    int* d_blk = nullptr;     // matrix-pipe mel variant (r16x16, float32): per 16-filter block {chunk0, steps, offset}
+    float* d_atab = nullptr;  // ... and its lane-ordered A operands [steps][64]
+    int n_blocks = 0;
     void* d_tw = nullptr;
     void* d_filt = nullptr;
     int32_t* d_bin_pts = nullptr;
@@ -354,6 +358,41 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
             }
         }
         if (rc == AUD_OK && !fast_usable) fast_kind = aud_plan::kNoFast;
+        if (rc == AUD_OK && fast_kind == aud_plan::kR16 && d->compute_dtype == AUD_F32) {
+            // tables of the matrix-pipe mel variant (option "r16_mel" = 1): filters in blocks of 16, each block a
+            // dense [16 filters x 4-bin steps] band; lane l of a step holds filter 16 b + (l & 15), bin + (l >> 4)
+            const int nb = (nf + 15) / 16;
+            std::vector<int> blk(3 * size_t(nb), 0);
+            std::vector<float> atab;
+            for (int b = 0; b < nb; ++b) {
+                int cmin = INT_MAX, cmax = -1;
+                for (int f = 16 * b; f < std::min(nf, 16 * b + 16); ++f) {
+                    const int lo = d->bin_pts[f], hi = d->bin_pts[f + 2];
+                    if (hi < lo) continue;
+                    cmin = std::min(cmin, lo >> 2);
+                    cmax = std::max(cmax, hi >> 2);
+                }
+                const int ns = cmax >= 0 ? cmax - cmin + 1 : 0;
+                blk[3 * b] = ns ? cmin : 0;
+                blk[3 * b + 1] = ns;
+                blk[3 * b + 2] = int(atab.size() / 64);
+                for (int st = 0; st < ns; ++st)
+                    for (int l = 0; l < 64; ++l) {
+                        const int f = 16 * b + (l & 15), bin = 4 * (cmin + st) + (l >> 4);
+                        float w = 0.f;
+                        if (f < nf) {
+                            const int lo = d->bin_pts[f], hi = d->bin_pts[f + 2];
+                            if (bin >= lo && bin <= hi) w = float(d->mel_filters[int64_t(f) * (nf + 2) + (bin - lo)]);
+                        }
+                        atab.push_back(w);
+                    }
+            }
+            if (atab.empty()) atab.assign(64, 0.f);
+            p->n_blocks = nb;
+            rc = upload(c, reinterpret_cast<void**>(&p->d_blk), blk.data(), blk.size() * sizeof(int));
+            if (rc == AUD_OK)
+                rc = upload(c, reinterpret_cast<void**>(&p->d_atab), atab.data(), atab.size() * sizeof(float));
+        }
         if (rc == AUD_OK && fast_kind != aud_plan::kNoFast) {
             p->fast_kind = fast_kind;
             p->use_fast = true;
@@ -364,6 +403,10 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
             p->r16.grp_flt = p->d_grp + goff;
             p->r16.chunk = p->d_grp + goff + nf;
             p->r16.w4 = p->d_w4;
+            p->r16.mel_mfma = 0;
+            p->r16.n_blocks = p->n_blocks;
+            p->r16.blk = p->d_blk;
+            p->r16.atab = p->d_atab;
         }
     }
     if (rc != AUD_OK) {
@@ -384,6 +427,8 @@ int aud_plan_destroy(aud_plan* p) {
     if (p->d_dct) (void)hipFree(p->d_dct);
     if (p->d_grp) (void)hipFree(p->d_grp);
     if (p->d_w4) (void)hipFree(p->d_w4);
+    if (p->d_blk) (void)hipFree(p->d_blk);
+    if (p->d_atab) (void)hipFree(p->d_atab);
     delete p;
     return AUD_OK;
 }
@@ -427,6 +472,14 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
         if (value != 1 && value != 2) return fail(c, AUD_EINVAL, "r16_tiles: 1 or 2");
         if (value == 2 && !p->r16.direct) return fail(c, AUD_EINVAL, "r16_tiles = 2 needs the direct input variant");
         p->r16.ntile = value;
+        return AUD_OK;
+    }
+    if (key == "r16_mel") {  // 0 = chunked reduction on the vector pipe, 1 = banded filter x bin GEMM on the matrix pipe
+        if (p->fast_kind != aud_plan::kR16) return fail(c, AUD_EINVAL, "plan has no r16x16 kernel");
+        if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "r16_mel: 0 (vector pipe) or 1 (matrix pipe)");
+        if (value == 1 && p->d.compute_dtype != AUD_F32)
+            return fail(c, AUD_EINVAL, "r16_mel = 1 is a float32 variant (v_mfma_f32_16x16x4_f32)");
+        p->r16.mel_mfma = value;
         return AUD_OK;
     }
     return fail(c, AUD_EINVAL, "unknown option");

@@ -187,10 +187,8 @@ __device__ __forceinline__ double dev_log(double v) { return log(v); }
 // With lds_out set, mel values go to lds_out[flt * lds_pitch + lds_col0 + frame] instead of global memory
 // (kernels whose tiles are narrower than a 64-byte output run collect several tiles there first).
 template <typename TT, int NT, int F>
-__device__ __forceinline__ void tile_epilogue(const MelspecArgs& a, const FastArgs& e, const TT* P, int Hp,
-                                              const unsigned char* smem, const aud_item& it, int item, int t0,
-                                              int tid, float* lds_out = nullptr, int lds_pitch = 0,
-                                              int lds_col0 = 0) {
+__device__ __forceinline__ void tile_spectrum_outputs(const MelspecArgs& a, const TT* P, int Hp, const aud_item& it,
+                                                      int item, int t0, int tid) {
     const int T = a.T, H = a.H, N = a.N;
     const int64_t lim = it.sig_len;
     if (a.power || a.log_power) {
@@ -214,6 +212,16 @@ __device__ __forceinline__ void tile_epilogue(const MelspecArgs& a, const FastAr
             }
         }
     }
+}
+
+template <typename TT, int NT, int F>
+__device__ __forceinline__ void tile_epilogue(const MelspecArgs& a, const FastArgs& e, const TT* P, int Hp,
+                                              const unsigned char* smem, const aud_item& it, int item, int t0,
+                                              int tid, float* lds_out = nullptr, int lds_pitch = 0,
+                                              int lds_col0 = 0) {
+    const int T = a.T, N = a.N;
+    const int64_t lim = it.sig_len;
+    tile_spectrum_outputs<TT, NT, F>(a, P, Hp, it, item, t0, tid);
     const int ff = tid % F, grp = tid / F;
     const int sstep = t0 + ff;
     if (sstep >= T) return;
@@ -252,6 +260,65 @@ __device__ __forceinline__ void tile_epilogue(const MelspecArgs& a, const FastAr
             lds_out[flt * lds_pitch + lds_col0 + ff] = res;
         else
             a.mel[(size_t(item) * a.nf + flt) * T + sstep] = res;
+    }
+}
+
+// ---- mel on the matrix pipe (float32 only; an experiment the plan can switch on) -------------------
+// D[16 filters x 16 frames] += A[16 filters x 4 bins] * B[4 bins x 16 frames] per v_mfma_f32_16x16x4_f32:
+//   A: lane l holds W[16 b + (l & 15)][bin0 + (l >> 4)]   (pre-arranged on the host, 64 floats per K-step)
+//   B: lane l holds P[frame l & 15][bin0 + (l >> 4)]       (one 4-byte LDS read)
+//   D: register r of lane l = filter 16 b + 4 (l >> 4) + r, frame l & 15
+// The accumulation is a k-ordered fmaf chain (bins ascending), like the reference's sequential sum; bins
+// outside a triangle carry zero weights.  Filter block b runs on wave b mod 4.
+typedef float aud_f32x4 __attribute__((vector_size(16)));
+
+template <int NT, int F>
+__device__ __forceinline__ void tile_mel_mfma(const MelspecArgs& a, const FastArgs& e, const float* P, int Hp,
+                                              const aud_item& it, int item, int t0, int tid) {
+    static_assert(F == 16, "one MFMA column per frame of the tile");
+    const int wave = tid >> 6, lane = tid & 63;
+    const int frame = lane & 15, kq = lane >> 4;
+    const int T = a.T;
+    const int sstep = t0 + frame;
+    const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
+    const bool live = start + a.N <= int64_t(it.sig_len);
+    const float loff = float(a.mel_log_off), lmin = float(a.mel_log_min);
+    for (int b = wave; b < e.n_blocks; b += NT / 64) {
+        const int c0 = e.blk[3 * b], ns = e.blk[3 * b + 1], off = e.blk[3 * b + 2];
+        const float* __restrict__ arow = e.atab + size_t(off) * 64 + lane;
+        const float* prow = P + frame * Hp + 4 * c0 + kq;
+        aud_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 4 <= ns; s += 4) {  // operands of four steps in flight, then the dependent accumulate chain
+            float wa[4], pb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                wa[u] = arow[64 * (s + u)];
+                pb[u] = prow[4 * (s + u)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[u], pb[u], acc, 0, 0, 0);
+        }
+        for (; s < ns; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[64 * s], prow[4 * s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int flt = 16 * b + 4 * kq + r;
+            if (flt < a.nf && sstep < T) {
+                float res = 0.f;
+                if (live) {
+                    const float sum = acc[r] + loff;
+                    float val = (sum == 0.f) ? lmin : dev_log(sum);
+                    if (a.renorm) {
+                        val -= float(a.renorm_min);
+                        if (val < 0.f) val = 0.f;
+                        val *= float(a.renorm_scale);
+                        if (val > 1.f) val = 1.f;
+                    }
+                    res = val;
+                }
+                a.mel[(size_t(item) * a.nf + flt) * T + sstep] = res;
+            }
+        }
     }
 }
 

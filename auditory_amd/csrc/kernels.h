@@ -70,6 +70,10 @@ struct FastArgs {
     const int* grp_flt;    // [nf] device: filter ids, grouped so that groups carry equal tap counts
     const int* chunk;      // [nf][3] device: first 4-bin chunk, chunk count, offset into w4
     const void* w4;        // device: triangle weights as aligned 4-bin chunks (compute type)
+    int mel_mfma;          // r16x16 f32: 1 = mel on the matrix pipe (tile_mel_mfma), 0 = chunked reduction
+    int n_blocks;          // filter blocks of 16 for the matrix-pipe variant
+    const int* blk;        // [n_blocks][3] device: first 4-bin chunk, K-steps, offset (in steps) into atab
+    const float* atab;     // [steps][64] device: A operands, lane-ordered
 };
 
 // PrevSmooth != 0 mode: scan along the steps of a stored power tensor

@@ -158,6 +158,13 @@ __device__ __forceinline__ void r16_tile(const MelspecArgs& a, const FastArgs& e
     }
     __syncthreads();
 
+    if constexpr (sizeof(TT) == 4) {
+        if (e.mel_mfma) {  // uniform per launch
+            tile_spectrum_outputs<TT, 256, kF>(a, Pbase, kHp, it, item, t0, tid);
+            tile_mel_mfma<256, kF>(a, e, Pbase, kHp, it, item, t0, tid);
+            return;
+        }
+    }
     tile_epilogue<TT, 256, kF>(a, e, Pbase, kHp, smem, it, item, t0, tid);
 }
 

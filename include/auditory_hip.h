@@ -201,7 +201,9 @@ const char* aud_plan_kernel_name(const aud_plan* plan);
 /* Tuning / diagnostic switches; results are identical whatever they are set to.
  *   "kernel"    0 automatic (default), 1 force the generic any-N kernel
  *   "r16_input" 0 operands straight from global memory (default), 1 staged through LDS
- *   "r16_tiles" 1 (default) or 2 sixteen-frame tiles per workgroup, the second one's operands prefetched */
+ *   "r16_tiles" 1 (default) or 2 sixteen-frame tiles per workgroup, the second one's operands prefetched
+ *   "r16_mel"   0 mel triangles on the vector pipe (default), 1 as a banded filter x bin GEMM on the matrix
+ *               pipe (float32 plans only; same products, the sum also takes the zero weights of the band) */
 int aud_plan_set_option(aud_plan* plan, const char* name, int value);
 
 /* ---- hot path, device-resident (what bench.py times) ----------------------------- */

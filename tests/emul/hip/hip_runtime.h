@@ -107,5 +107,22 @@ inline T __shfl_up(T v, unsigned d, int width = 64) {
     return emul_shfl_any(v, (src >= 0 && (src & ~(width - 1)) == (lane & ~(width - 1))) ? src : lane);
 }
 
+// v_mfma_f32_16x16x4_f32 as the guide documents it: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15],
+// D register r of lane l = row 4 (l >> 4) + r, column l & 15; one k-ordered fmaf chain per element.
+template <typename V>
+inline V __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, V c, int, int, int) {
+    const int l = emul_lane();
+    const int col = l & 15, rq = l >> 4;
+    float bk[4];
+    for (int k = 0; k < 4; ++k) bk[k] = emul_shfl_any(b, col + 16 * k);
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * rq + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = std::fma(emul_shfl_any(a, row + 16 * k), bk[k], acc);
+        c[r] = acc;
+    }
+    return c;
+}
+
 using std::max;
 using std::min;

@@ -260,7 +260,8 @@ def case_prev_smooth(orc, name, cdt):
 
 # the kernel variants a 512-sample plan can run: all must agree with the oracle (and each other)
 N512_VARIANTS = {"r16_direct": {"r16_input": 0}, "r16_direct_2tiles": {"r16_input": 0, "r16_tiles": 2},
-                 "r16_staged": {"r16_input": 1}, "generic": {"kernel": 1}}
+                 "r16_staged": {"r16_input": 1}, "r16_mel_mfma": {"r16_input": 0, "r16_mel": 1},
+                 "r16_mel_mfma_staged_2": {"r16_input": 1, "r16_mel": 1}, "generic": {"kernel": 1}}
 
 
 def _fast_family(orc, name, cdt, seg_ms=None):
@@ -277,6 +278,8 @@ def case_n512_variants(orc, cdt, seg_ms=None, dur=1.0, rows=2, segs=(0,)):
     for name, opts in N512_VARIANTS.items():
         if "r16_input" in opts and not have_fast:
             continue
+        if opts.get("r16_mel") and cdt != capi.AUD_F32:
+            continue  # the matrix-pipe mel variant is float32 only (refusal checked below)
         case_melspec_vs_oracle(orc, case, cdt, seg_ms=seg_ms, options=opts)
     # a plan reports what it runs, and odd steps fall back to the generic kernel by themselves
     oc = W.OracleCfg(orc, "cfg2_16k_n512_nf40")
@@ -290,6 +293,9 @@ def case_n512_variants(orc, cdt, seg_ms=None, dur=1.0, rows=2, segs=(0,)):
     assert plan.kernel_name == auto
     with pytest.raises(capi.AuditoryError):
         plan.set_option("nonsense", 1)
+    if auto == "r16x16" and cdt == capi.AUD_F64:
+        with pytest.raises(capi.AuditoryError):
+            plan.set_option("r16_mel", 1)
     plan.close()
 
 

@@ -50,7 +50,8 @@ def main():
     variants = {"auto": {}, "generic": {"kernel": 1}}
     if args.win_ms == 32.0:
         variants = {"r16 direct": {"r16_input": 0}, "r16 direct x2": {"r16_input": 0, "r16_tiles": 2},
-                    "r16 staged": {"r16_input": 1}, "generic": {"kernel": 1}}
+                    "r16 staged": {"r16_input": 1}, "r16 direct mfma-mel": {"r16_input": 0, "r16_mel": 1},
+                    "r16 direct x2 mfma-mel": {"r16_input": 0, "r16_tiles": 2, "r16_mel": 1}, "generic": {"kernel": 1}}
     plans = {}
     for vname, opts in variants.items():
         p = W.product_plan(oc, cdt)
