@@ -58,6 +58,21 @@ class PlanDesc(C.Structure):
                 ("mfcc_coefs", C.c_int32)]
 
 
+class FffbParams(C.Structure):
+    _fields_ = [("on", C.c_int32)] + [(n, C.c_float) for n in ("gi", "ff", "fb", "fb_tau", "max_vs_avg", "ff0")]
+
+
+class Nxx1Params(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("thr", "gain", "nvar", "vm_act_thr", "sig_mult", "sig_mult_pow",
+                                         "sig_gain", "interp_range", "gain_cor_range", "gain_cor")]
+
+
+class KwtaParams(C.Structure):
+    _fields_ = [("on", C.c_int32), ("iters", C.c_int32), ("del_act_thr", C.c_float),
+                ("lay_fffb", FffbParams), ("pool_fffb", FffbParams), ("xx1", Nxx1Params),
+                ("act_tau", C.c_float), ("gbar", C.c_float * 4), ("erev", C.c_float * 4)]
+
+
 # every symbol include/auditory_hip.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
 SYMBOLS = {
@@ -104,6 +119,9 @@ SYMBOLS = {
     "aud_mel_filter_dft_host": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),
     "aud_gabor_batch_host": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_int,
                                        _VP]),
+    "aud_kwta_defaults": (None, [C.POINTER(KwtaParams)]),
+    "aud_kwta_batch_dev": (C.c_int, [_VP, C.POINTER(KwtaParams), _VP, _VP] + [C.c_int] * 7 + [_VP, C.c_int, _VP, _VP]),
+    "aud_kwta_batch_host": (C.c_int, [_VP, C.POINTER(KwtaParams), _VP, _VP] + [C.c_int] * 7 + [_VP, C.c_int, _VP]),
     "aud_comm_unique_id": (C.c_int, [_VP]),
     "aud_comm_init": (C.c_int, [_VP, C.c_int, C.c_int, _VP]),
     "aud_comm_destroy": (C.c_int, [_VP]),

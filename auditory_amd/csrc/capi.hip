@@ -893,6 +893,132 @@ constexpr int kNcclFloat32 = 7;  // ncclFloat32 in nccl.h / rccl.h
 
 extern "C" {
 
+// ---- k-WTA ------------------------------------------------------------------------------
+
+namespace {
+
+// KWTA.Update(): fffb / nxx1 / chans derived values, float32 like the Go code (mat32.Pow goes through float64)
+void fill_kwta_args(const aud_kwta_params* k, aud::KwtaArgs* a) {
+    auto fffb = [](const aud_fffb_params& p) {
+        aud::KwtaFffb f;
+        f.on = p.on;
+        f.gi = p.gi;
+        f.ff = p.ff;
+        f.fb = p.fb;
+        f.fb_dt = 1.0f / p.fb_tau;
+        f.max_vs_avg = p.max_vs_avg;
+        f.ff0 = p.ff0;
+        return f;
+    };
+    a->lay = fffb(k->lay_fffb);
+    a->pool = fffb(k->pool_fffb);
+    const aud_nxx1_params& x = k->xx1;
+    a->gain = x.gain;
+    a->nvar = x.nvar;
+    a->interp_range = x.interp_range;
+    a->gain_cor_range = x.gain_cor_range;
+    a->gain_cor = x.gain_cor;
+    a->sig_gain_nvar = x.sig_gain / x.nvar;
+    a->sig_mult_eff = x.sig_mult * float(std::pow(double(x.gain * x.nvar), double(x.sig_mult_pow)));
+    a->sig_val_at0 = 0.5f * a->sig_mult_eff;
+    {  // XX1GainCor(InterpRange) - SigValAt0
+        const float v = x.interp_range;
+        const float fact = (x.gain_cor_range - (v / x.nvar)) / x.gain_cor_range;
+        float y;
+        if (fact < 0.f) {
+            const float g = x.gain * v;
+            y = g / (g + 1.f);
+        } else {
+            const float g = (x.gain * (1.f - x.gain_cor * fact)) * v;
+            y = g / (g + 1.f);
+        }
+        a->interp_val = y - a->sig_val_at0;
+    }
+    a->gbar_e = k->gbar[0];
+    a->gbar_l = k->gbar[1];
+    a->gbar_i = k->gbar[2];
+    a->erev_sub_thr_i = k->erev[2] - x.thr;
+    a->erev_sub_thr_l = k->erev[1] - x.thr;
+    a->thr_sub_erev_e = x.thr - k->erev[0];
+    a->act_dt = 1.0f / k->act_tau;
+    a->iters = k->iters;
+    a->del_act_thr = k->del_act_thr;
+}
+
+}  // namespace
+
+int aud_kwta_batch_dev(aud_ctx* c, const aud_kwta_params* k, const float* raw, float* act, int n_items, int d0,
+                       int d1, int d2, int d3, int pool_level, int start_from_raw, float* pool_state,
+                       int sum_order, int32_t* cycles, void* stream) {
+    if (!c) return AUD_EINVAL;
+    if (!k) return fail(c, AUD_EINVAL, "null parameters");
+    if (n_items < 0 || d0 < 0 || d1 < 0 || d2 < 0 || d3 < 0) return fail(c, AUD_EINVAL, "bad shape");
+    if ((pool_level != 0 && pool_level != 1) || (sum_order != 0 && sum_order != 1))
+        return fail(c, AUD_EINVAL, "pool_level and sum_order are 0 or 1");
+    if (k->iters < 0) return fail(c, AUD_EINVAL, "Iters < 0");
+    if (!(k->act_tau != 0.f) || !(k->lay_fffb.fb_tau != 0.f) || !(k->pool_fffb.fb_tau != 0.f) || !(k->xx1.nvar != 0.f))
+        return fail(c, AUD_EINVAL, "ActTau, FBTau and NVar must be non-zero");
+    const int64_t n64 = int64_t(d0) * d1 * d2 * d3, lay64 = pool_level ? int64_t(d0) * d1 : 0;
+    if (n_items == 0 || n64 == 0) return AUD_OK;
+    if (!raw || !act) return fail(c, AUD_EINVAL, "null buffer");
+    if (raw == act) return fail(c, AUD_EINVAL, "act must not alias raw (the reference keeps both tensors)");
+    const size_t lds = n64 <= (1 << 20) ? aud::kwta_lds_bytes(int(n64), int(lay64)) : size_t(1) << 30;
+    if (lds > 160u * 1024u)
+        return fail(c, AUD_EINVAL, "tensor too large for one workgroup's LDS: (32 + n + 4 pools) * 4 bytes must fit 160 KB");
+    AUD_HIP(c, make_current(c));
+    if (lds > 64u * 1024u) AUD_HIP(c, aud::kwta_prepare(unsigned(lds)));
+    aud::KwtaArgs a;
+    std::memset(&a, 0, sizeof(a));
+    fill_kwta_args(k, &a);
+    a.raw = raw;
+    a.act = act;
+    a.n_items = n_items;
+    a.n = int(n64);
+    a.lay_n = int(lay64);
+    a.pl_n = pool_level ? d2 * d3 : 0;
+    a.start_from_raw = start_from_raw ? 1 : 0;
+    a.sum_order = sum_order;
+    a.state = pool_level ? pool_state : nullptr;
+    a.cycles = cycles;
+    a.lds_bytes = unsigned(lds);
+    AUD_HIP(c, aud::launch_kwta(a, static_cast<hipStream_t>(stream)));
+    return AUD_OK;
+}
+
+int aud_kwta_batch_host(aud_ctx* c, const aud_kwta_params* k, const float* raw, float* act, int n_items, int d0,
+                        int d1, int d2, int d3, int pool_level, int start_from_raw, float* pool_state,
+                        int sum_order, int32_t* cycles) {
+    if (!c) return AUD_EINVAL;
+    if (n_items < 0 || d0 < 0 || d1 < 0 || d2 < 0 || d3 < 0) return fail(c, AUD_EINVAL, "bad shape");
+    const size_t n = size_t(d0) * d1 * d2 * d3, total = size_t(n_items) * n;
+    if (total == 0) return AUD_OK;
+    if (!raw || !act) return fail(c, AUD_EINVAL, "null buffer");
+    AUD_HIP(c, make_current(c));
+    const size_t n_state = (pool_level && pool_state) ? size_t(n_items) * d0 * d1 * 2 : 0;
+    int rc;
+    if ((rc = ensure_ws(c, 2, total * 4)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 3, total * 4)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 1, (n_state + size_t(n_items)) * 4 + 16)) != AUD_OK) return rc;
+    float* d_raw = static_cast<float*>(c->ws[2]);
+    float* d_act = static_cast<float*>(c->ws[3]);
+    float* d_state = n_state ? static_cast<float*>(c->ws[1]) : nullptr;
+    int32_t* d_cyc = reinterpret_cast<int32_t*>(static_cast<float*>(c->ws[1]) + n_state);
+    AUD_HIP(c, hipMemcpyAsync(d_raw, raw, total * 4, hipMemcpyHostToDevice, c->stream));
+    if (!start_from_raw) AUD_HIP(c, hipMemcpyAsync(d_act, act, total * 4, hipMemcpyHostToDevice, c->stream));
+    if (n_state) AUD_HIP(c, hipMemcpyAsync(d_state, pool_state, n_state * 4, hipMemcpyHostToDevice, c->stream));
+    rc = aud_kwta_batch_dev(c, k, d_raw, d_act, n_items, d0, d1, d2, d3, pool_level, start_from_raw, d_state,
+                            sum_order, d_cyc, c->stream);
+    if (rc != AUD_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        return rc;
+    }
+    AUD_HIP(c, hipMemcpyAsync(act, d_act, total * 4, hipMemcpyDeviceToHost, c->stream));
+    if (n_state) AUD_HIP(c, hipMemcpyAsync(pool_state, d_state, n_state * 4, hipMemcpyDeviceToHost, c->stream));
+    if (cycles) AUD_HIP(c, hipMemcpyAsync(cycles, d_cyc, size_t(n_items) * 4, hipMemcpyDeviceToHost, c->stream));
+    AUD_HIP(c, hipStreamSynchronize(c->stream));
+    return AUD_OK;
+}
+
 int aud_comm_unique_id(char id[128]) {
     if (!id) return AUD_EINVAL;
     void* h = rccl_open();

@@ -295,4 +295,26 @@ int aud_gabor_iter_space(const aud_gabor_set* set, int mel_rows, int mel_cols, i
     return AUD_OK;
 }
 
+// kwta.KWTA.Defaults() of github.com/emer/vision v1.1.15 over leabra v1.1.48's fffb.Params.Defaults()
+// and nxx1.Params.Defaults().  Those sources are not in the reference tree; the values are the published
+// ones as far as known here.  A Go binding never needs this function: it passes the fields of the real
+// kwta.KWTA value (se.Kwta, sound/sndenv.go:175, set by se.Kwta.Defaults() at :189).
+void aud_kwta_defaults(aud_kwta_params* k) {
+    if (!k) return;
+    std::memset(k, 0, sizeof(*k));
+    k->on = 1;
+    k->iters = 20;
+    k->del_act_thr = 0.005f;
+    const aud_fffb_params f = {1, 1.8f, 1.0f, 1.0f, 1.4f, 0.0f, 0.1f};
+    k->lay_fffb = f;
+    k->pool_fffb = f;
+    k->pool_fffb.gi = 2.0f;
+    const aud_nxx1_params x = {0.5f, 80.0f, 0.01f, 0.01f, 0.33f, 0.8f, 3.0f, 0.01f, 10.0f, 0.1f};
+    k->xx1 = x;
+    k->act_tau = 3.0f;
+    const float gbar[4] = {0.5f, 0.1f, 1.0f, 1.0f}, erev[4] = {1.0f, 0.3f, 0.25f, 0.1f};
+    std::memcpy(k->gbar, gbar, sizeof gbar);
+    std::memcpy(k->erev, erev, sizeof erev);
+}
+
 }  // extern "C"

@@ -127,4 +127,33 @@ hipError_t launch_melspec_r1024(const MelspecArgs& a, const FastArgs& e, int com
 
 hipError_t launch_gabor(const GaborArgs& a, int compute_dtype, hipStream_t st);
 
+// k-WTA settling on the gabor output (SndEnv.ApplyKwta, sound/sndenv.go:313-323)
+struct KwtaFffb {
+    int on;
+    float gi, ff, fb, fb_dt, max_vs_avg, ff0;
+};
+struct KwtaArgs {
+    const float* raw;  // [n_items, n]  excitatory conductances (the raw gabor output)
+    float* act;        // [n_items, n]  activations: out, and in unless start_from_raw
+    int n_items, n;
+    int lay_n, pl_n;   // pool level: lay_n pools of pl_n consecutive values; layer level only: lay_n = 0
+    int start_from_raw;
+    int sum_order;     // 0: running float32 sums in the reference's index order; 1: fixed tree (faster)
+    float* state;      // [n_items, lay_n, 2] {FBi, Act.Avg} carried between calls, or null
+    int32_t* cycles;   // [n_items] settling cycles run, or null
+    int iters;
+    float del_act_thr;
+    KwtaFffb lay, pool;
+    // nxx1.Params and what its Update() derives
+    float gain, nvar, interp_range, gain_cor_range, gain_cor;
+    float sig_gain_nvar, sig_mult_eff, sig_val_at0, interp_val;
+    float gbar_e, gbar_l, gbar_i;
+    float erev_sub_thr_i, erev_sub_thr_l, thr_sub_erev_e;
+    float act_dt;
+    unsigned lds_bytes;
+};
+size_t kwta_lds_bytes(int n, int lay_n);
+hipError_t kwta_prepare(unsigned lds_bytes);
+hipError_t launch_kwta(const KwtaArgs& a, hipStream_t st);
+
 }  // namespace aud

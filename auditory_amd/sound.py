@@ -1,10 +1,10 @@
 """Host-side mirror of the reference's orchestrator `sound.SndEnv` (sound/sndenv.go) for the
 hot path: Init -> ProcessSegment -> ApplyGabor.  The frame loop itself runs on the GPU as one
 batched launch per call; the MFCC tail (CepstrumDct, Energy, deltas) runs as three small kernels
-behind it; the kwta stage of the reference is out of scope."""
+behind it."""
 import numpy as np
 
-from . import agabor, capi, dft, mel, runtime
+from . import agabor, capi, dft, kwta, mel, runtime
 
 
 def MSecToSamples(ms, rate):
@@ -133,6 +133,11 @@ class SndEnv:
         self.GborOutUnitsX = 0
         self.GborOutUnitsY = 0
         self.GborOutput = None
+        self.GborKwta = None                # post-kwta output (sndenv.go:163)
+        self.Inhibs = None                  # pool-level FFFB state KWTAPool carries between calls (:166)
+        self.ExtGi = None                   # stays all zeros: NeighInhib is not built (:169-172)
+        self.Kwta = kwta.KWTA()             # zero value (Kwta.On false) until Defaults(), as in Go
+        self.KwtaPool = False
         self.ByTime = False
         self._device = device
         self._compute_dtype = compute_dtype
@@ -156,6 +161,8 @@ class SndEnv:
         """sound/sndenv.go:185-192"""
         self.ParamDefaults()
         self.Mel.Defaults()
+        self.Kwta.Defaults()
+        self.KwtaPool = True
         self.ByTime = False
 
     def Init(self):
@@ -180,6 +187,8 @@ class SndEnv:
         else:
             print("GborOutPoolsX & GborOutPoolsY must both be == 0 or > 0 (i.e. 2D or 4D)")
             return None
+        self.ExtGi = np.zeros(self.GborOutput.shape, np.float32)
+        self.GborKwta = np.zeros(self.GborOutput.shape, np.float32)
 
         H = p.WinSamples // 2 + 1
         self.DFT.Defaults()
@@ -264,10 +273,30 @@ class SndEnv:
             self.LogPowerSegment = lp[-1]
         return m, pw, lp
 
+    def ApplyKwta(self):
+        """sound/sndenv.go:313-323: GborKwta <- GborOutput, then KWTAPool / KWTALayer when Kwta.On"""
+        self.GborKwta[...] = self.GborOutput
+        if self.Kwta.On:
+            if self.KwtaPool:
+                if self.GborOutput.ndim != 4:
+                    # the reference panics here (KWTAPool reads Dim(2), Dim(3) of a 2-D tensor)
+                    raise capi.AuditoryError(capi.AUD_EINVAL, "KwtaPool needs the 4-D gabor output")
+                n_pools = self.GborOutput.shape[0] * self.GborOutput.shape[1]
+                if self.Inhibs is None or self.Inhibs.shape[0] != n_pools:
+                    self.Inhibs = np.zeros((n_pools, 2), np.float32)
+                self.Kwta.KWTAPool(self.GborOutput, self.GborKwta, self.Inhibs, self.ExtGi, device=self._device)
+            else:
+                self.Kwta.KWTALayer(self.GborOutput, self.GborKwta, self.ExtGi, device=self._device)
+
     def ApplyGabor(self):
-        """sound/sndenv.go:481-497 without NeighInhib / Kwta (both off by default, out of scope)"""
+        """sound/sndenv.go:481-497.  NeighInhib is not built: ExtGi stays zero, which is the reference's
+        state whenever NeighInhib.On is false (its zero value; SndEnv.Defaults never turns it on)."""
         agabor.Convolve(self.MelFBankSegment, self.GaborFilters, self.GborOutput, self.ByTime,
                         plan=self._plan)
+        self.ExtGi[...] = 0
+        if self.Kwta.On:
+            self.ApplyKwta()
+            return self.GborKwta
         return self.GborOutput
 
     def AdjustForSilence(self, add, existing):

@@ -286,6 +286,58 @@ int aud_gabor_batch_host(aud_plan* plan, const double* mel, int n_items, int mel
                          int mel_cols, int out_rank, const int32_t* out_shape, int by_time,
                          float* out);
 
+/* ---- k-WTA settling of the gabor output ---------------------------------------------------
+ * SndEnv.ApplyKwta, sound/sndenv.go:313-323, which ApplyGabor (:481-497) runs when Kwta.On: the
+ * activation tensor starts as a copy of the raw gabor output (:315) and settles under layer- and
+ * pool-level FFFB inhibition.  The algorithm is third-party code that is not in the reference tree:
+ * kwta.KWTA / KWTAPool / KWTALayer of github.com/emer/vision v1.1.15 over fffb.Params, nxx1.Params and
+ * chans.Chans of github.com/emer/leabra v1.1.48 (go.mod:8-9).  The structs below carry those types'
+ * exported fields one for one so that a Go binding passes se.Kwta through unchanged; the defaults
+ * function restates KWTA.Defaults() as far as it is known here ("k-WTA").
+ * NeighInhib (sndenv.go:303-311) is not built: the external-inhibition tensor is taken as all zeros,
+ * which is what the reference has whenever NeighInhib.On is false (its zero value; :484-488). */
+typedef struct {
+    int32_t on;
+    float gi, ff, fb, fb_tau, max_vs_avg, ff0;
+} aud_fffb_params; /* leabra fffb.Params */
+
+typedef struct {
+    float thr, gain, nvar, vm_act_thr, sig_mult, sig_mult_pow, sig_gain, interp_range, gain_cor_range, gain_cor;
+} aud_nxx1_params; /* leabra nxx1.Params (settable fields; the derived ones are recomputed per call) */
+
+typedef struct {
+    int32_t on;    /* KWTA.On: informational here -- the caller decides whether to call */
+    int32_t iters; /* KWTA.Iters */
+    float del_act_thr;
+    aud_fffb_params lay_fffb, pool_fffb;
+    aud_nxx1_params xx1;
+    float act_tau;
+    float gbar[4]; /* chans.Chans E, L, I, K */
+    float erev[4];
+} aud_kwta_params;
+
+void aud_kwta_defaults(aud_kwta_params* k);
+
+/* raw, act: float32 [n_items, d0, d1, d2, d3] in device memory, act != raw.
+ * pool_level 1: KWTAPool (layer level over all values + pool level inside each (d0, d1) cell);
+ *            0: KWTALayer (layer level only; the four extents only give the value count).
+ * start_from_raw 1: act is output only and settling starts from act = raw (what ApplyKwta does);
+ *                0: act holds the starting activations on entry.
+ * pool_state: float32 [n_items, d0*d1, 2] = {FBi, Act.Avg} of every pool's fffb.Inhib, read on entry
+ *   and written on return -- the SndEnv.Inhibs slice (sndenv.go:166) that KWTAPool carries from call to
+ *   call; NULL = a fresh slice.  Ignored at layer level.
+ * sum_order 0: running float32 sums in the reference's index order (bit-faithful, the layer sum is
+ *   sequential); 1: fixed reduction tree (deterministic, differs from the reference's sums in the last ulps).
+ * cycles: int32 [n_items] settling cycles each item ran, or NULL.
+ * One workgroup per item with the activations in LDS: needs (32 + n + 4 d0 d1) * 4 bytes <= 160 KB. */
+int aud_kwta_batch_dev(aud_ctx* ctx, const aud_kwta_params* k, const float* raw, float* act, int n_items, int d0,
+                       int d1, int d2, int d3, int pool_level, int start_from_raw, float* pool_state,
+                       int sum_order, int32_t* cycles, void* stream);
+/* the same on host memory (copies in and out on the context's stream, synchronous) */
+int aud_kwta_batch_host(aud_ctx* ctx, const aud_kwta_params* k, const float* raw, float* act, int n_items, int d0,
+                        int d1, int d2, int d3, int pool_level, int start_from_raw, float* pool_state,
+                        int sum_order, int32_t* cycles);
+
 /* ---- multi-GPU reassembly (one process per GPU, RCCL over xGMI) ------------------ */
 
 /* 128-byte RCCL unique id, created on rank 0 and distributed by the host program */

@@ -18,8 +18,8 @@ ORC_OK, ORC_EINVAL, ORC_EPANIC, ORC_ESHORT = 0, 1, 2, 3
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "auditory_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("auditory_oracle.c", "kwta_oracle.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
     return so
 
@@ -40,6 +40,27 @@ class GaborSpec(C.Structure):
     _fields_ = [("off", C.c_int), ("wave_len", C.c_double), ("orientation", C.c_double),
                 ("sigma_width", C.c_double), ("sigma_length", C.c_double),
                 ("phase_offset", C.c_double), ("circle_edge", C.c_int), ("circular", C.c_int)]
+
+
+class Fffb(C.Structure):
+    _fields_ = [("on", C.c_int32)] + [(n, C.c_float) for n in ("gi", "ff", "fb", "fb_tau", "max_vs_avg", "ff0")]
+
+
+class Nxx1(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("thr", "gain", "nvar", "vm_act_thr", "sig_mult", "sig_mult_pow",
+                                         "sig_gain", "interp_range", "gain_cor_range", "gain_cor")]
+
+
+class Kwta(C.Structure):
+    _fields_ = [("on", C.c_int32), ("iters", C.c_int32), ("del_act_thr", C.c_float), ("lay", Fffb),
+                ("pool", Fffb), ("xx1", Nxx1), ("act_tau", C.c_float), ("gbar", C.c_float * 4),
+                ("erev", C.c_float * 4)]
+
+
+class KwtaDerived(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("lay_fb_dt", "pool_fb_dt", "sig_gain_nvar", "sig_mult_eff",
+                                         "sig_val_at0", "interp_val")] + \
+               [("erev_sub_thr", C.c_float * 4), ("thr_sub_erev", C.c_float * 4), ("act_dt", C.c_float)]
 
 
 class SndParams(C.Structure):
@@ -78,6 +99,12 @@ def lib():
         L.orc_snd_to_window.restype = C.c_int
         L.orc_mfcc_tail.restype = C.c_int
         L.orc_process_segment_mfcc.restype = C.c_int
+        L.orc_fast_exp.restype = C.c_float
+        L.orc_fast_exp.argtypes = [C.c_float]
+        L.orc_noisy_xx1.restype = C.c_float
+        L.orc_noisy_xx1.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
+        L.orc_kwta_layer.restype = C.c_int
+        L.orc_kwta_pool.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -271,3 +298,48 @@ def process_segment_mfcc(sp, d, m, bin_pts, filters, signal, segment=0, add_ms=0
                                           C.c_int(int(deltas)), _p(energy), _p(mfcc), _p(dl), _p(ddl))
     return dict(done=done, mel_seg=mel_seg, log_power_seg=log_power_seg, power_seg=power_seg, energy=energy,
                 mfcc=mfcc, deltas=dl, delta_deltas=ddl)
+
+
+# ---- k-WTA stage (kwta_oracle.c; third-party algorithm restated from memory of the published source) ----
+
+def kwta_defaults():
+    k = Kwta()
+    lib().orc_kwta_defaults(C.byref(k))
+    return k
+
+
+def kwta_update(k):
+    d = KwtaDerived()
+    lib().orc_kwta_update(C.byref(k), C.byref(d))
+    return d
+
+
+def fast_exp(x):
+    return lib().orc_fast_exp(float(x))
+
+
+def noisy_xx1(k, x):
+    d = kwta_update(k)
+    return lib().orc_noisy_xx1(C.byref(k), C.byref(d), float(x))
+
+
+def kwta_layer(k, raw):
+    """KWTALayer on one tensor: returns (settled activations, cycles run); starts from act = raw"""
+    raw = np.ascontiguousarray(raw, dtype=np.float32)
+    act = raw.copy()
+    cy = lib().orc_kwta_layer(C.byref(k), _p(raw), _p(act), C.c_int(raw.size))
+    return act, cy
+
+
+def kwta_pool(k, raw, state=None):
+    """KWTAPool on one [d0, d1, d2, d3] tensor: returns (act, cycles); state float32 [d0*d1, 2] is
+    updated in place when given (the carried fffb.Inhibs slice)"""
+    raw = np.ascontiguousarray(raw, dtype=np.float32)
+    assert raw.ndim == 4
+    act = raw.copy()
+    if state is not None:
+        assert state.dtype == np.float32 and state.shape == (raw.shape[0] * raw.shape[1], 2) \
+            and state.flags.c_contiguous
+    cy = lib().orc_kwta_pool(C.byref(k), _p(raw), _p(act), *[C.c_int(v) for v in raw.shape],
+                             _p(state) if state is not None else None)
+    return act, cy

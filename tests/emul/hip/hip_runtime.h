@@ -124,5 +124,16 @@ inline V __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, V c, int, int, i
     return c;
 }
 
+inline float __int_as_float(int v) {
+    float f;
+    std::memcpy(&f, &v, 4);
+    return f;
+}
+inline int __float_as_int(float f) {
+    int v;
+    std::memcpy(&v, &f, 4);
+    return v;
+}
+
 using std::max;
 using std::min;

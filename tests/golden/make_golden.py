@@ -1,4 +1,4 @@
-"""Generates tests/golden/*.npz from the CPU oracle (oracle/auditory_oracle.c).
+"""Generates tests/golden/*.npz from the CPU oracle (oracle/auditory_oracle.c, kwta_oracle.c).
 
 The reference (Go) cannot run in this pipeline and ships no vectors of its own, so these
 fixtures are REGRESSION vectors of the oracle, not reference outputs: they freeze today's oracle
@@ -55,6 +55,9 @@ def compute(name):
             assert orc.gabor_convolve(out["mel"][i], k, 3, 3, 2.0, g[i]) == 0
         out["gabor"] = g
         out["gabor_k"] = k
+        # SndEnv.ApplyKwta with the default parameters (KWTAPool, fresh Inhibs per item): float32, bit-exact
+        kw = orc.kwta_defaults()
+        out["kwta"] = np.stack([orc.kwta_pool(kw, g[i])[0] for i in range(len(items))])
     return out
 
 

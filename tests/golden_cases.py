@@ -50,5 +50,11 @@ def check_library_against_golden(name, compute_dtype):
             plan.gabor_host(mel, out)            # gabor of the library's own mel, as SndEnv does
             ok, msg = W.feature_close(out, gold["gabor"], compute_dtype)
             assert ok, (name, "gabor", msg)
+            # k-WTA of the STORED gabor tensor: float32 in the reference's order, so exact
+            from auditory_amd import kwta
+            k = kwta.KWTA()
+            k.Defaults()
+            act, _ = kwta.kwta_batch_host(k, gold["gabor"], pool=True)
+            assert np.array_equal(act, gold["kwta"]), (name, "kwta")
     finally:
         plan.close()

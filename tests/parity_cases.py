@@ -190,9 +190,18 @@ def case_sndenv_mirror_reads_like_the_reference(orc):
     assert (se.Params.WinSamples, se.Params.SegmentSteps, se.SegCnt) == (400, 14, 5)
     oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
     k = orc.gabor_to_tensor(W.DEFAULT_GABOR_SPECS, 9, 9)
+    assert se.Kwta.On and se.KwtaPool          # sndenv.go:189-190
+    kw, kw_state = orc.kwta_defaults(), np.zeros((8 * 2, 2), np.float32)
     for seg in range(se.SegCnt):
         se.ProcessSegment(seg, 0)
         tsr = se.ApplyGabor()
+        assert tsr is se.GborKwta              # :492-494
+        # the k-WTA stage is float32 in the reference's operation order: bit-exact against the oracle run
+        # on the same raw tensor, including the pool state SndEnv.Inhibs carries from segment to segment
+        ref_k, _ = orc.kwta_pool(kw, se.GborOutput, kw_state)
+        assert np.array_equal(tsr, ref_k)
+        assert np.array_equal(se.Inhibs, kw_state)
+        tsr = se.GborOutput
         o = orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig[0], segment=seg)
         ok, msg = W.feature_close(se.MelFBankSegment, o["mel_seg"], capi.AUD_F32, lin_axis=0)
         assert ok, msg
@@ -202,6 +211,118 @@ def case_sndenv_mirror_reads_like_the_reference(orc):
         assert orc.gabor_convolve(o["mel_seg"], k, 3, 3, 2.0, ref) == 0
         ok, msg = W.feature_close(tsr, ref, capi.AUD_F32)
         assert ok, "gabor " + msg
+
+
+# ---- k-WTA stage -------------------------------------------------------------------------------
+
+def _kwta_pair(orc, **over):
+    """(product KWTA mirror, oracle struct) with the same parameters; `over` maps dotted names to values"""
+    import ctypes as C
+    from auditory_amd import kwta
+    k = kwta.KWTA()
+    k.Defaults()
+    for name, v in over.items():
+        obj = k
+        parts = name.split(".")
+        for part in parts[:-1]:
+            obj = getattr(obj, part)
+        setattr(obj, parts[-1], v)
+    ko = orc.Kwta()
+    assert C.sizeof(ko) == C.sizeof(k.c)           # same field order on both sides
+    C.memmove(C.byref(ko), C.byref(k.c), C.sizeof(ko))
+    return k, ko
+
+
+def kwta_inputs(seed, n_items, shape=(11, 32, 2, 8)):
+    """gabor-like raw tensors: rectified on/off pairs, mostly small, a few strong units, one quiet item"""
+    rng = np.random.default_rng(seed)
+    v = rng.normal(0.0, 0.35, size=(n_items,) + shape[:2] + (shape[3],))
+    raw = np.zeros((n_items,) + shape, np.float32)
+    raw[:, :, :, 0, :] = np.maximum(v, 0)
+    if shape[2] > 1:
+        raw[:, :, :, 1, :] = np.maximum(-v, 0)
+    if n_items > 1:
+        raw[1] *= 0.05
+    if n_items > 2:
+        raw[2, : shape[0] // 2] = 0
+    return raw
+
+
+def case_kwta_vs_oracle(orc):
+    """KWTAPool / KWTALayer through the C ABI against the float32 oracle: bit-exact in the reference's
+    summation order, within a few ulp-amplified steps for the tree order."""
+    from auditory_amd import kwta
+    raw = kwta_inputs(11, 4)
+    variants = [{}, {"LayFFFB.MaxVsAvg": 0.3, "PoolFFFB.MaxVsAvg": 0.5}, {"PoolFFFB.On": False},
+                {"LayFFFB.On": False, "XX1.Gain": 40.0, "Iters": 7}, {"Iters": 0}, {"DelActThr": 0.2}]
+    for over in variants:
+        k, ko = _kwta_pair(orc, **over)
+        for pool in (True, False):
+            act, cyc = kwta.kwta_batch_host(k, raw, pool=pool)
+            for i in range(raw.shape[0]):
+                ref, c = (orc.kwta_pool(ko, raw[i]) if pool else orc.kwta_layer(ko, raw[i]))
+                assert np.array_equal(act[i], ref), (over, pool, i, np.abs(act[i] - ref).max())
+                assert cyc[i] == c
+    k, ko = _kwta_pair(orc)
+    ref = np.stack([orc.kwta_pool(ko, r)[0] for r in raw])
+    # it does something k-WTA-like: a sparse code, strongest inputs survive
+    assert 0.02 < (ref[0] > 0.1).mean() < 0.5 and ref[0].flat[np.argmax(raw[0])] > 0.5
+    # tree summation: same dynamics, last-ulp differences in the sums
+    act, _ = kwta.kwta_batch_host(k, raw, pool=True, sum_order=1)
+    assert np.abs(act - ref).max() <= 2e-5
+    act2, _ = kwta.kwta_batch_host(k, raw, pool=True, sum_order=1)
+    assert np.array_equal(act, act2)               # deterministic
+    # carried pool state over three calls (SndEnv.Inhibs), per item
+    st = np.zeros((4, 11 * 32, 2), np.float32)
+    st_o = st.copy()
+    for rep in range(3):
+        act, _ = kwta.kwta_batch_host(k, raw, pool=True, state=st)
+        for i in range(4):
+            r, _ = orc.kwta_pool(ko, raw[i], st_o[i])
+            assert np.array_equal(act[i], r)
+        assert np.array_equal(st, st_o)
+    assert np.abs(st).max() > 0
+    # the per-tensor methods: act is in/out (the caller copies raw into it, sndenv.go:315) ...
+    a = raw[0].copy()
+    cy = k.KWTAPool(raw[0], a, None, np.zeros_like(raw[0]))
+    assert np.array_equal(a, ref[0]) and cy == orc.kwta_pool(ko, raw[0])[1]
+    # ... or any other starting point
+    a0 = np.full_like(raw[0], 0.25)
+    a = a0.copy()
+    k.KWTALayer(raw[0], a)
+    import ctypes as C
+    r = a0.copy()
+    orc.lib().orc_kwta_layer(C.byref(ko), raw[0].ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p),
+                             C.c_int(r.size))
+    assert np.array_equal(a, r)
+    with pytest.raises(capi.AuditoryError):        # NeighInhib is not built
+        k.KWTAPool(raw[0], raw[0].copy(), None, np.ones_like(raw[0]))
+
+
+def case_kwta_shapes(orc):
+    """edge shapes: single values, one-unit pools, ragged pool counts over the 256 threads, a tensor whose
+    activations need more than the default 64 KB of LDS, and one that does not fit a workgroup at all"""
+    from auditory_amd import kwta
+    k, ko = _kwta_pair(orc)
+    for shape in [(1, 1, 1, 1), (1, 1, 2, 8), (3, 5, 1, 1), (17, 19, 2, 4), (1, 300, 1, 3), (2, 2, 16, 16)]:
+        raw = kwta_inputs(5, 2, shape)
+        for pool in (True, False):
+            act, cyc = kwta.kwta_batch_host(k, raw, pool=pool)
+            for i in range(2):
+                ref, c = (orc.kwta_pool(ko, raw[i]) if pool else orc.kwta_layer(ko, raw[i]))
+                assert np.array_equal(act[i], ref), (shape, pool, i)
+                assert cyc[i] == c
+    raw = kwta_inputs(6, 1, (11, 165, 2, 8))       # a 5 s segment: 29 040 values, 142 KB of LDS
+    act, cyc = kwta.kwta_batch_host(k, raw, pool=True)
+    ref, c = orc.kwta_pool(ko, raw[0])
+    assert np.array_equal(act[0], ref) and cyc[0] == c
+    act, _ = kwta.kwta_batch_host(k, np.zeros((0, 11, 32, 2, 8), np.float32))
+    assert act.shape == (0, 11, 32, 2, 8)
+    with pytest.raises(capi.AuditoryError):
+        kwta.kwta_batch_host(k, np.zeros((1, 11, 400, 2, 8), np.float32))
+    kz = kwta.KWTA()                               # Go zero value: ActTau = 0 etc.
+    with pytest.raises(capi.AuditoryError):
+        kwta.kwta_batch_host(kz, np.zeros((1, 2, 2, 2, 2), np.float32))
 
 
 def case_recreated_tone_fixtures_f64(orc):

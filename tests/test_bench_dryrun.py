@@ -132,4 +132,5 @@ def test_device_api_tests_dry_run(monkeypatch, orc):
     with backend.emulated("plain"):
         G.test_input_dtypes_agree(orc, torch)
         G.test_process_batch_mel_plus_gabor(orc, torch)
+        G.test_process_then_kwta_device_resident(orc, torch, n=2)
         G.test_full_size_properties_cfg2(orc, torch, B=4)

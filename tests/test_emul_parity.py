@@ -122,3 +122,11 @@ def test_emul_kernels_under_asan_ubsan():
 
 def test_emul_kernels_under_tsan():
     _sanitizer_run("tsan", "quick")
+
+
+def test_emul_kwta_vs_oracle(orc, emu):
+    PC.case_kwta_vs_oracle(orc)
+
+
+def test_emul_kwta_shapes(orc, emu):
+    PC.case_kwta_shapes(orc)

@@ -84,6 +84,14 @@ def test_per_step_api(orc, torch_cuda, cdt):
     PC.case_per_step_api(orc, cdt)
 
 
+def test_kwta_vs_oracle(orc, torch_cuda):
+    PC.case_kwta_vs_oracle(orc)
+
+
+def test_kwta_shapes(orc, torch_cuda):
+    PC.case_kwta_shapes(orc)
+
+
 def test_recreated_tone_fixtures_f64(orc, torch_cuda):
     PC.case_recreated_tone_fixtures_f64(orc)
 
@@ -133,6 +141,38 @@ def test_process_batch_mel_plus_gabor(orc, torch_cuda):
     assert ok, "mel " + msg
     ok, msg = W.feature_close(gab.cpu().numpy(), ref_g, capi.AUD_F32)
     assert ok, "gabor " + msg
+    plan.close()
+
+
+def test_process_then_kwta_device_resident(orc, torch_cuda, n=6):
+    """SndEnv.ApplyGabor with Kwta.On (sndenv.go:481-497) on device-resident tensors: mel + gabor, then the
+    k-WTA stage on the gabor tensor where it lies in HBM; bit-exact against the oracle run on that tensor"""
+    torch = torch_cuda
+    from auditory_amd import kwta
+    from auditory_amd.batch import BatchProcessor
+    oc = W.OracleCfg(orc, "cfg2_16k_n512_nf40")
+    L = oc.full_len()
+    sig, _ = synth.batch(9, n, 16000, oc.sr, row_len=L)
+    plan = W.product_plan(oc, capi.AUD_F32, PC.GABOR_DEFAULT)
+    bp = BatchProcessor(plan, "cuda:0")
+    items = bp.upload_items(runtime.make_items(np.arange(n) * L, [L] * n, [0] * n))
+    _, gab = bp.process(torch.from_numpy(sig.astype(np.float32)).cuda().view(-1), items, n, 11, 32)
+    k, ko = PC._kwta_pair(orc)
+    act = torch.empty(gab.shape, dtype=torch.float32, device=gab.device)
+    cyc = torch.zeros(n, dtype=torch.int32, device=gab.device)
+    state = torch.zeros((n, 11 * 32, 2), dtype=torch.float32, device=gab.device)
+    stream = torch.cuda.current_stream().cuda_stream
+    kwta.kwta_batch_dev(k, gab, act, pool=True, state=state, cycles=cyc, stream=stream)
+    torch.cuda.synchronize()
+    raw = gab.cpu().numpy()
+    st_o = np.zeros((n, 11 * 32, 2), np.float32)
+    for i in range(n):
+        ref, c = orc.kwta_pool(ko, raw[i], st_o[i])
+        assert np.array_equal(act[i].cpu().numpy(), ref)
+        assert int(cyc[i]) == c
+    assert np.array_equal(state.cpu().numpy(), st_o)
+    # the gabor tensor was only read
+    assert np.array_equal(gab.cpu().numpy(), raw)
     plan.close()
 
 

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import np_ref
+import np_ref as R
 from auditory_amd import synth
 
 
@@ -349,3 +350,76 @@ def test_mfcc_tail_semantics(orc):
     # a short signal: unprocessed steps keep MFCC rows 1.. at zero, row 0 still gets Energy
     o2 = orc.process_segment_mfcc(sp, d, m, bins, filt, sig[0][:1900], segment=0)
     assert o2["done"] == 12 and np.all(o2["mfcc"][1:, 12:] == 0)
+
+
+# ---- k-WTA stage (oracle/kwta_oracle.c) ---------------------------------------------------------
+
+def test_fast_exp_is_the_quartic_spline(orc):
+    """FastExp tracks exp to ~1e-5 relative over the range NoisyXX1 uses it on (0, 50], is continuous across
+    mantissa wrap-arounds, and agrees with an independent integer restatement bit for bit"""
+    xs = np.linspace(-80.0, 80.0, 4001)
+    rel = np.array([abs(orc.fast_exp(x) - np.exp(x)) / np.exp(x) for x in xs])
+    assert rel.max() < 2e-5
+    for x in (0.0, 1e-3, 0.37, 1.0, 17.25, 49.999, -3.5):
+        assert np.float32(orc.fast_exp(x)) == R.fast_exp32(x)
+    assert orc.fast_exp(-100.0) == 0.0
+
+
+def test_noisy_xx1_shape(orc):
+    k = orc.kwta_defaults()
+    d = orc.kwta_update(k)
+    assert abs(d.sig_gain_nvar - 300.0) < 1e-4 and abs(d.act_dt - 1 / 3) < 1e-7
+    assert np.allclose(list(d.erev_sub_thr), [0.5, -0.2, -0.25, -0.4], atol=1e-7)
+    xs = np.linspace(-0.3, 1.0, 5201).astype(np.float32)
+    ys = np.array([orc.noisy_xx1(k, float(x)) for x in xs])
+    assert ys[0] == 0.0 and (np.diff(ys) >= -2e-6).all() and 0.97 < ys[-1] < 1.0   # monotone (to FastExp's ripple), saturating
+    # continuous where its three pieces meet (x = 0 and x = InterpRange)
+    for x0 in (0.0, 0.01):
+        lo, hi = orc.noisy_xx1(k, np.nextafter(np.float32(x0), np.float32(-1))), orc.noisy_xx1(k, x0)
+        assert abs(hi - lo) < 1e-4
+    assert abs(orc.noisy_xx1(k, 0.0) - d.sig_val_at0) < 1e-7
+    ref = R.KwtaRef(k)
+    for x in (-0.1, -0.01, -1e-4, 0.0, 0.004, 0.01, 0.03, 0.2, 0.9):
+        assert np.float32(orc.noisy_xx1(k, x)) == ref.noisy_xx1(np.float32(x))
+
+
+def test_kwta_pool_vs_python_restatement(orc):
+    """the C oracle against a scalar numpy-float32 restatement written separately (small tensor)"""
+    k = orc.kwta_defaults()
+    rng = np.random.default_rng(4)
+    raw = np.maximum(rng.normal(0, 0.4, (3, 4, 2, 4)), 0).astype(np.float32)
+    act, cy = orc.kwta_pool(k, raw)
+    ref, cy_ref = R.KwtaRef(k).pool(raw)
+    assert cy == cy_ref and np.array_equal(act, ref)
+
+
+def test_kwta_behaviour(orc):
+    k = orc.kwta_defaults()
+    rng = np.random.default_rng(8)
+    raw = np.maximum(rng.normal(0, 0.35, (11, 32, 2, 8)), 0).astype(np.float32)
+    act, cy = orc.kwta_pool(k, raw)
+    assert 3 < cy <= k.iters and act.min() >= 0 and act.max() < 1
+    on = act > 0.1
+    assert 0.02 < on.mean() < 0.4                       # sparse
+    assert raw[on].min() > np.median(raw)               # and it is the strong inputs that survive
+    # more inhibition -> fewer active units
+    k2 = orc.kwta_defaults()
+    k2.pool.gi, k2.lay.gi = 3.0, 2.5
+    act2, _ = orc.kwta_pool(k2, raw)
+    assert (act2 > 0.1).sum() < on.sum()
+    # no inhibition at all: every unit above the leak threshold fires
+    k3 = orc.kwta_defaults()
+    k3.pool.on = k3.lay.on = 0
+    act3, _ = orc.kwta_pool(k3, raw)
+    assert (act3 > 0.1).sum() > 2 * on.sum()
+    # all-zero input: a fresh state stays (numerically) silent
+    z, _ = orc.kwta_pool(k, np.zeros((2, 3, 2, 8), np.float32))
+    assert z.max() < 1e-3
+    # pool level at work: the layer-only result differs
+    lay, _ = orc.kwta_layer(k, raw)
+    assert np.abs(lay - act).max() > 0.05
+    # the carried state matters on the second call and converges
+    st = np.zeros((11 * 32, 2), np.float32)
+    a1, _ = orc.kwta_pool(k, raw, st)
+    a2, _ = orc.kwta_pool(k, raw, st)
+    assert np.array_equal(a1, act) and not np.array_equal(a2, a1)
