@@ -16,6 +16,8 @@ package auditoryhip
 import "C"
 
 import (
+	"github.com/emer/leabra/fffb"
+	"github.com/emer/vision/kwta"
 	"errors"
 	"fmt"
 	"unsafe"
@@ -130,4 +132,66 @@ func (p *Plan) Convolve(mel []float64, nItems, rows, cols int, outShape []int32,
 	rc := C.aud_gabor_batch_host(p.h, (*C.double)(unsafe.Pointer(&mel[0])), C.int(nItems), C.int(rows), C.int(cols),
 		C.int(len(outShape)), (*C.int32_t)(unsafe.Pointer(&outShape[0])), bt, (*C.float)(unsafe.Pointer(&out[0])))
 	return status(p.ctx, rc)
+}
+
+// KwtaParams copies the exported fields of a kwta.KWTA (github.com/emer/vision/kwta) into the C struct,
+// one for one.  The derived fields (ErevSubThr, ThrSubErev, ActDt, the nxx1 Sig* values, FBDt) are
+// recomputed inside the library, like KWTA.Update() does.
+func KwtaParams(k *kwta.KWTA) C.aud_kwta_params {
+	fffb := func(p *fffb.Params) C.aud_fffb_params {
+		on := C.int32_t(0)
+		if p.On {
+			on = 1
+		}
+		return C.aud_fffb_params{on: on, gi: C.float(p.Gi), ff: C.float(p.FF), fb: C.float(p.FB),
+			fb_tau: C.float(p.FBTau), max_vs_avg: C.float(p.MaxVsAvg), ff0: C.float(p.FF0)}
+	}
+	var c C.aud_kwta_params
+	if k.On {
+		c.on = 1
+	}
+	c.iters = C.int32_t(k.Iters)
+	c.del_act_thr = C.float(k.DelActThr)
+	c.lay_fffb, c.pool_fffb = fffb(&k.LayFFFB), fffb(&k.PoolFFFB)
+	x := &k.XX1
+	c.xx1 = C.aud_nxx1_params{thr: C.float(x.Thr), gain: C.float(x.Gain), nvar: C.float(x.NVar),
+		vm_act_thr: C.float(x.VmActThr), sig_mult: C.float(x.SigMult), sig_mult_pow: C.float(x.SigMultPow),
+		sig_gain: C.float(x.SigGain), interp_range: C.float(x.InterpRange),
+		gain_cor_range: C.float(x.GainCorRange), gain_cor: C.float(x.GainCor)}
+	c.act_tau = C.float(k.ActTau)
+	c.gbar = [4]C.float{C.float(k.Gbar.E), C.float(k.Gbar.L), C.float(k.Gbar.I), C.float(k.Gbar.K)}
+	c.erev = [4]C.float{C.float(k.Erev.E), C.float(k.Erev.L), C.float(k.Erev.I), C.float(k.Erev.K)}
+	return c
+}
+
+// Kwta is SndEnv.ApplyKwta's KWTAPool / KWTALayer call (sound/sndenv.go:313-323) on one or more tensors:
+// raw and act are [nItems][shape...] float32, act in/out (the caller has copied raw into it, :315);
+// state is the flattened {FBi, Act.Avg} of the pool-level fffb.Inhibs (nil = fresh), see PoolState.
+func (c *Ctx) Kwta(k *kwta.KWTA, raw, act []float32, nItems int, shape [4]int, pool bool, state []float32) error {
+	kp := KwtaParams(k)
+	pl := C.int(0)
+	if pool {
+		pl = 1
+	}
+	var st *C.float
+	if len(state) > 0 {
+		st = (*C.float)(unsafe.Pointer(&state[0]))
+	}
+	rc := C.aud_kwta_batch_host(c.h, &kp, (*C.float)(unsafe.Pointer(&raw[0])), (*C.float)(unsafe.Pointer(&act[0])),
+		C.int(nItems), C.int(shape[0]), C.int(shape[1]), C.int(shape[2]), C.int(shape[3]), pl, 0, st, 0, nil)
+	return status(c, rc)
+}
+
+// PoolState / SetPoolState move the two fields of fffb.Inhib that KWTAPool carries between calls
+// (FBi and Act.Avg) between the Go slice (SndEnv.Inhibs) and the flat float32 layout of the C ABI.
+func PoolState(inh fffb.Inhibs, state []float32) {
+	for i := range inh {
+		state[2*i], state[2*i+1] = inh[i].FBi, inh[i].Act.Avg
+	}
+}
+
+func SetPoolState(inh fffb.Inhibs, state []float32) {
+	for i := range inh {
+		inh[i].FBi, inh[i].Act.Avg = state[2*i], state[2*i+1]
+	}
 }

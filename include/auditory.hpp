@@ -15,6 +15,7 @@
 #ifndef AUDITORY_HPP
 #define AUDITORY_HPP
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -179,6 +180,35 @@ inline void Convolve(aud_plan* plan, const Float64& melData, const FilterSet&, F
 }
 }  // namespace agabor
 
+// kwta.KWTA of github.com/emer/vision v1.1.15 (parameters only; the settling runs on the GPU).  A
+// default-constructed value is all zeros like the Go zero value; Defaults() as KWTA.Defaults().
+namespace kwta {
+struct KWTA : aud_kwta_params {
+    KWTA() : aud_kwta_params{} {}
+    bool On() const { return on != 0; }
+    void Defaults() { aud_kwta_defaults(this); }
+    // KWTAPool(raw, act, inhib, extGi) / KWTALayer(raw, act, extGi) with extGi == zeros: act is in/out,
+    // inhib the carried [pools][2] state (resized like the Go slice)
+    int KWTAPool(const Float32& raw, Float32* act, std::vector<float>* inhib) const {
+        const size_t pools = size_t(raw.Dim(0)) * raw.Dim(1);
+        if (inhib && inhib->size() != 2 * pools) inhib->assign(2 * pools, 0.f);
+        int32_t cyc = 0;
+        const int rc = aud_kwta_batch_host(default_ctx(), this, raw.Values.data(), act->Values.data(), 1, raw.Dim(0),
+                                           raw.Dim(1), raw.Dim(2), raw.Dim(3), 1, 0, inhib ? inhib->data() : nullptr,
+                                           0, &cyc);
+        if (rc != AUD_OK) std::fprintf(stderr, "kwta.KWTAPool: %s\n", aud_last_error(default_ctx()));
+        return cyc;
+    }
+    int KWTALayer(const Float32& raw, Float32* act) const {
+        int32_t cyc = 0;
+        const int rc = aud_kwta_batch_host(default_ctx(), this, raw.Values.data(), act->Values.data(), 1,
+                                           int(raw.Values.size()), 1, 1, 1, 0, 0, nullptr, 0, &cyc);
+        if (rc != AUD_OK) std::fprintf(stderr, "kwta.KWTALayer: %s\n", aud_last_error(default_ctx()));
+        return cyc;
+    }
+};
+}  // namespace kwta
+
 namespace sound {
 inline int MSecToSamples(double ms, int rate) { return aud_msec_to_samples(ms, rate); }  // sndenv.go:522-524
 
@@ -201,6 +231,11 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
     agabor::FilterSet GaborFilters;
     int GborOutPoolsX = 0, GborOutPoolsY = 0, GborOutUnitsX = 0, GborOutUnitsY = 0;
     Float32 GborOutput;
+    Float32 GborKwta;            // post-kwta output (sndenv.go:163)
+    std::vector<float> Inhibs;   // pool-level FFFB state carried between calls (fffb.Inhibs, :166)
+    Float32 ExtGi;               // stays zero: NeighInhib is not built (:169-172)
+    kwta::KWTA Kwta;
+    bool KwtaPool = false;
     bool ByTime = false;
     int ComputeDtype = AUD_F32;
     PlanHandle plan;
@@ -214,6 +249,8 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
     void Defaults() {  // sndenv.go:185-192
         ParamDefaults();
         Mel.Defaults();
+        Kwta.Defaults();
+        KwtaPool = true;
         ByTime = false;
     }
 
@@ -238,6 +275,8 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
             std::fprintf(stderr, "GborOutPoolsX & GborOutPoolsY must both be == 0 or > 0 (i.e. 2D or 4D)\n");
             return "";
         }
+        ExtGi.SetShape(GborOutput.Shape);
+        GborKwta.SetShape(GborOutput.Shape);
         const int H = Params_.WinSamples / 2 + 1;
         DFT.Defaults();
         if (!Mel.InitFilters(Params_.WinSamples, SampleRate, &MelFilters)) return "mel filter table overflow";
@@ -273,9 +312,29 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
         if (rc != AUD_OK) std::printf("%s\n", aud_last_error(default_ctx()));  // fmt.Println(err), sndenv.go:356
     }
 
-    // sndenv.go:481-497 without NeighInhib / Kwta (off by default; out of scope)
+    // sndenv.go:313-323
+    void ApplyKwta() {
+        GborKwta.Values = GborOutput.Values;  // CopyFrom
+        if (!Kwta.On()) return;
+        if (KwtaPool) {
+            if (GborOutput.NumDims() != 4) {  // the Go code panics here (Dim(2) of a 2-D tensor)
+                std::fprintf(stderr, "KwtaPool needs the 4-D gabor output\n");
+                return;
+            }
+            Kwta.KWTAPool(GborOutput, &GborKwta, &Inhibs);
+        } else {
+            Kwta.KWTALayer(GborOutput, &GborKwta);
+        }
+    }
+
+    // sndenv.go:481-497; NeighInhib is not built (ExtGi stays zero, the reference's state when it is off)
     Float32* ApplyGabor() {
         agabor::Convolve(plan.p, MelFBankSegment, GaborFilters, &GborOutput, ByTime);
+        std::fill(ExtGi.Values.begin(), ExtGi.Values.end(), 0.f);
+        if (Kwta.On()) {
+            ApplyKwta();
+            return &GborKwta;
+        }
         return &GborOutput;
     }
 };

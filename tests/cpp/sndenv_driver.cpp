@@ -1,7 +1,7 @@
 // Drives include/auditory.hpp the way an emergent simulation drives sound.SndEnv:
 //   Defaults -> set fields -> Init -> for each segment { ProcessSegment; ApplyGabor }
 // argv: <signal.f64> <sample_rate> <out.bin>.  Output: for every segment, float64 mel [nf*T],
-// float64 log-power [H*T], float32 gabor [8*2*2*8], preceded by one int32 header {SegCnt, nf, T, H}.
+// float64 log-power [H*T], float32 raw gabor [8*2*2*8], float32 post-kwta [8*2*2*8], preceded by one int32 header {SegCnt, nf, T, H}.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -49,8 +49,10 @@ int main(int argc, char** argv) {
     for (int seg = 0; seg < se.SegCnt; ++seg) {
         se.ProcessSegment(seg, 0);
         Float32* g = se.ApplyGabor();
+        if (g != &se.GborKwta) return 6;  // Defaults() leaves Kwta.On (sndenv.go:189, :492-494)
         std::fwrite(se.MelFBankSegment.Values.data(), 8, se.MelFBankSegment.Values.size(), o);
         std::fwrite(se.LogPowerSegment.Values.data(), 8, se.LogPowerSegment.Values.size(), o);
+        std::fwrite(se.GborOutput.Values.data(), 4, se.GborOutput.Values.size(), o);
         std::fwrite(g->Values.data(), 4, g->Values.size(), o);
     }
     std::fclose(o);

@@ -33,10 +33,14 @@ def _run_driver(lib_path, tmp_path, orc):
     oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
     k = orc.gabor_to_tensor(W.DEFAULT_GABOR_SPECS, 9, 9)
     pos = 16
+    kw, kw_state = orc.kwta_defaults(), np.zeros((16, 2), np.float32)
     for seg in range(segcnt):
         mel = np.frombuffer(raw, np.float64, nf * T, pos).reshape(nf, T); pos += 8 * nf * T
         lp = np.frombuffer(raw, np.float64, H * T, pos).reshape(H, T); pos += 8 * H * T
         gab = np.frombuffer(raw, np.float32, 8 * 2 * 2 * 8, pos).reshape(8, 2, 2, 8); pos += 4 * 256
+        kwt = np.frombuffer(raw, np.float32, 8 * 2 * 2 * 8, pos).reshape(8, 2, 2, 8); pos += 4 * 256
+        ref_k, _ = orc.kwta_pool(kw, gab, kw_state)     # exact, incl. the state carried across segments
+        assert np.array_equal(kwt, ref_k), seg
         o = orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig[0], segment=seg)
         ok, msg = W.feature_close(mel, o["mel_seg"], capi.AUD_F32, lin_axis=0)
         assert ok, (seg, msg)
