@@ -94,6 +94,9 @@ def main():
                     help="cfg2: BASELINE configs[1] (the judged line).  Secondary lines for BASELINE.md's table: "
                          "cfg4 = cfg2 + agabor.Convolve (default FilterSet, 4-D [11,32,2,8] pools); "
                          "cfg5 = 44.1 kHz 5 s streams, N=2048, 128 mel (use --batch 128)")
+    ap.add_argument("--kwta", choices=["off", "exact", "tree"], default="off",
+                    help="cfg4 only: add the k-WTA settling of the gabor tensor (SndEnv.ApplyKwta) to every step; "
+                         "exact = the reference's float32 summation order, tree = fixed reduction tree")
     ap.add_argument("--compute", choices=["f32", "f64"], default="f32")
     ap.add_argument("--launch", choices=["graph", "eager"], default="graph",
                     help="graph: the K steps are replayed from hipGraphs of up to 50 captured steps each "
@@ -158,6 +161,17 @@ def main():
     mels = [mel] + [torch.empty_like(mel) for _ in range(n_streams - 1)]
     gouts = [torch.zeros((B, 11, 32, 2, 8), dtype=torch.float32, device=dev) if gab else None for _ in range(n_streams)]
     gout = gouts[0]
+    kw = None
+    if args.kwta != "off":
+        if not gab:
+            raise SystemExit("--kwta needs --workload cfg4 (it settles the gabor tensor)")
+        import ctypes
+        from auditory_amd import kwta as kwta_mod
+        kw = kwta_mod.KWTA()
+        kw.Defaults()
+        kw_ref = ctypes.byref(kw.c)
+        kouts = [torch.empty_like(g) for g in gouts]
+        kw_order = 0 if args.kwta == "exact" else 1
     side = [None] + [torch.cuda.Stream(dev) for _ in range(n_streams - 1)] if n_streams > 1 else [None]
     step_no = [0]
 
@@ -168,6 +182,9 @@ def main():
         else:
             rc = lib.aud_melspec_batch_dev(plan_h, dsig.data_ptr(), capi.AUD_F32, items.data_ptr(), B,
                                            mels[buf].data_ptr(), None, None, st)
+        if rc == 0 and kw is not None:  # fresh pool state per utterance (they are independent sounds)
+            rc = lib.aud_kwta_batch_dev(plan.ctx.handle, kw_ref, gouts[buf].data_ptr(), kouts[buf].data_ptr(), B,
+                                        11, 32, 2, 8, 1, 1, None, kw_order, None, st)
         if rc != 0:
             raise RuntimeError("hot path launch: %d %s" % (rc, lib.aud_last_error(plan.ctx.handle)))
 
@@ -290,6 +307,8 @@ def main():
     alg_bytes = B * (4 * dur + 4 * oc.nf * oc.T)  # each sample read once + each mel value written once
     if gab:  # unfused gabor: re-read the mel tensor, write the pooled on/off pairs
         alg_bytes += B * (4 * oc.nf * oc.T + 4 * 11 * 32 * 2 * 8)
+    if kw is not None:  # read the gabor tensor, write the settled one
+        alg_bytes += B * 2 * 4 * 11 * 32 * 2 * 8
     kern_ms = dev_ms / args.steps
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     line = {
@@ -309,7 +328,7 @@ def main():
                                         "T=504 frames, 128 mel" % B}[args.workload],
                    "batch_per_gpu": B, "win_samples": oc.N, "step_samples": oc.S,
                    "segment_steps": oc.T, "n_mel": oc.nf, "kernel": plan.kernel_name, "launch": launch_mode, "streams": n_streams,
-                   "options": args.option,
+                   "options": args.option, "kwta": args.kwta,
                    "sharding": "utterances, contiguous block per rank"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
