@@ -32,6 +32,7 @@ def main():
             PC.case_prev_smooth(orc, "sndenv_16k_n400_nf32", capi.AUD_F32)
             PC.case_mfcc_tail(orc, "sndenv_16k_n400_nf32", capi.AUD_F32)
             PC.case_gabor_4d_and_2d_vs_oracle(orc, capi.AUD_F32)
+            PC.case_kwta_quick(orc)
         else:
             PC.case_melspec_vs_oracle(orc, by_name[which], capi.AUD_F32)
     print("DRIVE-OK", variant, which)

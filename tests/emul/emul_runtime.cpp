@@ -81,6 +81,18 @@ uint64_t wave_exchange(uint64_t mine, int src_lane) {
     return got;
 }
 
+// every lane of the wave publishes one value; returns the wave's 64 slots for reading; wave_release() ends the
+// read phase (two barriers per publish however many lanes are read)
+const uint64_t* wave_publish(uint64_t mine) {
+    const int tid = int(threadIdx.x);
+    const int w = tid >> 6;
+    g_xchg[tid] = mine;
+    g_wave[w].arrive_and_wait();
+    return &g_xchg[w << 6];
+}
+
+void wave_release() { g_wave[int(threadIdx.x) >> 6].arrive_and_wait(); }
+
 void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body) {
     const int nthr = int(block.x * block.y * block.z);
     if (nthr < 1 || nthr > kMaxThreads || lds_bytes > sizeof(aud::aud_dyn_lds)) {

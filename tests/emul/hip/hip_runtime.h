@@ -65,6 +65,8 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
 void sync_block();
 // exchange one 8-byte payload between the lanes of the calling thread's wave
 uint64_t wave_exchange(uint64_t mine, int src_lane);
+const uint64_t* wave_publish(uint64_t mine);
+void wave_release();
 }  // namespace aud_emul
 
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
@@ -113,14 +115,21 @@ template <typename V>
 inline V __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, V c, int, int, int) {
     const int l = emul_lane();
     const int col = l & 15, rq = l >> 4;
-    float bk[4];
-    for (int k = 0; k < 4; ++k) bk[k] = emul_shfl_any(b, col + 16 * k);
+    uint32_t ab[2];
+    std::memcpy(&ab[0], &a, 4);
+    std::memcpy(&ab[1], &b, 4);
+    uint64_t packed;
+    std::memcpy(&packed, ab, 8);
+    const uint64_t* all = aud_emul::wave_publish(packed);
+    auto a_of = [&](int lane) { float f; std::memcpy(&f, reinterpret_cast<const char*>(&all[lane]), 4); return f; };
+    auto b_of = [&](int lane) { float f; std::memcpy(&f, reinterpret_cast<const char*>(&all[lane]) + 4, 4); return f; };
     for (int r = 0; r < 4; ++r) {
         const int row = 4 * rq + r;
         float acc = c[r];
-        for (int k = 0; k < 4; ++k) acc = std::fma(emul_shfl_any(a, row + 16 * k), bk[k], acc);
+        for (int k = 0; k < 4; ++k) acc = std::fma(a_of(row + 16 * k), b_of(col + 16 * k), acc);
         c[r] = acc;
     }
+    aud_emul::wave_release();
     return c;
 }
 

@@ -258,8 +258,9 @@ def case_kwta_vs_oracle(orc):
     for over in variants:
         k, ko = _kwta_pair(orc, **over)
         for pool in (True, False):
-            act, cyc = kwta.kwta_batch_host(k, raw, pool=pool)
-            for i in range(raw.shape[0]):
+            sub = raw if not over else raw[:2]
+            act, cyc = kwta.kwta_batch_host(k, sub, pool=pool)
+            for i in range(sub.shape[0]):
                 ref, c = (orc.kwta_pool(ko, raw[i]) if pool else orc.kwta_layer(ko, raw[i]))
                 assert np.array_equal(act[i], ref), (over, pool, i, np.abs(act[i] - ref).max())
                 assert cyc[i] == c
@@ -297,6 +298,24 @@ def case_kwta_vs_oracle(orc):
     assert np.array_equal(a, r)
     with pytest.raises(capi.AuditoryError):        # NeighInhib is not built
         k.KWTAPool(raw[0], raw[0].copy(), None, np.ones_like(raw[0]))
+
+
+def case_kwta_quick(orc):
+    """small shapes for the sanitizer builds: both levels, both summation orders, carried state"""
+    from auditory_amd import kwta
+    k, ko = _kwta_pair(orc)
+    for shape in [(3, 5, 2, 4), (17, 19, 1, 3)]:
+        raw = kwta_inputs(7, 2, shape)
+        st = np.zeros((2, shape[0] * shape[1], 2), np.float32)
+        st_o = st.copy()
+        for pool in (True, False):
+            act, cyc = kwta.kwta_batch_host(k, raw, pool=pool, state=st if pool else None)
+            for i in range(2):
+                ref, c = (orc.kwta_pool(ko, raw[i], st_o[i]) if pool else orc.kwta_layer(ko, raw[i]))
+                assert np.array_equal(act[i], ref) and cyc[i] == c
+            tree, _ = kwta.kwta_batch_host(k, raw, pool=pool, sum_order=1)
+            assert np.abs(tree - kwta.kwta_batch_host(k, raw, pool=pool)[0]).max() <= 2e-5
+        assert np.array_equal(st, st_o)
 
 
 def case_kwta_shapes(orc):
