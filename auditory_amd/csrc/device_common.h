@@ -174,6 +174,69 @@ __device__ __forceinline__ TT load_sample(const void* sig, int dtype, int64_t i)
     return TT(static_cast<const int16_t*>(sig)[i]) / TT(0x7FFF);  // sound.go:138
 }
 
+// int16 PCM / 0x7FFF (sound.go:138) in float32 without the full division sequence: q = x * RN(1/32767), one
+// residual step.  Equal to the correctly rounded quotient for every int16 value (Markstein's correction step;
+// tests/test_gpu_parity.py::test_int16_normalisation_exhaustive runs all 65536), i.e. to what load_sample returns.
+__device__ __forceinline__ float pcm16_to_float(int v) {
+    const float x = float(v);
+    constexpr float r = 1.0f / 32767.0f;
+    const float q = x * r;
+    return fmaf(fmaf(-q, 32767.0f, x), r, q);
+}
+
+// First-pass operands of one frame for the register-resident kernels: the frame's N samples as N/2 packed
+// pairs z[n] = (x[2n], x[2n+1]); this lane takes z[lane + STRIDE n1], n1 = 0..NV-1.  Three routes:
+//   * float32 samples, frame inside the stream, pairs 8-byte aligned: one 8-byte load per pair;
+//   * int16 samples under the same conditions (4-byte aligned): one 4-byte load per pair, normalised here
+//     (half the input bytes of the float route);
+//   * anything else (stream edges, left zero pad, float64 samples, odd offsets): guarded element loads.
+template <typename TT, int NV, int STRIDE, int N, bool PCM16_ROUTE = true>
+__device__ __forceinline__ void load_frame_pairs(const MelspecArgs& a, const aud_item& it, int sstep, int lane,
+                                                 C2<TT> (&v)[NV]) {
+    const int T = a.T, S = a.S;
+    const int64_t lim = it.sig_len;
+    const int64_t start = int64_t(it.start0) + int64_t(S) * (sstep - a.border);
+    const int64_t pos0 = start + 2 * lane;
+    const bool frame_on = sstep < T;
+    bool done = false;
+    if constexpr (sizeof(TT) == 4) {
+        // whole frame inside the stream, f32 samples, 8-byte aligned pairs
+        const bool fast = frame_on && start >= 0 && start + N <= lim && a.sig_dtype == AUD_F32 &&
+                          ((it.sig_off + start) & 1) == 0 && (reinterpret_cast<uintptr_t>(a.sig) & 7) == 0;
+        if (fast) {
+            const C2<TT>* __restrict__ src =
+                reinterpret_cast<const C2<TT>*>(static_cast<const float*>(a.sig) + it.sig_off + pos0);
+#pragma unroll
+            for (int n1 = 0; n1 < NV; ++n1) v[n1] = src[STRIDE * n1];
+            done = true;
+        }
+        if constexpr (PCM16_ROUTE) {
+            const bool fast16 = !fast && frame_on && start >= 0 && start + N <= lim && a.sig_dtype == AUD_I16 &&
+                                ((it.sig_off + start) & 1) == 0 && (reinterpret_cast<uintptr_t>(a.sig) & 3) == 0;
+            if (fast16) {
+                const uint32_t* __restrict__ src =
+                    reinterpret_cast<const uint32_t*>(static_cast<const int16_t*>(a.sig) + it.sig_off + pos0);
+#pragma unroll
+                for (int n1 = 0; n1 < NV; ++n1) {
+                    const uint32_t w = src[STRIDE * n1];
+                    v[n1].x = pcm16_to_float(int(int16_t(w & 0xFFFFu)));
+                    v[n1].y = pcm16_to_float(int(int16_t(w >> 16)));
+                }
+                done = true;
+            }
+        }
+    }
+    if (!done) {
+#pragma unroll
+        for (int n1 = 0; n1 < NV; ++n1) {
+            const int64_t p = pos0 + 2 * STRIDE * n1;
+            v[n1].x = (frame_on && p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p) : TT(0);
+            v[n1].y = (frame_on && p + 1 >= 0 && p + 1 < lim)
+                          ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p + 1) : TT(0);
+        }
+    }
+}
+
 __device__ __forceinline__ float dev_log(float v) { return logf(v); }
 __device__ __forceinline__ double dev_log(double v) { return log(v); }
 

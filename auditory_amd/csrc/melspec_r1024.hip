@@ -45,14 +45,13 @@ __global__ __launch_bounds__(256) void k_melspec_r1024(const MelspecArgs a, cons
     const int tid = threadIdx.x;
     const int f = tid >> 6;  // frame within the tile = wave
     const int l = tid & 63;  // lane
-    const int T = a.T, S = a.S;
+    const int T = a.T;
 
     const int tiles = (T + kTile - 1) / kTile;
     const int item = blockIdx.x / tiles;
     const int tile0 = (blockIdx.x - item * tiles) * kTile;
     const aud_item it = a.items[item];
     const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_2048^k
-    const int64_t lim = it.sig_len;
     C2<TT>* fr = xch + f * kFrameC;  // this frame's LDS region
     float* melbuf = reinterpret_cast<float*>(smem + e.out_off);  // [nf][kTile]
 
@@ -64,32 +63,8 @@ __global__ __launch_bounds__(256) void k_melspec_r1024(const MelspecArgs a, cons
 
     // ---- stage 1 operands: z[64 n1 + l] = (x[128 n1 + 2 l], x[128 n1 + 2 l + 1]) ------------------
     C2<TT> v[16];
-    {
-        const int sstep = t0 + f;
-        const int64_t start = int64_t(it.start0) + int64_t(S) * (sstep - a.border);
-        const int64_t pos0 = start + 2 * l;
-        const bool frame_on = sstep < T;
-        bool fast = false;
-        if constexpr (sizeof(TT) == 4) {
-            fast = frame_on && start >= 0 && start + kN <= lim && a.sig_dtype == AUD_F32 &&
-                   ((it.sig_off + start) & 1) == 0 && (reinterpret_cast<uintptr_t>(a.sig) & 7) == 0;
-            if (fast) {
-                const C2<TT>* __restrict__ src = reinterpret_cast<const C2<TT>*>(
-                    static_cast<const float*>(a.sig) + it.sig_off + pos0);
-#pragma unroll
-                for (int n1 = 0; n1 < 16; ++n1) v[n1] = src[64 * n1];
-            }
-        }
-        if (!fast) {
-#pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                const int64_t p = pos0 + 128 * n1;
-                v[n1].x = (frame_on && p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p) : TT(0);
-                v[n1].y = (frame_on && p + 1 >= 0 && p + 1 < lim)
-                              ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p + 1) : TT(0);
-            }
-        }
-    }
+    // (no int16 route here: it pushes this kernel from 162 to 194 VGPRs, i.e. from 3 waves per SIMD to 2)
+    load_frame_pairs<TT, 16, 64, kN, false>(a, it, t0 + f, l, v);
 
     // ---- stage 1: DFT over n1, twiddle W_1024^(l k1) = W_2048^(2 l k1), row k1 column l -----------
     SmallDft<TT, 16>::run(v, nullptr, 0);

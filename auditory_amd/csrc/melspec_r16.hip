@@ -47,37 +47,12 @@ struct Layout {
 };
 
 // pass-1 operands of frame (t0 + f) straight from global memory: z[16 n1 + j] = (x[32 n1 + 2j], x[.. + 1])
-template <typename TT>
+// (the two-tile kernel is built without the int16 route -- it would cost it a fourth wave per SIMD -- and the
+// launcher sends int16 input to the one-tile kernel)
+template <typename TT, bool PCM16_ROUTE>
 __device__ __forceinline__ void r16_load_direct(const MelspecArgs& a, const aud_item& it, int t0, int f, int j,
                                                 C2<TT> (&v)[16]) {
-    const int T = a.T, S = a.S;
-    const int64_t lim = it.sig_len;
-    const int sstep = t0 + f;
-    const int64_t start = int64_t(it.start0) + int64_t(S) * (sstep - a.border);
-    const int64_t pos0 = start + 2 * j;
-    const bool frame_on = sstep < T;
-    bool fast = false;
-    if constexpr (sizeof(TT) == 4) {
-        // whole frame inside the stream, f32 samples, 8-byte aligned pairs
-        fast = frame_on && start >= 0 && start + kN <= lim && a.sig_dtype == AUD_F32 &&
-               ((it.sig_off + start) & 1) == 0 && (reinterpret_cast<uintptr_t>(a.sig) & 7) == 0;
-        if (fast) {
-            const C2<TT>* __restrict__ src = reinterpret_cast<const C2<TT>*>(
-                static_cast<const float*>(a.sig) + it.sig_off + pos0);
-#pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) v[n1] = src[16 * n1];
-        }
-    }
-    if (!fast) {
-        // tile edges (left zero pad, end of stream), other sample types: guarded element loads
-#pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) {
-            const int64_t p = pos0 + 32 * n1;
-            v[n1].x = (frame_on && p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p) : TT(0);
-            v[n1].y = (frame_on && p + 1 >= 0 && p + 1 < lim)
-                          ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p + 1) : TT(0);
-        }
-    }
+    load_frame_pairs<TT, 16, 16, kN, PCM16_ROUTE>(a, it, t0 + f, j, v);
 }
 
 // everything after the pass-1 operands are in registers: both DFT passes, the transpose, the split, the
@@ -193,8 +168,8 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
     C2<TT> v[16];
     C2<TT> v2[NTILE > 1 ? 16 : 1];
     if constexpr (DIRECT) {
-        r16_load_direct<TT>(a, it, t0, f, j, v);
-        if constexpr (NTILE > 1) r16_load_direct<TT>(a, it, t0 + kF, f, j, v2);  // in flight during tile 1
+        r16_load_direct<TT, NTILE == 1>(a, it, t0, f, j, v);
+        if constexpr (NTILE > 1) r16_load_direct<TT, NTILE == 1>(a, it, t0 + kF, f, j, v2);  // in flight during tile 1
     } else {
         // ---- stage the tile's sample span: positions g0 .. g0 + span of the item's stream ------
         const int64_t g0 = int64_t(it.start0) + int64_t(S) * (t0 - a.border);
@@ -298,7 +273,8 @@ hipError_t melspec_r16_prepare(unsigned lds_bytes) {
 }
 
 hipError_t launch_melspec_r16(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st) {
-    const int ntile = (e.direct && e.ntile == 2) ? 2 : 1;
+    // int16 samples: the one-tile kernel has the 4-byte-per-pair route
+    const int ntile = (e.direct && e.ntile == 2 && a.sig_dtype != AUD_I16) ? 2 : 1;
     const int tiles = (a.T + kF * ntile - 1) / (kF * ntile);
     const dim3 grid(unsigned(a.n_items) * unsigned(tiles)), blk(256);
     const unsigned lds = e.lds_bytes;

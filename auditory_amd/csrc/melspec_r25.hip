@@ -43,45 +43,19 @@ __global__ __launch_bounds__(128) void k_melspec_r25(const MelspecArgs a, const 
     const int tid = threadIdx.x;
     const int f = tid >> 3;  // frame within the tile
     const int j = tid & 7;   // lane within the frame's 8-lane group
-    const int T = a.T, S = a.S;
+    const int T = a.T;
 
     const int tiles = (T + kF - 1) / kF;
     const int item = blockIdx.x / tiles;
     const int t0 = (blockIdx.x - item * tiles) * kF;
     const aud_item it = a.items[item];
     const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_400^k
-    const int64_t lim = it.sig_len;
 
     stage_mel_weights<TT, kNT>(e, smem, tid);
 
     // ---- pass A operands: z[8 n1 + j] = (x[16 n1 + 2j], x[16 n1 + 2j + 1]), n1 = 0..24 ---------
     C2<TT> v[25];
-    {
-        const int sstep = t0 + f;
-        const int64_t start = int64_t(it.start0) + int64_t(S) * (sstep - a.border);
-        const int64_t pos0 = start + 2 * j;
-        const bool frame_on = sstep < T;
-        bool fast = false;
-        if constexpr (sizeof(TT) == 4) {
-            fast = frame_on && start >= 0 && start + kN <= lim && a.sig_dtype == AUD_F32 &&
-                   ((it.sig_off + start) & 1) == 0 && (reinterpret_cast<uintptr_t>(a.sig) & 7) == 0;
-            if (fast) {
-                const C2<TT>* __restrict__ src = reinterpret_cast<const C2<TT>*>(
-                    static_cast<const float*>(a.sig) + it.sig_off + pos0);
-#pragma unroll
-                for (int n1 = 0; n1 < 25; ++n1) v[n1] = src[8 * n1];
-            }
-        }
-        if (!fast) {
-#pragma unroll
-            for (int n1 = 0; n1 < 25; ++n1) {
-                const int64_t p = pos0 + 16 * n1;
-                v[n1].x = (frame_on && p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p) : TT(0);
-                v[n1].y = (frame_on && p + 1 >= 0 && p + 1 < lim)
-                              ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p + 1) : TT(0);
-            }
-        }
-    }
+    load_frame_pairs<TT, 25, 8, kN>(a, it, t0 + f, j, v);
 
     // ---- pass A: 25-point DFT over n1, twiddle W_200^(j k1) = W_400^(2 j k1), column write -------
     SmallDft<TT, 25>::run(v, tw, kN);

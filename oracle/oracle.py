@@ -17,6 +17,13 @@ ORC_OK, ORC_EINVAL, ORC_EPANIC, ORC_ESHORT = 0, 1, 2, 3
 
 
 def build(force=False):
+    import fcntl
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:  # parallel test workers build once, not at once
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build(force)
+
+
+def _build(force):
     so = os.path.join(_HERE, "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("auditory_oracle.c", "kwta_oracle.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):

@@ -25,6 +25,13 @@ def lib_path(variant="plain"):
 
 
 def build(variant="plain", force=False):
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:  # parallel test workers build once, not at once
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build(variant, force)
+
+
+def _build(variant, force):
     out = lib_path(variant)
     srcs = product_build.sources() + [os.path.join(HERE, "emul_runtime.cpp")]
     deps = srcs + [os.path.join(HERE, "hip", "hip_runtime.h"),
@@ -40,7 +47,10 @@ def build(variant="plain", force=False):
     for s in srcs:
         cmd += ["-x", "c++", s]
     cmd += ["-ldl"]
+    tmp = out + ".tmp%d" % os.getpid()
+    cmd[cmd.index(out)] = tmp
     subprocess.check_call(cmd)
+    os.replace(tmp, out)  # readers never see a half-written library
     return out
 
 

@@ -131,7 +131,11 @@ def test_device_api_tests_dry_run(monkeypatch, orc):
     monkeypatch.setattr(torch, "empty", lambda *a, **k: real_empty(*a, **{**k, "device": "cpu"}))
     monkeypatch.setattr(torch, "zeros", lambda *a, **k: real_zeros(*a, **{**k, "device": "cpu"}))
     with backend.emulated("plain"):
-        G.test_input_dtypes_agree(orc, torch)
+        G.test_input_dtypes_agree(orc, torch, "cfg2_16k_n512_nf40", 300.0)
+        G.test_int16_normalisation_exhaustive(orc, torch)
+        G.test_input_dtypes_agree(orc, torch, "cfg2_16k_n400_nf40", 200.0)
+        G.test_input_dtypes_agree(orc, torch, "cfg5_44k_n2048_nf128", 80.0)
+        G.test_input_dtypes_agree(orc, torch, "cfg1_44k_n1103_nf32", None)
         G.test_process_batch_mel_plus_gabor(orc, torch)
         G.test_process_then_kwta_device_resident(orc, torch, n=2)
         G.test_full_size_properties_cfg2(orc, torch, B=4)

@@ -96,12 +96,18 @@ def test_recreated_tone_fixtures_f64(orc, torch_cuda):
     PC.case_recreated_tone_fixtures_f64(orc)
 
 
-def test_input_dtypes_agree(orc, torch_cuda):
+@pytest.mark.parametrize("name,seg_ms", [("cfg2_16k_n512_nf40", None), ("cfg2_16k_n400_nf40", None),
+                                         ("cfg5_44k_n2048_nf128", 300.0), ("cfg1_44k_n1103_nf32", None)],
+                         ids=["n512", "n400", "n2048", "n1103"])
+def test_input_dtypes_agree(orc, torch_cuda, name, seg_ms):
+    """float32, float64 and int16 PCM samples (sound.go:116-141 normalisation on the device) through every
+    kernel family; int16 takes the 4-byte-per-pair route when a frame's pairs are aligned and the guarded
+    route when they are not -- the results must not depend on which"""
     torch = torch_cuda
     from auditory_amd.batch import BatchProcessor
-    oc = W.OracleCfg(orc, "cfg2_16k_n512_nf40")
+    oc = W.OracleCfg(orc, name, seg_ms)
     L = oc.full_len()
-    sig, pcm = synth.batch(12, 4, 16000, oc.sr, row_len=L)
+    sig, pcm = synth.batch(12, 4, L - oc.N // 2, oc.sr, row_len=L)
     plan = W.product_plan(oc)
     bp = BatchProcessor(plan, "cuda:0")
     items = bp.upload_items(runtime.make_items(np.arange(4) * L, [L] * 4, [0] * 4))
@@ -109,14 +115,44 @@ def test_input_dtypes_agree(orc, torch_cuda):
     for t in (torch.from_numpy(sig.astype(np.float32)), torch.from_numpy(sig), torch.from_numpy(pcm)):
         outs.append(bp.melspec(t.cuda().contiguous().view(-1), items, 4).cpu().numpy())
     torch.cuda.synchronize()
-    plan.close()
-    assert np.array_equal(outs[0], outs[2])            # i16/0x7FFF in f32 == f32(round(f64 value))
+    assert np.array_equal(outs[0], outs[2], equal_nan=True)   # i16/0x7FFF in f32 == f32(round(f64 value))
     ok, msg = W.close_enough(outs[1], outs[0], 2e-6)
     assert ok, msg
     ref, _, _ = PC.oracle_items(orc, oc, sig, [(r, 0) for r in range(4)])
     ok, msg = W.feature_close(outs[0], ref, capi.AUD_F32, lin_axis=1)
     assert ok, msg
     assert not (ref[:, :, -1] == 0).all()              # zero tail keeps every frame in bounds
+    # the same streams at an odd row pitch: rows 1 and 3 start at odd sample offsets (unaligned pairs)
+    Lo = L + 1 if L % 2 == 0 else L + 2
+    for arr in (pcm, sig.astype(np.float32)):
+        wide = np.zeros((4, Lo), arr.dtype)
+        wide[:, :L] = arr
+        items_o = bp.upload_items(runtime.make_items(np.arange(4) * Lo, [L] * 4, [0] * 4))
+        got = bp.melspec(torch.from_numpy(wide).cuda().contiguous().view(-1), items_o, 4).cpu().numpy()
+        assert np.array_equal(got, outs[0], equal_nan=True)
+    plan.close()
+
+
+def test_int16_normalisation_exhaustive(orc, torch_cuda):
+    """every int16 value once: the 4-byte-per-pair int16 route (x * RN(1/32767) + one residual step) must give
+    what the correctly rounded float32 division gives -- numpy's float32 quotient fed in as float samples"""
+    torch = torch_cuda
+    from auditory_amd.batch import BatchProcessor
+    oc = W.OracleCfg(orc, "cfg2_16k_n512_nf40")
+    pcm = np.arange(-32768, 32768, dtype=np.int64)
+    pcm = np.concatenate([pcm[::2], pcm[1::2][::-1], np.zeros(oc.N, np.int64)]).astype(np.int16)  # not a ramp
+    f32 = pcm.astype(np.float32) / np.float32(32767.0)
+    n_seg = (65536 + oc.sp.stride_samples - 1) // oc.sp.stride_samples
+    plan = W.product_plan(oc)
+    bp = BatchProcessor(plan, "cuda:0")
+    items = bp.upload_items(runtime.make_items([0] * n_seg, [len(pcm)] * n_seg,
+                                               [s * oc.sp.stride_samples for s in range(n_seg)]))
+    power = [torch.empty((n_seg, oc.H, oc.T), dtype=torch.float32, device="cuda:0") for _ in range(2)]
+    a = bp.melspec(torch.from_numpy(pcm).cuda(), items, n_seg, power=power[0]).cpu().numpy()
+    b = bp.melspec(torch.from_numpy(f32).cuda(), items, n_seg, power=power[1]).cpu().numpy()
+    torch.cuda.synchronize()
+    assert np.array_equal(a, b) and np.array_equal(power[0].cpu().numpy(), power[1].cpu().numpy())
+    plan.close()
 
 
 def test_process_batch_mel_plus_gabor(orc, torch_cuda):
