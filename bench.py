@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--kwta", choices=["off", "exact", "tree"], default="off",
                     help="cfg4 only: add the k-WTA settling of the gabor tensor (SndEnv.ApplyKwta) to every step; "
                          "exact = the reference's float32 summation order, tree = fixed reduction tree")
+    ap.add_argument("--sig-dtype", choices=["f32", "i16"], default="f32",
+                    help="resident sample format: float32 (the metric's definition) or int16 PCM normalised on the "
+                         "device (sound.go:116-141; half the input bytes)")
     ap.add_argument("--compute", choices=["f32", "f64"], default="f32")
     ap.add_argument("--launch", choices=["graph", "eager"], default="graph",
                     help="graph: the K steps are replayed from hipGraphs of up to 50 captured steps each "
@@ -143,7 +146,7 @@ def main():
     B, sr = args.batch, oc.sr
     dur = 5 * sr if args.workload == "cfg5" else 16000        # samples of real audio per stream
     L = (oc.full_len() + 63) // 64 * 64          # zero tail so every frame is in bounds, 64-sample pitch
-    sig64, _ = synth.batch(2, B, dur, sr, row_len=L, first_idx=rank * B)
+    sig64, pcm16 = synth.batch(2, B, dur, sr, row_len=L, first_idx=rank * B)
     cdt = capi.AUD_F32 if args.compute == "f32" else capi.AUD_F64
     gab = dict(size=(9, 9), stride=(3, 3), gain=2.0, specs=W.DEFAULT_GABOR_SPECS) if args.workload == "cfg4" else None
     plan = W.product_plan(oc, cdt, gab, device=local_rank)
@@ -151,7 +154,10 @@ def main():
         k, v = kv.split("=")
         plan.set_option(k, int(v))
     bp = BatchProcessor(plan, dev)
-    dsig = torch.from_numpy(sig64.astype(np.float32)).to(dev).view(-1)
+    if args.sig_dtype == "i16":
+        dsig, sig_code, sample_bytes = torch.from_numpy(pcm16).to(dev).view(-1), capi.AUD_I16, 2
+    else:
+        dsig, sig_code, sample_bytes = torch.from_numpy(sig64.astype(np.float32)).to(dev).view(-1), capi.AUD_F32, 4
     items = bp.upload_items(runtime.make_items(np.arange(B) * L, [L] * B, [0] * B))
     mel = torch.empty((B, oc.nf, oc.T), dtype=torch.float32, device=dev)
 
@@ -177,10 +183,10 @@ def main():
 
     def launch(buf, st):
         if gab:
-            rc = lib.aud_process_batch_dev(plan_h, dsig.data_ptr(), capi.AUD_F32, items.data_ptr(), B,
+            rc = lib.aud_process_batch_dev(plan_h, dsig.data_ptr(), sig_code, items.data_ptr(), B,
                                            mels[buf].data_ptr(), 11, 32, gouts[buf].data_ptr(), st)
         else:
-            rc = lib.aud_melspec_batch_dev(plan_h, dsig.data_ptr(), capi.AUD_F32, items.data_ptr(), B,
+            rc = lib.aud_melspec_batch_dev(plan_h, dsig.data_ptr(), sig_code, items.data_ptr(), B,
                                            mels[buf].data_ptr(), None, None, st)
         if rc == 0 and kw is not None:  # fresh pool state per utterance (they are independent sounds)
             rc = lib.aud_kwta_batch_dev(plan.ctx.handle, kw_ref, gouts[buf].data_ptr(), kouts[buf].data_ptr(), B,
@@ -304,7 +310,7 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
     audio_s_per_step = B * world * (dur / float(sr))
-    alg_bytes = B * (4 * dur + 4 * oc.nf * oc.T)  # each sample read once + each mel value written once
+    alg_bytes = B * (sample_bytes * dur + 4 * oc.nf * oc.T)  # each sample read once + each mel value written once
     if gab:  # unfused gabor: re-read the mel tensor, write the pooled on/off pairs
         alg_bytes += B * (4 * oc.nf * oc.T + 4 * 11 * 32 * 2 * 8)
     if kw is not None:  # read the gabor tensor, write the settled one
@@ -328,7 +334,7 @@ def main():
                                         "T=504 frames, 128 mel" % B}[args.workload],
                    "batch_per_gpu": B, "win_samples": oc.N, "step_samples": oc.S,
                    "segment_steps": oc.T, "n_mel": oc.nf, "kernel": plan.kernel_name, "launch": launch_mode, "streams": n_streams,
-                   "options": args.option, "kwta": args.kwta,
+                   "options": args.option, "kwta": args.kwta, "sig_dtype": args.sig_dtype,
                    "sharding": "utterances, contiguous block per rank"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,

@@ -81,7 +81,7 @@ class _SideStream(_Stream):
         pass
 
 
-@pytest.mark.parametrize("extra", [[], ["--streams", "2"], ["--win-ms", "25"], ["--workload", "cfg4"], ["--workload", "cfg4", "--kwta", "exact"],
+@pytest.mark.parametrize("extra", [[], ["--streams", "2"], ["--win-ms", "25"], ["--workload", "cfg4"], ["--workload", "cfg4", "--kwta", "exact"], ["--sig-dtype", "i16"],
                                    ["--compute", "f64", "--launch", "eager"]])
 def test_bench_dry_run(monkeypatch, capsys, extra):
     import backend

@@ -22,6 +22,7 @@ step pytest_gpu 600 python -m pytest tests -q -m gpu &&
 step bench 300 python bench.py &&
 { grep '^{' "gpurun_out/${TAG}_bench.log" | tail -1 > "gpurun_out/${TAG}_bench.json"; true; } &&
 step bench_n400 200 python bench.py --win-ms 25 --no-cpu-baseline &&
+step bench_i16 200 python bench.py --sig-dtype i16 --no-cpu-baseline &&
 step bench_cfg4_kwta 200 python bench.py --workload cfg4 --kwta exact --steps 200 --no-cpu-baseline &&
 step bench_cfg4_kwta_tree 200 python bench.py --workload cfg4 --kwta tree --steps 200 --no-cpu-baseline &&
 step ab_n512 200 python tools/ab_bench.py &&
