@@ -57,7 +57,7 @@ __device__ __forceinline__ void r16_load_direct(const MelspecArgs& a, const aud_
 
 // everything after the pass-1 operands are in registers: both DFT passes, the transpose, the split, the
 // power spectrum and the tile epilogue, for the 16 frames t0 .. t0 + 15
-template <typename TT, bool DIRECT>
+template <typename TT, bool DIRECT, bool MELMFMA>
 __device__ __forceinline__ void r16_tile(const MelspecArgs& a, const FastArgs& e, unsigned char* smem, C2<TT>* xch,
                                          TT* Pbase, const C2<TT>* __restrict__ tw, const aud_item& it, int item,
                                          int t0, int tid, int f, int j, C2<TT> (&v)[16]) {
@@ -133,20 +133,19 @@ __device__ __forceinline__ void r16_tile(const MelspecArgs& a, const FastArgs& e
     }
     __syncthreads();
 
-    if constexpr (sizeof(TT) == 4) {
-        if (e.mel_mfma) {  // uniform per launch
-            tile_spectrum_outputs<TT, 256, kF>(a, Pbase, kHp, it, item, t0, tid);
-            tile_mel_mfma<256, kF>(a, e, Pbase, kHp, it, item, t0, tid);
-            return;
-        }
+    if constexpr (MELMFMA) {  // own instantiations: the accumulator AGPRs would cost the others a wave per SIMD
+        static_assert(sizeof(TT) == 4, "float32 variant");
+        tile_spectrum_outputs<TT, 256, kF>(a, Pbase, kHp, it, item, t0, tid);
+        tile_mel_mfma<256, kF>(a, e, Pbase, kHp, it, item, t0, tid);
+    } else {
+        tile_epilogue<TT, 256, kF>(a, e, Pbase, kHp, smem, it, item, t0, tid);
     }
-    tile_epilogue<TT, 256, kF>(a, e, Pbase, kHp, smem, it, item, t0, tid);
 }
 
 // NTILE tiles of 16 frames per workgroup.  With NTILE = 2 (DIRECT only) the operands of the second tile are
 // requested before the first tile is computed, so their memory latency hides behind a whole tile of work,
 // and the grid shrinks to one residency round at the bench size.
-template <typename TT, bool DIRECT, int NTILE>
+template <typename TT, bool DIRECT, int NTILE, bool MELMFMA>
 __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const FastArgs e) {
     unsigned char* smem = dyn_lds();
     TT* sigbuf = reinterpret_cast<TT*>(smem);                   // STAGED only: [span]
@@ -210,11 +209,11 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) v[n1] = fr[16 * n1];
     }
-    r16_tile<TT, DIRECT>(a, e, smem, xch, Pbase, tw, it, item, t0, tid, f, j, v);
+    r16_tile<TT, DIRECT, MELMFMA>(a, e, smem, xch, Pbase, tw, it, item, t0, tid, f, j, v);
     if constexpr (NTILE > 1) {
         if (t0 + kF < T) {          // uniform: the item has a second tile for this workgroup
             __syncthreads();        // the power spectrum of tile 1 is consumed: the buffers are free again
-            r16_tile<TT, DIRECT>(a, e, smem, xch, Pbase, tw, it, item, t0 + kF, tid, f, j, v2);
+            r16_tile<TT, DIRECT, MELMFMA>(a, e, smem, xch, Pbase, tw, it, item, t0 + kF, tid, f, j, v2);
         }
     }
 }
@@ -259,12 +258,15 @@ bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, bool d
 
 hipError_t melspec_r16_prepare(unsigned lds_bytes) {
     // more than 64 KiB of dynamic LDS has to be requested explicitly
-    const void* fns[6] = {reinterpret_cast<const void*>(&k_melspec_r16<double, true, 1>),
-                          reinterpret_cast<const void*>(&k_melspec_r16<double, true, 2>),
-                          reinterpret_cast<const void*>(&k_melspec_r16<double, false, 1>),
-                          reinterpret_cast<const void*>(&k_melspec_r16<float, true, 1>),
-                          reinterpret_cast<const void*>(&k_melspec_r16<float, true, 2>),
-                          reinterpret_cast<const void*>(&k_melspec_r16<float, false, 1>)};
+    const void* fns[] = {reinterpret_cast<const void*>(&k_melspec_r16<double, true, 1, false>),
+                         reinterpret_cast<const void*>(&k_melspec_r16<double, true, 2, false>),
+                         reinterpret_cast<const void*>(&k_melspec_r16<double, false, 1, false>),
+                         reinterpret_cast<const void*>(&k_melspec_r16<float, true, 1, false>),
+                         reinterpret_cast<const void*>(&k_melspec_r16<float, true, 2, false>),
+                         reinterpret_cast<const void*>(&k_melspec_r16<float, false, 1, false>),
+                         reinterpret_cast<const void*>(&k_melspec_r16<float, true, 1, true>),
+                         reinterpret_cast<const void*>(&k_melspec_r16<float, true, 2, true>),
+                         reinterpret_cast<const void*>(&k_melspec_r16<float, false, 1, true>)};
     for (const void* fn : fns) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
         if (e != hipSuccess) return e;
@@ -278,21 +280,22 @@ hipError_t launch_melspec_r16(const MelspecArgs& a, const FastArgs& e, int compu
     const int tiles = (a.T + kF * ntile - 1) / (kF * ntile);
     const dim3 grid(unsigned(a.n_items) * unsigned(tiles)), blk(256);
     const unsigned lds = e.lds_bytes;
-    if (compute_dtype == AUD_F64) {
-        if (e.direct && ntile == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<double, true, 2>), grid, blk, lds, st, a, e);
-        else if (e.direct)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<double, true, 1>), grid, blk, lds, st, a, e);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<double, false, 1>), grid, blk, lds, st, a, e);
-    } else {
-        if (e.direct && ntile == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<float, true, 2>), grid, blk, lds, st, a, e);
-        else if (e.direct)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<float, true, 1>), grid, blk, lds, st, a, e);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<float, false, 1>), grid, blk, lds, st, a, e);
-    }
+#define AUD_R16_LAUNCH(TT, MF)                                                                                  \
+    do {                                                                                                        \
+        if (e.direct && ntile == 2)                                                                             \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<TT, true, 2, MF>), grid, blk, lds, st, a, e);      \
+        else if (e.direct)                                                                                      \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<TT, true, 1, MF>), grid, blk, lds, st, a, e);      \
+        else                                                                                                    \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_r16<TT, false, 1, MF>), grid, blk, lds, st, a, e);     \
+    } while (0)
+    if (compute_dtype == AUD_F64)
+        AUD_R16_LAUNCH(double, false);
+    else if (e.mel_mfma)
+        AUD_R16_LAUNCH(float, true);
+    else
+        AUD_R16_LAUNCH(float, false);
+#undef AUD_R16_LAUNCH
     return hipGetLastError();
 }
 

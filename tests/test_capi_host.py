@@ -179,10 +179,12 @@ def test_kernels_use_no_scratch_and_fit_their_occupancy():
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not installed")
     from auditory_amd import build as B
-    budget = {"k_melspec_r16IfLb1ELi1": 128, "k_melspec_r16IfLb1ELi2": 128, "k_melspec_r16IfLb0ELi1": 168,
-              "k_melspec_r25If": 168, "k_melspec_r1024If": 168, "k_melspec_genericIf": 256}
+    # waves per SIMD each float32 kernel's launch geometry assumes (LDS allows no more than this anyway)
+    need_occupancy = {"k_melspec_r16IfLb1ELi1": 4, "k_melspec_r16IfLb1ELi2": 4, "k_melspec_r16IfLb0ELi1": 3,
+                      "k_melspec_r25If": 3, "k_melspec_r1024If": 3, "k_melspec_genericIf": 2}
     seen = {}
-    for src in ("melspec_r16.hip", "melspec_r25.hip", "melspec_r1024.hip", "melspec_generic.hip"):
+    for src in ("melspec_r16.hip", "melspec_r25.hip", "melspec_r1024.hip", "melspec_generic.hip", "gabor.hip",
+                "kwta.hip"):
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17",
                             "-I" + B.INCLUDE, "-I" + B.CSRC, "-c", os.path.join(B.CSRC, src), "-o", "/dev/null",
                             "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd="/tmp")
@@ -192,18 +194,22 @@ def test_kernels_use_no_scratch_and_fit_their_occupancy():
             m = re.search(r"Function Name: (\S+)", line)
             if m:
                 name = m.group(1)
-            m = re.search(r"VGPRs: (\d+)", line)
-            if m and name:
-                seen.setdefault(name, {})["vgpr"] = int(m.group(1))
-            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
-            if m and name:
-                seen.setdefault(name, {})["scratch"] = int(m.group(1))
-    assert len(seen) >= 12
+            for key, pat in (("vgpr", r" VGPRs: (\d+)"), ("agpr", r" AGPRs: (\d+)"),
+                             ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                             ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)")):
+                m = re.search(pat, line)
+                if m and name:
+                    seen.setdefault(name, {})[key] = int(m.group(1))
+    assert len(seen) >= 20
     for name, res in seen.items():
         assert res["scratch"] == 0, (name, res)
-        for key, lim in budget.items():
+        # (the register file is unified on gfx950, so hipcc's occupancy counts accumulation registers too: an
+        # unused MFMA code path inside a kernel once took a wave per SIMD from it this way)
+        for key, need in need_occupancy.items():
             if key in name:
-                assert res["vgpr"] <= lim, (name, res, lim)
+                assert res["occupancy"] >= need, (name, res, need)
+        if "k_melspec_r16" in name and "ELb1EEEv" not in name:
+            assert res["agpr"] == 0, (name, res)   # only the matrix-pipe mel instantiations use AGPRs
 
 
 def test_header_is_plain_c(tmp_path):
