@@ -29,7 +29,8 @@ def pytest_cmdline_main(config):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    if not hasattr(config, "workerinput"):
+    cpu_tier = (getattr(config.option, "markexpr", "") or "").strip() == "not gpu"
+    if cpu_tier and not hasattr(config, "workerinput"):
         # controller (or a plain single-process run): build the checkers once, before any worker needs them
         # (the builders also take a file lock, so a worker that gets there first is safe too)
         try:

@@ -213,6 +213,38 @@ def case_sndenv_mirror_reads_like_the_reference(orc):
         assert ok, "gabor " + msg
 
 
+def case_sndenv_mirror_2d_gabor_kwta_layer(orc):
+    """the gaborview flavour (examples/gaborview/gbv.go:799-846): 2-D gabor output [2 nFy, nFx nG] and
+    layer-level k-WTA; KwtaPool on a 2-D tensor is an error here where the reference panics"""
+    from auditory_amd import agabor, sound
+    sig, _ = synth.batch(15, 1, 4800, 16000)
+    se = sound.SndEnv()
+    se.Defaults()
+    se.SampleRate, se.Signal = 16000, sig[0]
+    se.Params.SegmentMs = se.Params.StrideMs = 300.0
+    se.GaborSpecs = [agabor.Filter(WaveLen=2.0, Orientation=o, SigmaWidth=0.5, SigmaLength=0.5,
+                                   PhaseOffset=0, CircleEdge=True) for o in (0, 45, 90, 135)]
+    gf = se.GaborFilters
+    gf.SizeX = gf.SizeY = 8
+    gf.StrideX, gf.StrideY, gf.Gain = 6, 3, 1.5
+    T, nf = 34, 32
+    nfy, nfx = (nf - 8) // 3 + 1, (T - 8) // 6 + 1
+    se.GborOutUnitsY, se.GborOutUnitsX = 2 * nfy, nfx * 4
+    se.ByTime = True
+    assert se.Init() is None and se.Params.SegmentSteps == T
+    se.ProcessSegment(0, 0)
+    with pytest.raises(capi.AuditoryError):
+        se.ApplyGabor()                        # Defaults() left KwtaPool on
+    se.KwtaPool = False
+    tsr = se.ApplyGabor()
+    assert tsr is se.GborKwta and tsr.shape == (2 * nfy, nfx * 4)
+    assert np.abs(se.GborOutput).max() > 0
+    ref, _ = orc.kwta_layer(orc.kwta_defaults(), se.GborOutput)
+    assert np.array_equal(tsr, ref)
+    se.Kwta.On = False
+    assert se.ApplyGabor() is se.GborOutput    # sndenv.go:495
+
+
 # ---- k-WTA stage -------------------------------------------------------------------------------
 
 def _kwta_pair(orc, **over):

@@ -130,3 +130,7 @@ def test_emul_kwta_vs_oracle(orc, emu):
 
 def test_emul_kwta_shapes(orc, emu):
     PC.case_kwta_shapes(orc)
+
+
+def test_emul_sndenv_mirror_2d_gabor_kwta_layer(orc, emu):
+    PC.case_sndenv_mirror_2d_gabor_kwta_layer(orc)
