@@ -38,6 +38,7 @@ struct aud_plan {
     enum Fast { kNoFast = 0, kR16 = 1, kR25 = 2, kR1024 = 3 };
     int fast_kind = kNoFast;   // which family the tables below were built for
     bool use_fast = false;     // false: generic kernel (no fast family, or forced by an option)
+    int xcd_remap = 1;         // workgroup -> tile order keeps an XCD on one run of tiles (kernels.h)
     int r16_chunks = 0;
     aud::FastArgs r16{};
     int* d_grp = nullptr;  // [17 + nf + 3 nf]: group offsets, filter ids, per-filter chunk info
@@ -153,6 +154,7 @@ void fill_melspec_args(const aud_plan* p, aud::MelspecArgs* a) {
     a->dft_log_min = d.dft.log_min;
     a->dft_log_off = d.dft.log_offset;
     a->F = p->F_generic;
+    a->xcd_remap = p->xcd_remap;
 }
 
 // the plan's frame -> power -> mel kernel (whatever family it selected), raw power, no smoothing
@@ -472,6 +474,11 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
         if (value != 1 && value != 2) return fail(c, AUD_EINVAL, "r16_tiles: 1 or 2");
         if (value == 2 && !p->r16.direct) return fail(c, AUD_EINVAL, "r16_tiles = 2 needs the direct input variant");
         p->r16.ntile = value;
+        return AUD_OK;
+    }
+    if (key == "xcd_remap") {  // 1 (default): every XCD walks a contiguous run of tiles; 0: tiles in workgroup-id order
+        if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "xcd_remap: 0 or 1");
+        p->xcd_remap = value;
         return AUD_OK;
     }
     if (key == "r16_mel") {  // 0 = chunked reduction on the vector pipe, 1 = banded filter x bin GEMM on the matrix pipe

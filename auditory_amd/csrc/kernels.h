@@ -16,6 +16,17 @@ __device__ __forceinline__ unsigned char* dyn_lds() {
     return aud_dyn_lds;
 }
 
+// Workgroup -> tile order.  The hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its
+// own L2), while consecutive tiles of a stream share N - S samples of input.  With the remap the workgroups that
+// share an XCD (equal id mod 8) walk one contiguous run of tiles, so the overlap is an L2 hit instead of a second
+// fetch through the fabric.  A bijection for any grid size (the first n % 8 runs are one tile longer); results do
+// not depend on it.  It pays once the batch no longer fits the 256 MB Infinity Cache (BASELINE config 5: 1.1 GB).
+__device__ __forceinline__ unsigned tile_of_workgroup(unsigned b, unsigned n, int remap) {
+    if (!remap || n < 16) return b;
+    const unsigned x = b & 7u, i = b >> 3, per = n >> 3, rem = n & 7u;
+    return x * per + (x < rem ? x : rem) + i;
+}
+
 // Arguments of every frame->mel kernel family.  Doubles are converted to the compute
 // type inside the kernel; `tw` and `filt` are already stored in the compute type.
 struct MelspecArgs {
@@ -41,6 +52,7 @@ struct MelspecArgs {
     float* power;      // [n_items, H, T] or null
     float* log_power;  // [n_items, H, T] or null
     int F;             // frames per workgroup
+    int xcd_remap;     // 1: tile_of_workgroup() order (plan option "xcd_remap", default on)
 };
 
 struct GaborArgs {

@@ -49,8 +49,9 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
     const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);
 
     const int tiles = (T + F - 1) / F;
-    const int item = blockIdx.x / tiles;
-    const int t0 = (blockIdx.x - item * tiles) * F;
+    const int wg = int(tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap));
+    const int item = wg / tiles;
+    const int t0 = (wg - item * tiles) * F;
     const aud_item it = a.items[item];
     const bool even = (a.ratio == 2);
 

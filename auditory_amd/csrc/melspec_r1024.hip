@@ -48,8 +48,9 @@ __global__ __launch_bounds__(256) void k_melspec_r1024(const MelspecArgs a, cons
     const int T = a.T;
 
     const int tiles = (T + kTile - 1) / kTile;
-    const int item = blockIdx.x / tiles;
-    const int tile0 = (blockIdx.x - item * tiles) * kTile;
+    const int wg = int(tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap));
+    const int item = wg / tiles;
+    const int tile0 = (wg - item * tiles) * kTile;
     const aud_item it = a.items[item];
     const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_2048^k
     C2<TT>* fr = xch + f * kFrameC;  // this frame's LDS region

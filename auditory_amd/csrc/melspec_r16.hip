@@ -157,8 +157,9 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
     const int T = a.T, S = a.S;
 
     const int tiles = (T + kF * NTILE - 1) / (kF * NTILE);
-    const int item = blockIdx.x / tiles;
-    const int t0 = (blockIdx.x - item * tiles) * kF * NTILE;
+    const int wg = int(tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap));
+    const int item = wg / tiles;
+    const int t0 = (wg - item * tiles) * kF * NTILE;
     const aud_item it = a.items[item];
     const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_512^k
     const int64_t lim = it.sig_len;

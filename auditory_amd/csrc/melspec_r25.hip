@@ -46,8 +46,9 @@ __global__ __launch_bounds__(128) void k_melspec_r25(const MelspecArgs a, const 
     const int T = a.T;
 
     const int tiles = (T + kF - 1) / kF;
-    const int item = blockIdx.x / tiles;
-    const int t0 = (blockIdx.x - item * tiles) * kF;
+    const int wg = int(tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap));
+    const int item = wg / tiles;
+    const int t0 = (wg - item * tiles) * kF;
     const aud_item it = a.items[item];
     const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_400^k
 

@@ -200,6 +200,8 @@ int aud_plan_destroy(aud_plan* plan);
 const char* aud_plan_kernel_name(const aud_plan* plan);
 /* Tuning / diagnostic switches; results are identical whatever they are set to.
  *   "kernel"    0 automatic (default), 1 force the generic any-N kernel
+ *   "xcd_remap" 1 (default) workgroups that share an XCD take one contiguous run of tiles (L2 reuse of the
+ *               samples neighbouring tiles share), 0 tiles in workgroup-id order
  *   "r16_input" 0 operands straight from global memory (default), 1 staged through LDS
  *   "r16_tiles" 1 (default) or 2 sixteen-frame tiles per workgroup, the second one's operands prefetched
  *   "r16_mel"   0 mel triangles on the vector pipe (default), 1 as a banded filter x bin GEMM on the matrix

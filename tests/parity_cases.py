@@ -78,6 +78,42 @@ def case_melspec_vs_oracle(orc, case, cdt, seg_ms=None, options=None):
         assert np.isnan(mel[:, 0, :3]).all()
 
 
+def case_workgroup_order(orc, cdt):
+    """the XCD-contiguous workgroup -> tile order (option "xcd_remap") is a bijection for grid sizes that are
+    not multiples of 8 and changes nothing in the results: every kernel family, remap on == off, bit for bit"""
+    for name, seg_ms, dur, rows, seg_list, opts in [
+            ("cfg2_16k_n512_nf40", 200.0, 0.25, 9, [0], {}),                  # r16x16: 18 workgroups (18 % 8 = 2)
+            ("cfg2_16k_n512_nf40", 520.0, 0.55, 9, [0], {"r16_tiles": 2}),    # two-tile kernel: 18 workgroups
+            ("sndenv_16k_n400_nf32", None, 0.75, 3, list(range(7)), {}),      # r25x8: 21 one-tile items
+            ("cfg1_44k_n1103_nf32", None, 0.3, 3, [0, 1], {}),                # generic, prime N
+            ("cfg5_44k_n2048_nf128", 120.0, 0.5, 5, [0, 1, 2, 3], {})]:       # r16x16x4: 20 items
+        oc = W.OracleCfg(orc, name, seg_ms)
+        L = int(dur * oc.sr)
+        sig, _ = synth.batch(19, rows, L, oc.sr)
+        segs = [(r, s) for r in range(rows) for s in seg_list]
+        items = make_items(oc, L, segs)
+        outs = []
+        for remap in (1, 0):
+            plan = W.product_plan(oc, cdt)
+            try:
+                for k, v in opts.items():
+                    if not (k.startswith("r16_") and plan.kernel_name != "r16x16"):
+                        plan.set_option(k, v)
+                plan.set_option("xcd_remap", remap)
+                outs.append(plan.melspec_host(sig.ravel(), items, True, False))
+            finally:
+                plan.close()
+        assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True), name
+        assert np.array_equal(outs[0][1], outs[1][1], equal_nan=True), name
+        ref_mel, _, _ = oracle_items(orc, oc, sig, segs[:6])
+        ok, msg = W.feature_close(outs[0][0][:6], ref_mel, cdt, lin_axis=1)
+        assert ok, (name, msg)
+    plan = W.product_plan(W.OracleCfg(orc, "sndenv_16k_n400_nf32"), cdt)
+    with pytest.raises(capi.AuditoryError):
+        plan.set_option("xcd_remap", 2)
+    plan.close()
+
+
 def case_zero_signal_and_empty_batch(orc):
     oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
     plan = W.product_plan(oc)

@@ -134,3 +134,7 @@ def test_emul_kwta_shapes(orc, emu):
 
 def test_emul_sndenv_mirror_2d_gabor_kwta_layer(orc, emu):
     PC.case_sndenv_mirror_2d_gabor_kwta_layer(orc)
+
+
+def test_emul_workgroup_order(orc, emu):
+    PC.case_workgroup_order(orc, capi.AUD_F32)

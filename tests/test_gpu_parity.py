@@ -50,6 +50,11 @@ def test_n512_odd_step(orc, torch_cuda, cdt):
     PC.case_n512_odd_step_and_sample_types(orc, cdt)
 
 
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_workgroup_order(orc, torch_cuda, cdt):
+    PC.case_workgroup_order(orc, cdt)
+
+
 def test_zero_signal_and_empty_batch(orc, torch_cuda):
     PC.case_zero_signal_and_empty_batch(orc)
 
