@@ -78,7 +78,7 @@ def case_melspec_vs_oracle(orc, case, cdt, seg_ms=None, options=None):
         assert np.isnan(mel[:, 0, :3]).all()
 
 
-def case_workgroup_order(orc, cdt):
+def case_workgroup_order(orc, cdt, with_n2048=True):
     """the XCD-contiguous workgroup -> tile order (option "xcd_remap") is a bijection for grid sizes that are
     not multiples of 8 and changes nothing in the results: every kernel family, remap on == off, bit for bit"""
     for name, seg_ms, dur, rows, seg_list, opts in [
@@ -86,7 +86,7 @@ def case_workgroup_order(orc, cdt):
             ("cfg2_16k_n512_nf40", 520.0, 0.55, 9, [0], {"r16_tiles": 2}),    # two-tile kernel: 18 workgroups
             ("sndenv_16k_n400_nf32", None, 0.75, 3, list(range(7)), {}),      # r25x8: 21 one-tile items
             ("cfg1_44k_n1103_nf32", None, 0.3, 3, [0, 1], {}),                # generic, prime N
-            ("cfg5_44k_n2048_nf128", 120.0, 0.5, 5, [0, 1, 2, 3], {})]:       # r16x16x4: 20 items
+            ("cfg5_44k_n2048_nf128", 120.0, 0.5, 5, [0, 1, 2, 3], {})][:5 if with_n2048 else 4]:  # r16x16x4: 20 items
         oc = W.OracleCfg(orc, name, seg_ms)
         L = int(dur * oc.sr)
         sig, _ = synth.batch(19, rows, L, oc.sr)
