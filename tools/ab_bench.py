@@ -47,9 +47,9 @@ def main():
     sig = np.tile(sig64.astype(np.float32), (reps, 1))[:B]
     dsig = torch.from_numpy(sig).to(dev).view(-1)
     cdt = capi.AUD_F32 if args.compute == "f32" else capi.AUD_F64
-    variants = {"auto": {}, "generic": {"kernel": 1}}
+    variants = {"auto": {}, "auto, tiles in workgroup-id order": {"xcd_remap": 0}, "generic": {"kernel": 1}}
     if args.win_ms == 32.0:
-        variants = {"r16 direct": {"r16_input": 0}, "r16 direct x2": {"r16_input": 0, "r16_tiles": 2},
+        variants = {"r16 direct": {"r16_input": 0}, "r16 direct, no xcd remap": {"r16_input": 0, "xcd_remap": 0}, "r16 direct x2": {"r16_input": 0, "r16_tiles": 2},
                     "r16 staged": {"r16_input": 1}, "r16 direct mfma-mel": {"r16_input": 0, "r16_mel": 1},
                     "r16 direct x2 mfma-mel": {"r16_input": 0, "r16_tiles": 2, "r16_mel": 1}, "generic": {"kernel": 1}}
     plans = {}
