@@ -109,6 +109,26 @@ def test_bench_dry_run(monkeypatch, capsys, extra):
     assert line["value"] > 0 and line["roofline"]["achieved"] >= 0
 
 
+@pytest.mark.parametrize("extra", [[], ["--win-ms", "25"]])
+def test_ab_bench_dry_run(monkeypatch, capsys, extra):
+    """tools/ab_bench.py (the interleaved A/B of kernel variants run at first GPU contact) end to end on the CPU"""
+    import importlib.util
+    import backend
+    _patch(monkeypatch)
+    monkeypatch.setattr(torch.Tensor, "to", lambda self, *a, **k: self)
+    real_empty = torch.empty
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: real_empty(*a, **{**k, "device": "cpu"}))
+    spec = importlib.util.spec_from_file_location("ab_bench", os.path.join(ROOT, "tools", "ab_bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["ab_bench.py", "--batch", "2", "--rounds", "1", "--launches", "1", "--warm", "1"] + extra)
+    with backend.emulated("plain"):
+        mod.main()
+    out = capsys.readouterr().out
+    assert "median" in out and "generic" in out
+    assert ("mfma-mel" in out) == (not extra)          # every N = 512 variant was accepted and timed
+
+
 def test_smoke_dry_run(monkeypatch, capsys):
     """__graft_entry__.smoke() end to end on the CPU (emulator build, torch.cuda stubbed)"""
     import backend

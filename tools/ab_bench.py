@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--win-ms", type=float, default=32.0)
     ap.add_argument("--rounds", type=int, default=15)
     ap.add_argument("--launches", type=int, default=200)
+    ap.add_argument("--warm", type=int, default=20, help="untimed launches per variant before the rounds")
     ap.add_argument("--compute", choices=["f32", "f64"], default="f32")
     args = ap.parse_args()
 
@@ -73,7 +74,7 @@ def main():
 
     times = {v: [] for v in plans}
     for v, p in plans.items():            # warm every variant
-        for _ in range(20):
+        for _ in range(args.warm):
             launch(p)
     torch.cuda.synchronize()
     for _ in range(args.rounds):
