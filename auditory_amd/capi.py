@@ -79,6 +79,7 @@ SYMBOLS = {
     "aud_version": (C.c_int, []),
     "aud_status_string": (C.c_char_p, [C.c_int]),
     "aud_msec_to_samples": (C.c_int, [C.c_double, C.c_int]),
+    "aud_samples_to_msec": (C.c_double, [C.c_int, C.c_int]),
     "aud_sound_params_defaults": (None, [C.POINTER(SoundParams)]),
     "aud_sound_params_derive": (C.c_int, [C.POINTER(SoundParams), C.c_int]),
     "aud_seg_cnt": (C.c_int, [C.c_int] * 4),
@@ -117,6 +118,8 @@ SYMBOLS = {
     "aud_snd_to_window": (C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int, _VP]),
     "aud_dft_filter_host": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, _VP, _VP]),
     "aud_mel_filter_dft_host": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),
+    "aud_dft_power_host": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, _VP, _VP]),
+    "aud_cepstrum_dct_host": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),
     "aud_gabor_batch_host": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_int,
                                        _VP]),
     "aud_kwta_defaults": (None, [C.POINTER(KwtaParams)]),

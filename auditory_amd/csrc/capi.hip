@@ -748,6 +748,82 @@ int aud_dft_filter_host(aud_plan* p, int step, const double* window, double* pow
     return AUD_OK;
 }
 
+int aud_dft_power_host(aud_plan* p, int step, const double* fft_coefs, double* power, double* log_power,
+                       double* power_seg, double* log_power_seg) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    const int T = p->d.segment_steps, H = p->H;
+    if (!fft_coefs || !power || !power_seg || step < 0 || step >= T) return fail(c, AUD_EINVAL, "bad argument");
+    AUD_HIP(c, make_current(c));
+    int rc;
+    if ((rc = ensure_ws(c, 0, size_t(H) * 16 + 16)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 1, size_t(H) * 8 * 3 + size_t(H) * 4 + 16)) != AUD_OK) return rc;
+    double* d_carry = static_cast<double*>(c->ws[1]);
+    double* d_p = d_carry + H;
+    double* d_lp = d_p + H;
+    float* d_raw = reinterpret_cast<float*>(d_lp + H);
+    AUD_HIP(c, hipMemcpyAsync(c->ws[0], fft_coefs, size_t(H) * 16, hipMemcpyHostToDevice, c->stream));
+    AUD_HIP(c, hipMemcpyAsync(d_carry, power, size_t(H) * 8, hipMemcpyHostToDevice, c->stream));
+    AUD_HIP(c, aud::launch_power_from_coefs(static_cast<const double*>(c->ws[0]), H, d_raw, p->d.compute_dtype,
+                                            c->stream));
+    AUD_HIP(c, aud::launch_frame_blend(d_raw, 1, d_carry, H, step, p->d.dft.prev_smooth, p->d.dft.cur_smooth,
+                                       p->d.dft.comp_log_pow, p->d.dft.log_offset, p->d.dft.log_min, d_p, d_lp,
+                                       p->d.compute_dtype, c->stream));
+    std::vector<double> hp(size_t(H) * 2);
+    AUD_HIP(c, hipMemcpyAsync(hp.data(), d_p, size_t(H) * 16, hipMemcpyDeviceToHost, c->stream));
+    AUD_HIP(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < H; ++k) {  // the tensor stores of dft.go:70-83
+        power[k] = hp[k];
+        power_seg[size_t(k) * T + step] = hp[k];
+        if (p->d.dft.comp_log_pow) {
+            if (log_power) log_power[k] = hp[size_t(H) + k];
+            if (log_power_seg) log_power_seg[size_t(k) * T + step] = hp[size_t(H) + k];
+        }
+    }
+    return AUD_OK;
+}
+
+int aud_cepstrum_dct_host(aud_plan* p, int step, const double* fbank, double* mfcc_seg, double* mfcc_dct) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    const int N = p->d.win_samples, T = p->d.segment_steps, nf = p->d.mel.n_filters, nc = p->d.mfcc_coefs;
+    if (nc < 1 || !p->d_dct) return fail(c, AUD_EINVAL, "plan was created without mfcc_coefs");
+    if (!fbank || !mfcc_seg || step < 0 || step >= T) return fail(c, AUD_EINVAL, "bad argument");
+    AUD_HIP(c, make_current(c));
+    int rc;
+    if ((rc = ensure_ws(c, 1, sizeof(aud_item))) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 2, size_t(nf + nc) * 4 + 16)) != AUD_OK) return rc;
+    const aud_item it{0, N, p->d.step_samples * p->d.border_steps};  // a one-step segment whose only step is live
+    float* d_mel = static_cast<float*>(c->ws[2]);
+    float* d_mfcc = d_mel + nf;
+    std::vector<float> hm(static_cast<size_t>(nf));
+    for (int j = 0; j < nf; ++j) hm[size_t(j)] = float(fbank[j]);
+    AUD_HIP(c, hipMemcpyAsync(c->ws[1], &it, sizeof(it), hipMemcpyHostToDevice, c->stream));
+    AUD_HIP(c, hipMemcpyAsync(d_mel, hm.data(), size_t(nf) * 4, hipMemcpyHostToDevice, c->stream));
+    aud::MfccArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.items = static_cast<const aud_item*>(c->ws[1]);
+    a.n_items = 1;
+    a.N = N;
+    a.S = p->d.step_samples;
+    a.T = 1;
+    a.border = p->d.border_steps;
+    a.H = p->H;
+    a.nf = nf;
+    a.n_coefs = nc;
+    a.dct = p->d_dct;
+    a.mel = d_mel;
+    a.mfcc = d_mfcc;
+    AUD_HIP(c, aud::launch_mfcc_dct(a, p->d.compute_dtype, c->stream));
+    std::vector<float> out(static_cast<size_t>(nc));
+    AUD_HIP(c, hipMemcpyAsync(out.data(), d_mfcc, size_t(nc) * 4, hipMemcpyDeviceToHost, c->stream));
+    AUD_HIP(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < nc; ++i) mfcc_seg[size_t(i) * T + step] = double(out[size_t(i)]);  // mel.go:207-209
+    if (mfcc_dct)
+        for (int j = 0; j < nf; ++j) mfcc_dct[j] = fbank[j];  // mel.go:193: the work tensor ends up a copy of the input
+    return AUD_OK;
+}
+
 int aud_mel_filter_dft_host(aud_plan* p, int step, const double* power, double* segment, double* fbank) {
     if (!p) return AUD_EINVAL;
     aud_ctx* c = p->ctx;

@@ -295,6 +295,9 @@ int aud_gabor_iter_space(const aud_gabor_set* set, int mel_rows, int mel_cols, i
     return AUD_OK;
 }
 
+// sound/sndenv.go:527-529
+double aud_samples_to_msec(int samples, int rate) { return 1000.0 * double(samples) / double(rate); }
+
 // kwta.KWTA.Defaults() of github.com/emer/vision v1.1.15 over leabra v1.1.48's fffb.Params.Defaults()
 // and nxx1.Params.Defaults().  Those sources are not in the reference tree; the values are the published
 // ones as far as known here.  A Go binding never needs this function: it passes the fields of the real

@@ -99,6 +99,7 @@ struct SmoothArgs {
 };
 hipError_t launch_power_smooth(const SmoothArgs& a, int compute_dtype, hipStream_t st);
 hipError_t launch_mel_from_power(const MelspecArgs& a, int compute_dtype, hipStream_t st);
+hipError_t launch_power_from_coefs(const double* coefs, int H, float* raw, int compute_dtype, hipStream_t st);
 hipError_t launch_frame_blend(const float* raw, int raw_stride, const double* carry, int H, int step,
                               double prev, double cur, int comp_log_pow, double log_off, double log_min,
                               double* out_p, double* out_lp, int compute_dtype, hipStream_t st);
@@ -116,6 +117,7 @@ struct MfccArgs {
     float* energy;           // [n_items, T] or null
 };
 hipError_t launch_mfcc(const MfccArgs& a, int compute_dtype, hipStream_t st);
+hipError_t launch_mfcc_dct(const MfccArgs& a, int compute_dtype, hipStream_t st);
 
 // generic any-N kernel (Stockham in LDS, radix 2/4 + per-output generic radix)
 size_t melspec_generic_lds_bytes(int M, int F, int compute_dtype);

@@ -73,6 +73,16 @@ __global__ __launch_bounds__(256) void k_mfcc_deltas(const MfccArgs a, const flo
 
 }  // namespace
 
+// mel.Params.CepstrumDct alone (the reference's per-step entry point)
+hipError_t launch_mfcc_dct(const MfccArgs& a, int compute_dtype, hipStream_t st) {
+    const int64_t n1 = int64_t(a.n_items) * a.n_coefs * a.T;
+    if (n1 == 0) return hipSuccess;
+    const dim3 g1(unsigned((n1 + 255) / 256)), b(256);
+    if (compute_dtype == AUD_F64) hipLaunchKernelGGL(k_mfcc_dct<double>, g1, b, 0, st, a);
+    else hipLaunchKernelGGL(k_mfcc_dct<float>, g1, b, 0, st, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_mfcc(const MfccArgs& a, int compute_dtype, hipStream_t st) {
     const bool f64 = compute_dtype == AUD_F64;
     const int64_t n1 = int64_t(a.n_items) * a.n_coefs * a.T, n2 = int64_t(a.n_items) * a.T;

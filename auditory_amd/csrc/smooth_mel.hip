@@ -66,6 +66,16 @@ __global__ __launch_bounds__(256) void k_frame_blend(const float* raw, int raw_s
     }
 }
 
+// dft.Params.Power's first line for ONE step (dft/dft.go:63-66): raw[k] = re^2 + im^2 of the caller's complex128
+// coefficients, in the compute type, stored like the FFT kernels store their raw power (float32)
+template <typename TT>
+__global__ __launch_bounds__(256) void k_power_from_coefs(const double* coefs, int H, float* raw) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= H) return;
+    const TT rl = TT(coefs[2 * k]), im = TT(coefs[2 * k + 1]);
+    raw[k] = float(rl * rl + im * im);
+}
+
 // mel.Params.FilterDft (mel/mel.go:120-153) applied to a stored power tensor [item, H, T]
 template <typename TT>
 __global__ __launch_bounds__(256) void k_mel_from_power(const MelspecArgs a) {
@@ -122,6 +132,15 @@ hipError_t launch_frame_blend(const float* raw, int raw_stride, const double* ca
     else
         hipLaunchKernelGGL(k_frame_blend<float>, grid, dim3(256), 0, st, raw, raw_stride, carry, H, step, prev, cur,
                            comp_log_pow, log_off, log_min, out_p, out_lp);
+    return hipGetLastError();
+}
+
+hipError_t launch_power_from_coefs(const double* coefs, int H, float* raw, int compute_dtype, hipStream_t st) {
+    const dim3 grid(unsigned((H + 255) / 256));
+    if (compute_dtype == AUD_F64)
+        hipLaunchKernelGGL(k_power_from_coefs<double>, grid, dim3(256), 0, st, coefs, H, raw);
+    else
+        hipLaunchKernelGGL(k_power_from_coefs<float>, grid, dim3(256), 0, st, coefs, H, raw);
     return hipGetLastError();
 }
 

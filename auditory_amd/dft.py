@@ -32,6 +32,24 @@ class Params:
         plan.ctx.check(plan.lib.aud_dft_filter_host(plan.handle, int(step), vp(w), vp(power), vp(logPower),
                                                     vp(powerForSegment), vp(logPowerForSegment)))
 
+    def FftReal(self, fftCoefs, windowIn):
+        """dft/dft.go:53-59: fftCoefs[i] = complex(windowIn[i], 0) -- a host copy, no arithmetic"""
+        n = len(fftCoefs)
+        fftCoefs[:] = 0
+        fftCoefs.real[:] = windowIn[:n]
+
+    def Power(self, step, winSamples, fftCoefs, power, logPower, powerForSegment, logPowerForSegment, plan):
+        """dft/dft.go:62-85 for ONE step on coefficients the caller computed (complex128 [>= winSamples/2 + 1]);
+        the squares, the PrevSmooth blend with the `power` carry and the log run on the GPU like Filter's."""
+        import ctypes as C
+        import numpy as np
+        H = winSamples // 2 + 1
+        assert H == plan.H
+        co = np.ascontiguousarray(np.asarray(fftCoefs, np.complex128)[:H])
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        plan.ctx.check(plan.lib.aud_dft_power_host(plan.handle, int(step), vp(co), vp(power), vp(logPower),
+                                                   vp(powerForSegment), vp(logPowerForSegment)))
+
     def to_c(self):
         return capi.DftParams(int(self.CompLogPow), self.LogMin, self.LogOffSet, self.PrevSmooth,
                               self.CurSmooth)

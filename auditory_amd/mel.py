@@ -78,6 +78,20 @@ class Params:
         pw = np.ascontiguousarray(dftPowerOut, np.float64)
         plan.ctx.check(plan.lib.aud_mel_filter_dft_host(plan.handle, int(step), vp(pw), vp(segmentData), vp(fBankData)))
 
+    def FftReal(self, out, inp):
+        """mel/mel.go:183-189: out[i] = complex(inp[i], 0) -- a host copy, no arithmetic"""
+        out[:] = 0
+        out.real[:] = inp[:len(out)]
+
+    def CepstrumDct(self, step, fBankData, mfccSegment, mfccDct, plan):
+        """mel/mel.go:192-212 for ONE step on the GPU: DCT-I of the nf log-mel values, c0 <- ln(1 + c0^2), the
+        first NCoefs into column `step` of mfccSegment [NCoefs, T]; mfccDct [nf] ends as a copy of fBankData.
+        `plan` must have been created with mfcc_coefs = NCoefs."""
+        import ctypes as C
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        fb = np.ascontiguousarray(fBankData, np.float64)
+        plan.ctx.check(plan.lib.aud_cepstrum_dct_host(plan.handle, int(step), vp(fb), vp(mfccSegment), vp(mfccDct)))
+
     def InitFilters(self, dftSize, sampleRate):
         """mel/mel.go:77-117.  Returns the [NFilters, NFilters+2] float64 filter tensor (the Go
         code fills the tensor passed by the caller); sets BinPts / HzPts and clears FBank.Renorm."""

@@ -12,6 +12,15 @@ def MSecToSamples(ms, rate):
     return capi.load().aud_msec_to_samples(float(ms), int(rate))
 
 
+def SamplesToMSec(samples, rate):
+    """sound/sndenv.go:527-529"""
+    return capi.load().aud_samples_to_msec(int(samples), int(rate))
+
+
+# sound.SoundSampleType, sound/sound.go:22-30
+Unknown, SignedInt, UnSignedInt, Float = 0, 1, 2, 3
+
+
 class Wave:
     """sound.Wave, sound/sound.go:32-141 (PCM WAV in, normalised float64 out).  Host I/O: the RIFF parsing
     replaces go-audio's decoder; the int -> float rule is Wave.GetFloatAtIdx (sound.go:130-141)."""
@@ -60,6 +69,40 @@ class Wave:
     def Channels(self):
         """sound.go:93-103"""
         return self._channels
+
+    def SampleSize(self):
+        """sound.go:88-94 (the reference returns 16 whatever the file holds)"""
+        return 16
+
+    def SampleType(self):
+        """sound.go:107-109"""
+        return SignedInt
+
+    def GetFloatAtIdx(self, idx):
+        """sound.go:130-141"""
+        return capi.load().aud_pcm_to_float(int(self.Data[idx]), int(self.SourceBitDepth))
+
+    def WriteWave(self, fn):
+        """sound.go:55-76: the buffer back to a PCM WAV file at its own rate, depth and channel count"""
+        import struct
+        depth, ch = int(self.SourceBitDepth), max(int(self._channels), 1)
+        if depth == 8:
+            body = (self.Data + 128).astype(np.uint8).tobytes()
+        elif depth == 16:
+            body = self.Data.astype("<i2").tobytes()
+        elif depth == 24:
+            v = self.Data.astype(np.int64) & 0xFFFFFF
+            body = np.stack([v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF], axis=1).astype(np.uint8).tobytes()
+        elif depth == 32:
+            body = self.Data.astype("<i4").tobytes()
+        else:
+            print("Encoding failed on write: unsupported bit depth %d" % depth)
+            return "unsupported bit depth"
+        hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(body), b"WAVE", b"fmt ", 16, 1, ch, self._rate,
+                          self._rate * ch * depth // 8, ch * depth // 8, depth, b"data", len(body))
+        with open(fn, "wb") as f:
+            f.write(hdr + body + (b"\0" if len(body) & 1 else b""))
+        return None
 
     def NumFrames(self):
         return len(self.Data) // max(self._channels, 1)
@@ -272,6 +315,17 @@ class SndEnv:
         if lp is not None:
             self.LogPowerSegment = lp[-1]
         return m, pw, lp
+
+    def ApplyNeighInhib(self):
+        """sound/sndenv.go:303-311.  NeighInhib.Inhib4 (emer/vision) is not built: there is no NeighInhib field to
+        turn on here, so this is the `else` branch -- ExtGi is cleared."""
+        self.ExtGi[...] = 0
+
+    def Name(self):
+        return getattr(self, "Nm", "")
+
+    def Desc(self):
+        return getattr(self, "Dsc", "")
 
     def ApplyKwta(self):
         """sound/sndenv.go:313-323: GborKwta <- GborOutput, then KWTAPool / KWTALayer when Kwta.On"""

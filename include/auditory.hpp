@@ -16,6 +16,7 @@
 #define AUDITORY_HPP
 
 #include <algorithm>
+#include <complex>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -68,6 +69,27 @@ struct Params {  // dft/dft.go:15-31
         CurSmooth = c.cur_smooth;
     }
     aud_dft_params c() const { return aud_dft_params{CompLogPow ? 1 : 0, LogMin, LogOffSet, PrevSmooth, CurSmooth}; }
+
+    // The reference's per-step entry points, one frame per GPU round trip (correct, never fast; batch at
+    // ProcessSegment level).  `plan` is the plan of these parameters (SndEnv::plan.p).
+    // dft/dft.go:42-50
+    int Filter(aud_plan* plan, int step, const Float64& windowIn, Float64* power, Float64* logPower,
+               Float64* powerForSegment, Float64* logPowerForSegment) const {
+        return aud_dft_filter_host(plan, step, windowIn.Values.data(), power->Values.data(),
+                                   logPower ? logPower->Values.data() : nullptr, powerForSegment->Values.data(),
+                                   logPowerForSegment ? logPowerForSegment->Values.data() : nullptr);
+    }
+    // dft/dft.go:53-59
+    static void FftReal(std::vector<std::complex<double>>* fftCoefs, const Float64& in) {
+        for (size_t i = 0; i < fftCoefs->size(); ++i) (*fftCoefs)[i] = std::complex<double>(in.Values[i], 0.0);
+    }
+    // dft/dft.go:62-85 on coefficients the caller computed
+    int Power(aud_plan* plan, int step, const std::vector<std::complex<double>>& fftCoefs, Float64* power,
+              Float64* logPower, Float64* powerForSegment, Float64* logPowerForSegment) const {
+        return aud_dft_power_host(plan, step, reinterpret_cast<const double*>(fftCoefs.data()), power->Values.data(),
+                                  logPower ? logPower->Values.data() : nullptr, powerForSegment->Values.data(),
+                                  logPowerForSegment ? logPowerForSegment->Values.data() : nullptr);
+    }
 };
 }  // namespace dft
 
@@ -117,6 +139,16 @@ struct Params {  // mel/mel.go:47-66
         const int rc = aud_mel_init_filters(&c, dftSize, sampleRate, BinPts.data(), HzPts.data(), filters->Values.data());
         FBank.from(c);
         return rc == AUD_OK;
+    }
+    // mel/mel.go:120-153 for one step (`filters` lives on the device inside the plan)
+    int FilterDft(aud_plan* plan, int step, const Float64& dftPowerOut, Float64* segmentData, Float64* fBankData) const {
+        return aud_mel_filter_dft_host(plan, step, dftPowerOut.Values.data(), segmentData->Values.data(),
+                                       fBankData ? fBankData->Values.data() : nullptr);
+    }
+    // mel/mel.go:192-212 for one step (plan created with mfcc_coefs = NCoefs)
+    int CepstrumDct(aud_plan* plan, int step, const Float64& fBankData, Float64* mfccSegment, Float64* mfccDct) const {
+        return aud_cepstrum_dct_host(plan, step, fBankData.Values.data(), mfccSegment->Values.data(),
+                                     mfccDct ? mfccDct->Values.data() : nullptr);
     }
 };
 }  // namespace mel
@@ -211,6 +243,7 @@ struct KWTA : aud_kwta_params {
 
 namespace sound {
 inline int MSecToSamples(double ms, int rate) { return aud_msec_to_samples(ms, rate); }  // sndenv.go:522-524
+inline double SamplesToMSec(int samples, int rate) { return aud_samples_to_msec(samples, rate); }  // :527-529
 
 struct Params {  // sound/sndenv.go:24-61
     double WinMs = 0, StepMs = 0, SegmentMs = 0, StrideMs = 0;
@@ -227,6 +260,7 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
     dft::Params DFT;
     mel::Params Mel;
     Float64 MelFilters, PowerSegment, LogPowerSegment, MelFBankSegment;
+    Float64 Energy, MFCCSegment, MFCCDeltas, MFCCDeltaDeltas;  // sndenv.go:104-131 (filled when Mel.MFCC)
     std::vector<agabor::Filter> GaborSpecs;
     agabor::FilterSet GaborFilters;
     int GborOutPoolsX = 0, GborOutPoolsY = 0, GborOutUnitsX = 0, GborOutUnitsY = 0;
@@ -285,6 +319,12 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
         Params_.Steps.clear();
         for (int i = 0; i < Params_.SegmentSteps; ++i) Params_.Steps.push_back(Params_.StepSamples * (i - Params_.BorderSteps));
         MelFBankSegment.SetShape({Mel.FBank.NFilters, Params_.SegmentSteps});
+        Energy.SetShape({Params_.SegmentSteps});
+        if (Mel.MFCC) {  // sndenv.go:252-256
+            MFCCSegment.SetShape({Mel.NCoefs, Params_.SegmentSteps});
+            MFCCDeltas.SetShape({Mel.NCoefs, Params_.SegmentSteps});
+            MFCCDeltaDeltas.SetShape({Mel.NCoefs, Params_.SegmentSteps});
+        }
         SegCnt = aud_seg_cnt(int(Signal.Values.size()), Params_.SegmentSamples, Params_.StrideSamples, Channels);
 
         if (ensure_ctx() != AUD_OK) return "no HIP device (libauditory_hip has no CPU fallback)";
@@ -297,6 +337,7 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
         d.gabor = GaborFilters.c();
         d.gabor_filters = d.n_gabor ? GaborFilters.Filters.Values.data() : nullptr;
         d.compute_dtype = ComputeDtype;
+        d.mfcc_coefs = Mel.MFCC ? Mel.NCoefs : 0;
         if (plan.p) { aud_plan_destroy(plan.p); plan.p = nullptr; }
         if (aud_plan_create(default_ctx(), &d, &plan.p) != AUD_OK) return aud_last_error(default_ctx());
         return "";
@@ -306,9 +347,17 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
     void ProcessSegment(int segment, int add) {
         aud_item it{0, int32_t(Signal.Values.size()),
                     int32_t(segment * Params_.StrideSamples + MSecToSamples(double(add), SampleRate))};  // :440-441
-        const int rc = aud_melspec_batch_host(plan.p, Signal.Values.data(), int64_t(Signal.Values.size()), &it, 1,
-                                              MelFBankSegment.Values.data(), PowerSegment.Values.data(),
-                                              DFT.CompLogPow ? LogPowerSegment.Values.data() : nullptr);
+        int rc;
+        if (Mel.MFCC && DFT.CompLogPow)  // the MFCC tail of the loop too: CepstrumDct, Energy, deltas (:360-432)
+            rc = aud_melspec_mfcc_batch_host(plan.p, Signal.Values.data(), int64_t(Signal.Values.size()), &it, 1,
+                                             MelFBankSegment.Values.data(), PowerSegment.Values.data(),
+                                             LogPowerSegment.Values.data(), MFCCSegment.Values.data(),
+                                             Mel.Deltas ? MFCCDeltas.Values.data() : nullptr,
+                                             Mel.Deltas ? MFCCDeltaDeltas.Values.data() : nullptr, Energy.Values.data());
+        else
+            rc = aud_melspec_batch_host(plan.p, Signal.Values.data(), int64_t(Signal.Values.size()), &it, 1,
+                                        MelFBankSegment.Values.data(), PowerSegment.Values.data(),
+                                        DFT.CompLogPow ? LogPowerSegment.Values.data() : nullptr);
         if (rc != AUD_OK) std::printf("%s\n", aud_last_error(default_ctx()));  // fmt.Println(err), sndenv.go:356
     }
 

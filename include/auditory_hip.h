@@ -144,6 +144,8 @@ const char* aud_status_string(int status);
 
 /* sound.MSecToSamples, sound/sndenv.go:522-524 */
 int aud_msec_to_samples(double ms, int rate);
+/* sound.SamplesToMSec, sound/sndenv.go:527-529 */
+double aud_samples_to_msec(int samples, int rate);
 /* SndEnv.ParamDefaults, sound/sndenv.go:64-71 */
 void aud_sound_params_defaults(aud_sound_params* p);
 /* the derivations of SndEnv.Init, sound/sndenv.go:202-207; AUD_EINVAL if sample_rate <= 0 (:196-201) */
@@ -278,6 +280,15 @@ int aud_snd_to_window(const double* signal, int64_t sig_len, int64_t start, int 
  * return; log_power [H]; power_seg / log_power_seg [H, T] get column `step` (log_* may be NULL). */
 int aud_dft_filter_host(aud_plan* plan, int step, const double* window, double* power, double* log_power,
                         double* power_seg, double* log_power_seg);
+
+/* dft.Params.Power, dft/dft.go:62-85, for one step, on coefficients the caller computed: fft_coefs is complex128
+ * [>= H] as (re, im) pairs; the other arguments as aud_dft_filter_host. */
+int aud_dft_power_host(aud_plan* plan, int step, const double* fft_coefs, double* power, double* log_power,
+                       double* power_seg, double* log_power_seg);
+
+/* mel.Params.CepstrumDct, mel/mel.go:192-212, for one step (plan created with mfcc_coefs = NCoefs): fbank [nf];
+ * mfcc_seg [NCoefs, T] gets column `step`; mfcc_dct [nf] (may be NULL) ends as a copy of fbank, as in the Go code. */
+int aud_cepstrum_dct_host(aud_plan* plan, int step, const double* fbank, double* mfcc_seg, double* mfcc_dct);
 
 /* mel.Params.FilterDft, mel/mel.go:120-153, for one step: power [H]; segment [nf, T] gets column `step`,
  * fbank [nf] the same values. */

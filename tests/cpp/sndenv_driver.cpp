@@ -1,7 +1,8 @@
 // Drives include/auditory.hpp the way an emergent simulation drives sound.SndEnv:
 //   Defaults -> set fields -> Init -> for each segment { ProcessSegment; ApplyGabor }
 // argv: <signal.f64> <sample_rate> <out.bin>.  Output: for every segment, float64 mel [nf*T],
-// float64 log-power [H*T], float32 raw gabor [8*2*2*8], float32 post-kwta [8*2*2*8], preceded by one int32 header {SegCnt, nf, T, H}.
+// float64 log-power [H*T], float32 raw gabor [8*2*2*8], float32 post-kwta [8*2*2*8], float64 MFCC [13*T],
+// MFCC deltas [13*T], Energy [T], preceded by one int32 header {SegCnt, nf, T, H}.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -54,6 +55,27 @@ int main(int argc, char** argv) {
         std::fwrite(se.LogPowerSegment.Values.data(), 8, se.LogPowerSegment.Values.size(), o);
         std::fwrite(se.GborOutput.Values.data(), 4, se.GborOutput.Values.size(), o);
         std::fwrite(g->Values.data(), 4, g->Values.size(), o);
+        std::fwrite(se.MFCCSegment.Values.data(), 8, se.MFCCSegment.Values.size(), o);
+        std::fwrite(se.MFCCDeltas.Values.data(), 8, se.MFCCDeltas.Values.size(), o);
+        std::fwrite(se.Energy.Values.data(), 8, se.Energy.Values.size(), o);
+    }
+    // the reference's per-step calls for step 2 of segment 0 (sndenv.go:438-452, mel.go:192-212): window ->
+    // dft.Filter -> mel.FilterDft -> mel.CepstrumDct; appended as mel [nf] and mfcc [NCoefs]
+    {
+        const int N = se.Params_.WinSamples, H = N / 2 + 1, T = se.Params_.SegmentSteps, nf = se.Mel.FBank.NFilters;
+        Float64 window, power, logPower, pSeg, lSeg, fbank, mSeg, mfccSeg, mfccDct;
+        window.SetShape({N}); power.SetShape({H}); logPower.SetShape({H}); pSeg.SetShape({H, T}); lSeg.SetShape({H, T});
+        fbank.SetShape({nf}); mSeg.SetShape({nf, T}); mfccSeg.SetShape({se.Mel.NCoefs, T}); mfccDct.SetShape({nf});
+        const int step = 2;
+        if (aud_snd_to_window(se.Signal.Values.data(), int64_t(se.Signal.Values.size()), se.Params_.Steps[step], N,
+                              window.Values.data()) != AUD_OK) return 7;
+        if (se.DFT.Filter(se.plan.p, step, window, &power, &logPower, &pSeg, &lSeg) != AUD_OK) return 8;
+        if (se.Mel.FilterDft(se.plan.p, step, power, &mSeg, &fbank) != AUD_OK) return 9;
+        if (se.Mel.CepstrumDct(se.plan.p, step, fbank, &mfccSeg, &mfccDct) != AUD_OK) return 10;
+        std::vector<double> col(size_t(se.Mel.NCoefs));
+        for (int i = 0; i < se.Mel.NCoefs; ++i) col[size_t(i)] = mfccSeg.Values[size_t(i) * T + step];
+        std::fwrite(fbank.Values.data(), 8, fbank.Values.size(), o);
+        std::fwrite(col.data(), 8, col.size(), o);
     }
     std::fclose(o);
     aud_shutdown(default_ctx());

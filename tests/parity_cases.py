@@ -639,6 +639,46 @@ def case_per_step_api(orc, cdt):
         ok, msg = W.feature_close(se.MelFBankSegment, se2_mel, cdt, lin_axis=0)
         assert ok, "batched vs per-step " + msg
         se._plan.close()
+    # dft.Params.Power on coefficients the caller computed (numpy's FFT stands in for gonum's), with the carry;
+    # mel.Params.CepstrumDct on one step's filterbank values
+    se = sound.SndEnv(compute_dtype=cdt)
+    se.Defaults()                                   # Mel.MFCC on: the plan gets the DCT rows
+    se.SampleRate, se.Signal = 16000, sig[0]
+    se.GborOutUnitsX = se.GborOutUnitsY = 1
+    assert se.Init() is None
+    se.DFT.PrevSmooth, se.DFT.CurSmooth = 0.3, 0.7
+    se._make_plan()
+    N, T, H = se.Params.WinSamples, se.Params.SegmentSteps, se.Params.WinSamples // 2 + 1
+    power, logp = np.zeros(H), np.zeros(H)
+    pseg, lseg = np.zeros((H, T)), np.zeros((H, T))
+    carry = np.zeros(H)
+    for step in range(3):
+        win = sig[0][step * 160:step * 160 + N]
+        co = np.zeros(N, np.complex128)
+        se.DFT.FftReal(co, win)
+        assert np.array_equal(co.real, win) and not co.imag.any()
+        co = np.fft.fft(co)
+        se.DFT.Power(step, N, co, power, logp, pseg, lseg, se._plan)
+        raw = (co.real ** 2 + co.imag ** 2)[:H]
+        want = raw if step == 0 else 0.3 * carry + 0.7 * raw     # dft.go:67-69
+        carry = want
+        tol = 3e-6 if cdt == capi.AUD_F32 else 3e-7               # (raw power is held in float32 on the device)
+        assert np.abs(power - want).max() <= tol * want.max(), step
+        assert np.array_equal(pseg[:, step], power) and np.array_equal(lseg[:, step], logp)
+        assert np.abs(logp - np.log(want + 1.0)).max() <= 1e-5
+    fb = np.random.default_rng(3).normal(2.0, 3.0, se.Mel.FBank.NFilters)
+    mseg = np.zeros((se.Mel.NCoefs, T))
+    work = np.zeros(se.Mel.FBank.NFilters)
+    se.Mel.CepstrumDct(5, fb, mseg, work, se._plan)
+    want = orc.dct1(fb.astype(np.float32).astype(np.float64))
+    want[0] = np.log(1.0 + want[0] ** 2)                          # mel.go:203-204
+    tol = 2e-5 if cdt == capi.AUD_F32 else 1e-6
+    assert np.abs(mseg[:, 5] - want[:13]).max() <= tol * np.abs(want[:13]).max()
+    assert not mseg[:, :5].any() and not mseg[:, 6:].any() and np.array_equal(work, fb)
+    with pytest.raises(capi.AuditoryError):
+        se.Mel.CepstrumDct(T, fb, mseg, work, se._plan)           # step out of range: the Go code panics
+    se._plan.close()
+    assert sound.SamplesToMSec(441, 44100) == 10.0
 
 
 REF_SOUNDS = "/root/reference/examples/processspeech/sounds"

@@ -41,6 +41,14 @@ def _run_driver(lib_path, tmp_path, orc):
         kwt = np.frombuffer(raw, np.float32, 8 * 2 * 2 * 8, pos).reshape(8, 2, 2, 8); pos += 4 * 256
         ref_k, _ = orc.kwta_pool(kw, gab, kw_state)     # exact, incl. the state carried across segments
         assert np.array_equal(kwt, ref_k), seg
+        mfcc = np.frombuffer(raw, np.float64, 13 * T, pos).reshape(13, T); pos += 8 * 13 * T
+        dlt = np.frombuffer(raw, np.float64, 13 * T, pos).reshape(13, T); pos += 8 * 13 * T
+        eng = np.frombuffer(raw, np.float64, T, pos); pos += 8 * T
+        om = orc.process_segment_mfcc(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig[0], segment=seg)
+        scale = max(1.0, np.abs(om["mfcc"]).max())
+        assert np.abs(mfcc - om["mfcc"]).max() <= 2e-4 * scale, seg      # f32 tail on f32-stored mel (see case_mfcc_tail)
+        assert np.abs(dlt - om["deltas"]).max() <= 2e-4 * scale, seg
+        assert np.abs(eng - om["energy"]).max() <= 2e-5 * max(1.0, np.abs(om["energy"]).max()), seg
         o = orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig[0], segment=seg)
         ok, msg = W.feature_close(mel, o["mel_seg"], capi.AUD_F32, lin_axis=0)
         assert ok, (seg, msg)
@@ -50,6 +58,16 @@ def _run_driver(lib_path, tmp_path, orc):
         assert orc.gabor_convolve(o["mel_seg"], k, 3, 3, 2.0, ref) == 0
         ok, msg = W.feature_close(gab, ref, capi.AUD_F32)
         assert ok, (seg, msg)
+        if seg == 0:
+            mel_seg0 = mel.copy()
+    # the per-step calls (step 2 of segment 0): the same mel column as the batched call, and its DCT
+    fb = np.frombuffer(raw, np.float64, nf, pos); pos += 8 * nf
+    cep = np.frombuffer(raw, np.float64, 13, pos); pos += 8 * 13
+    ok, msg = W.feature_close(fb[None], mel_seg0[:, 2][None], capi.AUD_F32)
+    assert ok, "per-step mel " + msg
+    want = orc.dct1(fb.astype(np.float32).astype(np.float64))
+    want[0] = np.log(1.0 + want[0] ** 2)
+    assert np.abs(cep - want[:13]).max() <= 2e-5 * np.abs(want[:13]).max()
     assert pos == len(raw)
 
 
