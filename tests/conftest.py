@@ -11,12 +11,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 @pytest.hookimpl(tryfirst=True)
 def pytest_cmdline_main(config):
-    """CPU tier only (`-m "not gpu"`): spread the tests over 4 xdist workers unless the caller chose a worker
+    """CPU tier only (`-m "not gpu"`): spread the tests over (cores - 1, at most 7) xdist workers unless the caller chose a worker
     count (or AUD_TEST_WORKERS=0).  The emulator tests spend their time in thread barriers, so this cuts the
-    tier from ~7 to ~3 minutes on 8 cores.  The GPU tier always runs in one process (one process on the card)."""
+    tier from ~8 to ~3 minutes on 8 cores.  The GPU tier always runs in one process (one process on the card)."""
     if hasattr(config, "workerinput") or os.environ.get("PYTEST_XDIST_WORKER"):
         return None  # an xdist worker: never spawn workers of its own
-    want = os.environ.get("AUD_TEST_WORKERS", "4")
+    want = os.environ.get("AUD_TEST_WORKERS", str(max(2, min(8, os.cpu_count() or 4) - 1)))
     if (getattr(config.option, "markexpr", "") or "").strip() != "not gpu" or want in ("", "0"):
         return None
     if not config.pluginmanager.hasplugin("xdist") or getattr(config.option, "numprocesses", None):
