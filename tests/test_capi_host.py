@@ -239,3 +239,26 @@ int main(void) {
                            "-Wl,-rpath," + libdir])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("C-ABI-OK 100 200"), out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("depth", [8, 16, 24, 32])
+def test_wave_write_load_round_trip(tmp_path, depth):
+    """sound.Wave (sound.go:37-141): WriteWave -> Load gives the samples back at every integer depth, and
+    SoundToTensor applies GetFloatAtIdx's divisor for that depth"""
+    from auditory_amd import sound
+    rng = np.random.default_rng(depth)
+    lim = 1 << (depth - 1)
+    w = sound.Wave()
+    w.Data = rng.integers(-lim + 1 if depth > 8 else -127, lim, 501).astype(np.int64)
+    w.Data[:3] = [lim - 1, -(lim - 1), 0]
+    w.SourceBitDepth, w._rate, w._channels = depth, 22050, 1
+    fn = str(tmp_path / ("w%d.wav" % depth))
+    assert w.WriteWave(fn) is None
+    r = sound.Wave()
+    r.Load(fn)
+    assert (r.SampleRate(), r.Channels(), r.SourceBitDepth, r.NumFrames()) == (22050, 1, depth, 501)
+    assert np.array_equal(r.Data, w.Data)
+    x = r.SoundToTensor()
+    div = {8: 0x7F, 16: 0x7FFF, 24: 0x7FFFFF, 32: 0x7FFFFFFF}[depth]
+    assert x[0] == 1.0 and x[1] == -1.0 and x[2] == 0.0 and np.array_equal(x, w.Data / float(div))
+    assert r.GetFloatAtIdx(0) == 1.0 and r.SampleSize() == 16 and r.SampleType() == sound.SignedInt
