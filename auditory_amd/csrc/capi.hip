@@ -1045,7 +1045,10 @@ int aud_kwta_batch_dev(aud_ctx* c, const aud_kwta_params* k, const float* raw, f
     if (n_items == 0 || n64 == 0) return AUD_OK;
     if (!raw || !act) return fail(c, AUD_EINVAL, "null buffer");
     if (raw == act) return fail(c, AUD_EINVAL, "act must not alias raw (the reference keeps both tensors)");
-    const size_t lds = n64 <= (1 << 20) ? aud::kwta_lds_bytes(int(n64), int(lay64)) : size_t(1) << 30;
+    if (n64 > (1 << 20)) return fail(c, AUD_EINVAL, "tensor too large for one workgroup's LDS");
+    // the zero-skipping list of the serial sum needs n more floats of LDS: used when they fit 64 KB with the rest
+    bool compact = pool_level && sum_order == 0 && aud::kwta_lds_bytes(int(n64), int(lay64), true) <= 64u * 1024u;
+    const size_t lds = aud::kwta_lds_bytes(int(n64), int(lay64), compact);
     if (lds > 160u * 1024u)
         return fail(c, AUD_EINVAL, "tensor too large for one workgroup's LDS: (32 + n + 4 pools) * 4 bytes must fit 160 KB");
     AUD_HIP(c, make_current(c));
@@ -1061,6 +1064,7 @@ int aud_kwta_batch_dev(aud_ctx* c, const aud_kwta_params* k, const float* raw, f
     a.pl_n = pool_level ? d2 * d3 : 0;
     a.start_from_raw = start_from_raw ? 1 : 0;
     a.sum_order = sum_order;
+    a.compact = compact ? 1 : 0;
     a.state = pool_level ? pool_state : nullptr;
     a.cycles = cycles;
     a.lds_bytes = unsigned(lds);

@@ -153,6 +153,7 @@ struct KwtaArgs {
     int lay_n, pl_n;   // pool level: lay_n pools of pl_n consecutive values; layer level only: lay_n = 0
     int start_from_raw;
     int sum_order;     // 0: running float32 sums in the reference's index order; 1: fixed tree (faster)
+    int compact;       // sum_order 0, pool level: the serial layer sum walks an order-preserving list of the non-zeros
     float* state;      // [n_items, lay_n, 2] {FBi, Act.Avg} carried between calls, or null
     int32_t* cycles;   // [n_items] settling cycles run, or null
     int iters;
@@ -166,7 +167,7 @@ struct KwtaArgs {
     float act_dt;
     unsigned lds_bytes;
 };
-size_t kwta_lds_bytes(int n, int lay_n);
+size_t kwta_lds_bytes(int n, int lay_n, bool compact);
 hipError_t kwta_prepare(unsigned lds_bytes);
 hipError_t launch_kwta(const KwtaArgs& a, hipStream_t st);
 

@@ -12,6 +12,13 @@
 // fixed reduction tree over per-thread partial sums: deterministic, a few ulp away from the reference's
 // sum, and the whole workgroup takes part.
 //
+// In the pool-level mode the serial sum skips exact zeros.  That is exact: the running sum starts at +0 and can
+// never become -0 (x + y is -0 only for x = y = -0), and s + (+-0) == s for every other s, so the running sum
+// over the non-zero activations, taken in index order, equals the running sum over all of them bit for bit.
+// The rectified gabor output is exactly zero in half of its cells and those stay zero while they settle, so an
+// order-preserving compaction (per-pool counts, a wave scan, scattered writes: all parallel) halves the serial
+// section.  It needs n more floats of LDS; when they do not fit, the sum walks every value.
+//
 // Per settling cycle: layer FFFB (thread 0) -> every pool, one thread each: pool FFFB, gi = max(layer,
 // pool), threshold, the pool's units in order (noisy XX1, ActDt integration, running pool sum) -> max |dAct|
 // and the layer sum -> stop when cycle > 2 and max |dAct| < DelActThr.  Activations live in LDS.
@@ -112,9 +119,12 @@ __global__ __launch_bounds__(kNT) void k_kwta(const KwtaArgs a) {
     float* p_act_avg = p_fbi + lay_n;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int item = blockIdx.x;
+    const bool tree = a.sum_order != 0;
+    int* p_off = reinterpret_cast<int*>(p_act_avg + lay_n);  // [lay_n + 1] (compaction only)
+    float* packed = reinterpret_cast<float*>(p_off + ((lay_n + 1 + 3) & ~3));  // [n] (compaction only)
+    const bool compact = a.compact != 0 && lay_n > 0 && !tree;
     const float* __restrict__ raw = a.raw + size_t(item) * n;
     float* act_g = a.act + size_t(item) * n;
-    const bool tree = a.sum_order != 0;
 
     // ---- Ge statistics: layer (all values, index order) and pools ----
     for (int i = tid; i < n; i += kNT) acts[i] = a.start_from_raw ? raw[i] : act_g[i];
@@ -181,14 +191,17 @@ __global__ __launch_bounds__(kNT) void k_kwta(const KwtaArgs a) {
                 // the external-inhibition tensor is all zeros on this path: max(gi, Pool.Gi * FFInhib(0, 0)) = gi
                 const float ge_thr = ge_thr_from_g(a, fmaxf(lay_gi, gi));
                 float s = 0.f;
+                int nz = 0;
                 for (int ui = 0; ui < pl_n; ++ui) {
                     const int idx = pi * pl_n + ui;
                     const float nw = unit_update(a, raw[idx], ge_thr, acts[idx], mx);
                     s += nw;
+                    nz += nw != 0.f ? 1 : 0;  // a NaN counts: it must reach the sum
                     acts[idx] = nw;
                 }
                 part += s;
                 p_act_avg[pi] = calc_avg(s, pl_n);
+                if (compact) p_off[pi] = nz;
             }
         } else {
             const float ge_thr = ge_thr_from_g(a, lay_gi);
@@ -205,6 +218,39 @@ __global__ __launch_bounds__(kNT) void k_kwta(const KwtaArgs a) {
             ctrl[12 + wave] = part;
         }
         __syncthreads();
+        int n_sum = n;
+        const float* sum_src = acts;
+        if (compact) {
+            // exclusive scan of the per-pool non-zero counts in pool order (wave 0, 64 pools per step) ...
+            if (wave == 0) {
+                int base = 0;
+                for (int p0 = 0; p0 < lay_n; p0 += 64) {
+                    const int pi = p0 + lane;
+                    const int c = pi < lay_n ? p_off[pi] : 0;
+                    int incl = c;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int up = __shfl_up(incl, o);
+                        if (lane >= o) incl += up;
+                    }
+                    if (pi < lay_n) p_off[pi] = base + incl - c;
+                    base += __shfl(incl, 63);
+                }
+                if (lane == 0) p_off[lay_n] = base;
+            }
+            __syncthreads();
+            // ... and every pool's non-zero activations to their place, order kept
+            for (int pi = tid; pi < lay_n; pi += kNT) {
+                int o = p_off[pi];
+                for (int ui = 0; ui < pl_n; ++ui) {
+                    const float v = acts[pi * pl_n + ui];
+                    if (v != 0.f) packed[o++] = v;
+                }
+            }
+            __syncthreads();
+            n_sum = p_off[lay_n];
+            sum_src = packed;
+        }
         if (tid == 0) {
             const float max_del = fmaxf(fmaxf(ctrl[8], ctrl[9]), fmaxf(ctrl[10], ctrl[11]));
             float s = 0.f;
@@ -212,7 +258,7 @@ __global__ __launch_bounds__(kNT) void k_kwta(const KwtaArgs a) {
                 s = (ctrl[12] + ctrl[13]) + (ctrl[14] + ctrl[15]);
             } else {
 #pragma unroll 8
-                for (int i = 0; i < n; ++i) s += acts[i];
+                for (int i = 0; i < n_sum; ++i) s += sum_src[i];
             }
             const float act_avg = calc_avg(s, n);
             ctrl[5] = act_avg;
@@ -243,8 +289,10 @@ __global__ __launch_bounds__(kNT) void k_kwta(const KwtaArgs a) {
 
 }  // namespace
 
-size_t kwta_lds_bytes(int n, int lay_n) {
-    return (size_t(kCtrl) + size_t((n + 3) & ~3) + 4 * size_t(lay_n)) * sizeof(float);
+size_t kwta_lds_bytes(int n, int lay_n, bool compact) {
+    size_t words = size_t(kCtrl) + size_t((n + 3) & ~3) + 4 * size_t(lay_n);
+    if (compact) words += size_t((lay_n + 1 + 3) & ~3) + size_t(n);
+    return words * sizeof(float);
 }
 
 hipError_t kwta_prepare(unsigned lds_bytes) {
