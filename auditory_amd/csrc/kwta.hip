@@ -4,7 +4,7 @@
 // reference tree; the algorithm is restated from their published sources ("k-WTA", says what
 // anchors it and what is unverified).
 //
-// One workgroup settles one item.  All arithmetic is float32 in the reference's operation order with
+// One 512-thread workgroup settles one item.  All arithmetic is float32 in the reference's operation order with
 // contraction off, FastExp is the integer bit trick of goki/mat32, so in sum_order 0 the result is meant
 // to equal the reference's bit for bit.  What cannot be parallelised under that constraint is the
 // layer-level running sum (a float32 accumulation over every value in index order): thread 0 does it from
@@ -29,10 +29,11 @@
 namespace aud {
 namespace {
 
-constexpr int kNT = 256;
+constexpr int kNT = 512;   // 352 pools of a 1 s segment in one round; two waves per SIMD keep the vector pipe fed
+constexpr int kNW = kNT / 64;
 constexpr int kCtrl = 32;  // control words at the head of dynamic LDS (floats)
 // ctrl[0] layer gi   ctrl[1] stop flag   ctrl[2] layer FBi   ctrl[3] layer Ge.Avg   ctrl[4] layer Ge.Max
-// ctrl[5] layer Act.Avg   ctrl[8..11] per-wave max |dAct|   ctrl[12..15] per-wave partial sums / maxima
+// ctrl[5] layer Act.Avg   ctrl[8..15] per-wave max |dAct|   ctrl[16..23] per-wave partial sums
 
 // goki/mat32 FastExp (Schraudolph's quartic spline on the float32 bit pattern); |arg| stays far inside
 // the int32 range here (callers pass 0 < x <= 50)
@@ -105,6 +106,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// the per-wave slots combined in a fixed order
+__device__ __forceinline__ float wave_slots_sum(const float* v) {
+    return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
+__device__ __forceinline__ float wave_slots_max(const float* v) {
+    return fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+}
+static_assert(kNW == 8, "wave_slots_* combine 8 slots");
+
 // AvgMax32.CalcAvg
 __device__ __forceinline__ float calc_avg(float sum, int n) { return n > 0 ? sum / float(n) : sum; }
 
@@ -155,20 +165,20 @@ __global__ __launch_bounds__(kNT) void k_kwta(const KwtaArgs a) {
     gpart = wave_sum(gpart);
     if (lane == 0) {
         ctrl[8 + wave] = gmax;
-        ctrl[12 + wave] = gpart;
+        ctrl[16 + wave] = gpart;
     }
     __syncthreads();
     if (tid == 0) {
         float s = 0.f;
         if (tree) {
-            s = (ctrl[12] + ctrl[13]) + (ctrl[14] + ctrl[15]);
+            s = wave_slots_sum(ctrl + 16);
         } else if (a.start_from_raw) {
             for (int i = 0; i < n; ++i) s += acts[i];  // acts == raw here
         } else {
             for (int i = 0; i < n; ++i) s += raw[i];
         }
         const float ge_avg = calc_avg(s, n);
-        const float ge_max = n > 0 ? fmaxf(fmaxf(ctrl[8], ctrl[9]), fmaxf(ctrl[10], ctrl[11])) : ge_avg;
+        const float ge_max = n > 0 ? wave_slots_max(ctrl + 8) : ge_avg;
         float fbi = 0.f, gi = 0.f;  // a fresh layer-level fffb.Inhib on every call
         fffb_inhib(a.lay, ge_avg, ge_max, 0.f, fbi, gi);
         ctrl[0] = gi;
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(kNT) void k_kwta(const KwtaArgs a) {
         part = wave_sum(part);
         if (lane == 0) {
             ctrl[8 + wave] = mx;
-            ctrl[12 + wave] = part;
+            ctrl[16 + wave] = part;
         }
         __syncthreads();
         int n_sum = n;
@@ -252,10 +262,10 @@ __global__ __launch_bounds__(kNT) void k_kwta(const KwtaArgs a) {
             sum_src = packed;
         }
         if (tid == 0) {
-            const float max_del = fmaxf(fmaxf(ctrl[8], ctrl[9]), fmaxf(ctrl[10], ctrl[11]));
+            const float max_del = wave_slots_max(ctrl + 8);
             float s = 0.f;
             if (tree) {
-                s = (ctrl[12] + ctrl[13]) + (ctrl[14] + ctrl[15]);
+                s = wave_slots_sum(ctrl + 16);
             } else {
 #pragma unroll 8
                 for (int i = 0; i < n_sum; ++i) s += sum_src[i];
