@@ -316,13 +316,15 @@ def kwta_inputs(seed, n_items, shape=(11, 32, 2, 8)):
     return raw
 
 
-def case_kwta_vs_oracle(orc):
+def case_kwta_vs_oracle(orc, quick=False):
     """KWTAPool / KWTALayer through the C ABI against the float32 oracle: bit-exact in the reference's
     summation order, within a few ulp-amplified steps for the tree order."""
     from auditory_amd import kwta
     raw = kwta_inputs(11, 4)
     variants = [{}, {"LayFFFB.MaxVsAvg": 0.3, "PoolFFFB.MaxVsAvg": 0.5}, {"PoolFFFB.On": False},
                 {"LayFFFB.On": False, "XX1.Gain": 40.0, "Iters": 7}, {"Iters": 0}, {"DelActThr": 0.2}]
+    if quick:  # the thread emulator pays ~1 s per settled tensor; the parameter space is tests/test_emul_fuzz.py's
+        raw, variants = raw[:3], variants[:2]
     for over in variants:
         k, ko = _kwta_pair(orc, **over)
         for pool in (True, False):
@@ -342,11 +344,11 @@ def case_kwta_vs_oracle(orc):
     act2, _ = kwta.kwta_batch_host(k, raw, pool=True, sum_order=1)
     assert np.array_equal(act, act2)               # deterministic
     # carried pool state over three calls (SndEnv.Inhibs), per item
-    st = np.zeros((4, 11 * 32, 2), np.float32)
+    st = np.zeros((raw.shape[0], 11 * 32, 2), np.float32)
     st_o = st.copy()
-    for rep in range(3):
+    for rep in range(2 if quick else 3):
         act, _ = kwta.kwta_batch_host(k, raw, pool=True, state=st)
-        for i in range(4):
+        for i in range(raw.shape[0]):
             r, _ = orc.kwta_pool(ko, raw[i], st_o[i])
             assert np.array_equal(act[i], r)
         assert np.array_equal(st, st_o)
@@ -372,13 +374,13 @@ def case_kwta_quick(orc):
     """small shapes for the sanitizer builds: both levels, both summation orders, carried state"""
     from auditory_amd import kwta
     k, ko = _kwta_pair(orc)
-    for shape in [(3, 5, 2, 4), (17, 19, 1, 3)]:
-        raw = kwta_inputs(7, 2, shape)
-        st = np.zeros((2, shape[0] * shape[1], 2), np.float32)
+    for shape in [(5, 15, 2, 4)]:          # 75 pools: more than one 64-pool step of the compaction scan
+        raw = kwta_inputs(7, 1, shape)
+        st = np.zeros((1, shape[0] * shape[1], 2), np.float32)
         st_o = st.copy()
         for pool in (True, False):
             act, cyc = kwta.kwta_batch_host(k, raw, pool=pool, state=st if pool else None)
-            for i in range(2):
+            for i in range(1):
                 ref, c = (orc.kwta_pool(ko, raw[i], st_o[i]) if pool else orc.kwta_layer(ko, raw[i]))
                 assert np.array_equal(act[i], ref) and cyc[i] == c
             tree, _ = kwta.kwta_batch_host(k, raw, pool=pool, sum_order=1)

@@ -157,5 +157,5 @@ def test_device_api_tests_dry_run(monkeypatch, orc):
         G.test_input_dtypes_agree(orc, torch, "cfg5_44k_n2048_nf128", 80.0)
         G.test_input_dtypes_agree(orc, torch, "cfg1_44k_n1103_nf32", None)
         G.test_process_batch_mel_plus_gabor(orc, torch)
-        G.test_process_then_kwta_device_resident(orc, torch, n=2)
+        G.test_process_then_kwta_device_resident(orc, torch, n=1)
         G.test_full_size_properties_cfg2(orc, torch, B=4)

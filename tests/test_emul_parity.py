@@ -125,7 +125,7 @@ def test_emul_kernels_under_tsan():
 
 
 def test_emul_kwta_vs_oracle(orc, emu):
-    PC.case_kwta_vs_oracle(orc)
+    PC.case_kwta_vs_oracle(orc, quick=True)
 
 
 def test_emul_kwta_shapes(orc, emu):
