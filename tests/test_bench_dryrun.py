@@ -159,3 +159,33 @@ def test_device_api_tests_dry_run(monkeypatch, orc):
         G.test_process_batch_mel_plus_gabor(orc, torch)
         G.test_process_then_kwta_device_resident(orc, torch, n=1)
         G.test_full_size_properties_cfg2(orc, torch, B=4)
+
+
+def test_rocprof_summary_on_synthetic_csvs(tmp_path):
+    """tools/rocprof_summary.py against CSVs laid out like rocprofv3's (<dir>/<pass>/<host>/<pid>_*.csv): the
+    per-launch HBM bytes it hands to bench.py (FETCH_SIZE doubled and in KB, WRITE_SIZE in KB, per the guide)"""
+    import subprocess
+    k = "void aud::(anonymous namespace)::k_melspec_r16<float, true, 1, false>(aud::MelspecArgs, aud::FastArgs)"
+    d = tmp_path / "prof"
+    (d / "stats" / "box" ).mkdir(parents=True)
+    (d / "stats" / "box" / "77_kernel_stats.csv").write_text(
+        '"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
+        '"%s",220,1100000,5000.0,97.1,4800,6100,80.0\n"other",3,30000,10000.0,2.9,1,2,3\n' % k)
+    for name, ctr, val in (("fetch", "FETCH_SIZE", 8000.0), ("write", "WRITE_SIZE", 4160.0)):
+        (d / name / "box").mkdir(parents=True)
+        rows = ['"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size",'
+                '"Kernel_Id","Kernel_Name","Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count",'
+                '"Accum_VGPR_Count","SGPR_Count","Counter_Name","Counter_Value","Start_Timestamp","End_Timestamp"']
+        for i in range(4):
+            rows.append('%d,%d,1,1,77,77,458752,9,"%s",256,40960,0,72,0,96,"%s",%s,1,2' % (i, i, k, ctr, val))
+        (d / name / "box" / "77_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    out = tmp_path / "profiles"
+    out.mkdir()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), str(d), "rXX", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "k_melspec_r16" in r.stdout and "5000.0" in r.stdout
+    t = json.load(open(out / "pmc_traffic.json"))
+    assert t["read_bytes"] == 2 * 8000.0 * 1024 and t["write_bytes"] == 4160.0 * 1024
+    assert t["read_bytes_raw_fetch_size"] == 8000.0 * 1024
+    assert t["hbm_bytes_per_launch"] == t["read_bytes"] + t["write_bytes"] and "r16" in t["kernel"]

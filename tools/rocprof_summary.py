@@ -18,6 +18,8 @@ def rows(pattern):
 def main():
     import json
     out, tag = sys.argv[1], sys.argv[2]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof_dir = sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, "profiles")
     traffic = {}
     print("# rocprofv3 summary %s" % tag)
     stats = list(rows(os.path.join(out, "stats", "**", "*kernel_stats.csv")))
@@ -58,8 +60,7 @@ def main():
         if "read_bytes" in v and "write_bytes" in v:
             best = {"kernel": k, "hbm_bytes_per_launch": v["read_bytes"] + v["write_bytes"], "tag": tag, **v}
     if best:
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        with open(os.path.join(root, "profiles", "pmc_traffic.json"), "w") as fh:
+        with open(os.path.join(prof_dir, "pmc_traffic.json"), "w") as fh:
             json.dump(best, fh, indent=1)
         print("## wrote profiles/pmc_traffic.json:", best)
 
