@@ -291,11 +291,11 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
     std::memset(&fastcfg, 0, sizeof(fastcfg));
     int fast_kind = aud_plan::kNoFast, n_groups = 0;
     const char* fast_name = "generic";
-    if (aud::melspec_r16_supported(N, d->step_samples, d->compute_dtype, r16_chunks, true, &fastcfg)) {
+    if (aud::melspec_r16_supported(N, d->step_samples, d->compute_dtype, r16_chunks, nf, true, &fastcfg)) {
         fast_kind = aud_plan::kR16;
         n_groups = 16;  // 256 threads = 16 frames x 16 filter groups
         fast_name = "r16x16";
-    } else if (aud::melspec_r25_supported(N, d->step_samples, d->compute_dtype, r16_chunks, &fastcfg)) {
+    } else if (aud::melspec_r25_supported(N, d->step_samples, d->compute_dtype, r16_chunks, nf, &fastcfg)) {
         fast_kind = aud_plan::kR25;
         n_groups = 8;  // 128 threads = 16 frames x 8 filter groups
         fast_name = "r25x8";
@@ -463,7 +463,7 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
         if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "r16_input: 0 (direct) or 1 (staged)");
         aud::FastArgs cfg = p->r16;
         if (!aud::melspec_r16_supported(p->d.win_samples, p->d.step_samples, p->d.compute_dtype, p->r16_chunks,
-                                        value == 0, &cfg))
+                                        p->d.mel.n_filters, value == 0, &cfg))
             return fail(c, AUD_EINVAL, "this r16x16 variant does not support the plan (odd step?)");
         cfg.ntile = value == 0 ? p->r16.ntile : 1;
         p->r16 = cfg;

@@ -3,6 +3,7 @@
 // power / log-power outputs, mel triangle reduction + log) that runs once the tile's power
 // spectrum is parked in LDS.
 #pragma once
+#include <type_traits>
 #include "kernels.h"
 
 namespace aud {
@@ -277,7 +278,7 @@ __device__ __forceinline__ void tile_spectrum_outputs(const MelspecArgs& a, cons
     }
 }
 
-template <typename TT, int NT, int F>
+template <typename TT, int NT, int F, bool SCHED_LDS = true>
 __device__ __forceinline__ void tile_epilogue(const MelspecArgs& a, const FastArgs& e, const TT* P, int Hp,
                                               const unsigned char* smem, const aud_item& it, int item, int t0,
                                               int tid, float* lds_out = nullptr, int lds_pitch = 0,
@@ -294,11 +295,26 @@ __device__ __forceinline__ void tile_epilogue(const MelspecArgs& a, const FastAr
     const quad_t* w4 = reinterpret_cast<const quad_t*>(smem + e.w4_off);
     const quad_t* prow = reinterpret_cast<const quad_t*>(P + ff * Hp);
     const TT loff = TT(a.mel_log_off), lmin = TT(a.mel_log_min);
-    for (int idx = e.grp_off[grp]; idx < e.grp_off[grp + 1]; ++idx) {
-        const int flt = e.grp_flt[idx];
+    // the filter-group schedule: the LDS copy made by stage_mel_weights (16-bit entries), or the plan's table in
+    // global memory for the kernel that has no LDS to spare for it
+    typedef typename std::conditional<SCHED_LDS, unsigned short, int>::type sched_t;
+    const sched_t* s_off;
+    const sched_t* s_flt;
+    const sched_t* s_chunk;
+    if constexpr (SCHED_LDS) {
+        s_off = reinterpret_cast<const sched_t*>(smem + e.sched_off);
+        s_flt = s_off + e.n_groups + 1;
+        s_chunk = s_flt + a.nf;
+    } else {
+        s_off = reinterpret_cast<const sched_t*>(e.grp_off);
+        s_flt = reinterpret_cast<const sched_t*>(e.grp_flt);
+        s_chunk = reinterpret_cast<const sched_t*>(e.chunk);
+    }
+    for (int idx = s_off[grp]; idx < int(s_off[grp + 1]); ++idx) {
+        const int flt = s_flt[idx];
         float res = 0.f;
         if (live) {
-            const int c0 = e.chunk[3 * flt], nc = e.chunk[3 * flt + 1], wo = e.chunk[3 * flt + 2];
+            const int c0 = s_chunk[3 * flt], nc = s_chunk[3 * flt + 1], wo = s_chunk[3 * flt + 2];
             TT sum = TT(0);
 #pragma unroll 4
             for (int c = 0; c < nc; ++c) {
@@ -392,6 +408,31 @@ __device__ __forceinline__ void stage_mel_weights(const FastArgs& e, unsigned ch
     const quad_t* __restrict__ gw = static_cast<const quad_t*>(e.w4);
     quad_t* lw = reinterpret_cast<quad_t*>(smem + e.w4_off);
     for (int c = tid; c < e.n_chunks; c += NT) lw[c] = gw[c];
+}
+
+// The filter-group schedule ([groups + 1] offsets | [nf] filter ids | [nf][3] chunk info) goes into LDS as 16-bit
+// entries (filter ids, chunk indices and offsets into w4 all stay far below 65536: LDS bounds them).  The epilogue
+// walks it once per filter; from global memory every step of that walk is a dependent load behind an
+// s_waitcnt vmcnt(0) that also waits for the previous filter's store.  Two steps so that the kernel can put the
+// operand loads between them: the fetch is issued first and costs two registers, the store waits only for it
+// (loads return in order), and the operand loads are neither delayed nor squeezed for registers.
+struct SchedRegs {
+    int v0, v1;
+};
+template <int NT>
+__device__ __forceinline__ SchedRegs mel_schedule_fetch(const FastArgs& e, int tid) {
+    SchedRegs r;
+    r.v0 = tid < e.n_sched ? e.grp_off[tid] : 0;
+    r.v1 = tid + NT < e.n_sched ? e.grp_off[tid + NT] : 0;
+    return r;
+}
+template <int NT>
+__device__ __forceinline__ void mel_schedule_store(const FastArgs& e, unsigned char* smem, int tid, const SchedRegs& r) {
+    unsigned short* ls = reinterpret_cast<unsigned short*>(smem + e.sched_off);
+    if (tid < e.n_sched) ls[tid] = static_cast<unsigned short>(r.v0);
+    if (tid + NT < e.n_sched) ls[tid + NT] = static_cast<unsigned short>(r.v1);
+#pragma unroll 1
+    for (int c = tid + 2 * NT; c < e.n_sched; c += NT) ls[c] = static_cast<unsigned short>(e.grp_off[c]);  // nf > ~120
 }
 
 }  // namespace aud

@@ -76,6 +76,9 @@ struct FastArgs {
     int p_off;             // byte offset of the power spectrum (aliases the span or the transpose buffer)
     int w4_off;            // byte offset of the LDS copy of the chunked mel weights
     int out_off;           // byte offset of the LDS mel tile (kernels that collect several frame groups)
+    int sched_off;         // byte offset of the LDS copy of the filter-group schedule (grp_off | grp_flt | chunk)
+    int n_sched;           // its length in ints: groups + 1 + 4 nf
+    int n_groups;          // filter groups of the epilogue (threads per workgroup / frames per tile)
     unsigned lds_bytes;    // dynamic LDS of the launch
     int n_chunks;          // number of 4-element chunks in w4
     const int* grp_off;    // [groups + 1] device: filter-group boundaries into grp_flt
@@ -125,12 +128,12 @@ int melspec_generic_pick_F(int M, int compute_dtype);
 hipError_t launch_melspec_generic(const MelspecArgs& a, int compute_dtype, hipStream_t st);
 
 // N = 512 fast path
-bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, bool direct, FastArgs* out);
+bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, int nf, bool direct, FastArgs* out);
 hipError_t melspec_r16_prepare(unsigned lds_bytes);
 hipError_t launch_melspec_r16(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
 
 // N = 400 fast path
-bool melspec_r25_supported(int N, int S, int compute_dtype, int n_chunks, FastArgs* out);
+bool melspec_r25_supported(int N, int S, int compute_dtype, int n_chunks, int nf, FastArgs* out);
 hipError_t melspec_r25_prepare(unsigned lds_bytes);
 hipError_t launch_melspec_r25(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
 

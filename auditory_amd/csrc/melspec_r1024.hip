@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_melspec_r1024(const MelspecArgs a, cons
     }
     __syncthreads();
 
-    tile_epilogue<TT, kNT, kF>(a, e, Pbase, kHp, smem, it, item, t0, tid, melbuf, kTile, sub * kF);
+    tile_epilogue<TT, kNT, kF, false>(a, e, Pbase, kHp, smem, it, item, t0, tid, melbuf, kTile, sub * kF);
     __syncthreads();  // the power spectrum is consumed: the next group may reuse the frame regions
   }
 
@@ -171,9 +171,14 @@ bool melspec_r1024_supported(int N, int S, int compute_dtype, int n_chunks, int 
     const size_t w4 = (size_t(n_chunks) * 4 * tsz + 31) & ~size_t(31);
     const size_t first = (frames + 31) & ~size_t(31);
     const size_t outb = size_t(nf) * kTile * sizeof(float);  // the 16-frame mel tile
+    // (no LDS copy of the filter-group schedule here: its 1.2 KB would cost the third workgroup per CU)
+    const int n_groups = 256 / kF, n_sched = 0;
     const size_t total = first + w4 + outb;
     if (total > 160 * 1024) return false;
     if (out) {
+        out->sched_off = 0;
+        out->n_sched = n_sched;
+        out->n_groups = n_groups;
         out->direct = 1;
         out->xch_off = 0;
         out->p_off = 0;

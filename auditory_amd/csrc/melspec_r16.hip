@@ -57,7 +57,7 @@ __device__ __forceinline__ void r16_load_direct(const MelspecArgs& a, const aud_
 
 // everything after the pass-1 operands are in registers: both DFT passes, the transpose, the split, the
 // power spectrum and the tile epilogue, for the 16 frames t0 .. t0 + 15
-template <typename TT, bool DIRECT, bool MELMFMA>
+template <typename TT, bool DIRECT, bool MELMFMA, bool SCHED_LDS>
 __device__ __forceinline__ void r16_tile(const MelspecArgs& a, const FastArgs& e, unsigned char* smem, C2<TT>* xch,
                                          TT* Pbase, const C2<TT>* __restrict__ tw, const aud_item& it, int item,
                                          int t0, int tid, int f, int j, C2<TT> (&v)[16]) {
@@ -138,7 +138,7 @@ __device__ __forceinline__ void r16_tile(const MelspecArgs& a, const FastArgs& e
         tile_spectrum_outputs<TT, 256, kF>(a, Pbase, kHp, it, item, t0, tid);
         tile_mel_mfma<256, kF>(a, e, Pbase, kHp, it, item, t0, tid);
     } else {
-        tile_epilogue<TT, 256, kF>(a, e, Pbase, kHp, smem, it, item, t0, tid);
+        tile_epilogue<TT, 256, kF, SCHED_LDS>(a, e, Pbase, kHp, smem, it, item, t0, tid);
     }
 }
 
@@ -164,6 +164,12 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
     const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_512^k
     const int64_t lim = it.sig_len;
     (void)sigbuf; (void)lim; (void)S;
+
+    // the two-tile kernel keeps the schedule in global memory: with 64 operand registers in flight the LDS copy
+    // costs it its fourth wave per SIMD
+    constexpr bool kSchedLds = NTILE == 1;
+    SchedRegs sched{0, 0};
+    if constexpr (kSchedLds) sched = mel_schedule_fetch<256>(e, tid);  // issued ahead of the operand loads
 
     C2<TT> v[16];
     C2<TT> v2[NTILE > 1 ? 16 : 1];
@@ -198,7 +204,9 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
         }
     }
 
-    // the chunked mel weights (a few KB) ride along into LDS; first used after the last barrier
+    // the filter-group schedule and the chunked mel weights (a few KB) ride along into LDS; first used after the
+    // last barrier
+    if constexpr (kSchedLds) mel_schedule_store<256>(e, smem, tid, sched);
     stage_mel_weights<TT, 256>(e, smem, tid);
 
     if constexpr (!DIRECT) {
@@ -210,11 +218,11 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) v[n1] = fr[16 * n1];
     }
-    r16_tile<TT, DIRECT, MELMFMA>(a, e, smem, xch, Pbase, tw, it, item, t0, tid, f, j, v);
+    r16_tile<TT, DIRECT, MELMFMA, kSchedLds>(a, e, smem, xch, Pbase, tw, it, item, t0, tid, f, j, v);
     if constexpr (NTILE > 1) {
         if (t0 + kF < T) {          // uniform: the item has a second tile for this workgroup
             __syncthreads();        // the power spectrum of tile 1 is consumed: the buffers are free again
-            r16_tile<TT, DIRECT, MELMFMA>(a, e, smem, xch, Pbase, tw, it, item, t0 + kF, tid, f, j, v2);
+            r16_tile<TT, DIRECT, MELMFMA, kSchedLds>(a, e, smem, xch, Pbase, tw, it, item, t0 + kF, tid, f, j, v2);
         }
     }
 }
@@ -222,8 +230,10 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
 
 }  // namespace
 
-bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, bool direct, FastArgs* out) {
-    if (N != kN || S < 1) return false;
+bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, int nf, bool direct, FastArgs* out) {
+    if (N != kN || S < 1 || nf < 1) return false;
+    const int n_groups = 256 / kF, n_sched = n_groups + 1 + 4 * nf;
+    const size_t sched = (size_t(n_sched) * 2 + 15) & ~size_t(15);  // kept as uint16 in LDS
     if (!direct && (S & 1)) return false;  // the staged variant reads 8-byte pairs from LDS
     const size_t tsz = compute_dtype == AUD_F64 ? 8 : 4;
     const size_t rowc = compute_dtype == AUD_F64 ? 17 : 18;
@@ -243,9 +253,12 @@ bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, bool d
         xch_off = first;
         first += xch;
     }
-    const size_t total = first + w4;
+    const size_t total = first + w4 + sched;
     if (total > 160 * 1024) return false;
     if (out) {
+        out->sched_off = int(first + w4);
+        out->n_sched = n_sched;
+        out->n_groups = n_groups;
         out->xch_off = int(xch_off);
         out->p_off = int(p_off);
         out->w4_off = int(first);

@@ -52,11 +52,16 @@ __global__ __launch_bounds__(128) void k_melspec_r25(const MelspecArgs a, const 
     const aud_item it = a.items[item];
     const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_400^k
 
-    stage_mel_weights<TT, kNT>(e, smem, tid);
+    const SchedRegs sched = mel_schedule_fetch<kNT>(e, tid);  // issued ahead of the operand loads
 
     // ---- pass A operands: z[8 n1 + j] = (x[16 n1 + 2j], x[16 n1 + 2j + 1]), n1 = 0..24 ---------
     C2<TT> v[25];
     load_frame_pairs<TT, 25, 8, kN>(a, it, t0 + f, j, v);
+
+    // the filter-group schedule and the chunked mel weights ride along into LDS behind the operand loads; first
+    // used after the last barrier
+    mel_schedule_store<kNT>(e, smem, tid, sched);
+    stage_mel_weights<TT, kNT>(e, smem, tid);
 
     // ---- pass A: 25-point DFT over n1, twiddle W_200^(j k1) = W_400^(2 j k1), column write -------
     SmallDft<TT, 25>::run(v, tw, kN);
@@ -140,8 +145,10 @@ __global__ __launch_bounds__(128) void k_melspec_r25(const MelspecArgs a, const 
 
 }  // namespace
 
-bool melspec_r25_supported(int N, int S, int compute_dtype, int n_chunks, FastArgs* out) {
-    if (N != kN || S < 1) return false;
+bool melspec_r25_supported(int N, int S, int compute_dtype, int n_chunks, int nf, FastArgs* out) {
+    if (N != kN || S < 1 || nf < 1) return false;
+    const int n_groups = kNT / kF, n_sched = n_groups + 1 + 4 * nf;
+    const size_t sched = (size_t(n_sched) * 2 + 15) & ~size_t(15);  // kept as uint16 in LDS
     const size_t tsz = compute_dtype == AUD_F64 ? 8 : 4;
     const size_t framec = compute_dtype == AUD_F64 ? 226 : 264;
     const size_t xch = size_t(kF) * framec * 2 * tsz;
@@ -149,9 +156,12 @@ bool melspec_r25_supported(int N, int S, int compute_dtype, int n_chunks, FastAr
     const size_t w4 = (size_t(n_chunks) * 4 * tsz + 31) & ~size_t(31);
     size_t first = xch > pbytes ? xch : pbytes;
     first = (first + 31) & ~size_t(31);
-    const size_t total = first + w4;
+    const size_t total = first + w4 + sched;
     if (total > 160 * 1024) return false;
     if (out) {
+        out->sched_off = int(first + w4);
+        out->n_sched = n_sched;
+        out->n_groups = n_groups;
         out->direct = 1;
         out->xch_off = 0;
         out->p_off = 0;

@@ -36,6 +36,8 @@ CASES = [  # config, seconds of audio, rows, segments to process per row
     ("cfg5_44k_n2048_nf128", 0.25, 2, [0]),              # NaN mel row (Q3), T=504 mostly masked
     ("odd_15k_n375_nf32", 0.3, 1, [0, 1]),
     ("mixed_16k_n480_nf32", 0.5, 1, [0, 1]),
+    ("many_16k_n512_nf124", 0.3, 2, [0, 1]),             # degenerate low triangles (NaN rows), long schedule
+    ("many_16k_n400_nf64", 0.3, 2, [0, 1]),
 ]
 
 GABOR_DEFAULT = dict(size=(9, 9), stride=(3, 3), gain=2.0, specs=W.DEFAULT_GABOR_SPECS)

@@ -16,6 +16,9 @@ CONFIGS = {
     "cfg5_44k_n2048_nf128": (44100, 46.44, 10.0, 5000.0, 5000.0, 2, 128, 0.0, 22050.0),
     "odd_15k_n375_nf32": (15000, 25.0, 10.0, 100.0, 100.0, 2, 32, 0.0, 7000.0),     # 375 = 3 * 5^3
     "mixed_16k_n480_nf32": (16000, 30.0, 10.0, 200.0, 200.0, 3, 32, 300.0, 8000.0),  # 480 = 2^5 * 3 * 5
+    # many narrow filters: the filter-group schedule outgrows one / two entries per thread of the staging code
+    "many_16k_n512_nf124": (16000, 32.0, 10.0, 100.0, 100.0, 2, 124, 0.0, 8000.0),
+    "many_16k_n400_nf64": (16000, 25.0, 10.0, 100.0, 100.0, 2, 64, 0.0, 8000.0),
 }
 
 
