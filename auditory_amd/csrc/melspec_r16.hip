@@ -57,6 +57,7 @@ __device__ __forceinline__ void r16_load_direct(const MelspecArgs& a, const aud_
 
 // everything after the pass-1 operands are in registers: both DFT passes, the transpose, the split, the
 // power spectrum and the tile epilogue, for the 16 frames t0 .. t0 + 15
+// SCHED_LDS: the one-tile kernels, which have registers and LDS to spare (schedule in LDS, split twiddles early)
 template <typename TT, bool DIRECT, bool MELMFMA, bool SCHED_LDS>
 __device__ __forceinline__ void r16_tile(const MelspecArgs& a, const FastArgs& e, unsigned char* smem, C2<TT>* xch,
                                          TT* Pbase, const C2<TT>* __restrict__ tw, const aud_item& it, int item,
@@ -93,6 +94,13 @@ __device__ __forceinline__ void r16_tile(const MelspecArgs& a, const FastArgs& e
             for (int n2 = 0; n2 < 16; ++n2) v[n2] = row[n2];
         }
     }
+    // the split's twiddles W_512^(j + 16 q): requested here so that the second DFT covers their latency (the
+    // compiler cannot lift them over the barrier by itself).  16 registers: one-tile kernels only.
+    C2<TT> wsp[SCHED_LDS ? 8 : 1];
+    if constexpr (SCHED_LDS) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wsp[q] = tw[j + 16 * q];
+    }
     if constexpr (DIRECT) __syncthreads();  // P reuses the transpose buffer: every row must have been read
     dft16(v);
 
@@ -115,7 +123,9 @@ __device__ __forceinline__ void r16_tile(const MelspecArgs& a, const FastArgs& e
             B.y = __shfl(mine_y, partner, 64);
             const C2<TT> A = v[q];
             const int k = j + 16 * q;
-            const C2<TT> w = tw[k];                     // W_512^k
+            C2<TT> w;                                   // W_512^k
+            if constexpr (SCHED_LDS) w = wsp[q];
+            else w = tw[k];
             const C2<TT> E = {A.x + B.x, A.y - B.y};    // A + conj(B)
             const C2<TT> D = {A.x - B.x, A.y + B.y};    // A - conj(B)
             const C2<TT> mD = {D.y, -D.x};              // -i D
