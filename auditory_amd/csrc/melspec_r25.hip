@@ -73,6 +73,15 @@ __global__ __launch_bounds__(128) void k_melspec_r25(const MelspecArgs a, const 
     }
     __syncthreads();
 
+    // the split's twiddles W_400^(j + 8 i): requested here so that pass B covers their latency (the compiler
+    // cannot lift them over the barrier behind pass B by itself)
+    C2<TT> wsp[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        const int k = j + 8 * i;
+        wsp[i] = tw[k <= kM / 2 ? k : 0];
+    }
+
     // ---- pass B: rows k1 = j, j+8, j+16 (and 24 on lane 0): 8-point DFT over n2, in place --------
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(128) void k_melspec_r25(const MelspecArgs a, const 
                 const int kb = (k == 0) ? 0 : kM - k;
                 const C2<TT> A = Z[(k % 25) * Layout<TT>::kRowC + k / 25];
                 const C2<TT> B = Z[(kb % 25) * Layout<TT>::kRowC + kb / 25];
-                const C2<TT> w = tw[k];
+                const C2<TT> w = wsp[i];
                 const C2<TT> E = {A.x + B.x, A.y - B.y};
                 const C2<TT> D = {A.x - B.x, A.y + B.y};
                 const C2<TT> mD = {D.y, -D.x};
