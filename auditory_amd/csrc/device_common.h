@@ -295,6 +295,7 @@ __device__ __forceinline__ void tile_epilogue(const MelspecArgs& a, const FastAr
     const quad_t* w4 = reinterpret_cast<const quad_t*>(smem + e.w4_off);
     const quad_t* prow = reinterpret_cast<const quad_t*>(P + ff * Hp);
     const TT loff = TT(a.mel_log_off), lmin = TT(a.mel_log_min);
+    float* mel_col = a.mel + (size_t(item) * a.nf * T + sstep);  // one 64-bit base, then flt * T per filter
     // the filter-group schedule: the LDS copy made by stage_mel_weights (16-bit entries), or the plan's table in
     // global memory for the kernel that has no LDS to spare for it
     typedef typename std::conditional<SCHED_LDS, unsigned short, int>::type sched_t;
@@ -338,7 +339,7 @@ __device__ __forceinline__ void tile_epilogue(const MelspecArgs& a, const FastAr
         if (lds_out)
             lds_out[flt * lds_pitch + lds_col0 + ff] = res;
         else
-            a.mel[(size_t(item) * a.nf + flt) * T + sstep] = res;
+            mel_col[size_t(flt) * T] = res;  // MelFBankSegment[item][flt][sstep]
     }
 }
 
