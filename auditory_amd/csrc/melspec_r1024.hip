@@ -85,6 +85,12 @@ __global__ __launch_bounds__(256) void k_melspec_r1024(const MelspecArgs a, cons
 #pragma unroll
     for (int k2 = 1; k2 < 16; ++k2) v[k2] = cmul(v[k2], tw[32 * n3 * k2]);
 
+    // the split's twiddles W_2048^(l + 64 i): requested here so that stage 3 and the spectrum scatter cover their
+    // latency (the compiler cannot lift them over the two barriers in between by itself)
+    C2<TT> wsp[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wsp[i] = tw[l + 64 * i];
+
     // ---- stage 3: 4-point DFT over n3 across the quad (lanes 4 k1 .. 4 k1 + 3) ----------------------
     // xor-2 butterfly, then xor-1 butterfly with the -i twiddle on the odd branch; lane n3 ends with
     // output index k3 = bitrev2(n3): n3 0,1,2,3 -> k3 0,2,1,3
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(256) void k_melspec_r1024(const MelspecArgs a, cons
         const int kb = (k == 0) ? 0 : kM - k;
         const C2<TT> A = fr[zpos(k)];
         const C2<TT> B = fr[zpos(kb)];
-        const C2<TT> w = tw[k];  // W_2048^k
+        const C2<TT> w = wsp[i];  // W_2048^k
         const C2<TT> E = {A.x + B.x, A.y - B.y};
         const C2<TT> D = {A.x - B.x, A.y + B.y};
         const C2<TT> mD = {D.y, -D.x};
