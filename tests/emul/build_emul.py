@@ -41,15 +41,19 @@ def _build(variant, force):
              if f.endswith((".h", ".hpp", ".inc"))]
     if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
-    cmd = ["g++", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
-           "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-function", "-Wno-attributes"] + FLAGS[variant] + [
-           "-I" + HERE, "-I" + product_build.INCLUDE, "-I" + product_build.CSRC, "-o", out]
-    for s in srcs:
-        cmd += ["-x", "c++", s]
-    cmd += ["-ldl"]
-    tmp = out + ".tmp%d" % os.getpid()
-    cmd[cmd.index(out)] = tmp
-    subprocess.check_call(cmd)
+    common = ["g++", "-std=c++17", "-fPIC", "-pthread", "-ffp-contract=off",
+              "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-function", "-Wno-attributes"] + FLAGS[variant] + [
+              "-I" + HERE, "-I" + product_build.INCLUDE, "-I" + product_build.CSRC]
+    # one compile job per source, a few at a time (the sanitizer variants take a minute otherwise), then one link
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    with tempfile.TemporaryDirectory(prefix="aud_emul_") as tmpdir:
+        objs = [os.path.join(tmpdir, "%d_%s.o" % (i, os.path.basename(src))) for i, src in enumerate(srcs)]
+        with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as pool:
+            list(pool.map(lambda so: subprocess.check_call(common + ["-c", "-x", "c++", so[0], "-o", so[1]]),
+                          zip(srcs, objs)))
+        tmp = out + ".tmp%d" % os.getpid()
+        subprocess.check_call(common + ["-shared", "-o", tmp] + objs + ["-ldl"])
     os.replace(tmp, out)  # readers never see a half-written library
     return out
 
