@@ -61,6 +61,22 @@ class BatchProcessor:
                       mel.data_ptr(), pools_y, pools_x, gabor.data_ptr(), self._stream())
         return mel, gabor
 
+    def kwta(self, gabor, params, act=None, pool=True, state=None, cycles=None, sum_order=0):
+        """SndEnv.ApplyKwta on a device-resident gabor tensor [n, PY, PX, UY, UX] (settling starts from the raw
+        values); `params` is an auditory_amd.kwta.KWTA.  Returns the settled tensor."""
+        from . import kwta as kwta_mod
+        if act is None:
+            act = torch.empty_like(gabor)
+        kwta_mod.kwta_batch_dev(params, gabor, act, pool=pool, state=state, cycles=cycles,
+                                device=self.plan.ctx.device, sum_order=sum_order, stream=self._stream())
+        return act
+
+    def process_sndenv(self, sig, items_dev, n_items, pools_y, pools_x, params, state=None):
+        """ProcessSegment + ApplyGabor with Kwta.On for every item, device-resident end to end:
+        returns (mel, raw gabor, settled gabor)."""
+        mel, gab = self.process(sig, items_dev, n_items, pools_y, pools_x)
+        return mel, gab, self.kwta(gab, params, state=state)
+
 
 def allgather_features(local, world_size, group=None, n_total=None):
     """The one collective of the path: reassemble the per-rank [B_r, ...] slabs into [B, ...] on

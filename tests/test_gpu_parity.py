@@ -201,8 +201,10 @@ def test_process_then_kwta_device_resident(orc, torch_cuda, n=6):
     plan = W.product_plan(oc, capi.AUD_F32, PC.GABOR_DEFAULT)
     bp = BatchProcessor(plan, "cuda:0")
     items = bp.upload_items(runtime.make_items(np.arange(n) * L, [L] * n, [0] * n))
-    _, gab = bp.process(torch.from_numpy(sig.astype(np.float32)).cuda().view(-1), items, n, 11, 32)
+    dsig = torch.from_numpy(sig.astype(np.float32)).cuda().view(-1)
+    _, gab = bp.process(dsig, items, n, 11, 32)
     k, ko = PC._kwta_pair(orc)
+    _, gab2, act2 = bp.process_sndenv(dsig, items, n, 11, 32, k)     # the one-call form
     act = torch.empty(gab.shape, dtype=torch.float32, device=gab.device)
     cyc = torch.zeros(n, dtype=torch.int32, device=gab.device)
     state = torch.zeros((n, 11 * 32, 2), dtype=torch.float32, device=gab.device)
@@ -218,6 +220,7 @@ def test_process_then_kwta_device_resident(orc, torch_cuda, n=6):
     assert np.array_equal(state.cpu().numpy(), st_o)
     # the gabor tensor was only read
     assert np.array_equal(gab.cpu().numpy(), raw)
+    assert np.array_equal(gab2.cpu().numpy(), raw) and np.array_equal(act2.cpu().numpy(), act.cpu().numpy())
     plan.close()
 
 
