@@ -271,8 +271,14 @@ static void dft_power(const orc_dft_params* d, int step, int win_samples, const 
 int orc_dft_filter(const orc_dft_params* d, const orc_fft_plan* plan, int step,
                    const double* window, int win_samples, double* power, double* log_power,
                    double* power_seg, double* log_power_seg, int T) {
-    double* c = (double*)malloc(sizeof(double) * 2 * (size_t)win_samples);   /* dft.go:43 */
-    double* o = (double*)malloc(sizeof(double) * 2 * (size_t)win_samples);
+    if (win_samples < 1) return ORC_EINVAL;
+    double* c = (double*)calloc(2 * (size_t)win_samples, sizeof(double));   /* dft.go:43 */
+    double* o = (double*)calloc(2 * (size_t)win_samples, sizeof(double));
+    if (!c || !o) {
+        free(c);
+        free(o);
+        return ORC_EINVAL;
+    }
     for (int i = 0; i < win_samples; i++) { /* dft.go:53-59 */
         c[2 * i] = window[i];
         c[2 * i + 1] = 0;
