@@ -194,6 +194,22 @@ def case_gabor_4d_and_2d_vs_oracle(orc, cdt):
         plan.gabor_host(mel, big)
     assert (big == 7.0).all()
     plan.close()
+    # processspeech hands Convolve a 5-D tensor (processspeech.go:265): "The output tensor should have 2 or 4
+    # dimensions" is logged and nothing is written (Q9, Q11); so does a mel matrix narrower than the filters
+    from auditory_amd import agabor
+    fs = agabor.FilterSet()
+    fs.SizeX = fs.SizeY = 9
+    fs.StrideX = fs.StrideY = 3
+    fs.Gain = 2.0
+    agabor.ToTensor([agabor.Filter(WaveLen=s["wave_len"], Orientation=s["orientation"], SigmaWidth=s["sigma_width"],
+                                   SigmaLength=s["sigma_length"], PhaseOffset=s["phase_offset"],
+                                   CircleEdge=bool(s["circle_edge"])) for s in W.DEFAULT_GABOR_SPECS], fs)
+    five = np.full((1, 11, 32, 2, 8), 7.0, np.float32)
+    agabor.Convolve(mel[0], fs, five, False)
+    assert (five == 7.0).all()
+    narrow = np.full((11, 32, 2, 8), 7.0, np.float32)
+    agabor.Convolve(mel[0][:, :5], fs, narrow, False)
+    assert (narrow == 7.0).all()
     # 2-D output, gaborview sizing, both orders
     k4 = orc.gabor_to_tensor(W.DEFAULT_GABOR_SPECS[::2], 8, 8)
     plan = W.product_plan(oc, cdt, GABOR_VIEW)
