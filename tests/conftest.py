@@ -7,6 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import memguard  # noqa: E402  resident-memory ceiling: a runaway allocation ends this process, not the GPU box
+
+memguard.install()
 
 
 @pytest.hookimpl(tryfirst=True)
