@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libauditory_hip.so")
-SOURCES = ["host_setup.cpp", "capi.hip", "melspec_generic.hip", "melspec_r16.hip", "melspec_r25.hip", "melspec_r1024.hip", "smooth_mel.hip", "mfcc.hip", "gabor.hip", "kwta.hip"]
+SOURCES = ["host_setup.cpp", "capi.hip", "melspec_generic.hip", "melspec_wave.hip", "melspec_r16.hip", "melspec_r25.hip", "melspec_r1024.hip", "smooth_mel.hip", "mfcc.hip", "gabor.hip", "kwta.hip"]
 
 
 def _hipcc():
@@ -30,18 +30,46 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> libauditory_hip.so.  Returns the path."""
+def _flags():
+    # -fno-slp-vectorize: hipcc otherwise packs neighbouring f32 adds/muls of the butterflies into
+    # v_pk_* instructions, which on gfx950 issue no faster than two scalar ops (measured: profiles/
+    # r02_valu_issue_rates.txt) and cost ~90 extra v_mov per wave to pair registers up -- see DESIGN.md 4.1
+    return ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC",
+            "-Xarch_host", "-ffp-contract=off", "-I" + INCLUDE, "-I" + CSRC]
+
+
+def build(force=False, verbose=False, stamps=False):
+    """hipcc --offload-arch=gfx950 -> libauditory_hip.so.  One compile job per source (only the stale ones, a few
+    at a time), then one link.  Returns the path.  stamps=True builds the diagnostic variant
+    libauditory_hip_stamps.so (-DAUD_STAMPS: s_memtime stamps in the wave kernels, tools/stamp_profile.py)."""
+    if stamps:
+        return _build(True, verbose, os.path.join(HERE, "obj_stamps"), LIB.replace(".so", "_stamps.so"), ["-DAUD_STAMPS=1"])
     if not force and not stale():
         return LIB
-    # -fno-slp-vectorize: hipcc otherwise packs neighbouring f32 adds/muls of the butterflies into
-    # v_pk_* instructions, which on gfx950 issue no faster than two scalar ops and cost ~90 extra
-    # v_mov per wave to pair registers up (and 20 more VGPRs) -- see DESIGN.md 4.1
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared",
-           "-Xarch_host", "-ffp-contract=off", "-I" + INCLUDE, "-I" + CSRC, "-o", LIB] + sources() + ["-ldl"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    return _build(force, verbose, os.path.join(HERE, "obj"), LIB, [])
+
+
+def _build(force, verbose, objdir, LIB, extra):
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(INCLUDE, "auditory_hip.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC)
+                                                           if f.endswith((".h", ".hpp", ".inc"))]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
+            jobs.append([_hipcc()] + _flags() + extra + ["-x", "hip", "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as pool:
+        list(pool.map(run, jobs))
+    run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

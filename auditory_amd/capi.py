@@ -45,7 +45,8 @@ class GaborSet(C.Structure):
 
 
 class Item(C.Structure):
-    _fields_ = [("sig_off", C.c_int64), ("sig_len", C.c_int32), ("start0", C.c_int32)]
+    _fields_ = [("sig_off", C.c_int64), ("sig_len", C.c_int32), ("start0", C.c_int32),
+                ("sig_stride", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PlanDesc(C.Structure):

@@ -41,6 +41,11 @@ struct aud_plan {
     int xcd_remap = 1;         // workgroup -> tile order keeps an XCD on one run of tiles (kernels.h)
     int r16_chunks = 0;
     aud::FastArgs r16{};
+    // wave-autonomous kernel of the same window length (melspec_wave.hip), the default where it exists
+    enum Wave { kNoWave = 0, kW16 = 1, kW25 = 2 };
+    int wave_kind = kNoWave;
+    bool use_wave = false;     // false: the workgroup-tile kernel of fast_kind (plan option "kernel" = 2)
+    aud::FastArgs wv{};
     int* d_grp = nullptr;  // [17 + nf + 3 nf]: group offsets, filter ids, per-filter chunk info
     void* d_w4 = nullptr;  // chunked triangle weights
     int* d_blk = nullptr;     // matrix-pipe mel variant (r16x16, float32): per 16-filter block {chunk0, steps, offset}
@@ -51,10 +56,17 @@ struct aud_plan {
     int32_t* d_bin_pts = nullptr;
     void* d_gabor = nullptr;
     void* d_dct = nullptr;  // [mfcc_coefs][nf] DCT-I rows
+    unsigned long long stamps = 0;  // diagnostic builds (-DAUD_STAMPS): device buffer for the phase stamps
     const char* family = "generic";
 };
 
 namespace {
+
+// buffer element holding the last sample of an item's stream (-1 for an empty stream)
+int64_t item_last(const aud_item& it) {
+    if (it.sig_len <= 0) return it.sig_off - 1;
+    return it.sig_off + int64_t(it.sig_len - 1) * (it.sig_stride > 1 ? it.sig_stride : 1);
+}
 
 int fail(aud_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg;
@@ -155,15 +167,35 @@ void fill_melspec_args(const aud_plan* p, aud::MelspecArgs* a) {
     a->dft_log_off = d.dft.log_offset;
     a->F = p->F_generic;
     a->xcd_remap = p->xcd_remap;
+    a->stamps = reinterpret_cast<unsigned long long*>(p->stamps);
 }
 
 // the plan's frame -> power -> mel kernel (whatever family it selected), raw power, no smoothing
 hipError_t launch_frames(const aud_plan* p, const aud::MelspecArgs& a, hipStream_t st) {
+    if (p->use_fast && p->use_wave && p->wave_kind == aud_plan::kW16)
+        return aud::launch_melspec_w16(a, p->wv, p->d.compute_dtype, st);
+    if (p->use_fast && p->use_wave && p->wave_kind == aud_plan::kW25)
+        return aud::launch_melspec_w25(a, p->wv, p->d.compute_dtype, st);
     if (p->use_fast && p->fast_kind == aud_plan::kR16) return aud::launch_melspec_r16(a, p->r16, p->d.compute_dtype, st);
     if (p->use_fast && p->fast_kind == aud_plan::kR25) return aud::launch_melspec_r25(a, p->r16, p->d.compute_dtype, st);
     if (p->use_fast && p->fast_kind == aud_plan::kR1024)
         return aud::launch_melspec_r1024(a, p->r16, p->d.compute_dtype, st);
     return aud::launch_melspec_generic(a, p->d.compute_dtype, st);
+}
+
+const char* plan_family(const aud_plan* p);
+// the r16_* switches are variants of the workgroup-tile kernel: setting one selects that kernel
+void select_tile_kernel(aud_plan* p) {
+    p->use_fast = true;
+    p->use_wave = false;
+    p->family = plan_family(p);
+}
+
+const char* plan_family(const aud_plan* p) {
+    if (!p->use_fast || p->fast_kind == aud_plan::kNoFast) return "generic";
+    if (p->use_wave && p->wave_kind == aud_plan::kW16) return "w16x16";
+    if (p->use_wave && p->wave_kind == aud_plan::kW25) return "w25x8";
+    return p->fast_kind == aud_plan::kR16 ? "r16x16" : p->fast_kind == aud_plan::kR25 ? "r25x8" : "r16x16x4";
 }
 
 }  // namespace
@@ -409,6 +441,33 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
             p->r16.n_blocks = p->n_blocks;
             p->r16.blk = p->d_blk;
             p->r16.atab = p->d_atab;
+            // the wave-autonomous kernel of this window length shares the tables (same number of filter groups)
+            aud::FastArgs wcfg;
+            int wave_kind = aud_plan::kNoWave;
+            if (fast_kind == aud_plan::kR16 &&
+                aud::melspec_w16_supported(N, d->step_samples, d->compute_dtype, r16_chunks, nf, &wcfg))
+                wave_kind = aud_plan::kW16;
+            else if (fast_kind == aud_plan::kR25 &&
+                     aud::melspec_w25_supported(N, d->step_samples, d->compute_dtype, r16_chunks, nf, &wcfg))
+                wave_kind = aud_plan::kW25;
+            if (wave_kind != aud_plan::kNoWave && wcfg.lds_bytes > 64u * 1024u) {
+                const hipError_t pe = wave_kind == aud_plan::kW16 ? aud::melspec_w16_prepare(wcfg.lds_bytes)
+                                                                  : aud::melspec_w25_prepare(wcfg.lds_bytes);
+                if (pe != hipSuccess) {
+                    (void)hipGetLastError();
+                    wave_kind = aud_plan::kNoWave;
+                }
+            }
+            if (wave_kind != aud_plan::kNoWave) {
+                wcfg.grp_off = p->r16.grp_off;
+                wcfg.grp_flt = p->r16.grp_flt;
+                wcfg.chunk = p->r16.chunk;
+                wcfg.w4 = p->r16.w4;
+                p->wv = wcfg;
+                p->wave_kind = wave_kind;
+                p->use_wave = true;
+                p->family = plan_family(p);
+            }
         }
     }
     if (rc != AUD_OK) {
@@ -441,22 +500,14 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
     if (!p || !name) return AUD_EINVAL;
     aud_ctx* c = p->ctx;
     const std::string key(name);
-    if (key == "kernel") {  // 0 = automatic choice, 1 = force the generic any-N kernel
-        if (value == 1) {
-            p->use_fast = false;
-            p->family = "generic";
-            return AUD_OK;
-        }
-        if (value == 0) {
-            if (p->fast_kind != aud_plan::kNoFast) {
-                p->use_fast = true;
-                p->family = p->fast_kind == aud_plan::kR16   ? "r16x16"
-                            : p->fast_kind == aud_plan::kR25 ? "r25x8"
-                                                             : "r16x16x4";
-            }
-            return AUD_OK;
-        }
-        return fail(c, AUD_EINVAL, "kernel: 0 (auto) or 1 (generic)");
+    if (key == "kernel") {  // 0 = automatic choice, 1 = the generic any-N kernel, 2 = the workgroup-tile kernel
+        if (value < 0 || value > 2) return fail(c, AUD_EINVAL, "kernel: 0 (auto), 1 (generic) or 2 (workgroup-tile family)");
+        if (value == 2 && p->fast_kind == aud_plan::kNoFast)
+            return fail(c, AUD_EINVAL, "kernel = 2: this window length has no workgroup-tile kernel");
+        p->use_fast = value != 1 && p->fast_kind != aud_plan::kNoFast;
+        p->use_wave = value == 0 && p->wave_kind != aud_plan::kNoWave;
+        p->family = plan_family(p);
+        return AUD_OK;
     }
     if (key == "r16_input") {  // 0 = operands straight from global memory, 1 = staged through LDS
         if (p->fast_kind != aud_plan::kR16) return fail(c, AUD_EINVAL, "plan has no r16x16 kernel");
@@ -467,6 +518,7 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
             return fail(c, AUD_EINVAL, "this r16x16 variant does not support the plan (odd step?)");
         cfg.ntile = value == 0 ? p->r16.ntile : 1;
         p->r16 = cfg;
+        select_tile_kernel(p);
         return AUD_OK;
     }
     if (key == "r16_tiles") {  // 16-frame tiles per workgroup of the direct r16x16 kernel: 1 or 2 (second prefetched)
@@ -474,6 +526,7 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
         if (value != 1 && value != 2) return fail(c, AUD_EINVAL, "r16_tiles: 1 or 2");
         if (value == 2 && !p->r16.direct) return fail(c, AUD_EINVAL, "r16_tiles = 2 needs the direct input variant");
         p->r16.ntile = value;
+        select_tile_kernel(p);
         return AUD_OK;
     }
     if (key == "xcd_remap") {  // 1 (default): every XCD walks a contiguous run of tiles; 0: tiles in workgroup-id order
@@ -487,8 +540,13 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
         if (value == 1 && p->d.compute_dtype != AUD_F32)
             return fail(c, AUD_EINVAL, "r16_mel = 1 is a float32 variant (v_mfma_f32_16x16x4_f32)");
         p->r16.mel_mfma = value;
+        select_tile_kernel(p);
         return AUD_OK;
     }
+#ifdef AUD_STAMPS
+    if (key == "stamps_lo") { p->stamps = (p->stamps & 0xFFFFFFFF00000000ull) | uint32_t(value); return AUD_OK; }
+    if (key == "stamps_hi") { p->stamps = (p->stamps & 0xFFFFFFFFull) | (uint64_t(uint32_t(value)) << 32); return AUD_OK; }
+#endif
     return fail(c, AUD_EINVAL, "unknown option");
 }
 
@@ -652,7 +710,7 @@ int aud_melspec_batch_host(aud_plan* p, const double* sig, int64_t sig_total, co
         return fail(c, AUD_EINVAL, "null buffer");
     if (n_items == 0) return AUD_OK;
     for (int i = 0; i < n_items; ++i)
-        if (items[i].sig_off < 0 || items[i].sig_len < 0 || items[i].sig_off + items[i].sig_len > sig_total)
+        if (items[i].sig_off < 0 || items[i].sig_len < 0 || items[i].sig_stride < 0 || item_last(items[i]) >= sig_total)
             return fail(c, AUD_EINVAL, "item outside the signal buffer");
     AUD_HIP(c, make_current(c));
     const int nf = p->d.mel.n_filters, T = p->d.segment_steps, H = p->H;
@@ -871,7 +929,7 @@ int aud_melspec_mfcc_batch_host(aud_plan* p, const double* sig, int64_t sig_tota
     if (delta_deltas && !deltas) return fail(c, AUD_EINVAL, "delta_deltas needs deltas");
     if (n_items == 0) return AUD_OK;
     for (int i = 0; i < n_items; ++i)
-        if (items[i].sig_off < 0 || items[i].sig_len < 0 || items[i].sig_off + items[i].sig_len > sig_total)
+        if (items[i].sig_off < 0 || items[i].sig_len < 0 || items[i].sig_stride < 0 || item_last(items[i]) >= sig_total)
             return fail(c, AUD_EINVAL, "item outside the signal buffer");
     AUD_HIP(c, make_current(c));
     const int nf = p->d.mel.n_filters, T = p->d.segment_steps, H = p->H, nc = p->d.mfcc_coefs;

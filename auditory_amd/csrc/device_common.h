@@ -185,12 +185,28 @@ __device__ __forceinline__ float pcm16_to_float(int v) {
     return fmaf(fmaf(-q, 32767.0f, x), r, q);
 }
 
+// the same quotient in float64 (what the reference computes: float64(v) / float64(0x7FFF)), again without the
+// division sequence; exact for every int16 value (checked exhaustively on the host: tests/test_capi_host.py)
+__device__ __forceinline__ double pcm16_to_double(int v) {
+    const double x = double(v);
+    constexpr double r = 1.0 / 32767.0;
+    const double q = x * r;
+    return fma(fma(-q, 32767.0, x), r, q);
+}
+template <typename TT>
+__device__ __forceinline__ TT pcm16_to(int v) {
+    if constexpr (sizeof(TT) == 4) return pcm16_to_float(v);
+    else return pcm16_to_double(v);
+}
+
 // First-pass operands of one frame for the register-resident kernels: the frame's N samples as N/2 packed
 // pairs z[n] = (x[2n], x[2n+1]); this lane takes z[lane + STRIDE n1], n1 = 0..NV-1.  Three routes:
-//   * float32 samples, frame inside the stream, pairs 8-byte aligned: one 8-byte load per pair;
+//   * float32 samples, frame inside the stream, pairs 8-byte aligned: one 8-byte load per pair (widened to the
+//     compute type in registers);
 //   * int16 samples under the same conditions (4-byte aligned): one 4-byte load per pair, normalised here
 //     (half the input bytes of the float route);
-//   * anything else (stream edges, left zero pad, float64 samples, odd offsets): guarded element loads.
+//   * anything else (stream edges, left zero pad, float64 samples, odd offsets, strided streams): guarded
+//     element loads.
 template <typename TT, int NV, int STRIDE, int N, bool PCM16_ROUTE = true>
 __device__ __forceinline__ void load_frame_pairs(const MelspecArgs& a, const aud_item& it, int sstep, int lane,
                                                  C2<TT> (&v)[NV]) {
@@ -199,47 +215,72 @@ __device__ __forceinline__ void load_frame_pairs(const MelspecArgs& a, const aud
     const int64_t start = int64_t(it.start0) + int64_t(S) * (sstep - a.border);
     const int64_t pos0 = start + 2 * lane;
     const bool frame_on = sstep < T;
+    const bool inside = frame_on && start >= 0 && start + N <= lim && it.sig_stride <= 1 &&
+                        ((it.sig_off + start) & 1) == 0;
     bool done = false;
-    if constexpr (sizeof(TT) == 4) {
-        // whole frame inside the stream, f32 samples, 8-byte aligned pairs
-        const bool fast = frame_on && start >= 0 && start + N <= lim && a.sig_dtype == AUD_F32 &&
-                          ((it.sig_off + start) & 1) == 0 && (reinterpret_cast<uintptr_t>(a.sig) & 7) == 0;
-        if (fast) {
-            const C2<TT>* __restrict__ src =
-                reinterpret_cast<const C2<TT>*>(static_cast<const float*>(a.sig) + it.sig_off + pos0);
+    // whole frame inside the stream, f32 samples, 8-byte aligned pairs
+    const bool fast = inside && a.sig_dtype == AUD_F32 && (reinterpret_cast<uintptr_t>(a.sig) & 7) == 0;
+    if (fast) {
+        const C2<float>* __restrict__ src =
+            reinterpret_cast<const C2<float>*>(static_cast<const float*>(a.sig) + it.sig_off + pos0);
+        C2<float> raw[NV];
 #pragma unroll
-            for (int n1 = 0; n1 < NV; ++n1) v[n1] = src[STRIDE * n1];
-            done = true;
-        }
-        if constexpr (PCM16_ROUTE) {
-            const bool fast16 = !fast && frame_on && start >= 0 && start + N <= lim && a.sig_dtype == AUD_I16 &&
-                                ((it.sig_off + start) & 1) == 0 && (reinterpret_cast<uintptr_t>(a.sig) & 3) == 0;
-            if (fast16) {
-                const uint32_t* __restrict__ src =
-                    reinterpret_cast<const uint32_t*>(static_cast<const int16_t*>(a.sig) + it.sig_off + pos0);
+        for (int n1 = 0; n1 < NV; ++n1) raw[n1] = src[STRIDE * n1];
 #pragma unroll
-                for (int n1 = 0; n1 < NV; ++n1) {
-                    const uint32_t w = src[STRIDE * n1];
-                    v[n1].x = pcm16_to_float(int(int16_t(w & 0xFFFFu)));
-                    v[n1].y = pcm16_to_float(int(int16_t(w >> 16)));
-                }
-                done = true;
+        for (int n1 = 0; n1 < NV; ++n1) v[n1] = C2<TT>{TT(raw[n1].x), TT(raw[n1].y)};
+        done = true;
+    }
+    if constexpr (PCM16_ROUTE) {
+        const bool fast16 = !fast && inside && a.sig_dtype == AUD_I16 && (reinterpret_cast<uintptr_t>(a.sig) & 3) == 0;
+        if (fast16) {
+            const uint32_t* __restrict__ src =
+                reinterpret_cast<const uint32_t*>(static_cast<const int16_t*>(a.sig) + it.sig_off + pos0);
+            uint32_t raw[NV];
+#pragma unroll
+            for (int n1 = 0; n1 < NV; ++n1) raw[n1] = src[STRIDE * n1];
+#pragma unroll
+            for (int n1 = 0; n1 < NV; ++n1) {
+                v[n1].x = pcm16_to<TT>(int(int16_t(raw[n1] & 0xFFFFu)));
+                v[n1].y = pcm16_to<TT>(int(int16_t(raw[n1] >> 16)));
             }
+            done = true;
         }
     }
     if (!done) {
+        const int64_t str = it.sig_stride > 1 ? it.sig_stride : 1;
 #pragma unroll
         for (int n1 = 0; n1 < NV; ++n1) {
             const int64_t p = pos0 + 2 * STRIDE * n1;
-            v[n1].x = (frame_on && p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p) : TT(0);
+            v[n1].x = (frame_on && p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p * str) : TT(0);
             v[n1].y = (frame_on && p + 1 >= 0 && p + 1 < lim)
-                          ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p + 1) : TT(0);
+                          ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + (p + 1) * str) : TT(0);
         }
     }
 }
 
 __device__ __forceinline__ float dev_log(float v) { return logf(v); }
 __device__ __forceinline__ double dev_log(double v) { return log(v); }
+
+// ln of a float64 band power whose result is stored as float32 (mel.go:133-139, dft.go:76-82): the sum is
+// rounded to float32 and the logarithm taken there -- 6e-8 from the rounding plus logf's last-place error, both
+// below the float32 spacing of the stored value -- instead of ~100 float64 instructions per value.  Outside the
+// range where float32 is safely normal the float64 logarithm is used (a rare, data-dependent branch:
+// tests/parity_cases.py::case_tiny_and_huge_power forces it).
+__device__ __forceinline__ float feature_log(float v) { return logf(v); }
+__device__ __forceinline__ double feature_log(double v) {
+    if (v >= 1e-30 && v <= 1e30) return double(logf(float(v)));
+    return log(v);
+}
+
+// Orders the LDS traffic of ONE wave: stores issued before it are visible to loads issued after it by any lane
+// of the same wave.  The hardware executes a wave's LDS instructions in order, so this emits no instruction; it
+// stops the compiler from moving a lane's loads above other lanes' stores (the lanes of a wave exchanging data
+// through LDS without a workgroup barrier -- what the wave-autonomous kernels do).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 
 // ---- tile epilogue ------------------------------------------------------------------------------
@@ -270,7 +311,7 @@ __device__ __forceinline__ void tile_spectrum_outputs(const MelspecArgs& a, cons
                 float lp = 0.f;
                 if (live && a.comp_log_pow) {
                     const TT vv = pw + off;
-                    lp = float(vv == TT(0) ? lmin : dev_log(vv));
+                    lp = float(vv == TT(0) ? lmin : feature_log(vv));
                 }
                 a.log_power[o] = lp;
             }
@@ -327,7 +368,7 @@ __device__ __forceinline__ void tile_epilogue(const MelspecArgs& a, const FastAr
                 sum += ww.w * pw.w;
             }
             sum += loff;
-            TT val = (sum == TT(0)) ? lmin : dev_log(sum);
+            TT val = (sum == TT(0)) ? lmin : feature_log(sum);
             if (a.renorm) {
                 val -= TT(a.renorm_min);
                 if (val < TT(0)) val = TT(0);

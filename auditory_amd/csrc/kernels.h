@@ -53,7 +53,32 @@ struct MelspecArgs {
     float* log_power;  // [n_items, H, T] or null
     int F;             // frames per workgroup
     int xcd_remap;     // 1: tile_of_workgroup() order (plan option "xcd_remap", default on)
+    // diagnostic builds only (-DAUD_STAMPS, tools/stamp_profile.py): [waves][16] s_memtime stamps of the wave
+    // kernels' phases.  Never read by anything that computes an output.
+    unsigned long long* stamps;
 };
+
+#ifdef AUD_STAMPS
+// one stamp = s_memtime behind a drained LDS queue, fenced against the scheduler (cdna_hip_programming.md 7)
+#define AUD_STAMP_DECL unsigned long long aud_stamp_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define AUD_STAMP(i)                                                                          \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(aud_stamp_[i])::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
+#define AUD_STAMP_FLUSH(a, wave_tile, lane)                                                   \
+    do {                                                                                      \
+        if ((a).stamps && (lane) == 0) {                                                      \
+            for (int s_ = 0; s_ < 12; ++s_) (a).stamps[size_t(wave_tile) * 16 + s_] = aud_stamp_[s_]; \
+            (a).stamps[size_t(wave_tile) * 16 + 12] = __builtin_amdgcn_s_getreg((4 << 11) | 20); /* XCC_ID */ \
+        }                                                                                     \
+    } while (0)
+#else
+#define AUD_STAMP_DECL
+#define AUD_STAMP(i)
+#define AUD_STAMP_FLUSH(a, wave_tile, lane)
+#endif
 
 struct GaborArgs {
     const float* mel;  // [n_items, rows, cols]
@@ -136,6 +161,15 @@ hipError_t launch_melspec_r16(const MelspecArgs& a, const FastArgs& e, int compu
 bool melspec_r25_supported(int N, int S, int compute_dtype, int n_chunks, int nf, FastArgs* out);
 hipError_t melspec_r25_prepare(unsigned lds_bytes);
 hipError_t launch_melspec_r25(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
+
+// wave-autonomous kernels (melspec_wave.hip): N = 512 as 16 x 16 and N = 400 as 25 x 8, one wave per 4 / 8 frames,
+// no workgroup barrier behind the weight staging.  FastArgs: w4_off / sched_off / xch_off (first wave region).
+bool melspec_w16_supported(int N, int S, int compute_dtype, int n_chunks, int nf, FastArgs* out);
+hipError_t melspec_w16_prepare(unsigned lds_bytes);
+hipError_t launch_melspec_w16(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
+bool melspec_w25_supported(int N, int S, int compute_dtype, int n_chunks, int nf, FastArgs* out);
+hipError_t melspec_w25_prepare(unsigned lds_bytes);
+hipError_t launch_melspec_w25(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
 
 // N = 2048 fast path (one wave per frame, 16 x 16 x 4)
 bool melspec_r1024_supported(int N, int S, int compute_dtype, int n_chunks, int nf, FastArgs* out);

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
         const bool live = s < T && start + N <= int64_t(it.sig_len);
         const int64_t pos = start + n;
         TT v = TT(0);
-        if (live && pos >= 0) v = load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + pos);
+        if (live && pos >= 0) v = load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + pos * (it.sig_stride > 1 ? it.sig_stride : 1));
         if (even) {
             reinterpret_cast<TT*>(src)[size_t(f) * N + n] = v;  // z[n/2] = (x[2j], x[2j+1])
         } else {

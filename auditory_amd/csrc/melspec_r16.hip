@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
         // ---- stage the tile's sample span: positions g0 .. g0 + span of the item's stream ------
         const int64_t g0 = int64_t(it.start0) + int64_t(S) * (t0 - a.border);
         const int span = (kF - 1) * S + kN;
-        if (a.sig_dtype == AUD_F32 && sizeof(TT) == 4 && ((it.sig_off + g0) & 3) == 0 &&
+        if (a.sig_dtype == AUD_F32 && sizeof(TT) == 4 && it.sig_stride <= 1 && ((it.sig_off + g0) & 3) == 0 &&
             (reinterpret_cast<uintptr_t>(a.sig) & 15) == 0) {
             const float* __restrict__ src = static_cast<const float*>(a.sig) + it.sig_off;
             for (int c = tid; c * 4 < span; c += 256) {
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_melspec_r16(const MelspecArgs a, const 
         } else {
             for (int c = tid; c < span; c += 256) {
                 const int64_t p = g0 + c;
-                sigbuf[c] = (p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p) : TT(0);
+                sigbuf[c] = (p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p * (it.sig_stride > 1 ? it.sig_stride : 1)) : TT(0);
             }
         }
     }

@@ -155,12 +155,14 @@ class Plan:
             self.handle = None
 
 
-ITEM_DTYPE = np.dtype([("sig_off", np.int64), ("sig_len", np.int32), ("start0", np.int32)])
+ITEM_DTYPE = np.dtype([("sig_off", np.int64), ("sig_len", np.int32), ("start0", np.int32),
+                       ("sig_stride", np.int32), ("reserved", np.int32)])
 assert ITEM_DTYPE.itemsize == C.sizeof(capi.Item)
 
 
-def make_items(sig_off, sig_len, start0):
+def make_items(sig_off, sig_len, start0, sig_stride=1):
+    """aud_item array; sig_stride = 2 with sig_off = 0 / 1 addresses the channels of interleaved stereo PCM"""
     n = len(sig_off)
     it = np.zeros(n, ITEM_DTYPE)
-    it["sig_off"], it["sig_len"], it["start0"] = sig_off, sig_len, start0
+    it["sig_off"], it["sig_len"], it["start0"], it["sig_stride"] = sig_off, sig_len, start0, sig_stride
     return it

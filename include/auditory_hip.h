@@ -112,11 +112,17 @@ typedef struct {
  * of the stream that begins at element sig_off of the signal buffer and is sig_len
  * samples long.  start0 = segment*StrideSamples + MSecToSamples(add) (sndenv.go:440-441).
  * Negative positions read as zero; a frame whose end exceeds sig_len is masked to zero,
- * as are all later frames of the segment (sndenv.go:354-358, :458-460). */
+ * as are all later frames of the segment (sndenv.go:354-358, :458-460).
+ * sig_stride is the distance, in elements of the signal buffer, between successive samples of the
+ * stream: 1 (or 0) for a mono buffer; 2 with sig_off = 0 / 1 addresses the left / right channel of an
+ * interleaved stereo PCM buffer (sound.go:116-127) as two mono streams without a de-interleaving copy.
+ * sig_len counts samples of the stream, not buffer elements. */
 typedef struct {
     int64_t sig_off;
     int32_t sig_len;
     int32_t start0;
+    int32_t sig_stride;
+    int32_t reserved; /* 0 */
 } aud_item;
 
 /* Everything a plan needs.  Tables are built host-side (aud_mel_init_filters,

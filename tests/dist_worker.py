@@ -30,7 +30,7 @@ def main():
     lo, hi = shard_range(n_total, rank, world)
     with backend.emulated("plain"):
         plan = W.product_plan(oc, capi.AUD_F32)
-        assert plan.kernel_name == "r16x16"
+        assert plan.kernel_name == "w16x16"
         n = hi - lo
         items = runtime.make_items(np.arange(n) * L, [L] * n, [0] * n)
         mel, _, _ = plan.melspec_host(sig[lo:hi].ravel(), items)      # this rank only touches its shard

@@ -133,6 +133,8 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
 
 }  // namespace aud_emul
 
+void aud_emul_wave_barrier() { g_wave[int(threadIdx.x) >> 6].arrive_and_wait(); }
+
 hipError_t hipGetDeviceCount(int* n) {
     *n = 8;  // one emulated node
     return hipSuccess;

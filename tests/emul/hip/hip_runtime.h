@@ -73,6 +73,11 @@ void wave_release();
     aud_emul::launch((grid), (block), (lds), [=]() { kernel(__VA_ARGS__); })
 
 inline void __syncthreads() { aud_emul::sync_block(); }
+// wave-level ordering of LDS traffic (device_common.h wave_lds_fence): on the GPU a scheduling fence, here a
+// real barrier over the wave's threads, so a missing one is a data race TSan reports
+void aud_emul_wave_barrier();
+inline void __builtin_amdgcn_wave_barrier() { aud_emul_wave_barrier(); }
+#define __builtin_amdgcn_fence(order, ...) __atomic_thread_fence(order)
 
 template <typename T>
 inline T emul_shfl_any(T v, int src_lane) {

@@ -50,7 +50,7 @@ def main():
     cdt = capi.AUD_F32 if args.compute == "f32" else capi.AUD_F64
     variants = {"auto": {}, "auto, tiles in workgroup-id order": {"xcd_remap": 0}, "generic": {"kernel": 1}}
     if args.win_ms == 32.0:
-        variants = {"r16 direct": {"r16_input": 0}, "r16 direct, no xcd remap": {"r16_input": 0, "xcd_remap": 0}, "r16 direct x2": {"r16_input": 0, "r16_tiles": 2},
+        variants = {"w16 wave-autonomous": {}, "w16, tiles in workgroup-id order": {"xcd_remap": 0}, "r16 direct": {"r16_input": 0}, "r16 direct, no xcd remap": {"r16_input": 0, "xcd_remap": 0}, "r16 direct x2": {"r16_input": 0, "r16_tiles": 2},
                     "r16 staged": {"r16_input": 1}, "r16 direct mfma-mel": {"r16_input": 0, "r16_mel": 1},
                     "r16 direct x2 mfma-mel": {"r16_input": 0, "r16_tiles": 2, "r16_mel": 1}, "generic": {"kernel": 1}}
     plans = {}
@@ -73,19 +73,27 @@ def main():
         p.melspec_dev(dsig.data_ptr(), capi.AUD_F32, items.data_ptr(), B, mel.data_ptr(), 0, 0, stream)
 
     times = {v: [] for v in plans}
-    for v, p in plans.items():            # warm every variant
+    graphs = {}
+    for v, p in plans.items():            # warm every variant, then capture its launches into one hipGraph
         for _ in range(args.warm):
             launch(p)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            s_cap = torch.cuda.current_stream(dev).cuda_stream
+            for _ in range(args.launches):
+                p.melspec_dev(dsig.data_ptr(), capi.AUD_F32, items.data_ptr(), B, mel.data_ptr(), 0, 0, s_cap)
+        g.replay()
+        graphs[v] = g
     torch.cuda.synchronize()
     for _ in range(args.rounds):
         for v, p in plans.items():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(args.launches):
-                launch(p)
+            graphs[v].replay()
             e1.record()
             torch.cuda.synchronize()
-            times[v].append(e0.elapsed_time(e1) * 1e3 / args.launches)   # us per launch (incl. launch gaps)
+            times[v].append(e0.elapsed_time(e1) * 1e3 / args.launches)   # us per launch (incl. kernel boundaries)
     alg = B * (4 * 16000 + 4 * oc.nf * oc.T)
     print("workload: %s, batch %d, %s; %d rounds x %d launches; algorithmic bytes/launch %.2f MB"
           % (name, B, args.compute, args.rounds, args.launches, alg / 1e6))

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Where a wave of the wave-autonomous kernels spends its life (run on the GPU box).
+
+Loads the DIAGNOSTIC build of the library (auditory_amd/libauditory_hip_stamps.so, -DAUD_STAMPS: s_memtime stamps
+at the phase boundaries, fenced against the scheduler and with the LDS queue drained at each stamp -- its run time
+is not the product's, its SHARES are what to read), launches one batch and prints, per phase, the median / p90
+cycles over all waves, plus the launch's timeline (first wave start -> last wave end) per XCD.
+
+  python tools/stamp_profile.py --win-ms 32 --compute f64 --batch 256
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")]
+import memguard  # noqa: E402
+
+memguard.install()
+
+PHASES = ["0-1 issue loads + stage weights", "1-2 workgroup barrier", "2-3 operands land (vmcnt 0)",
+          "3-4 pass-1 DFT + twiddle", "4-5 LDS transpose re/im", "5-6 pass-2 DFT", "6-7 split + power -> LDS",
+          "7-8 mel epilogue + stores"]
+PHASES_W25 = ["0-1 issue loads + stage weights", "1-2 workgroup barrier", "2-3 operands land (vmcnt 0)",
+              "3-4 pass-A DFT25 + twiddle", "4-5 LDS transpose re/im", "5-6 pass-B DFT8 rows", "6-7 split + power -> LDS",
+              "7-8 mel epilogue + stores"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--win-ms", type=float, default=32.0)
+    ap.add_argument("--compute", choices=["f32", "f64"], default="f64")
+    args = ap.parse_args()
+
+    import torch
+    from auditory_amd import build, capi, runtime, synth
+    lib_path = build.LIB.replace(".so", "_stamps.so")
+    if not os.path.exists(lib_path):
+        build.build(stamps=True)
+    lib = C.CDLL(lib_path)
+    for name, (res, argt) in capi.SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, argt
+    capi._LIB = lib          # this process only ever uses the diagnostic build
+    import workloads as W
+    from oracle import oracle as orc  # parameter blocks only
+    from auditory_amd.batch import BatchProcessor
+
+    dev = torch.device("cuda", 0)
+    name = {32.0: "cfg2_16k_n512_nf40", 25.0: "cfg2_16k_n400_nf40"}[args.win_ms]
+    oc = W.OracleCfg(orc, name)
+    B = args.batch
+    L = (oc.full_len() + 63) // 64 * 64
+    sig64, _ = synth.batch(2, min(B, 256), 16000, oc.sr, row_len=L)
+    reps = (B + sig64.shape[0] - 1) // sig64.shape[0]
+    sig = np.tile(sig64.astype(np.float32), (reps, 1))[:B]
+    dsig = torch.from_numpy(sig).to(dev).view(-1)
+    cdt = capi.AUD_F32 if args.compute == "f32" else capi.AUD_F64
+    plan = W.product_plan(oc, cdt)
+    fpw = 4 if oc.N == 512 else 8
+    n_waves = B * ((oc.T + fpw - 1) // fpw)
+    stamps = torch.zeros((n_waves, 16), dtype=torch.int64, device=dev)
+    ptr = stamps.data_ptr()
+    plan.set_option("stamps_lo", C.c_int32(ptr & 0xFFFFFFFF).value)
+    plan.set_option("stamps_hi", C.c_int32((ptr >> 32) & 0xFFFFFFFF).value)
+    bp = BatchProcessor(plan, dev)
+    items = bp.upload_items(runtime.make_items(np.arange(B) * L, [L] * B, [0] * B))
+    mel = torch.empty((B, oc.nf, oc.T), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for _ in range(20):
+        plan.melspec_dev(dsig.data_ptr(), capi.AUD_F32, items.data_ptr(), B, mel.data_ptr(), 0, 0, st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    plan.melspec_dev(dsig.data_ptr(), capi.AUD_F32, items.data_ptr(), B, mel.data_ptr(), 0, 0, st)
+    e1.record()
+    torch.cuda.synchronize()
+    s = stamps.cpu().numpy().astype(np.int64)
+    print("kernel %s, %s, batch %d: %d waves, launch %.1f us (diagnostic build: stamps cost time)"
+          % (plan.kernel_name, args.compute, B, n_waves, e0.elapsed_time(e1) * 1e3))
+    t = s[:, :9]
+    ok = (t[:, 8] > 0)
+    t = t[ok]
+    d = np.diff(t, axis=1)
+    life = t[:, 8] - t[:, 0]
+    names = PHASES if oc.N == 512 else PHASES_W25
+    print("%-36s %9s %9s %9s  %6s" % ("phase (s_memtime ticks = shader cycles)", "median", "p10", "p90", "share"))
+    for i, nm in enumerate(names):
+        print("%-36s %9.0f %9.0f %9.0f  %5.1f%%" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 10),
+                                                 np.percentile(d[:, i], 90), 100 * d[:, i].sum() / life.sum()))
+    print("%-36s %9.0f %9.0f %9.0f" % ("wave lifetime", np.median(life), np.percentile(life, 10), np.percentile(life, 90)))
+    xcc = s[ok, 12] & 15
+    print("timeline per XCD (ticks from the launch's first stamp): first start, median start, last start, last end")
+    base = t[:, 0].min()
+    for x in sorted(set(xcc.tolist())):
+        m = xcc == x
+        print("  XCC %d: %5d waves  first %7d  median %7d  last start %7d  last end %7d"
+              % (x, m.sum(), t[m, 0].min() - base, np.median(t[m, 0]) - base, t[m, 0].max() - base, t[m, 8].max() - base))
+    print("whole launch: %d ticks from first stamp to last stamp" % (t[:, 8].max() - base))
+    plan.close()
+
+
+if __name__ == "__main__":
+    main()
