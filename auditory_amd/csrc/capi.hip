@@ -48,6 +48,7 @@ struct aud_plan {
     aud::FastArgs wv{};
     int* d_grp = nullptr;  // [17 + nf + 3 nf]: group offsets, filter ids, per-filter chunk info
     void* d_w4 = nullptr;  // chunked triangle weights
+    void* d_slots = nullptr;  // wave kernels: [groups][n_slots] filter slot records
     int* d_blk = nullptr;     // matrix-pipe mel variant (r16x16, float32): per 16-filter block {chunk0, steps, offset}
     float* d_atab = nullptr;  // ... and its lane-ordered A operands [steps][64]
     int n_blocks = 0;
@@ -459,6 +460,32 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
                 }
             }
             if (wave_kind != aud_plan::kNoWave) {
+                // filter slots: per group its filters as {filter | first chunk << 16, chunks | w4 offset << 16}
+                int n_slots = 1;
+                for (int g = 0; g < n_groups; ++g) n_slots = std::max(n_slots, tab[g + 1] - tab[g]);
+                bool fits16 = true;
+                std::vector<uint32_t> slots(size_t(n_groups) * n_slots * 2, 0);
+                for (int g = 0; g < n_groups; ++g)
+                    for (int sl = 0; sl < n_slots; ++sl) {
+                        uint32_t* r = &slots[(size_t(g) * n_slots + sl) * 2];
+                        if (tab[g] + sl < tab[g + 1]) {
+                            const int f = tab[goff + tab[g] + sl];
+                            const int* ci = &tab[goff + nf + 3 * f];
+                            fits16 = fits16 && f < 0xFFFF && ci[0] < 0x10000 && ci[1] < 0x10000 && ci[2] < 0x10000;
+                            r[0] = uint32_t(f) | (uint32_t(ci[0]) << 16);
+                            r[1] = uint32_t(ci[1]) | (uint32_t(ci[2]) << 16);
+                        } else {
+                            r[0] = 0xFFFFu;  // empty slot
+                            r[1] = 0;
+                        }
+                    }
+                if (!fits16 || n_slots > aud::wave_slot_bound(nf, n_groups)) wave_kind = aud_plan::kNoWave;
+                if (wave_kind != aud_plan::kNoWave)
+                    rc = upload(c, &p->d_slots, slots.data(), slots.size() * sizeof(uint32_t));
+                wcfg.n_slots = n_slots;
+                wcfg.slots = static_cast<const uint2*>(p->d_slots);
+            }
+            if (rc == AUD_OK && wave_kind != aud_plan::kNoWave) {
                 wcfg.grp_off = p->r16.grp_off;
                 wcfg.grp_flt = p->r16.grp_flt;
                 wcfg.chunk = p->r16.chunk;
@@ -488,6 +515,7 @@ int aud_plan_destroy(aud_plan* p) {
     if (p->d_dct) (void)hipFree(p->d_dct);
     if (p->d_grp) (void)hipFree(p->d_grp);
     if (p->d_w4) (void)hipFree(p->d_w4);
+    if (p->d_slots) (void)hipFree(p->d_slots);
     if (p->d_blk) (void)hipFree(p->d_blk);
     if (p->d_atab) (void)hipFree(p->d_atab);
     delete p;

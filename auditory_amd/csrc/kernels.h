@@ -114,6 +114,11 @@ struct FastArgs {
     int n_blocks;          // filter blocks of 16 for the matrix-pipe variant
     const int* blk;        // [n_blocks][3] device: first 4-bin chunk, K-steps, offset (in steps) into atab
     const float* atab;     // [steps][64] device: A operands, lane-ordered
+    // wave-autonomous kernels: per filter group, n_slots records {filter | first chunk << 16, chunks | w4 offset << 16}
+    // (filter 0xFFFF = empty slot); one 8-byte LDS read per filter instead of a three-level table walk
+    const uint2* slots;    // [n_groups][n_slots] device
+    int n_slots;
+    int slots_off;         // byte offset of the LDS copy
 };
 
 // PrevSmooth != 0 mode: scan along the steps of a stored power tensor
@@ -161,6 +166,12 @@ hipError_t launch_melspec_r16(const MelspecArgs& a, const FastArgs& e, int compu
 bool melspec_r25_supported(int N, int S, int compute_dtype, int n_chunks, int nf, FastArgs* out);
 hipError_t melspec_r25_prepare(unsigned lds_bytes);
 hipError_t launch_melspec_r25(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
+
+// filter slots per group the wave kernels reserve LDS for (the plan's balanced grouping must fit, else no wave kernel)
+inline int wave_slot_bound(int nf, int n_groups) {
+    const int b = 2 * ((nf + n_groups - 1) / n_groups) + 2;
+    return b < nf ? b : nf;
+}
 
 // wave-autonomous kernels (melspec_wave.hip): N = 512 as 16 x 16 and N = 400 as 25 x 8, one wave per 4 / 8 frames,
 // no workgroup barrier behind the weight staging.  FastArgs: w4_off / sched_off / xch_off (first wave region).

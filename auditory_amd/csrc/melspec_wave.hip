@@ -9,7 +9,17 @@
 //   * the unit of work is a WAVE, not a workgroup: 64 lanes carry 4 frames x 16 lanes (N = 512) or 8 frames x
 //     8 lanes (N = 400) from the samples to the mel values.  Lanes of one wave exchange data through a
 //     wave-private LDS region ordered by wave_lds_fence() -- the hardware runs a wave's LDS instructions in
-//     order -- so after the one barrier behind the staging of the mel weights there is no workgroup barrier;
+//     order -- and there is NO workgroup barrier at all: the stamps of the first version (profiles/r02c_stamps_*)
+//     showed the one barrier behind the staging of the mel weights costing 11 % of a wave's life (the waves of a
+//     workgroup leave their load phase thousands of cycles apart).  Each wave now writes its own, identical copy
+//     of the small read-only tables (mel weights, filter slots) to the shared LDS locations just before its
+//     epilogue -- a benign same-value race with the other waves' reads -- so no wave ever waits for another;
+//   * the wave index is made scalar (readfirstlane), so the work-item record is one scalar load and the
+//     address arithmetic runs on the scalar unit; operand and twiddle loads are issued back to back before the
+//     first wait;
+//   * the mel reduction walks per-group filter slots ({filter, first chunk, chunks, weight offset} records, one
+//     LDS read each) two filters at a time with four partial sums per filter: eight independent FMA chains
+//     instead of one (the first version's epilogue was a single dependent chain and took 27 % of the wave);
 //   * the transposes go through LDS one component at a time (all real parts, then all imaginary parts), which
 //     halves the footprint: 9 KB (N = 512) / 16 KB (N = 400) per wave in float64, half of that in float32;
 //     the power spectrum then reuses the same region.  That is 3 waves per SIMD in float64 for N = 512, 2 for
@@ -54,8 +64,8 @@ template <typename TT, bool PCM16>
 __global__ __launch_bounds__(64 * kWaves) void k_melspec_w16(const MelspecArgs a, const FastArgs e) {
     using L = w16::Layout<TT>;
     unsigned char* smem = dyn_lds();
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);  // scalar: item record and addresses on the SALU
+    const int lane = int(threadIdx.x) & 63;
     const int f = lane >> 4;   // frame within the wave
     const int j = lane & 15;   // lane within the frame's 16-lane group
     const int T = a.T;
@@ -63,34 +73,25 @@ __global__ __launch_bounds__(64 * kWaves) void k_melspec_w16(const MelspecArgs a
     const int tiles = (T + w16::kFW - 1) / w16::kFW;  // wave tiles per item
     const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
     const int64_t wt = int64_t(wg) * kWaves + wave;
-    const bool on = wt < int64_t(a.n_items) * tiles;  // wave-uniform
-    const int item = on ? int(wt / tiles) : 0;
-    const int t0 = on ? int(wt - int64_t(item) * tiles) * w16::kFW : 0;
+    if (wt >= int64_t(a.n_items) * tiles) return;  // wave-uniform; no barrier anywhere below
+    const int item = int(wt / tiles);
+    const int t0 = int(wt - int64_t(item) * tiles) * w16::kFW;
     const aud_item it = a.items[item];
     const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_512^k
-
     AUD_STAMP_DECL;
     AUD_STAMP(0);
-    const SchedRegs sched = mel_schedule_fetch<64 * kWaves>(e, tid);  // issued ahead of the operand loads
 
     // ---- pass 1 operands straight from global memory: z[16 n1 + j] = (x[32 n1 + 2j], x[.. + 1]) --------------
     C2<TT> v[16];
-    if (on) load_frame_pairs<TT, 16, 16, w16::kN, PCM16>(a, it, t0 + f, j, v);
-
-    // the filter-group schedule and the chunked mel weights (a few KB, shared by the workgroup's waves)
-    mel_schedule_store<64 * kWaves>(e, smem, tid, sched);
-    stage_mel_weights<TT, 64 * kWaves>(e, smem, tid);
-    AUD_STAMP(1);
-    __syncthreads();  // the only workgroup barrier
-    if (!on) return;
-    AUD_STAMP(2);
-
-    TT* xw = reinterpret_cast<TT*>(smem + e.xch_off + wave * L::kRegion);  // this wave's region
-
-    // per-lane twiddles W_256^(j k1) = W_512^(2 j k1): 15 L1-resident loads
+    load_frame_pairs<TT, 16, 16, w16::kN, PCM16>(a, it, t0 + f, j, v);
+    // per-lane twiddles W_256^(j k1) = W_512^(2 j k1): 15 L1/L2-resident loads behind the operands, one wait for both
     C2<TT> tw1[16];
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) tw1[k1] = tw[2 * j * k1];
+    AUD_STAMP(1);
+    AUD_STAMP(2);
+
+    TT* xw = reinterpret_cast<TT*>(smem + e.xch_off + wave * L::kRegion);  // this wave's region
 
     // ---- pass 1: 16-point DFT over n1, twiddle -----------------------------------------------------------
 #ifdef AUD_STAMPS
@@ -146,6 +147,9 @@ __global__ __launch_bounds__(64 * kWaves) void k_melspec_w16(const MelspecArgs a
     SmallDft<TT, 16>::run(v, nullptr, 0);
     wave_lds_fence();  // every row has been read: the region may take the power spectrum
     AUD_STAMP(6);
+    // this wave's copy of the mel weights and filter slots: requested now, stored behind the split
+    WaveTables<TT, 3> tabs;
+    wave_tables_fetch<TT, 3>(e, lane, tabs);
 
     // ---- real-FFT split + power (as melspec_r16.hip) -----------------------------------------------------
     // For k = j + 16 q (q = 0..7) the partner Z[256 - k] sits in lane (16 - j) & 15, register 15 - q (lane 0
@@ -181,11 +185,12 @@ __global__ __launch_bounds__(64 * kWaves) void k_melspec_w16(const MelspecArgs a
         // bins 257..259 only pad the last 4-bin chunk; their weights are zero but 0 * garbage must stay 0
         if (j >= 13) P[w16::kH + (j - 13)] = TT(0);
     }
+    wave_tables_store<TT, 3>(e, smem, lane, tabs);
     wave_lds_fence();
     AUD_STAMP(7);
 
     // ---- optional spectrum outputs and the mel reduction: 4 frames x 16 filter groups on this wave ----------
-    tile_epilogue<TT, 64, w16::kFW, true>(a, e, Pw, w16::kHp, smem, it, item, t0, lane);
+    wave_mel_epilogue<TT, w16::kFW>(a, e, Pw, w16::kHp, smem, it, item, t0, lane);
     AUD_STAMP(8);
     AUD_STAMP_FLUSH(a, wt, lane);
 }
@@ -245,12 +250,14 @@ __device__ __forceinline__ void split_pair(TT* P, const C2<TT>* __restrict__ tw,
 }
 }  // namespace w25
 
+// second launch-bounds argument = waves per SIMD the register allocator must leave room for: without it the
+// float64 instantiation is scheduled into 256 VGPRs + 30 AGPRs (one wave per SIMD); LDS admits two
 template <typename TT, bool PCM16>
-__global__ __launch_bounds__(64 * kWaves) void k_melspec_w25(const MelspecArgs a, const FastArgs e) {
+__global__ __launch_bounds__(64 * kWaves, 2) void k_melspec_w25(const MelspecArgs a, const FastArgs e) {
     using L = w25::Layout<TT>;
     unsigned char* smem = dyn_lds();
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);  // scalar: item record and addresses on the SALU
+    const int lane = int(threadIdx.x) & 63;
     const int f = lane >> 3;  // frame within the wave
     const int j = lane & 7;   // lane within the frame's 8-lane group
     const int T = a.T;
@@ -258,25 +265,18 @@ __global__ __launch_bounds__(64 * kWaves) void k_melspec_w25(const MelspecArgs a
     const int tiles = (T + w25::kFW - 1) / w25::kFW;  // wave tiles per item
     const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
     const int64_t wt = int64_t(wg) * kWaves + wave;
-    const bool on = wt < int64_t(a.n_items) * tiles;  // wave-uniform
-    const int item = on ? int(wt / tiles) : 0;
-    const int t0 = on ? int(wt - int64_t(item) * tiles) * w25::kFW : 0;
+    if (wt >= int64_t(a.n_items) * tiles) return;  // wave-uniform; no barrier anywhere below
+    const int item = int(wt / tiles);
+    const int t0 = int(wt - int64_t(item) * tiles) * w25::kFW;
     const aud_item it = a.items[item];
     const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_400^k
-
     AUD_STAMP_DECL;
     AUD_STAMP(0);
-    const SchedRegs sched = mel_schedule_fetch<64 * kWaves>(e, tid);  // issued ahead of the operand loads
 
     // ---- pass A operands: z[8 n1 + j] = (x[16 n1 + 2j], x[16 n1 + 2j + 1]), n1 = 0..24 ---------------------
     C2<TT> v[25];
-    if (on) load_frame_pairs<TT, 25, 8, w25::kN, PCM16>(a, it, t0 + f, j, v);
-
-    mel_schedule_store<64 * kWaves>(e, smem, tid, sched);
-    stage_mel_weights<TT, 64 * kWaves>(e, smem, tid);
+    load_frame_pairs<TT, 25, 8, w25::kN, PCM16>(a, it, t0 + f, j, v);
     AUD_STAMP(1);
-    __syncthreads();  // the only workgroup barrier
-    if (!on) return;
     AUD_STAMP(2);
 
     TT* xw = reinterpret_cast<TT*>(smem + e.xch_off + wave * L::kRegion);  // this wave's region
@@ -287,96 +287,86 @@ __global__ __launch_bounds__(64 * kWaves) void k_melspec_w25(const MelspecArgs a
 
     // ---- pass A: 25-point DFT over n1, twiddle W_200^(j k1) = W_400^(2 j k1) -------------------------------
     SmallDft<TT, 25>::run(v, tw, w25::kN);
+    // six twiddles at a time: left alone the scheduler requests all 24 first (96 registers in float64)
 #pragma unroll
-    for (int k1 = 1; k1 < 25; ++k1) v[k1] = cmul(v[k1], tw[2 * j * k1]);
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int k1 = 1 + 6 * g; k1 < 7 + 6 * g; ++k1) v[k1] = cmul(v[k1], tw[2 * j * k1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     AUD_STAMP(4);
 
     // ---- transpose through the wave's LDS region, real parts then imaginary parts ----------------------------
-    // element (row k1, column n2 = j) of frame f; afterwards lane j holds rows j, j + 8, j + 16 (and 24 on lane 0)
+    // element (row k1, column n2 = j) of frame f.  Pass B and the real-FFT split then work on ROW PAIRS: the partner
+    // of Z[k], k = k1 + 25 k2, is Z[200 - k] = element (row 25 - k1, column 7 - k2), so a lane that holds rows r and
+    // 25 - r has both halves of all eight pairs in its own registers (no cross-lane traffic, no selects):
+    //   slot 0: rows j + 1 and 24 - j           (lanes 0..7: row pairs 1..8)
+    //   slot 1: rows 9 + j and 16 - j           (lanes 0..3: row pairs 9..12);  row 0, which pairs with itself (lane 4)
     TT* col = xw + f * L::kFrame + j;
-    const TT* rows = xw + f * L::kFrame + j * L::kRow;
-    TT ur[4][8], ui[4][8];
+    const TT* rows = xw + f * L::kFrame;
+    const int r0 = j + 1, r0p = 24 - j;                       // slot 0
+    const bool pair1 = j <= 3, self1 = j == 4;                // slot 1: a row pair, or row 0 alone
+    const int r1 = pair1 ? 9 + j : 0, r1p = 16 - j;
+    TT ur[4][8], ui[4][8];  // [slot 0 row, its partner, slot 1 row, its partner][column]
 #pragma unroll
     for (int k1 = 0; k1 < 25; ++k1) col[k1 * L::kRow] = v[k1].x;
     wave_lds_fence();
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        if (m < 3 || j == 0) w25::read_row8<TT>(rows + 8 * m * L::kRow, ur[m]);
-    }
+    w25::read_row8<TT>(rows + r0 * L::kRow, ur[0]);
+    w25::read_row8<TT>(rows + r0p * L::kRow, ur[1]);
+    if (pair1 || self1) w25::read_row8<TT>(rows + r1 * L::kRow, ur[2]);
+    if (pair1) w25::read_row8<TT>(rows + r1p * L::kRow, ur[3]);
     wave_lds_fence();
 #pragma unroll
     for (int k1 = 0; k1 < 25; ++k1) col[k1 * L::kRow] = v[k1].y;
     wave_lds_fence();
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        if (m < 3 || j == 0) w25::read_row8<TT>(rows + 8 * m * L::kRow, ui[m]);
-    }
+    w25::read_row8<TT>(rows + r0 * L::kRow, ui[0]);
+    w25::read_row8<TT>(rows + r0p * L::kRow, ui[1]);
+    if (pair1 || self1) w25::read_row8<TT>(rows + r1 * L::kRow, ui[2]);
+    if (pair1) w25::read_row8<TT>(rows + r1p * L::kRow, ui[3]);
     wave_lds_fence();  // every row has been read: the region may take the power spectrum
     AUD_STAMP(5);
+    // this wave's copy of the mel weights and filter slots: requested now, stored behind the split
+    WaveTables<TT, 3> tabs;
+    wave_tables_fetch<TT, 3>(e, lane, tabs);
 
-    // ---- pass B: 8-point DFT over n2 of each row, in registers: Z[k1 + 25 k2] = (ur, ui)[m][k2], k1 = j + 8 m ---
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        if (m < 3 || j == 0) {
-            C2<TT> u[8];
-#pragma unroll
-            for (int n2 = 0; n2 < 8; ++n2) u[n2] = C2<TT>{ur[m][n2], ui[m][n2]};
-            SmallDft<TT, 8>::run(u, nullptr, 0);
-#pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) {
-                ur[m][k2] = u[k2].x;
-                ui[m][k2] = u[k2].y;
-            }
-        }
-    }
-
-    AUD_STAMP(6);
-    // ---- real-FFT split + power ------------------------------------------------------------------------------
-    // Z[200 - k] of k = k1 + 25 k2 (k1 >= 1) is element (row 25 - k1, column 7 - k2); row 25 - k1 of this lane's
-    // rows j + 8 m sits in lane (9 - j) & 7 of the frame.  Rows 1..12 compute (both bins of the pair), rows 13..24
-    // only send: row j <-> row 25 - j = partner's row m = 2 (m = 3, row 24, for j = 1); row j + 8 (j <= 4) <->
-    // row 17 - j = partner's row m = 2 for j <= 1, m = 1 for j = 2..4.  Row 0 (lane 0) pairs with itself:
-    // k = 25 k2 <-> column 8 - k2.  Pairs are always evaluated from their k <= 100 side, as melspec_r25.hip does.
+    // ---- pass B (8-point DFT over n2 of each row, in registers: Z[k1 + 25 k2]) + real-FFT split + power ---------
+    // pairs are always evaluated from their k <= 100 side, A = Z[k], B = Z[200 - k], as melspec_r25.hip does:
+    // rows (r, r' = 25 - r), r <= 12: k = r + 25 c and k = r' + 25 c for c = 0..3, partners in column 7 - c
     TT* Pw = xw;  // [8][kHp]
     TT* P = Pw + f * w25::kHp;
-    {
-        const int partner = (lane & 56) | ((9 - j) & 7);
 #pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) {
-            // what my partner needs from me, column 7 - k2 (selected by value)
-            const int c = 7 - k2;
-            const TT sAx = (j == 0) ? ur[3][c] : ur[2][c], sAy = (j == 0) ? ui[3][c] : ui[2][c];
-            const TT sBx = (j <= 1) ? ur[2][c] : ur[1][c], sBy = (j <= 1) ? ui[2][c] : ui[1][c];
-            C2<TT> rA, rB;
-            rA.x = __shfl(sAx, partner, 64);
-            rA.y = __shfl(sAy, partner, 64);
-            rB.x = __shfl(sBx, partner, 64);
-            rB.y = __shfl(sBy, partner, 64);
-            // row m = 0: k1 = j
-            {
-                const C2<TT> mine = {ur[0][k2], ui[0][k2]};
-                if (j == 0) {
-                    if (k2 <= 4) w25::split_pair<TT>(P, tw, 25 * k2, mine, C2<TT>{ur[0][(8 - k2) & 7], ui[0][(8 - k2) & 7]});
-                } else if (k2 < 4) {
-                    w25::split_pair<TT>(P, tw, j + 25 * k2, mine, rA);
-                } else {
-                    w25::split_pair<TT>(P, tw, w25::kM - (j + 25 * k2), rA, mine);
+    for (int sl = 0; sl < 2; ++sl) {
+        const bool is_pair = sl == 0 || pair1;
+        const bool is_self = sl == 1 && self1;
+        if (is_pair || is_self) {
+            const int ra = sl == 0 ? r0 : r1, rb = sl == 0 ? r0p : r1p;
+            C2<TT> za[8], zb[8];
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) za[n2] = C2<TT>{ur[2 * sl][n2], ui[2 * sl][n2]};
+            SmallDft<TT, 8>::run(za, nullptr, 0);
+            if (is_pair) {
+#pragma unroll
+                for (int n2 = 0; n2 < 8; ++n2) zb[n2] = C2<TT>{ur[2 * sl + 1][n2], ui[2 * sl + 1][n2]};
+                SmallDft<TT, 8>::run(zb, nullptr, 0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    w25::split_pair<TT>(P, tw, ra + 25 * c, za[c], zb[7 - c]);
+                    w25::split_pair<TT>(P, tw, rb + 25 * c, zb[c], za[7 - c]);
                 }
-            }
-            // row m = 1: k1 = j + 8, computing for k1 <= 12
-            if (j <= 4) {
-                const C2<TT> mine = {ur[1][k2], ui[1][k2]};
-                if (k2 < 4) w25::split_pair<TT>(P, tw, j + 8 + 25 * k2, mine, rB);
-                else w25::split_pair<TT>(P, tw, w25::kM - (j + 8 + 25 * k2), rB, mine);
+            } else {  // row 0: k = 25 c pairs with column 8 - c of the same row (c = 0: DC + Nyquist; c = 4: itself)
+#pragma unroll
+                for (int c = 0; c <= 4; ++c) w25::split_pair<TT>(P, tw, 25 * c, za[c], za[(8 - c) & 7]);
             }
         }
-        if (j < 3) P[w25::kH + j] = TT(0);  // pad bins of the last 4-bin chunk
     }
+    AUD_STAMP(6);
+    if (j < 3) P[w25::kH + j] = TT(0);  // pad bins of the last 4-bin chunk
+    wave_tables_store<TT, 3>(e, smem, lane, tabs);
     wave_lds_fence();
     AUD_STAMP(7);
 
     // ---- optional spectrum outputs and the mel reduction: 8 frames x 8 filter groups on this wave -------------
-    tile_epilogue<TT, 64, w25::kFW, true>(a, e, Pw, w25::kHp, smem, it, item, t0, lane);
+    wave_mel_epilogue<TT, w25::kFW>(a, e, Pw, w25::kHp, smem, it, item, t0, lane);
     AUD_STAMP(8);
     AUD_STAMP_FLUSH(a, wt, lane);
 }
@@ -388,7 +378,8 @@ bool melspec_w16_supported(int N, int S, int compute_dtype, int n_chunks, int nf
     const int n_groups = 64 / w16::kFW, n_sched = n_groups + 1 + 4 * nf;
     const size_t tsz = compute_dtype == AUD_F64 ? 8 : 4;
     const size_t w4 = (size_t(n_chunks) * 4 * tsz + 31) & ~size_t(31);
-    const size_t sched = (size_t(n_sched) * 2 + 31) & ~size_t(31);  // kept as uint16 in LDS
+    const int n_slots = wave_slot_bound(nf, n_groups);               // LDS carve; the plan sets the actual n_slots
+    const size_t sched = (size_t(n_groups) * n_slots * 8 + 31) & ~size_t(31);  // filter slots, 8 bytes each
     const size_t region = compute_dtype == AUD_F64 ? size_t(w16::Layout<double>::kRegion) : size_t(w16::Layout<float>::kRegion);
     const size_t total = w4 + sched + kWaves * region;
     if (total > 160 * 1024) return false;
@@ -396,6 +387,7 @@ bool melspec_w16_supported(int N, int S, int compute_dtype, int n_chunks, int nf
         *out = FastArgs{};
         out->w4_off = 0;
         out->sched_off = int(w4);
+        out->slots_off = int(w4);
         out->xch_off = int(w4 + sched);
         out->p_off = out->xch_off;
         out->n_sched = n_sched;
@@ -434,7 +426,8 @@ bool melspec_w25_supported(int N, int S, int compute_dtype, int n_chunks, int nf
     const int n_groups = 64 / w25::kFW, n_sched = n_groups + 1 + 4 * nf;
     const size_t tsz = compute_dtype == AUD_F64 ? 8 : 4;
     const size_t w4 = (size_t(n_chunks) * 4 * tsz + 31) & ~size_t(31);
-    const size_t sched = (size_t(n_sched) * 2 + 31) & ~size_t(31);  // kept as uint16 in LDS
+    const int n_slots = wave_slot_bound(nf, n_groups);               // LDS carve; the plan sets the actual n_slots
+    const size_t sched = (size_t(n_groups) * n_slots * 8 + 31) & ~size_t(31);  // filter slots, 8 bytes each
     const size_t region = compute_dtype == AUD_F64 ? size_t(w25::Layout<double>::kRegion) : size_t(w25::Layout<float>::kRegion);
     const size_t total = w4 + sched + kWaves * region;
     if (total > 160 * 1024) return false;
@@ -442,6 +435,7 @@ bool melspec_w25_supported(int N, int S, int compute_dtype, int n_chunks, int nf
         *out = FastArgs{};
         out->w4_off = 0;
         out->sched_off = int(w4);
+        out->slots_off = int(w4);
         out->xch_off = int(w4 + sched);
         out->p_off = out->xch_off;
         out->n_sched = n_sched;
