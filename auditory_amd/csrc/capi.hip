@@ -48,7 +48,7 @@ struct aud_plan {
     aud::FastArgs wv{};
     int* d_grp = nullptr;  // [17 + nf + 3 nf]: group offsets, filter ids, per-filter chunk info
     void* d_w4 = nullptr;  // chunked triangle weights
-    void* d_slots = nullptr;  // wave kernels: [groups][n_slots] filter slot records
+    void* d_blob = nullptr;   // wave kernels: every read-only table, laid out like its LDS copy (kernels.h FastArgs)
     int* d_blk = nullptr;     // matrix-pipe mel variant (r16x16, float32): per 16-filter block {chunk0, steps, offset}
     float* d_atab = nullptr;  // ... and its lane-ordered A operands [steps][64]
     int n_blocks = 0;
@@ -174,9 +174,9 @@ void fill_melspec_args(const aud_plan* p, aud::MelspecArgs* a) {
 // the plan's frame -> power -> mel kernel (whatever family it selected), raw power, no smoothing
 hipError_t launch_frames(const aud_plan* p, const aud::MelspecArgs& a, hipStream_t st) {
     if (p->use_fast && p->use_wave && p->wave_kind == aud_plan::kW16)
-        return aud::launch_melspec_w16(a, p->wv, p->d.compute_dtype, st);
+        return aud::launch_melspec_wave(1, a, p->wv, p->d.compute_dtype, st);
     if (p->use_fast && p->use_wave && p->wave_kind == aud_plan::kW25)
-        return aud::launch_melspec_w25(a, p->wv, p->d.compute_dtype, st);
+        return aud::launch_melspec_wave(2, a, p->wv, p->d.compute_dtype, st);
     if (p->use_fast && p->fast_kind == aud_plan::kR16) return aud::launch_melspec_r16(a, p->r16, p->d.compute_dtype, st);
     if (p->use_fast && p->fast_kind == aud_plan::kR25) return aud::launch_melspec_r25(a, p->r16, p->d.compute_dtype, st);
     if (p->use_fast && p->fast_kind == aud_plan::kR1024)
@@ -185,6 +185,130 @@ hipError_t launch_frames(const aud_plan* p, const aud::MelspecArgs& a, hipStream
 }
 
 const char* plan_family(const aud_plan* p);
+
+// Tables of the wave-autonomous kernels (melspec_wave.hip) as one blob that is copied verbatim into LDS:
+//   w4     the mel triangles as aligned 4-bin chunks (zero weights outside [lo, hi]) + one all-zero chunk
+//   steps  per filter group a flat, padded list of chunk steps {P chunk, w4 chunk, slot, first / last of its filter};
+//          groups are balanced by step count (longest filter first), so every lane runs the same number of steps
+//   slots  per group the filter id of each slot
+//   twa    pass twiddles W_N^(2 j k1), [k1 - 1][j]; tws: split twiddles W_N^k, k <= N/4
+// A plan whose tables do not fit (16-bit indices, LDS) simply has no wave kernel.
+int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_filters) {
+    aud_ctx* c = p->ctx;
+    const aud_plan_desc& d = p->d;
+    const int N = d.win_samples, nf = d.mel.n_filters, dt = d.compute_dtype;
+    const int kind = p->fast_kind == aud_plan::kR16 ? 1 : p->fast_kind == aud_plan::kR25 ? 2 : 0;
+    aud::WaveGeometry g;
+    if (!kind || !aud::melspec_wave_geometry(kind, N, &g)) return AUD_OK;
+    const size_t tsz = dt == AUD_F64 ? 8 : 4;
+    // chunks per filter
+    std::vector<int> c0(nf), nc(nf), wo(nf);
+    std::vector<double> w4;
+    for (int f = 0; f < nf; ++f) {
+        const int lo = bin_pts[f], hi = bin_pts[f + 2];
+        c0[f] = lo >> 2;
+        nc[f] = hi >= lo ? (hi >> 2) - (lo >> 2) + 1 : 0;
+        wo[f] = int(w4.size() / 4);
+        for (int ci = 0; ci < nc[f]; ++ci)
+            for (int el = 0; el < 4; ++el) {
+                const int bin = 4 * (c0[f] + ci) + el;
+                w4.push_back(bin >= lo && bin <= hi ? mel_filters[int64_t(f) * (nf + 2) + (bin - lo)] : 0.0);
+            }
+    }
+    const int zero_chunk = int(w4.size() / 4);
+    w4.insert(w4.end(), 4, 0.0);
+    if (zero_chunk >= 0xFFFF || nf >= 0xFFFF) return AUD_OK;
+    // groups balanced by step count (a filter without taps still takes one step: its sum is 0 + LogOff)
+    std::vector<int> order(nf), load(g.n_groups, 0), cnt(g.n_groups, 0), owner(nf);
+    for (int f = 0; f < nf; ++f) order[f] = f;
+    auto steps_of = [&](int f) { return nc[f] > 0 ? nc[f] : 1; };
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return steps_of(x) > steps_of(y); });
+    for (int f : order) {
+        int best = -1;
+        for (int cnd = 0; cnd < g.n_groups; ++cnd)
+            if (cnt[cnd] < 16 && (best < 0 || load[cnd] < load[best])) best = cnd;
+        if (best < 0) return AUD_OK;  // more than 16 filters per group: no wave kernel
+        owner[f] = best;
+        load[best] += steps_of(f);
+        ++cnt[best];
+    }
+    int n_steps = 1, n_slots = 1;
+    for (int gi = 0; gi < g.n_groups; ++gi) {
+        n_steps = std::max(n_steps, load[gi]);
+        n_slots = std::max(n_slots, cnt[gi]);
+    }
+    n_steps = (n_steps + 3) & ~3;  // the step loop is unrolled by four
+    std::vector<uint32_t> steps(size_t(g.n_groups) * n_steps * 2);
+    std::vector<uint16_t> slots(size_t(g.n_groups) * n_slots, 0xFFFF);
+    for (int gi = 0; gi < g.n_groups; ++gi) {
+        int pos = 0, slot = 0;
+        for (int f = 0; f < nf; ++f) {  // ascending filter order inside a group
+            if (owner[f] != gi) continue;
+            slots[size_t(gi) * n_slots + slot] = uint16_t(f);
+            const int ns = steps_of(f);
+            for (int st = 0; st < ns; ++st, ++pos) {
+                uint32_t* r = &steps[(size_t(gi) * n_steps + pos) * 2];
+                const int pc = nc[f] > 0 ? c0[f] + st : 0, wi = nc[f] > 0 ? wo[f] + st : zero_chunk;
+                r[0] = uint32_t(pc) | (uint32_t(wi) << 16);
+                r[1] = uint32_t(slot) | (st == 0 ? 0x100u : 0u) | (st == ns - 1 ? 0x200u : 0u);
+            }
+            ++slot;
+        }
+        for (; pos < n_steps; ++pos) {  // padding: a step that restarts the running sum and belongs to no slot
+            uint32_t* r = &steps[(size_t(gi) * n_steps + pos) * 2];
+            r[0] = uint32_t(zero_chunk) << 16;
+            r[1] = 0xFFu | 0x100u;
+        }
+    }
+    // twiddles, from the same long-double formula as the plan's W_N table
+    const long double w = -2.0L * 3.14159265358979323846264338327950288L / (long double)N;
+    auto tw = [&](int k, double* out) { out[0] = double(cosl(w * (k % N))); out[1] = double(sinl(w * (k % N))); };
+    std::vector<double> twa(size_t(g.k1_rows - 1) * g.lanes_per_frame * 2), tws(size_t(g.split_count) * 2);
+    for (int k1 = 1; k1 < g.k1_rows; ++k1)
+        for (int j = 0; j < g.lanes_per_frame; ++j) tw(2 * j * k1, &twa[(size_t(k1 - 1) * g.lanes_per_frame + j) * 2]);
+    for (int k = 0; k < g.split_count; ++k) tw(k, &tws[size_t(k) * 2]);
+    // the blob
+    auto align32 = [](size_t v) { return (v + 31) & ~size_t(31); };
+    aud::FastArgs e{};
+    const size_t w4_bytes = align32(w4.size() * tsz);
+    e.w4_off = 0;
+    e.n_chunks = zero_chunk + 1;
+    e.steps_off = int(w4_bytes);
+    e.n_steps = n_steps;
+    e.slots_off = int(e.steps_off + align32(steps.size() * 4));
+    e.n_slots = n_slots;
+    e.twa_off = int(e.slots_off + align32(slots.size() * 2));
+    e.tws_off = int(e.twa_off + align32(twa.size() * tsz));
+    e.blob_bytes = int(e.tws_off + align32(tws.size() * tsz));
+    e.n_groups = g.n_groups;
+    std::vector<unsigned char> blob(size_t(e.blob_bytes), 0);
+    auto put_real = [&](size_t off, const std::vector<double>& v) {
+        if (dt == AUD_F64) std::memcpy(&blob[off], v.data(), v.size() * 8);
+        else {
+            std::vector<float> fv = convert<float>(v.data(), v.size());
+            std::memcpy(&blob[off], fv.data(), fv.size() * 4);
+        }
+    };
+    put_real(size_t(e.w4_off), w4);
+    std::memcpy(&blob[size_t(e.steps_off)], steps.data(), steps.size() * 4);
+    std::memcpy(&blob[size_t(e.slots_off)], slots.data(), slots.size() * 2);
+    put_real(size_t(e.twa_off), twa);
+    put_real(size_t(e.tws_off), tws);
+    if (!aud::melspec_wave_finish(kind, dt, &e)) return AUD_OK;  // does not fit LDS
+    if (e.lds_bytes > 64u * 1024u && aud::melspec_wave_prepare(kind, e.lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return AUD_OK;
+    }
+    const int rc = upload(c, &p->d_blob, blob.data(), blob.size());
+    if (rc != AUD_OK) return rc;
+    e.blob = p->d_blob;
+    p->wv = e;
+    p->wave_kind = kind == 1 ? aud_plan::kW16 : aud_plan::kW25;
+    p->use_wave = true;
+    p->family = plan_family(p);
+    return AUD_OK;
+}
+
 // the r16_* switches are variants of the workgroup-tile kernel: setting one selects that kernel
 void select_tile_kernel(aud_plan* p) {
     p->use_fast = true;
@@ -442,59 +566,8 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
             p->r16.n_blocks = p->n_blocks;
             p->r16.blk = p->d_blk;
             p->r16.atab = p->d_atab;
-            // the wave-autonomous kernel of this window length shares the tables (same number of filter groups)
-            aud::FastArgs wcfg;
-            int wave_kind = aud_plan::kNoWave;
-            if (fast_kind == aud_plan::kR16 &&
-                aud::melspec_w16_supported(N, d->step_samples, d->compute_dtype, r16_chunks, nf, &wcfg))
-                wave_kind = aud_plan::kW16;
-            else if (fast_kind == aud_plan::kR25 &&
-                     aud::melspec_w25_supported(N, d->step_samples, d->compute_dtype, r16_chunks, nf, &wcfg))
-                wave_kind = aud_plan::kW25;
-            if (wave_kind != aud_plan::kNoWave && wcfg.lds_bytes > 64u * 1024u) {
-                const hipError_t pe = wave_kind == aud_plan::kW16 ? aud::melspec_w16_prepare(wcfg.lds_bytes)
-                                                                  : aud::melspec_w25_prepare(wcfg.lds_bytes);
-                if (pe != hipSuccess) {
-                    (void)hipGetLastError();
-                    wave_kind = aud_plan::kNoWave;
-                }
-            }
-            if (wave_kind != aud_plan::kNoWave) {
-                // filter slots: per group its filters as {filter | first chunk << 16, chunks | w4 offset << 16}
-                int n_slots = 1;
-                for (int g = 0; g < n_groups; ++g) n_slots = std::max(n_slots, tab[g + 1] - tab[g]);
-                bool fits16 = true;
-                std::vector<uint32_t> slots(size_t(n_groups) * n_slots * 2, 0);
-                for (int g = 0; g < n_groups; ++g)
-                    for (int sl = 0; sl < n_slots; ++sl) {
-                        uint32_t* r = &slots[(size_t(g) * n_slots + sl) * 2];
-                        if (tab[g] + sl < tab[g + 1]) {
-                            const int f = tab[goff + tab[g] + sl];
-                            const int* ci = &tab[goff + nf + 3 * f];
-                            fits16 = fits16 && f < 0xFFFF && ci[0] < 0x10000 && ci[1] < 0x10000 && ci[2] < 0x10000;
-                            r[0] = uint32_t(f) | (uint32_t(ci[0]) << 16);
-                            r[1] = uint32_t(ci[1]) | (uint32_t(ci[2]) << 16);
-                        } else {
-                            r[0] = 0xFFFFu;  // empty slot
-                            r[1] = 0;
-                        }
-                    }
-                if (!fits16 || n_slots > aud::wave_slot_bound(nf, n_groups)) wave_kind = aud_plan::kNoWave;
-                if (wave_kind != aud_plan::kNoWave)
-                    rc = upload(c, &p->d_slots, slots.data(), slots.size() * sizeof(uint32_t));
-                wcfg.n_slots = n_slots;
-                wcfg.slots = static_cast<const uint2*>(p->d_slots);
-            }
-            if (rc == AUD_OK && wave_kind != aud_plan::kNoWave) {
-                wcfg.grp_off = p->r16.grp_off;
-                wcfg.grp_flt = p->r16.grp_flt;
-                wcfg.chunk = p->r16.chunk;
-                wcfg.w4 = p->r16.w4;
-                p->wv = wcfg;
-                p->wave_kind = wave_kind;
-                p->use_wave = true;
-                p->family = plan_family(p);
-            }
+            // the wave-autonomous kernel of this window length (melspec_wave.hip) has its own table blob
+            if (rc == AUD_OK) rc = build_wave_tables(p, d->bin_pts, d->mel_filters);
         }
     }
     if (rc != AUD_OK) {
@@ -515,7 +588,7 @@ int aud_plan_destroy(aud_plan* p) {
     if (p->d_dct) (void)hipFree(p->d_dct);
     if (p->d_grp) (void)hipFree(p->d_grp);
     if (p->d_w4) (void)hipFree(p->d_w4);
-    if (p->d_slots) (void)hipFree(p->d_slots);
+    if (p->d_blob) (void)hipFree(p->d_blob);
     if (p->d_blk) (void)hipFree(p->d_blk);
     if (p->d_atab) (void)hipFree(p->d_atab);
     delete p;

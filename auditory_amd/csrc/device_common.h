@@ -385,110 +385,50 @@ __device__ __forceinline__ void tile_epilogue(const MelspecArgs& a, const FastAr
 }
 
 // ---- epilogue of the wave-autonomous kernels ---------------------------------------------------------------
-// Same-value races on the read-only LDS tables are part of their design (every wave of a workgroup writes its
-// own identical copy; see melspec_wave.hip).  The emulator's ThreadSanitizer build is told so; on the GPU the
-// macros are empty.
-#ifndef AUD_BENIGN_RACE_BEGIN
-#define AUD_BENIGN_RACE_BEGIN()
-#define AUD_BENIGN_RACE_END()
-#endif
-
-// Table loads of one wave (issued early, held in registers while other work covers their latency) ...
-template <typename TT, int MAXQ>
-struct WaveTables {
-    Q4<TT> w[MAXQ];
-    uint2 slot[2];
-};
-template <typename TT, int MAXQ>
-__device__ __forceinline__ void wave_tables_fetch(const FastArgs& e, int lane, WaveTables<TT, MAXQ>& t) {
-    const Q4<TT>* __restrict__ gw = static_cast<const Q4<TT>*>(e.w4);
-#pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-        const int c = lane + 64 * q;
-        t.w[q] = gw[c < e.n_chunks ? c : 0];
-    }
-    const int ns = e.n_groups * e.n_slots;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int c = lane + 64 * q;
-        t.slot[q] = e.slots[c < ns ? c : 0];
-    }
-}
-// ... and their stores into the workgroup's LDS copy (every wave stores the same values to the same places)
-template <typename TT, int MAXQ>
-__device__ __forceinline__ void wave_tables_store(const FastArgs& e, unsigned char* smem, int lane,
-                                                  const WaveTables<TT, MAXQ>& t) {
-    Q4<TT>* lw = reinterpret_cast<Q4<TT>*>(smem + e.w4_off);
-    uint2* ls = reinterpret_cast<uint2*>(smem + e.slots_off);
-    const Q4<TT>* __restrict__ gw = static_cast<const Q4<TT>*>(e.w4);
-    AUD_BENIGN_RACE_BEGIN();
-#pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-        const int c = lane + 64 * q;
-        if (c < e.n_chunks) lw[c] = t.w[q];
-    }
-#pragma unroll 1
-    for (int c = lane + 64 * MAXQ; c < e.n_chunks; c += 64) lw[c] = gw[c];  // plans with very many chunks
-    const int ns = e.n_groups * e.n_slots;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int c = lane + 64 * q;
-        if (c < ns) ls[c] = t.slot[q];
-    }
-#pragma unroll 1
-    for (int c = lane + 128; c < ns; c += 64) ls[c] = e.slots[c];
-    AUD_BENIGN_RACE_END();
-}
-
 // P: this wave's [FPW][Hp] power spectrum in LDS.  64 lanes = FPW frames x (64 / FPW) filter groups.  Optional
-// spectrum outputs as tile_epilogue; the mel reduction (mel/mel.go:120-153) takes the group's filter slots two at a
-// time, four partial sums per filter (bins 4c, 4c+1, 4c+2, 4c+3 of the aligned chunks), combined pairwise at the
-// end: the products are the reference's, the order of the additions is not (float64: far below the float32 spacing
-// of the stored value; float32: no worse than the sequential order).
-template <typename TT, int FPW>
-__device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const FastArgs& e, const TT* P, int Hp,
-                                                  const unsigned char* smem, const aud_item& it, int item, int t0,
-                                                  int lane) {
-    const int T = a.T, N = a.N;
-    tile_spectrum_outputs<TT, 64, FPW>(a, P, Hp, it, item, t0, lane);
-    const int ff = lane % FPW, grp = lane / FPW;
-    const int sstep = t0 + ff;
-    const bool col_on = sstep < T;
-    const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
-    const bool live = col_on && start + N <= int64_t(it.sig_len);
+// spectrum outputs as tile_epilogue.  The mel reduction (mel/mel.go:120-153) walks the group's padded list of chunk
+// steps (kernels.h FastArgs): every step is one 4-bin chunk of one filter, dot(w4 chunk, P chunk) added to a running
+// sum that a step flagged `first` restarts; a step flagged `last` parks the sum in its filter's slot.  The loop has
+// no data-dependent branch, so the LDS reads of four steps are in flight together (the first version walked one
+// dependent chain per filter and took 27 % of a wave's life, profiles/r02c_stamps_*); logarithms and stores follow
+// for all slots at once.  Products are the reference's; the additions are pairwise inside a chunk and in bin order
+// across chunks (float64: far below the float32 spacing of the stored value).
+template <typename TT, int FPW, int MAXS>
+__device__ __forceinline__ void wave_mel_steps_impl(const MelspecArgs& a, const FastArgs& e, const TT* P, int Hp,
+                                                    const unsigned char* smem, int item, int sstep, bool col_on,
+                                                    bool live, int ff, int grp) {
+    const int T = a.T;
     typedef Q4<TT> quad_t;
     const quad_t* w4 = reinterpret_cast<const quad_t*>(smem + e.w4_off);
     const quad_t* prow = reinterpret_cast<const quad_t*>(P + ff * Hp);
-    const uint2* recs = reinterpret_cast<const uint2*>(smem + e.slots_off) + grp * e.n_slots;
+    const uint2* recs = reinterpret_cast<const uint2*>(smem + e.steps_off) + grp * e.n_steps;
+    TT acc = TT(0);
+    TT sums[MAXS];
+#pragma unroll
+    for (int k = 0; k < MAXS; ++k) sums[k] = TT(0);
+    if (live) {
+#pragma unroll 4
+        for (int s = 0; s < e.n_steps; ++s) {
+            const uint2 r = recs[s];
+            const quad_t pw = prow[r.x & 0xFFFFu], ww = w4[r.x >> 16];
+            const TT t0 = ww.x * pw.x + ww.y * pw.y, t1 = ww.z * pw.z + ww.w * pw.w;
+            const TT part = t0 + t1;
+            acc = (r.y & 0x100u) ? part : acc + part;
+            const int slot = (r.y & 0x200u) ? int(r.y & 0xFFu) : -1;
+#pragma unroll
+            for (int k = 0; k < MAXS; ++k) sums[k] = (slot == k) ? acc : sums[k];
+        }
+    }
+    const unsigned short* slots = reinterpret_cast<const unsigned short*>(smem + e.slots_off) + grp * e.n_slots;
     const TT loff = TT(a.mel_log_off), lmin = TT(a.mel_log_min);
     float* mel_col = a.mel + (size_t(item) * a.nf * T + (col_on ? sstep : 0));
-    AUD_BENIGN_RACE_BEGIN();
-    for (int s = 0; s < e.n_slots; s += 2) {
-        const uint2 ra = recs[s];
-        const uint2 rb = (s + 1 < e.n_slots) ? recs[s + 1] : uint2{0xFFFFu, 0u};
-        const int flt_a = int(ra.x & 0xFFFFu), flt_b = int(rb.x & 0xFFFFu);
-        const int c0_a = int(ra.x >> 16), c0_b = int(rb.x >> 16);
-        const int wo_a = int(ra.y >> 16), wo_b = int(rb.y >> 16);
-        const int nc_a = live ? int(ra.y & 0xFFFFu) : 0, nc_b = live ? int(rb.y & 0xFFFFu) : 0;
-        const int ncm = nc_a > nc_b ? nc_a : nc_b;
-        TT a0 = TT(0), a1 = TT(0), a2 = TT(0), a3 = TT(0), b0 = TT(0), b1 = TT(0), b2 = TT(0), b3 = TT(0);
-#pragma unroll 2
-        for (int c = 0; c < ncm; ++c) {
-            if (c < nc_a) {
-                const quad_t pw = prow[c0_a + c], ww = w4[wo_a + c];
-                a0 += ww.x * pw.x; a1 += ww.y * pw.y; a2 += ww.z * pw.z; a3 += ww.w * pw.w;
-            }
-            if (c < nc_b) {
-                const quad_t pw = prow[c0_b + c], ww = w4[wo_b + c];
-                b0 += ww.x * pw.x; b1 += ww.y * pw.y; b2 += ww.z * pw.z; b3 += ww.w * pw.w;
-            }
-        }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int flt = h ? flt_b : flt_a;
+    for (int k = 0; k < MAXS; ++k) {
+        if (k < e.n_slots) {
+            const int flt = slots[k];
             float res = 0.f;
             if (live) {
-                const TT sum = (h ? (b0 + b1) + (b2 + b3) : (a0 + a1) + (a2 + a3)) + loff;
+                const TT sum = sums[k] + loff;
                 TT val = (sum == TT(0)) ? lmin : feature_log(sum);
                 if (a.renorm) {
                     val -= TT(a.renorm_min);
@@ -501,7 +441,21 @@ __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const Fa
             if (col_on && flt != 0xFFFF) mel_col[size_t(flt) * T] = res;  // MelFBankSegment[item][flt][sstep]
         }
     }
-    AUD_BENIGN_RACE_END();
+}
+
+template <typename TT, int FPW>
+__device__ __forceinline__ void wave_mel_steps(const MelspecArgs& a, const FastArgs& e, const TT* P, int Hp,
+                                               const unsigned char* smem, const aud_item& it, int item, int t0,
+                                               int lane) {
+    tile_spectrum_outputs<TT, 64, FPW>(a, P, Hp, it, item, t0, lane);
+    const int ff = lane % FPW, grp = lane / FPW;
+    const int sstep = t0 + ff;
+    const bool col_on = sstep < a.T;
+    const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
+    const bool live = col_on && start + a.N <= int64_t(it.sig_len);
+    if (e.n_slots <= 4) wave_mel_steps_impl<TT, FPW, 4>(a, e, P, Hp, smem, item, sstep, col_on, live, ff, grp);
+    else if (e.n_slots <= 8) wave_mel_steps_impl<TT, FPW, 8>(a, e, P, Hp, smem, item, sstep, col_on, live, ff, grp);
+    else wave_mel_steps_impl<TT, FPW, 16>(a, e, P, Hp, smem, item, sstep, col_on, live, ff, grp);
 }
 
 // ---- mel on the matrix pipe (float32 only; an experiment the plan can switch on) -------------------

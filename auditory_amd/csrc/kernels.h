@@ -114,11 +114,18 @@ struct FastArgs {
     int n_blocks;          // filter blocks of 16 for the matrix-pipe variant
     const int* blk;        // [n_blocks][3] device: first 4-bin chunk, K-steps, offset (in steps) into atab
     const float* atab;     // [steps][64] device: A operands, lane-ordered
-    // wave-autonomous kernels: per filter group, n_slots records {filter | first chunk << 16, chunks | w4 offset << 16}
-    // (filter 0xFFFF = empty slot); one 8-byte LDS read per filter instead of a three-level table walk
-    const uint2* slots;    // [n_groups][n_slots] device
+    // wave-autonomous kernels (melspec_wave.hip): all read-only tables live in ONE device blob laid out exactly like
+    // its LDS copy -- [w4 chunks + one zero chunk | step records | slot filter ids | pass twiddles | split twiddles]
+    // -- so staging is a flat 16-byte-piece copy.  Offsets below are bytes from the start of dynamic LDS / the blob.
+    const void* blob;      // device
+    int blob_bytes;        // multiple of 16
+    int steps_off;         // uint2 [n_groups][n_steps]: {P chunk | w4 chunk << 16, slot | first << 8 | last << 9}
+    int n_steps;
+    int slots_off;         // uint16 [n_groups][n_slots]: filter id, 0xFFFF = empty
     int n_slots;
-    int slots_off;         // byte offset of the LDS copy
+    int twa_off;           // pass twiddles, C2<TT> [K1 - 1][lanes per frame]: W^(2 j k1)
+    int tws_off;           // split twiddles, C2<TT> [N/4 + 1]: W_N^k
+    int waves;             // waves per workgroup of the launch
 };
 
 // PrevSmooth != 0 mode: scan along the steps of a stored power tensor
@@ -167,20 +174,17 @@ bool melspec_r25_supported(int N, int S, int compute_dtype, int n_chunks, int nf
 hipError_t melspec_r25_prepare(unsigned lds_bytes);
 hipError_t launch_melspec_r25(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
 
-// filter slots per group the wave kernels reserve LDS for (the plan's balanced grouping must fit, else no wave kernel)
-inline int wave_slot_bound(int nf, int n_groups) {
-    const int b = 2 * ((nf + n_groups - 1) / n_groups) + 2;
-    return b < nf ? b : nf;
-}
-
 // wave-autonomous kernels (melspec_wave.hip): N = 512 as 16 x 16 and N = 400 as 25 x 8, one wave per 4 / 8 frames,
 // no workgroup barrier behind the weight staging.  FastArgs: w4_off / sched_off / xch_off (first wave region).
-bool melspec_w16_supported(int N, int S, int compute_dtype, int n_chunks, int nf, FastArgs* out);
-hipError_t melspec_w16_prepare(unsigned lds_bytes);
-hipError_t launch_melspec_w16(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
-bool melspec_w25_supported(int N, int S, int compute_dtype, int n_chunks, int nf, FastArgs* out);
-hipError_t melspec_w25_prepare(unsigned lds_bytes);
-hipError_t launch_melspec_w25(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
+// kind: 1 = w16x16 (N = 512), 2 = w25x8 (N = 400).  *_geometry: filter groups of the epilogue, lanes per frame and
+// twiddle rows of the pass table; *_finish: carve LDS behind a blob of blob_bytes, false if it cannot fit.
+struct WaveGeometry {
+    int n_groups, lanes_per_frame, k1_rows, split_count;
+};
+bool melspec_wave_geometry(int kind, int N, WaveGeometry* g);
+bool melspec_wave_finish(int kind, int compute_dtype, FastArgs* e);
+hipError_t melspec_wave_prepare(int kind, unsigned lds_bytes);
+hipError_t launch_melspec_wave(int kind, const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
 
 // N = 2048 fast path (one wave per frame, 16 x 16 x 4)
 bool melspec_r1024_supported(int N, int S, int compute_dtype, int n_chunks, int nf, FastArgs* out);

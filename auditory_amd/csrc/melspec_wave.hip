@@ -4,33 +4,30 @@
 // instantiations keep a whole tile's complex transpose buffer in LDS (58-72 KB per workgroup), so a CU holds one
 // or two waves per SIMD, every wave spends more than half its life parked at one of three workgroup barriers
 // (SQ_WAIT_ANY 55 % of SQ_WAVE_CYCLES) and the vector ALU is busy a fifth of the time.  These kernels remove the
-// cause instead of tuning around it:
+// causes instead of tuning around them (s_memtime stamps of each step of the way: profiles/r02c..e_stamps_*):
 //
 //   * the unit of work is a WAVE, not a workgroup: 64 lanes carry 4 frames x 16 lanes (N = 512) or 8 frames x
 //     8 lanes (N = 400) from the samples to the mel values.  Lanes of one wave exchange data through a
 //     wave-private LDS region ordered by wave_lds_fence() -- the hardware runs a wave's LDS instructions in
-//     order -- and there is NO workgroup barrier at all: the stamps of the first version (profiles/r02c_stamps_*)
-//     showed the one barrier behind the staging of the mel weights costing 11 % of a wave's life (the waves of a
-//     workgroup leave their load phase thousands of cycles apart).  Each wave now writes its own, identical copy
-//     of the small read-only tables (mel weights, filter slots) to the shared LDS locations just before its
-//     epilogue -- a benign same-value race with the other waves' reads -- so no wave ever waits for another;
-//   * the wave index is made scalar (readfirstlane), so the work-item record is one scalar load and the
-//     address arithmetic runs on the scalar unit; operand and twiddle loads are issued back to back before the
-//     first wait;
-//   * the mel reduction walks per-group filter slots ({filter, first chunk, chunks, weight offset} records, one
-//     LDS read each) two filters at a time with four partial sums per filter: eight independent FMA chains
-//     instead of one (the first version's epilogue was a single dependent chain and took 27 % of the wave);
+//     order -- so the data path has no workgroup barrier;
+//   * every read-only table (mel weight chunks, the epilogue's step records, pass and split twiddles) comes as ONE
+//     blob that the workgroup copies into LDS at its very start: the blob loads are issued first, the operand
+//     loads behind them, and a counted wait (the loads return in order) lets the blob be stored and the single
+//     barrier be passed while the operands are still in flight.  Twiddles read from global memory per wave were
+//     two thirds of the first version's L1 traffic (15 + 2 KB per 4 frames in float64, against 8 KB of samples);
 //   * the transposes go through LDS one component at a time (all real parts, then all imaginary parts), which
-//     halves the footprint: 9 KB (N = 512) / 16 KB (N = 400) per wave in float64, half of that in float32;
-//     the power spectrum then reuses the same region.  That is 3 waves per SIMD in float64 for N = 512, 2 for
-//     N = 400, 4-6 in float32;
-//   * row pitches are an odd number of 16-byte slots and frame pitches a multiple of 16 slots, so the column
-//     stores (one frame per 16-lane store group) and the 16-byte row loads are conflict-free;
-//   * float64 plans take the final logarithm in float32 (feature_log, device_common.h): the stored value is a
-//     float32 anyway.
+//     halves the footprint: 9 KB (N = 512) / 17 KB (N = 400) per wave in float64, half of that in float32; the
+//     power spectrum then reuses the same region.  Row pitches are an odd number of 16-byte slots and frame
+//     pitches 0 / 8 (mod 16) slots, so the 16-byte row loads are conflict-free;
+//   * N = 400: the partner of Z[k1 + 25 k2] in the real-FFT split is element (25 - k1, 7 - k2), so a lane takes
+//     the row PAIR (r, 25 - r) and has both halves of all eight pairs in its own registers: no cross-lane traffic;
+//   * the wave index is scalar (readfirstlane): the work-item record is one scalar load and the address
+//     arithmetic runs on the scalar unit;
+//   * the mel reduction is a branch-free walk over padded chunk steps (wave_mel_steps, device_common.h);
+//   * float64 plans take the final logarithm in float32 (feature_log): the stored value is a float32 anyway.
 //
-// Arithmetic (DFT factorisation, twiddles, real-FFT split, chunked mel reduction and its summation order) is
-// that of the workgroup-tile kernels, which stay in the library as plan option "kernel" = 2.
+// Arithmetic (DFT factorisation, twiddle values, real-FFT split) is that of the workgroup-tile kernels, which stay
+// in the library as plan option "kernel" = 2.
 //
 // Reference semantics: sound/sndenv.go:438-478, dft/dft.go:53-85, mel/mel.go:120-153.
 #include "device_common.h"
@@ -38,7 +35,35 @@
 namespace aud {
 namespace {
 
-constexpr int kWaves = 4;  // waves per workgroup (they only share the LDS copy of the mel weights)
+// The workgroup's table blob: loads first (kept in registers), stores after the caller has issued its operand loads.
+// NT threads, up to 4 x 16 bytes per thread in flight; larger blobs finish with a plain copy loop.
+template <int NT>
+struct BlobRegs {
+    uint4 v[4];
+};
+template <int NT>
+__device__ __forceinline__ void blob_fetch(const FastArgs& e, int tid, BlobRegs<NT>& b) {
+    const uint4* __restrict__ g = static_cast<const uint4*>(e.blob);
+    const int n16 = e.blob_bytes >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = tid + NT * q;
+        b.v[q] = g[i < n16 ? i : 0];
+    }
+}
+template <int NT>
+__device__ __forceinline__ void blob_store(const FastArgs& e, unsigned char* smem, int tid, const BlobRegs<NT>& b) {
+    uint4* l = reinterpret_cast<uint4*>(smem);
+    const uint4* __restrict__ g = static_cast<const uint4*>(e.blob);
+    const int n16 = e.blob_bytes >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = tid + NT * q;
+        if (i < n16) l[i] = b.v[q];
+    }
+#pragma unroll 1
+    for (int i = tid + 4 * NT; i < n16; i += NT) l[i] = g[i];
+}
 
 // ================================================================================================
 // N = 512: 256-point complex FFT as 16 x 16, 16 lanes per frame, 4 frames per wave
@@ -60,47 +85,53 @@ struct Layout {
 };
 }  // namespace w16
 
-template <typename TT, bool PCM16>
-__global__ __launch_bounds__(64 * kWaves) void k_melspec_w16(const MelspecArgs a, const FastArgs e) {
+template <typename TT, bool PCM16, int NW>
+__global__ __launch_bounds__(64 * NW) void k_melspec_w16(const MelspecArgs a, const FastArgs e) {
     using L = w16::Layout<TT>;
     unsigned char* smem = dyn_lds();
-    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);  // scalar: item record and addresses on the SALU
-    const int lane = int(threadIdx.x) & 63;
+    const int tid = int(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: item record and addresses on the SALU
+    const int lane = tid & 63;
     const int f = lane >> 4;   // frame within the wave
     const int j = lane & 15;   // lane within the frame's 16-lane group
     const int T = a.T;
-
-    const int tiles = (T + w16::kFW - 1) / w16::kFW;  // wave tiles per item
-    const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
-    const int64_t wt = int64_t(wg) * kWaves + wave;
-    if (wt >= int64_t(a.n_items) * tiles) return;  // wave-uniform; no barrier anywhere below
-    const int item = int(wt / tiles);
-    const int t0 = int(wt - int64_t(item) * tiles) * w16::kFW;
-    const aud_item it = a.items[item];
-    const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_512^k
     AUD_STAMP_DECL;
     AUD_STAMP(0);
 
+    // the workgroup's tables: requested before anything else so that a counted wait can pick them out
+    BlobRegs<64 * NW> blob;
+    blob_fetch<64 * NW>(e, tid, blob);
+
+    const int tiles = (T + w16::kFW - 1) / w16::kFW;  // wave tiles per item
+    const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
+    const int64_t wt = int64_t(wg) * NW + wave;
+    const bool on = wt < int64_t(a.n_items) * tiles;  // wave-uniform
+    const int item = on ? int(wt / tiles) : 0;
+    const int t0 = on ? int(wt - int64_t(item) * tiles) * w16::kFW : 0;
+    const aud_item it = a.items[item];
+
     // ---- pass 1 operands straight from global memory: z[16 n1 + j] = (x[32 n1 + 2j], x[.. + 1]) --------------
     C2<TT> v[16];
-    load_frame_pairs<TT, 16, 16, w16::kN, PCM16>(a, it, t0 + f, j, v);
-    // per-lane twiddles W_256^(j k1) = W_512^(2 j k1): 15 L1/L2-resident loads behind the operands, one wait for both
-    C2<TT> tw1[16];
-#pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) tw1[k1] = tw[2 * j * k1];
+    if (on) load_frame_pairs<TT, 16, 16, w16::kN, PCM16>(a, it, t0 + f, j, v);
     AUD_STAMP(1);
+
+    blob_store<64 * NW>(e, smem, tid, blob);  // waits for the blob loads only: the operands stay in flight
+    __syncthreads();                          // the one barrier: tables visible to the workgroup's waves
+    if (!on) return;
     AUD_STAMP(2);
 
     TT* xw = reinterpret_cast<TT*>(smem + e.xch_off + wave * L::kRegion);  // this wave's region
+    const C2<TT>* twa = reinterpret_cast<const C2<TT>*>(smem + e.twa_off);  // W_512^(2 j k1) at [(k1 - 1) 16 + j]
+    const C2<TT>* tws = reinterpret_cast<const C2<TT>*>(smem + e.tws_off);  // W_512^k, k <= 128
 
     // ---- pass 1: 16-point DFT over n1, twiddle -----------------------------------------------------------
 #ifdef AUD_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // operands and twiddles have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // operands have landed
 #endif
     AUD_STAMP(3);
     SmallDft<TT, 16>::run(v, nullptr, 0);
 #pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmul(v[k1], tw1[k1]);
+    for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmul(v[k1], twa[(k1 - 1) * 16 + j]);
     AUD_STAMP(4);
 
     // ---- transpose through the wave's LDS region, real parts then imaginary parts ---------------------------
@@ -136,10 +167,6 @@ __global__ __launch_bounds__(64 * kWaves) void k_melspec_w16(const MelspecArgs a
         }
     }
     AUD_STAMP(5);
-    // the split's twiddles W_512^(j + 16 q): requested here so that the second DFT covers their latency
-    C2<TT> wsp[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) wsp[q] = tw[j + 16 * q];
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2) v[n2] = C2<TT>{re[n2], im[n2]};
 
@@ -147,9 +174,6 @@ __global__ __launch_bounds__(64 * kWaves) void k_melspec_w16(const MelspecArgs a
     SmallDft<TT, 16>::run(v, nullptr, 0);
     wave_lds_fence();  // every row has been read: the region may take the power spectrum
     AUD_STAMP(6);
-    // this wave's copy of the mel weights and filter slots: requested now, stored behind the split
-    WaveTables<TT, 3> tabs;
-    wave_tables_fetch<TT, 3>(e, lane, tabs);
 
     // ---- real-FFT split + power (as melspec_r16.hip) -----------------------------------------------------
     // For k = j + 16 q (q = 0..7) the partner Z[256 - k] sits in lane (16 - j) & 15, register 15 - q (lane 0
@@ -169,7 +193,7 @@ __global__ __launch_bounds__(64 * kWaves) void k_melspec_w16(const MelspecArgs a
             B.y = __shfl(mine_y, partner, 64);
             const C2<TT> A = v[q];
             const int k = j + 16 * q;
-            const C2<TT> w = wsp[q];                    // W_512^k
+            const C2<TT> w = tws[k];                    // W_512^k
             const C2<TT> E = {A.x + B.x, A.y - B.y};    // A + conj(B)
             const C2<TT> D = {A.x - B.x, A.y + B.y};    // A - conj(B)
             const C2<TT> mD = {D.y, -D.x};              // -i D
@@ -185,16 +209,14 @@ __global__ __launch_bounds__(64 * kWaves) void k_melspec_w16(const MelspecArgs a
         // bins 257..259 only pad the last 4-bin chunk; their weights are zero but 0 * garbage must stay 0
         if (j >= 13) P[w16::kH + (j - 13)] = TT(0);
     }
-    wave_tables_store<TT, 3>(e, smem, lane, tabs);
     wave_lds_fence();
     AUD_STAMP(7);
 
     // ---- optional spectrum outputs and the mel reduction: 4 frames x 16 filter groups on this wave ----------
-    wave_mel_epilogue<TT, w16::kFW>(a, e, Pw, w16::kHp, smem, it, item, t0, lane);
+    wave_mel_steps<TT, w16::kFW>(a, e, Pw, w16::kHp, smem, it, item, t0, lane);
     AUD_STAMP(8);
     AUD_STAMP_FLUSH(a, wt, lane);
 }
-
 
 // ================================================================================================
 // N = 400: 200-point complex FFT as 25 x 8, 8 lanes per frame, 8 frames per wave
@@ -252,34 +274,45 @@ __device__ __forceinline__ void split_pair(TT* P, const C2<TT>* __restrict__ tw,
 
 // second launch-bounds argument = waves per SIMD the register allocator must leave room for: without it the
 // float64 instantiation is scheduled into 256 VGPRs + 30 AGPRs (one wave per SIMD); LDS admits two
-template <typename TT, bool PCM16>
-__global__ __launch_bounds__(64 * kWaves, 2) void k_melspec_w25(const MelspecArgs a, const FastArgs e) {
+template <typename TT, bool PCM16, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_melspec_w25(const MelspecArgs a, const FastArgs e) {
     using L = w25::Layout<TT>;
     unsigned char* smem = dyn_lds();
-    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);  // scalar: item record and addresses on the SALU
-    const int lane = int(threadIdx.x) & 63;
+    const int tid = int(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: item record and addresses on the SALU
+    const int lane = tid & 63;
     const int f = lane >> 3;  // frame within the wave
     const int j = lane & 7;   // lane within the frame's 8-lane group
     const int T = a.T;
-
-    const int tiles = (T + w25::kFW - 1) / w25::kFW;  // wave tiles per item
-    const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
-    const int64_t wt = int64_t(wg) * kWaves + wave;
-    if (wt >= int64_t(a.n_items) * tiles) return;  // wave-uniform; no barrier anywhere below
-    const int item = int(wt / tiles);
-    const int t0 = int(wt - int64_t(item) * tiles) * w25::kFW;
-    const aud_item it = a.items[item];
-    const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_400^k
     AUD_STAMP_DECL;
     AUD_STAMP(0);
 
+    // the workgroup's tables: requested before anything else so that a counted wait can pick them out
+    BlobRegs<64 * NW> blob;
+    blob_fetch<64 * NW>(e, tid, blob);
+
+    const int tiles = (T + w25::kFW - 1) / w25::kFW;  // wave tiles per item
+    const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
+    const int64_t wt = int64_t(wg) * NW + wave;
+    const bool on = wt < int64_t(a.n_items) * tiles;  // wave-uniform
+    const int item = on ? int(wt / tiles) : 0;
+    const int t0 = on ? int(wt - int64_t(item) * tiles) * w25::kFW : 0;
+    const aud_item it = a.items[item];
+    const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_400^k (the 25-point DFT's wave-uniform inner twiddles)
+
     // ---- pass A operands: z[8 n1 + j] = (x[16 n1 + 2j], x[16 n1 + 2j + 1]), n1 = 0..24 ---------------------
     C2<TT> v[25];
-    load_frame_pairs<TT, 25, 8, w25::kN, PCM16>(a, it, t0 + f, j, v);
+    if (on) load_frame_pairs<TT, 25, 8, w25::kN, PCM16>(a, it, t0 + f, j, v);
     AUD_STAMP(1);
+
+    blob_store<64 * NW>(e, smem, tid, blob);  // waits for the blob loads only: the operands stay in flight
+    __syncthreads();                          // the one barrier: tables visible to the workgroup's waves
+    if (!on) return;
     AUD_STAMP(2);
 
     TT* xw = reinterpret_cast<TT*>(smem + e.xch_off + wave * L::kRegion);  // this wave's region
+    const C2<TT>* twa = reinterpret_cast<const C2<TT>*>(smem + e.twa_off);  // W_400^(2 j k1) at [(k1 - 1) 8 + j]
+    const C2<TT>* tws = reinterpret_cast<const C2<TT>*>(smem + e.tws_off);  // W_400^k, k <= 100
 #ifdef AUD_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // operands have landed
 #endif
@@ -287,13 +320,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_melspec_w25(const MelspecArg
 
     // ---- pass A: 25-point DFT over n1, twiddle W_200^(j k1) = W_400^(2 j k1) -------------------------------
     SmallDft<TT, 25>::run(v, tw, w25::kN);
-    // six twiddles at a time: left alone the scheduler requests all 24 first (96 registers in float64)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-#pragma unroll
-        for (int k1 = 1 + 6 * g; k1 < 7 + 6 * g; ++k1) v[k1] = cmul(v[k1], tw[2 * j * k1]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int k1 = 1; k1 < 25; ++k1) v[k1] = cmul(v[k1], twa[(k1 - 1) * 8 + j]);
     AUD_STAMP(4);
 
     // ---- transpose through the wave's LDS region, real parts then imaginary parts ----------------------------
@@ -325,9 +353,6 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_melspec_w25(const MelspecArg
     if (pair1) w25::read_row8<TT>(rows + r1p * L::kRow, ui[3]);
     wave_lds_fence();  // every row has been read: the region may take the power spectrum
     AUD_STAMP(5);
-    // this wave's copy of the mel weights and filter slots: requested now, stored behind the split
-    WaveTables<TT, 3> tabs;
-    wave_tables_fetch<TT, 3>(e, lane, tabs);
 
     // ---- pass B (8-point DFT over n2 of each row, in registers: Z[k1 + 25 k2]) + real-FFT split + power ---------
     // pairs are always evaluated from their k <= 100 side, A = Z[k], B = Z[200 - k], as melspec_r25.hip does:
@@ -350,122 +375,85 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_melspec_w25(const MelspecArg
                 SmallDft<TT, 8>::run(zb, nullptr, 0);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    w25::split_pair<TT>(P, tw, ra + 25 * c, za[c], zb[7 - c]);
-                    w25::split_pair<TT>(P, tw, rb + 25 * c, zb[c], za[7 - c]);
+                    w25::split_pair<TT>(P, tws, ra + 25 * c, za[c], zb[7 - c]);
+                    w25::split_pair<TT>(P, tws, rb + 25 * c, zb[c], za[7 - c]);
                 }
             } else {  // row 0: k = 25 c pairs with column 8 - c of the same row (c = 0: DC + Nyquist; c = 4: itself)
 #pragma unroll
-                for (int c = 0; c <= 4; ++c) w25::split_pair<TT>(P, tw, 25 * c, za[c], za[(8 - c) & 7]);
+                for (int c = 0; c <= 4; ++c) w25::split_pair<TT>(P, tws, 25 * c, za[c], za[(8 - c) & 7]);
             }
         }
     }
     AUD_STAMP(6);
     if (j < 3) P[w25::kH + j] = TT(0);  // pad bins of the last 4-bin chunk
-    wave_tables_store<TT, 3>(e, smem, lane, tabs);
     wave_lds_fence();
     AUD_STAMP(7);
 
     // ---- optional spectrum outputs and the mel reduction: 8 frames x 8 filter groups on this wave -------------
-    wave_mel_epilogue<TT, w25::kFW>(a, e, Pw, w25::kHp, smem, it, item, t0, lane);
+    wave_mel_steps<TT, w25::kFW>(a, e, Pw, w25::kHp, smem, it, item, t0, lane);
     AUD_STAMP(8);
     AUD_STAMP_FLUSH(a, wt, lane);
 }
 
 }  // namespace
 
-bool melspec_w16_supported(int N, int S, int compute_dtype, int n_chunks, int nf, FastArgs* out) {
-    if (N != w16::kN || S < 1 || nf < 1) return false;
-    const int n_groups = 64 / w16::kFW, n_sched = n_groups + 1 + 4 * nf;
-    const size_t tsz = compute_dtype == AUD_F64 ? 8 : 4;
-    const size_t w4 = (size_t(n_chunks) * 4 * tsz + 31) & ~size_t(31);
-    const int n_slots = wave_slot_bound(nf, n_groups);               // LDS carve; the plan sets the actual n_slots
-    const size_t sched = (size_t(n_groups) * n_slots * 8 + 31) & ~size_t(31);  // filter slots, 8 bytes each
-    const size_t region = compute_dtype == AUD_F64 ? size_t(w16::Layout<double>::kRegion) : size_t(w16::Layout<float>::kRegion);
-    const size_t total = w4 + sched + kWaves * region;
-    if (total > 160 * 1024) return false;
-    if (out) {
-        *out = FastArgs{};
-        out->w4_off = 0;
-        out->sched_off = int(w4);
-        out->slots_off = int(w4);
-        out->xch_off = int(w4 + sched);
-        out->p_off = out->xch_off;
-        out->n_sched = n_sched;
-        out->n_groups = n_groups;
-        out->lds_bytes = unsigned(total);
-        out->n_chunks = n_chunks;
-        out->direct = 1;
-        out->ntile = 1;
+// waves per workgroup: the waves of a workgroup share one LDS copy of the table blob.  Float64 N = 400 regions are
+// 17 KB per wave, so its workgroups are eight waves (two per SIMD) around one copy; everything else uses four.
+static int wave_kernel_waves(int kind, int compute_dtype) { return (kind == 2 && compute_dtype == AUD_F64) ? 8 : 4; }
+
+bool melspec_wave_geometry(int kind, int N, WaveGeometry* g) {
+    if (kind == 1 && N == w16::kN) {
+        *g = WaveGeometry{64 / w16::kFW, 16, 16, w16::kM / 2 + 1};
+        return true;
     }
+    if (kind == 2 && N == w25::kN) {
+        *g = WaveGeometry{64 / w25::kFW, 8, 25, w25::kM / 2 + 1};
+        return true;
+    }
+    return false;
+}
+
+bool melspec_wave_finish(int kind, int compute_dtype, FastArgs* e) {
+    const bool f64 = compute_dtype == AUD_F64;
+    const size_t region = kind == 1 ? (f64 ? size_t(w16::Layout<double>::kRegion) : size_t(w16::Layout<float>::kRegion))
+                                    : (f64 ? size_t(w25::Layout<double>::kRegion) : size_t(w25::Layout<float>::kRegion));
+    const int nw = wave_kernel_waves(kind, compute_dtype);
+    const size_t first = (size_t(e->blob_bytes) + 255) & ~size_t(255);
+    const size_t total = first + size_t(nw) * region;
+    if (total > 160 * 1024) return false;
+    e->xch_off = int(first);
+    e->p_off = int(first);
+    e->lds_bytes = unsigned(total);
+    e->waves = nw;
+    e->direct = 1;
+    e->ntile = 1;
     return true;
 }
 
-hipError_t melspec_w16_prepare(unsigned lds_bytes) {
-    const void* fns[] = {reinterpret_cast<const void*>(&k_melspec_w16<double, true>),
-                         reinterpret_cast<const void*>(&k_melspec_w16<float, true>)};
-    for (const void* fn : fns) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
+hipError_t melspec_wave_prepare(int kind, unsigned lds_bytes) {
+    const void* fns16[] = {reinterpret_cast<const void*>(&k_melspec_w16<double, true, 4>),
+                           reinterpret_cast<const void*>(&k_melspec_w16<float, true, 4>)};
+    const void* fns25[] = {reinterpret_cast<const void*>(&k_melspec_w25<double, true, 8>),
+                           reinterpret_cast<const void*>(&k_melspec_w25<float, true, 4>)};
+    for (int i = 0; i < 2; ++i) {
+        hipError_t e = hipFuncSetAttribute(kind == 1 ? fns16[i] : fns25[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           int(lds_bytes));
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }
 
-hipError_t launch_melspec_w16(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st) {
-    const int64_t tiles = (a.T + w16::kFW - 1) / w16::kFW;
+hipError_t launch_melspec_wave(int kind, const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st) {
+    const int fw = kind == 1 ? w16::kFW : w25::kFW;
+    const int64_t tiles = (a.T + fw - 1) / fw;
     const int64_t waves = int64_t(a.n_items) * tiles;
-    const dim3 grid(unsigned((waves + kWaves - 1) / kWaves)), blk(64 * kWaves);
-    if (compute_dtype == AUD_F64)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_w16<double, true>), grid, blk, e.lds_bytes, st, a, e);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_w16<float, true>), grid, blk, e.lds_bytes, st, a, e);
-    return hipGetLastError();
-}
-
-bool melspec_w25_supported(int N, int S, int compute_dtype, int n_chunks, int nf, FastArgs* out) {
-    if (N != w25::kN || S < 1 || nf < 1) return false;
-    const int n_groups = 64 / w25::kFW, n_sched = n_groups + 1 + 4 * nf;
-    const size_t tsz = compute_dtype == AUD_F64 ? 8 : 4;
-    const size_t w4 = (size_t(n_chunks) * 4 * tsz + 31) & ~size_t(31);
-    const int n_slots = wave_slot_bound(nf, n_groups);               // LDS carve; the plan sets the actual n_slots
-    const size_t sched = (size_t(n_groups) * n_slots * 8 + 31) & ~size_t(31);  // filter slots, 8 bytes each
-    const size_t region = compute_dtype == AUD_F64 ? size_t(w25::Layout<double>::kRegion) : size_t(w25::Layout<float>::kRegion);
-    const size_t total = w4 + sched + kWaves * region;
-    if (total > 160 * 1024) return false;
-    if (out) {
-        *out = FastArgs{};
-        out->w4_off = 0;
-        out->sched_off = int(w4);
-        out->slots_off = int(w4);
-        out->xch_off = int(w4 + sched);
-        out->p_off = out->xch_off;
-        out->n_sched = n_sched;
-        out->n_groups = n_groups;
-        out->lds_bytes = unsigned(total);
-        out->n_chunks = n_chunks;
-        out->direct = 1;
-        out->ntile = 1;
-    }
-    return true;
-}
-
-hipError_t melspec_w25_prepare(unsigned lds_bytes) {
-    const void* fns[] = {reinterpret_cast<const void*>(&k_melspec_w25<double, true>),
-                         reinterpret_cast<const void*>(&k_melspec_w25<float, true>)};
-    for (const void* fn : fns) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
-        if (e != hipSuccess) return e;
-    }
-    return hipSuccess;
-}
-
-hipError_t launch_melspec_w25(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st) {
-    const int64_t tiles = (a.T + w25::kFW - 1) / w25::kFW;
-    const int64_t waves = int64_t(a.n_items) * tiles;
-    const dim3 grid(unsigned((waves + kWaves - 1) / kWaves)), blk(64 * kWaves);
-    if (compute_dtype == AUD_F64)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_w25<double, true>), grid, blk, e.lds_bytes, st, a, e);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_w25<float, true>), grid, blk, e.lds_bytes, st, a, e);
+    const int nw = e.waves;
+    const dim3 grid(unsigned((waves + nw - 1) / nw)), blk(64 * nw);
+    const bool f64 = compute_dtype == AUD_F64;
+    if (kind == 1 && f64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_w16<double, true, 4>), grid, blk, e.lds_bytes, st, a, e);
+    else if (kind == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_w16<float, true, 4>), grid, blk, e.lds_bytes, st, a, e);
+    else if (f64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_w25<double, true, 8>), grid, blk, e.lds_bytes, st, a, e);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_w25<float, true, 4>), grid, blk, e.lds_bytes, st, a, e);
     return hipGetLastError();
 }
 

@@ -40,17 +40,12 @@ struct alignas(8) float2 {
 struct alignas(8) uint2 {
     unsigned x, y;
 };
+struct alignas(16) uint4 {
+    unsigned x, y, z, w;
+};
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 inline void __builtin_amdgcn_sched_barrier(int) {}  // callers pass wave-uniform values
-// same-value races the wave kernels have by design (device_common.h): ThreadSanitizer is told to look away
-#if defined(__SANITIZE_THREAD__)
-extern "C" void AnnotateIgnoreReadsBegin(const char*, int);
-extern "C" void AnnotateIgnoreReadsEnd(const char*, int);
-extern "C" void AnnotateIgnoreWritesBegin(const char*, int);
-extern "C" void AnnotateIgnoreWritesEnd(const char*, int);
-#define AUD_BENIGN_RACE_BEGIN() do { AnnotateIgnoreReadsBegin(__FILE__, __LINE__); AnnotateIgnoreWritesBegin(__FILE__, __LINE__); } while (0)
-#define AUD_BENIGN_RACE_END() do { AnnotateIgnoreWritesEnd(__FILE__, __LINE__); AnnotateIgnoreReadsEnd(__FILE__, __LINE__); } while (0)
-#endif
+
 
 typedef int hipError_t;
 typedef struct emul_stream* hipStream_t;
