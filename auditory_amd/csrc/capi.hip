@@ -295,7 +295,7 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
     put_real(size_t(e.twa_off), twa);
     put_real(size_t(e.tws_off), tws);
     if (!aud::melspec_wave_finish(kind, dt, &e)) return AUD_OK;  // does not fit LDS
-    if (e.lds_bytes > 64u * 1024u && aud::melspec_wave_prepare(kind, e.lds_bytes) != hipSuccess) {
+    if (aud::melspec_wave_prepare(kind, dt, &e) != hipSuccess) {
         (void)hipGetLastError();
         return AUD_OK;
     }
@@ -628,6 +628,25 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
         if (value == 2 && !p->r16.direct) return fail(c, AUD_EINVAL, "r16_tiles = 2 needs the direct input variant");
         p->r16.ntile = value;
         select_tile_kernel(p);
+        return AUD_OK;
+    }
+    if (key == "wave_variant") {  // A/B of the persistent wave kernels: 0 prefetch, 1 prefetch + capped registers, 2 no prefetch
+        if (p->wave_kind == aud_plan::kNoWave) return fail(c, AUD_EINVAL, "plan has no wave kernel");
+        if (value < 0 || value > 2) return fail(c, AUD_EINVAL, "wave_variant: 0, 1 or 2");
+        aud::FastArgs cfg = p->wv;
+        cfg.variant = value;
+        AUD_HIP(c, make_current(c));
+        if (aud::melspec_wave_prepare(p->wave_kind == aud_plan::kW16 ? 1 : 2, p->d.compute_dtype, &cfg) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(c, AUD_EHIP, "wave_variant: the runtime refused the kernel attributes");
+        }
+        p->wv = cfg;
+        return AUD_OK;
+    }
+    if (key == "wave_grid") {  // 0 (default): one wave tile per wave; 1: persistent grid of resident workgroups
+        if (p->wave_kind == aud_plan::kNoWave) return fail(c, AUD_EINVAL, "plan has no wave kernel");
+        if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "wave_grid: 0 or 1");
+        p->wv.persistent = value;
         return AUD_OK;
     }
     if (key == "xcd_remap") {  // 1 (default): every XCD walks a contiguous run of tiles; 0: tiles in workgroup-id order

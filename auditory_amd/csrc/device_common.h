@@ -201,75 +201,97 @@ __device__ __forceinline__ TT pcm16_to(int v) {
 
 // First-pass operands of one frame for the register-resident kernels: the frame's N samples as N/2 packed
 // pairs z[n] = (x[2n], x[2n+1]); this lane takes z[lane + STRIDE n1], n1 = 0..NV-1.  Three routes:
-//   * float32 samples, frame inside the stream, pairs 8-byte aligned: one 8-byte load per pair (widened to the
+//   1 float32 samples, frame inside the stream, pairs 8-byte aligned: one 8-byte load per pair (widened to the
 //     compute type in registers);
-//   * int16 samples under the same conditions (4-byte aligned): one 4-byte load per pair, normalised here
+//   2 int16 samples under the same conditions (4-byte aligned): one 4-byte load per pair, normalised on the fly
 //     (half the input bytes of the float route);
-//   * anything else (stream edges, left zero pad, float64 samples, odd offsets, strided streams): guarded
+//   0 anything else (stream edges, left zero pad, float64 samples, odd offsets, strided streams): guarded
 //     element loads.
+// Split in two so that a persistent kernel can request the next tile's operands before it computes the current
+// one: frame_pairs_issue() only issues the loads of routes 1 / 2 (raw words, no wait), frame_pairs_take() converts
+// them -- or runs route 0 on the spot.
+template <int NV>
+struct FrameRaw {
+    uint2 w[NV];  // route 1: the two float bit patterns; route 2: .x = the packed int16 pair
+    int route;
+};
+template <int NV, int STRIDE, int N, bool PCM16_ROUTE = true>
+__device__ __forceinline__ void frame_pairs_issue(const MelspecArgs& a, const aud_item& it, int sstep, int lane,
+                                                  FrameRaw<NV>& r) {
+    const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
+    const int64_t pos0 = start + 2 * lane;
+    const bool inside = sstep < a.T && start >= 0 && start + N <= int64_t(it.sig_len) && it.sig_stride <= 1 &&
+                        ((it.sig_off + start) & 1) == 0;
+    r.route = 0;
+    if (inside && a.sig_dtype == AUD_F32 && (reinterpret_cast<uintptr_t>(a.sig) & 7) == 0) {
+        const uint2* __restrict__ src = reinterpret_cast<const uint2*>(static_cast<const float*>(a.sig) + it.sig_off + pos0);
+#pragma unroll
+        for (int n1 = 0; n1 < NV; ++n1) r.w[n1] = src[STRIDE * n1];
+        r.route = 1;
+    }
+    if constexpr (PCM16_ROUTE) {
+        if (inside && a.sig_dtype == AUD_I16 && (reinterpret_cast<uintptr_t>(a.sig) & 3) == 0) {
+            const uint32_t* __restrict__ src =
+                reinterpret_cast<const uint32_t*>(static_cast<const int16_t*>(a.sig) + it.sig_off + pos0);
+#pragma unroll
+            for (int n1 = 0; n1 < NV; ++n1) r.w[n1].x = src[STRIDE * n1];
+            r.route = 2;
+        }
+    }
+}
+template <typename TT, int NV, int STRIDE, int N, bool PCM16_ROUTE = true>
+__device__ __forceinline__ void frame_pairs_take(const MelspecArgs& a, const aud_item& it, int sstep, int lane,
+                                                 const FrameRaw<NV>& r, C2<TT> (&v)[NV]) {
+    if (r.route == 1) {
+#pragma unroll
+        for (int n1 = 0; n1 < NV; ++n1)
+            v[n1] = C2<TT>{TT(__uint_as_float(r.w[n1].x)), TT(__uint_as_float(r.w[n1].y))};
+        return;
+    }
+    if constexpr (PCM16_ROUTE) {
+        if (r.route == 2) {
+#pragma unroll
+            for (int n1 = 0; n1 < NV; ++n1) {
+                v[n1].x = pcm16_to<TT>(int(int16_t(r.w[n1].x & 0xFFFFu)));
+                v[n1].y = pcm16_to<TT>(int(int16_t(r.w[n1].x >> 16)));
+            }
+            return;
+        }
+    }
+    const int64_t lim = it.sig_len;
+    const int64_t pos0 = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border) + 2 * lane;
+    const bool frame_on = sstep < a.T;
+    const int64_t str = it.sig_stride > 1 ? it.sig_stride : 1;
+#pragma unroll
+    for (int n1 = 0; n1 < NV; ++n1) {
+        const int64_t p = pos0 + 2 * STRIDE * n1;
+        v[n1].x = (frame_on && p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p * str) : TT(0);
+        v[n1].y = (frame_on && p + 1 >= 0 && p + 1 < lim)
+                      ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + (p + 1) * str) : TT(0);
+    }
+}
 template <typename TT, int NV, int STRIDE, int N, bool PCM16_ROUTE = true>
 __device__ __forceinline__ void load_frame_pairs(const MelspecArgs& a, const aud_item& it, int sstep, int lane,
                                                  C2<TT> (&v)[NV]) {
-    const int T = a.T, S = a.S;
-    const int64_t lim = it.sig_len;
-    const int64_t start = int64_t(it.start0) + int64_t(S) * (sstep - a.border);
-    const int64_t pos0 = start + 2 * lane;
-    const bool frame_on = sstep < T;
-    const bool inside = frame_on && start >= 0 && start + N <= lim && it.sig_stride <= 1 &&
-                        ((it.sig_off + start) & 1) == 0;
-    bool done = false;
-    // whole frame inside the stream, f32 samples, 8-byte aligned pairs
-    const bool fast = inside && a.sig_dtype == AUD_F32 && (reinterpret_cast<uintptr_t>(a.sig) & 7) == 0;
-    if (fast) {
-        const C2<float>* __restrict__ src =
-            reinterpret_cast<const C2<float>*>(static_cast<const float*>(a.sig) + it.sig_off + pos0);
-        C2<float> raw[NV];
-#pragma unroll
-        for (int n1 = 0; n1 < NV; ++n1) raw[n1] = src[STRIDE * n1];
-#pragma unroll
-        for (int n1 = 0; n1 < NV; ++n1) v[n1] = C2<TT>{TT(raw[n1].x), TT(raw[n1].y)};
-        done = true;
-    }
-    if constexpr (PCM16_ROUTE) {
-        const bool fast16 = !fast && inside && a.sig_dtype == AUD_I16 && (reinterpret_cast<uintptr_t>(a.sig) & 3) == 0;
-        if (fast16) {
-            const uint32_t* __restrict__ src =
-                reinterpret_cast<const uint32_t*>(static_cast<const int16_t*>(a.sig) + it.sig_off + pos0);
-            uint32_t raw[NV];
-#pragma unroll
-            for (int n1 = 0; n1 < NV; ++n1) raw[n1] = src[STRIDE * n1];
-#pragma unroll
-            for (int n1 = 0; n1 < NV; ++n1) {
-                v[n1].x = pcm16_to<TT>(int(int16_t(raw[n1] & 0xFFFFu)));
-                v[n1].y = pcm16_to<TT>(int(int16_t(raw[n1] >> 16)));
-            }
-            done = true;
-        }
-    }
-    if (!done) {
-        const int64_t str = it.sig_stride > 1 ? it.sig_stride : 1;
-#pragma unroll
-        for (int n1 = 0; n1 < NV; ++n1) {
-            const int64_t p = pos0 + 2 * STRIDE * n1;
-            v[n1].x = (frame_on && p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p * str) : TT(0);
-            v[n1].y = (frame_on && p + 1 >= 0 && p + 1 < lim)
-                          ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + (p + 1) * str) : TT(0);
-        }
-    }
+    FrameRaw<NV> r;
+    frame_pairs_issue<NV, STRIDE, N, PCM16_ROUTE>(a, it, sstep, lane, r);
+    frame_pairs_take<TT, NV, STRIDE, N, PCM16_ROUTE>(a, it, sstep, lane, r, v);
 }
 
 __device__ __forceinline__ float dev_log(float v) { return logf(v); }
 __device__ __forceinline__ double dev_log(double v) { return log(v); }
 
-// ln of a float64 band power whose result is stored as float32 (mel.go:133-139, dft.go:76-82): the sum is
-// rounded to float32 and the logarithm taken there -- 6e-8 from the rounding plus logf's last-place error, both
-// below the float32 spacing of the stored value -- instead of ~100 float64 instructions per value.  Outside the
-// range where float32 is safely normal the float64 logarithm is used (a rare, data-dependent branch:
-// tests/parity_cases.py::case_tiny_and_huge_power forces it).
+// ln of a float64 band power whose result is stored as float32 (mel.go:133-139, dft.go:76-82): mantissa and exponent
+// are split in float64 (two instructions), the logarithm of the mantissa is taken in float32 and the exponent's
+// share added with one fused multiply-add.  Error: the float32 rounding of the mantissa (6e-8), logf's last place
+// on a value in [-0.7, 0] and the rounding of the result -- all below the float32 spacing of the stored value --
+// instead of ~100 float64 instructions and their constants.  Any magnitude a double can hold takes this route
+// (no range branch); zero, negative and NaN inputs behave as in log().
 __device__ __forceinline__ float feature_log(float v) { return logf(v); }
 __device__ __forceinline__ double feature_log(double v) {
-    if (v >= 1e-30 && v <= 1e30) return double(logf(float(v)));
-    return log(v);
+    int ex = 0;
+    const double m = frexp(v, &ex);  // v = m 2^ex, 0.5 <= |m| < 1 (m = v for 0, inf and NaN, with ex = 0)
+    return double(fmaf(float(ex), 0.693147180559945309417f, logf(float(m))));
 }
 
 // Orders the LDS traffic of ONE wave: stores issued before it are visible to loads issued after it by any lane
@@ -443,7 +465,7 @@ __device__ __forceinline__ void wave_mel_steps_impl(const MelspecArgs& a, const 
     }
 }
 
-template <typename TT, int FPW>
+template <typename TT, int FPW, int MAXS>
 __device__ __forceinline__ void wave_mel_steps(const MelspecArgs& a, const FastArgs& e, const TT* P, int Hp,
                                                const unsigned char* smem, const aud_item& it, int item, int t0,
                                                int lane) {
@@ -453,9 +475,7 @@ __device__ __forceinline__ void wave_mel_steps(const MelspecArgs& a, const FastA
     const bool col_on = sstep < a.T;
     const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
     const bool live = col_on && start + a.N <= int64_t(it.sig_len);
-    if (e.n_slots <= 4) wave_mel_steps_impl<TT, FPW, 4>(a, e, P, Hp, smem, item, sstep, col_on, live, ff, grp);
-    else if (e.n_slots <= 8) wave_mel_steps_impl<TT, FPW, 8>(a, e, P, Hp, smem, item, sstep, col_on, live, ff, grp);
-    else wave_mel_steps_impl<TT, FPW, 16>(a, e, P, Hp, smem, item, sstep, col_on, live, ff, grp);
+    wave_mel_steps_impl<TT, FPW, MAXS>(a, e, P, Hp, smem, item, sstep, col_on, live, ff, grp);  // e.n_slots <= MAXS (host)
 }
 
 // ---- mel on the matrix pipe (float32 only; an experiment the plan can switch on) -------------------

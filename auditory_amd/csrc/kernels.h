@@ -126,6 +126,9 @@ struct FastArgs {
     int twa_off;           // pass twiddles, C2<TT> [K1 - 1][lanes per frame]: W^(2 j k1)
     int tws_off;           // split twiddles, C2<TT> [N/4 + 1]: W_N^k
     int waves;             // waves per workgroup of the launch
+    int variant;           // A/B variant of the wave kernel (plan option "wave_variant")
+    int persistent;        // 1: grid capped at max_wgs, waves walk several tiles (plan option "wave_grid"); 0: one tile per wave
+    int max_wgs;           // persistent grid: workgroups resident on the device at once (occupancy x CUs)
 };
 
 // PrevSmooth != 0 mode: scan along the steps of a stored power tensor
@@ -183,7 +186,7 @@ struct WaveGeometry {
 };
 bool melspec_wave_geometry(int kind, int N, WaveGeometry* g);
 bool melspec_wave_finish(int kind, int compute_dtype, FastArgs* e);
-hipError_t melspec_wave_prepare(int kind, unsigned lds_bytes);
+hipError_t melspec_wave_prepare(int kind, int compute_dtype, FastArgs* e);  // LDS opt-in + resident workgroup count
 hipError_t launch_melspec_wave(int kind, const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
 
 // N = 2048 fast path (one wave per frame, 16 x 16 x 4)

@@ -85,49 +85,43 @@ struct Layout {
 };
 }  // namespace w16
 
-template <typename TT, bool PCM16, int NW>
-__global__ __launch_bounds__(64 * NW) void k_melspec_w16(const MelspecArgs a, const FastArgs e) {
+// One wave tile (4 consecutive frames of one item) from its operands to its mel values.  MODE says where the operands
+// come from: 0 = `raw` (requested earlier); the next tile's are requested into `raw` before the arithmetic starts;
+// 1 = `raw`, nothing requested; 2 = requested and awaited here.
+template <typename TT, bool PCM16, int MAXS, int MODE>
+__device__ __forceinline__ void w16_tile(const MelspecArgs& a, const FastArgs& e, unsigned char* smem, TT* xw,
+                                         const C2<TT>* twa, const C2<TT>* tws, int lane_in, int tiles, int64_t wt,
+                                         int64_t wt_next, int64_t total, FrameRaw<16>& raw, aud_item& it, int& item,
+                                         int& t0) {
     using L = w16::Layout<TT>;
-    unsigned char* smem = dyn_lds();
-    const int tid = int(threadIdx.x);
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: item record and addresses on the SALU
-    const int lane = tid & 63;
+    // the lane id is made opaque per tile: otherwise the compiler hoists what only depends on it out of the tile loop
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
     const int f = lane >> 4;   // frame within the wave
     const int j = lane & 15;   // lane within the frame's 16-lane group
-    const int T = a.T;
     AUD_STAMP_DECL;
     AUD_STAMP(0);
-
-    // the workgroup's tables: requested before anything else so that a counted wait can pick them out
-    BlobRegs<64 * NW> blob;
-    blob_fetch<64 * NW>(e, tid, blob);
-
-    const int tiles = (T + w16::kFW - 1) / w16::kFW;  // wave tiles per item
-    const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
-    const int64_t wt = int64_t(wg) * NW + wave;
-    const bool on = wt < int64_t(a.n_items) * tiles;  // wave-uniform
-    const int item = on ? int(wt / tiles) : 0;
-    const int t0 = on ? int(wt - int64_t(item) * tiles) * w16::kFW : 0;
-    const aud_item it = a.items[item];
-
-    // ---- pass 1 operands straight from global memory: z[16 n1 + j] = (x[32 n1 + 2j], x[.. + 1]) --------------
     C2<TT> v[16];
-    if (on) load_frame_pairs<TT, 16, 16, w16::kN, PCM16>(a, it, t0 + f, j, v);
-    AUD_STAMP(1);
-
-    blob_store<64 * NW>(e, smem, tid, blob);  // waits for the blob loads only: the operands stay in flight
-    __syncthreads();                          // the one barrier: tables visible to the workgroup's waves
-    if (!on) return;
-    AUD_STAMP(2);
-
-    TT* xw = reinterpret_cast<TT*>(smem + e.xch_off + wave * L::kRegion);  // this wave's region
-    const C2<TT>* twa = reinterpret_cast<const C2<TT>*>(smem + e.twa_off);  // W_512^(2 j k1) at [(k1 - 1) 16 + j]
-    const C2<TT>* tws = reinterpret_cast<const C2<TT>*>(smem + e.tws_off);  // W_512^k, k <= 128
+    if constexpr (MODE == 2) {
+        item = int(wt / tiles);
+        t0 = int(wt - int64_t(item) * tiles) * w16::kFW;
+        it = a.items[item];
+        load_frame_pairs<TT, 16, 16, w16::kN, PCM16>(a, it, t0 + f, j, v);
+    } else {
+        frame_pairs_take<TT, 16, 16, w16::kN, PCM16>(a, it, t0 + f, j, raw, v);
+    }
+    const int item_cur = item, t0_cur = t0;
+    const aud_item it_cur = it;
+    if constexpr (MODE == 0) {
+        if (wt_next < total) {  // the next tile's operands land while this tile is computed
+            item = int(wt_next / tiles);
+            t0 = int(wt_next - int64_t(item) * tiles) * w16::kFW;
+            it = a.items[item];
+            frame_pairs_issue<16, 16, w16::kN, PCM16>(a, it, t0 + f, j, raw);
+        }
+    }
 
     // ---- pass 1: 16-point DFT over n1, twiddle -----------------------------------------------------------
-#ifdef AUD_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // operands have landed
-#endif
     AUD_STAMP(3);
     SmallDft<TT, 16>::run(v, nullptr, 0);
 #pragma unroll
@@ -213,9 +207,65 @@ __global__ __launch_bounds__(64 * NW) void k_melspec_w16(const MelspecArgs a, co
     AUD_STAMP(7);
 
     // ---- optional spectrum outputs and the mel reduction: 4 frames x 16 filter groups on this wave ----------
-    wave_mel_steps<TT, w16::kFW>(a, e, Pw, w16::kHp, smem, it, item, t0, lane);
+    wave_mel_steps<TT, w16::kFW, MAXS>(a, e, Pw, w16::kHp, smem, it_cur, item_cur, t0_cur, lane);
     AUD_STAMP(8);
     AUD_STAMP_FLUSH(a, wt, lane);
+    wave_lds_fence();  // the region is free for the next tile
+}
+
+// Persistent kernel: the workgroup stages the table blob once, then each of its waves walks wave tiles wt, wt + stride, ...
+// VAR (A/B, plan option "wave_variant"): 0 = every tile requests the next tile's operands before it computes
+// (32 more live registers); 1 = the same with the register budget capped for 3 (float64) / 5 (float32) waves per SIMD;
+// 2 = only the first tile's operands are requested early (under the blob staging), later tiles load at their top.
+template <typename TT, bool PCM16, int NW, int MAXS, int VAR>
+__global__ __launch_bounds__(64 * NW, VAR == 1 ? (sizeof(TT) == 8 ? 3 : 5) : 1) void k_melspec_w16(const MelspecArgs a,
+                                                                                                    const FastArgs e) {
+    using L = w16::Layout<TT>;
+    unsigned char* smem = dyn_lds();
+    const int tid = int(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: item record and addresses on the SALU
+    const int lane = tid & 63;
+
+    // the workgroup's tables: requested before anything else so that a counted wait can pick them out
+    BlobRegs<64 * NW> blob;
+    blob_fetch<64 * NW>(e, tid, blob);
+
+    const int tiles = (a.T + w16::kFW - 1) / w16::kFW;  // wave tiles per item
+    const int64_t total = int64_t(a.n_items) * tiles;
+    const int64_t stride = int64_t(gridDim.x) * NW;
+    const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
+    int64_t wt = int64_t(wg) * NW + wave;
+    int item = wt < total ? int(wt / tiles) : 0;
+    int t0 = wt < total ? int(wt - int64_t(item) * tiles) * w16::kFW : 0;
+    aud_item it = a.items[item];
+
+    // pass 1 operands of the first tile: z[16 n1 + j] = (x[32 n1 + 2j], x[.. + 1])
+    FrameRaw<16> raw;
+    raw.route = 0;
+    if (wt < total) frame_pairs_issue<16, 16, w16::kN, PCM16>(a, it, t0 + (lane >> 4), lane & 15, raw);
+
+    blob_store<64 * NW>(e, smem, tid, blob);  // waits for the blob loads only: the operands stay in flight
+    __syncthreads();                          // the one barrier: tables visible to the workgroup's waves
+
+    TT* xw = reinterpret_cast<TT*>(smem + e.xch_off + wave * L::kRegion);  // this wave's region
+    const C2<TT>* twa = reinterpret_cast<const C2<TT>*>(smem + e.twa_off);  // W_512^(2 j k1) at [(k1 - 1) 16 + j]
+    const C2<TT>* tws = reinterpret_cast<const C2<TT>*>(smem + e.tws_off);  // W_512^k, k <= 128
+
+    if constexpr (VAR == 2) {
+        if (wt < total) {
+            w16_tile<TT, PCM16, MAXS, 1>(a, e, smem, xw, twa, tws, lane, tiles, wt, wt + stride, total, raw, it, item, t0);
+            wt += stride;
+        }
+        while (wt < total) {
+            w16_tile<TT, PCM16, MAXS, 2>(a, e, smem, xw, twa, tws, lane, tiles, wt, wt + stride, total, raw, it, item, t0);
+            wt += stride;
+        }
+    } else {
+        while (wt < total) {
+            w16_tile<TT, PCM16, MAXS, 0>(a, e, smem, xw, twa, tws, lane, tiles, wt, wt + stride, total, raw, it, item, t0);
+            wt += stride;
+        }
+    }
 }
 
 // ================================================================================================
@@ -272,50 +322,39 @@ __device__ __forceinline__ void split_pair(TT* P, const C2<TT>* __restrict__ tw,
 }
 }  // namespace w25
 
-// second launch-bounds argument = waves per SIMD the register allocator must leave room for: without it the
-// float64 instantiation is scheduled into 256 VGPRs + 30 AGPRs (one wave per SIMD); LDS admits two
-template <typename TT, bool PCM16, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void k_melspec_w25(const MelspecArgs a, const FastArgs e) {
+// One wave tile (8 consecutive frames of one item); MODE as w16_tile.
+template <typename TT, bool PCM16, int MAXS, int MODE>
+__device__ __forceinline__ void w25_tile(const MelspecArgs& a, const FastArgs& e, unsigned char* smem, TT* xw,
+                                         const C2<TT>* twa, const C2<TT>* tws, int lane_in, int tiles, int64_t wt,
+                                         int64_t wt_next, int64_t total, FrameRaw<25>& raw, aud_item& it, int& item,
+                                         int& t0) {
     using L = w25::Layout<TT>;
-    unsigned char* smem = dyn_lds();
-    const int tid = int(threadIdx.x);
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: item record and addresses on the SALU
-    const int lane = tid & 63;
+    int lane = lane_in;  // opaque per tile (see w16_tile)
+    asm volatile("" : "+v"(lane));
     const int f = lane >> 3;  // frame within the wave
     const int j = lane & 7;   // lane within the frame's 8-lane group
-    const int T = a.T;
+    const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_400^k (the 25-point DFT's wave-uniform inner twiddles)
     AUD_STAMP_DECL;
     AUD_STAMP(0);
-
-    // the workgroup's tables: requested before anything else so that a counted wait can pick them out
-    BlobRegs<64 * NW> blob;
-    blob_fetch<64 * NW>(e, tid, blob);
-
-    const int tiles = (T + w25::kFW - 1) / w25::kFW;  // wave tiles per item
-    const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
-    const int64_t wt = int64_t(wg) * NW + wave;
-    const bool on = wt < int64_t(a.n_items) * tiles;  // wave-uniform
-    const int item = on ? int(wt / tiles) : 0;
-    const int t0 = on ? int(wt - int64_t(item) * tiles) * w25::kFW : 0;
-    const aud_item it = a.items[item];
-    const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_400^k (the 25-point DFT's wave-uniform inner twiddles)
-
-    // ---- pass A operands: z[8 n1 + j] = (x[16 n1 + 2j], x[16 n1 + 2j + 1]), n1 = 0..24 ---------------------
     C2<TT> v[25];
-    if (on) load_frame_pairs<TT, 25, 8, w25::kN, PCM16>(a, it, t0 + f, j, v);
-    AUD_STAMP(1);
-
-    blob_store<64 * NW>(e, smem, tid, blob);  // waits for the blob loads only: the operands stay in flight
-    __syncthreads();                          // the one barrier: tables visible to the workgroup's waves
-    if (!on) return;
-    AUD_STAMP(2);
-
-    TT* xw = reinterpret_cast<TT*>(smem + e.xch_off + wave * L::kRegion);  // this wave's region
-    const C2<TT>* twa = reinterpret_cast<const C2<TT>*>(smem + e.twa_off);  // W_400^(2 j k1) at [(k1 - 1) 8 + j]
-    const C2<TT>* tws = reinterpret_cast<const C2<TT>*>(smem + e.tws_off);  // W_400^k, k <= 100
-#ifdef AUD_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // operands have landed
-#endif
+    if constexpr (MODE == 2) {
+        item = int(wt / tiles);
+        t0 = int(wt - int64_t(item) * tiles) * w25::kFW;
+        it = a.items[item];
+        load_frame_pairs<TT, 25, 8, w25::kN, PCM16>(a, it, t0 + f, j, v);
+    } else {
+        frame_pairs_take<TT, 25, 8, w25::kN, PCM16>(a, it, t0 + f, j, raw, v);
+    }
+    const int item_cur = item, t0_cur = t0;
+    const aud_item it_cur = it;
+    if constexpr (MODE == 0) {
+        if (wt_next < total) {  // the next tile's operands land while this tile is computed
+            item = int(wt_next / tiles);
+            t0 = int(wt_next - int64_t(item) * tiles) * w25::kFW;
+            it = a.items[item];
+            frame_pairs_issue<25, 8, w25::kN, PCM16>(a, it, t0 + f, j, raw);
+        }
+    }
     AUD_STAMP(3);
 
     // ---- pass A: 25-point DFT over n1, twiddle W_200^(j k1) = W_400^(2 j k1) -------------------------------
@@ -390,16 +429,70 @@ __global__ __launch_bounds__(64 * NW, 2) void k_melspec_w25(const MelspecArgs a,
     AUD_STAMP(7);
 
     // ---- optional spectrum outputs and the mel reduction: 8 frames x 8 filter groups on this wave -------------
-    wave_mel_steps<TT, w25::kFW>(a, e, Pw, w25::kHp, smem, it, item, t0, lane);
+    wave_mel_steps<TT, w25::kFW, MAXS>(a, e, Pw, w25::kHp, smem, it_cur, item_cur, t0_cur, lane);
     AUD_STAMP(8);
     AUD_STAMP_FLUSH(a, wt, lane);
+    wave_lds_fence();  // the region is free for the next tile
+}
+
+// Persistent kernel, as k_melspec_w16.  VAR 0 / 1 / 2 likewise (the float64 instantiation only exists as VAR 2: the
+// 50 registers of a prefetched tile would all spill).  Second launch-bounds argument = waves per SIMD the register
+// allocator must leave room for: LDS admits two (float64) / three (float32).
+template <typename TT, bool PCM16, int NW, int MAXS, int VAR>
+__global__ __launch_bounds__(64 * NW, sizeof(TT) == 8 ? 2 : (VAR == 1 ? 3 : 2)) void k_melspec_w25(const MelspecArgs a,
+                                                                                                   const FastArgs e) {
+    using L = w25::Layout<TT>;
+    unsigned char* smem = dyn_lds();
+    const int tid = int(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: item record and addresses on the SALU
+    const int lane = tid & 63;
+
+    BlobRegs<64 * NW> blob;
+    blob_fetch<64 * NW>(e, tid, blob);
+
+    const int tiles = (a.T + w25::kFW - 1) / w25::kFW;  // wave tiles per item
+    const int64_t total = int64_t(a.n_items) * tiles;
+    const int64_t stride = int64_t(gridDim.x) * NW;
+    const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
+    int64_t wt = int64_t(wg) * NW + wave;
+    int item = wt < total ? int(wt / tiles) : 0;
+    int t0 = wt < total ? int(wt - int64_t(item) * tiles) * w25::kFW : 0;
+    aud_item it = a.items[item];
+
+    // pass A operands of the first tile: z[8 n1 + j] = (x[16 n1 + 2j], x[16 n1 + 2j + 1]), n1 = 0..24
+    FrameRaw<25> raw;
+    raw.route = 0;
+    if (wt < total) frame_pairs_issue<25, 8, w25::kN, PCM16>(a, it, t0 + (lane >> 3), lane & 7, raw);
+
+    blob_store<64 * NW>(e, smem, tid, blob);  // waits for the blob loads only: the operands stay in flight
+    __syncthreads();                          // the one barrier: tables visible to the workgroup's waves
+
+    TT* xw = reinterpret_cast<TT*>(smem + e.xch_off + wave * L::kRegion);  // this wave's region
+    const C2<TT>* twa = reinterpret_cast<const C2<TT>*>(smem + e.twa_off);  // W_400^(2 j k1) at [(k1 - 1) 8 + j]
+    const C2<TT>* tws = reinterpret_cast<const C2<TT>*>(smem + e.tws_off);  // W_400^k, k <= 100
+
+    if constexpr (VAR == 2) {
+        if (wt < total) {
+            w25_tile<TT, PCM16, MAXS, 1>(a, e, smem, xw, twa, tws, lane, tiles, wt, wt + stride, total, raw, it, item, t0);
+            wt += stride;
+        }
+        while (wt < total) {
+            w25_tile<TT, PCM16, MAXS, 2>(a, e, smem, xw, twa, tws, lane, tiles, wt, wt + stride, total, raw, it, item, t0);
+            wt += stride;
+        }
+    } else {
+        while (wt < total) {
+            w25_tile<TT, PCM16, MAXS, 0>(a, e, smem, xw, twa, tws, lane, tiles, wt, wt + stride, total, raw, it, item, t0);
+            wt += stride;
+        }
+    }
 }
 
 }  // namespace
 
-// waves per workgroup: the waves of a workgroup share one LDS copy of the table blob.  Float64 N = 400 regions are
-// 17 KB per wave, so its workgroups are eight waves (two per SIMD) around one copy; everything else uses four.
-static int wave_kernel_waves(int kind, int compute_dtype) { return (kind == 2 && compute_dtype == AUD_F64) ? 8 : 4; }
+// waves per workgroup: the waves of a workgroup share one LDS copy of the table blob (eight-wave workgroups were
+// tried for the 17 KB float64 N = 400 regions: their one barrier cost a quarter of the wave's life)
+static int wave_kernel_waves(int, int) { return 4; }
 
 bool melspec_wave_geometry(int kind, int N, WaveGeometry* g) {
     if (kind == 1 && N == w16::kN) {
@@ -425,21 +518,45 @@ bool melspec_wave_finish(int kind, int compute_dtype, FastArgs* e) {
     e->p_off = int(first);
     e->lds_bytes = unsigned(total);
     e->waves = nw;
+    e->max_wgs = 0;  // set by melspec_wave_prepare
+    e->variant = 2;  // measured (profiles/r02f_ab_*): one tile per wave, first operands under the blob staging
+    e->persistent = 0;
     e->direct = 1;
     e->ntile = 1;
     return true;
 }
 
-hipError_t melspec_wave_prepare(int kind, unsigned lds_bytes) {
-    const void* fns16[] = {reinterpret_cast<const void*>(&k_melspec_w16<double, true, 4>),
-                           reinterpret_cast<const void*>(&k_melspec_w16<float, true, 4>)};
-    const void* fns25[] = {reinterpret_cast<const void*>(&k_melspec_w25<double, true, 8>),
-                           reinterpret_cast<const void*>(&k_melspec_w25<float, true, 4>)};
-    for (int i = 0; i < 2; ++i) {
-        hipError_t e = hipFuncSetAttribute(kind == 1 ? fns16[i] : fns25[i], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           int(lds_bytes));
-        if (e != hipSuccess) return e;
+// the instantiation a plan runs: kind, compute type and the slot capacity of its epilogue (4 or 8)
+typedef void (*wave_kernel_t)(const MelspecArgs, const FastArgs);
+static wave_kernel_t wave_kernel(int kind, bool f64, int n_slots, int var) {
+    const bool s8 = n_slots > 4;
+    if (kind == 1) {
+#define AUD_W16(TT, S) (var == 1 ? k_melspec_w16<TT, true, 4, S, 1> : var == 2 ? k_melspec_w16<TT, true, 4, S, 2> : k_melspec_w16<TT, true, 4, S, 0>)
+        if (f64) return s8 ? AUD_W16(double, 8) : AUD_W16(double, 4);
+        return s8 ? AUD_W16(float, 8) : AUD_W16(float, 4);
+#undef AUD_W16
     }
+    if (f64) return s8 ? k_melspec_w25<double, true, 4, 8, 2> : k_melspec_w25<double, true, 4, 4, 2>;
+#define AUD_W25(S) (var == 1 ? k_melspec_w25<float, true, 4, S, 1> : var == 2 ? k_melspec_w25<float, true, 4, S, 2> : k_melspec_w25<float, true, 4, S, 0>)
+    return s8 ? AUD_W25(8) : AUD_W25(4);
+#undef AUD_W25
+}
+
+hipError_t melspec_wave_prepare(int kind, int compute_dtype, FastArgs* e) {
+    if (e->n_slots > 8) return hipErrorInvalidValue;  // more filters per group than the epilogue has slots for
+    const void* fn = reinterpret_cast<const void*>(wave_kernel(kind, compute_dtype == AUD_F64, e->n_slots, e->variant));
+    if (e->lds_bytes > 64u * 1024u) {
+        hipError_t rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(e->lds_bytes));
+        if (rc != hipSuccess) return rc;
+    }
+    // the persistent grid: as many workgroups as are resident at once (no grid-wide wait anywhere, so an
+    // over-estimate only queues the surplus workgroups behind the first ones)
+    int dev = 0, cus = 0, per_cu = 0;
+    hipError_t rc = hipGetDevice(&dev);
+    if (rc == hipSuccess) rc = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (rc == hipSuccess) rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * e->waves, e->lds_bytes);
+    if (rc != hipSuccess) return rc;
+    e->max_wgs = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
     return hipSuccess;
 }
 
@@ -448,12 +565,10 @@ hipError_t launch_melspec_wave(int kind, const MelspecArgs& a, const FastArgs& e
     const int64_t tiles = (a.T + fw - 1) / fw;
     const int64_t waves = int64_t(a.n_items) * tiles;
     const int nw = e.waves;
-    const dim3 grid(unsigned((waves + nw - 1) / nw)), blk(64 * nw);
-    const bool f64 = compute_dtype == AUD_F64;
-    if (kind == 1 && f64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_w16<double, true, 4>), grid, blk, e.lds_bytes, st, a, e);
-    else if (kind == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_w16<float, true, 4>), grid, blk, e.lds_bytes, st, a, e);
-    else if (f64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_w25<double, true, 8>), grid, blk, e.lds_bytes, st, a, e);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_w25<float, true, 4>), grid, blk, e.lds_bytes, st, a, e);
+    int64_t wgs = (waves + nw - 1) / nw;
+    if (e.persistent && e.max_wgs > 0 && wgs > e.max_wgs) wgs = e.max_wgs;  // every wave walks tiles wt, wt + stride, ...
+    const dim3 grid{unsigned(wgs)}, blk(64 * nw);
+    hipLaunchKernelGGL(wave_kernel(kind, compute_dtype == AUD_F64, e.n_slots, e.variant), grid, blk, e.lds_bytes, st, a, e);
     return hipGetLastError();
 }
 

@@ -54,6 +54,11 @@ enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMe
 enum { hipStreamNonBlocking = 1 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return 0; }
+// a small emulated device (4 CUs, 2 resident workgroups each) so that the persistent kernels' tile loops run more
+// than one trip in the CPU tier
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 4; return 0; }
+inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 2; return 0; }
 
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipSetDevice(int d);
@@ -148,6 +153,11 @@ inline V __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, V c, int, int, i
 }
 
 inline float __int_as_float(int v) {
+    float f;
+    std::memcpy(&f, &v, 4);
+    return f;
+}
+inline float __uint_as_float(unsigned v) {
     float f;
     std::memcpy(&f, &v, 4);
     return f;

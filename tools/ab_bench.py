@@ -48,9 +48,12 @@ def main():
     sig = np.tile(sig64.astype(np.float32), (reps, 1))[:B]
     dsig = torch.from_numpy(sig).to(dev).view(-1)
     cdt = capi.AUD_F32 if args.compute == "f32" else capi.AUD_F64
-    variants = {"auto": {}, "auto, tiles in workgroup-id order": {"xcd_remap": 0}, "generic": {"kernel": 1}}
+    variants = {"w25 (default)": {}, "w25 persistent var 2": {"wave_grid": 1}, "w25 persistent prefetch": {"wave_grid": 1, "wave_variant": 0},
+                "w25, no xcd remap": {"xcd_remap": 0}, "r25 tile kernel": {"kernel": 2}, "generic": {"kernel": 1}}
     if args.win_ms == 32.0:
-        variants = {"w16 wave-autonomous": {}, "w16, tiles in workgroup-id order": {"xcd_remap": 0}, "r16 direct": {"r16_input": 0}, "r16 direct, no xcd remap": {"r16_input": 0, "xcd_remap": 0}, "r16 direct x2": {"r16_input": 0, "r16_tiles": 2},
+        variants = {"w16 (default)": {}, "w16 persistent var 2": {"wave_grid": 1}, "w16 persistent prefetch": {"wave_grid": 1, "wave_variant": 0},
+                    "w16, no xcd remap": {"xcd_remap": 0},
+                    "r16 direct": {"r16_input": 0}, "r16 direct, no xcd remap": {"r16_input": 0, "xcd_remap": 0}, "r16 direct x2": {"r16_input": 0, "r16_tiles": 2},
                     "r16 staged": {"r16_input": 1}, "r16 direct mfma-mel": {"r16_input": 0, "r16_mel": 1},
                     "r16 direct x2 mfma-mel": {"r16_input": 0, "r16_tiles": 2, "r16_mel": 1}, "generic": {"kernel": 1}}
     plans = {}
@@ -99,7 +102,7 @@ def main():
           % (name, B, args.compute, args.rounds, args.launches, alg / 1e6))
     for v, ts in times.items():
         med, mn = statistics.median(ts), min(ts)
-        print("%-12s kernel=%-9s median %8.2f us  min %8.2f us  -> %6.2f TB/s algorithmic, %7.1f M audio-s/s"
+        print("%-28s kernel=%-9s median %8.2f us  min %8.2f us  -> %6.2f TB/s algorithmic, %7.1f M audio-s/s"
               % (v, plans[v].kernel_name, med, mn, alg / (med * 1e-6) / 1e12, B / med))
     for p in plans.values():
         p.close()
