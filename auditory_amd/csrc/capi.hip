@@ -643,9 +643,9 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
         p->wv = cfg;
         return AUD_OK;
     }
-    if (key == "wave_grid") {  // 0 (default): one wave tile per wave; 1: persistent grid of resident workgroups
+    if (key == "wave_grid") {  // -1 (default): by launch size; 0: one wave tile per wave; 1: persistent grid of resident workgroups
         if (p->wave_kind == aud_plan::kNoWave) return fail(c, AUD_EINVAL, "plan has no wave kernel");
-        if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "wave_grid: 0 or 1");
+        if (value < -1 || value > 1) return fail(c, AUD_EINVAL, "wave_grid: -1, 0 or 1");
         p->wv.persistent = value;
         return AUD_OK;
     }

@@ -145,16 +145,34 @@ struct SmallDft<TT, 16> {  // 16 = 4 x 4
             }
     }
 };
+// exp(-2 pi i m / 25), m = 0..16 (the inner twiddles of the 5 x 5 factorisation, m = b k1).  Literals rather than reads
+// of the plan's W_N table: sixteen table values kept alive through the butterflies were what pushed the float64
+// N = 400 kernel past its register budget (43 spilled registers, 38 MB of scratch traffic per launch).
 template <typename TT>
-struct SmallDft<TT, 25> {  // 25 = 5 x 5, inner twiddles W25^(b k1) = W_N^(b k1 N / 25) from the table
-    static __device__ __forceinline__ void run(C2<TT> (&v)[25], const C2<TT>* tw, int N) {
-        const int w25 = N / 25;
+__device__ __forceinline__ C2<TT> w25_literal(int m) {
+    constexpr long double c[17] = {1.0L, 0.9685831611286311194902L, 0.8763066800438635873081L, 0.7289686274214115231467L,
+                                   0.5358267949789966182713L, 0.3090169943749474241023L, 0.06279051952931337607618L,
+                                   -0.1873813145857246305426L, -0.4257792915650726488625L, -0.6374239897486897101767L,
+                                   -0.8090169943749474241023L, -0.9297764858882514036609L, -0.9921147013144778310498L,
+                                   -0.9921147013144778310498L, -0.9297764858882514036609L, -0.8090169943749474241023L,
+                                   -0.6374239897486897101767L};
+    constexpr long double sn[17] = {0.0L, -0.2486898871648547882423L, -0.4817536741017152749872L, -0.6845471059286886737323L,
+                                    -0.8443279255020150785486L, -0.9510565162951535721164L, -0.9980267284282715619523L,
+                                    -0.9822872507286886810856L, -0.9048270524660195277137L, -0.770513242775789230803L,
+                                    -0.5877852522924731291687L, -0.3681245526846779591569L, -0.1253332335643042453731L,
+                                    0.1253332335643042453731L, 0.3681245526846779591569L, 0.5877852522924731291687L,
+                                    0.770513242775789230803L};
+    return C2<TT>{TT(c[m]), TT(sn[m])};
+}
+template <typename TT>
+struct SmallDft<TT, 25> {  // 25 = 5 x 5, inner twiddles W25^(b k1)
+    static __device__ __forceinline__ void run(C2<TT> (&v)[25], const C2<TT>*, int) {
 #pragma unroll
         for (int b = 0; b < 5; ++b) dft5(v[b], v[5 + b], v[10 + b], v[15 + b], v[20 + b]);
 #pragma unroll
         for (int k1 = 1; k1 < 5; ++k1)
 #pragma unroll
-            for (int b = 1; b < 5; ++b) v[5 * k1 + b] = cmul(v[5 * k1 + b], tw[b * k1 * w25]);
+            for (int b = 1; b < 5; ++b) v[5 * k1 + b] = cmul(v[5 * k1 + b], w25_literal<TT>(b * k1));
 #pragma unroll
         for (int k1 = 0; k1 < 5; ++k1) dft5(v[5 * k1], v[5 * k1 + 1], v[5 * k1 + 2], v[5 * k1 + 3], v[5 * k1 + 4]);
 #pragma unroll

@@ -127,7 +127,7 @@ struct FastArgs {
     int tws_off;           // split twiddles, C2<TT> [N/4 + 1]: W_N^k
     int waves;             // waves per workgroup of the launch
     int variant;           // A/B variant of the wave kernel (plan option "wave_variant")
-    int persistent;        // 1: grid capped at max_wgs, waves walk several tiles (plan option "wave_grid"); 0: one tile per wave
+    int persistent;        // 1: grid capped at max_wgs, waves walk several tiles; 0: one tile per wave; -1: by launch size (plan option "wave_grid")
     int max_wgs;           // persistent grid: workgroups resident on the device at once (occupancy x CUs)
 };
 

@@ -237,6 +237,7 @@ def main():  # noqa: C901
                     help="aud_plan_set_option switches for A/B runs, e.g. kernel=2 (workgroup-tile family) or kernel=1 (generic)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for CPU dry runs)")
     ap.add_argument("--only-headline", action="store_true", help="skip the float32 / N = 512 modes and the cfg3 region")
+    ap.add_argument("--cfg3-total", type=int, default=4096, help="total utterances of the configs[2] region (CPU dry runs shrink it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
     args = ap.parse_args()
@@ -369,7 +370,8 @@ def main():  # noqa: C901
         if check and rank == 0:
             # parity of the TIMED outputs: all of ring buffer 0, plus 16 streams of two other buffers
             osd = OracleSide(wl)
-            picks = [(0, np.arange(B))] + [(r, np.arange(0, B, max(1, B // 16))[:16]) for r in sorted({ring.R // 2, ring.R - 1} - {0})]
+            touched = min(ring.R, K)                                   # ring buffers the timed steps wrote
+            picks = [(0, np.arange(B))] + [(r, np.arange(0, B, max(1, B // 16))[:16]) for r in sorted({touched // 2, touched - 1} - {0})]
             got = np.concatenate([ring.mel[r].cpu().numpy()[idx] for r, idx in picks])
             ref = np.concatenate([osd.mel(ring.host_rows64(r, idx)) for r, idx in picks])
             res["parity"] = strict_parity(got, ref)
@@ -428,7 +430,7 @@ def main():  # noqa: C901
                 else:
                     full = allgather_features(mels[s], world, n_total=nb * world)
 
-            for i in range(3):
+            for i in range(3 if steps > 2 else 1):
                 one(i)
             sync_all()
             t0 = time.perf_counter()
@@ -438,7 +440,7 @@ def main():  # noqa: C901
             el = max_over_ranks(time.perf_counter() - t0)
             return el, list(full.shape)
 
-        k2 = max(10, min(K, 200))
+        k2 = max(10, min(K, 200)) if args.min_seconds > 0 else 2
         el, shape = gather_region(B, ring.sig, ring.items, ring.mel[:2], k2)
         with_ag = {"value": round(B * world * head_wl.dur_s * k2 / el, 1), "unit": "audio-seconds/sec", "steps": k2,
                    "ms_per_step": round(1e3 * el / k2, 4), "gathered_shape": shape,
@@ -448,23 +450,24 @@ def main():  # noqa: C901
         if not args.only_headline:
             # BASELINE configs[2]: 4096 utterances in total, contiguous shards (auditory_amd.batch.shard_range)
             from auditory_amd import runtime
-            lo, hi = shard_range(4096, rank, world)
+            lo, hi = shard_range(args.cfg3_total, rank, world)
             nb = hi - lo
             reps3 = (nb + B - 1) // B
             sig3 = torch.cat([ring.sig[r % ring.R] for r in range(reps3)])[:nb * head_wl.L].contiguous()
             it3 = runtime.make_items(np.arange(nb) * head_wl.L, [head_wl.L] * nb, [0] * nb)
             items3 = torch.from_numpy(np.frombuffer(np.ascontiguousarray(it3).tobytes(), np.uint8).copy()).to(dev)
             mel3 = [torch.empty((nb, head_wl.nf, head_wl.T), dtype=torch.float32, device=dev) for _ in range(2)]
-            el3, shape3 = gather_region(nb, [sig3], items3, mel3, 40)
-            cfg3 = {"value": round(4096 * head_wl.dur_s * 40 / el3, 1), "unit": "audio-seconds/sec", "steps": 40,
-                    "ms_per_step": round(1e3 * el3 / 40, 4), "total_batch": 4096, "streams_this_rank": nb,
+            n3 = 40 if args.cfg3_total >= 1024 else 2
+            el3, shape3 = gather_region(nb, [sig3], items3, mel3, n3)
+            cfg3 = {"value": round(args.cfg3_total * head_wl.dur_s * n3 / el3, 1), "unit": "audio-seconds/sec", "steps": n3,
+                    "ms_per_step": round(1e3 * el3 / n3, 4), "total_batch": args.cfg3_total, "streams_this_rank": nb,
                     "gathered_shape": shape3, "note": "BASELINE configs[2] as stated, strong scaling; kernel + overlapped all-gather"}
         plan.close()
     elif world == 1 and args.workload == "headline" and not args.only_headline:
         # the 1-GPU point of configs[2]'s strong-scaling curve: all 4096 utterances on this GPU, nothing to gather
         ring = ring_for(head_wl)
         from auditory_amd import runtime
-        nb = 4096
+        nb = args.cfg3_total
         plan = head_wl.plan(args.compute, local_rank)
         reps3 = (nb + B - 1) // B
         sig3 = torch.cat([ring.sig[r % ring.R] for r in range(reps3)])[:nb * head_wl.L].contiguous()
@@ -472,16 +475,17 @@ def main():  # noqa: C901
         items3 = torch.from_numpy(np.frombuffer(np.ascontiguousarray(it3).tobytes(), np.uint8).copy()).to(dev)
         mel3 = torch.empty((nb, head_wl.nf, head_wl.T), dtype=torch.float32, device=dev)
         st = torch.cuda.current_stream(dev).cuda_stream
-        for _ in range(3):
+        for _ in range(3 if nb >= 1024 else 1):
             plan.melspec_dev(sig3.data_ptr(), sig_code, items3.data_ptr(), nb, mel3.data_ptr(), 0, 0, st)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for _ in range(40):
+        n3 = 40 if nb >= 1024 else 2
+        for _ in range(n3):
             plan.melspec_dev(sig3.data_ptr(), sig_code, items3.data_ptr(), nb, mel3.data_ptr(), 0, 0, st)
         torch.cuda.synchronize(dev)
         el3 = time.perf_counter() - t0
-        cfg3 = {"value": round(nb * head_wl.dur_s * 40 / el3, 1), "unit": "audio-seconds/sec", "steps": 40,
-                "ms_per_step": round(1e3 * el3 / 40, 4), "total_batch": 4096, "streams_this_rank": nb,
+        cfg3 = {"value": round(nb * head_wl.dur_s * n3 / el3, 1), "unit": "audio-seconds/sec", "steps": n3,
+                "ms_per_step": round(1e3 * el3 / n3, 4), "total_batch": nb, "streams_this_rank": nb,
                 "note": "BASELINE configs[2] on one GPU (the G = 1 point of its strong-scaling curve; no collective)"}
         plan.close()
 

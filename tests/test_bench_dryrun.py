@@ -62,15 +62,19 @@ def test_bench_dry_run_two_ranks(tmp_path):
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, worker, "--gpus", "2", "--steps", "4", "--warmup", "1",
-                                       "--batch", "2", "--prewarm-s", "0", "--dist-backend", "gloo"],
+        procs.append(subprocess.Popen([sys.executable, worker, "--gpus", "2", "--steps", "2", "--warmup", "1",
+                                       "--batch", "2", "--ring-mb", "0.2", "--min-seconds", "0", "--cfg3-total", "6",
+                                       "--dist-backend", "gloo"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs[0][1][-2000:] + outs[1][1][-2000:]
     line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]   # only rank 0 prints the JSON line
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "cpu_baseline" not in line
-    assert line["allgather"]["gathered_shape"] == [4, 40, 104]
+    assert line["with_allgather"]["gathered_shape"] == [4, 40, 104]          # kernel + overlapped all-gather region
+    assert line["cfg3"]["total_batch"] == 6 and line["cfg3"]["streams_this_rank"] == 3   # configs[2] region, shrunk
+    assert line["cfg3"]["gathered_shape"] == [6, 40, 104]
+    assert line["parity"]["pass"] and line["parity"]["n_past_1e-5"] == 0
 
 
 class _SideStream(_Stream):
@@ -81,16 +85,16 @@ class _SideStream(_Stream):
         pass
 
 
-@pytest.mark.parametrize("extra", [[], ["--streams", "2"], ["--win-ms", "25"], ["--workload", "cfg4"], ["--workload", "cfg4", "--kwta", "exact"], ["--sig-dtype", "i16"],
-                                   ["--compute", "f64", "--launch", "eager"]])
+@pytest.mark.parametrize("extra", [["--only-headline"], ["--workload", "cfg4"], ["--sig-dtype", "i16", "--only-headline"],
+                                   ["--compute", "f32", "--launch", "eager", "--only-headline"]])
 def test_bench_dry_run(monkeypatch, capsys, extra):
     import backend
     import bench
     _patch(monkeypatch)
     monkeypatch.setattr(bench, "cpu_baseline",
-                        lambda oc, sig, L, audio_s=1.0: bench.__dict__["_real_cpu_baseline"](oc, sig, L, target_s=0.2,
-                                                                                          audio_s=audio_s))
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--batch", "2", "--prewarm-s", "0"] + extra)
+                        lambda wl, pcm: bench.__dict__["_real_cpu_baseline"](wl, pcm, target_s=0.2))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--batch", "2", "--ring-mb", "0.2",
+                                      "--min-seconds", "0", "--cfg3-total", "4"] + extra)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
     with backend.emulated("plain"):
@@ -100,7 +104,9 @@ def test_bench_dry_run(monkeypatch, capsys, extra):
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
-    assert line["unit"] == "audio-seconds/sec" and line["n_gpus"] == 1 and line["steps"] == 2
+    assert line["unit"] == "audio-seconds/sec" and line["n_gpus"] == 1 and line["steps"] == 2 * line["config"]["repeats"]
+    assert "25 ms" in line["metric"] and line["config"]["win_samples"] == 400     # the metric's own parameter set
+    assert set(line["parity"]) >= {"criterion", "elements", "max_scaled_err", "n_past_1e-5", "pass"} and line["parity"]["pass"]
     assert line["vs_baseline"] is None and line["scaling"] == "weak" and line["data"] == "synthetic"
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
@@ -137,7 +143,7 @@ def test_smoke_dry_run(monkeypatch, capsys):
     monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
     with backend.emulated("plain"):
         G.smoke()
-    assert "smoke ok: kernel=r16x16" in capsys.readouterr().out
+    assert "smoke ok: kernel=w16x16" in capsys.readouterr().out
 
 
 def test_device_api_tests_dry_run(monkeypatch, orc):

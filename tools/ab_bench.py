@@ -48,10 +48,10 @@ def main():
     sig = np.tile(sig64.astype(np.float32), (reps, 1))[:B]
     dsig = torch.from_numpy(sig).to(dev).view(-1)
     cdt = capi.AUD_F32 if args.compute == "f32" else capi.AUD_F64
-    variants = {"w25 (default)": {}, "w25 persistent var 2": {"wave_grid": 1}, "w25 persistent prefetch": {"wave_grid": 1, "wave_variant": 0},
+    variants = {"w25 (default)": {}, "w25 one tile per wave": {"wave_grid": 0}, "w25 persistent var 2": {"wave_grid": 1}, "w25 persistent prefetch": {"wave_grid": 1, "wave_variant": 0},
                 "w25, no xcd remap": {"xcd_remap": 0}, "r25 tile kernel": {"kernel": 2}, "generic": {"kernel": 1}}
     if args.win_ms == 32.0:
-        variants = {"w16 (default)": {}, "w16 persistent var 2": {"wave_grid": 1}, "w16 persistent prefetch": {"wave_grid": 1, "wave_variant": 0},
+        variants = {"w16 (default)": {}, "w16 one tile per wave": {"wave_grid": 0}, "w16 persistent var 2": {"wave_grid": 1}, "w16 persistent prefetch": {"wave_grid": 1, "wave_variant": 0},
                     "w16, no xcd remap": {"xcd_remap": 0},
                     "r16 direct": {"r16_input": 0}, "r16 direct, no xcd remap": {"r16_input": 0, "xcd_remap": 0}, "r16 direct x2": {"r16_input": 0, "r16_tiles": 2},
                     "r16 staged": {"r16_input": 1}, "r16 direct mfma-mel": {"r16_input": 0, "r16_mel": 1},
@@ -81,19 +81,27 @@ def main():
         for _ in range(args.warm):
             launch(p)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            s_cap = torch.cuda.current_stream(dev).cuda_stream
-            for _ in range(args.launches):
-                p.melspec_dev(dsig.data_ptr(), capi.AUD_F32, items.data_ptr(), B, mel.data_ptr(), 0, 0, s_cap)
-        g.replay()
-        graphs[v] = g
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                s_cap = torch.cuda.current_stream(dev).cuda_stream
+                for _ in range(args.launches):
+                    p.melspec_dev(dsig.data_ptr(), capi.AUD_F32, items.data_ptr(), B, mel.data_ptr(), 0, 0, s_cap)
+            g.replay()
+            graphs[v] = g
+        except Exception as ex:  # no graph capture here (CPU dry run): eager launches
+            print("no hipGraph (%s): eager launches" % ex)
+            graphs[v] = None
     torch.cuda.synchronize()
     for _ in range(args.rounds):
         for v, p in plans.items():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            graphs[v].replay()
+            if graphs[v] is not None:
+                graphs[v].replay()
+            else:
+                for _ in range(args.launches):
+                    launch(p)
             e1.record()
             torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1) * 1e3 / args.launches)   # us per launch (incl. kernel boundaries)

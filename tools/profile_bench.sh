@@ -11,7 +11,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT" "$ROOT/profiles"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --launch eager --prewarm-s 0 $*"
+BENCH="python3 $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --only-headline --launch eager --min-seconds 0.02 $*"
 pass() {  # pass <name> <rocprofv3 args...>: a timeout or a death by signal ends the script (no GPU step after it)
     local name=$1; shift
     echo "[profile] $name pass"

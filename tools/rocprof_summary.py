@@ -56,9 +56,15 @@ def main():
             print("%-70s %-12s %7d %14.1f%s" % (k[:70], n, cnt, mean, note))
     # what bench.py reports as roofline.traffic: HBM bytes per launch of the frame->mel kernel
     best = None
+    fams = {"k_melspec_w25": "w25x8", "k_melspec_w16": "w16x16", "k_melspec_r16": "r16x16", "k_melspec_r25": "r25x8",
+            "k_melspec_r1024": "r16x16x4", "k_melspec_generic": "generic"}
+    avg_ns = {r.get("Name", ""): float(r.get("AverageNs", r.get("Average", 0)) or 0) for r in stats}
     for k, v in traffic.items():
         if "read_bytes" in v and "write_bytes" in v:
-            best = {"kernel": k, "hbm_bytes_per_launch": v["read_bytes"] + v["write_bytes"], "tag": tag, **v}
+            fam = next((f for key, f in fams.items() if key in k), "?")
+            best = {"kernel": k, "family": fam, "compute": "f64" if "<double" in k else "f32",
+                    "batch": int(os.environ.get("AUD_PROFILE_BATCH", "256")),
+                    "avg_duration_ns": avg_ns.get(k), "hbm_bytes_per_launch": v["read_bytes"] + v["write_bytes"], "tag": tag, **v}
     if best:
         with open(os.path.join(prof_dir, "pmc_traffic.json"), "w") as fh:
             json.dump(best, fh, indent=1)
