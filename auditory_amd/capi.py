@@ -53,9 +53,7 @@ class PlanDesc(C.Structure):
     _fields_ = [("win_samples", C.c_int32), ("step_samples", C.c_int32),
                 ("segment_steps", C.c_int32), ("border_steps", C.c_int32),
                 ("dft", DftParams), ("mel", MelFBank),
-                ("bin_pts", C.POINTER(C.c_int32)), ("mel_filters", C.POINTER(C.c_double)),
-                ("n_gabor", C.c_int32), ("gabor", GaborSet),
-                ("gabor_filters", C.POINTER(C.c_double)), ("compute_dtype", C.c_int32),
+                ("n_gabor", C.c_int32), ("gabor", GaborSet), ("compute_dtype", C.c_int32),
                 ("mfcc_coefs", C.c_int32)]
 
 
@@ -104,7 +102,8 @@ SYMBOLS = {
     "aud_shutdown": (C.c_int, [_VP]),
     "aud_last_error": (C.c_char_p, [_VP]),
     "aud_device_id": (C.c_int, [_VP]),
-    "aud_plan_create": (C.c_int, [_VP, C.POINTER(PlanDesc), C.POINTER(_VP)]),
+    "aud_plan_create": (C.c_int, [_VP, C.POINTER(PlanDesc), C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double), C.POINTER(_VP)]),
     "aud_plan_destroy": (C.c_int, [_VP]),
     "aud_plan_kernel_name": (C.c_char_p, [_VP]),
     "aud_plan_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int]),

@@ -360,13 +360,14 @@ int aud_shutdown(aud_ctx* c) {
 const char* aud_last_error(const aud_ctx* c) { return c ? c->err.c_str() : "null context"; }
 int aud_device_id(const aud_ctx* c) { return c ? c->device : -1; }
 
-int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
+int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, const double* mel_filters,
+                    const double* gabor_filters, aud_plan** out) {
     if (!c || !d || !out) return AUD_EINVAL;
     *out = nullptr;
     const int N = d->win_samples, nf = d->mel.n_filters;
     if (N < 4 || d->step_samples < 1 || d->segment_steps < 1 || d->border_steps < 0)
         return fail(c, AUD_EINVAL, "win_samples >= 4, step_samples >= 1, segment_steps >= 1 required");
-    if (nf < 1 || !d->bin_pts || !d->mel_filters) return fail(c, AUD_EINVAL, "mel table missing");
+    if (nf < 1 || !bin_pts || !mel_filters) return fail(c, AUD_EINVAL, "mel table missing");
     if (d->compute_dtype != AUD_F32 && d->compute_dtype != AUD_F64)
         return fail(c, AUD_EINVAL, "compute_dtype must be AUD_F32 or AUD_F64");
     const int H = N / 2 + 1;
@@ -374,7 +375,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
     // inside the [nf, nf+2] table (flat offset); outside it the Go code panics.
     const int64_t cells = int64_t(nf) * (nf + 2);
     for (int f = 0; f < nf; ++f) {
-        const int lo = d->bin_pts[f], hi = d->bin_pts[f + 2];
+        const int lo = bin_pts[f], hi = bin_pts[f + 2];
         if (lo < 0 || hi >= H) return fail(c, AUD_EINVAL, "mel BinPts outside the power spectrum (HiHz > Nyquist?)");
         if (hi >= lo && int64_t(f) * (nf + 2) + (hi - lo) >= cells)
             return fail(c, AUD_EINVAL, "mel triangle wider than the filter table (SURVEY Q4)");
@@ -382,7 +383,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
     if (d->mfcc_coefs < 0 || d->mfcc_coefs > nf || (d->mfcc_coefs > 0 && nf < 2))
         return fail(c, AUD_EINVAL, "mfcc_coefs must be 0..n_filters (and n_filters >= 2: fourier.NewDCT panics)");
     if (d->n_gabor > 0) {
-        if (!d->gabor_filters || d->gabor.size_x < 1 || d->gabor.size_y < 1 || d->gabor.stride_x < 1 ||
+        if (!gabor_filters || d->gabor.size_x < 1 || d->gabor.size_y < 1 || d->gabor.stride_x < 1 ||
             d->gabor.stride_y < 1)
             return fail(c, AUD_EINVAL, "gabor filter set incomplete");
     }
@@ -392,9 +393,6 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
     if (!p) return AUD_ENOMEM;
     p->ctx = c;
     p->d = *d;
-    p->d.bin_pts = nullptr;
-    p->d.mel_filters = nullptr;
-    p->d.gabor_filters = nullptr;
     p->H = H;
     p->ratio = (N % 2 == 0) ? 2 : 1;
     p->M = N / p->ratio;
@@ -415,11 +413,11 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
         }
         rc = upload_real(c, &p->d_tw, tw.data(), tw.size(), d->compute_dtype);
     }
-    if (rc == AUD_OK) rc = upload_real(c, &p->d_filt, d->mel_filters, size_t(cells), d->compute_dtype);
+    if (rc == AUD_OK) rc = upload_real(c, &p->d_filt, mel_filters, size_t(cells), d->compute_dtype);
     if (rc == AUD_OK)
-        rc = upload(c, reinterpret_cast<void**>(&p->d_bin_pts), d->bin_pts, sizeof(int32_t) * (nf + 2));
+        rc = upload(c, reinterpret_cast<void**>(&p->d_bin_pts), bin_pts, sizeof(int32_t) * (nf + 2));
     if (rc == AUD_OK && d->n_gabor > 0)
-        rc = upload_real(c, &p->d_gabor, d->gabor_filters,
+        rc = upload_real(c, &p->d_gabor, gabor_filters,
                          size_t(d->n_gabor) * d->gabor.size_x * d->gabor.size_y, d->compute_dtype);
     if (rc == AUD_OK && d->mfcc_coefs > 0) {
         // rows of the unnormalised DCT-I (FFTPACK cost / gonum fourier.DCT):
@@ -439,7 +437,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
     // kernel family: the in-register 16 x 16 kernel for 512-sample windows, else the generic one
     int r16_chunks = 0;
     for (int f = 0; f < nf; ++f) {
-        const int lo = d->bin_pts[f], hi = d->bin_pts[f + 2];
+        const int lo = bin_pts[f], hi = bin_pts[f + 2];
         if (hi >= lo) r16_chunks += (hi >> 2) - (lo >> 2) + 1;
     }
     if (r16_chunks == 0) r16_chunks = 1;
@@ -466,7 +464,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
         std::vector<int> order(nf), load(n_groups, 0), owner(nf);
         for (int f = 0; f < nf; ++f) order[f] = f;
         auto taps = [&](int f) {  // cost model: 4-bin chunks + a fixed per-filter epilogue (log, store)
-            const int lo = d->bin_pts[f], hi = d->bin_pts[f + 2];
+            const int lo = bin_pts[f], hi = bin_pts[f + 2];
             return (hi >= lo ? (hi >> 2) - (lo >> 2) + 1 : 0) * 6 + 30;
         };
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return taps(x) > taps(y); });
@@ -490,7 +488,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
         // reference's flat offset f*(nf+2) + (bin - lo), weights outside [lo, hi] are zero
         std::vector<double> w4;
         for (int f = 0; f < nf; ++f) {
-            const int lo = d->bin_pts[f], hi = d->bin_pts[f + 2];
+            const int lo = bin_pts[f], hi = bin_pts[f + 2];
             int* ci = &tab[goff + nf + 3 * f];
             ci[0] = lo >> 2;
             ci[1] = hi >= lo ? (hi >> 2) - (lo >> 2) + 1 : 0;
@@ -498,7 +496,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
             for (int cidx = 0; cidx < ci[1]; ++cidx)
                 for (int el = 0; el < 4; ++el) {
                     const int bin = 4 * (ci[0] + cidx) + el;
-                    w4.push_back(bin >= lo && bin <= hi ? d->mel_filters[int64_t(f) * (nf + 2) + (bin - lo)] : 0.0);
+                    w4.push_back(bin >= lo && bin <= hi ? mel_filters[int64_t(f) * (nf + 2) + (bin - lo)] : 0.0);
                 }
         }
         if (w4.empty()) w4.assign(4, 0.0);
@@ -526,7 +524,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
             for (int b = 0; b < nb; ++b) {
                 int cmin = INT_MAX, cmax = -1;
                 for (int f = 16 * b; f < std::min(nf, 16 * b + 16); ++f) {
-                    const int lo = d->bin_pts[f], hi = d->bin_pts[f + 2];
+                    const int lo = bin_pts[f], hi = bin_pts[f + 2];
                     if (hi < lo) continue;
                     cmin = std::min(cmin, lo >> 2);
                     cmax = std::max(cmax, hi >> 2);
@@ -540,8 +538,8 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
                         const int f = 16 * b + (l & 15), bin = 4 * (cmin + st) + (l >> 4);
                         float w = 0.f;
                         if (f < nf) {
-                            const int lo = d->bin_pts[f], hi = d->bin_pts[f + 2];
-                            if (bin >= lo && bin <= hi) w = float(d->mel_filters[int64_t(f) * (nf + 2) + (bin - lo)]);
+                            const int lo = bin_pts[f], hi = bin_pts[f + 2];
+                            if (bin >= lo && bin <= hi) w = float(mel_filters[int64_t(f) * (nf + 2) + (bin - lo)]);
                         }
                         atab.push_back(w);
                     }
@@ -567,7 +565,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, aud_plan** out) {
             p->r16.blk = p->d_blk;
             p->r16.atab = p->d_atab;
             // the wave-autonomous kernel of this window length (melspec_wave.hip) has its own table blob
-            if (rc == AUD_OK) rc = build_wave_tables(p, d->bin_pts, d->mel_filters);
+            if (rc == AUD_OK) rc = build_wave_tables(p, bin_pts, mel_filters);
         }
     }
     if (rc != AUD_OK) {

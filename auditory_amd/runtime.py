@@ -64,21 +64,21 @@ class Plan:
         d.win_samples, d.step_samples = win_samples, step_samples
         d.segment_steps, d.border_steps = segment_steps, border_steps
         d.dft, d.mel = dft, fbank
-        d.bin_pts = _dptr(bp, C.c_int32)
-        d.mel_filters = _dptr(mf, C.c_double)
         self.n_gabor = 0
+        gk_ptr = None
         if gabor_filters is not None and len(gabor_filters):
             gk = np.ascontiguousarray(gabor_filters, np.float64)
             d.n_gabor = gk.shape[0]
             d.gabor = gabor_set
-            d.gabor_filters = _dptr(gk, C.c_double)
+            gk_ptr = _dptr(gk, C.c_double)
             self.n_gabor = gk.shape[0]
             self.gabor_set = gabor_set
         d.compute_dtype = compute_dtype
         d.mfcc_coefs = int(mfcc_coefs)
         self.mfcc_coefs = int(mfcc_coefs)
         h = C.c_void_p()
-        ctx.check(self.lib.aud_plan_create(ctx.handle, C.byref(d), C.byref(h)))
+        ctx.check(self.lib.aud_plan_create(ctx.handle, C.byref(d), _dptr(bp, C.c_int32), _dptr(mf, C.c_double), gk_ptr,
+                                           C.byref(h)))
         self.handle = h
 
     @property

@@ -36,11 +36,14 @@ type Plan struct {
 	NGabor   int
 }
 
-// Item is one segment of one mono stream: see aud_item in auditory_hip.h.
+// Item is one segment of one mono stream: see aud_item in auditory_hip.h (same layout, 24 bytes).
+// SigStride 0 or 1 = contiguous mono; 2 with SigOff 0 / 1 = left / right channel of interleaved stereo PCM.
 type Item struct {
-	SigOff int64
-	SigLen int32
-	Start0 int32
+	SigOff    int64
+	SigLen    int32
+	Start0    int32
+	SigStride int32
+	Reserved  int32
 }
 
 func status(ctx *Ctx, rc C.int) error {
@@ -86,12 +89,21 @@ func GaborToTensor(specs []C.aud_gabor_spec, set *C.aud_gabor_set, out []float64
 	return int(n), status(nil, rc)
 }
 
-// NewPlan uploads the tables.  desc's pointer fields must point at Go slices that stay alive for
-// the duration of this call only (they are copied to the device before it returns).
-func (c *Ctx) NewPlan(desc *C.aud_plan_desc) (*Plan, error) {
+// NewPlan uploads the tables.  desc holds scalars only (no pointers), so passing its address is within the cgo
+// pointer rules; binPts, melFilters and gaborFilters are Go slices passed as direct call arguments, which cgo
+// pins for the duration of the call, and the library copies them to the device before it returns.
+// binPts: mel.Params.BinPts [nf+2]; melFilters: SndEnv.MelFilters.Values [nf*(nf+2)];
+// gaborFilters: FilterSet.Filters.Values [nG*SizeY*SizeX] or nil.
+func (c *Ctx) NewPlan(desc *C.aud_plan_desc, binPts []int32, melFilters, gaborFilters []float64) (*Plan, error) {
 	p := &Plan{ctx: c, NFilters: int(desc.mel.n_filters), Steps: int(desc.segment_steps),
 		Bins: int(desc.win_samples)/2 + 1, NGabor: int(desc.n_gabor)}
-	if rc := C.aud_plan_create(c.h, desc, &p.h); rc != C.AUD_OK {
+	var gk *C.double
+	if len(gaborFilters) > 0 {
+		gk = (*C.double)(unsafe.Pointer(&gaborFilters[0]))
+	}
+	rc := C.aud_plan_create(c.h, desc, (*C.int32_t)(unsafe.Pointer(&binPts[0])),
+		(*C.double)(unsafe.Pointer(&melFilters[0])), gk, &p.h)
+	if rc != C.AUD_OK {
 		return nil, status(c, rc)
 	}
 	return p, nil
@@ -225,4 +237,289 @@ func SetPoolState(inh fffb.Inhibs, state []float32) {
 	for i := range inh {
 		inh[i].FBi, inh[i].Act.Avg = state[2*i], state[2*i+1]
 	}
+}
+
+// ---- per-step entry points (one frame per call: correct, never fast; see auditory_hip.h) -------------------
+
+// DftFilter is dft.Params.Filter for one step (dft/dft.go:42-85): window [N]; power [H] carries the previous
+// step's power in and this step's out; powerSeg / logPowerSeg are the [H, T] segment tensors (column `step`).
+func (p *Plan) DftFilter(step int, window, power, logPower, powerSeg, logPowerSeg []float64) error {
+	var lp, lps *C.double
+	if logPower != nil {
+		lp = (*C.double)(unsafe.Pointer(&logPower[0]))
+	}
+	if logPowerSeg != nil {
+		lps = (*C.double)(unsafe.Pointer(&logPowerSeg[0]))
+	}
+	rc := C.aud_dft_filter_host(p.h, C.int(step), (*C.double)(unsafe.Pointer(&window[0])),
+		(*C.double)(unsafe.Pointer(&power[0])), lp, (*C.double)(unsafe.Pointer(&powerSeg[0])), lps)
+	return status(p.ctx, rc)
+}
+
+// DftPower is dft.Params.Power (dft/dft.go:62-85) on coefficients the caller computed.
+func (p *Plan) DftPower(step int, fftCoefs []complex128, power, logPower, powerSeg, logPowerSeg []float64) error {
+	var lp, lps *C.double
+	if logPower != nil {
+		lp = (*C.double)(unsafe.Pointer(&logPower[0]))
+	}
+	if logPowerSeg != nil {
+		lps = (*C.double)(unsafe.Pointer(&logPowerSeg[0]))
+	}
+	rc := C.aud_dft_power_host(p.h, C.int(step), (*C.double)(unsafe.Pointer(&fftCoefs[0])),
+		(*C.double)(unsafe.Pointer(&power[0])), lp, (*C.double)(unsafe.Pointer(&powerSeg[0])), lps)
+	return status(p.ctx, rc)
+}
+
+// MelFilterDft is mel.Params.FilterDft for one step (mel/mel.go:120-153).
+func (p *Plan) MelFilterDft(step int, power, segment, fbank []float64) error {
+	rc := C.aud_mel_filter_dft_host(p.h, C.int(step), (*C.double)(unsafe.Pointer(&power[0])),
+		(*C.double)(unsafe.Pointer(&segment[0])), (*C.double)(unsafe.Pointer(&fbank[0])))
+	return status(p.ctx, rc)
+}
+
+// CepstrumDct is mel.Params.CepstrumDct for one step (mel/mel.go:192-212); the plan needs mfcc_coefs = NCoefs.
+func (p *Plan) CepstrumDct(step int, fbank, mfccSeg, mfccDct []float64) error {
+	var md *C.double
+	if mfccDct != nil {
+		md = (*C.double)(unsafe.Pointer(&mfccDct[0]))
+	}
+	rc := C.aud_cepstrum_dct_host(p.h, C.int(step), (*C.double)(unsafe.Pointer(&fbank[0])),
+		(*C.double)(unsafe.Pointer(&mfccSeg[0])), md)
+	return status(p.ctx, rc)
+}
+
+// SndToWindow is SndEnv.SndToWindow (sound/sndenv.go:455-478); ErrShort mirrors its "end beyond signal length".
+var ErrShort = errors.New("SndToWindow: end beyond signal length!!")
+
+func SndToWindow(signal []float64, start, winSamples int, window []float64) error {
+	rc := C.aud_snd_to_window((*C.double)(unsafe.Pointer(&signal[0])), C.int64_t(len(signal)), C.int64_t(start),
+		C.int(winSamples), (*C.double)(unsafe.Pointer(&window[0])))
+	if rc == C.AUD_ESHORT {
+		return ErrShort
+	}
+	return status(nil, rc)
+}
+
+// Default is the process-wide context the drop-in packages (go/dft, go/mel, go/agabor, go/sound) share.
+var defaultCtx *Ctx
+
+func Default() (*Ctx, error) {
+	if defaultCtx == nil {
+		c, err := Init(0)
+		if err != nil {
+			return nil, err
+		}
+		defaultCtx = c
+	}
+	return defaultCtx, nil
+}
+
+// ---- plain-Go mirrors of the C parameter blocks, for the drop-in packages (no C types in their signatures) -------
+
+type DftParams struct {
+	CompLogPow                               bool
+	LogMin, LogOffSet, PrevSmooth, CurSmooth float64
+}
+type MelFBank struct {
+	NFilters                                              int
+	LoHz, HiHz, LogOff, LogMin                            float64
+	Renorm                                                bool
+	RenormMin, RenormMax, RenormScale                     float64
+}
+type SoundParams struct {
+	WinMs, StepMs, SegmentMs, StrideMs                                        float64
+	BorderSteps, Channel                                                      int
+	WinSamples, StepSamples, SegmentSamples, StrideSamples, SegmentSteps     int
+}
+type GaborSpec struct {
+	Off                                                           bool
+	WaveLen, Orientation, SigmaWidth, SigmaLength, PhaseOffset    float64
+	CircleEdge, Circular                                          bool
+}
+
+func b2i(b bool) C.int32_t {
+	if b {
+		return 1
+	}
+	return 0
+}
+
+// DftDefaults is dft.Params.Defaults (dft/dft.go:33-39).
+func DftDefaults() DftParams {
+	var d C.aud_dft_params
+	C.aud_dft_defaults(&d)
+	return DftParams{d.comp_log_pow != 0, float64(d.log_min), float64(d.log_offset), float64(d.prev_smooth), float64(d.cur_smooth)}
+}
+
+// MelDefaults is mel.FilterBank.Defaults (mel/mel.go:171-180).
+func MelDefaults() MelFBank {
+	var m C.aud_mel_fbank
+	C.aud_mel_defaults(&m)
+	return MelFBank{int(m.n_filters), float64(m.lo_hz), float64(m.hi_hz), float64(m.log_off), float64(m.log_min),
+		m.renorm != 0, float64(m.renorm_min), float64(m.renorm_max), float64(m.renorm_scale)}
+}
+
+func (m MelFBank) c() C.aud_mel_fbank {
+	return C.aud_mel_fbank{n_filters: C.int32_t(m.NFilters), lo_hz: C.double(m.LoHz), hi_hz: C.double(m.HiHz),
+		log_off: C.double(m.LogOff), log_min: C.double(m.LogMin), renorm: b2i(m.Renorm),
+		renorm_min: C.double(m.RenormMin), renorm_max: C.double(m.RenormMax), renorm_scale: C.double(m.RenormScale)}
+}
+
+// MelInitFiltersGo is mel.Params.InitFilters' arithmetic (mel/mel.go:77-117) on Go slices.
+func MelInitFiltersGo(fb *MelFBank, dftSize, sampleRate int, binPts []int32, hzPts, filters []float64) error {
+	cfb := fb.c()
+	err := MelInitFilters(&cfb, dftSize, sampleRate, binPts, hzPts, filters)
+	fb.Renorm = cfb.renorm != 0
+	return err
+}
+
+func FreqToMel(f float64) float64 { return float64(C.aud_freq_to_mel(C.double(f))) }
+func MelToFreq(m float64) float64 { return float64(C.aud_mel_to_freq(C.double(m))) }
+func FreqToBin(f, nFft, sr float64) int {
+	return int(C.aud_freq_to_bin(C.double(f), C.double(nFft), C.double(sr)))
+}
+
+// SoundParamDefaults / SoundParamsDerive: SndEnv.ParamDefaults and the derivations of SndEnv.Init (sndenv.go:64-71, :202-207).
+func SoundParamDefaults() SoundParams {
+	var p C.aud_sound_params
+	C.aud_sound_params_defaults(&p)
+	return SoundParams{WinMs: float64(p.win_ms), StepMs: float64(p.step_ms), SegmentMs: float64(p.segment_ms),
+		StrideMs: float64(p.stride_ms), BorderSteps: int(p.border_steps), Channel: int(p.channel)}
+}
+func SoundParamsDerive(winMs, stepMs, segMs, strideMs float64, border, rate int) (SoundParams, error) {
+	p := C.aud_sound_params{win_ms: C.double(winMs), step_ms: C.double(stepMs), segment_ms: C.double(segMs),
+		stride_ms: C.double(strideMs), border_steps: C.int32_t(border)}
+	if rc := C.aud_sound_params_derive(&p, C.int(rate)); rc != C.AUD_OK {
+		return SoundParams{}, status(nil, rc)
+	}
+	return SoundParams{winMs, stepMs, segMs, strideMs, border, 0, int(p.win_samples), int(p.step_samples),
+		int(p.segment_samples), int(p.stride_samples), int(p.segment_steps)}, nil
+}
+func SegCnt(sigLen, segSamples, strideSamples, channels int) int {
+	return int(C.aud_seg_cnt(C.int(sigLen), C.int(segSamples), C.int(strideSamples), C.int(channels)))
+}
+func Tail(sigLen, segSamples, strideSamples int) int {
+	return int(C.aud_tail(C.int(sigLen), C.int(segSamples), C.int(strideSamples)))
+}
+func PadLen(sigLen, segSamples, strideSamples, stepSamples int) int {
+	return int(C.aud_pad_len(C.int(sigLen), C.int(segSamples), C.int(strideSamples), C.int(stepSamples)))
+}
+func AdjustForSilence(add, existing float64, rate int) (offset, delta int) {
+	var d C.int
+	off := C.aud_adjust_for_silence(C.double(add), C.double(existing), C.int(rate), &d)
+	return int(off), int(d)
+}
+
+func GaborSpecOf(off bool, waveLen, orient, sw, sl, phase float64, circleEdge, circular bool) GaborSpec {
+	return GaborSpec{off, waveLen, orient, sw, sl, phase, circleEdge, circular}
+}
+func (g GaborSpec) c() C.aud_gabor_spec {
+	return C.aud_gabor_spec{off: b2i(g.Off), wave_len: C.double(g.WaveLen), orientation: C.double(g.Orientation),
+		sigma_width: C.double(g.SigmaWidth), sigma_length: C.double(g.SigmaLength), phase_offset: C.double(g.PhaseOffset),
+		circle_edge: b2i(g.CircleEdge), circular: b2i(g.Circular)}
+}
+
+// GaborSpecDefaults is agabor.Filter.Defaults (agabor/gabor.go:73-86): zero fields get their defaults, with the notice.
+func GaborSpecDefaults(g *GaborSpec, i int) {
+	if g.WaveLen == 0 {
+		fmt.Printf("filter %v: WaveLen is 0 -- using default of 2\n", i)
+		g.WaveLen = 2
+	}
+	if g.SigmaLength == 0 && !g.Circular {
+		fmt.Printf("filter %v: SigmaLength is 0 -- using default of 0.5\n", i)
+		g.SigmaLength = 0.5
+	}
+	if g.SigmaWidth == 0 {
+		fmt.Printf("filter %v: SigmaWidth is 0 -- using default of 0.5\n", i)
+		g.SigmaWidth = 0.5
+	}
+}
+
+func gaborSet(sx, sy, stx, sty int, gain float64, distribute bool) C.aud_gabor_set {
+	return C.aud_gabor_set{size_x: C.int32_t(sx), size_y: C.int32_t(sy), stride_x: C.int32_t(stx), stride_y: C.int32_t(sty),
+		gain: C.double(gain), distribute: b2i(distribute)}
+}
+
+// GaborToTensorGo is agabor.ToTensor (agabor/gabor.go:89-222) on Go values.
+func GaborToTensorGo(specs []GaborSpec, sx, sy, stx, sty int, gain float64, distribute bool, out []float64) (int, error) {
+	cs := make([]C.aud_gabor_spec, len(specs))
+	for i, g := range specs {
+		cs[i] = g.c()
+	}
+	set := gaborSet(sx, sy, stx, sty, gain, distribute)
+	return GaborToTensor(cs, &set, out)
+}
+
+func planDesc(n, s, t, border int, d DftParams, m MelFBank, f64 bool, mfcc int) C.aud_plan_desc {
+	desc := C.aud_plan_desc{win_samples: C.int32_t(n), step_samples: C.int32_t(s), segment_steps: C.int32_t(t),
+		border_steps: C.int32_t(border), mfcc_coefs: C.int32_t(mfcc)}
+	desc.dft = C.aud_dft_params{comp_log_pow: b2i(d.CompLogPow), log_min: C.double(d.LogMin), log_offset: C.double(d.LogOffSet),
+		prev_smooth: C.double(d.PrevSmooth), cur_smooth: C.double(d.CurSmooth)}
+	desc.mel = m.c()
+	desc.compute_dtype = C.AUD_F32
+	if f64 {
+		desc.compute_dtype = C.AUD_F64
+	}
+	return desc
+}
+
+// NewSndEnvPlan is what SndEnv.Init builds: the segment geometry, dft / mel parameters and tables, and the gabor set.
+func (c *Ctx) NewSndEnvPlan(sp SoundParams, compLogPow bool, logMin, logOff, prevSmooth, curSmooth float64,
+	nf int, loHz, hiHz, melLogOff, melLogMin float64, renorm bool, renormMin, renormMax, renormScale float64,
+	binPts []int32, melFilters []float64, gsx, gsy, gstx, gsty int, gain float64, gaborFilters []float64,
+	mfccCoefs int, f64 bool) (*Plan, error) {
+	desc := planDesc(sp.WinSamples, sp.StepSamples, sp.SegmentSteps, sp.BorderSteps,
+		DftParams{compLogPow, logMin, logOff, prevSmooth, curSmooth},
+		MelFBank{nf, loHz, hiHz, melLogOff, melLogMin, renorm, renormMin, renormMax, renormScale}, f64, mfccCoefs)
+	if n := gsx * gsy; n > 0 && len(gaborFilters) >= n {
+		desc.n_gabor = C.int32_t(len(gaborFilters) / n)
+		desc.gabor = gaborSet(gsx, gsy, gstx, gsty, gain, false)
+	}
+	return c.NewPlan(&desc, binPts, melFilters, gaborFilters)
+}
+
+// NewStepPlan serves dft.Params.Filter / Power called on their own: a one-filter dummy mel table keeps the plan valid.
+func NewStepPlan(winSamples, steps int, compLogPow bool, logMin, logOff, prevSmooth, curSmooth float64) (*Plan, error) {
+	c, err := Default()
+	if err != nil {
+		return nil, err
+	}
+	desc := planDesc(winSamples, 1, steps, 0, DftParams{compLogPow, logMin, logOff, prevSmooth, curSmooth},
+		MelFBank{NFilters: 1, LogMin: -10}, true, 0)
+	return c.NewPlan(&desc, []int32{0, 0, 0}, []float64{1, 0, 0}, nil)
+}
+
+// NewMelStepPlan serves mel.Params.FilterDft / CepstrumDct called on their own.
+func NewMelStepPlan(winSamples, steps int, fb MelFBank, binPts []int32, filters []float64, nCoefs int) (*Plan, error) {
+	c, err := Default()
+	if err != nil {
+		return nil, err
+	}
+	desc := planDesc(winSamples, 1, steps, 0, DftDefaults(), fb, true, nCoefs)
+	return c.NewPlan(&desc, binPts, filters, nil)
+}
+
+// GaborPlan serves agabor.Convolve called on its own (plans cached per tap set would go here).
+func GaborPlan(sx, sy, stx, sty int, gain float64, taps []float64) (*Plan, error) {
+	c, err := Default()
+	if err != nil {
+		return nil, err
+	}
+	desc := planDesc(4, 1, 1, 0, DftDefaults(), MelFBank{NFilters: 1, LogMin: -10}, true, 0)
+	desc.n_gabor = C.int32_t(len(taps) / (sx * sy))
+	desc.gabor = gaborSet(sx, sy, stx, sty, gain, false)
+	return c.NewPlan(&desc, []int32{0, 0, 0}, []float64{1, 0, 0}, taps)
+}
+
+// MelSpecMFCC is ProcessSegment with Mel.MFCC on (sndenv.go:342-435) for all items in one call.
+func (p *Plan) MelSpecMFCC(sig []float64, items []Item, mel, power, logPower, mfcc, deltas, deltaDeltas, energy []float64) error {
+	ptr := func(s []float64) *C.double {
+		if len(s) == 0 {
+			return nil
+		}
+		return (*C.double)(unsafe.Pointer(&s[0]))
+	}
+	rc := C.aud_melspec_mfcc_batch_host(p.h, ptr(sig), C.int64_t(len(sig)), (*C.aud_item)(unsafe.Pointer(&items[0])),
+		C.int(len(items)), ptr(mel), ptr(power), ptr(logPower), ptr(mfcc), ptr(deltas), ptr(deltaDeltas), ptr(energy))
+	return status(p.ctx, rc)
 }

@@ -1,0 +1,300 @@
+// Package sound is the drop-in for github.com/emer/auditory/sound's SndEnv (sound/sndenv.go:24-536 of the reference):
+// same exported types, fields and method signatures.  Init builds a device plan next to the tensors; ProcessSegment is
+// ONE call into libauditory_hip.so for the whole segment (all T steps: window extraction, DFT, power, log-power, mel,
+// and the MFCC tail when Mel.MFCC is on); ApplyGabor is one more.  The per-step methods keep working through the
+// per-step entry points.  ProcessSegments (new) takes every segment of the sound in one launch.
+//
+// NOT COMPILED IN THIS PIPELINE (no Go toolchain in the build image).  Wave (sound/sound.go) is host I/O and stays the
+// reference's own file; only SndEnv is replaced.
+package sound
+
+import (
+	"errors"
+	"fmt"
+	"log"
+
+	"github.com/emer/auditory/go/agabor"
+	"github.com/emer/auditory/go/auditoryhip"
+	"github.com/emer/auditory/go/dft"
+	"github.com/emer/auditory/go/mel"
+	"github.com/emer/etable/etable"
+	"github.com/emer/etable/etensor"
+	"github.com/emer/leabra/fffb"
+	"github.com/emer/vision/kwta"
+)
+
+// Params: sound/sndenv.go:24-61.
+type Params struct {
+	WinMs          float64
+	StepMs         float64
+	SegmentMs      float64
+	StrideMs       float64
+	BorderSteps    int
+	Channel        int
+	WinSamples     int
+	StepSamples    int
+	SegmentSamples int
+	StrideSamples  int
+	SegmentSteps   int
+	Steps          []int
+}
+
+// SndEnv: sound/sndenv.go:73-182, field for field.
+type SndEnv struct {
+	Nm              string
+	Dsc             string
+	On              bool
+	Sound           Wave
+	Params          Params
+	Signal          etensor.Float64
+	SegCnt          int
+	Window          etensor.Float64
+	DFT             dft.Params
+	Power           etensor.Float64
+	LogPower        etensor.Float64
+	PowerSegment    etensor.Float64
+	LogPowerSegment etensor.Float64
+	Mel             mel.Params
+	MelFBank        etensor.Float64
+	MelFBankSegment etensor.Float64
+	MelFilters      etensor.Float64
+	Energy          etensor.Float64
+	MFCCDCT         etensor.Float64
+	MFCCSegment     etensor.Float64
+	MFCCDeltas      etensor.Float64
+	MFCCDeltaDeltas etensor.Float64
+	GaborSpecs      []agabor.Filter
+	GaborFilters    agabor.FilterSet
+	GaborTab        etable.Table
+	GborOutPoolsX   int
+	GborOutPoolsY   int
+	GborOutUnitsX   int
+	GborOutUnitsY   int
+	GborOutput      etensor.Float32
+	GborKwta        etensor.Float32
+	Inhibs          fffb.Inhibs
+	ExtGi           etensor.Float32
+	NeighInhib      kwta.NeighInhib
+	Kwta            kwta.KWTA
+	KwtaPool        bool
+	ByTime          bool
+
+	// ComputeF32 selects the float32 kernels (1.5x faster; a few elements per million miss 1e-5 of the reference).
+	// The zero value keeps the reference's arithmetic: float64.
+	ComputeF32 bool
+
+	ctx  *auditoryhip.Ctx
+	plan *auditoryhip.Plan
+}
+
+// ParamDefaults: sound/sndenv.go:64-71.
+func (se *SndEnv) ParamDefaults() {
+	p := auditoryhip.SoundParamDefaults()
+	se.Params.WinMs, se.Params.StepMs, se.Params.SegmentMs, se.Params.StrideMs = p.WinMs, p.StepMs, p.SegmentMs, p.StrideMs
+	se.Params.BorderSteps, se.Params.Channel = p.BorderSteps, p.Channel
+}
+
+// Defaults: sound/sndenv.go:185-192.
+func (se *SndEnv) Defaults() {
+	se.ParamDefaults()
+	se.DFT.Defaults()
+	se.Mel.Defaults()
+	se.Kwta.Defaults()
+	se.KwtaPool = true
+}
+
+// Init: sound/sndenv.go:195-267 -- derived sample counts, tensor shapes, the mel table, SegCnt; then the device plan.
+func (se *SndEnv) Init() (err error) {
+	sr := se.Sound.SampleRate()
+	if sr <= 0 {
+		fmt.Println("sample rate <= 0")
+		return errors.New("sample rate <= 0")
+	}
+	d, err := auditoryhip.SoundParamsDerive(se.Params.WinMs, se.Params.StepMs, se.Params.SegmentMs, se.Params.StrideMs, se.Params.BorderSteps, sr)
+	if err != nil {
+		return err
+	}
+	se.Params.WinSamples, se.Params.StepSamples = d.WinSamples, d.StepSamples
+	se.Params.SegmentSamples, se.Params.StrideSamples, se.Params.SegmentSteps = d.SegmentSamples, d.StrideSamples, d.SegmentSteps
+	T, H, nf := se.Params.SegmentSteps, se.Params.WinSamples/2+1, se.Mel.FBank.NFilters
+	se.Params.Steps = make([]int, T)
+	for i := range se.Params.Steps {
+		se.Params.Steps[i] = se.Params.StepSamples * (i - se.Params.BorderSteps)
+	}
+	se.Window.SetShape([]int{se.Params.WinSamples}, nil, nil)
+	se.Power.SetShape([]int{H}, nil, nil)
+	se.LogPower.SetShape([]int{H}, nil, nil)
+	se.PowerSegment.SetShape([]int{H, T}, nil, nil)
+	se.LogPowerSegment.SetShape([]int{H, T}, nil, nil)
+	se.Mel.InitFilters(se.Params.WinSamples, sr, &se.MelFilters)
+	se.MelFBank.SetShape([]int{nf}, nil, nil)
+	se.MelFBankSegment.SetShape([]int{nf, T}, nil, nil)
+	se.Energy.SetShape([]int{T}, nil, nil)
+	if se.Mel.MFCC {
+		se.MFCCDCT.SetShape([]int{nf}, nil, nil)
+		se.MFCCSegment.SetShape([]int{se.Mel.NCoefs, T}, nil, nil)
+		se.MFCCDeltas.SetShape([]int{se.Mel.NCoefs, T}, nil, nil)
+		se.MFCCDeltaDeltas.SetShape([]int{se.Mel.NCoefs, T}, nil, nil)
+	}
+	se.SegCnt = auditoryhip.SegCnt(len(se.Signal.Values), se.Params.SegmentSamples, se.Params.StrideSamples, se.Sound.Channels())
+
+	if se.ctx == nil {
+		if se.ctx, err = auditoryhip.Default(); err != nil {
+			return err // no HIP device: there is no CPU fallback
+		}
+	}
+	if se.plan != nil {
+		se.plan.Close()
+	}
+	nc := 0
+	if se.Mel.MFCC {
+		nc = se.Mel.NCoefs
+	}
+	se.plan, err = se.ctx.NewSndEnvPlan(d, se.DFT.CompLogPow, se.DFT.LogMin, se.DFT.LogOffSet, se.DFT.PrevSmooth, se.DFT.CurSmooth,
+		se.Mel.FBank.NFilters, se.Mel.FBank.LoHz, se.Mel.FBank.HiHz, se.Mel.FBank.LogOff, se.Mel.FBank.LogMin, se.Mel.FBank.Renorm,
+		se.Mel.FBank.RenormMin, se.Mel.FBank.RenormMax, se.Mel.FBank.RenormScale, se.Mel.BinPts, se.MelFilters.Values,
+		se.GaborFilters.SizeX, se.GaborFilters.SizeY, se.GaborFilters.StrideX, se.GaborFilters.StrideY, se.GaborFilters.Gain,
+		se.GaborFilters.Filters.Values, nc, !se.ComputeF32)
+	return err
+}
+
+func (se *SndEnv) item(segment, add int) auditoryhip.Item {
+	start0 := segment*se.Params.StrideSamples + MSecToSamples(float64(add), se.Sound.SampleRate()) // sndenv.go:440-441
+	return auditoryhip.Item{SigOff: 0, SigLen: int32(len(se.Signal.Values)), Start0: int32(start0), SigStride: 1}
+}
+
+// ProcessSegment: sound/sndenv.go:342-435 -- one launch for the T steps of the segment.  A window that runs past the
+// signal leaves that step and all later ones zero, as the reference's print-and-break does (:354-358).
+func (se *SndEnv) ProcessSegment(segment, add int) {
+	items := []auditoryhip.Item{se.item(segment, add)}
+	var err error
+	if se.Mel.MFCC {
+		err = se.plan.MelSpecMFCC(se.Signal.Values, items, se.MelFBankSegment.Values, se.PowerSegment.Values,
+			se.LogPowerSegment.Values, se.MFCCSegment.Values, se.MFCCDeltas.Values, se.MFCCDeltaDeltas.Values, se.Energy.Values)
+	} else {
+		err = se.plan.MelSpec(se.Signal.Values, items, se.MelFBankSegment.Values, se.PowerSegment.Values, se.LogPowerSegment.Values)
+	}
+	if err != nil {
+		fmt.Println(err)
+	}
+}
+
+// ProcessSegments (new): segments first .. first+n-1 of the sound in one launch; mel is [n][nf][T] float64.
+func (se *SndEnv) ProcessSegments(first, n, add int, mel []float64) error {
+	items := make([]auditoryhip.Item, n)
+	for i := range items {
+		items[i] = se.item(first+i, add)
+	}
+	return se.plan.MelSpec(se.Signal.Values, items, mel, nil, nil)
+}
+
+// ProcessStep: sound/sndenv.go:438-452 (one step: SndToWindow, DFT.Filter, Mel.FilterDft, CepstrumDct).
+func (se *SndEnv) ProcessStep(segment, step, add int) error {
+	offset := se.Params.Steps[step]
+	start := segment*se.Params.StrideSamples + offset + MSecToSamples(float64(add), se.Sound.SampleRate())
+	if err := se.SndToWindow(start); err != nil {
+		return err
+	}
+	se.DFT.Filter(step, &se.Window, se.Params.WinSamples, &se.Power, &se.LogPower, &se.PowerSegment, &se.LogPowerSegment)
+	se.Mel.FilterDft(step, &se.Power, &se.MelFBankSegment, &se.MelFBank, &se.MelFilters)
+	if se.Mel.MFCC {
+		se.Mel.CepstrumDct(step, &se.MelFBank, &se.MFCCSegment, &se.MFCCDCT)
+	}
+	return nil
+}
+
+// SndToWindow: sound/sndenv.go:455-478 (left zero pad; "end beyond signal length" past the end).
+func (se *SndEnv) SndToWindow(start int) error {
+	return auditoryhip.SndToWindow(se.Signal.Values, start, se.Params.WinSamples, se.Window.Values)
+}
+
+// ApplyGabor: sound/sndenv.go:481-497.
+func (se *SndEnv) ApplyGabor() (tsr *etensor.Float32) {
+	shp := make([]int32, se.GborOutput.NumDims())
+	for i := range shp {
+		shp[i] = int32(se.GborOutput.Dim(i))
+	}
+	if err := se.plan.Convolve(se.MelFBankSegment.Values, 1, se.MelFBankSegment.Dim(0), se.MelFBankSegment.Dim(1), shp, se.ByTime, se.GborOutput.Values); err != nil {
+		log.Println(err) // Convolve logs and returns with rawOut untouched (gabor.go:226-229, :259-262)
+	}
+	if se.NeighInhib.On {
+		se.ApplyNeighInhib()
+	} else {
+		se.ExtGi.SetZeros()
+	}
+	if se.Kwta.On {
+		se.ApplyKwta()
+		return &se.GborKwta
+	}
+	return &se.GborOutput
+}
+
+// ApplyNeighInhib: sound/sndenv.go:303-311 (emer/vision code, not on the device path).
+func (se *SndEnv) ApplyNeighInhib() {
+	if se.NeighInhib.On {
+		se.NeighInhib.Inhib4(&se.GborOutput, &se.ExtGi)
+	} else {
+		se.ExtGi.SetZeros()
+	}
+}
+
+// ApplyKwta: sound/sndenv.go:313-323.
+func (se *SndEnv) ApplyKwta() {
+	se.GborKwta.CopyFrom(&se.GborOutput)
+	if !se.Kwta.On {
+		return
+	}
+	if se.NeighInhib.On { // non-zero ExtGi: the Go path of emer/vision
+		if se.KwtaPool {
+			se.Kwta.KWTAPool(&se.GborOutput, &se.GborKwta, &se.Inhibs, &se.ExtGi)
+		} else {
+			se.Kwta.KWTALayer(&se.GborOutput, &se.GborKwta, &se.ExtGi)
+		}
+		return
+	}
+	shp := [4]int{se.GborOutput.Dim(0), se.GborOutput.Dim(1), se.GborOutput.Dim(2), se.GborOutput.Dim(3)}
+	if len(se.Inhibs) < shp[0]*shp[1] {
+		se.Inhibs = make(fffb.Inhibs, shp[0]*shp[1])
+	}
+	st := make([]float32, 2*shp[0]*shp[1])
+	auditoryhip.PoolState(se.Inhibs, st)
+	if err := se.ctx.Kwta(&se.Kwta, se.GborOutput.Values, se.GborKwta.Values, 1, shp, se.KwtaPool, st); err != nil {
+		log.Println(err)
+	}
+	auditoryhip.SetPoolState(se.Inhibs, st)
+}
+
+// ToTensor: sound/sndenv.go:297-300.
+func (se *SndEnv) ToTensor() bool { return se.Sound.SoundToTensor(&se.Signal) }
+
+// AdjustForSilence / Tail / Pad: sound/sndenv.go:274-294, :503-519.
+func (se *SndEnv) AdjustForSilence(add, existing float64) (offset int) {
+	off, delta := auditoryhip.AdjustForSilence(add, existing, se.Sound.SampleRate())
+	switch {
+	case delta < 0:
+		se.Signal.Values = se.Signal.Values[-delta:]
+	case delta > 0:
+		se.Signal.Values = append(make([]float64, delta), se.Signal.Values...)
+	}
+	return off
+}
+
+func (se *SndEnv) Tail(signal []float64) int {
+	return auditoryhip.Tail(len(signal), se.Params.SegmentSamples, se.Params.StrideSamples)
+}
+
+func (se *SndEnv) Pad(signal []float64, value float64) (padded []float64) {
+	n := auditoryhip.PadLen(len(signal), se.Params.SegmentSamples, se.Params.StrideSamples, se.Params.StepSamples)
+	padded = append(signal, make([]float64, n)...)
+	for i := len(signal); i < len(padded); i++ {
+		padded[i] = value
+	}
+	return padded
+}
+
+func (se *SndEnv) Name() string { return se.Nm }
+func (se *SndEnv) Desc() string { return se.Dsc }
+
+// MSecToSamples / SamplesToMSec: sound/sndenv.go:522-529.
+func MSecToSamples(ms float64, rate int) int     { return auditoryhip.MSecToSamples(ms, rate) }
+func SamplesToMSec(samples int, rate int) float64 { return auditoryhip.SamplesToMSec(samples, rate) }

@@ -332,14 +332,14 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
         d.win_samples = Params_.WinSamples; d.step_samples = Params_.StepSamples;
         d.segment_steps = Params_.SegmentSteps; d.border_steps = Params_.BorderSteps;
         d.dft = DFT.c(); d.mel = Mel.FBank.c();
-        d.bin_pts = Mel.BinPts.data(); d.mel_filters = MelFilters.Values.data();
         d.n_gabor = GaborFilters.Filters.NumDims() == 3 ? GaborFilters.Filters.Dim(0) : 0;
         d.gabor = GaborFilters.c();
-        d.gabor_filters = d.n_gabor ? GaborFilters.Filters.Values.data() : nullptr;
         d.compute_dtype = ComputeDtype;
         d.mfcc_coefs = Mel.MFCC ? Mel.NCoefs : 0;
         if (plan.p) { aud_plan_destroy(plan.p); plan.p = nullptr; }
-        if (aud_plan_create(default_ctx(), &d, &plan.p) != AUD_OK) return aud_last_error(default_ctx());
+        if (aud_plan_create(default_ctx(), &d, Mel.BinPts.data(), MelFilters.Values.data(),
+                            d.n_gabor ? GaborFilters.Filters.Values.data() : nullptr, &plan.p) != AUD_OK)
+            return aud_last_error(default_ctx());
         return "";
     }
 

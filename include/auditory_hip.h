@@ -125,8 +125,10 @@ typedef struct {
     int32_t reserved; /* 0 */
 } aud_item;
 
-/* Everything a plan needs.  Tables are built host-side (aud_mel_init_filters,
- * aud_gabor_to_tensor) so device code never re-derives them. */
+/* The scalar part of a plan.  It holds NO pointers: a cgo caller builds it in Go memory and may pass it by address
+ * (the cgo rules forbid handing C a Go pointer to memory that itself contains Go pointers).  The tables -- built
+ * host-side by aud_mel_init_filters / aud_gabor_to_tensor so device code never re-derives them -- are separate
+ * arguments of aud_plan_create. */
 typedef struct {
     int32_t win_samples;         /* N: FFT length = window length, no taper (sndenv.go:470) */
     int32_t step_samples;        /* S */
@@ -134,11 +136,8 @@ typedef struct {
     int32_t border_steps;
     aud_dft_params dft;
     aud_mel_fbank mel;
-    const int32_t* bin_pts;      /* [n_filters+2]           mel.Params.BinPts */
-    const double* mel_filters;   /* [n_filters, n_filters+2] SndEnv.MelFilters */
     int32_t n_gabor;             /* 0 = no gabor stage */
     aud_gabor_set gabor;
-    const double* gabor_filters; /* [n_gabor, size_y, size_x] FilterSet.Filters, or NULL */
     int32_t compute_dtype;       /* AUD_F32 (default) or AUD_F64 */
     int32_t mfcc_coefs;          /* mel.Params.NCoefs if the MFCC tail is wanted (Mel.MFCC), else 0 */
 } aud_plan_desc;
@@ -202,7 +201,12 @@ int aud_shutdown(aud_ctx* ctx);
 const char* aud_last_error(const aud_ctx* ctx); /* never NULL */
 int aud_device_id(const aud_ctx* ctx);
 
-int aud_plan_create(aud_ctx* ctx, const aud_plan_desc* desc, aud_plan** plan);
+/* bin_pts      [n_filters + 2]            mel.Params.BinPts          (mel/mel.go:16-31)
+ * mel_filters  [n_filters, n_filters + 2] SndEnv.MelFilters.Values   (sound/sndenv.go:139; built by mel.go:77-117)
+ * gabor_filters [n_gabor, size_y, size_x] FilterSet.Filters.Values   (agabor/gabor.go:45-70), NULL when n_gabor = 0
+ * The tables are copied to the device before the call returns; nothing is retained. */
+int aud_plan_create(aud_ctx* ctx, const aud_plan_desc* desc, const int32_t* bin_pts, const double* mel_filters,
+                    const double* gabor_filters, aud_plan** plan);
 int aud_plan_destroy(aud_plan* plan);
 /* which frame->mel kernel family the plan selected: "generic", "r16x16", ... (diagnostic) */
 const char* aud_plan_kernel_name(const aud_plan* plan);

@@ -118,6 +118,39 @@ def case_workgroup_order(orc, cdt, with_n2048=True):
     plan.close()
 
 
+def case_interleaved_stereo(orc, cdt, names=("cfg2_16k_n400_nf40", "cfg2_16k_n512_nf40", "cfg1_44k_n1103_nf32"), seg_ms=200.0):
+    """BASELINE config 5 is stereo: an interleaved L,R,L,R buffer (sound.go:116-127 keeps the interleave) is addressed
+    as two mono streams through aud_item.sig_stride = 2 with sig_off = 0 / 1 -- no de-interleaving copy -- and must give,
+    bit for bit, what the two channels give as separate contiguous streams (every kernel family, float64 / float32 /
+    int16 samples)."""
+    import ctypes as C
+    lib = capi.load()
+    for name in names:
+        oc = W.OracleCfg(orc, name, seg_ms)
+        L = oc.full_len() + 37                                   # odd offsets too
+        sig, pcm = synth.batch(23, 2, L - oc.N // 3, oc.sr, row_len=L)   # rows = left, right; tails run off the end
+        inter = np.empty(2 * L, np.float64)
+        inter[0::2], inter[1::2] = sig[0], sig[1]
+        inter16 = np.empty(2 * L, np.int16)
+        inter16[0::2], inter16[1::2] = pcm[0], pcm[1]
+        plan = W.product_plan(oc, cdt)
+        try:
+            mono, _, _ = plan.melspec_host(sig.ravel(), runtime.make_items([0, L], [L, L], [0, 0]))
+            st_items = runtime.make_items([0, 1], [L, L], [0, 0], sig_stride=2)
+            stereo, _, _ = plan.melspec_host(inter, st_items)
+            assert np.array_equal(mono, stereo, equal_nan=True), name
+            ref = np.stack([orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig[r])["mel_seg"] for r in range(2)])
+            ok, msg = W.feature_close(stereo, ref, cdt, lin_axis=1)
+            assert ok, (name, msg)
+            # a stream may not run past the buffer: the last sample of channel 1 is element 2 L - 1
+            bad = runtime.make_items([1], [L + 1], [0], sig_stride=2)
+            with pytest.raises(capi.AuditoryError):
+                plan.melspec_host(inter, bad)
+        finally:
+            plan.close()
+    del C, lib, inter16
+
+
 def case_zero_signal_and_empty_batch(orc):
     oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
     plan = W.product_plan(oc)

@@ -62,11 +62,11 @@ def test_plan_argument_errors(orc, emu):
     lib = ctx.lib
     d = capi.PlanDesc()
     h = C.c_void_p()
-    assert lib.aud_plan_create(ctx.handle, None, C.byref(h)) == capi.AUD_EINVAL
-    assert lib.aud_plan_create(None, C.byref(d), C.byref(h)) == capi.AUD_EINVAL
+    assert lib.aud_plan_create(ctx.handle, None, None, None, None, C.byref(h)) == capi.AUD_EINVAL
+    assert lib.aud_plan_create(None, C.byref(d), None, None, None, C.byref(h)) == capi.AUD_EINVAL
     d.win_samples, d.step_samples, d.segment_steps = 400, 160, 14
     d.mel.n_filters = 32
-    assert lib.aud_plan_create(ctx.handle, C.byref(d), C.byref(h)) == capi.AUD_EINVAL      # no tables
+    assert lib.aud_plan_create(ctx.handle, C.byref(d), None, None, None, C.byref(h)) == capi.AUD_EINVAL      # no tables
     dftp = capi.DftParams(1, -100.0, 1.0, 0.0, 1.0)
     fb = capi.MelFBank(32, 0.0, 8000.0, 0.0, -10.0, 0, -6.0, 4.0, 0.0)
     for kw in (dict(compute_dtype=7), dict(mfcc_coefs=33), dict(mfcc_coefs=-1)):

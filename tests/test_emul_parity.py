@@ -61,6 +61,11 @@ def test_emul_n512_odd_step(orc, emu, cdt):
     PC.case_n512_odd_step_and_sample_types(orc, cdt)
 
 
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_emul_interleaved_stereo(orc, emu, cdt):
+    PC.case_interleaved_stereo(orc, cdt, seg_ms=100.0)
+
+
 def test_emul_zero_signal_and_empty_batch(orc, emu):
     PC.case_zero_signal_and_empty_batch(orc)
 

@@ -55,6 +55,12 @@ def test_workgroup_order(orc, torch_cuda, cdt):
     PC.case_workgroup_order(orc, cdt)
 
 
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_interleaved_stereo(orc, torch_cuda, cdt):
+    PC.case_interleaved_stereo(orc, cdt, names=("cfg2_16k_n400_nf40", "cfg2_16k_n512_nf40", "cfg1_44k_n1103_nf32",
+                                                 "cfg5_44k_n2048_nf128"))
+
+
 def test_zero_signal_and_empty_batch(orc, torch_cuda):
     PC.case_zero_signal_and_empty_batch(orc)
 
