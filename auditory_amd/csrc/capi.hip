@@ -39,6 +39,7 @@ struct aud_plan {
     int fast_kind = kNoFast;   // which family the tables below were built for
     bool use_fast = false;     // false: generic kernel (no fast family, or forced by an option)
     int xcd_remap = 1;         // workgroup -> tile order keeps an XCD on one run of tiles (kernels.h)
+    int gabor_lds = 0;         // 1: LDS-tiled gabor kernel where the mel matrix fits (option "gabor_lds"); measured slower, off
     int r16_chunks = 0;
     aud::FastArgs r16{};
     // wave-autonomous kernel of the same window length (melspec_wave.hip), the default where it exists
@@ -647,6 +648,11 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
         p->wv.persistent = value;
         return AUD_OK;
     }
+    if (key == "gabor_lds") {  // 0 (default): the global-memory gabor kernel; 1: LDS-tiled kernel where an item's mel matrix fits
+        if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "gabor_lds: 0 or 1");
+        p->gabor_lds = value;
+        return AUD_OK;
+    }
     if (key == "xcd_remap") {  // 1 (default): every XCD walks a contiguous run of tiles; 0: tiles in workgroup-id order
         if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "xcd_remap: 0 or 1");
         p->xcd_remap = value;
@@ -805,6 +811,7 @@ int aud_gabor_batch_dev(aud_plan* p, const float* mel, int n_items, int rows, in
     a.nF = nF;
     a.t_max_strides = strides;
     a.out = out;
+    a.use_lds = p->gabor_lds;
     AUD_HIP(c, aud::launch_gabor(a, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
     return AUD_OK;
 }

@@ -91,6 +91,7 @@ struct GaborArgs {
     int by_time;
     int nT, nF, t_max_strides;
     float* out;
+    int use_lds;  // 1: the LDS-tiled kernel when the item's mel matrix fits (plan option "gabor_lds", default on)
 };
 
 // extra arguments of the register-resident two-pass kernels (r16x16 for N = 512, r25x8 for N = 400)

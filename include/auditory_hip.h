@@ -210,10 +210,17 @@ int aud_plan_create(aud_ctx* ctx, const aud_plan_desc* desc, const int32_t* bin_
 int aud_plan_destroy(aud_plan* plan);
 /* which frame->mel kernel family the plan selected: "generic", "r16x16", ... (diagnostic) */
 const char* aud_plan_kernel_name(const aud_plan* plan);
-/* Tuning / diagnostic switches; results are identical whatever they are set to.
- *   "kernel"    0 automatic (default), 1 force the generic any-N kernel
+/* Tuning / diagnostic switches; results are identical whatever they are set to (up to the last-place effects of a
+ * different summation order between kernel families).
+ *   "kernel"    0 automatic (default: the wave-autonomous kernels w16x16 / w25x8 where they exist), 1 force the generic
+ *               any-N kernel, 2 the workgroup-tile kernels of round 1 (r16x16 / r25x8 / r16x16x4)
+ *   "wave_grid" -1 (default) persistent grid when a launch holds >= 4 rounds of resident waves, 0 one tile per wave, 1 persistent
+ *   "wave_variant" 2 (default) / 0 / 1: operand prefetch variants of the persistent loop (A/B)
+ *   "gabor_lds" 0 (default) the gabor kernel reads the mel matrix through L1/L2, 1 it stages the item's matrix in LDS first
+ *               (where it fits 60 KB); measured on the MI355X: 9.4 vs 11.9 us per 256 items in float64, so off by default
  *   "xcd_remap" 1 (default) workgroups that share an XCD take one contiguous run of tiles (L2 reuse of the
  *               samples neighbouring tiles share), 0 tiles in workgroup-id order
+ *   the "r16_*" switches are variants of the round-1 N = 512 tile kernel; setting one selects that kernel
  *   "r16_input" 0 operands straight from global memory (default), 1 staged through LDS
  *   "r16_tiles" 1 (default) or 2 sixteen-frame tiles per workgroup, the second one's operands prefetched
  *   "r16_mel"   0 mel triangles on the vector pipe (default), 1 as a banded filter x bin GEMM on the matrix
