@@ -49,6 +49,8 @@ struct aud_plan {
     aud::FastArgs wv{};
     int* d_grp = nullptr;  // [17 + nf + 3 nf]: group offsets, filter ids, per-filter chunk info
     void* d_w4 = nullptr;  // chunked triangle weights
+    unsigned* d_queue = nullptr;  // wave kernels, dynamic grid: ring of 64 x 128-byte queue slots, one per launch in flight
+    unsigned launch_seq = 0;
     void* d_blob = nullptr;   // wave kernels: every read-only table, laid out like its LDS copy (kernels.h FastArgs)
     int* d_blk = nullptr;     // matrix-pipe mel variant (r16x16, float32): per 16-filter block {chunk0, steps, offset}
     float* d_atab = nullptr;  // ... and its lane-ordered A operands [steps][64]
@@ -300,7 +302,10 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
         (void)hipGetLastError();
         return AUD_OK;
     }
-    const int rc = upload(c, &p->d_blob, blob.data(), blob.size());
+    int rc = upload(c, &p->d_blob, blob.data(), blob.size());
+    if (rc != AUD_OK) return rc;
+    std::vector<unsigned> zeros(64 * 32, 0u);
+    rc = upload(c, reinterpret_cast<void**>(&p->d_queue), zeros.data(), zeros.size() * sizeof(unsigned));
     if (rc != AUD_OK) return rc;
     e.blob = p->d_blob;
     p->wv = e;
@@ -588,6 +593,7 @@ int aud_plan_destroy(aud_plan* p) {
     if (p->d_grp) (void)hipFree(p->d_grp);
     if (p->d_w4) (void)hipFree(p->d_w4);
     if (p->d_blob) (void)hipFree(p->d_blob);
+    if (p->d_queue) (void)hipFree(p->d_queue);
     if (p->d_blk) (void)hipFree(p->d_blk);
     if (p->d_atab) (void)hipFree(p->d_atab);
     delete p;
@@ -644,7 +650,17 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
     }
     if (key == "wave_grid") {  // -1 (default): by launch size; 0: one wave tile per wave; 1: persistent grid of resident workgroups
         if (p->wave_kind == aud_plan::kNoWave) return fail(c, AUD_EINVAL, "plan has no wave kernel");
-        if (value < -1 || value > 1) return fail(c, AUD_EINVAL, "wave_grid: -1, 0 or 1");
+        if (value < -1 || value > 2) return fail(c, AUD_EINVAL, "wave_grid: -1, 0, 1 or 2");
+        if (value == 2) {  // the dynamic variant's attributes
+            aud::FastArgs cfg = p->wv;
+            cfg.variant = 3;
+            AUD_HIP(c, make_current(c));
+            if (aud::melspec_wave_prepare(p->wave_kind == aud_plan::kW16 ? 1 : 2, p->d.compute_dtype, &cfg) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(c, AUD_EHIP, "wave_grid: the runtime refused the kernel attributes");
+            }
+            p->wv.max_wgs = cfg.max_wgs;
+        }
         p->wv.persistent = value;
         return AUD_OK;
     }
@@ -700,6 +716,9 @@ int aud_melspec_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
     a.mel = mel;
     a.power = power;
     a.log_power = log_power;
+    // dynamic grid: every launch takes the next slot of the queue ring (launches of one plan may overlap on several
+    // streams; a captured launch keeps its slot, and replays of one graph are ordered)
+    a.queue = p->d_queue ? p->d_queue + 32 * (p->launch_seq++ & 63u) : nullptr;
     AUD_HIP(c, launch_frames(p, a, static_cast<hipStream_t>(stream)));
     if (smooth) {
         // dft.go:67-69: p_s = Prev*p_{s-1} + Cur*raw_s along the steps, then log-power and mel from it

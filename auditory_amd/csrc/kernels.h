@@ -56,6 +56,10 @@ struct MelspecArgs {
     // diagnostic builds only (-DAUD_STAMPS, tools/stamp_profile.py): [waves][16] s_memtime stamps of the wave
     // kernels' phases.  Never read by anything that computes an output.
     unsigned long long* stamps;
+    // persistent wave kernels with a dynamic tile queue (plan option "wave_grid" = 2): one slot of the plan's ring,
+    // queue[0] = tiles handed out beyond the first one of every wave, queue[16] = waves that have left; both are zero
+    // when a launch starts and the last wave to leave zeroes them again
+    unsigned* queue;
 };
 
 #ifdef AUD_STAMPS

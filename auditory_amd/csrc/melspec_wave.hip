@@ -92,7 +92,7 @@ template <typename TT, bool PCM16, int MAXS, int MODE>
 __device__ __forceinline__ void w16_tile(const MelspecArgs& a, const FastArgs& e, unsigned char* smem, TT* xw,
                                          const C2<TT>* twa, const C2<TT>* tws, int lane_in, int tiles, int64_t wt,
                                          int64_t wt_next, int64_t total, FrameRaw<16>& raw, aud_item& it, int& item,
-                                         int& t0) {
+                                         int& t0, unsigned* queue_fetch = nullptr) {
     using L = w16::Layout<TT>;
     // the lane id is made opaque per tile: otherwise the compiler hoists what only depends on it out of the tile loop
     int lane = lane_in;
@@ -112,6 +112,11 @@ __device__ __forceinline__ void w16_tile(const MelspecArgs& a, const FastArgs& e
     }
     const int item_cur = item, t0_cur = t0;
     const aud_item it_cur = it;
+    if (queue_fetch) {  // dynamic grid: ask for the next tile now, the answer is read after this tile's arithmetic
+        unsigned got = 0;
+        if (lane == 0) got = atomicAdd(a.queue, 1u);
+        *queue_fetch = got;
+    }
     if constexpr (MODE == 0) {
         if (wt_next < total) {  // the next tile's operands land while this tile is computed
             item = int(wt_next / tiles);
@@ -251,7 +256,27 @@ __global__ __launch_bounds__(64 * NW, VAR == 1 ? (sizeof(TT) == 8 ? 3 : 5) : 1) 
     const C2<TT>* twa = reinterpret_cast<const C2<TT>*>(smem + e.twa_off);  // W_512^(2 j k1) at [(k1 - 1) 16 + j]
     const C2<TT>* tws = reinterpret_cast<const C2<TT>*>(smem + e.tws_off);  // W_512^k, k <= 128
 
-    if constexpr (VAR == 2) {
+    if constexpr (VAR == 3) {
+        // dynamic tile queue: the first tile of every wave is static (its operands are already in flight), further
+        // tiles are handed out by one returning atomic each, requested a tile ahead.  The last wave to leave resets
+        // the slot for the next launch.
+        const unsigned grid_waves = gridDim.x * NW;
+        bool first = true;
+        while (wt < total) {
+            unsigned nxt = 0;
+            if (first) w16_tile<TT, PCM16, MAXS, 1>(a, e, smem, xw, twa, tws, lane, tiles, wt, wt, total, raw, it, item, t0, &nxt);
+            else w16_tile<TT, PCM16, MAXS, 2>(a, e, smem, xw, twa, tws, lane, tiles, wt, wt, total, raw, it, item, t0, &nxt);
+            first = false;
+            wt = int64_t(grid_waves) + unsigned(__builtin_amdgcn_readfirstlane(int(nxt)));
+        }
+        if (lane == 0) {
+            const unsigned left = atomicAdd(a.queue + 16, 1u);
+            if (left == grid_waves - 1) {  // every other wave has left: nobody touches the slot any more
+                atomicExch(a.queue, 0u);
+                atomicExch(a.queue + 16, 0u);
+            }
+        }
+    } else if constexpr (VAR == 2) {
         if (wt < total) {
             w16_tile<TT, PCM16, MAXS, 1>(a, e, smem, xw, twa, tws, lane, tiles, wt, wt + stride, total, raw, it, item, t0);
             wt += stride;
@@ -327,7 +352,7 @@ template <typename TT, bool PCM16, int MAXS, int MODE>
 __device__ __forceinline__ void w25_tile(const MelspecArgs& a, const FastArgs& e, unsigned char* smem, TT* xw,
                                          const C2<TT>* twa, const C2<TT>* tws, int lane_in, int tiles, int64_t wt,
                                          int64_t wt_next, int64_t total, FrameRaw<25>& raw, aud_item& it, int& item,
-                                         int& t0) {
+                                         int& t0, unsigned* queue_fetch = nullptr) {
     using L = w25::Layout<TT>;
     int lane = lane_in;  // opaque per tile (see w16_tile)
     asm volatile("" : "+v"(lane));
@@ -347,6 +372,11 @@ __device__ __forceinline__ void w25_tile(const MelspecArgs& a, const FastArgs& e
     }
     const int item_cur = item, t0_cur = t0;
     const aud_item it_cur = it;
+    if (queue_fetch) {  // dynamic grid: ask for the next tile now, the answer is read after this tile's arithmetic
+        unsigned got = 0;
+        if (lane == 0) got = atomicAdd(a.queue, 1u);
+        *queue_fetch = got;
+    }
     if constexpr (MODE == 0) {
         if (wt_next < total) {  // the next tile's operands land while this tile is computed
             item = int(wt_next / tiles);
@@ -471,7 +501,24 @@ __global__ __launch_bounds__(64 * NW, sizeof(TT) == 8 ? 2 : (VAR == 1 ? 3 : 2)) 
     const C2<TT>* twa = reinterpret_cast<const C2<TT>*>(smem + e.twa_off);  // W_400^(2 j k1) at [(k1 - 1) 8 + j]
     const C2<TT>* tws = reinterpret_cast<const C2<TT>*>(smem + e.tws_off);  // W_400^k, k <= 100
 
-    if constexpr (VAR == 2) {
+    if constexpr (VAR == 3) {  // dynamic tile queue, as k_melspec_w16
+        const unsigned grid_waves = gridDim.x * NW;
+        bool first = true;
+        while (wt < total) {
+            unsigned nxt = 0;
+            if (first) w25_tile<TT, PCM16, MAXS, 1>(a, e, smem, xw, twa, tws, lane, tiles, wt, wt, total, raw, it, item, t0, &nxt);
+            else w25_tile<TT, PCM16, MAXS, 2>(a, e, smem, xw, twa, tws, lane, tiles, wt, wt, total, raw, it, item, t0, &nxt);
+            first = false;
+            wt = int64_t(grid_waves) + unsigned(__builtin_amdgcn_readfirstlane(int(nxt)));
+        }
+        if (lane == 0) {
+            const unsigned left = atomicAdd(a.queue + 16, 1u);
+            if (left == grid_waves - 1) {  // every other wave has left: nobody touches the slot any more
+                atomicExch(a.queue, 0u);
+                atomicExch(a.queue + 16, 0u);
+            }
+        }
+    } else if constexpr (VAR == 2) {
         if (wt < total) {
             w25_tile<TT, PCM16, MAXS, 1>(a, e, smem, xw, twa, tws, lane, tiles, wt, wt + stride, total, raw, it, item, t0);
             wt += stride;
@@ -531,13 +578,14 @@ typedef void (*wave_kernel_t)(const MelspecArgs, const FastArgs);
 static wave_kernel_t wave_kernel(int kind, bool f64, int n_slots, int var) {
     const bool s8 = n_slots > 4;
     if (kind == 1) {
-#define AUD_W16(TT, S) (var == 1 ? k_melspec_w16<TT, true, 4, S, 1> : var == 2 ? k_melspec_w16<TT, true, 4, S, 2> : k_melspec_w16<TT, true, 4, S, 0>)
+#define AUD_W16(TT, S) (var == 1 ? k_melspec_w16<TT, true, 4, S, 1> : var == 2 ? k_melspec_w16<TT, true, 4, S, 2> : var == 3 ? k_melspec_w16<TT, true, 4, S, 3> : k_melspec_w16<TT, true, 4, S, 0>)
         if (f64) return s8 ? AUD_W16(double, 8) : AUD_W16(double, 4);
         return s8 ? AUD_W16(float, 8) : AUD_W16(float, 4);
 #undef AUD_W16
     }
-    if (f64) return s8 ? k_melspec_w25<double, true, 4, 8, 2> : k_melspec_w25<double, true, 4, 4, 2>;
-#define AUD_W25(S) (var == 1 ? k_melspec_w25<float, true, 4, S, 1> : var == 2 ? k_melspec_w25<float, true, 4, S, 2> : k_melspec_w25<float, true, 4, S, 0>)
+    if (f64) return var == 3 ? (s8 ? k_melspec_w25<double, true, 4, 8, 3> : k_melspec_w25<double, true, 4, 4, 3>)
+                             : (s8 ? k_melspec_w25<double, true, 4, 8, 2> : k_melspec_w25<double, true, 4, 4, 2>);
+#define AUD_W25(S) (var == 1 ? k_melspec_w25<float, true, 4, S, 1> : var == 2 ? k_melspec_w25<float, true, 4, S, 2> : var == 3 ? k_melspec_w25<float, true, 4, S, 3> : k_melspec_w25<float, true, 4, S, 0>)
     return s8 ? AUD_W25(8) : AUD_W25(4);
 #undef AUD_W25
 }
@@ -568,10 +616,12 @@ hipError_t launch_melspec_wave(int kind, const MelspecArgs& a, const FastArgs& e
     int64_t wgs = (waves + nw - 1) / nw;
     // persistent grid (every wave walks tiles wt, wt + stride, ...): measured to pay once a launch holds several rounds
     // of resident waves (profiles/r02i_ab_*: B = 4096 12-15 % faster, B = 256 up to 20 % slower: static tile assignment)
-    const bool persistent = e.persistent == 1 || (e.persistent < 0 && wgs >= 4 * int64_t(e.max_wgs));
+    const bool dynamic = e.persistent == 2 && a.queue != nullptr;  // persistent grid + dynamic tile queue
+    const bool persistent = dynamic || e.persistent == 1 || (e.persistent < 0 && wgs >= 4 * int64_t(e.max_wgs));
     if (persistent && e.max_wgs > 0 && wgs > e.max_wgs) wgs = e.max_wgs;
     const dim3 grid{unsigned(wgs)}, blk(64 * nw);
-    hipLaunchKernelGGL(wave_kernel(kind, compute_dtype == AUD_F64, e.n_slots, e.variant), grid, blk, e.lds_bytes, st, a, e);
+    hipLaunchKernelGGL(wave_kernel(kind, compute_dtype == AUD_F64, e.n_slots, dynamic ? 3 : e.variant), grid, blk, e.lds_bytes, st,
+                       a, e);
     return hipGetLastError();
 }
 

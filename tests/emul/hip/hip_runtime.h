@@ -43,8 +43,9 @@ struct alignas(8) uint2 {
 struct alignas(16) uint4 {
     unsigned x, y, z, w;
 };
-inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
-inline void __builtin_amdgcn_sched_barrier(int) {}  // callers pass wave-uniform values
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
+inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_ACQ_REL); }  // callers pass wave-uniform values
 
 
 typedef int hipError_t;
@@ -104,6 +105,8 @@ inline T emul_shfl_any(T v, int src_lane) {
     return out;
 }
 inline int emul_lane() { return int(threadIdx.x & 63u); }
+// the first lane's value for the whole wave (every lane of the wave calls it)
+inline int __builtin_amdgcn_readfirstlane(int v) { return emul_shfl_any(v, emul_lane() & ~63); }
 template <typename T>
 inline T __shfl(T v, int src, int width = 64) {
     const int lane = emul_lane();

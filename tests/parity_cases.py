@@ -533,7 +533,8 @@ def case_prev_smooth(orc, name, cdt):
 
 
 # the kernel variants a 512-sample plan can run: all must agree with the oracle (and each other)
-N512_VARIANTS = {"w16_default": {}, "w16_persistent": {"wave_grid": 1}, "w16_persistent_prefetch": {"wave_grid": 1, "wave_variant": 0},
+N512_VARIANTS = {"w16_default": {}, "w16_persistent": {"wave_grid": 1}, "w16_dynamic_queue": {"wave_grid": 2},
+                 "w16_persistent_prefetch": {"wave_grid": 1, "wave_variant": 0},
                  "w16_persistent_prefetch_capped": {"wave_grid": 1, "wave_variant": 1},
                  "r16_tile_kernel": {"kernel": 2},
                  "r16_direct": {"r16_input": 0}, "r16_direct_2tiles": {"r16_input": 0, "r16_tiles": 2},
@@ -627,7 +628,7 @@ def case_n400_variants(orc, cdt, seg_ms=None, dur=1.0, rows=2, segs=(0,)):
         fam = _fast_family(orc, name, cdt, seg_ms)
         assert fam == "w25x8"
         # wave-autonomous (its three persistent variants), workgroup-tile (r25x8), generic
-        for opts in ({}, {"wave_grid": 1}, {"wave_grid": 1, "wave_variant": 0}, {"wave_grid": 1, "wave_variant": 1},
+        for opts in ({}, {"wave_grid": 1}, {"wave_grid": 2}, {"wave_grid": 1, "wave_variant": 0}, {"wave_grid": 1, "wave_variant": 1},
                      {"kernel": 2}, {"kernel": 1}):
             case_melspec_vs_oracle(orc, (name, dur, rows, list(segs)), cdt, seg_ms=seg_ms, options=opts)
 
