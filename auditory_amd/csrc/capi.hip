@@ -9,6 +9,7 @@
 #include <climits>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -18,6 +19,7 @@ struct aud_ctx {
     int device = -1;
     std::string err = "";
     hipStream_t stream = nullptr;  // used by the _host entry points
+    std::mutex host_mutex;         // ... which serialise on it (HostCallGuard)
     // grow-only device workspaces for the _host entry points
     void* ws[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t ws_cap[4] = {0, 0, 0, 0};
@@ -80,6 +82,18 @@ int fail(aud_ctx* c, int code, const std::string& msg) {
 int hip_fail(aud_ctx* c, hipError_t e, const char* what) {
     return fail(c, AUD_EHIP, std::string(what) + ": " + hipGetErrorString(e));
 }
+
+// Host entry points queue asynchronous copies from / to caller-owned (pageable) memory on the context's stream: on EVERY
+// exit behind the first such copy the stream is drained, so the caller may free or reuse its buffers whatever the status.
+// They also serialise on the context: its workspaces and stream are shared state (two goroutines on one aud_ctx).
+struct HostCallGuard {
+    aud_ctx* c;
+    explicit HostCallGuard(aud_ctx* ctx) : c(ctx) { c->host_mutex.lock(); }
+    ~HostCallGuard() {
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        c->host_mutex.unlock();
+    }
+};
 
 #define AUD_HIP(c, call)                                   \
     do {                                                   \
@@ -623,6 +637,13 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
                                         p->d.mel.n_filters, value == 0, &cfg))
             return fail(c, AUD_EINVAL, "this r16x16 variant does not support the plan (odd step?)");
         cfg.ntile = value == 0 ? p->r16.ntile : 1;
+        if (cfg.lds_bytes > 64u * 1024u && cfg.lds_bytes > p->r16.lds_bytes) {  // the staged float64 variant: ~93 KB
+            AUD_HIP(c, make_current(c));
+            if (aud::melspec_r16_prepare(cfg.lds_bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(c, AUD_EHIP, "r16_input: the runtime refused the LDS size of this variant");
+            }
+        }
         p->r16 = cfg;
         select_tile_kernel(p);
         return AUD_OK;
@@ -857,6 +878,7 @@ int aud_melspec_batch_host(aud_plan* p, const double* sig, int64_t sig_total, co
         if (items[i].sig_off < 0 || items[i].sig_len < 0 || items[i].sig_stride < 0 || item_last(items[i]) >= sig_total)
             return fail(c, AUD_EINVAL, "item outside the signal buffer");
     AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
     const int nf = p->d.mel.n_filters, T = p->d.segment_steps, H = p->H;
     const size_t n_mel = size_t(n_items) * nf * T, n_pow = size_t(n_items) * H * T;
     const size_t sig_bytes = size_t(sig_total) * 8, item_bytes = size_t(n_items) * sizeof(aud_item);
@@ -908,6 +930,7 @@ int aud_dft_filter_host(aud_plan* p, int step, const double* window, double* pow
     const int N = p->d.win_samples, T = p->d.segment_steps, H = p->H, nf = p->d.mel.n_filters;
     if (!window || !power || !power_seg || step < 0 || step >= T) return fail(c, AUD_EINVAL, "bad argument");
     AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
     // the window becomes a one-frame stream: frame 0 of the item covers [0, N), every later frame is dead
     const aud_item it{0, N, p->d.step_samples * p->d.border_steps};
     const size_t n_mel = size_t(nf) * T, n_pow = size_t(H) * T;
@@ -957,6 +980,7 @@ int aud_dft_power_host(aud_plan* p, int step, const double* fft_coefs, double* p
     const int T = p->d.segment_steps, H = p->H;
     if (!fft_coefs || !power || !power_seg || step < 0 || step >= T) return fail(c, AUD_EINVAL, "bad argument");
     AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
     int rc;
     if ((rc = ensure_ws(c, 0, size_t(H) * 16 + 16)) != AUD_OK) return rc;
     if ((rc = ensure_ws(c, 1, size_t(H) * 8 * 3 + size_t(H) * 4 + 16)) != AUD_OK) return rc;
@@ -992,6 +1016,7 @@ int aud_cepstrum_dct_host(aud_plan* p, int step, const double* fbank, double* mf
     if (nc < 1 || !p->d_dct) return fail(c, AUD_EINVAL, "plan was created without mfcc_coefs");
     if (!fbank || !mfcc_seg || step < 0 || step >= T) return fail(c, AUD_EINVAL, "bad argument");
     AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
     int rc;
     if ((rc = ensure_ws(c, 1, sizeof(aud_item))) != AUD_OK) return rc;
     if ((rc = ensure_ws(c, 2, size_t(nf + nc) * 4 + 16)) != AUD_OK) return rc;
@@ -1032,6 +1057,7 @@ int aud_mel_filter_dft_host(aud_plan* p, int step, const double* power, double* 
     const int N = p->d.win_samples, T = p->d.segment_steps, H = p->H, nf = p->d.mel.n_filters;
     if (!power || !segment || step < 0 || step >= T) return fail(c, AUD_EINVAL, "bad argument");
     AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
     const aud_item it{0, N, p->d.step_samples * p->d.border_steps};  // only column 0 is live
     const size_t n_mel = size_t(nf) * T, n_pow = size_t(H) * T;
     int rc;
@@ -1076,6 +1102,7 @@ int aud_melspec_mfcc_batch_host(aud_plan* p, const double* sig, int64_t sig_tota
         if (items[i].sig_off < 0 || items[i].sig_len < 0 || items[i].sig_stride < 0 || item_last(items[i]) >= sig_total)
             return fail(c, AUD_EINVAL, "item outside the signal buffer");
     AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
     const int nf = p->d.mel.n_filters, T = p->d.segment_steps, H = p->H, nc = p->d.mfcc_coefs;
     const size_t n_mel = size_t(n_items) * nf * T, n_pow = size_t(n_items) * H * T;
     const size_t n_cc = size_t(n_items) * nc * T, n_en = size_t(n_items) * T;
@@ -1131,6 +1158,7 @@ int aud_gabor_batch_host(aud_plan* p, const double* mel, int n_items, int rows, 
     if (n_items == 0) return AUD_OK;
     if (!mel || !out) return fail(c, AUD_EINVAL, "null buffer");
     AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
     size_t out_cells = 1;
     for (int i = 0; i < out_rank; ++i) out_cells *= size_t(out_shape[i] > 0 ? out_shape[i] : 0);
     const size_t n_mel = size_t(n_items) * rows * cols, n_out = size_t(n_items) * out_cells;
@@ -1283,6 +1311,7 @@ int aud_kwta_batch_host(aud_ctx* c, const aud_kwta_params* k, const float* raw, 
     if (total == 0) return AUD_OK;
     if (!raw || !act) return fail(c, AUD_EINVAL, "null buffer");
     AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
     const size_t n_state = (pool_level && pool_state) ? size_t(n_items) * d0 * d1 * 2 : 0;
     int rc;
     if ((rc = ensure_ws(c, 2, total * 4)) != AUD_OK) return rc;

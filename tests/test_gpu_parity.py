@@ -230,31 +230,29 @@ def test_process_then_kwta_device_resident(orc, torch_cuda, n=6):
     plan.close()
 
 
-def test_full_size_properties_cfg2(orc, torch_cuda, B=256):
-    """BASELINE config #2 at full size (B=256 x 1 s @16 kHz, N=512, 40 mel) through
-    size-independent properties; the oracle only spot-checks 4 utterances."""
-    torch = torch_cuda
+def _full_size_properties(orc, torch, name, B, dur, cdt, spot_step, parseval_steps, gain_tol):
+    """A BASELINE batch at full size through size-independent properties; the oracle only spot-checks a few streams."""
     from auditory_amd.batch import BatchProcessor
-    oc = W.OracleCfg(orc, "cfg2_16k_n512_nf40")
+    oc = W.OracleCfg(orc, name)
     L = oc.full_len()
     Lp = (L + 63) // 64 * 64
-    sig, _ = synth.batch(2, B, 16000, oc.sr, row_len=Lp)
-    plan = W.product_plan(oc)
+    sig, _ = synth.batch(2, B, dur, oc.sr, row_len=Lp)
+    plan = W.product_plan(oc, cdt)
     bp = BatchProcessor(plan, "cuda:0")
     dsig = torch.from_numpy(sig.astype(np.float32)).cuda().view(-1)
     items = bp.upload_items(runtime.make_items(np.arange(B) * Lp, [Lp] * B, [0] * B))
     power = torch.empty((B, oc.H, oc.T), dtype=torch.float32, device=dsig.device)
     mel = bp.melspec(dsig, items, B, power=power).cpu().numpy()
     pw = power.cpu().numpy().astype(np.float64)
-    # (a) spot parity on 16 utterances spread over the batch
-    idx = sorted(set(list(range(0, B, 17)) + [B - 1]))
-    ref = np.stack([orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig[i])["mel_seg"] for i in idx])
-    ok, msg = W.feature_close(mel[idx], ref, capi.AUD_F32, lin_axis=1)
+    x32 = sig.astype(np.float32).astype(np.float64)     # what the device saw
+    # (a) spot parity on streams spread over the batch
+    idx = sorted(set(list(range(0, B, spot_step)) + [B - 1]))
+    ref = np.stack([orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, x32[i])["mel_seg"] for i in idx])
+    ok, msg = W.feature_close(mel[idx], ref, cdt, lin_axis=1)
     assert ok, msg
     # (b) Parseval on every frame: sum_k c_k P[k] = N * sum x^2
     c = np.full(oc.H, 2.0); c[0] = c[-1] = 1.0
-    x32 = sig.astype(np.float32).astype(np.float64)
-    for s in (0, 1, 2, 50, 103):
+    for s in parseval_steps:
         st = oc.S * (s - 2)
         fr = np.zeros((B, oc.N))
         a = max(st, 0)
@@ -265,19 +263,39 @@ def test_full_size_properties_cfg2(orc, torch_cuda, B=256):
     # (c) batch-position invariance: reversed item order gives the reversed result, bit for bit
     items_r = bp.upload_items(runtime.make_items(np.arange(B)[::-1] * Lp, [Lp] * B, [0] * B))
     mel_r = bp.melspec(dsig, items_r, B).cpu().numpy()
-    assert np.array_equal(mel_r[::-1], mel)
+    assert np.array_equal(mel_r[::-1], mel, equal_nan=True)
     # (d) time shift: start0 = +S moves every column one step left
     items_s = bp.upload_items(runtime.make_items(np.arange(B) * Lp, [Lp] * B, [oc.S] * B))
     mel_s = bp.melspec(dsig, items_s, B).cpu().numpy()
-    assert np.array_equal(mel_s[:, :, :-1], mel[:, :, 1:])
-    assert np.all(mel_s[:, :, -1] == 0)                 # last frame now runs off the end
+    assert np.array_equal(mel_s[:, :, :-1], mel[:, :, 1:], equal_nan=True)
+    fin = ~np.isnan(mel_s[:, :, -1])
+    assert np.all(mel_s[:, :, -1][fin] == 0)            # last frame now runs off the end
     # (e) gain: 2x input -> power x4 exactly (power of two), mel + ln 4
     mel2 = bp.melspec(dsig * 2.0, items, B).cpu().numpy()
-    silent = mel == -10.0                               # frames inside the zero tail: power exactly 0 -> LogMin (Q2)
-    assert silent.any() and np.array_equal(mel2[silent], mel[silent])
-    assert np.abs(mel2 - (mel + np.log(4.0)))[~silent].max() <= 2e-6 * np.abs(mel).max() + 1e-6
+    ok_cells = ~np.isnan(mel)
+    silent = ok_cells & (mel == -10.0)                  # frames inside the zero tail: power exactly 0 -> LogMin (Q2)
+    assert np.array_equal(mel2[silent], mel[silent])
+    live = ok_cells & ~silent
+    assert np.abs(mel2 - (mel + np.log(4.0)))[live].max() <= gain_tol * np.abs(mel[live]).max() + 1e-6
     plan.close()
+    return mel
 
+
+def test_full_size_properties_cfg2(orc, torch_cuda, B=256):
+    """BASELINE configs[1] at full size (B = 256 x 1 s @16 kHz, N = 512, 40 mel), float32 plan"""
+    mel = _full_size_properties(orc, torch_cuda, "cfg2_16k_n512_nf40", B, 16000, capi.AUD_F32, 17, (0, 1, 2, 50, 103), 2e-6)
+    assert (mel == -10.0).any()
+
+
+def test_full_size_properties_metric_config_f64(orc, torch_cuda, B=256):
+    """the metric's own parameter set (N = 400) at full size, float64 plan: what bench.py's headline runs"""
+    _full_size_properties(orc, torch_cuda, "cfg2_16k_n400_nf40", B, 16000, capi.AUD_F64, 17, (0, 1, 2, 50, 103), 1e-6)
+
+
+def test_full_size_properties_cfg5(orc, torch_cuda, B=96):
+    """BASELINE configs[4] (44.1 kHz, 5 s streams, N = 2048, 128 mel with its NaN row) at 96 streams = 85 MB of input"""
+    mel = _full_size_properties(orc, torch_cuda, "cfg5_44k_n2048_nf128", B, 5 * 44100, capi.AUD_F64, 31, (0, 2, 250, 503), 1e-6)
+    assert np.isnan(mel[:, 0, :]).all()                 # filter 0 is a degenerate triangle (Q3)
 
 
 def test_rccl_allgather_single_rank(torch_cuda):
