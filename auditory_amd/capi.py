@@ -107,6 +107,7 @@ SYMBOLS = {
     "aud_plan_destroy": (C.c_int, [_VP]),
     "aud_plan_kernel_name": (C.c_char_p, [_VP]),
     "aud_plan_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int]),
+    "aud_plan_get_info": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int64)]),
     "aud_melspec_batch_dev": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, _VP, _VP, _VP, _VP]),
     "aud_mfcc_batch_dev": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "aud_melspec_mfcc_batch_host": (C.c_int, [_VP, _VP, C.c_int64, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

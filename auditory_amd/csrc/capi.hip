@@ -45,7 +45,9 @@ struct aud_plan {
     int r16_chunks = 0;
     aud::FastArgs r16{};
     // wave-autonomous kernel of the same window length (melspec_wave.hip), the default where it exists
-    enum Wave { kNoWave = 0, kW16 = 1, kW25 = 2 };
+    enum Wave { kNoWave = 0, kW16 = 1, kW25 = 2, kW20 = 3 };  // = the kind number of melspec_wave.hip
+    std::vector<int32_t> h_bin_pts;   // host copies of the mel table: a change of wave geometry rebuilds the blob
+    std::vector<double> h_mel_filters;
     int wave_kind = kNoWave;
     bool use_wave = false;     // false: the workgroup-tile kernel of fast_kind (plan option "kernel" = 2)
     aud::FastArgs wv{};
@@ -190,10 +192,8 @@ void fill_melspec_args(const aud_plan* p, aud::MelspecArgs* a) {
 
 // the plan's frame -> power -> mel kernel (whatever family it selected), raw power, no smoothing
 hipError_t launch_frames(const aud_plan* p, const aud::MelspecArgs& a, hipStream_t st) {
-    if (p->use_fast && p->use_wave && p->wave_kind == aud_plan::kW16)
-        return aud::launch_melspec_wave(1, a, p->wv, p->d.compute_dtype, st);
-    if (p->use_fast && p->use_wave && p->wave_kind == aud_plan::kW25)
-        return aud::launch_melspec_wave(2, a, p->wv, p->d.compute_dtype, st);
+    if (p->use_fast && p->use_wave && p->wave_kind != aud_plan::kNoWave)
+        return aud::launch_melspec_wave(p->wave_kind, a, p->wv, p->d.compute_dtype, st);
     if (p->use_fast && p->fast_kind == aud_plan::kR16) return aud::launch_melspec_r16(a, p->r16, p->d.compute_dtype, st);
     if (p->use_fast && p->fast_kind == aud_plan::kR25) return aud::launch_melspec_r25(a, p->r16, p->d.compute_dtype, st);
     if (p->use_fast && p->fast_kind == aud_plan::kR1024)
@@ -204,78 +204,58 @@ hipError_t launch_frames(const aud_plan* p, const aud::MelspecArgs& a, hipStream
 const char* plan_family(const aud_plan* p);
 
 // Tables of the wave-autonomous kernels (melspec_wave.hip) as one blob that is copied verbatim into LDS:
-//   w4     the mel triangles as aligned 4-bin chunks (zero weights outside [lo, hi]) + one all-zero chunk
-//   steps  per filter group a flat, padded list of chunk steps {P chunk, w4 chunk, slot, first / last of its filter};
-//          groups are balanced by step count (longest filter first), so every lane runs the same number of steps
-//   slots  per group the filter id of each slot
+//   w4     per filter group one row of weights: the group's filters (its slots) one after the other, each as aligned
+//          4-bin chunks (zero weights outside [lo, hi]), slot k padded to slot_steps[k] chunks in every group
+//   slots  per group and slot: the filter's first P chunk and its id
 //   twa    pass twiddles W_N^(2 j k1), [k1 - 1][j]; tws: split twiddles W_N^k, k <= N/4
 // A plan whose tables do not fit (16-bit indices, LDS) simply has no wave kernel.
-int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_filters) {
+int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_filters, int force_kind = 0) {
     aud_ctx* c = p->ctx;
     const aud_plan_desc& d = p->d;
     const int N = d.win_samples, nf = d.mel.n_filters, dt = d.compute_dtype;
-    const int kind = p->fast_kind == aud_plan::kR16 ? 1 : p->fast_kind == aud_plan::kR25 ? 2 : 0;
+    // N = 512 -> w16x16; N = 400 -> w20x10 (default) or w25x8 (plan option "n400_geometry" = 25)
+    const int kind = force_kind ? force_kind : p->fast_kind == aud_plan::kR16 ? 1 : p->fast_kind == aud_plan::kR25 ? 3 : 0;
     aud::WaveGeometry g;
     if (!kind || !aud::melspec_wave_geometry(kind, N, &g)) return AUD_OK;
     const size_t tsz = dt == AUD_F64 ? 8 : 4;
-    // chunks per filter
-    std::vector<int> c0(nf), nc(nf), wo(nf);
-    std::vector<double> w4;
+    const int G = g.n_groups, p_chunks = (N / 2 + 1 + 3) / 4;  // chunks of a padded power row (kHp / 4 of the kernel)
+    if (nf >= 0xFFFF || nf > 8 * G) return AUD_OK;  // more than eight filters per group: no wave kernel
+    // chunks per filter; a filter without taps still takes one (all-zero) step: its sum is 0 + LogOff
+    std::vector<int> c0(nf), nc(nf), order(nf);
     for (int f = 0; f < nf; ++f) {
         const int lo = bin_pts[f], hi = bin_pts[f + 2];
-        c0[f] = lo >> 2;
-        nc[f] = hi >= lo ? (hi >> 2) - (lo >> 2) + 1 : 0;
-        wo[f] = int(w4.size() / 4);
-        for (int ci = 0; ci < nc[f]; ++ci)
-            for (int el = 0; el < 4; ++el) {
-                const int bin = 4 * (c0[f] + ci) + el;
-                w4.push_back(bin >= lo && bin <= hi ? mel_filters[int64_t(f) * (nf + 2) + (bin - lo)] : 0.0);
-            }
+        c0[f] = hi >= lo ? lo >> 2 : 0;
+        nc[f] = hi >= lo ? (hi >> 2) - (lo >> 2) + 1 : 1;
+        if (c0[f] + nc[f] > p_chunks) return AUD_OK;  // table reaches past the spectrum: the generic path reports it
+        order[f] = f;
     }
-    const int zero_chunk = int(w4.size() / 4);
-    w4.insert(w4.end(), 4, 0.0);
-    if (zero_chunk >= 0xFFFF || nf >= 0xFFFF) return AUD_OK;
-    // groups balanced by step count (a filter without taps still takes one step: its sum is 0 + LogOff)
-    std::vector<int> order(nf), load(g.n_groups, 0), cnt(g.n_groups, 0), owner(nf);
-    for (int f = 0; f < nf; ++f) order[f] = f;
-    auto steps_of = [&](int f) { return nc[f] > 0 ? nc[f] : 1; };
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return steps_of(x) > steps_of(y); });
-    for (int f : order) {
-        int best = -1;
-        for (int cnd = 0; cnd < g.n_groups; ++cnd)
-            if (cnt[cnd] < 16 && (best < 0 || load[cnd] < load[best])) best = cnd;
-        if (best < 0) return AUD_OK;  // more than 16 filters per group: no wave kernel
-        owner[f] = best;
-        load[best] += steps_of(f);
-        ++cnt[best];
+    // widest filters first, dealt round-robin: slot k of every group then holds filters of nearly equal width
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return nc[x] > nc[y]; });
+    const int n_slots = std::max(1, (nf + G - 1) / G);
+    aud::FastArgs e{};
+    int n_steps = 0;
+    std::vector<int> slot_pos(n_slots);
+    for (int k = 0; k < n_slots; ++k) {
+        int mx = 1;
+        for (int r = k * G; r < std::min(nf, (k + 1) * G); ++r) mx = std::max(mx, nc[order[r]]);
+        if (mx > 255) return AUD_OK;
+        e.slot_steps[k] = static_cast<unsigned char>(mx);
+        slot_pos[k] = n_steps;
+        n_steps += mx;
     }
-    int n_steps = 1, n_slots = 1;
-    for (int gi = 0; gi < g.n_groups; ++gi) {
-        n_steps = std::max(n_steps, load[gi]);
-        n_slots = std::max(n_slots, cnt[gi]);
-    }
-    n_steps = (n_steps + 3) & ~3;  // the step loop is unrolled by four
-    std::vector<uint32_t> steps(size_t(g.n_groups) * n_steps * 2);
-    std::vector<uint16_t> slots(size_t(g.n_groups) * n_slots, 0xFFFF);
-    for (int gi = 0; gi < g.n_groups; ++gi) {
-        int pos = 0, slot = 0;
-        for (int f = 0; f < nf; ++f) {  // ascending filter order inside a group
-            if (owner[f] != gi) continue;
-            slots[size_t(gi) * n_slots + slot] = uint16_t(f);
-            const int ns = steps_of(f);
-            for (int st = 0; st < ns; ++st, ++pos) {
-                uint32_t* r = &steps[(size_t(gi) * n_steps + pos) * 2];
-                const int pc = nc[f] > 0 ? c0[f] + st : 0, wi = nc[f] > 0 ? wo[f] + st : zero_chunk;
-                r[0] = uint32_t(pc) | (uint32_t(wi) << 16);
-                r[1] = uint32_t(slot) | (st == 0 ? 0x100u : 0u) | (st == ns - 1 ? 0x200u : 0u);
-            }
-            ++slot;
-        }
-        for (; pos < n_steps; ++pos) {  // padding: a step that restarts the running sum and belongs to no slot
-            uint32_t* r = &steps[(size_t(gi) * n_steps + pos) * 2];
-            r[0] = uint32_t(zero_chunk) << 16;
-            r[1] = 0xFFu | 0x100u;
-        }
+    // weight rows: row stride an odd number of 16-byte pieces, so that the groups' reads of one step spread over the banks
+    size_t w_stride = size_t(n_steps) * 4 * tsz;
+    if ((w_stride / 16) % 2 == 0) w_stride += 16;
+    std::vector<double> wrows(size_t(G) * (w_stride / tsz), 0.0);
+    std::vector<uint32_t> slots(size_t(G) * n_slots, 0xFFFFu << 16);
+    for (int r = 0; r < nf; ++r) {
+        const int f = order[r], k = r / G, gi = r % G, ns = e.slot_steps[k];
+        const int lo = bin_pts[f], hi = bin_pts[f + 2];
+        const int pc0 = std::min(c0[f], p_chunks - ns);  // every step of the slot reads inside the row
+        slots[size_t(gi) * n_slots + k] = uint32_t(pc0) | (uint32_t(f) << 16);
+        double* wr = &wrows[size_t(gi) * (w_stride / tsz) + size_t(slot_pos[k]) * 4];
+        if (hi >= lo)
+            for (int bin = lo; bin <= hi; ++bin) wr[bin - 4 * pc0] = mel_filters[int64_t(f) * (nf + 2) + (bin - lo)];
     }
     // twiddles, from the same long-double formula as the plan's W_N table
     const long double w = -2.0L * 3.14159265358979323846264338327950288L / (long double)N;
@@ -286,18 +266,16 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
     for (int k = 0; k < g.split_count; ++k) tw(k, &tws[size_t(k) * 2]);
     // the blob
     auto align32 = [](size_t v) { return (v + 31) & ~size_t(31); };
-    aud::FastArgs e{};
-    const size_t w4_bytes = align32(w4.size() * tsz);
+    const size_t w4_bytes = align32(wrows.size() * tsz);
     e.w4_off = 0;
-    e.n_chunks = zero_chunk + 1;
-    e.steps_off = int(w4_bytes);
+    e.w_stride = int(w_stride);
     e.n_steps = n_steps;
-    e.slots_off = int(e.steps_off + align32(steps.size() * 4));
+    e.slots_off = int(w4_bytes);
     e.n_slots = n_slots;
-    e.twa_off = int(e.slots_off + align32(slots.size() * 2));
+    e.twa_off = int(e.slots_off + align32(slots.size() * 4));
     e.tws_off = int(e.twa_off + align32(twa.size() * tsz));
     e.blob_bytes = int(e.tws_off + align32(tws.size() * tsz));
-    e.n_groups = g.n_groups;
+    e.n_groups = G;
     std::vector<unsigned char> blob(size_t(e.blob_bytes), 0);
     auto put_real = [&](size_t off, const std::vector<double>& v) {
         if (dt == AUD_F64) std::memcpy(&blob[off], v.data(), v.size() * 8);
@@ -306,9 +284,8 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
             std::memcpy(&blob[off], fv.data(), fv.size() * 4);
         }
     };
-    put_real(size_t(e.w4_off), w4);
-    std::memcpy(&blob[size_t(e.steps_off)], steps.data(), steps.size() * 4);
-    std::memcpy(&blob[size_t(e.slots_off)], slots.data(), slots.size() * 2);
+    put_real(size_t(e.w4_off), wrows);
+    std::memcpy(&blob[size_t(e.slots_off)], slots.data(), slots.size() * 4);
     put_real(size_t(e.twa_off), twa);
     put_real(size_t(e.tws_off), tws);
     if (!aud::melspec_wave_finish(kind, dt, &e)) return AUD_OK;  // does not fit LDS
@@ -316,14 +293,20 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
         (void)hipGetLastError();
         return AUD_OK;
     }
+    if (p->d_blob) {  // a rebuild for another geometry
+        (void)hipFree(p->d_blob);
+        p->d_blob = nullptr;
+    }
     int rc = upload(c, &p->d_blob, blob.data(), blob.size());
     if (rc != AUD_OK) return rc;
-    std::vector<unsigned> zeros(64 * 32, 0u);
-    rc = upload(c, reinterpret_cast<void**>(&p->d_queue), zeros.data(), zeros.size() * sizeof(unsigned));
-    if (rc != AUD_OK) return rc;
+    if (!p->d_queue) {
+        std::vector<unsigned> zeros(64 * 32, 0u);
+        rc = upload(c, reinterpret_cast<void**>(&p->d_queue), zeros.data(), zeros.size() * sizeof(unsigned));
+        if (rc != AUD_OK) return rc;
+    }
     e.blob = p->d_blob;
     p->wv = e;
-    p->wave_kind = kind == 1 ? aud_plan::kW16 : aud_plan::kW25;
+    p->wave_kind = kind;
     p->use_wave = true;
     p->family = plan_family(p);
     return AUD_OK;
@@ -340,6 +323,7 @@ const char* plan_family(const aud_plan* p) {
     if (!p->use_fast || p->fast_kind == aud_plan::kNoFast) return "generic";
     if (p->use_wave && p->wave_kind == aud_plan::kW16) return "w16x16";
     if (p->use_wave && p->wave_kind == aud_plan::kW25) return "w25x8";
+    if (p->use_wave && p->wave_kind == aud_plan::kW20) return "w20x10";
     return p->fast_kind == aud_plan::kR16 ? "r16x16" : p->fast_kind == aud_plan::kR25 ? "r25x8" : "r16x16x4";
 }
 
@@ -585,6 +569,8 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
             p->r16.blk = p->d_blk;
             p->r16.atab = p->d_atab;
             // the wave-autonomous kernel of this window length (melspec_wave.hip) has its own table blob
+            p->h_bin_pts.assign(bin_pts, bin_pts + nf + 2);
+            p->h_mel_filters.assign(mel_filters, mel_filters + cells);
             if (rc == AUD_OK) rc = build_wave_tables(p, bin_pts, mel_filters);
         }
     }
@@ -615,6 +601,19 @@ int aud_plan_destroy(aud_plan* p) {
 }
 
 const char* aud_plan_kernel_name(const aud_plan* p) { return p ? p->family : ""; }
+
+int aud_plan_get_info(const aud_plan* p, const char* name, int64_t* value) {
+    if (!p || !name || !value) return AUD_EINVAL;
+    const std::string key(name);
+    const bool wave = p->use_wave, tile = !wave && p->use_fast;
+    const aud::FastArgs* f = wave ? &p->wv : tile ? &p->r16 : nullptr;
+    if (key == "lds_bytes") *value = f ? int64_t(f->lds_bytes) : 0;
+    else if (key == "waves_per_wg") *value = wave ? p->wv.waves : 4;
+    else if (key == "wgs_per_cu") *value = wave ? p->wv.wgs_per_cu : 0;
+    else if (key == "frames_per_wave") *value = wave ? (p->wave_kind == 1 ? 4 : p->wave_kind == 2 ? 8 : 6) : 0;
+    else return fail(p->ctx, AUD_EINVAL, "aud_plan_get_info: unknown name");
+    return AUD_OK;
+}
 
 int aud_plan_set_option(aud_plan* p, const char* name, int value) {
     if (!p || !name) return AUD_EINVAL;
@@ -662,11 +661,24 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
         aud::FastArgs cfg = p->wv;
         cfg.variant = value;
         AUD_HIP(c, make_current(c));
-        if (aud::melspec_wave_prepare(p->wave_kind == aud_plan::kW16 ? 1 : 2, p->d.compute_dtype, &cfg) != hipSuccess) {
+        if (aud::melspec_wave_prepare(p->wave_kind, p->d.compute_dtype, &cfg) != hipSuccess) {
             (void)hipGetLastError();
             return fail(c, AUD_EHIP, "wave_variant: the runtime refused the kernel attributes");
         }
         p->wv = cfg;
+        return AUD_OK;
+    }
+    if (key == "n400_geometry") {  // N = 400 wave kernel: 20 (default: 20 x 10, 6 frames per wave) or 25 (25 x 8, 8 frames per wave)
+        if (p->fast_kind != aud_plan::kR25 || p->h_bin_pts.empty()) return fail(c, AUD_EINVAL, "plan is not an N = 400 plan");
+        if (value != 20 && value != 25) return fail(c, AUD_EINVAL, "n400_geometry: 20 or 25");
+        AUD_HIP(c, make_current(c));
+        const int keep_grid = p->wv.persistent;
+        p->wave_kind = aud_plan::kNoWave;
+        const int rc = build_wave_tables(p, p->h_bin_pts.data(), p->h_mel_filters.data(), value == 20 ? 3 : 2);
+        if (rc != AUD_OK) return rc;
+        if (p->wave_kind == aud_plan::kNoWave) return fail(c, AUD_EINVAL, "n400_geometry: the tables of this plan do not fit that kernel");
+        p->wv.persistent = keep_grid;
+        p->family = plan_family(p);
         return AUD_OK;
     }
     if (key == "wave_grid") {  // -1 (default): by launch size; 0: one wave tile per wave; 1: persistent grid of resident workgroups
@@ -676,11 +688,12 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
             aud::FastArgs cfg = p->wv;
             cfg.variant = 3;
             AUD_HIP(c, make_current(c));
-            if (aud::melspec_wave_prepare(p->wave_kind == aud_plan::kW16 ? 1 : 2, p->d.compute_dtype, &cfg) != hipSuccess) {
+            if (aud::melspec_wave_prepare(p->wave_kind, p->d.compute_dtype, &cfg) != hipSuccess) {
                 (void)hipGetLastError();
                 return fail(c, AUD_EHIP, "wave_grid: the runtime refused the kernel attributes");
             }
             p->wv.max_wgs = cfg.max_wgs;
+            p->wv.wgs_per_cu = cfg.wgs_per_cu;
         }
         p->wv.persistent = value;
         return AUD_OK;

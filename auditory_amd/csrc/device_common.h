@@ -17,6 +17,12 @@ template <typename TT>
 struct alignas(4 * sizeof(TT)) Q4 {
     TT x, y, z, w;
 };
+// the same four values where only 16-byte alignment is promised (weight rows of the wave kernels: their row stride is an
+// odd number of 16-byte pieces); LDS moves 16 bytes per instruction anyway
+template <typename TT>
+struct alignas(16) Q4a {
+    TT x, y, z, w;
+};
 // two complex values moved as one 16-byte (f32) LDS access
 template <typename TT>
 struct alignas(16) C2x2 {
@@ -186,6 +192,64 @@ struct SmallDft<TT, 25> {  // 25 = 5 x 5, inner twiddles W25^(b k1)
     }
 };
 
+// exp(-2 pi i m / 20), m = 0..12: inner twiddles of the 4 x 5 and 2 x 5 factorisations below (literals: no table reads)
+template <typename TT>
+__device__ __forceinline__ C2<TT> w20_literal(int m) {
+    constexpr long double c[13] = {1.0L, 0.9510565162951535721164L, 0.8090169943749474241023L, 0.5877852522924731291687L,
+                                   0.3090169943749474241023L, 0.0L, -0.3090169943749474241023L, -0.5877852522924731291687L,
+                                   -0.8090169943749474241023L, -0.9510565162951535721164L, -1.0L, -0.9510565162951535721164L,
+                                   -0.8090169943749474241023L};
+    constexpr long double sn[13] = {0.0L, -0.3090169943749474241023L, -0.5877852522924731291687L, -0.8090169943749474241023L,
+                                    -0.9510565162951535721164L, -1.0L, -0.9510565162951535721164L, -0.8090169943749474241023L,
+                                    -0.5877852522924731291687L, -0.3090169943749474241023L, 0.0L, 0.3090169943749474241023L,
+                                    0.5877852522924731291687L};
+    return C2<TT>{TT(c[m]), TT(sn[m])};
+}
+// 20 = 4 x 5: n = 5 a + b, k = ka + 4 kb.  4-point DFTs over a, twiddle W20^(b ka), 5-point DFTs over b.
+template <typename TT>
+struct SmallDft<TT, 20> {
+    static __device__ __forceinline__ void run(C2<TT> (&v)[20], const C2<TT>*, int) {
+#pragma unroll
+        for (int b = 0; b < 5; ++b) dft4(v[b], v[5 + b], v[10 + b], v[15 + b]);      // v[5 ka + b] = y[b][ka]
+#pragma unroll
+        for (int ka = 1; ka < 4; ++ka)
+#pragma unroll
+            for (int b = 1; b < 5; ++b) {
+                if (b * ka == 5) v[5 * ka + b] = mul_mi(v[5 * ka + b]);              // W20^5 = -i (never hit: 5 is prime to b, ka < 5)
+                else v[5 * ka + b] = cmul(v[5 * ka + b], w20_literal<TT>(b * ka));
+            }
+#pragma unroll
+        for (int ka = 0; ka < 4; ++ka) dft5(v[5 * ka], v[5 * ka + 1], v[5 * ka + 2], v[5 * ka + 3], v[5 * ka + 4]);
+        // v[5 ka + kb] = X[ka + 4 kb]  ->  natural order
+        C2<TT> t[20];
+#pragma unroll
+        for (int ka = 0; ka < 4; ++ka)
+#pragma unroll
+            for (int kb = 0; kb < 5; ++kb) t[ka + 4 * kb] = v[5 * ka + kb];
+#pragma unroll
+        for (int k = 0; k < 20; ++k) v[k] = t[k];
+    }
+};
+// 10 = 2 x 5: n = 5 a + b, k = ka + 2 kb.
+template <typename TT>
+struct SmallDft<TT, 10> {
+    static __device__ __forceinline__ void run(C2<TT> (&v)[10], const C2<TT>*, int) {
+#pragma unroll
+        for (int b = 0; b < 5; ++b) dft2(v[b], v[5 + b]);                              // v[5 ka + b] = y[b][ka]
+#pragma unroll
+        for (int b = 1; b < 5; ++b) v[5 + b] = cmul(v[5 + b], w20_literal<TT>(2 * b));   // W10^b
+        dft5(v[0], v[1], v[2], v[3], v[4]);
+        dft5(v[5], v[6], v[7], v[8], v[9]);
+        C2<TT> t[10];
+#pragma unroll
+        for (int ka = 0; ka < 2; ++ka)
+#pragma unroll
+            for (int kb = 0; kb < 5; ++kb) t[ka + 2 * kb] = v[5 * ka + kb];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) v[k] = t[k];
+    }
+};
+
 template <typename TT>
 __device__ __forceinline__ TT load_sample(const void* sig, int dtype, int64_t i) {
     if (dtype == AUD_F32) return TT(static_cast<const float*>(sig)[i]);
@@ -311,6 +375,13 @@ __device__ __forceinline__ double feature_log(double v) {
     const double m = frexp(v, &ex);  // v = m 2^ex, 0.5 <= |m| < 1 (m = v for 0, inf and NaN, with ex = 0)
     return double(fmaf(float(ex), 0.693147180559945309417f, logf(float(m))));
 }
+
+// Same-value stores by two lanes of one wave to one LDS address (the 20 x 10 kernel's shadow lanes) are harmless on the
+// GPU; the emulator's ThreadSanitizer build is told so, everywhere else the macros are empty.
+#ifndef AUD_BENIGN_RACE_BEGIN
+#define AUD_BENIGN_RACE_BEGIN()
+#define AUD_BENIGN_RACE_END()
+#endif
 
 // Orders the LDS traffic of ONE wave: stores issued before it are visible to loads issued after it by any lane
 // of the same wave.  The hardware executes a wave's LDS instructions in order, so this emits no instruction; it
@@ -439,45 +510,39 @@ __device__ __forceinline__ void wave_mel_steps_impl(const MelspecArgs& a, const 
                                                     bool live, int ff, int grp) {
     const int T = a.T;
     typedef Q4<TT> quad_t;
-    const quad_t* w4 = reinterpret_cast<const quad_t*>(smem + e.w4_off);
+    // no LDS access below sits under a lane condition (a masked frame still reads its -- valid -- row and drops the sums)
+    const Q4a<TT>* wrow = reinterpret_cast<const Q4a<TT>*>(smem + e.w4_off + grp * e.w_stride);
     const quad_t* prow = reinterpret_cast<const quad_t*>(P + ff * Hp);
-    const uint2* recs = reinterpret_cast<const uint2*>(smem + e.steps_off) + grp * e.n_steps;
-    TT acc = TT(0);
-    TT sums[MAXS];
-#pragma unroll
-    for (int k = 0; k < MAXS; ++k) sums[k] = TT(0);
-    if (live) {
-#pragma unroll 4
-        for (int s = 0; s < e.n_steps; ++s) {
-            const uint2 r = recs[s];
-            const quad_t pw = prow[r.x & 0xFFFFu], ww = w4[r.x >> 16];
-            const TT t0 = ww.x * pw.x + ww.y * pw.y, t1 = ww.z * pw.z + ww.w * pw.w;
-            const TT part = t0 + t1;
-            acc = (r.y & 0x100u) ? part : acc + part;
-            const int slot = (r.y & 0x200u) ? int(r.y & 0xFFu) : -1;
-#pragma unroll
-            for (int k = 0; k < MAXS; ++k) sums[k] = (slot == k) ? acc : sums[k];
-        }
-    }
-    const unsigned short* slots = reinterpret_cast<const unsigned short*>(smem + e.slots_off) + grp * e.n_slots;
+    const unsigned* recs = reinterpret_cast<const unsigned*>(smem + e.slots_off) + grp * e.n_slots;
     const TT loff = TT(a.mel_log_off), lmin = TT(a.mel_log_min);
     float* mel_col = a.mel + (size_t(item) * a.nf * T + (col_on ? sstep : 0));
 #pragma unroll
     for (int k = 0; k < MAXS; ++k) {
-        if (k < e.n_slots) {
-            const int flt = slots[k];
-            float res = 0.f;
-            if (live) {
-                const TT sum = sums[k] + loff;
-                TT val = (sum == TT(0)) ? lmin : feature_log(sum);
-                if (a.renorm) {
-                    val -= TT(a.renorm_min);
-                    if (val < TT(0)) val = TT(0);
-                    val *= TT(a.renorm_scale);
-                    if (val > TT(1)) val = TT(1);
-                }
-                res = float(val);
+        if (k < e.n_slots) {  // wave-uniform
+            const unsigned rec = recs[k];
+            const int ns = e.slot_steps[k];  // wave-uniform trip count: slot k is equally long in every group
+            const quad_t* pp = prow + (rec & 0xFFFFu);
+            TT s0 = TT(0), s1 = TT(0);
+#pragma unroll 2
+            for (int s = 0; s < ns; ++s) {
+                const quad_t pw = pp[s];
+                const Q4a<TT> ww = wrow[s];
+                s0 += ww.x * pw.x;
+                s1 += ww.y * pw.y;
+                s0 += ww.z * pw.z;
+                s1 += ww.w * pw.w;
             }
+            wrow += ns;
+            const int flt = int(rec >> 16);
+            const TT sum = (s0 + s1) + loff;
+            TT val = (sum == TT(0)) ? lmin : feature_log(sum);
+            if (a.renorm) {
+                val -= TT(a.renorm_min);
+                if (val < TT(0)) val = TT(0);
+                val *= TT(a.renorm_scale);
+                if (val > TT(1)) val = TT(1);
+            }
+            const float res = live ? float(val) : 0.f;
             if (col_on && flt != 0xFFFF) mel_col[size_t(flt) * T] = res;  // MelFBankSegment[item][flt][sstep]
         }
     }
@@ -488,9 +553,12 @@ __device__ __forceinline__ void wave_mel_steps(const MelspecArgs& a, const FastA
                                                const unsigned char* smem, const aud_item& it, int item, int t0,
                                                int lane) {
     tile_spectrum_outputs<TT, 64, FPW>(a, P, Hp, it, item, t0, lane);
-    const int ff = lane % FPW, grp = lane / FPW;
+    // 64 is not a multiple of FPW = 6: lanes 60..63 have no filter group; they run group n_groups - 1 again and store nothing
+    const int ff = lane % FPW, g0 = lane / FPW;
+    const bool has = g0 < e.n_groups;
+    const int grp = has ? g0 : e.n_groups - 1;
     const int sstep = t0 + ff;
-    const bool col_on = sstep < a.T;
+    const bool col_on = has && sstep < a.T;
     const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
     const bool live = col_on && start + a.N <= int64_t(it.sig_len);
     wave_mel_steps_impl<TT, FPW, MAXS>(a, e, P, Hp, smem, item, sstep, col_on, live, ff, grp);  // e.n_slots <= MAXS (host)

@@ -120,20 +120,25 @@ struct FastArgs {
     const int* blk;        // [n_blocks][3] device: first 4-bin chunk, K-steps, offset (in steps) into atab
     const float* atab;     // [steps][64] device: A operands, lane-ordered
     // wave-autonomous kernels (melspec_wave.hip): all read-only tables live in ONE device blob laid out exactly like
-    // its LDS copy -- [w4 chunks + one zero chunk | step records | slot filter ids | pass twiddles | split twiddles]
-    // -- so staging is a flat 16-byte-piece copy.  Offsets below are bytes from the start of dynamic LDS / the blob.
+    // its LDS copy -- [per-group weight rows | slot records | pass twiddles | split twiddles] -- so staging is a flat
+    // 16-byte-piece copy.  Offsets below are bytes from the start of dynamic LDS / the blob.
+    // The mel epilogue: a lane owns (frame, filter group); a group's filters sit in SLOTS, slot k of every group takes
+    // the same number of 4-bin chunk steps slot_steps[k] (filters are dealt to groups in order of width, so the padding
+    // is small), a filter's chunks are consecutive in P, its weights consecutive in the group's weight row.
     const void* blob;      // device
     int blob_bytes;        // multiple of 16
-    int steps_off;         // uint2 [n_groups][n_steps]: {P chunk | w4 chunk << 16, slot | first << 8 | last << 9}
-    int n_steps;
-    int slots_off;         // uint16 [n_groups][n_slots]: filter id, 0xFFFF = empty
+    int w_stride;          // bytes between the weight rows of two groups (an odd number of 16-byte pieces: bank spread)
+    int n_steps;           // chunk steps of a lane: sum of slot_steps
+    int slots_off;         // uint32 [n_groups][n_slots]: first P chunk | filter id << 16 (0xFFFF = empty)
     int n_slots;
+    unsigned char slot_steps[8];
     int twa_off;           // pass twiddles, C2<TT> [K1 - 1][lanes per frame]: W^(2 j k1)
     int tws_off;           // split twiddles, C2<TT> [N/4 + 1]: W_N^k
     int waves;             // waves per workgroup of the launch
     int variant;           // A/B variant of the wave kernel (plan option "wave_variant")
     int persistent;        // 1: grid capped at max_wgs, waves walk several tiles; 0: one tile per wave; -1: by launch size (plan option "wave_grid")
     int max_wgs;           // persistent grid: workgroups resident on the device at once (occupancy x CUs)
+    int wgs_per_cu;        // the occupancy answer itself (aud_plan_get_info)
 };
 
 // PrevSmooth != 0 mode: scan along the steps of a stored power tensor

@@ -535,6 +535,233 @@ __global__ __launch_bounds__(64 * NW, sizeof(TT) == 8 ? 2 : (VAR == 1 ? 3 : 2)) 
     }
 }
 
+
+// ================================================================================================
+// N = 400, second geometry: 200-point complex FFT as 20 x 10, 10 lanes per frame, 6 frames per wave (60 of 64 lanes)
+// ================================================================================================
+// The 25 x 8 kernel keeps 25 points and then four 8-column rows per lane: 174 registers and 17 KB of LDS per wave in
+// float64 -- two waves per SIMD, and the stamps show its vector ALU waiting.  20 x 10 gives a lane 20 points and then
+// exactly one row PAIR (r, 20 - r) of 10 columns: every lane has both halves of its ten split pairs locally (lane 0
+// takes the two self-paired rows 0 and 10), two thirds of the registers, 10 KB of LDS per wave: three waves per SIMD.
+namespace w20 {
+constexpr int kFW = 6;    // frames per wave
+constexpr int kLPF = 10;  // lanes per frame
+constexpr int kM = 200, kN = 400, kH = 201, kHp = 204;
+template <typename TT>
+struct Layout {
+    // scalar transpose rows of 10 (+2 pad in float32: 16-byte rows); pitches from a search over the hardware's lane
+    // groups (10-lane frames cannot be conflict-free against 16-lane groups: 2-way at best, which these reach)
+    static constexpr int kRow = (sizeof(TT) == 4) ? 12 : 10;
+    static constexpr int kFrame = (sizeof(TT) == 4) ? 248 : 206;
+    static constexpr int kXch = kFW * kFrame;
+    static constexpr int kP = kFW * kHp;
+    static constexpr int kRegion = ((kXch > kP ? kXch : kP) * int(sizeof(TT)) + 31) & ~31;  // bytes per wave
+};
+template <typename TT>
+__device__ __forceinline__ void read_row10(const TT* row, C2<TT> (&z)[10], bool imag) {
+    TT d[12];
+    if constexpr (sizeof(TT) == 4) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const Q4<TT> r4 = reinterpret_cast<const Q4<TT>*>(row)[q];
+            d[4 * q] = r4.x; d[4 * q + 1] = r4.y; d[4 * q + 2] = r4.z; d[4 * q + 3] = r4.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const C2<TT> r2 = reinterpret_cast<const C2<TT>*>(row)[q];
+            d[2 * q] = r2.x; d[2 * q + 1] = r2.y;
+        }
+    }
+#pragma unroll
+    for (int n2 = 0; n2 < 10; ++n2) {
+        if (imag) z[n2].y = d[n2];
+        else z[n2].x = d[n2];
+    }
+}
+}  // namespace w20
+
+template <typename TT, bool PCM16, int MAXS, int MODE>
+__device__ __forceinline__ void w20_tile(const MelspecArgs& a, const FastArgs& e, unsigned char* smem, TT* xw,
+                                         const C2<TT>* twa, const C2<TT>* tws, int lane_in, int tiles, int64_t wt,
+                                         int64_t wt_next, int64_t total, FrameRaw<20>& raw, aud_item& it, int& item,
+                                         int& t0, unsigned* queue_fetch = nullptr) {
+    using L = w20::Layout<TT>;
+    int lane = lane_in;  // opaque per tile (see w16_tile)
+    asm volatile("" : "+v"(lane));
+    // lanes 60..63 have no frame of their own: they SHADOW lanes 50..53 (same frame, same column) through the whole FFT --
+    // same loads, same arithmetic, same values stored to the same LDS addresses -- so that no LDS access sits under a
+    // lane condition (a lane-conditional block of LDS stores or loads costs hipcc 60-100 registers here)
+    const bool own = lane < w20::kFW * w20::kLPF;
+    const int f = own ? lane / w20::kLPF : w20::kFW - 1;
+    const int j = own ? lane - f * w20::kLPF : lane - w20::kFW * w20::kLPF;
+    AUD_STAMP_DECL;
+    AUD_STAMP(0);
+    C2<TT> v[20];
+    if constexpr (MODE == 2) {
+        item = int(wt / tiles);
+        t0 = int(wt - int64_t(item) * tiles) * w20::kFW;
+        it = a.items[item];
+        load_frame_pairs<TT, 20, 10, w20::kN, PCM16>(a, it, t0 + f, j, v);
+    } else {
+        frame_pairs_take<TT, 20, 10, w20::kN, PCM16>(a, it, t0 + f, j, raw, v);
+    }
+    const int item_cur = item, t0_cur = t0;
+    const aud_item it_cur = it;
+    if (queue_fetch) {
+        unsigned got = 0;
+        if (lane == 0) got = atomicAdd(a.queue, 1u);
+        *queue_fetch = got;
+    }
+    if constexpr (MODE == 0) {
+        if (wt_next < total) {
+            item = int(wt_next / tiles);
+            t0 = int(wt_next - int64_t(item) * tiles) * w20::kFW;
+            it = a.items[item];
+            frame_pairs_issue<20, 10, w20::kN, PCM16>(a, it, t0 + f, j, raw);
+        }
+    }
+    AUD_STAMP(3);
+
+    // ---- pass A: 20-point DFT over n1, twiddle W_200^(j k1) = W_400^(2 j k1) -------------------------------
+    SmallDft<TT, 20>::run(v, nullptr, 0);
+#pragma unroll
+    for (int k1 = 1; k1 < 20; ++k1) v[k1] = cmul(v[k1], twa[(k1 - 1) * w20::kLPF + j]);
+    AUD_STAMP(4);
+
+    // ---- transpose (real parts, then imaginary parts): element (row k1, column n2 = j) of frame f; afterwards the lane
+    // holds the row pair (j, 20 - j) -- lane 0 the self-paired rows 0 and 10 -- with all ten columns of each
+    TT* col = xw + f * L::kFrame + j;
+    constexpr int cstep = L::kRow;
+    const TT* rows = xw + f * L::kFrame;
+    const int ra = j, rb = j == 0 ? 10 : 20 - j;
+    C2<TT> za[10], zb[10];
+    AUD_BENIGN_RACE_BEGIN();
+#pragma unroll
+    for (int k1 = 0; k1 < 20; ++k1) col[k1 * cstep] = v[k1].x;
+    AUD_BENIGN_RACE_END();
+    wave_lds_fence();
+    w20::read_row10<TT>(rows + ra * L::kRow, za, false);
+    w20::read_row10<TT>(rows + rb * L::kRow, zb, false);
+    wave_lds_fence();
+    AUD_BENIGN_RACE_BEGIN();
+#pragma unroll
+    for (int k1 = 0; k1 < 20; ++k1) col[k1 * cstep] = v[k1].y;
+    AUD_BENIGN_RACE_END();
+    wave_lds_fence();
+    w20::read_row10<TT>(rows + ra * L::kRow, za, true);
+    w20::read_row10<TT>(rows + rb * L::kRow, zb, true);
+    wave_lds_fence();  // every row has been read: the region may take the power spectrum
+    AUD_STAMP(5);
+
+    // ---- pass B: 10-point DFT over n2 of both rows: Z[k1 + 20 k2] -----------------------------------------------
+    SmallDft<TT, 10>::run(za, nullptr, 0);
+    SmallDft<TT, 10>::run(zb, nullptr, 0);
+    AUD_STAMP(6);
+
+    // ---- real-FFT split + power: the partner of Z[k1 + 20 k2] is element (20 - k1, 9 - k2); pairs are evaluated from
+    // their k <= 100 side (A = Z[k], B = Z[200 - k]) as everywhere else
+    TT* Pw = xw;  // [6][kHp]
+    TT* P = Pw + f * w20::kHp;
+    AUD_BENIGN_RACE_BEGIN();
+    {
+        // lanes 1..9: rows (j, 20 - j): k = j + 20 c pairs with (row 20 - j, column 9 - c) and vice versa, c = 0..4;
+        // lane 0: row 0: k = 20 c pairs with column 10 - c of the same row (c = 0: DC + Nyquist; c = 5: itself), row 10:
+        // k = 10 + 20 c pairs with column 9 - c of the same row.  One code path, partners selected by value.
+        const bool self = j == 0;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const C2<TT> pa = za[(10 - c) % 10], pb = zb[9 - c], pc = za[9 - c];
+            const C2<TT> b_first = {self ? pa.x : pb.x, self ? pa.y : pb.y};
+            const C2<TT> b_second = {self ? pb.x : pc.x, self ? pb.y : pc.y};
+            w25::split_pair<TT>(P, tws, ra + 20 * c, za[c], b_first);
+            w25::split_pair<TT>(P, tws, rb + 20 * c, zb[c], b_second);
+        }
+        // lane 0's eleventh pair, k = 100 (row 0, column 5, paired with itself); the other lanes repeat their k = j pair
+        w25::split_pair<TT>(P, tws, self ? 100 : ra, self ? za[5] : za[0], self ? za[5] : zb[9]);
+        P[w20::kH + (j < 3 ? j : 0)] = TT(0);  // pad bins 201..203 of the last 4-bin chunk
+    }
+    AUD_BENIGN_RACE_END();
+    wave_lds_fence();
+    AUD_STAMP(7);
+
+    // ---- optional spectrum outputs and the mel reduction: 6 frames x 10 filter groups on this wave ---------------
+    wave_mel_steps<TT, w20::kFW, MAXS>(a, e, Pw, w20::kHp, smem, it_cur, item_cur, t0_cur, lane);
+    AUD_STAMP(8);
+    AUD_STAMP_FLUSH(a, wt, lane);
+    wave_lds_fence();  // the region is free for the next tile
+}
+
+template <typename TT, bool PCM16, int NW, int MAXS, int VAR>
+__global__ __launch_bounds__(64 * NW, sizeof(TT) == 8 ? 3 : 4) void k_melspec_w20(const MelspecArgs a, const FastArgs e) {
+    using L = w20::Layout<TT>;
+    unsigned char* smem = dyn_lds();
+    const int tid = int(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+
+    BlobRegs<64 * NW> blob;
+    blob_fetch<64 * NW>(e, tid, blob);
+
+    const int tiles = (a.T + w20::kFW - 1) / w20::kFW;  // wave tiles per item
+    const int64_t total = int64_t(a.n_items) * tiles;
+    const int64_t stride = int64_t(gridDim.x) * NW;
+    const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
+    int64_t wt = int64_t(wg) * NW + wave;
+    int item = wt < total ? int(wt / tiles) : 0;
+    int t0 = wt < total ? int(wt - int64_t(item) * tiles) * w20::kFW : 0;
+    aud_item it = a.items[item];
+
+    FrameRaw<20> raw;
+    raw.route = 0;
+    {
+        const bool own = lane < w20::kFW * w20::kLPF;  // lanes 60..63 shadow lanes 50..53 (w20_tile)
+        const int f0 = own ? lane / w20::kLPF : w20::kFW - 1;
+        const int j0 = own ? lane - f0 * w20::kLPF : lane - w20::kFW * w20::kLPF;
+        if (wt < total) frame_pairs_issue<20, 10, w20::kN, PCM16>(a, it, t0 + f0, j0, raw);
+    }
+
+    blob_store<64 * NW>(e, smem, tid, blob);
+    __syncthreads();  // the one barrier: tables visible to the workgroup's waves
+
+    TT* xw = reinterpret_cast<TT*>(smem + e.xch_off + wave * L::kRegion);
+    const C2<TT>* twa = reinterpret_cast<const C2<TT>*>(smem + e.twa_off);  // W_400^(2 j k1) at [(k1 - 1) 10 + j]
+    const C2<TT>* tws = reinterpret_cast<const C2<TT>*>(smem + e.tws_off);  // W_400^k, k <= 100
+
+    if constexpr (VAR == 3) {
+        const unsigned grid_waves = gridDim.x * NW;
+        bool first = true;
+        while (wt < total) {
+            unsigned nxt = 0;
+            if (first) w20_tile<TT, PCM16, MAXS, 1>(a, e, smem, xw, twa, tws, lane, tiles, wt, wt, total, raw, it, item, t0, &nxt);
+            else w20_tile<TT, PCM16, MAXS, 2>(a, e, smem, xw, twa, tws, lane, tiles, wt, wt, total, raw, it, item, t0, &nxt);
+            first = false;
+            wt = int64_t(grid_waves) + unsigned(__builtin_amdgcn_readfirstlane(int(nxt)));
+        }
+        if (lane == 0) {
+            const unsigned left = atomicAdd(a.queue + 16, 1u);
+            if (left == grid_waves - 1) {
+                atomicExch(a.queue, 0u);
+                atomicExch(a.queue + 16, 0u);
+            }
+        }
+    } else if constexpr (VAR == 2) {
+        if (wt < total) {
+            w20_tile<TT, PCM16, MAXS, 1>(a, e, smem, xw, twa, tws, lane, tiles, wt, wt + stride, total, raw, it, item, t0);
+            wt += stride;
+        }
+        while (wt < total) {
+            w20_tile<TT, PCM16, MAXS, 2>(a, e, smem, xw, twa, tws, lane, tiles, wt, wt + stride, total, raw, it, item, t0);
+            wt += stride;
+        }
+    } else {
+        while (wt < total) {
+            w20_tile<TT, PCM16, MAXS, 0>(a, e, smem, xw, twa, tws, lane, tiles, wt, wt + stride, total, raw, it, item, t0);
+            wt += stride;
+        }
+    }
+}
+
 }  // namespace
 
 // waves per workgroup: the waves of a workgroup share one LDS copy of the table blob (eight-wave workgroups were
@@ -550,13 +777,18 @@ bool melspec_wave_geometry(int kind, int N, WaveGeometry* g) {
         *g = WaveGeometry{64 / w25::kFW, 8, 25, w25::kM / 2 + 1};
         return true;
     }
+    if (kind == 3 && N == w20::kN) {
+        *g = WaveGeometry{10, w20::kLPF, 20, w20::kM / 2 + 1};
+        return true;
+    }
     return false;
 }
 
 bool melspec_wave_finish(int kind, int compute_dtype, FastArgs* e) {
     const bool f64 = compute_dtype == AUD_F64;
-    const size_t region = kind == 1 ? (f64 ? size_t(w16::Layout<double>::kRegion) : size_t(w16::Layout<float>::kRegion))
-                                    : (f64 ? size_t(w25::Layout<double>::kRegion) : size_t(w25::Layout<float>::kRegion));
+    const size_t region = kind == 1   ? (f64 ? size_t(w16::Layout<double>::kRegion) : size_t(w16::Layout<float>::kRegion))
+                          : kind == 2 ? (f64 ? size_t(w25::Layout<double>::kRegion) : size_t(w25::Layout<float>::kRegion))
+                                      : (f64 ? size_t(w20::Layout<double>::kRegion) : size_t(w20::Layout<float>::kRegion));
     const int nw = wave_kernel_waves(kind, compute_dtype);
     const size_t first = (size_t(e->blob_bytes) + 255) & ~size_t(255);
     const size_t total = first + size_t(nw) * region;
@@ -583,6 +815,12 @@ static wave_kernel_t wave_kernel(int kind, bool f64, int n_slots, int var) {
         return s8 ? AUD_W16(float, 8) : AUD_W16(float, 4);
 #undef AUD_W16
     }
+    if (kind == 3) {
+#define AUD_W20(TT, S) (var == 3 ? k_melspec_w20<TT, true, 4, S, 3> : k_melspec_w20<TT, true, 4, S, 2>)
+        if (f64) return s8 ? AUD_W20(double, 8) : AUD_W20(double, 4);
+        return s8 ? AUD_W20(float, 8) : AUD_W20(float, 4);
+#undef AUD_W20
+    }
     if (f64) return var == 3 ? (s8 ? k_melspec_w25<double, true, 4, 8, 3> : k_melspec_w25<double, true, 4, 4, 3>)
                              : (s8 ? k_melspec_w25<double, true, 4, 8, 2> : k_melspec_w25<double, true, 4, 4, 2>);
 #define AUD_W25(S) (var == 1 ? k_melspec_w25<float, true, 4, S, 1> : var == 2 ? k_melspec_w25<float, true, 4, S, 2> : var == 3 ? k_melspec_w25<float, true, 4, S, 3> : k_melspec_w25<float, true, 4, S, 0>)
@@ -605,11 +843,12 @@ hipError_t melspec_wave_prepare(int kind, int compute_dtype, FastArgs* e) {
     if (rc == hipSuccess) rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * e->waves, e->lds_bytes);
     if (rc != hipSuccess) return rc;
     e->max_wgs = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+    e->wgs_per_cu = per_cu;
     return hipSuccess;
 }
 
 hipError_t launch_melspec_wave(int kind, const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st) {
-    const int fw = kind == 1 ? w16::kFW : w25::kFW;
+    const int fw = kind == 1 ? w16::kFW : kind == 2 ? w25::kFW : w20::kFW;
     const int64_t tiles = (a.T + fw - 1) / fw;
     const int64_t waves = int64_t(a.n_items) * tiles;
     const int nw = e.waves;

@@ -85,6 +85,12 @@ class Plan:
     def kernel_name(self):
         return self.lib.aud_plan_kernel_name(self.handle).decode()
 
+    def info(self, name):
+        """aud_plan_get_info: "lds_bytes", "waves_per_wg", "wgs_per_cu", "frames_per_wave" of the mel kernel"""
+        v = C.c_int64(0)
+        self.ctx.check(self.lib.aud_plan_get_info(self.handle, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def set_option(self, name, value):
         """aud_plan_set_option: "kernel" (0 auto / 1 generic), "r16_input" (0 direct / 1 staged)"""
         self.ctx.check(self.lib.aud_plan_set_option(self.handle, name.encode(), int(value)))

@@ -227,6 +227,14 @@ const char* aud_plan_kernel_name(const aud_plan* plan);
  *               pipe (float32 plans only; same products, the sum also takes the zero weights of the band) */
 int aud_plan_set_option(aud_plan* plan, const char* name, int value);
 
+/* Launch facts of the kernel the plan will run for the mel path (diagnostics: profiles/, bench.py).
+ *   "lds_bytes"        LDS per workgroup
+ *   "waves_per_wg"     waves of 64 lanes per workgroup
+ *   "wgs_per_cu"       workgroups resident per compute unit (the runtime's occupancy answer at plan time)
+ *   "frames_per_wave"  frames one wave transforms together (0: a workgroup-tile or generic kernel)
+ * AUD_EINVAL for an unknown name. */
+int aud_plan_get_info(const aud_plan* plan, const char* name, int64_t* value);
+
 /* ---- hot path, device-resident (what bench.py times) ----------------------------- */
 
 /* The SndEnv.ProcessSegment frame loop (sound/sndenv.go:342-359 -> :438-478) fused with

@@ -44,6 +44,13 @@ struct alignas(16) uint4 {
     unsigned x, y, z, w;
 };
 inline void __builtin_amdgcn_sched_barrier(int) {}
+// same-value races the 20 x 10 wave kernel has by design (shadow lanes): ThreadSanitizer is told to look away
+#if defined(__SANITIZE_THREAD__)
+extern "C" void AnnotateIgnoreWritesBegin(const char*, int);
+extern "C" void AnnotateIgnoreWritesEnd(const char*, int);
+#define AUD_BENIGN_RACE_BEGIN() AnnotateIgnoreWritesBegin(__FILE__, __LINE__)
+#define AUD_BENIGN_RACE_END() AnnotateIgnoreWritesEnd(__FILE__, __LINE__)
+#endif
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
 inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_ACQ_REL); }  // callers pass wave-uniform values
 

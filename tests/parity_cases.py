@@ -87,10 +87,11 @@ def case_workgroup_order(orc, cdt, with_n2048=True):
             ("cfg2_16k_n512_nf40", 200.0, 0.25, 9, [0], {}),                  # w16x16: 54 wave tiles, 14 workgroups
             ("cfg2_16k_n512_nf40", 200.0, 0.25, 9, [0], {"kernel": 2}),       # r16x16: 18 workgroups (18 % 8 = 2)
             ("cfg2_16k_n512_nf40", 520.0, 0.55, 9, [0], {"r16_tiles": 2}),    # two-tile kernel: 18 workgroups
-            ("sndenv_16k_n400_nf32", None, 0.75, 3, list(range(7)), {}),      # w25x8: 21 items x 2 wave tiles
+            ("sndenv_16k_n400_nf32", None, 0.75, 3, list(range(7)), {}),      # w20x10: 21 items x 3 wave tiles
+            ("sndenv_16k_n400_nf32", None, 0.75, 3, list(range(7)), {"n400_geometry": 25}),  # w25x8: 21 items x 2 wave tiles
             ("sndenv_16k_n400_nf32", None, 0.75, 3, list(range(7)), {"kernel": 2}),  # r25x8: 21 one-tile items
             ("cfg1_44k_n1103_nf32", None, 0.3, 3, [0, 1], {}),                # generic, prime N
-            ("cfg5_44k_n2048_nf128", 120.0, 0.5, 5, [0, 1, 2, 3], {})][:7 if with_n2048 else 6]:  # r16x16x4: 20 items
+            ("cfg5_44k_n2048_nf128", 120.0, 0.5, 5, [0, 1, 2, 3], {})][:8 if with_n2048 else 7]:  # r16x16x4: 20 items
         oc = W.OracleCfg(orc, name, seg_ms)
         L = int(dur * oc.sr)
         sig, _ = synth.batch(19, rows, L, oc.sr)
@@ -626,10 +627,12 @@ def case_n400_variants(orc, cdt, seg_ms=None, dur=1.0, rows=2, segs=(0,)):
     """25 ms @ 16 kHz (N = 400): the r25x8 kernel and the generic kernel, both against the oracle"""
     for name in ("cfg2_16k_n400_nf40", "sndenv_16k_n400_nf32"):
         fam = _fast_family(orc, name, cdt, seg_ms)
-        assert fam == "w25x8"
-        # wave-autonomous (its three persistent variants), workgroup-tile (r25x8), generic
-        for opts in ({}, {"wave_grid": 1}, {"wave_grid": 2}, {"wave_grid": 1, "wave_variant": 0}, {"wave_grid": 1, "wave_variant": 1},
-                     {"kernel": 2}, {"kernel": 1}):
+        assert fam == "w20x10"
+        # wave-autonomous 20 x 10 (default; persistent and dynamic-queue grids), 25 x 8 (and its variants), workgroup-tile
+        # (r25x8), generic
+        for opts in ({}, {"wave_grid": 1}, {"wave_grid": 2}, {"n400_geometry": 25}, {"n400_geometry": 25, "wave_grid": 1},
+                     {"n400_geometry": 25, "wave_grid": 2}, {"n400_geometry": 25, "wave_grid": 1, "wave_variant": 0},
+                     {"n400_geometry": 25, "wave_grid": 1, "wave_variant": 1}, {"kernel": 2}, {"kernel": 1}):
             case_melspec_vs_oracle(orc, (name, dur, rows, list(segs)), cdt, seg_ms=seg_ms, options=opts)
 
 

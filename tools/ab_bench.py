@@ -48,8 +48,10 @@ def main():
     sig = np.tile(sig64.astype(np.float32), (reps, 1))[:B]
     dsig = torch.from_numpy(sig).to(dev).view(-1)
     cdt = capi.AUD_F32 if args.compute == "f32" else capi.AUD_F64
-    variants = {"w25 (default)": {}, "w25 one tile per wave": {"wave_grid": 0}, "w25 persistent var 2": {"wave_grid": 1}, "w25 persistent prefetch": {"wave_grid": 1, "wave_variant": 0},
-                "w25, no xcd remap": {"xcd_remap": 0}, "r25 tile kernel": {"kernel": 2}, "generic": {"kernel": 1}}
+    variants = {"w20 (default)": {}, "w20 one tile per wave": {"wave_grid": 0}, "w20 persistent": {"wave_grid": 1},
+                "w25 (25 x 8 geometry)": {"n400_geometry": 25}, "w25 one tile per wave": {"n400_geometry": 25, "wave_grid": 0},
+                "w25 persistent": {"n400_geometry": 25, "wave_grid": 1},
+                "w20, no xcd remap": {"xcd_remap": 0}, "r25 tile kernel": {"kernel": 2}, "generic": {"kernel": 1}}
     if args.win_ms == 32.0:
         variants = {"w16 (default)": {}, "w16 one tile per wave": {"wave_grid": 0}, "w16 persistent var 2": {"wave_grid": 1}, "w16 persistent prefetch": {"wave_grid": 1, "wave_variant": 0},
                     "w16, no xcd remap": {"xcd_remap": 0},
@@ -110,8 +112,9 @@ def main():
           % (name, B, args.compute, args.rounds, args.launches, alg / 1e6))
     for v, ts in times.items():
         med, mn = statistics.median(ts), min(ts)
-        print("%-28s kernel=%-9s median %8.2f us  min %8.2f us  -> %6.2f TB/s algorithmic, %7.1f M audio-s/s"
-              % (v, plans[v].kernel_name, med, mn, alg / (med * 1e-6) / 1e12, B / med))
+        print("%-28s kernel=%-9s lds %6d B, %d wg/CU  median %8.2f us  min %8.2f us  -> %6.2f TB/s algorithmic, %7.1f M audio-s/s"
+              % (v, plans[v].kernel_name, plans[v].info("lds_bytes"), plans[v].info("wgs_per_cu"), med, mn,
+                 alg / (med * 1e-6) / 1e12, B / med))
     for p in plans.values():
         p.close()
 

@@ -61,7 +61,7 @@ def main():
     dsig = torch.from_numpy(sig).to(dev).view(-1)
     cdt = capi.AUD_F32 if args.compute == "f32" else capi.AUD_F64
     plan = W.product_plan(oc, cdt)
-    fpw = 4 if oc.N == 512 else 8
+    fpw = plan.info("frames_per_wave")
     n_waves = B * ((oc.T + fpw - 1) // fpw)
     stamps = torch.zeros((n_waves, 16), dtype=torch.int64, device=dev)
     ptr = stamps.data_ptr()
@@ -94,13 +94,23 @@ def main():
                                                  np.percentile(d[:, i], 90), 100 * d[:, i].sum() / life.sum()))
     print("%-36s %9.0f %9.0f %9.0f" % ("wave lifetime", np.median(life), np.percentile(life, 10), np.percentile(life, 90)))
     xcc = s[ok, 12] & 15
-    print("timeline per XCD (ticks from the launch's first stamp): first start, median start, last start, last end")
-    base = t[:, 0].min()
+    # every XCD has its own counter; a wave slot the last launch did not run keeps an older launch's stamps: drop those
+    print("timeline per XCD (ticks from the XCD's first start of this launch): median start, last start, median end, last end")
+    span = []
     for x in sorted(set(xcc.tolist())):
         m = xcc == x
-        print("  XCC %d: %5d waves  first %7d  median %7d  last start %7d  last end %7d"
-              % (x, m.sum(), t[m, 0].min() - base, np.median(t[m, 0]) - base, t[m, 0].max() - base, t[m, 8].max() - base))
-    print("whole launch: %d ticks from first stamp to last stamp" % (t[:, 8].max() - base))
+        tx = t[m]
+        cur = tx[:, 0] > np.median(tx[:, 0]) - 2_000_000
+        tx = tx[cur]
+        base = tx[:, 0].min()
+        span.append(tx[:, 8].max() - base)
+        print("  XCC %d: %5d waves (%d stale)  median start %7d  last start %7d  median end %7d  last end %7d"
+              % (x, cur.sum(), (~cur).sum(), np.median(tx[:, 0]) - base, tx[:, 0].max() - base,
+                 np.median(tx[:, 8]) - base, tx[:, 8].max() - base))
+        hist, _ = np.histogram(tx[:, 0] - base, bins=12, range=(0, span[-1]))
+        print("          wave starts per twelfth of the XCD's span: %s" % " ".join("%4d" % h for h in hist))
+    print("longest XCD span %d ticks; the launch took %.1f us by HIP events -> %.2f ticks per ns if the span were the whole launch"
+          % (max(span), e0.elapsed_time(e1) * 1e3, max(span) / (e0.elapsed_time(e1) * 1e6)))
     plan.close()
 
 
