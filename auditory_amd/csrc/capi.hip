@@ -255,7 +255,8 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
         slots[size_t(gi) * n_slots + k] = uint32_t(pc0) | (uint32_t(f) << 16);
         double* wr = &wrows[size_t(gi) * (w_stride / tsz) + size_t(slot_pos[k]) * 4];
         if (hi >= lo)
-            for (int bin = lo; bin <= hi; ++bin) wr[bin - 4 * pc0] = mel_filters[int64_t(f) * (nf + 2) + (bin - lo)];
+            for (int bin = lo; bin <= hi; ++bin)  // x 1/4 (exact): the kernels keep FOUR times the power in LDS
+                wr[bin - 4 * pc0] = 0.25 * mel_filters[int64_t(f) * (nf + 2) + (bin - lo)];
     }
     // twiddles, from the same long-double formula as the plan's W_N table
     const long double w = -2.0L * 3.14159265358979323846264338327950288L / (long double)N;

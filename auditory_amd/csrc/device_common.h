@@ -192,59 +192,41 @@ struct SmallDft<TT, 25> {  // 25 = 5 x 5, inner twiddles W25^(b k1)
     }
 };
 
-// exp(-2 pi i m / 20), m = 0..12: inner twiddles of the 4 x 5 and 2 x 5 factorisations below (literals: no table reads)
+// 20 = 4 x 5 and 10 = 2 x 5 have coprime factors: the prime-factor (Good-Thomas) index maps
+//   n = (N2 n1 + N1 n2) mod N,   k = (N2 (N2^-1 mod N1) k1 + N1 (N1^-1 mod N2) k2) mod N
+// turn the DFT into N2 DFTs of length N1 and N1 of length N2 with NO twiddles between them; every index below is a
+// compile-time constant, so the maps cost nothing (the unrolled arrays live in registers).
 template <typename TT>
-__device__ __forceinline__ C2<TT> w20_literal(int m) {
-    constexpr long double c[13] = {1.0L, 0.9510565162951535721164L, 0.8090169943749474241023L, 0.5877852522924731291687L,
-                                   0.3090169943749474241023L, 0.0L, -0.3090169943749474241023L, -0.5877852522924731291687L,
-                                   -0.8090169943749474241023L, -0.9510565162951535721164L, -1.0L, -0.9510565162951535721164L,
-                                   -0.8090169943749474241023L};
-    constexpr long double sn[13] = {0.0L, -0.3090169943749474241023L, -0.5877852522924731291687L, -0.8090169943749474241023L,
-                                    -0.9510565162951535721164L, -1.0L, -0.9510565162951535721164L, -0.8090169943749474241023L,
-                                    -0.5877852522924731291687L, -0.3090169943749474241023L, 0.0L, 0.3090169943749474241023L,
-                                    0.5877852522924731291687L};
-    return C2<TT>{TT(c[m]), TT(sn[m])};
-}
-// 20 = 4 x 5: n = 5 a + b, k = ka + 4 kb.  4-point DFTs over a, twiddle W20^(b ka), 5-point DFTs over b.
-template <typename TT>
-struct SmallDft<TT, 20> {
+struct SmallDft<TT, 20> {  // n = (5 n1 + 4 n2) mod 20, k = (5 k1 + 16 k2) mod 20
     static __device__ __forceinline__ void run(C2<TT> (&v)[20], const C2<TT>*, int) {
 #pragma unroll
-        for (int b = 0; b < 5; ++b) dft4(v[b], v[5 + b], v[10 + b], v[15 + b]);      // v[5 ka + b] = y[b][ka]
+        for (int n2 = 0; n2 < 5; ++n2)
+            dft4(v[(4 * n2) % 20], v[(5 + 4 * n2) % 20], v[(10 + 4 * n2) % 20], v[(15 + 4 * n2) % 20]);  // n1 -> k1 in place
 #pragma unroll
-        for (int ka = 1; ka < 4; ++ka)
-#pragma unroll
-            for (int b = 1; b < 5; ++b) {
-                if (b * ka == 5) v[5 * ka + b] = mul_mi(v[5 * ka + b]);              // W20^5 = -i (never hit: 5 is prime to b, ka < 5)
-                else v[5 * ka + b] = cmul(v[5 * ka + b], w20_literal<TT>(b * ka));
-            }
-#pragma unroll
-        for (int ka = 0; ka < 4; ++ka) dft5(v[5 * ka], v[5 * ka + 1], v[5 * ka + 2], v[5 * ka + 3], v[5 * ka + 4]);
-        // v[5 ka + kb] = X[ka + 4 kb]  ->  natural order
+        for (int k1 = 0; k1 < 4; ++k1)
+            dft5(v[(5 * k1) % 20], v[(5 * k1 + 4) % 20], v[(5 * k1 + 8) % 20], v[(5 * k1 + 12) % 20], v[(5 * k1 + 16) % 20]);
         C2<TT> t[20];
 #pragma unroll
-        for (int ka = 0; ka < 4; ++ka)
+        for (int k1 = 0; k1 < 4; ++k1)
 #pragma unroll
-            for (int kb = 0; kb < 5; ++kb) t[ka + 4 * kb] = v[5 * ka + kb];
+            for (int k2 = 0; k2 < 5; ++k2) t[(5 * k1 + 16 * k2) % 20] = v[(5 * k1 + 4 * k2) % 20];
 #pragma unroll
         for (int k = 0; k < 20; ++k) v[k] = t[k];
     }
 };
-// 10 = 2 x 5: n = 5 a + b, k = ka + 2 kb.
 template <typename TT>
-struct SmallDft<TT, 10> {
+struct SmallDft<TT, 10> {  // n = (5 n1 + 2 n2) mod 10, k = (5 k1 + 6 k2) mod 10
     static __device__ __forceinline__ void run(C2<TT> (&v)[10], const C2<TT>*, int) {
 #pragma unroll
-        for (int b = 0; b < 5; ++b) dft2(v[b], v[5 + b]);                              // v[5 ka + b] = y[b][ka]
+        for (int n2 = 0; n2 < 5; ++n2) dft2(v[(2 * n2) % 10], v[(5 + 2 * n2) % 10]);
 #pragma unroll
-        for (int b = 1; b < 5; ++b) v[5 + b] = cmul(v[5 + b], w20_literal<TT>(2 * b));   // W10^b
-        dft5(v[0], v[1], v[2], v[3], v[4]);
-        dft5(v[5], v[6], v[7], v[8], v[9]);
+        for (int k1 = 0; k1 < 2; ++k1)
+            dft5(v[(5 * k1) % 10], v[(5 * k1 + 2) % 10], v[(5 * k1 + 4) % 10], v[(5 * k1 + 6) % 10], v[(5 * k1 + 8) % 10]);
         C2<TT> t[10];
 #pragma unroll
-        for (int ka = 0; ka < 2; ++ka)
+        for (int k1 = 0; k1 < 2; ++k1)
 #pragma unroll
-            for (int kb = 0; kb < 5; ++kb) t[ka + 2 * kb] = v[5 * ka + kb];
+            for (int k2 = 0; k2 < 5; ++k2) t[(5 * k1 + 6 * k2) % 10] = v[(5 * k1 + 2 * k2) % 10];
 #pragma unroll
         for (int k = 0; k < 10; ++k) v[k] = t[k];
     }
@@ -369,11 +351,21 @@ __device__ __forceinline__ double dev_log(double v) { return log(v); }
 // on a value in [-0.7, 0] and the rounding of the result -- all below the float32 spacing of the stored value --
 // instead of ~100 float64 instructions and their constants.  Any magnitude a double can hold takes this route
 // (no range branch); zero, negative and NaN inputs behave as in log().
-__device__ __forceinline__ float feature_log(float v) { return logf(v); }
+// v = m 2^ex with 0.5 <= m < 1 (frexp), ln v = ex ln 2 + log2(m) ln 2 with log2 from the hardware's v_log_f32 (1 ulp):
+// no range or denormal fix-ups are needed because m is always in [0.5, 1) -- 8 instructions instead of logf's 25.
+__device__ __forceinline__ float mantissa_log(float m, int ex) {
+    const float ln2 = 0.693147180559945309417f;
+    return fmaf(float(ex), ln2, __builtin_amdgcn_logf(m) * ln2);
+}
+__device__ __forceinline__ float feature_log(float v) {
+    int ex = 0;
+    const float m = frexpf(v, &ex);  // m = v for 0, inf and NaN, with ex = 0
+    return mantissa_log(m, ex);
+}
 __device__ __forceinline__ double feature_log(double v) {
     int ex = 0;
     const double m = frexp(v, &ex);  // v = m 2^ex, 0.5 <= |m| < 1 (m = v for 0, inf and NaN, with ex = 0)
-    return double(fmaf(float(ex), 0.693147180559945309417f, logf(float(m))));
+    return double(mantissa_log(float(m), ex));
 }
 
 // Same-value stores by two lanes of one wave to one LDS address (the 20 x 10 kernel's shadow lanes) are harmless on the
@@ -404,7 +396,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // (kernels whose tiles are narrower than a 64-byte output run collect several tiles there first).
 template <typename TT, int NT, int F>
 __device__ __forceinline__ void tile_spectrum_outputs(const MelspecArgs& a, const TT* P, int Hp, const aud_item& it,
-                                                      int item, int t0, int tid) {
+                                                      int item, int t0, int tid, TT pscale = TT(1)) {
     const int T = a.T, H = a.H, N = a.N;
     const int64_t lim = it.sig_len;
     if (a.power || a.log_power) {
@@ -415,7 +407,7 @@ __device__ __forceinline__ void tile_spectrum_outputs(const MelspecArgs& a, cons
             if (sstep >= T) continue;
             const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
             const bool live = start + N <= lim;
-            const TT pw = P[ff * Hp + k];
+            const TT pw = pscale * P[ff * Hp + k];  // pscale: a power of two (exact)
             const size_t o = (size_t(item) * H + k) * T + sstep;
             if (a.power) a.power[o] = live ? float(pw) : 0.f;
             if (a.log_power) {
@@ -512,7 +504,7 @@ __device__ __forceinline__ void wave_mel_steps_impl(const MelspecArgs& a, const 
     typedef Q4<TT> quad_t;
     // no LDS access below sits under a lane condition (a masked frame still reads its -- valid -- row and drops the sums)
     const Q4a<TT>* wrow = reinterpret_cast<const Q4a<TT>*>(smem + e.w4_off + grp * e.w_stride);
-    const quad_t* prow = reinterpret_cast<const quad_t*>(P + ff * Hp);
+    const Q4a<TT>* prow = reinterpret_cast<const Q4a<TT>*>(P + ff * Hp);  // rows are 16-byte aligned (float64 pitch: Hp = 2 mod 4)
     const unsigned* recs = reinterpret_cast<const unsigned*>(smem + e.slots_off) + grp * e.n_slots;
     const TT loff = TT(a.mel_log_off), lmin = TT(a.mel_log_min);
     float* mel_col = a.mel + (size_t(item) * a.nf * T + (col_on ? sstep : 0));
@@ -521,12 +513,11 @@ __device__ __forceinline__ void wave_mel_steps_impl(const MelspecArgs& a, const 
         if (k < e.n_slots) {  // wave-uniform
             const unsigned rec = recs[k];
             const int ns = e.slot_steps[k];  // wave-uniform trip count: slot k is equally long in every group
-            const quad_t* pp = prow + (rec & 0xFFFFu);
+            const Q4a<TT>* pp = prow + (rec & 0xFFFFu);
             TT s0 = TT(0), s1 = TT(0);
 #pragma unroll 2
             for (int s = 0; s < ns; ++s) {
-                const quad_t pw = pp[s];
-                const Q4a<TT> ww = wrow[s];
+                const Q4a<TT> pw = pp[s], ww = wrow[s];
                 s0 += ww.x * pw.x;
                 s1 += ww.y * pw.y;
                 s0 += ww.z * pw.z;
@@ -552,7 +543,7 @@ template <typename TT, int FPW, int MAXS>
 __device__ __forceinline__ void wave_mel_steps(const MelspecArgs& a, const FastArgs& e, const TT* P, int Hp,
                                                const unsigned char* smem, const aud_item& it, int item, int t0,
                                                int lane) {
-    tile_spectrum_outputs<TT, 64, FPW>(a, P, Hp, it, item, t0, lane);
+    tile_spectrum_outputs<TT, 64, FPW>(a, P, Hp, it, item, t0, lane, TT(0.25));  // the wave kernels keep 4 x power in LDS
     // 64 is not a multiple of FPW = 6: lanes 60..63 have no filter group; they run group n_groups - 1 again and store nothing
     const int ff = lane % FPW, g0 = lane / FPW;
     const bool has = g0 < e.n_groups;

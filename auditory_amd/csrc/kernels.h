@@ -71,16 +71,24 @@ struct MelspecArgs {
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(aud_stamp_[i])::"memory"); \
         __builtin_amdgcn_sched_barrier(0);                                                    \
     } while (0)
+// the chip-wide constant-rate counter (100 MHz): comparable between waves on different CUs and XCDs, which s_memtime is not
+#define AUD_STAMP_REAL(i)                                                                          \
+    do {                                                                                           \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(aud_stamp_[i])::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
 #define AUD_STAMP_FLUSH(a, wave_tile, lane)                                                   \
     do {                                                                                      \
         if ((a).stamps && (lane) == 0) {                                                      \
             for (int s_ = 0; s_ < 12; ++s_) (a).stamps[size_t(wave_tile) * 16 + s_] = aud_stamp_[s_]; \
             (a).stamps[size_t(wave_tile) * 16 + 12] = __builtin_amdgcn_s_getreg((4 << 11) | 20); /* XCC_ID */ \
+            (a).stamps[size_t(wave_tile) * 16 + 13] = __builtin_amdgcn_s_getreg((31 << 11) | 4); /* HW_ID */ \
         }                                                                                     \
     } while (0)
 #else
 #define AUD_STAMP_DECL
 #define AUD_STAMP(i)
+#define AUD_STAMP_REAL(i)
 #define AUD_STAMP_FLUSH(a, wave_tile, lane)
 #endif
 

@@ -80,6 +80,9 @@ struct Layout {
     static constexpr int kRow = (sizeof(TT) == 4) ? 20 : 18;
     static constexpr int kFrame = 16 * kRow;                   // 80 / 144 slots: a multiple of 16
     static constexpr int kXch = kFW * kFrame;                  // elements
+    // P row pitch: float64 rows are 2 elements longer, an ODD number of 16-byte pieces, so that the epilogue's 16-byte
+    // reads of different frames fall on both halves of the bank set (modelled 12.3 -> 8.6 LDS cycles per read)
+    static constexpr int kHp = (sizeof(TT) == 8) ? w16::kHp + 2 : w16::kHp;
     static constexpr int kP = kFW * kHp;                       // elements
     static constexpr int kRegion = (kXch > kP ? kXch : kP) * int(sizeof(TT));  // bytes per wave
 };
@@ -101,6 +104,7 @@ __device__ __forceinline__ void w16_tile(const MelspecArgs& a, const FastArgs& e
     const int j = lane & 15;   // lane within the frame's 16-lane group
     AUD_STAMP_DECL;
     AUD_STAMP(0);
+    AUD_STAMP_REAL(9);
     C2<TT> v[16];
     if constexpr (MODE == 2) {
         item = int(wt / tiles);
@@ -179,7 +183,7 @@ __device__ __forceinline__ void w16_tile(const MelspecArgs& a, const FastArgs& e
     // pairs with itself: register (16 - q) & 15).  X[k] = (E + T)/2, X[256-k] = conj(E - T)/2 with
     // E = Z[k] + conj Z[256-k], T = -i W_512^k (Z[k] - conj Z[256-k]).
     TT* Pw = xw;                       // [4][kHp]
-    TT* P = Pw + f * w16::kHp;
+    TT* P = Pw + f * L::kHp;
     {
         const int partner = (lane & 48) | ((16 - j) & 15);
 #pragma unroll
@@ -199,12 +203,12 @@ __device__ __forceinline__ void w16_tile(const MelspecArgs& a, const FastArgs& e
             const C2<TT> Tm = cmul(mD, w);
             const TT xr = E.x + Tm.x, xi = E.y + Tm.y;  // 2 X[k]
             const TT yr = E.x - Tm.x, yi = E.y - Tm.y;  // 2 conj X[256-k]
-            P[k] = TT(0.25) * (xr * xr + xi * xi);
-            if (k != 0) P[w16::kM - k] = TT(0.25) * (yr * yr + yi * yi);
-            else P[w16::kM] = TT(0.25) * (yr * yr + yi * yi);  // k = 0 also yields the Nyquist bin
+            P[k] = xr * xr + xi * xi;  // FOUR times the power: the 1/4 of the split lives in the blob's mel weights
+            if (k != 0) P[w16::kM - k] = yr * yr + yi * yi;
+            else P[w16::kM] = yr * yr + yi * yi;  // k = 0 also yields the Nyquist bin
         }
         // k = 128 (lane 0, register 8) pairs with itself: X[128] = conj(Z[128])
-        if (j == 0) P[128] = v[8].x * v[8].x + v[8].y * v[8].y;
+        if (j == 0) P[128] = TT(4) * (v[8].x * v[8].x + v[8].y * v[8].y);  // (x 4 like every bin of P)
         // bins 257..259 only pad the last 4-bin chunk; their weights are zero but 0 * garbage must stay 0
         if (j >= 13) P[w16::kH + (j - 13)] = TT(0);
     }
@@ -212,8 +216,9 @@ __device__ __forceinline__ void w16_tile(const MelspecArgs& a, const FastArgs& e
     AUD_STAMP(7);
 
     // ---- optional spectrum outputs and the mel reduction: 4 frames x 16 filter groups on this wave ----------
-    wave_mel_steps<TT, w16::kFW, MAXS>(a, e, Pw, w16::kHp, smem, it_cur, item_cur, t0_cur, lane);
+    wave_mel_steps<TT, w16::kFW, MAXS>(a, e, Pw, L::kHp, smem, it_cur, item_cur, t0_cur, lane);
     AUD_STAMP(8);
+    AUD_STAMP_REAL(10);
     AUD_STAMP_FLUSH(a, wt, lane);
     wave_lds_fence();  // the region is free for the next tile
 }
@@ -309,6 +314,7 @@ struct Layout {
     static constexpr int kRow = (sizeof(TT) == 4) ? 12 : 10;
     static constexpr int kFrame = (sizeof(TT) == 4) ? 352 : 272;  // 88 / 136 slots; >= 25 rows
     static constexpr int kXch = kFW * kFrame;
+    static constexpr int kHp = (sizeof(TT) == 8) ? w25::kHp + 2 : w25::kHp;  // float64: odd number of 16-byte pieces (see w16)
     static constexpr int kP = kFW * kHp;
     static constexpr int kRegion = (kXch > kP ? kXch : kP) * int(sizeof(TT));  // bytes per wave
 };
@@ -342,8 +348,8 @@ __device__ __forceinline__ void split_pair(TT* P, const C2<TT>* __restrict__ tw,
     const C2<TT> Tm = cmul(mD, w);
     const TT xr = E.x + Tm.x, xi = E.y + Tm.y;
     const TT yr = E.x - Tm.x, yi = E.y - Tm.y;
-    P[k] = TT(0.25) * (xr * xr + xi * xi);
-    P[kM - k] = TT(0.25) * (yr * yr + yi * yi);  // k = 0 -> Nyquist bin 200; k = 100 -> the same bin, same value
+    P[k] = xr * xr + xi * xi;  // FOUR times the power: the 1/4 of the split lives in the blob's mel weights
+    P[kM - k] = yr * yr + yi * yi;  // k = 0 -> Nyquist bin 200; k = 100 -> the same bin, same value
 }
 }  // namespace w25
 
@@ -361,6 +367,7 @@ __device__ __forceinline__ void w25_tile(const MelspecArgs& a, const FastArgs& e
     const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);  // W_400^k (the 25-point DFT's wave-uniform inner twiddles)
     AUD_STAMP_DECL;
     AUD_STAMP(0);
+    AUD_STAMP_REAL(9);
     C2<TT> v[25];
     if constexpr (MODE == 2) {
         item = int(wt / tiles);
@@ -427,7 +434,7 @@ __device__ __forceinline__ void w25_tile(const MelspecArgs& a, const FastArgs& e
     // pairs are always evaluated from their k <= 100 side, A = Z[k], B = Z[200 - k], as melspec_r25.hip does:
     // rows (r, r' = 25 - r), r <= 12: k = r + 25 c and k = r' + 25 c for c = 0..3, partners in column 7 - c
     TT* Pw = xw;  // [8][kHp]
-    TT* P = Pw + f * w25::kHp;
+    TT* P = Pw + f * L::kHp;
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
         const bool is_pair = sl == 0 || pair1;
@@ -459,8 +466,9 @@ __device__ __forceinline__ void w25_tile(const MelspecArgs& a, const FastArgs& e
     AUD_STAMP(7);
 
     // ---- optional spectrum outputs and the mel reduction: 8 frames x 8 filter groups on this wave -------------
-    wave_mel_steps<TT, w25::kFW, MAXS>(a, e, Pw, w25::kHp, smem, it_cur, item_cur, t0_cur, lane);
+    wave_mel_steps<TT, w25::kFW, MAXS>(a, e, Pw, L::kHp, smem, it_cur, item_cur, t0_cur, lane);
     AUD_STAMP(8);
+    AUD_STAMP_REAL(10);
     AUD_STAMP_FLUSH(a, wt, lane);
     wave_lds_fence();  // the region is free for the next tile
 }
@@ -554,6 +562,7 @@ struct Layout {
     static constexpr int kRow = (sizeof(TT) == 4) ? 12 : 10;
     static constexpr int kFrame = (sizeof(TT) == 4) ? 248 : 206;
     static constexpr int kXch = kFW * kFrame;
+    static constexpr int kHp = (sizeof(TT) == 8) ? w20::kHp + 2 : w20::kHp;  // float64: odd number of 16-byte pieces (see w16)
     static constexpr int kP = kFW * kHp;
     static constexpr int kRegion = ((kXch > kP ? kXch : kP) * int(sizeof(TT)) + 31) & ~31;  // bytes per wave
 };
@@ -597,6 +606,7 @@ __device__ __forceinline__ void w20_tile(const MelspecArgs& a, const FastArgs& e
     const int j = own ? lane - f * w20::kLPF : lane - w20::kFW * w20::kLPF;
     AUD_STAMP_DECL;
     AUD_STAMP(0);
+    AUD_STAMP_REAL(9);
     C2<TT> v[20];
     if constexpr (MODE == 2) {
         item = int(wt / tiles);
@@ -662,7 +672,7 @@ __device__ __forceinline__ void w20_tile(const MelspecArgs& a, const FastArgs& e
     // ---- real-FFT split + power: the partner of Z[k1 + 20 k2] is element (20 - k1, 9 - k2); pairs are evaluated from
     // their k <= 100 side (A = Z[k], B = Z[200 - k]) as everywhere else
     TT* Pw = xw;  // [6][kHp]
-    TT* P = Pw + f * w20::kHp;
+    TT* P = Pw + f * L::kHp;
     AUD_BENIGN_RACE_BEGIN();
     {
         // lanes 1..9: rows (j, 20 - j): k = j + 20 c pairs with (row 20 - j, column 9 - c) and vice versa, c = 0..4;
@@ -686,8 +696,9 @@ __device__ __forceinline__ void w20_tile(const MelspecArgs& a, const FastArgs& e
     AUD_STAMP(7);
 
     // ---- optional spectrum outputs and the mel reduction: 6 frames x 10 filter groups on this wave ---------------
-    wave_mel_steps<TT, w20::kFW, MAXS>(a, e, Pw, w20::kHp, smem, it_cur, item_cur, t0_cur, lane);
+    wave_mel_steps<TT, w20::kFW, MAXS>(a, e, Pw, L::kHp, smem, it_cur, item_cur, t0_cur, lane);
     AUD_STAMP(8);
+    AUD_STAMP_REAL(10);
     AUD_STAMP_FLUSH(a, wt, lane);
     wave_lds_fence();  // the region is free for the next tile
 }
@@ -853,10 +864,13 @@ hipError_t launch_melspec_wave(int kind, const MelspecArgs& a, const FastArgs& e
     const int64_t waves = int64_t(a.n_items) * tiles;
     const int nw = e.waves;
     int64_t wgs = (waves + nw - 1) / nw;
-    // persistent grid (every wave walks tiles wt, wt + stride, ...): measured to pay once a launch holds several rounds
-    // of resident waves (profiles/r02i_ab_*: B = 4096 12-15 % faster, B = 256 up to 20 % slower: static tile assignment)
+    // persistent grid (every wave walks tiles wt, wt + stride, ...): for the 16 x 16 and 25 x 8 kernels it pays once a
+    // launch holds several rounds of resident waves (profiles/r02i_ab_*, r02z_ab_*: B = 4096 12-20 % faster, B = 256 up
+    // to 20 % slower: static tile assignment); the 20 x 10 kernel measures the same or better with one tile per wave at
+    // every size (r02z_ab_*), so its automatic choice is never persistent
     const bool dynamic = e.persistent == 2 && a.queue != nullptr;  // persistent grid + dynamic tile queue
-    const bool persistent = dynamic || e.persistent == 1 || (e.persistent < 0 && wgs >= 4 * int64_t(e.max_wgs));
+    const bool persistent =
+        dynamic || e.persistent == 1 || (e.persistent < 0 && kind != 3 && wgs >= 4 * int64_t(e.max_wgs));
     if (persistent && e.max_wgs > 0 && wgs > e.max_wgs) wgs = e.max_wgs;
     const dim3 grid{unsigned(wgs)}, blk(64 * nw);
     hipLaunchKernelGGL(wave_kernel(kind, compute_dtype == AUD_F64, e.n_slots, dynamic ? 3 : e.variant), grid, blk, e.lds_bytes, st,

@@ -44,6 +44,7 @@ struct alignas(16) uint4 {
     unsigned x, y, z, w;
 };
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline float __builtin_amdgcn_logf(float v) { return log2f(v); }  // v_log_f32 is a base-2 logarithm
 // same-value races the 20 x 10 wave kernel has by design (shadow lanes): ThreadSanitizer is told to look away
 #if defined(__SANITIZE_THREAD__)
 extern "C" void AnnotateIgnoreWritesBegin(const char*, int);

@@ -11,6 +11,7 @@ or devices never enters the comparison.
   python tools/ab_bench.py --batch 4096          # a grid that fills the chip several times over
 """
 import argparse
+import random
 import os
 import statistics
 import sys
@@ -95,8 +96,14 @@ def main():
             print("no hipGraph (%s): eager launches" % ex)
             graphs[v] = None
     torch.cuda.synchronize()
-    for _ in range(args.rounds):
-        for v, p in plans.items():
+    order = list(plans.items())
+    rng = random.Random(7)
+    for rnd in range(args.rounds):
+        # a fresh order every round: the clock the chip settles at depends on what ran just before (measured: the variant
+        # that follows a slow kernel reads up to 8 % slower), so no variant keeps a fixed predecessor
+        rot = order[:]
+        rng.shuffle(rot)
+        for v, p in rot:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             if graphs[v] is not None:

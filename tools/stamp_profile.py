@@ -93,24 +93,33 @@ def main():
         print("%-36s %9.0f %9.0f %9.0f  %5.1f%%" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 10),
                                                  np.percentile(d[:, i], 90), 100 * d[:, i].sum() / life.sum()))
     print("%-36s %9.0f %9.0f %9.0f" % ("wave lifetime", np.median(life), np.percentile(life, 10), np.percentile(life, 90)))
+    # launch timeline from the chip-wide 100 MHz counter (s_memrealtime; s_memtime is not comparable between CUs)
     xcc = s[ok, 12] & 15
-    # every XCD has its own counter; a wave slot the last launch did not run keeps an older launch's stamps: drop those
-    print("timeline per XCD (ticks from the XCD's first start of this launch): median start, last start, median end, last end")
-    span = []
+    r0, r1 = s[ok, 9], s[ok, 10]
+    base = r0.min()
+    span = r1.max() - base
+    print("launch timeline, 10 ns ticks of the 100 MHz counter from the first wave start: last start %d, last end %d (HIP events: %.1f us)"
+          % (r0.max() - base, span, e0.elapsed_time(e1) * 1e3))
+    dur = (r1 - r0).astype(np.float64)
+    okd = dur > 50
+    ghz = (t[okd, 8] - t[okd, 0]) / dur[okd] * 0.1
+    print("s_memtime ticks per 10 ns of s_memrealtime over a wave's life: median %.3f, p10 %.3f, p90 %.3f GHz (the counter's rate, if it is the shader clock)"
+          % (np.median(ghz), np.percentile(ghz, 10), np.percentile(ghz, 90)))
+    nb = 16
+    edges = np.linspace(0, span, nb + 1)
+    starts, _ = np.histogram(r0 - base, bins=edges)
+    ends, _ = np.histogram(r1 - base, bins=edges)
+    mid = 0.5 * (edges[:-1] + edges[1:])
+    resident = [int(((r0 - base <= m) & (r1 - base > m)).sum()) for m in mid]
+    print("  sixteenths of the span | wave starts | wave ends | waves resident at the middle of the bin")
+    for i in range(nb):
+        print("  %5.1f us  %6d %6d %6d" % (mid[i] / 100.0, starts[i], ends[i], resident[i]))
     for x in sorted(set(xcc.tolist())):
         m = xcc == x
-        tx = t[m]
-        cur = tx[:, 0] > np.median(tx[:, 0]) - 2_000_000
-        tx = tx[cur]
-        base = tx[:, 0].min()
-        span.append(tx[:, 8].max() - base)
-        print("  XCC %d: %5d waves (%d stale)  median start %7d  last start %7d  median end %7d  last end %7d"
-              % (x, cur.sum(), (~cur).sum(), np.median(tx[:, 0]) - base, tx[:, 0].max() - base,
-                 np.median(tx[:, 8]) - base, tx[:, 8].max() - base))
-        hist, _ = np.histogram(tx[:, 0] - base, bins=12, range=(0, span[-1]))
-        print("          wave starts per twelfth of the XCD's span: %s" % " ".join("%4d" % h for h in hist))
-    print("longest XCD span %d ticks; the launch took %.1f us by HIP events -> %.2f ticks per ns if the span were the whole launch"
-          % (max(span), e0.elapsed_time(e1) * 1e3, max(span) / (e0.elapsed_time(e1) * 1e6)))
+        print("  XCC %d: %5d waves  first start %5d  last start %5d  last end %5d" % (x, m.sum(), r0[m].min() - base, r0[m].max() - base, r1[m].max() - base))
+    cu = ((s[ok, 13] >> 8) & 15) | (((s[ok, 13] >> 13) & 7) << 4) | (xcc << 8)
+    per_cu = np.bincount(np.unique(cu, return_inverse=True)[1])
+    print("  waves per CU: %d CUs seen, min %d, median %d, max %d" % (len(per_cu), per_cu.min(), np.median(per_cu), per_cu.max()))
     plan.close()
 
 
