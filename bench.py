@@ -240,6 +240,9 @@ def main():  # noqa: C901
     ap.add_argument("--ring-mb", type=float, default=320.0, help="resident input ring per GPU (> the 256 MB Infinity Cache)")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="minimum device time of a timed region")
     ap.add_argument("--launch", choices=["graph", "eager"], default="graph")
+    ap.add_argument("--graph-steps", type=int, default=200,
+                    help="steps one captured hipGraph holds: the requested --steps repeated until at least this many, so "
+                         "that the fork/join of the streams at the two ends of a replay is not what is timed")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are dealt over round-robin inside the graph (independent resident batches, "
                          "own output buffers): 1 = every step waits for the previous one; 2 (default) = consecutive launches "
@@ -325,6 +328,7 @@ def main():  # noqa: C901
                 raise RuntimeError("hot path launch: %d %s" % (rc, lib.aud_last_error(plan.ctx.handle)))
 
         cur = lambda: torch.cuda.current_stream(dev).cuda_stream  # noqa: E731
+        GK = K * max(1, -(-args.graph_steps // K)) if args.launch == "graph" else K   # steps per replay: a multiple of K
         for i in range(args.warmup):
             launch(i, cur())
         sync_all()
@@ -337,23 +341,24 @@ def main():  # noqa: C901
                     for sst in side:
                         sst.wait_stream(main)
                     lanes = [main] + side
-                    for i in range(K):
+                    for i in range(GK):
                         launch(i, lanes[i % n_streams].cuda_stream)
                     for sst in side:
                         main.wait_stream(sst)
                 graph.replay()
                 torch.cuda.synchronize(dev)
-                launch_mode = "hipGraph of %d steps" % K
+                launch_mode = "hipGraph of %d steps" % GK + (" (%d x the %d requested)" % (GK // K, K) if GK != K else "")
             except Exception as ex:  # capture unsupported here (CPU dry run): say so and time eager launches
                 print("WARNING: hipGraph capture failed (%s); timing eager launches" % ex, file=sys.stderr)
                 graph = None
+                GK = K
                 torch.cuda.synchronize(dev)
 
         def replay():
             if graph is not None:
                 graph.replay()
             else:
-                for i in range(K):
+                for i in range(GK):
                     launch(i, cur())
 
         # calibrate the number of replays: >= --min-seconds of device time, the same count on every rank
@@ -373,8 +378,8 @@ def main():  # noqa: C901
             evs[r + 1].record()
         sync_all()
         elapsed = max_over_ranks(time.perf_counter() - t0)
-        per_step_us = np.array([evs[r].elapsed_time(evs[r + 1]) for r in range(reps)]) * 1e3 / K
-        steps = K * reps
+        per_step_us = np.array([evs[r].elapsed_time(evs[r + 1]) for r in range(reps)]) * 1e3 / GK
+        steps = GK * reps
         audio_s = B * world * wl.dur_s
         alg = B * (ring.sample_bytes * wl.dur + 4 * wl.nf * wl.T)       # each sample read once + each mel value written once
         if gabor:  # unfused gabor: re-read the mel tensor, write the pooled on/off pairs
@@ -392,7 +397,7 @@ def main():  # noqa: C901
         if check and rank == 0:
             # parity of the TIMED outputs: all of ring buffer 0, plus 16 streams of two other buffers
             osd = OracleSide(wl)
-            touched = min(ring.R, K)                                   # ring buffers the timed steps wrote
+            touched = min(ring.R, GK)                                  # ring buffers the timed steps wrote
             n0 = min(B, 256 if wl.dur_s <= 1.0 else 24)                 # long streams: a smaller sample (the oracle is ~150 audio-s/s)
             picks = [(0, np.arange(n0))] + [(r, np.arange(0, B, max(1, B // 16))[:16 if wl.dur_s <= 1.0 else 4])
                                             for r in sorted({touched // 2, touched - 1} - {0})]

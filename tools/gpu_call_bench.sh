@@ -12,7 +12,7 @@ for f in ("driver","default"):
     except Exception as e:
         print(f, "no json", e); continue
     print(f, d["value"], d["steps"], d["ms_per_step"], d["us_per_step_device"], d["roofline"]["frac"], d["parity"]["max_scaled_err"], d["parity"]["n_past_1e-5"])
-    for k,v in (d.get("modes") or {}).items(): print("  mode", k, v["value"], v["us_per_step_device"]["median"], v["parity"]["max_scaled_err"], v["parity"]["n_past_1e-5"])
-    for k,v in (d.get("also") or {}).items(): print("  also", k, v["value"], v["us_per_step_device"]["median"], v["parity"]["max_scaled_err"], v["parity"]["n_past_1e-5"])
+    for k,v in (d.get("modes") or {}).items(): print("  mode", k, v["value"], v["us_per_step_device"]["median"], (v.get("parity") or {}).get("max_scaled_err"), (v.get("parity") or {}).get("n_past_1e-5"))
+    for k,v in (d.get("also") or {}).items(): print("  also", k, v["value"], v["us_per_step_device"]["median"], (v.get("parity") or {}).get("max_scaled_err"), (v.get("parity") or {}).get("n_past_1e-5"))
     print("  cfg3", d.get("cfg3")); print("  cpu", d.get("cpu_baseline"))
 PY
