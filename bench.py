@@ -14,13 +14,15 @@ and reported beside the headline ("modes"), never as `value`.  Every mode carrie
 outputs of several ring buffers checked against the oracle under the strict criterion |d| <= 1e-5 max(1, |ref|); a
 headline mode with an element past it makes the run exit non-zero without a JSON line.
 
-The K steps asked for are captured into one hipGraph (a ~20 us kernel is otherwise bound by the Python launch path) and
-that graph is replayed back to back until at least --min-seconds of device time have passed; `steps` in the JSON line is
-the number of steps actually timed (K x repeats), bracketed by a barrier + synchronize on both sides, max over ranks.
+The K steps asked for are captured into one hipGraph (a ~20 us kernel is otherwise bound by the Python launch path) --
+repeated inside the graph until it holds at least --graph-steps (200) steps, so that the fork / join of the streams at
+the ends of a replay is not what is timed -- and that graph is replayed back to back until at least --min-seconds of
+device time have passed; `steps` in the JSON line is the number of steps actually timed (graph steps x repeats),
+bracketed by a barrier + synchronize on both sides, max over ranks.
 Inside the graph consecutive steps alternate between two streams (--streams 2, the default): the steps are independent
-batches with their own output buffers, and a launch of 256 utterances is a burst of 1.6 rounds of resident waves whose
+batches with their own output buffers, and a launch of 256 utterances is a burst of 1.5 rounds of resident waves whose
 load phase and tail leave the chip half idle -- overlapping step i+1's start with step i's tail is what a double-buffered
-pipeline does (35.0 -> 23.4 us per step).  `roofline` is priced on the kernel ALONE (a one-stream region of the same run).
+pipeline does (27.1 -> 16.3 us per step).  `roofline` is priced on the kernel ALONE (a one-stream region of the same run).
 
   python bench.py                                    # 1 GPU
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
