@@ -265,12 +265,11 @@ __device__ __forceinline__ TT pcm16_to(int v) {
 
 // First-pass operands of one frame for the register-resident kernels: the frame's N samples as N/2 packed
 // pairs z[n] = (x[2n], x[2n+1]); this lane takes z[lane + STRIDE n1], n1 = 0..NV-1.  Three routes:
-//   1 float32 samples, frame inside the stream, pairs 8-byte aligned: one 8-byte load per pair (widened to the
-//     compute type in registers);
-//   2 int16 samples under the same conditions (4-byte aligned): one 4-byte load per pair, normalised on the fly
-//     (half the input bytes of the float route);
-//   0 anything else (stream edges, left zero pad, float64 samples, odd offsets, strided streams): guarded
-//     element loads.
+//   1 float32 samples, frame inside the stream: one 8-byte load per pair (two 4-byte loads where the frame starts on
+//     an odd sample), widened to the compute type in registers;
+//   2 int16 samples under the same conditions: one 4-byte load per pair (two 2-byte loads on odd starts), normalised
+//     on the fly (half the input bytes of the float route);
+//   0 anything else (stream edges, left zero pad, float64 samples, strided streams): guarded element loads.
 // Split in two so that a persistent kernel can request the next tile's operands before it computes the current
 // one: frame_pairs_issue() only issues the loads of routes 1 / 2 (raw words, no wait), frame_pairs_take() converts
 // them -- or runs route 0 on the spot.
@@ -284,21 +283,39 @@ __device__ __forceinline__ void frame_pairs_issue(const MelspecArgs& a, const au
                                                   FrameRaw<NV>& r) {
     const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
     const int64_t pos0 = start + 2 * lane;
-    const bool inside = sstep < a.T && start >= 0 && start + N <= int64_t(it.sig_len) && it.sig_stride <= 1 &&
-                        ((it.sig_off + start) & 1) == 0;
+    const bool inside = sstep < a.T && start >= 0 && start + N <= int64_t(it.sig_len) && it.sig_stride <= 1;
+    // a frame that starts on an odd sample (odd step lengths: 441 at 44.1 kHz) has pairs that straddle the 8-byte
+    // (int16: 4-byte) grid: its pairs are fetched as two element loads each -- same raw words, same conversion
+    const bool even = ((it.sig_off + start) & 1) == 0;
     r.route = 0;
     if (inside && a.sig_dtype == AUD_F32 && (reinterpret_cast<uintptr_t>(a.sig) & 7) == 0) {
-        const uint2* __restrict__ src = reinterpret_cast<const uint2*>(static_cast<const float*>(a.sig) + it.sig_off + pos0);
+        if (even) {
+            const uint2* __restrict__ src =
+                reinterpret_cast<const uint2*>(static_cast<const float*>(a.sig) + it.sig_off + pos0);
 #pragma unroll
-        for (int n1 = 0; n1 < NV; ++n1) r.w[n1] = src[STRIDE * n1];
+            for (int n1 = 0; n1 < NV; ++n1) r.w[n1] = src[STRIDE * n1];
+        } else {
+            const uint32_t* __restrict__ src =
+                reinterpret_cast<const uint32_t*>(static_cast<const float*>(a.sig) + it.sig_off + pos0);
+#pragma unroll
+            for (int n1 = 0; n1 < NV; ++n1) r.w[n1] = uint2{src[2 * STRIDE * n1], src[2 * STRIDE * n1 + 1]};
+        }
         r.route = 1;
     }
     if constexpr (PCM16_ROUTE) {
         if (inside && a.sig_dtype == AUD_I16 && (reinterpret_cast<uintptr_t>(a.sig) & 3) == 0) {
-            const uint32_t* __restrict__ src =
-                reinterpret_cast<const uint32_t*>(static_cast<const int16_t*>(a.sig) + it.sig_off + pos0);
+            if (even) {
+                const uint32_t* __restrict__ src =
+                    reinterpret_cast<const uint32_t*>(static_cast<const int16_t*>(a.sig) + it.sig_off + pos0);
 #pragma unroll
-            for (int n1 = 0; n1 < NV; ++n1) r.w[n1].x = src[STRIDE * n1];
+                for (int n1 = 0; n1 < NV; ++n1) r.w[n1].x = src[STRIDE * n1];
+            } else {
+                const unsigned short* __restrict__ src =
+                    reinterpret_cast<const unsigned short*>(static_cast<const int16_t*>(a.sig) + it.sig_off + pos0);
+#pragma unroll
+                for (int n1 = 0; n1 < NV; ++n1)
+                    r.w[n1].x = uint32_t(src[2 * STRIDE * n1]) | (uint32_t(src[2 * STRIDE * n1 + 1]) << 16);
+            }
             r.route = 2;
         }
     }
@@ -496,34 +513,50 @@ __device__ __forceinline__ void tile_epilogue(const MelspecArgs& a, const FastAr
 // dependent chain per filter and took 27 % of a wave's life, profiles/r02c_stamps_*); logarithms and stores follow
 // for all slots at once.  Products are the reference's; the additions are pairwise inside a chunk and in bin order
 // across chunks (float64: far below the float32 spacing of the stored value).
-template <typename TT, int FPW, int MAXS>
+template <typename TT, int FPW, int MAXS, bool COMPACT>
 __device__ __forceinline__ void wave_mel_steps_impl(const MelspecArgs& a, const FastArgs& e, const TT* P, int Hp,
                                                     const unsigned char* smem, int item, int sstep, bool col_on,
                                                     bool live, int ff, int grp) {
     const int T = a.T;
-    typedef Q4<TT> quad_t;
     // no LDS access below sits under a lane condition (a masked frame still reads its -- valid -- row and drops the sums)
-    const Q4a<TT>* wrow = reinterpret_cast<const Q4a<TT>*>(smem + e.w4_off + grp * e.w_stride);
+    // COMPACT (one filter group per lane, w64x16): a filter's row holds only its own chunks, steps past its end read the
+    // table's shared zero chunk; otherwise every group's row has the slot's full length
+    const Q4a<TT>* wrow = reinterpret_cast<const Q4a<TT>*>(smem + e.w4_off + (COMPACT ? 0 : grp * e.w_stride));
     const Q4a<TT>* prow = reinterpret_cast<const Q4a<TT>*>(P + ff * Hp);  // rows are 16-byte aligned (float64 pitch: Hp = 2 mod 4)
-    const unsigned* recs = reinterpret_cast<const unsigned*>(smem + e.slots_off) + grp * e.n_slots;
+    const unsigned* recs = reinterpret_cast<const unsigned*>(smem + e.slots_off) + grp * e.n_slots * (COMPACT ? 2 : 1);
     const TT loff = TT(a.mel_log_off), lmin = TT(a.mel_log_min);
     float* mel_col = a.mel + (size_t(item) * a.nf * T + (col_on ? sstep : 0));
 #pragma unroll
     for (int k = 0; k < MAXS; ++k) {
         if (k < e.n_slots) {  // wave-uniform
-            const unsigned rec = recs[k];
+            const unsigned rec = recs[COMPACT ? 2 * k : k];
             const int ns = e.slot_steps[k];  // wave-uniform trip count: slot k is equally long in every group
             const Q4a<TT>* pp = prow + (rec & 0xFFFFu);
             TT s0 = TT(0), s1 = TT(0);
+            if constexpr (COMPACT) {
+                const unsigned row = recs[2 * k + 1];
+                const int own = int(row >> 16);
+                const unsigned char* wown = reinterpret_cast<const unsigned char*>(wrow) + 16 * (row & 0xFFFFu);  // rows start on any 16-byte piece
 #pragma unroll 2
-            for (int s = 0; s < ns; ++s) {
-                const Q4a<TT> pw = pp[s], ww = wrow[s];
-                s0 += ww.x * pw.x;
-                s1 += ww.y * pw.y;
-                s0 += ww.z * pw.z;
-                s1 += ww.w * pw.w;
+                for (int s = 0; s < ns; ++s) {
+                    const Q4a<TT> pw = pp[s];
+                    const Q4a<TT> ww = *(s < own ? reinterpret_cast<const Q4a<TT>*>(wown) + s : wrow);  // wrow[0] = the zero chunk
+                    s0 += ww.x * pw.x;
+                    s1 += ww.y * pw.y;
+                    s0 += ww.z * pw.z;
+                    s1 += ww.w * pw.w;
+                }
+            } else {
+#pragma unroll 2
+                for (int s = 0; s < ns; ++s) {
+                    const Q4a<TT> pw = pp[s], ww = wrow[s];
+                    s0 += ww.x * pw.x;
+                    s1 += ww.y * pw.y;
+                    s0 += ww.z * pw.z;
+                    s1 += ww.w * pw.w;
+                }
+                wrow += ns;
             }
-            wrow += ns;
             const int flt = int(rec >> 16);
             const TT sum = (s0 + s1) + loff;
             TT val = (sum == TT(0)) ? lmin : feature_log(sum);
@@ -539,7 +572,7 @@ __device__ __forceinline__ void wave_mel_steps_impl(const MelspecArgs& a, const 
     }
 }
 
-template <typename TT, int FPW, int MAXS>
+template <typename TT, int FPW, int MAXS, bool COMPACT = false>
 __device__ __forceinline__ void wave_mel_steps(const MelspecArgs& a, const FastArgs& e, const TT* P, int Hp,
                                                const unsigned char* smem, const aud_item& it, int item, int t0,
                                                int lane) {
@@ -552,7 +585,7 @@ __device__ __forceinline__ void wave_mel_steps(const MelspecArgs& a, const FastA
     const bool col_on = has && sstep < a.T;
     const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
     const bool live = col_on && start + a.N <= int64_t(it.sig_len);
-    wave_mel_steps_impl<TT, FPW, MAXS>(a, e, P, Hp, smem, item, sstep, col_on, live, ff, grp);  // e.n_slots <= MAXS (host)
+    wave_mel_steps_impl<TT, FPW, MAXS, COMPACT>(a, e, P, Hp, smem, item, sstep, col_on, live, ff, grp);  // e.n_slots <= MAXS (host)
 }
 
 // ---- mel on the matrix pipe (float32 only; an experiment the plan can switch on) -------------------

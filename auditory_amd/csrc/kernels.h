@@ -142,6 +142,8 @@ struct FastArgs {
     unsigned char slot_steps[8];
     int twa_off;           // pass twiddles, C2<TT> [K1 - 1][lanes per frame]: W^(2 j k1)
     int tws_off;           // split twiddles, C2<TT> [N/4 + 1]: W_N^k
+    int pairs_off;         // w64x16: uint16 [64][4]: base bins of the lane's two column pairs
+    const void* gtab;      // w64x16: device, lane-ordered twiddles read from global memory ([15][64] pass 1, [2][5][64] split)
     int waves;             // waves per workgroup of the launch
     int variant;           // A/B variant of the wave kernel (plan option "wave_variant")
     int persistent;        // 1: grid capped at max_wgs, waves walk several tiles; 0: one tile per wave; -1: by launch size (plan option "wave_grid")

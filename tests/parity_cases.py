@@ -637,11 +637,12 @@ def case_n400_variants(orc, cdt, seg_ms=None, dur=1.0, rows=2, segs=(0,)):
 
 
 def case_n2048_variants(orc, cdt, seg_ms=300.0, dur=0.4, rows=2):
-    """BASELINE config 5 parameters (44.1 kHz, N = 2048, 128 mel, NaN row): r16x16x4 and generic"""
+    """BASELINE config 5 parameters (44.1 kHz, N = 2048, 128 mel, NaN row): w64x16 (default), r16x16x4 (the round-1
+    workgroup-tile kernel, option kernel = 2) and generic"""
     name = "cfg5_44k_n2048_nf128"
     fam = _fast_family(orc, name, cdt, seg_ms)
-    assert fam == "r16x16x4" or (cdt == capi.AUD_F64 and fam == "generic")
-    for opts in ({}, {"kernel": 1}):
+    assert fam == "w64x16"
+    for opts in ({}, {"kernel": 2}, {"kernel": 1}):
         case_melspec_vs_oracle(orc, (name, dur, rows, [0, 1]), cdt, seg_ms=seg_ms, options=opts)
 
 

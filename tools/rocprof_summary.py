@@ -57,7 +57,7 @@ def main():
     # what bench.py reports as roofline.traffic: HBM bytes per launch of the frame->mel kernel
     best = None
     fams = {"k_melspec_w20": "w20x10", "k_melspec_w25": "w25x8", "k_melspec_w16": "w16x16", "k_melspec_r16": "r16x16", "k_melspec_r25": "r25x8",
-            "k_melspec_r1024": "r16x16x4", "k_melspec_generic": "generic"}
+            "k_melspec_w64": "w64x16", "k_melspec_r1024": "r16x16x4", "k_melspec_generic": "generic"}
     avg_ns = {r.get("Name", ""): float(r.get("AverageNs", r.get("Average", 0)) or 0) for r in stats}
     for k, v in traffic.items():
         if "read_bytes" in v and "write_bytes" in v:

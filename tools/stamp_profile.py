@@ -51,11 +51,11 @@ def main():
     from auditory_amd.batch import BatchProcessor
 
     dev = torch.device("cuda", 0)
-    name = {32.0: "cfg2_16k_n512_nf40", 25.0: "cfg2_16k_n400_nf40"}[args.win_ms]
-    oc = W.OracleCfg(orc, name)
+    name = {32.0: "cfg2_16k_n512_nf40", 25.0: "cfg2_16k_n400_nf40", 46.44: "cfg5_44k_n2048_nf128"}[args.win_ms]
+    oc = W.OracleCfg(orc, name, 5000.0 if args.win_ms == 46.44 else None)
     B = args.batch
     L = (oc.full_len() + 63) // 64 * 64
-    sig64, _ = synth.batch(2, min(B, 256), 16000, oc.sr, row_len=L)
+    sig64, _ = synth.batch(2, min(B, 256), L - 64, oc.sr, row_len=L)
     reps = (B + sig64.shape[0] - 1) // sig64.shape[0]
     sig = np.tile(sig64.astype(np.float32), (reps, 1))[:B]
     dsig = torch.from_numpy(sig).to(dev).view(-1)
@@ -89,9 +89,18 @@ def main():
     life = t[:, 8] - t[:, 0]
     names = PHASES if oc.N == 512 else PHASES_W25
     print("%-36s %9s %9s %9s  %6s" % ("phase (s_memtime ticks = shader cycles)", "median", "p10", "p90", "share"))
-    for i, nm in enumerate(names):
-        print("%-36s %9.0f %9.0f %9.0f  %5.1f%%" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 10),
-                                                 np.percentile(d[:, i], 90), 100 * d[:, i].sum() / life.sum()))
+    if oc.N == 2048:   # w64x16 stamps 0, 3..8 only
+        marks = [(0, 3, "0-3 operands issued and landed"), (3, 4, "3-4 pass-1 DFT16 + twiddle (global table)"),
+                 (4, 5, "4-5 LDS transpose 1 re/im"), (5, 6, "5-6 pass-2 DFT16 + twiddle + transpose 2"),
+                 (6, 7, "6-7 pass-3 DFT4 + split + power -> LDS"), (7, 8, "7-8 mel epilogue + stores")]
+        for lo, hi, nm in marks:
+            dd = t[:, hi] - t[:, lo]
+            print("%-44s %9.0f %9.0f %9.0f  %5.1f%%" % (nm, np.median(dd), np.percentile(dd, 10), np.percentile(dd, 90),
+                                                         100.0 * float(dd.sum()) / float(life.sum())))
+    else:
+        for i, nm in enumerate(names):
+            print("%-36s %9.0f %9.0f %9.0f  %5.1f%%" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 10),
+                                                     np.percentile(d[:, i], 90), 100 * d[:, i].sum() / life.sum()))
     print("%-36s %9.0f %9.0f %9.0f" % ("wave lifetime", np.median(life), np.percentile(life, 10), np.percentile(life, 90)))
     # launch timeline from the chip-wide 100 MHz counter (s_memrealtime; s_memtime is not comparable between CUs)
     xcc = s[ok, 12] & 15
