@@ -208,13 +208,17 @@ int aud_device_id(const aud_ctx* ctx);
 int aud_plan_create(aud_ctx* ctx, const aud_plan_desc* desc, const int32_t* bin_pts, const double* mel_filters,
                     const double* gabor_filters, aud_plan** plan);
 int aud_plan_destroy(aud_plan* plan);
-/* which frame->mel kernel family the plan selected: "generic", "r16x16", ... (diagnostic) */
+/* which frame->mel kernel family the plan selected: "generic", "w20x10", "r16x16", ... (diagnostic) */
 const char* aud_plan_kernel_name(const aud_plan* plan);
 /* Tuning / diagnostic switches; results are identical whatever they are set to (up to the last-place effects of a
  * different summation order between kernel families).
- *   "kernel"    0 automatic (default: the wave-autonomous kernels w16x16 / w25x8 where they exist), 1 force the generic
- *               any-N kernel, 2 the workgroup-tile kernels of round 1 (r16x16 / r25x8 / r16x16x4)
- *   "wave_grid" -1 (default) persistent grid when a launch holds >= 4 rounds of resident waves, 0 one tile per wave, 1 persistent
+ *   "kernel"    0 automatic (default: the wave-autonomous kernels where they exist: w16x16 for N = 512, w20x10 for
+ *               N = 400, w64x16 for N = 2048), 1 force the generic any-N kernel, 2 the workgroup-tile kernels of round 1
+ *               (r16x16 / r25x8 / r16x16x4)
+ *   "n400_geometry" 20 (default): the 200-point FFT of N = 400 as 20 x 10 (ten lanes per frame, six frames per wave,
+ *               three waves per SIMD in float64), 25: as 25 x 8 (w25x8: eight lanes per frame, eight frames per wave)
+ *   "wave_grid" -1 (default) w16x16 / w25x8: persistent grid when a launch holds >= 4 rounds of resident waves (w20x10 and
+ *               w64x16: never), 0 one tile per wave, 1 persistent, 2 persistent with a dynamic tile queue (A/B only)
  *   "wave_variant" 2 (default) / 0 / 1: operand prefetch variants of the persistent loop (A/B)
  *   "gabor_lds" 0 (default) the gabor kernel reads the mel matrix through L1/L2, 1 it stages the item's matrix in LDS first
  *               (where it fits 60 KB); measured on the MI355X: 9.4 vs 11.9 us per 256 items in float64, so off by default
