@@ -278,18 +278,21 @@ struct FrameRaw {
     uint2 w[NV];  // route 1: the two float bit patterns; route 2: .x = the packed int16 pair
     int route;
 };
-template <int NV, int STRIDE, int N, bool PCM16_ROUTE = true>
+template <int NV, int STRIDE, int N, bool PCM16_ROUTE = true, bool ODD_ROUTE = false>
 __device__ __forceinline__ void frame_pairs_issue(const MelspecArgs& a, const aud_item& it, int sstep, int lane,
                                                   FrameRaw<NV>& r) {
     const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
     const int64_t pos0 = start + 2 * lane;
-    const bool inside = sstep < a.T && start >= 0 && start + N <= int64_t(it.sig_len) && it.sig_stride <= 1;
     // a frame that starts on an odd sample (odd step lengths: 441 at 44.1 kHz) has pairs that straddle the 8-byte
-    // (int16: 4-byte) grid: its pairs are fetched as two element loads each -- same raw words, same conversion
+    // (int16: 4-byte) grid.  ODD_ROUTE (the one-frame-per-wave kernel, where the parity is wave-uniform): its pairs are
+    // fetched as two element loads each -- same raw words, same conversion; otherwise such frames take route 0 (in the
+    // kernels with several frames per wave the second flavour of loads under a lane condition cost 5-10 % on even frames)
     const bool even = ((it.sig_off + start) & 1) == 0;
+    const bool inside = sstep < a.T && start >= 0 && start + N <= int64_t(it.sig_len) && it.sig_stride <= 1 &&
+                        (ODD_ROUTE || even);
     r.route = 0;
     if (inside && a.sig_dtype == AUD_F32 && (reinterpret_cast<uintptr_t>(a.sig) & 7) == 0) {
-        if (even) {
+        if (!ODD_ROUTE || even) {
             const uint2* __restrict__ src =
                 reinterpret_cast<const uint2*>(static_cast<const float*>(a.sig) + it.sig_off + pos0);
 #pragma unroll
@@ -304,7 +307,7 @@ __device__ __forceinline__ void frame_pairs_issue(const MelspecArgs& a, const au
     }
     if constexpr (PCM16_ROUTE) {
         if (inside && a.sig_dtype == AUD_I16 && (reinterpret_cast<uintptr_t>(a.sig) & 3) == 0) {
-            if (even) {
+            if (!ODD_ROUTE || even) {
                 const uint32_t* __restrict__ src =
                     reinterpret_cast<const uint32_t*>(static_cast<const int16_t*>(a.sig) + it.sig_off + pos0);
 #pragma unroll
@@ -351,11 +354,11 @@ __device__ __forceinline__ void frame_pairs_take(const MelspecArgs& a, const aud
                       ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + (p + 1) * str) : TT(0);
     }
 }
-template <typename TT, int NV, int STRIDE, int N, bool PCM16_ROUTE = true>
+template <typename TT, int NV, int STRIDE, int N, bool PCM16_ROUTE = true, bool ODD_ROUTE = false>
 __device__ __forceinline__ void load_frame_pairs(const MelspecArgs& a, const aud_item& it, int sstep, int lane,
                                                  C2<TT> (&v)[NV]) {
     FrameRaw<NV> r;
-    frame_pairs_issue<NV, STRIDE, N, PCM16_ROUTE>(a, it, sstep, lane, r);
+    frame_pairs_issue<NV, STRIDE, N, PCM16_ROUTE, ODD_ROUTE>(a, it, sstep, lane, r);
     frame_pairs_take<TT, NV, STRIDE, N, PCM16_ROUTE>(a, it, sstep, lane, r, v);
 }
 

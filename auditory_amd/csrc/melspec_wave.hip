@@ -825,7 +825,7 @@ __device__ __forceinline__ void w64_tile(const MelspecArgs& a, const FastArgs& e
     AUD_STAMP(0);
     AUD_STAMP_REAL(9);
     C2<TT> v[16];
-    load_frame_pairs<TT, 16, 64, w64::kN, PCM16>(a, it, sstep, lane, v);
+    load_frame_pairs<TT, 16, 64, w64::kN, PCM16, true>(a, it, sstep, lane, v);
     AUD_STAMP(3);
 
     // ---- pass 1 ------------------------------------------------------------------------------------------------
