@@ -550,7 +550,7 @@ __device__ __forceinline__ void wave_mel_steps_impl(const MelspecArgs& a, const 
                     s1 += ww.w * pw.w;
                 }
             } else {
-#pragma unroll 2
+#pragma unroll 4
                 for (int s = 0; s < ns; ++s) {
                     const Q4a<TT> pw = pp[s], ww = wrow[s];
                     s0 += ww.x * pw.x;

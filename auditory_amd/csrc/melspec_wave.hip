@@ -623,14 +623,6 @@ __device__ __forceinline__ void w20_tile(const MelspecArgs& a, const FastArgs& e
         if (lane == 0) got = atomicAdd(a.queue, 1u);
         *queue_fetch = got;
     }
-    if constexpr (MODE == 0) {
-        if (wt_next < total) {
-            item = int(wt_next / tiles);
-            t0 = int(wt_next - int64_t(item) * tiles) * w20::kFW;
-            it = a.items[item];
-            frame_pairs_issue<20, 10, w20::kN, PCM16>(a, it, t0 + f, j, raw);
-        }
-    }
     AUD_STAMP(3);
 
     // ---- pass A: 20-point DFT over n1, twiddle W_200^(j k1) = W_400^(2 j k1) -------------------------------
@@ -663,6 +655,16 @@ __device__ __forceinline__ void w20_tile(const MelspecArgs& a, const FastArgs& e
     w20::read_row10<TT>(rows + rb * L::kRow, zb, true);
     wave_lds_fence();  // every row has been read: the region may take the power spectrum
     AUD_STAMP(5);
+    if constexpr (MODE == 0) {
+        // the next tile's operands are requested HERE, not at the top: the 40 registers of v[] are dead from this point
+        // on, so the raw words in flight do not add to the kernel's register peak (pass A + transposes)
+        if (wt_next < total) {
+            item = int(wt_next / tiles);
+            t0 = int(wt_next - int64_t(item) * tiles) * w20::kFW;
+            it = a.items[item];
+            frame_pairs_issue<20, 10, w20::kN, PCM16>(a, it, t0 + f, j, raw);
+        }
+    }
 
     // ---- pass B: 10-point DFT over n2 of both rows: Z[k1 + 20 k2] -----------------------------------------------
     SmallDft<TT, 10>::run(za, nullptr, 0);
@@ -1053,7 +1055,7 @@ static wave_kernel_t wave_kernel(int kind, bool f64, int n_slots, int var) {
         return s8 ? k_melspec_w64<float, true, 4, 8> : k_melspec_w64<float, true, 4, 4>;
     }
     if (kind == 3) {
-#define AUD_W20(TT, S) (var == 3 ? k_melspec_w20<TT, true, 4, S, 3> : k_melspec_w20<TT, true, 4, S, 2>)
+#define AUD_W20(TT, S) (var == 3 ? k_melspec_w20<TT, true, 4, S, 3> : var == 0 ? k_melspec_w20<TT, true, 4, S, 0> : k_melspec_w20<TT, true, 4, S, 2>)
         if (f64) return s8 ? AUD_W20(double, 8) : AUD_W20(double, 4);
         return s8 ? AUD_W20(float, 8) : AUD_W20(float, 4);
 #undef AUD_W20

@@ -630,7 +630,8 @@ def case_n400_variants(orc, cdt, seg_ms=None, dur=1.0, rows=2, segs=(0,)):
         assert fam == "w20x10"
         # wave-autonomous 20 x 10 (default; persistent and dynamic-queue grids), 25 x 8 (and its variants), workgroup-tile
         # (r25x8), generic
-        for opts in ({}, {"wave_grid": 1}, {"wave_grid": 2}, {"n400_geometry": 25}, {"n400_geometry": 25, "wave_grid": 1},
+        for opts in ({}, {"wave_grid": 1}, {"wave_grid": 1, "wave_variant": 0}, {"wave_grid": 2}, {"n400_geometry": 25},
+                     {"n400_geometry": 25, "wave_grid": 1},
                      {"n400_geometry": 25, "wave_grid": 2}, {"n400_geometry": 25, "wave_grid": 1, "wave_variant": 0},
                      {"n400_geometry": 25, "wave_grid": 1, "wave_variant": 1}, {"kernel": 2}, {"kernel": 1}):
             case_melspec_vs_oracle(orc, (name, dur, rows, list(segs)), cdt, seg_ms=seg_ms, options=opts)

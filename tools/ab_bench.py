@@ -50,6 +50,7 @@ def main():
     dsig = torch.from_numpy(sig).to(dev).view(-1)
     cdt = capi.AUD_F32 if args.compute == "f32" else capi.AUD_F64
     variants = {"w20 (default)": {}, "w20 one tile per wave": {"wave_grid": 0}, "w20 persistent": {"wave_grid": 1},
+                "w20 persistent, late prefetch": {"wave_grid": 1, "wave_variant": 0},
                 "w25 (25 x 8 geometry)": {"n400_geometry": 25}, "w25 one tile per wave": {"n400_geometry": 25, "wave_grid": 0},
                 "w25 persistent": {"n400_geometry": 25, "wave_grid": 1},
                 "w20, no xcd remap": {"xcd_remap": 0}, "r25 tile kernel": {"kernel": 2}, "generic": {"kernel": 1}}
