@@ -287,9 +287,10 @@ __device__ __forceinline__ void frame_pairs_issue(const MelspecArgs& a, const au
     // (int16: 4-byte) grid.  ODD_ROUTE (the one-frame-per-wave kernel, where the parity is wave-uniform): its pairs are
     // fetched as two element loads each -- same raw words, same conversion; otherwise such frames take route 0 (in the
     // kernels with several frames per wave the second flavour of loads under a lane condition cost 5-10 % on even frames)
-    const bool even = ((it.sig_off + start) & 1) == 0;
-    const bool inside = sstep < a.T && start >= 0 && start + N <= int64_t(it.sig_len) && it.sig_stride <= 1 &&
-                        (ODD_ROUTE || even);
+    // A strided stream (one channel of interleaved stereo, sig_stride = 2) is the same case: element loads, stride apart.
+    const int64_t str = it.sig_stride > 1 ? it.sig_stride : 1;
+    const bool even = ((it.sig_off + start) & 1) == 0 && str == 1;
+    const bool inside = sstep < a.T && start >= 0 && start + N <= int64_t(it.sig_len) && (ODD_ROUTE || even);
     r.route = 0;
     if (inside && a.sig_dtype == AUD_F32 && (reinterpret_cast<uintptr_t>(a.sig) & 7) == 0) {
         if (!ODD_ROUTE || even) {
@@ -299,9 +300,9 @@ __device__ __forceinline__ void frame_pairs_issue(const MelspecArgs& a, const au
             for (int n1 = 0; n1 < NV; ++n1) r.w[n1] = src[STRIDE * n1];
         } else {
             const uint32_t* __restrict__ src =
-                reinterpret_cast<const uint32_t*>(static_cast<const float*>(a.sig) + it.sig_off + pos0);
+                reinterpret_cast<const uint32_t*>(static_cast<const float*>(a.sig) + it.sig_off + pos0 * str);
 #pragma unroll
-            for (int n1 = 0; n1 < NV; ++n1) r.w[n1] = uint2{src[2 * STRIDE * n1], src[2 * STRIDE * n1 + 1]};
+            for (int n1 = 0; n1 < NV; ++n1) r.w[n1] = uint2{src[(2 * STRIDE * n1) * str], src[(2 * STRIDE * n1 + 1) * str]};
         }
         r.route = 1;
     }
@@ -314,10 +315,10 @@ __device__ __forceinline__ void frame_pairs_issue(const MelspecArgs& a, const au
                 for (int n1 = 0; n1 < NV; ++n1) r.w[n1].x = src[STRIDE * n1];
             } else {
                 const unsigned short* __restrict__ src =
-                    reinterpret_cast<const unsigned short*>(static_cast<const int16_t*>(a.sig) + it.sig_off + pos0);
+                    reinterpret_cast<const unsigned short*>(static_cast<const int16_t*>(a.sig) + it.sig_off + pos0 * str);
 #pragma unroll
                 for (int n1 = 0; n1 < NV; ++n1)
-                    r.w[n1].x = uint32_t(src[2 * STRIDE * n1]) | (uint32_t(src[2 * STRIDE * n1 + 1]) << 16);
+                    r.w[n1].x = uint32_t(src[(2 * STRIDE * n1) * str]) | (uint32_t(src[(2 * STRIDE * n1 + 1) * str]) << 16);
             }
             r.route = 2;
         }

@@ -202,9 +202,10 @@ def strict_parity(got, ref):
 class Ring:
     """R resident batches of B streams each ([B, L] float32 or int16 on the device) + their outputs"""
 
-    def __init__(self, torch, wl, B, R, rank, dev, sig_dtype, need_bytes=None):
+    def __init__(self, torch, wl, B, R, rank, dev, sig_dtype, need_bytes=None, stereo=False):
         from auditory_amd import runtime, synth
         self.B, self.R, self.wl = B, R, wl
+        assert not stereo or B % 2 == 0
         self.pcm = np.zeros((R * B, wl.L), np.int16)                  # host copy (parity / cpu_baseline), 2 B per sample
         for i in range(R * B):
             self.pcm[i, :wl.dur] = synth.utterance_pcm(2, rank * R * B + i, wl.dur, wl.sr)
@@ -212,8 +213,13 @@ class Ring:
         for r in range(R):
             blk = self.pcm[r * B:(r + 1) * B]
             host = blk if sig_dtype == "i16" else (blk.astype(np.float64) / 32767.0).astype(np.float32)
+            if stereo:  # streams 2c and 2c + 1 are the channels of clip c: [B/2, L, 2] interleaved, as a WAV holds them
+                host = host.reshape(B // 2, 2, wl.L).transpose(0, 2, 1)
             self.sig.append(torch.from_numpy(np.ascontiguousarray(host)).to(dev).view(-1))
-        items = runtime.make_items(np.arange(B) * wl.L, [wl.L] * B, [0] * B)
+        if stereo:  # two work items over one buffer: channel = sig_off parity, sig_stride 2 (aud_item)
+            items = runtime.make_items((np.arange(B) // 2) * (2 * wl.L) + (np.arange(B) % 2), [wl.L] * B, [0] * B, sig_stride=2)
+        else:
+            items = runtime.make_items(np.arange(B) * wl.L, [wl.L] * B, [0] * B)
         raw = np.frombuffer(np.ascontiguousarray(items).tobytes(), np.uint8).copy()
         self.items = torch.from_numpy(raw).to(dev)
         self.mel = [torch.empty((B, wl.nf, wl.T), dtype=torch.float32, device=dev) for _ in range(R)]
@@ -239,6 +245,9 @@ def main():  # noqa: C901
     ap.add_argument("--sig-dtype", choices=["f32", "i16"], default="f32",
                     help="resident sample format: float32 (the metric's definition) or int16 PCM normalised on the device "
                          "(sound.go:116-141; half the input bytes)")
+    ap.add_argument("--stereo", action="store_true",
+                    help="the resident streams are the channels of interleaved stereo clips (BASELINE configs[4] as worded): "
+                         "two strided work items per clip over one buffer, no de-interleaving copy")
     ap.add_argument("--ring-mb", type=float, default=320.0, help="resident input ring per GPU (> the 256 MB Infinity Cache)")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="minimum device time of a timed region")
     ap.add_argument("--launch", choices=["graph", "eager"], default="graph")
@@ -303,7 +312,7 @@ def main():  # noqa: C901
         if wl.name not in rings:
             per_batch = B * wl.L * (2 if args.sig_dtype == "i16" else 4)
             R = max(2, int(math.ceil(args.ring_mb * 1e6 / per_batch)))
-            rings[wl.name] = Ring(torch, wl, B, R, rank, dev, args.sig_dtype)
+            rings[wl.name] = Ring(torch, wl, B, R, rank, dev, args.sig_dtype, stereo=args.stereo)
         return rings[wl.name]
 
     def time_mode(wl, compute, check=True, n_streams=None):
@@ -546,6 +555,8 @@ def main():  # noqa: C901
                    "n_mel": head_wl.nf, "kernel": head["kernel"], "launch": head["launch"], "streams": head["streams"],
                    "steps_requested": K,
                    "repeats": head["repeats"], "ring": head["ring"], "options": args.option, "sig_dtype": args.sig_dtype,
+                   "layout": ("interleaved stereo clips: two strided work items (sig_stride 2) per clip over one buffer" if args.stereo
+                              else "one contiguous mono stream per work item"),
                    "sharding": "utterances, contiguous block per rank; no collective inside `value`"},
         "us_per_step_device": head["us_per_step_device"],
         "parity": head.get("parity"),

@@ -145,6 +145,13 @@ def test_input_dtypes_agree(orc, torch_cuda, name, seg_ms):
         items_o = bp.upload_items(runtime.make_items(np.arange(4) * Lo, [L] * 4, [0] * 4))
         got = bp.melspec(torch.from_numpy(wide).cuda().contiguous().view(-1), items_o, 4).cpu().numpy()
         assert np.array_equal(got, outs[0], equal_nan=True)
+    # and as the channels of two interleaved stereo clips (rows 0 | 1 and 2 | 3): strided work items over one buffer
+    for arr in (pcm, sig.astype(np.float32)):
+        inter = np.ascontiguousarray(arr.reshape(2, 2, L).transpose(0, 2, 1))        # [clip, sample, channel]
+        items_s = bp.upload_items(runtime.make_items((np.arange(4) // 2) * (2 * L) + np.arange(4) % 2, [L] * 4, [0] * 4,
+                                                     sig_stride=2))
+        got = bp.melspec(torch.from_numpy(inter).cuda().contiguous().view(-1), items_s, 4).cpu().numpy()
+        assert np.array_equal(got, outs[0], equal_nan=True)
     plan.close()
 
 
