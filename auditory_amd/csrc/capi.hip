@@ -789,7 +789,8 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
         return AUD_OK;
     }
     if (key == "gabor_lds") {  // 0 (default): the global-memory gabor kernel; 1: LDS-tiled kernel where an item's mel matrix fits
-        if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "gabor_lds: 0 or 1");
+        // 2 / 4: the default FilterSet with two / four threads per output position (k_gabor_split)
+        if (value != 0 && value != 1 && value != 2 && value != 4) return fail(c, AUD_EINVAL, "gabor_lds: 0, 1, 2 or 4");
         p->gabor_lds = value;
         return AUD_OK;
     }

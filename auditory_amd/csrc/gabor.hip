@@ -107,6 +107,57 @@ __global__ __launch_bounds__(256) void k_gabor(const GaborArgs a) {
     }
 }
 
+// The default FilterSet (9 x 9 taps, 8 filters) into rank-4 [PY, PX, 2, 8] pools with PARTS threads per output position:
+// thread `part` of a position owns 8 / PARTS filters (their on / off values are 8 / PARTS consecutive floats each).
+// k_gabor's one thread per position is a serial chain of 81 loads and 648 FMAs in 1.4 waves per SIMD; more, shorter
+// threads hide the load latency (the mel matrix is L1/L2-resident, so the repeated loads cost little).
+template <typename TT, int PARTS>
+__global__ __launch_bounds__(256) void k_gabor_split(const GaborArgs a) {
+    constexpr int KF = 8 / PARTS;
+    const int per_item = a.nF * a.nT;
+    // a WAVE owns one part of 64 positions, so the taps stay wave-uniform scalar operands
+    const int64_t wave_id = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int part = __builtin_amdgcn_readfirstlane(int(wave_id % PARTS));
+    const int64_t pos_id = (wave_id / PARTS) * 64 + (threadIdx.x & 63);
+    if (pos_id >= int64_t(a.n_items) * per_item) return;
+    const int item = int(pos_id / per_item);
+    const int r = int(pos_id - int64_t(item) * per_item);
+    const int f_idx = r / a.nT, t_idx = r - f_idx * a.nT;
+    const float* __restrict__ mel = a.mel + size_t(item) * a.rows * a.cols + size_t(f_idx * a.sty) * a.cols + t_idx * a.stx;
+    const TT* __restrict__ kf = static_cast<const TT*>(a.k) + part * KF * 81;
+    TT acc[KF];
+#pragma unroll
+    for (int c = 0; c < KF; ++c) acc[c] = TT(0);
+#pragma unroll
+    for (int ff = 0; ff < 9; ++ff) {
+        float mv[9];
+#pragma unroll
+        for (int ft = 0; ft < 9; ++ft) mv[ft] = mel[size_t(ff) * a.cols + ft];
+#pragma unroll
+        for (int ft = 0; ft < 9; ++ft) {
+            const float m = mv[ft] != mv[ft] ? 0.5f : mv[ft];  // math.IsNaN -> .5
+            const TT v = TT(m);
+#pragma unroll
+            for (int c = 0; c < KF; ++c) acc[c] += kf[c * 81 + ff * 9 + ft] * v;
+        }
+    }
+    const TT gain = TT(a.gain);
+    float on[KF], off[KF];
+#pragma unroll
+    for (int c = 0; c < KF; ++c) {
+        const bool pos = acc[c] >= TT(0);
+        const float act = float(gain * (acc[c] < TT(0) ? -acc[c] : acc[c]));
+        on[c] = pos ? act : 0.f;
+        off[c] = pos ? 0.f : act;
+    }
+    float* cell = a.out + size_t(item) * (size_t(a.d0) * a.d1 * 16) + (size_t(f_idx) * a.d1 + t_idx) * 16 + part * KF;
+#pragma unroll
+    for (int c = 0; c < KF; ++c) {
+        cell[c] = on[c];
+        cell[8 + c] = off[c];
+    }
+}
+
 // The LDS-tiled form (plan option "gabor_lds" = 1, where an item's mel matrix fits): a workgroup copies the item's whole
 // [rows, cols] mel matrix into LDS once -- coalesced 16-byte loads, NaN -> 0.5 applied on the way (:278-280) -- and
 // then works on kLdsPos output positions: a thread takes ONE position and kLdsChunk filters (taps wave-uniform scalar
@@ -215,7 +266,7 @@ hipError_t launch_gabor(const GaborArgs& a, int compute_dtype, hipStream_t st) {
     const dim3 grid(unsigned((total + 255) / 256));
     const bool dflt = a.SX == 9 && a.SY == 9 && a.nG == 8;  // processspeech.go:226-253
     const size_t lds = size_t(a.rows) * a.cols * sizeof(float);
-    if (lds <= 60 * 1024 && a.use_lds) {  // the item's mel matrix fits LDS (BASELINE configs[3]: 16.6 KB)
+    if (lds <= 60 * 1024 && a.use_lds == 1) {  // the item's mel matrix fits LDS (BASELINE configs[3]: 16.6 KB)
         const int per_item = a.nF * a.nT;
         const int n_split = (per_item + kLdsPos - 1) / kLdsPos;
         const dim3 g2(unsigned(a.n_items) * unsigned(n_split)), b2(kLdsPos * kLdsGroups);
@@ -226,6 +277,18 @@ hipError_t launch_gabor(const GaborArgs& a, int compute_dtype, hipStream_t st) {
         } else {
             if (d9) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor_lds<float, 9, 9, 8>), g2, b2, lds, st, a, n_split);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor_lds<float, 0, 0, 0>), g2, b2, lds, st, a, n_split);
+        }
+        return hipGetLastError();
+    }
+    if (dflt && a.rank == 4 && a.d2 == 2 && a.d3 == 8 && a.use_lds >= 2) {  // plan option "gabor_lds" = 2 / 4: threads per position
+        const int parts = a.use_lds == 2 ? 2 : 4;
+        const dim3 gs(unsigned((((total + 63) / 64) * 64 * parts + 255) / 256));
+        if (compute_dtype == AUD_F64) {
+            if (parts == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor_split<double, 2>), gs, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor_split<double, 4>), gs, dim3(256), 0, st, a);
+        } else {
+            if (parts == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor_split<float, 2>), gs, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor_split<float, 4>), gs, dim3(256), 0, st, a);
         }
         return hipGetLastError();
     }

@@ -221,7 +221,9 @@ const char* aud_plan_kernel_name(const aud_plan* plan);
  *               w64x16: never), 0 one tile per wave, 1 persistent, 2 persistent with a dynamic tile queue (A/B only)
  *   "wave_variant" 2 (default) / 0 / 1: operand prefetch variants of the persistent loop (A/B)
  *   "gabor_lds" 0 (default) the gabor kernel reads the mel matrix through L1/L2, 1 it stages the item's matrix in LDS first
- *               (where it fits 60 KB); measured on the MI355X: 9.4 vs 11.9 us per 256 items in float64, so off by default
+ *               (where it fits 60 KB); measured on the MI355X: 9.4 vs 11.9 us per 256 items in float64, so off by default;
+ *               2 / 4: the default 9 x 9 x 8 FilterSet with two / four threads per output position (measured: within 2 %
+ *               of the default when launches overlap, 4 % faster alone)
  *   "xcd_remap" 1 (default) workgroups that share an XCD take one contiguous run of tiles (L2 reuse of the
  *               samples neighbouring tiles share), 0 tiles in workgroup-id order
  *   the "r16_*" switches are variants of the round-1 N = 512 tile kernel; setting one selects that kernel
