@@ -254,12 +254,14 @@ def main():  # noqa: C901
     ap.add_argument("--graph-steps", type=int, default=200,
                     help="steps one captured hipGraph holds: the requested --steps repeated until at least this many, so "
                          "that the fork/join of the streams at the two ends of a replay is not what is timed")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the steps are dealt over round-robin inside the graph (independent resident batches, "
                          "own output buffers): 1 = every step waits for the previous one; 2 (default) = consecutive launches "
                          "overlap their load burst with the previous launch's tail, as a double-buffered pipeline does "
-                         "(measured 35.0 -> 23.4 us per step).  `roofline` is always taken from a 1-stream region: one kernel "
-                         "alone on the chip, the duration rocprofv3 reports")
+                         "(measured 27.1 -> 16.3 us per step; 3 and 4 add nothing).  Default for --workload cfg4: 4 -- a step is "
+                         "two dependent launches there and the short gabor launch fills the chip badly (measured 25.4 us per "
+                         "step on 2 streams, 19.8 on 3, 19.4 on 4).  `roofline` is always taken from a 1-stream region: one "
+                         "kernel alone on the chip, the duration rocprofv3 reports")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="aud_plan_set_option switches for A/B runs, e.g. kernel=2 (workgroup-tile family) or kernel=1 (generic)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for CPU dry runs)")
@@ -290,6 +292,8 @@ def main():  # noqa: C901
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    if args.streams <= 0:
+        args.streams = 4 if args.workload == "cfg4" else 2
     B, K = args.batch, max(1, args.steps)
     sig_code = capi.AUD_I16 if args.sig_dtype == "i16" else capi.AUD_F32
     gabor = args.workload == "cfg4"
