@@ -118,7 +118,7 @@ struct FastArgs {
     int n_sched;           // its length in ints: groups + 1 + 4 nf
     int n_groups;          // filter groups of the epilogue (threads per workgroup / frames per tile)
     unsigned lds_bytes;    // dynamic LDS of the launch
-    int n_chunks;          // number of 4-element chunks in w4
+    int n_chunks;          // tile kernels: number of 4-element chunks in w4; w64x16 (compact weight rows): unused, the zero chunk is piece 0
     const int* grp_off;    // [groups + 1] device: filter-group boundaries into grp_flt
     const int* grp_flt;    // [nf] device: filter ids, grouped so that groups carry equal tap counts
     const int* chunk;      // [nf][3] device: first 4-bin chunk, chunk count, offset into w4

@@ -1,4 +1,5 @@
-// Wave-autonomous frame -> FFT -> power -> mel -> log kernels: N = 512 ("w16x16") and N = 400 ("w25x8").
+// Wave-autonomous frame -> FFT -> power -> mel -> log kernels: N = 512 ("w16x16"), N = 400 ("w20x10", the default, and
+// "w25x8") and N = 2048 ("w64x16", one frame per wave).
 //
 // What the round-2 counters said about the workgroup-tile kernels (melspec_r16.hip, melspec_r25.hip): the float64
 // instantiations keep a whole tile's complex transpose buffer in LDS (58-72 KB per workgroup), so a CU holds one
@@ -6,11 +7,11 @@
 // (SQ_WAIT_ANY 55 % of SQ_WAVE_CYCLES) and the vector ALU is busy a fifth of the time.  These kernels remove the
 // causes instead of tuning around them (s_memtime stamps of each step of the way: profiles/r02c..e_stamps_*):
 //
-//   * the unit of work is a WAVE, not a workgroup: 64 lanes carry 4 frames x 16 lanes (N = 512) or 8 frames x
-//     8 lanes (N = 400) from the samples to the mel values.  Lanes of one wave exchange data through a
+//   * the unit of work is a WAVE, not a workgroup: 64 lanes carry 4 frames x 16 lanes (N = 512), 6 frames x 10 lanes or
+//     8 frames x 8 lanes (N = 400), or one frame (N = 2048) from the samples to the mel values.  Lanes of one wave exchange data through a
 //     wave-private LDS region ordered by wave_lds_fence() -- the hardware runs a wave's LDS instructions in
 //     order -- so the data path has no workgroup barrier;
-//   * every read-only table (mel weight chunks, the epilogue's step records, pass and split twiddles) comes as ONE
+//   * every read-only table (mel weight rows, the epilogue's slot records, pass and split twiddles) comes as ONE
 //     blob that the workgroup copies into LDS at its very start: the blob loads are issued first, the operand
 //     loads behind them, and a counted wait (the loads return in order) lets the blob be stored and the single
 //     barrier be passed while the operands are still in flight.  Twiddles read from global memory per wave were
@@ -19,11 +20,15 @@
 //     halves the footprint: 9 KB (N = 512) / 17 KB (N = 400) per wave in float64, half of that in float32; the
 //     power spectrum then reuses the same region.  Row pitches are an odd number of 16-byte slots and frame
 //     pitches 0 / 8 (mod 16) slots, so the 16-byte row loads are conflict-free;
-//   * N = 400: the partner of Z[k1 + 25 k2] in the real-FFT split is element (25 - k1, 7 - k2), so a lane takes
-//     the row PAIR (r, 25 - r) and has both halves of all eight pairs in its own registers: no cross-lane traffic;
+//   * N = 400: the partner of Z[k1 + 25 k2] in the real-FFT split is element (25 - k1, 7 - k2) (20 x 10: (20 - k1,
+//     9 - k2)), so a lane takes the row PAIR (r, 25 - r) and has both halves of all its pairs in its own registers: no
+//     cross-lane traffic; N = 2048 does the same with pairs of columns;
+//   * no LDS access (and no second flavour of global loads) sits under a lane condition: idle lanes read rows they do not
+//     use or shadow a working lane -- a lane-conditional access block costs hipcc 60-100 registers in these kernels;
 //   * the wave index is scalar (readfirstlane): the work-item record is one scalar load and the address
 //     arithmetic runs on the scalar unit;
-//   * the mel reduction is a branch-free walk over padded chunk steps (wave_mel_steps, device_common.h);
+//   * the mel reduction runs slot-uniform chunk steps: scalar loop bounds, two LDS reads and four FMAs per step
+//     (wave_mel_steps, device_common.h);
 //   * float64 plans take the final logarithm in float32 (feature_log): the stored value is a float32 anyway.
 //
 // Arithmetic (DFT factorisation, twiddle values, real-FFT split) is that of the workgroup-tile kernels, which stay
