@@ -71,6 +71,102 @@ __global__ __launch_bounds__(256) void k_mfcc_deltas(const MfccArgs a, const flo
     }
 }
 
+// The whole tail for one item in one workgroup (what launch_mfcc runs when the item's tensors fit LDS): the item's mel
+// matrix and the DCT rows are staged in LDS once (coalesced), the DCT reads them from there (the three-kernel form re-read
+// every mel value 13 times through L1), the Energy rows are summed by a wave each with lanes along the steps (coalesced;
+// the one-thread-per-row form walked 104 cache lines per load instruction), and the deltas / delta-deltas read the
+// float32-ROUNDED coefficients back from LDS, as the reference reads its float32 tensors.  Same arithmetic and the same
+// summation order as the kernels above, except that an Energy row is a tree sum of its float64-widened values.
+constexpr int kFusedThreads = 512;
+
+template <typename TT>
+__global__ __launch_bounds__(kFusedThreads) void k_mfcc_fused(const MfccArgs a) {
+    unsigned char* mfcc_lds = dyn_lds();
+    const int T = a.T, nf = a.nf, nc = a.n_coefs;
+    float* melL = reinterpret_cast<float*>(mfcc_lds);                 // [nf][T]
+    float* cofL = melL + nf * T;                                      // [nc][T]  mfcc, float32-rounded
+    float* dltL = cofL + nc * T;                                      // [nc][T]  deltas, float32-rounded
+    TT* dctL = reinterpret_cast<TT*>(dltL + nc * T + ((nf * T + 2 * nc * T) & 1));  // [nc][nf], 8-byte aligned
+    const int tid = int(threadIdx.x), item = int(blockIdx.x);
+    const aud_item it = a.items[item];
+    const float* __restrict__ mel = a.mel + size_t(item) * nf * T;
+    for (int i = tid; i < nf * T; i += kFusedThreads) melL[i] = mel[i];
+    const TT* __restrict__ C = static_cast<const TT*>(a.dct);
+    for (int i = tid; i < nc * nf; i += kFusedThreads) dctL[i] = C[i];
+    __syncthreads();
+    // CepstrumDct per processed step (mel/mel.go:192-212)
+    for (int idx = tid; idx < nc * T; idx += kFusedThreads) {
+        const int coef = idx / T, s = idx - coef * T;
+        const int64_t start = int64_t(it.start0) + int64_t(a.S) * (s - a.border);
+        float res = 0.f;
+        if (start + a.N <= int64_t(it.sig_len)) {
+            TT acc = TT(0);
+#pragma unroll 8
+            for (int j = 0; j < nf; ++j) acc += dctL[coef * nf + j] * TT(melL[j * T + s]);
+            if (coef == 0) acc = dev_log1p_sq(acc);
+            res = float(acc);
+        }
+        cofL[idx] = res;
+    }
+    __syncthreads();
+    // Energy[s] = sum over f < T of LogPowerSegment(s, f) (sound/sndenv.go:360-372) -> MFCC row 0
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        const float* __restrict__ lp = a.log_power + size_t(item) * a.H * T;
+        constexpr int R = 13, NW = kFusedThreads / 64;  // rows in flight per wave: their loads are issued together, then reduced one by one
+        for (int s0 = wave; s0 < T; s0 += NW * R) {
+            TT e[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int s = s0 + NW * r;
+                TT acc = TT(0);
+                if (s < T)
+                    for (int f = lane; f < T; f += 64) acc += TT(lp[size_t(s) * T + f]);
+                e[r] = acc;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                TT v = e[r];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                const int s = s0 + NW * r;
+                if (lane == 0 && s < T) {
+                    if (a.energy) a.energy[size_t(item) * T + s] = float(v);
+                    cofL[s] = float(v);  // SetFloatRowCell(0, s, Energy[s])
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* mf = a.mfcc + size_t(item) * nc * T;
+    for (int i = tid; i < nc * T; i += kFusedThreads) mf[i] = cofL[i];
+    if (!a.deltas) return;  // uniform
+    // deltas, then delta-deltas (sound/sndenv.go:378-431): one thread per step, coefficients in order with carried sums
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* in = pass ? dltL : cofL;
+        float* outL = pass ? nullptr : dltL;
+        float* out = (pass ? a.delta_deltas : a.deltas) + size_t(item) * nc * T;
+        for (int s = tid; s < T; s += kFusedThreads) {
+            TT prv = TT(0), nxt = TT(0);
+            for (int i = 0; i < nc; ++i) {
+                TT nume = TT(0), d = TT(0);
+                for (int n = 1; n <= 2; ++n) {
+                    const int sprv = max(s - n, 0), snxt = min(s + n, T - 1);
+                    prv += TT(in[i * T + sprv]);
+                    nxt += TT(in[i * T + snxt]);
+                    nume += TT(n) * (nxt - prv);
+                    d = nume / TT(2 * n * n);
+                }
+                const float df = float(d);
+                out[i * T + s] = df;
+                if (outL) outL[i * T + s] = df;
+            }
+        }
+        if (!a.delta_deltas) return;  // uniform
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 // mel.Params.CepstrumDct alone (the reference's per-step entry point)
@@ -88,6 +184,13 @@ hipError_t launch_mfcc(const MfccArgs& a, int compute_dtype, hipStream_t st) {
     const int64_t n1 = int64_t(a.n_items) * a.n_coefs * a.T, n2 = int64_t(a.n_items) * a.T;
     if (n1 == 0) return hipSuccess;
     const dim3 g1(unsigned((n1 + 255) / 256)), g2(unsigned((n2 + 255) / 256)), b(256);
+    const size_t lds = (size_t(a.nf) * a.T + 2 * size_t(a.n_coefs) * a.T + 1) * sizeof(float) +
+                       size_t(a.n_coefs) * a.nf * (f64 ? 8 : 4) + 8;
+    if (lds <= 64 * 1024) {  // the item's tensors fit LDS: one launch, one workgroup per item
+        if (f64) hipLaunchKernelGGL(k_mfcc_fused<double>, dim3(unsigned(a.n_items)), dim3(kFusedThreads), lds, st, a);
+        else hipLaunchKernelGGL(k_mfcc_fused<float>, dim3(unsigned(a.n_items)), dim3(kFusedThreads), lds, st, a);
+        return hipGetLastError();
+    }
     if (f64) hipLaunchKernelGGL(k_mfcc_dct<double>, g1, b, 0, st, a);
     else hipLaunchKernelGGL(k_mfcc_dct<float>, g1, b, 0, st, a);
     if (f64) hipLaunchKernelGGL(k_mfcc_energy<double>, g2, b, 0, st, a);

@@ -91,7 +91,7 @@ class Workload:
         need = self.S * (self.T - 1 - self.border) + self.N            # every frame of the segment in bounds
         self.L = (max(need, self.dur) + 63) // 64 * 64                 # row pitch: zero tail, 64-sample multiple
 
-    def plan(self, compute, device, gabor=False):
+    def plan(self, compute, device, gabor=False, mfcc=0):
         from auditory_amd import agabor, capi, runtime
         dftp = capi.DftParams()
         capi.load().aud_dft_defaults(dftp)
@@ -103,11 +103,11 @@ class Workload:
             gset, gk = fs.to_c(), fs.Filters
         cdt = capi.AUD_F64 if compute == "f64" else capi.AUD_F32
         return runtime.Plan(runtime.get_ctx(device), self.N, self.S, self.T, self.border, dftp, self.mp.FBank.to_c(),
-                            self.mp.BinPts, self.filt, gset, gk, cdt)
+                            self.mp.BinPts, self.filt, gset, gk, cdt, mfcc_coefs=mfcc)
 
     def describe(self, B):
         return ("%d synthetic %g kHz mono streams of %g s per GPU and step, WinMs %g (N = %d), StepMs %g (S = %d), "
-                "T = %d frames, %d mel, mel only" % (B, self.sr / 1e3, self.dur_s, self.win_ms, self.N, self.step_ms,
+                "T = %d frames, %d mel" % (B, self.sr / 1e3, self.dur_s, self.win_ms, self.N, self.step_ms,
                                                      self.S, self.T, self.nf))
 
 
@@ -237,10 +237,13 @@ def main():  # noqa: C901
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
-    ap.add_argument("--workload", choices=["headline", "cfg4", "cfg5", "cfg1"], default="headline",
+    ap.add_argument("--workload", choices=["headline", "cfg4", "cfg5", "cfg1", "sndenv"], default="headline",
                     help="headline: the judged line (N = 400, with the N = 512 variant under `also`).  Secondary lines for "
                          "BASELINE.md's table: cfg4 = headline + agabor.Convolve (default FilterSet, [11,32,2,8] pools); "
-                         "cfg5 = 44.1 kHz 5 s streams, N = 2048, 128 mel (use --batch 1280 for >= 1 GB resident input)")
+                         "cfg5 = 44.1 kHz 5 s streams, N = 2048, 128 mel (use --batch 1280 for >= 1 GB resident input); "
+                         "sndenv = the headline parameters with everything the unmodified SndEnv.ProcessSegment loop produces "
+                         "(SURVEY 8 f-1 + f-2): mel + Power + LogPower tensors + the MFCC tail (13 coefficients, deltas, "
+                         "delta-deltas, Energy)")
     ap.add_argument("--compute", choices=["f64", "f32"], default="f64", help="arithmetic of the headline mode")
     ap.add_argument("--sig-dtype", choices=["f32", "i16"], default="f32",
                     help="resident sample format: float32 (the metric's definition) or int16 PCM normalised on the device "
@@ -293,10 +296,11 @@ def main():  # noqa: C901
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     if args.streams <= 0:
-        args.streams = 4 if args.workload == "cfg4" else 2
+        args.streams = 4 if args.workload in ("cfg4", "sndenv") else 2
     B, K = args.batch, max(1, args.steps)
     sig_code = capi.AUD_I16 if args.sig_dtype == "i16" else capi.AUD_F32
     gabor = args.workload == "cfg4"
+    full = args.workload == "sndenv"
 
     def sync_all():
         if world > 1:
@@ -324,18 +328,29 @@ def main():  # noqa: C901
         n_streams = max(1, n_streams or args.streams)
         side = [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
         ring = ring_for(wl)
-        plan = wl.plan(compute, local_rank, gabor=gabor)
+        plan = wl.plan(compute, local_rank, gabor=gabor, mfcc=13 if full else 0)
         for kv in args.option:
             k, v = kv.split("=")
             plan.set_option(k, int(v))
         lib, ph = plan.lib, plan.handle
         gout = [torch.zeros((B, 11, 32, 2, 8), dtype=torch.float32, device=dev) for _ in range(ring.R)] if gabor else None
+        if full:  # Power / LogPower [B, H, T] and the MFCC tensors: four rotating sets (a stream reuses a set four steps later)
+            f32buf = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
+            sets = [dict(pw=f32buf(B, wl.H, wl.T), lp=f32buf(B, wl.H, wl.T), mfcc=f32buf(B, 13, wl.T), d1=f32buf(B, 13, wl.T),
+                         d2=f32buf(B, 13, wl.T), en=f32buf(B, wl.T)) for _ in range(4)]
 
         def launch(i, st):
             r = i % ring.R
             if gabor:
                 rc = lib.aud_process_batch_dev(ph, ring.sig[r].data_ptr(), sig_code, ring.items.data_ptr(), B,
                                                ring.mel[r].data_ptr(), 11, 32, gout[r].data_ptr(), st)
+            elif full:
+                o = sets[i % 4]
+                rc = lib.aud_melspec_batch_dev(ph, ring.sig[r].data_ptr(), sig_code, ring.items.data_ptr(), B,
+                                               ring.mel[r].data_ptr(), o["pw"].data_ptr(), o["lp"].data_ptr(), st)
+                if rc == 0:
+                    rc = lib.aud_mfcc_batch_dev(ph, ring.items.data_ptr(), B, ring.mel[r].data_ptr(), o["lp"].data_ptr(),
+                                                o["mfcc"].data_ptr(), o["d1"].data_ptr(), o["d2"].data_ptr(), o["en"].data_ptr(), st)
             else:
                 rc = lib.aud_melspec_batch_dev(ph, ring.sig[r].data_ptr(), sig_code, ring.items.data_ptr(), B,
                                                ring.mel[r].data_ptr(), None, None, st)
@@ -399,6 +414,8 @@ def main():  # noqa: C901
         alg = B * (ring.sample_bytes * wl.dur + 4 * wl.nf * wl.T)       # each sample read once + each mel value written once
         if gabor:  # unfused gabor: re-read the mel tensor, write the pooled on/off pairs
             alg += B * (4 * wl.nf * wl.T + 4 * 11 * 32 * 2 * 8)
+        if full:   # Power + LogPower written, mel + LogPower re-read by the MFCC tail, its four small tensors written
+            alg += B * (2 * 4 * wl.H * wl.T + 4 * wl.nf * wl.T + 4 * wl.H * wl.T + 4 * (3 * 13 + 1) * wl.T)
         mean_us = float(per_step_us.mean())
         res = {"workload": wl.name, "compute": compute, "kernel": plan.kernel_name, "launch": launch_mode, "streams": n_streams,
                "value": round(audio_s * steps / elapsed, 1), "steps": steps, "repeats": reps,
@@ -553,8 +570,11 @@ def main():  # noqa: C901
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.compute, "data": "synthetic",
         "config": {"workload": ("BASELINE configs[1] batch on the metric's parameters: " if args.workload == "headline" else
                                 "BASELINE configs[3] (configs[1] + agabor.Convolve, default FilterSet 9x9/3 x 8, [11,32,2,8] pools): "
-                                if gabor else "BASELINE configs[0] parameters (N = 1103), one 100 ms segment per item: "
-                                if args.workload == "cfg1" else "BASELINE configs[4]: ") + head_wl.describe(B),
+                                if gabor else "the whole unmodified SndEnv.ProcessSegment loop on the metric's parameters (mel + Power + "
+                                "LogPower tensors + MFCC tail with deltas and Energy: SURVEY 8 f-1, f-2): "
+                                if full else "BASELINE configs[0] parameters (N = 1103), one 100 ms segment per item: "
+                                if args.workload == "cfg1" else "BASELINE configs[4]: ") + head_wl.describe(B) +
+                               ("" if gabor or full else ", mel output only"),
                    "batch_per_gpu": B, "win_samples": head_wl.N, "step_samples": head_wl.S, "segment_steps": head_wl.T,
                    "n_mel": head_wl.nf, "kernel": head["kernel"], "launch": head["launch"], "streams": head["streams"],
                    "steps_requested": K,

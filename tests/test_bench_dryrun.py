@@ -86,7 +86,8 @@ class _SideStream(_Stream):
 
 
 @pytest.mark.parametrize("extra", [["--only-headline"], ["--workload", "cfg4"], ["--sig-dtype", "i16", "--only-headline"],
-                                   ["--compute", "f32", "--launch", "eager", "--only-headline"]])
+                                   ["--compute", "f32", "--launch", "eager", "--only-headline"],
+                                   ["--workload", "sndenv"], ["--stereo", "--only-headline"]])
 def test_bench_dry_run(monkeypatch, capsys, extra):
     import backend
     import bench
