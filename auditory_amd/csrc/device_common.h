@@ -420,6 +420,45 @@ __device__ __forceinline__ void tile_spectrum_outputs(const MelspecArgs& a, cons
                                                       int item, int t0, int tid, TT pscale = TT(1)) {
     const int T = a.T, H = a.H, N = a.N;
     const int64_t lim = it.sig_len;
+    if constexpr (NT == 64) {
+        // one wave: a lane keeps ONE frame (tid % F) and walks the bins k = tid / F, + 64 / F, ... -- step, liveness and the
+        // output addresses are per-lane constants and every iteration is one LDS read, the logarithm and two stores (the
+        // general form below re-derives frame, liveness and two 64-bit addresses for every element).  Lanes beyond
+        // F * (64 / F) repeat the last group and store nothing; reads past the last bin are clamped, not skipped.
+        if (a.power || a.log_power) {
+            constexpr int G = 64 / F;
+            const int ff = tid % F, g0 = tid / F;
+            const bool has = g0 < G;
+            const int g = has ? g0 : G - 1;
+            const int sstep = t0 + ff;
+            const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
+            const bool col_on = has && sstep < T;
+            const bool live = start + N <= lim;
+            const TT off = TT(a.dft_log_off), lmin = TT(a.dft_log_min);
+            const TT* prow = P + ff * Hp;
+            size_t o = (size_t(item) * H + g) * T + (col_on ? sstep : 0);
+            const size_t ostep = size_t(G) * T;
+            const bool want_lp = live && a.comp_log_pow;
+            const int n_it = (H + G - 1) / G;  // the same trip count for every lane
+            for (int i = 0; i < n_it; ++i) {
+                const int k = g + G * i;
+                const TT pw = pscale * prow[k < H ? k : H - 1];
+                if (col_on && k < H) {
+                    if (a.power) a.power[o] = live ? float(pw) : 0.f;
+                    if (a.log_power) {
+                        float lp = 0.f;
+                        if (want_lp) {
+                            const TT vv = pw + off;
+                            lp = float(vv == TT(0) ? lmin : feature_log(vv));
+                        }
+                        a.log_power[o] = lp;
+                    }
+                }
+                o += ostep;
+            }
+        }
+        return;
+    }
     if (a.power || a.log_power) {
         const TT off = TT(a.dft_log_off), lmin = TT(a.dft_log_min);
         for (int w = tid; w < F * H; w += NT) {
