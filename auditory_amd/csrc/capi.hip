@@ -36,6 +36,12 @@ struct aud_plan {
     int nfac = 0;
     int fac[aud::kMaxFactors] = {0};
     int F_generic = 0;
+    // generic kernel, Bluestein route (kernels.h MelspecArgs::bl_*): 0 = not used
+    int bl_L = 0, bl_nfac = 0;
+    int bl_fac[aud::kMaxFactors] = {0};
+    void* d_bl_chirp = nullptr;
+    void* d_bl_bhat = nullptr;
+    void* d_bl_tw = nullptr;
     // register-resident kernel of this plan, if its window length has one
     enum Fast { kNoFast = 0, kR16 = 1, kR25 = 2, kR1024 = 3 };
     int fast_kind = kNoFast;   // which family the tables below were built for
@@ -187,6 +193,12 @@ void fill_melspec_args(const aud_plan* p, aud::MelspecArgs* a) {
     a->dft_log_min = d.dft.log_min;
     a->dft_log_off = d.dft.log_offset;
     a->F = p->F_generic;
+    a->bl_L = p->bl_L;
+    a->bl_nfac = p->bl_nfac;
+    for (int i = 0; i < p->bl_nfac; ++i) a->bl_fac[i] = p->bl_fac[i];
+    a->bl_chirp = p->d_bl_chirp;
+    a->bl_bhat = p->d_bl_bhat;
+    a->bl_tw = p->d_bl_tw;
     a->xcd_remap = p->xcd_remap;
     a->stamps = reinterpret_cast<unsigned long long*>(p->stamps);
 }
@@ -506,6 +518,82 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
         }
         rc = upload_real(c, &p->d_tw, tw.data(), tw.size(), d->compute_dtype);
     }
+    // A prime factor the register radices do not cover costs O(p) per output (N = 1103, what 25 ms at 44.1 kHz gives, is
+    // prime: 0.6 M complex multiply-adds per frame).  Such lengths go through Bluestein's chirp convolution instead: two
+    // power-of-two FFTs of length L >= 2 M - 1 (melspec_generic.hip).  Tables in long double.
+    {
+        bool awkward = false;
+        for (int i = 0; i < p->nfac; ++i) awkward = awkward || p->fac[i] > 25;
+        const int L = awkward ? aud::melspec_generic_bluestein_L(p->M, d->compute_dtype) : 0;
+        if (rc == AUD_OK && L > 0) {
+            const int M = p->M;
+            const long double pi = 3.14159265358979323846264338327950288L;
+            const size_t Mz = size_t(M), Lz = size_t(L);
+            std::vector<long double> wr(Mz), wi(Mz);
+            for (int n = 0; n < M; ++n) {  // exp(-i pi n^2 / M) with n^2 reduced mod 2 M
+                const long double ang = -pi * (long double)((int64_t(n) * n) % (2 * int64_t(M))) / (long double)M;
+                wr[size_t(n)] = cosl(ang);
+                wi[size_t(n)] = sinl(ang);
+            }
+            // b[m] = conj(w[|m|]) wrapped to length L, bhat = FFT_L(b) / L by an iterative radix-2 FFT in long double
+            std::vector<long double> br(Lz, 0.0L), bi(Lz, 0.0L);
+            for (int m = 0; m < M; ++m) {
+                br[size_t(m)] = wr[size_t(m)];
+                bi[size_t(m)] = -wi[size_t(m)];
+                if (m > 0) {
+                    br[size_t(L - m)] = wr[size_t(m)];
+                    bi[size_t(L - m)] = -wi[size_t(m)];
+                }
+            }
+            for (int i = 1, j = 0; i < L; ++i) {  // bit reversal
+                int bit = L >> 1;
+                for (; j & bit; bit >>= 1) j ^= bit;
+                j ^= bit;
+                if (i < j) {
+                    std::swap(br[size_t(i)], br[size_t(j)]);
+                    std::swap(bi[size_t(i)], bi[size_t(j)]);
+                }
+            }
+            for (int len = 2; len <= L; len <<= 1) {
+                const long double ang = -2.0L * pi / (long double)len;
+                for (int i0 = 0; i0 < L; i0 += len)
+                    for (int k = 0; k < len / 2; ++k) {
+                        const long double cr = cosl(ang * k), ci = sinl(ang * k);
+                        const size_t u = size_t(i0 + k), v = size_t(i0 + k + len / 2);
+                        const long double tr = br[v] * cr - bi[v] * ci, ti = br[v] * ci + bi[v] * cr;
+                        br[v] = br[u] - tr;
+                        bi[v] = bi[u] - ti;
+                        br[u] += tr;
+                        bi[u] += ti;
+                    }
+            }
+            std::vector<double> chirp(Mz * 2), bhat(Lz * 2), twl(Lz * 2);
+            for (int n = 0; n < M; ++n) {
+                chirp[2 * size_t(n)] = double(wr[size_t(n)]);
+                chirp[2 * size_t(n) + 1] = double(wi[size_t(n)]);
+            }
+            for (int k = 0; k < L; ++k) {
+                bhat[2 * size_t(k)] = double(br[size_t(k)] / (long double)L);
+                bhat[2 * size_t(k) + 1] = double(bi[size_t(k)] / (long double)L);
+                const long double ang = -2.0L * pi * k / (long double)L;
+                twl[2 * size_t(k)] = double(cosl(ang));
+                twl[2 * size_t(k) + 1] = double(sinl(ang));
+            }
+            rc = upload_real(c, &p->d_bl_chirp, chirp.data(), chirp.size(), d->compute_dtype);
+            if (rc == AUD_OK) rc = upload_real(c, &p->d_bl_bhat, bhat.data(), bhat.size(), d->compute_dtype);
+            if (rc == AUD_OK) rc = upload_real(c, &p->d_bl_tw, twl.data(), twl.size(), d->compute_dtype);
+            const size_t lds = aud::melspec_generic_lds_bytes(L, 1, d->compute_dtype);
+            if (rc == AUD_OK && lds > 64u * 1024u && aud::melspec_generic_prepare(lds) != hipSuccess) {
+                (void)hipGetLastError();
+                rc = fail(c, AUD_EHIP, "the runtime refused the LDS size of the Bluestein route");
+            }
+            if (rc == AUD_OK) {
+                p->bl_L = L;
+                factorize(L, p->bl_fac, &p->bl_nfac);
+                p->F_generic = 1;
+            }
+        }
+    }
     if (rc == AUD_OK) rc = upload_real(c, &p->d_filt, mel_filters, size_t(cells), d->compute_dtype);
     if (rc == AUD_OK)
         rc = upload(c, reinterpret_cast<void**>(&p->d_bin_pts), bin_pts, sizeof(int32_t) * (nf + 2));
@@ -675,6 +763,9 @@ int aud_plan_destroy(aud_plan* p) {
     if (!p) return AUD_EINVAL;
     (void)hipSetDevice(p->ctx->device);
     if (p->d_tw) (void)hipFree(p->d_tw);
+    if (p->d_bl_chirp) (void)hipFree(p->d_bl_chirp);
+    if (p->d_bl_bhat) (void)hipFree(p->d_bl_bhat);
+    if (p->d_bl_tw) (void)hipFree(p->d_bl_tw);
     if (p->d_filt) (void)hipFree(p->d_filt);
     if (p->d_bin_pts) (void)hipFree(p->d_bin_pts);
     if (p->d_gabor) (void)hipFree(p->d_gabor);
@@ -700,6 +791,7 @@ int aud_plan_get_info(const aud_plan* p, const char* name, int64_t* value) {
     if (key == "lds_bytes") *value = f ? int64_t(f->lds_bytes) : 0;
     else if (key == "waves_per_wg") *value = wave ? p->wv.waves : 4;
     else if (key == "wgs_per_cu") *value = wave ? p->wv.wgs_per_cu : 0;
+    else if (key == "bluestein_L") *value = (!wave && !tile) ? p->bl_L : 0;
     else if (key == "frames_per_wave") *value = wave ? (p->wave_kind == 1 ? 4 : p->wave_kind == 2 ? 8 : p->wave_kind == 3 ? 6 : 1) : 0;
     else return fail(p->ctx, AUD_EINVAL, "aud_plan_get_info: unknown name");
     return AUD_OK;

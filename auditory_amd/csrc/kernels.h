@@ -52,6 +52,13 @@ struct MelspecArgs {
     float* power;      // [n_items, H, T] or null
     float* log_power;  // [n_items, H, T] or null
     int F;             // frames per workgroup
+    // generic kernel, Bluestein route for complex FFT lengths M with a prime factor > 25 (bl_L = 0: not used):
+    // Z = chirp . IFFT_L(FFT_L(z . chirp) . bhat), L a power of two >= 2 M - 1, one frame per workgroup
+    int bl_L, bl_nfac;
+    int bl_fac[kMaxFactors];
+    const void* bl_chirp;  // [M] complex<TT>: exp(-i pi n^2 / M)
+    const void* bl_bhat;   // [L] complex<TT>: FFT_L of the wrapped conjugate chirp, / L
+    const void* bl_tw;     // [L] complex<TT>: exp(-2 pi i k / L)
     int xcd_remap;     // 1: tile_of_workgroup() order (plan option "xcd_remap", default on)
     // diagnostic builds only (-DAUD_STAMPS, tools/stamp_profile.py): [waves][16] s_memtime stamps of the wave
     // kernels' phases.  Never read by anything that computes an output.
@@ -185,6 +192,8 @@ hipError_t launch_mfcc_dct(const MfccArgs& a, int compute_dtype, hipStream_t st)
 // generic any-N kernel (Stockham in LDS, radix 2/4 + per-output generic radix)
 size_t melspec_generic_lds_bytes(int M, int F, int compute_dtype);
 int melspec_generic_pick_F(int M, int compute_dtype);
+int melspec_generic_bluestein_L(int M, int compute_dtype);
+hipError_t melspec_generic_prepare(size_t lds_bytes);
 hipError_t launch_melspec_generic(const MelspecArgs& a, int compute_dtype, hipStream_t st);
 
 // N = 512 fast path

@@ -39,13 +39,36 @@ __device__ __forceinline__ void stage(const C2<TT>* src, C2<TT>* dst, const C2<T
     }
 }
 
+// the power-of-two FFT of the Bluestein route: radix 16 / 8 / 4 / 2 stages of one frame of length L, result in `src`
+template <typename TT>
+__device__ __forceinline__ void pow2_fft(C2<TT>*& src, C2<TT>*& dst, const MelspecArgs& a, int tid) {
+    const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.bl_tw);
+    const int L = a.bl_L;
+    int ncur = L, s = 1;
+    for (int stg = 0; stg < a.bl_nfac; ++stg) {
+        const int p = a.bl_fac[stg];
+        switch (p) {
+            case 16: stage<TT, 16>(src, dst, tw, 1, L, L, 1, ncur, s, tid); break;
+            case 8: stage<TT, 8>(src, dst, tw, 1, L, L, 1, ncur, s, tid); break;
+            case 4: stage<TT, 4>(src, dst, tw, 1, L, L, 1, ncur, s, tid); break;
+            default: stage<TT, 2>(src, dst, tw, 1, L, L, 1, ncur, s, tid); break;
+        }
+        __syncthreads();
+        C2<TT>* tmp = src;
+        src = dst;
+        dst = tmp;
+        ncur /= p;
+        s *= p;
+    }
+}
+
 template <typename TT>
 __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
     unsigned char* smem = dyn_lds();
     const int tid = threadIdx.x;
     const int F = a.F, M = a.M, N = a.N, H = a.H, T = a.T;
     C2<TT>* src = reinterpret_cast<C2<TT>*>(smem);
-    C2<TT>* dst = src + size_t(F) * M;
+    C2<TT>* dst = src + (a.bl_L ? size_t(a.bl_L) : size_t(F) * M);
     const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);
 
     const int tiles = (T + F - 1) / F;
@@ -72,9 +95,30 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
     }
     __syncthreads();
 
+    // ---- Bluestein route (M has a prime factor the register radices do not cover; F = 1): the length-M DFT as a
+    // circular convolution with a chirp, done with two power-of-two FFTs of length L >= 2 M - 1:
+    //   n k = (n^2 + k^2 - (k - n)^2) / 2  =>  Z[k] = w[k] sum_n (z[n] w[n]) conj(w)[k - n],  w[n] = exp(-i pi n^2 / M)
+    // The inverse FFT is a forward FFT of the conjugate; 1 / L is in bhat.
+    if (a.bl_L) {
+        const int L = a.bl_L;
+        const C2<TT>* __restrict__ chirp = static_cast<const C2<TT>*>(a.bl_chirp);
+        const C2<TT>* __restrict__ bhat = static_cast<const C2<TT>*>(a.bl_bhat);
+        for (int i = tid; i < L; i += blockDim.x) src[i] = i < M ? cmul<TT>(src[i], chirp[i]) : C2<TT>{TT(0), TT(0)};
+        __syncthreads();
+        pow2_fft<TT>(src, dst, a, tid);
+        for (int i = tid; i < L; i += blockDim.x) {
+            const C2<TT> c = cmul<TT>(src[i], bhat[i]);
+            src[i] = C2<TT>{c.x, -c.y};
+        }
+        __syncthreads();
+        pow2_fft<TT>(src, dst, a, tid);
+        for (int k = tid; k < M; k += blockDim.x) src[k] = cmul<TT>(chirp[k], C2<TT>{src[k].x, -src[k].y});
+        __syncthreads();
+    }
+
     // ---- Stockham stages: x[k + s(q + m i)] -> y[k + s(p q + j)] * W_ncur^(q j) ---------
     int ncur = M, s = 1;
-    for (int stg = 0; stg < a.nfac; ++stg) {
+    for (int stg = 0; stg < (a.bl_L ? 0 : a.nfac); ++stg) {
         const int p = a.fac[stg];
         const int m = ncur / p;
         const int nb = M / p;  // butterflies per frame
@@ -211,6 +255,23 @@ size_t melspec_generic_lds_bytes(int M, int F, int compute_dtype) {
     return size_t(2) * F * M * c;
 }
 
+// Bluestein: L = the power of two >= 2 M - 1 if two complex buffers of that length fit LDS, else 0
+int melspec_generic_bluestein_L(int M, int compute_dtype) {
+    int L = 1;
+    while (L < 2 * M - 1) L <<= 1;
+    return melspec_generic_lds_bytes(L, 1, compute_dtype) <= 160 * 1024 ? L : 0;
+}
+
+hipError_t melspec_generic_prepare(size_t lds_bytes) {
+    const void* fns[2] = {reinterpret_cast<const void*>(&k_melspec_generic<double>),
+                          reinterpret_cast<const void*>(&k_melspec_generic<float>)};
+    for (const void* fn : fns) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 int melspec_generic_pick_F(int M, int compute_dtype) {
     for (int F = 16; F >= 1; F >>= 1)
         if (melspec_generic_lds_bytes(M, F, compute_dtype) <= 64 * 1024) return F;
@@ -220,7 +281,7 @@ int melspec_generic_pick_F(int M, int compute_dtype) {
 hipError_t launch_melspec_generic(const MelspecArgs& a, int compute_dtype, hipStream_t st) {
     const int tiles = (a.T + a.F - 1) / a.F;
     const dim3 grid(unsigned(a.n_items) * unsigned(tiles));
-    const size_t lds = melspec_generic_lds_bytes(a.M, a.F, compute_dtype);
+    const size_t lds = a.bl_L ? melspec_generic_lds_bytes(a.bl_L, 1, compute_dtype) : melspec_generic_lds_bytes(a.M, a.F, compute_dtype);
     if (compute_dtype == AUD_F64)
         hipLaunchKernelGGL(k_melspec_generic<double>, grid, dim3(256), lds, st, a);
     else

@@ -86,7 +86,7 @@ class Plan:
         return self.lib.aud_plan_kernel_name(self.handle).decode()
 
     def info(self, name):
-        """aud_plan_get_info: "lds_bytes", "waves_per_wg", "wgs_per_cu", "frames_per_wave" of the mel kernel"""
+        """aud_plan_get_info: "lds_bytes", "waves_per_wg", "wgs_per_cu", "frames_per_wave", "bluestein_L" of the mel kernel"""
         v = C.c_int64(0)
         self.ctx.check(self.lib.aud_plan_get_info(self.handle, name.encode(), C.byref(v)))
         return int(v.value)

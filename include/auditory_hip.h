@@ -238,6 +238,7 @@ int aud_plan_set_option(aud_plan* plan, const char* name, int value);
  *   "waves_per_wg"     waves of 64 lanes per workgroup
  *   "wgs_per_cu"       workgroups resident per compute unit (the runtime's occupancy answer at plan time)
  *   "frames_per_wave"  frames one wave transforms together (0: a workgroup-tile or generic kernel)
+ *   "bluestein_L"      generic kernel: length of the power-of-two FFTs of its Bluestein route (0: direct factorisation)
  * AUD_EINVAL for an unknown name. */
 int aud_plan_get_info(const aud_plan* plan, const char* name, int64_t* value);
 
