@@ -6,9 +6,10 @@
 // triangle table.  Even N uses the packed-real trick (an N/2-point complex FFT plus one
 // split pass); odd N (e.g. the prime 1103 that 25 ms @ 44.1 kHz produces) runs a full
 // N-point complex FFT.  Radix 2, 3, 4, 5, 8, 16 and 25 stages run whole butterflies in registers
-// (the host factorises M into as few of them as possible); any other prime factor p goes
-// through an O(p) per-output pass, so every N is supported.  This is the
-// universal path; the common power-of-two sizes have faster specialised kernels.
+// (the host factorises M into as few of them as possible).  A length with any other prime factor
+// p takes Bluestein's chirp convolution (two power-of-two FFTs of length L >= 2 M - 1, one frame per
+// workgroup) where its two buffers fit LDS, and an O(p) per-output pass otherwise, so every N is
+// supported.  This is the universal path; the common sizes have faster specialised kernels.
 //
 // Reference semantics implemented here: sound/sndenv.go:438-478 (window extraction,
 // left zero pad, short-signal masking), dft/dft.go:53-85 (DFT of the raw window, power,
