@@ -143,3 +143,28 @@ def test_emul_sndenv_mirror_2d_gabor_kwta_layer(orc, emu):
 
 def test_emul_workgroup_order(orc, emu):
     PC.case_workgroup_order(orc, capi.AUD_F32, with_n2048=False)   # (one wave per frame: slow to emulate; GPU tier)
+
+
+def test_emul_plan_info(orc, emu):
+    """aud_plan_get_info: the launch facts of the kernel a plan selected, per family; unknown names are AUD_EINVAL"""
+    import workloads as W
+    expect = {"cfg2_16k_n400_nf40": ("w20x10", 6, 4), "cfg2_16k_n512_nf40": ("w16x16", 4, 4),
+              "cfg5_44k_n2048_nf128": ("w64x16", 1, 12), "cfg1_44k_n1103_nf32": ("generic", 0, 4)}
+    for name, (fam, fpw, waves) in expect.items():
+        oc = W.OracleCfg(orc, name, 100.0)
+        plan = W.product_plan(oc, capi.AUD_F64)
+        try:
+            assert plan.kernel_name == fam
+            assert plan.info("frames_per_wave") == fpw and plan.info("waves_per_wg") == waves
+            if fam == "generic":   # the prime window length takes the Bluestein route: L = the power of two >= 2 N - 1
+                assert plan.info("bluestein_L") == 4096 and plan.info("lds_bytes") == 0
+            else:
+                assert 0 < plan.info("lds_bytes") <= 160 * 1024 and plan.info("wgs_per_cu") >= 1
+                assert plan.info("bluestein_L") == 0
+            with pytest.raises(capi.AuditoryError):
+                plan.info("no_such_fact")
+            plan.set_option("kernel", 1)          # the generic kernel of a factorable length: no Bluestein
+            if fam != "generic":
+                assert plan.kernel_name == "generic" and plan.info("bluestein_L") == 0
+        finally:
+            plan.close()
