@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libauditory_hip.so")
-SOURCES = ["host_setup.cpp", "capi.hip", "melspec_generic.hip", "melspec_wave.hip", "melspec_r16.hip", "melspec_r25.hip", "melspec_r1024.hip", "smooth_mel.hip", "mfcc.hip", "gabor.hip", "kwta.hip"]
+SOURCES = ["host_setup.cpp", "capi.hip", "melspec_generic.hip", "melspec_wave.hip", "melspec_w16.hip", "melspec_w20.hip", "melspec_w64.hip", "smooth_mel.hip", "mfcc.hip", "gabor.hip", "kwta.hip"]
 
 
 def _hipcc():
@@ -38,12 +38,15 @@ def _flags():
             "-Xarch_host", "-ffp-contract=off", "-I" + INCLUDE, "-I" + CSRC]
 
 
-def build(force=False, verbose=False, stamps=False):
+def build(force=False, verbose=False, stamps=False, tag=None, defines=()):
     """hipcc --offload-arch=gfx950 -> libauditory_hip.so.  One compile job per source (only the stale ones, a few
     at a time), then one link.  Returns the path.  stamps=True builds the diagnostic variant
-    libauditory_hip_stamps.so (-DAUD_STAMPS: s_memtime stamps in the wave kernels, tools/stamp_profile.py)."""
+    libauditory_hip_stamps.so (-DAUD_STAMPS: s_memtime stamps in the wave kernels, tools/stamp_profile.py); tag + defines
+    an experimental build libauditory_hip_<tag>.so for tools/ab_bench.py (never shipped: *_<tag>.so is git-ignored)."""
     if stamps:
         return _build(True, verbose, os.path.join(HERE, "obj_stamps"), LIB.replace(".so", "_stamps.so"), ["-DAUD_STAMPS=1"])
+    if tag:
+        return _build(True, verbose, os.path.join(HERE, "obj_" + tag), LIB.replace(".so", "_%s.so" % tag), list(defines))
     if not force and not stale():
         return LIB
     return _build(force, verbose, os.path.join(HERE, "obj"), LIB, [])
@@ -74,4 +77,10 @@ def _build(force, verbose, objdir, LIB, extra):
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    argv = sys.argv[1:]
+    if "--tag" in argv:  # python -m auditory_amd.build --tag exp1 -DAUD_EXP_FOO=1
+        t = argv[argv.index("--tag") + 1]
+        print(build(tag=t, defines=[a for a in argv if a.startswith("-D")], verbose=True))
+    else:
+        print(build(force=True, verbose=True))

@@ -42,30 +42,13 @@ struct aud_plan {
     void* d_bl_chirp = nullptr;
     void* d_bl_bhat = nullptr;
     void* d_bl_tw = nullptr;
-    // register-resident kernel of this plan, if its window length has one
-    enum Fast { kNoFast = 0, kR16 = 1, kR25 = 2, kR1024 = 3 };
-    int fast_kind = kNoFast;   // which family the tables below were built for
-    bool use_fast = false;     // false: generic kernel (no fast family, or forced by an option)
     int xcd_remap = 1;         // workgroup -> tile order keeps an XCD on one run of tiles (kernels.h)
-    int gabor_lds = 0;         // 1: LDS-tiled gabor kernel where the mel matrix fits (option "gabor_lds"); measured slower, off
-    int r16_chunks = 0;
-    aud::FastArgs r16{};
-    // wave-autonomous kernel of the same window length (melspec_wave.hip), the default where it exists
-    enum Wave { kNoWave = 0, kW16 = 1, kW25 = 2, kW20 = 3, kW64 = 4 };  // = the kind number of melspec_wave.hip
-    std::vector<int32_t> h_bin_pts;   // host copies of the mel table: a change of wave geometry rebuilds the blob
-    std::vector<double> h_mel_filters;
-    int wave_kind = kNoWave;
-    bool use_wave = false;     // false: the workgroup-tile kernel of fast_kind (plan option "kernel" = 2)
-    aud::FastArgs wv{};
-    int* d_grp = nullptr;  // [17 + nf + 3 nf]: group offsets, filter ids, per-filter chunk info
-    void* d_w4 = nullptr;  // chunked triangle weights
-    unsigned* d_queue = nullptr;  // wave kernels, dynamic grid: ring of 64 x 128-byte queue slots, one per launch in flight
-    unsigned launch_seq = 0;
-    void* d_blob = nullptr;   // wave kernels: every read-only table, laid out like its LDS copy (kernels.h FastArgs)
+    // wave-autonomous kernel of this window length (melspec_wave.hip), the default where it exists
+    int wave_kind = 0;         // = the kind number of melspec_wave.hip (0: none)
+    bool use_wave = false;     // false: the generic kernel (no wave kernel, or plan option "kernel" = 1)
+    aud::WaveArgs wv{};
+    void* d_blob = nullptr;   // wave kernels: every read-only table, laid out like its LDS copy (kernels.h WaveArgs)
     void* d_gtab = nullptr;   // w64x16: lane-ordered pass-1 and split twiddles read from global memory
-    int* d_blk = nullptr;     // matrix-pipe mel variant (r16x16, float32): per 16-filter block {chunk0, steps, offset}
-    float* d_atab = nullptr;  // ... and its lane-ordered A operands [steps][64]
-    int n_blocks = 0;
     void* d_tw = nullptr;
     void* d_filt = nullptr;
     int32_t* d_bin_pts = nullptr;
@@ -205,34 +188,28 @@ void fill_melspec_args(const aud_plan* p, aud::MelspecArgs* a) {
 
 // the plan's frame -> power -> mel kernel (whatever family it selected), raw power, no smoothing
 hipError_t launch_frames(const aud_plan* p, const aud::MelspecArgs& a, hipStream_t st) {
-    if (p->use_fast && p->use_wave && p->wave_kind != aud_plan::kNoWave)
-        return aud::launch_melspec_wave(p->wave_kind, a, p->wv, p->d.compute_dtype, st);
-    if (p->use_fast && p->fast_kind == aud_plan::kR16) return aud::launch_melspec_r16(a, p->r16, p->d.compute_dtype, st);
-    if (p->use_fast && p->fast_kind == aud_plan::kR25) return aud::launch_melspec_r25(a, p->r16, p->d.compute_dtype, st);
-    if (p->use_fast && p->fast_kind == aud_plan::kR1024)
-        return aud::launch_melspec_r1024(a, p->r16, p->d.compute_dtype, st);
+    if (p->use_wave && p->wave_kind) return aud::launch_melspec_wave(p->wave_kind, a, p->wv, p->d.compute_dtype, st);
     return aud::launch_melspec_generic(a, p->d.compute_dtype, st);
 }
 
 const char* plan_family(const aud_plan* p);
 
 // Tables of the wave-autonomous kernels (melspec_wave.hip) as one blob that is copied verbatim into LDS:
-//   w4     per filter group one row of weights: the group's filters (its slots) one after the other, each as aligned
-//          4-bin chunks (zero weights outside [lo, hi]), slot k padded to slot_steps[k] chunks in every group
+//   w4     per filter group one row of FLOAT32 weights (both compute types; x 1/4, exact): the group's filters (its
+//          slots) one after the other, each as aligned 4-bin chunks (zero weights outside [lo, hi]), slot k padded to
+//          slot_steps[k] chunks in every group
 //   slots  per group and slot: the filter's first P chunk and its id (w64x16: compact rows, see below)
-//   twa    pass twiddles W_N^(2 j k1), [k1 - 1][j]; tws: split twiddles W_N^k, k <= N/4
+//   twa    pass twiddles W_N^(2 j k1), [k1 - 1][j]; tws: split twiddles W_N^k, k <= N/4 (compute type)
 // A plan whose tables do not fit (16-bit indices, LDS) simply has no wave kernel.
-int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_filters, int force_kind = 0) {
+int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_filters) {
     aud_ctx* c = p->ctx;
     const aud_plan_desc& d = p->d;
     const int N = d.win_samples, nf = d.mel.n_filters, dt = d.compute_dtype;
-    // N = 512 -> w16x16; N = 400 -> w20x10 (default) or w25x8 (plan option "n400_geometry" = 25)
-    // N = 2048 -> w64x16 (one frame per wave)
-    const int kind = force_kind ? force_kind : p->fast_kind == aud_plan::kR16 ? 1 : p->fast_kind == aud_plan::kR25 ? 3
-                                              : p->fast_kind == aud_plan::kR1024 ? 4 : 0;
+    const int kind = aud::melspec_wave_kind(N);  // N = 512 -> w16x16; N = 400 -> w20x10; N = 2048 -> w64x16
     aud::WaveGeometry g;
     if (!kind || !aud::melspec_wave_geometry(kind, N, &g)) return AUD_OK;
-    const size_t tsz = dt == AUD_F64 ? 8 : 4;
+    const size_t tsz = dt == AUD_F64 ? 8 : 4;  // twiddles
+    const size_t wsz = 4;                       // weights: float32
     const int G = g.n_groups, p_chunks = (N / 2 + 1 + 3) / 4;  // chunks of a padded power row (kHp / 4 of the kernel)
     if (nf >= 0xFFFF || nf > 8 * G) return AUD_OK;  // more than eight filters per group: no wave kernel
     // chunks per filter; a filter without taps still takes one (all-zero) step: its sum is 0 + LogOff
@@ -247,7 +224,7 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
     // widest filters first, dealt round-robin: slot k of every group then holds filters of nearly equal width
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return nc[x] > nc[y]; });
     const int n_slots = std::max(1, (nf + G - 1) / G);
-    aud::FastArgs e{};
+    aud::WaveArgs e{};
     int n_steps = 0;
     std::vector<int> slot_pos(n_slots);
     for (int k = 0; k < n_slots; ++k) {
@@ -264,9 +241,9 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
     std::vector<uint32_t> slots;
     if (!compact) {
         // weight rows: row stride an odd number of 16-byte pieces, so that the groups' reads of one step spread over the banks
-        w_stride = size_t(n_steps) * 4 * tsz;
+        w_stride = size_t(n_steps) * 4 * wsz;
         if ((w_stride / 16) % 2 == 0) w_stride += 16;
-        wrows.assign(size_t(G) * (w_stride / tsz), 0.0);
+        wrows.assign(size_t(G) * (w_stride / wsz), 0.0);
         slots.assign(size_t(G) * n_slots, 0xFFFFu << 16);
     } else {
         // compact rows: every filter keeps only its own chunks (from the first P chunk its slot reads), one shared all-zero
@@ -276,9 +253,8 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
         for (int gi = 0; gi < G; ++gi)
             for (int k = 0; k < n_slots; ++k) slots[(size_t(gi) * n_slots + k) * 2] = 0xFFFFu << 16;
         wrows.assign(4, 0.0);  // the zero chunk, at piece 0
-        e.n_chunks = 0;
     }
-    size_t wpieces = 4 * tsz / 16;        // compact rows: 16-byte pieces laid down so far
+    size_t wpieces = 4 * wsz / 16;        // compact rows: 16-byte pieces laid down so far
     unsigned used[8][4] = {};             // [slot][16-lane read group]: piece residues mod 16 taken
     for (int r = 0; r < nf; ++r) {
         const int f = order[r], k = r / G, gi = r % G, ns = e.slot_steps[k];
@@ -287,7 +263,7 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
         double* wr;
         if (!compact) {
             slots[size_t(gi) * n_slots + k] = uint32_t(pc0) | (uint32_t(f) << 16);
-            wr = &wrows[size_t(gi) * (w_stride / tsz) + size_t(slot_pos[k]) * 4];
+            wr = &wrows[size_t(gi) * (w_stride / wsz) + size_t(slot_pos[k]) * 4];
         } else {
             const int own = hi >= lo ? c0[f] + nc[f] - pc0 : 0;  // chunks from pc0 to the filter's last one
             // a row may start on any 16-byte piece; its start is pushed forward (<= 15 pieces) until its piece index mod 16
@@ -299,13 +275,13 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
             size_t piece = wpieces;
             for (int tries = 0; tries < 16 && (used[k][grp16] >> (piece & 15) & 1u); ++tries) ++piece;
             used[k][grp16] |= 1u << (piece & 15);
-            const size_t per_chunk = 4 * tsz / 16;  // 16-byte pieces per chunk: 1 (float32) or 2 (float64)
+            const size_t per_chunk = 4 * wsz / 16;  // 16-byte pieces per chunk
             if (piece + size_t(own) * per_chunk > 0xFFFF) return AUD_OK;
             slots[(size_t(gi) * n_slots + k) * 2] = uint32_t(pc0) | (uint32_t(f) << 16);
             slots[(size_t(gi) * n_slots + k) * 2 + 1] = uint32_t(piece) | (uint32_t(own) << 16);
             wpieces = piece + size_t(own) * per_chunk;
-            wrows.resize(wpieces * 16 / tsz, 0.0);
-            wr = wrows.data() + piece * 16 / tsz;
+            wrows.resize(wpieces * 16 / wsz, 0.0);
+            wr = wrows.data() + piece * 16 / wsz;
         }
         if (hi >= lo)
             for (int bin = lo; bin <= hi; ++bin)  // x 1/4 (exact): the kernels keep FOUR times the power in LDS
@@ -350,10 +326,9 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
     }
     // the blob
     auto align32 = [](size_t v) { return (v + 31) & ~size_t(31); };
-    const size_t w4_bytes = align32(wrows.size() * tsz);
+    const size_t w4_bytes = align32(wrows.size() * wsz);
     e.w4_off = 0;
     e.w_stride = int(w_stride);
-    e.n_steps = n_steps;
     e.slots_off = int(w4_bytes);
     e.n_slots = n_slots;
     e.twa_off = int(e.slots_off + align32(slots.size() * 4));
@@ -370,7 +345,10 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
             std::memcpy(&blob[off], fv.data(), fv.size() * 4);
         }
     };
-    put_real(size_t(e.w4_off), wrows);
+    {
+        std::vector<float> fw = convert<float>(wrows.data(), wrows.size());
+        std::memcpy(&blob[size_t(e.w4_off)], fw.data(), fw.size() * 4);
+    }
     std::memcpy(&blob[size_t(e.slots_off)], slots.data(), slots.size() * 4);
     put_real(size_t(e.twa_off), twa);
     put_real(size_t(e.tws_off), tws);
@@ -380,16 +358,8 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
         (void)hipGetLastError();
         return AUD_OK;
     }
-    if (p->d_blob) {  // a rebuild for another geometry
-        (void)hipFree(p->d_blob);
-        p->d_blob = nullptr;
-    }
     int rc = upload(c, &p->d_blob, blob.data(), blob.size());
     if (rc != AUD_OK) return rc;
-    if (p->d_gtab) {
-        (void)hipFree(p->d_gtab);
-        p->d_gtab = nullptr;
-    }
     if (!gtab.empty()) {
         if (dt == AUD_F64) rc = upload(c, &p->d_gtab, gtab.data(), gtab.size() * 8);
         else {
@@ -399,11 +369,6 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
         if (rc != AUD_OK) return rc;
     }
     e.gtab = p->d_gtab;
-    if (!p->d_queue) {
-        std::vector<unsigned> zeros(64 * 32, 0u);
-        rc = upload(c, reinterpret_cast<void**>(&p->d_queue), zeros.data(), zeros.size() * sizeof(unsigned));
-        if (rc != AUD_OK) return rc;
-    }
     e.blob = p->d_blob;
     p->wv = e;
     p->wave_kind = kind;
@@ -412,20 +377,9 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
     return AUD_OK;
 }
 
-// the r16_* switches are variants of the workgroup-tile kernel: setting one selects that kernel
-void select_tile_kernel(aud_plan* p) {
-    p->use_fast = true;
-    p->use_wave = false;
-    p->family = plan_family(p);
-}
-
 const char* plan_family(const aud_plan* p) {
-    if (!p->use_fast || p->fast_kind == aud_plan::kNoFast) return "generic";
-    if (p->use_wave && p->wave_kind == aud_plan::kW16) return "w16x16";
-    if (p->use_wave && p->wave_kind == aud_plan::kW25) return "w25x8";
-    if (p->use_wave && p->wave_kind == aud_plan::kW20) return "w20x10";
-    if (p->use_wave && p->wave_kind == aud_plan::kW64) return "w64x16";
-    return p->fast_kind == aud_plan::kR16 ? "r16x16" : p->fast_kind == aud_plan::kR25 ? "r25x8" : "r16x16x4";
+    if (!p->use_wave || !p->wave_kind) return "generic";
+    return p->wave_kind == 1 ? "w16x16" : p->wave_kind == 3 ? "w20x10" : "w64x16";
 }
 
 }  // namespace
@@ -615,142 +569,9 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
             }
         rc = upload_real(c, &p->d_dct, dct.data(), dct.size(), d->compute_dtype);
     }
-    // kernel family: the in-register 16 x 16 kernel for 512-sample windows, else the generic one
-    int r16_chunks = 0;
-    for (int f = 0; f < nf; ++f) {
-        const int lo = bin_pts[f], hi = bin_pts[f + 2];
-        if (hi >= lo) r16_chunks += (hi >> 2) - (lo >> 2) + 1;
-    }
-    if (r16_chunks == 0) r16_chunks = 1;
-    p->r16_chunks = r16_chunks;
-    aud::FastArgs fastcfg;
-    std::memset(&fastcfg, 0, sizeof(fastcfg));
-    int fast_kind = aud_plan::kNoFast, n_groups = 0;
-    const char* fast_name = "generic";
-    if (aud::melspec_r16_supported(N, d->step_samples, d->compute_dtype, r16_chunks, nf, true, &fastcfg)) {
-        fast_kind = aud_plan::kR16;
-        n_groups = 16;  // 256 threads = 16 frames x 16 filter groups
-        fast_name = "r16x16";
-    } else if (aud::melspec_r25_supported(N, d->step_samples, d->compute_dtype, r16_chunks, nf, &fastcfg)) {
-        fast_kind = aud_plan::kR25;
-        n_groups = 8;  // 128 threads = 16 frames x 8 filter groups
-        fast_name = "r25x8";
-    } else if (aud::melspec_r1024_supported(N, d->step_samples, d->compute_dtype, r16_chunks, nf, &fastcfg)) {
-        fast_kind = aud_plan::kR1024;
-        n_groups = 64;  // 256 threads = 4 frames x 64 filter groups
-        fast_name = "r16x16x4";
-    }
-    if (rc == AUD_OK && fast_kind != aud_plan::kNoFast) {
-        // balance the mel filters over the thread groups by tap count (longest first, LPT)
-        std::vector<int> order(nf), load(n_groups, 0), owner(nf);
-        for (int f = 0; f < nf; ++f) order[f] = f;
-        auto taps = [&](int f) {  // cost model: 4-bin chunks + a fixed per-filter epilogue (log, store)
-            const int lo = bin_pts[f], hi = bin_pts[f + 2];
-            return (hi >= lo ? (hi >> 2) - (lo >> 2) + 1 : 0) * 6 + 30;
-        };
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return taps(x) > taps(y); });
-        for (int f : order) {
-            int g = 0;
-            for (int cnd = 1; cnd < n_groups; ++cnd)
-                if (load[cnd] < load[g]) g = cnd;
-            owner[f] = g;
-            load[g] += taps(f);
-        }
-        const int goff = n_groups + 1;  // table: [n_groups + 1 offsets][nf filter ids][nf x 3 chunk info]
-        std::vector<int> tab(goff + nf + 3 * nf, 0);
-        int pos = 0;
-        for (int g = 0; g < n_groups; ++g) {
-            tab[g] = pos;
-            for (int f = 0; f < nf; ++f)
-                if (owner[f] == g) tab[goff + pos++] = f;
-        }
-        tab[n_groups] = pos;
-        // triangles as 4-bin chunks aligned to bins 0, 4, 8, ...; table cells are addressed by the
-        // reference's flat offset f*(nf+2) + (bin - lo), weights outside [lo, hi] are zero
-        std::vector<double> w4;
-        for (int f = 0; f < nf; ++f) {
-            const int lo = bin_pts[f], hi = bin_pts[f + 2];
-            int* ci = &tab[goff + nf + 3 * f];
-            ci[0] = lo >> 2;
-            ci[1] = hi >= lo ? (hi >> 2) - (lo >> 2) + 1 : 0;
-            ci[2] = int(w4.size() / 4);
-            for (int cidx = 0; cidx < ci[1]; ++cidx)
-                for (int el = 0; el < 4; ++el) {
-                    const int bin = 4 * (ci[0] + cidx) + el;
-                    w4.push_back(bin >= lo && bin <= hi ? mel_filters[int64_t(f) * (nf + 2) + (bin - lo)] : 0.0);
-                }
-        }
-        if (w4.empty()) w4.assign(4, 0.0);
-        rc = upload(c, reinterpret_cast<void**>(&p->d_grp), tab.data(), tab.size() * sizeof(int));
-        if (rc == AUD_OK) rc = upload_real(c, &p->d_w4, w4.data(), w4.size(), d->compute_dtype);
-        // Launches above the 64 KB default of dynamic LDS must be requested per kernel.  If the runtime
-        // refuses, the plan quietly keeps the generic kernel (same results, fits 64 KB by construction).
-        bool fast_usable = true;
-        if (rc == AUD_OK && fastcfg.lds_bytes > 64u * 1024u) {
-            const hipError_t pe = fast_kind == aud_plan::kR16   ? aud::melspec_r16_prepare(fastcfg.lds_bytes)
-                                  : fast_kind == aud_plan::kR25 ? aud::melspec_r25_prepare(fastcfg.lds_bytes)
-                                                                : aud::melspec_r1024_prepare(fastcfg.lds_bytes);
-            if (pe != hipSuccess) {
-                (void)hipGetLastError();
-                fast_usable = false;
-            }
-        }
-        if (rc == AUD_OK && !fast_usable) fast_kind = aud_plan::kNoFast;
-        if (rc == AUD_OK && fast_kind == aud_plan::kR16 && d->compute_dtype == AUD_F32) {
-            // tables of the matrix-pipe mel variant (option "r16_mel" = 1): filters in blocks of 16, each block a
-            // dense [16 filters x 4-bin steps] band; lane l of a step holds filter 16 b + (l & 15), bin + (l >> 4)
-            const int nb = (nf + 15) / 16;
-            std::vector<int> blk(3 * size_t(nb), 0);
-            std::vector<float> atab;
-            for (int b = 0; b < nb; ++b) {
-                int cmin = INT_MAX, cmax = -1;
-                for (int f = 16 * b; f < std::min(nf, 16 * b + 16); ++f) {
-                    const int lo = bin_pts[f], hi = bin_pts[f + 2];
-                    if (hi < lo) continue;
-                    cmin = std::min(cmin, lo >> 2);
-                    cmax = std::max(cmax, hi >> 2);
-                }
-                const int ns = cmax >= 0 ? cmax - cmin + 1 : 0;
-                blk[3 * b] = ns ? cmin : 0;
-                blk[3 * b + 1] = ns;
-                blk[3 * b + 2] = int(atab.size() / 64);
-                for (int st = 0; st < ns; ++st)
-                    for (int l = 0; l < 64; ++l) {
-                        const int f = 16 * b + (l & 15), bin = 4 * (cmin + st) + (l >> 4);
-                        float w = 0.f;
-                        if (f < nf) {
-                            const int lo = bin_pts[f], hi = bin_pts[f + 2];
-                            if (bin >= lo && bin <= hi) w = float(mel_filters[int64_t(f) * (nf + 2) + (bin - lo)]);
-                        }
-                        atab.push_back(w);
-                    }
-            }
-            if (atab.empty()) atab.assign(64, 0.f);
-            p->n_blocks = nb;
-            rc = upload(c, reinterpret_cast<void**>(&p->d_blk), blk.data(), blk.size() * sizeof(int));
-            if (rc == AUD_OK)
-                rc = upload(c, reinterpret_cast<void**>(&p->d_atab), atab.data(), atab.size() * sizeof(float));
-        }
-        if (rc == AUD_OK && fast_kind != aud_plan::kNoFast) {
-            p->fast_kind = fast_kind;
-            p->use_fast = true;
-            p->family = fast_name;
-            p->r16 = fastcfg;
-            p->r16.ntile = 1;
-            p->r16.grp_off = p->d_grp;
-            p->r16.grp_flt = p->d_grp + goff;
-            p->r16.chunk = p->d_grp + goff + nf;
-            p->r16.w4 = p->d_w4;
-            p->r16.mel_mfma = 0;
-            p->r16.n_blocks = p->n_blocks;
-            p->r16.blk = p->d_blk;
-            p->r16.atab = p->d_atab;
-            // the wave-autonomous kernel of this window length (melspec_wave.hip) has its own table blob
-            p->h_bin_pts.assign(bin_pts, bin_pts + nf + 2);
-            p->h_mel_filters.assign(mel_filters, mel_filters + cells);
-            if (rc == AUD_OK) rc = build_wave_tables(p, bin_pts, mel_filters);
-        }
-    }
+    // kernel family: the wave-autonomous kernel of this window length where one exists and its tables fit, else the
+    // generic any-N kernel
+    if (rc == AUD_OK) rc = build_wave_tables(p, bin_pts, mel_filters);
     if (rc != AUD_OK) {
         aud_plan_destroy(p);
         return rc;
@@ -770,13 +591,8 @@ int aud_plan_destroy(aud_plan* p) {
     if (p->d_bin_pts) (void)hipFree(p->d_bin_pts);
     if (p->d_gabor) (void)hipFree(p->d_gabor);
     if (p->d_dct) (void)hipFree(p->d_dct);
-    if (p->d_grp) (void)hipFree(p->d_grp);
-    if (p->d_w4) (void)hipFree(p->d_w4);
     if (p->d_blob) (void)hipFree(p->d_blob);
     if (p->d_gtab) (void)hipFree(p->d_gtab);
-    if (p->d_queue) (void)hipFree(p->d_queue);
-    if (p->d_blk) (void)hipFree(p->d_blk);
-    if (p->d_atab) (void)hipFree(p->d_atab);
     delete p;
     return AUD_OK;
 }
@@ -786,14 +602,17 @@ const char* aud_plan_kernel_name(const aud_plan* p) { return p ? p->family : "";
 int aud_plan_get_info(const aud_plan* p, const char* name, int64_t* value) {
     if (!p || !name || !value) return AUD_EINVAL;
     const std::string key(name);
-    const bool wave = p->use_wave, tile = !wave && p->use_fast;
-    const aud::FastArgs* f = wave ? &p->wv : tile ? &p->r16 : nullptr;
-    if (key == "lds_bytes") *value = f ? int64_t(f->lds_bytes) : 0;
+    const bool wave = p->use_wave && p->wave_kind;
+    if (key == "lds_bytes") *value = wave ? int64_t(p->wv.lds_bytes) : 0;
     else if (key == "waves_per_wg") *value = wave ? p->wv.waves : 4;
     else if (key == "wgs_per_cu") *value = wave ? p->wv.wgs_per_cu : 0;
-    else if (key == "bluestein_L") *value = (!wave && !tile) ? p->bl_L : 0;
-    else if (key == "frames_per_wave") *value = wave ? (p->wave_kind == 1 ? 4 : p->wave_kind == 2 ? 8 : p->wave_kind == 3 ? 6 : 1) : 0;
-    else return fail(p->ctx, AUD_EINVAL, "aud_plan_get_info: unknown name");
+    else if (key == "bluestein_L") *value = wave ? 0 : p->bl_L;
+    else if (key == "frames_per_wave") *value = wave ? aud::melspec_wave_frames_per_wave(p->wave_kind) : 0;
+    else if (key == "epilogue_steps") {
+        int n = 0;
+        for (int k = 0; k < p->wv.n_slots && k < 8; ++k) n += p->wv.slot_steps[k];
+        *value = wave ? n : 0;
+    } else return fail(p->ctx, AUD_EINVAL, "aud_plan_get_info: unknown name");
     return AUD_OK;
 }
 
@@ -801,103 +620,15 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
     if (!p || !name) return AUD_EINVAL;
     aud_ctx* c = p->ctx;
     const std::string key(name);
-    if (key == "kernel") {  // 0 = automatic choice, 1 = the generic any-N kernel, 2 = the workgroup-tile kernel
-        if (value < 0 || value > 2) return fail(c, AUD_EINVAL, "kernel: 0 (auto), 1 (generic) or 2 (workgroup-tile family)");
-        if (value == 2 && p->fast_kind == aud_plan::kNoFast)
-            return fail(c, AUD_EINVAL, "kernel = 2: this window length has no workgroup-tile kernel");
-        p->use_fast = value != 1 && p->fast_kind != aud_plan::kNoFast;
-        p->use_wave = value == 0 && p->wave_kind != aud_plan::kNoWave;
+    if (key == "kernel") {  // 0 = automatic choice, 1 = the generic any-N kernel
+        if (value < 0 || value > 1) return fail(c, AUD_EINVAL, "kernel: 0 (auto) or 1 (generic)");
+        p->use_wave = value == 0 && p->wave_kind != 0;
         p->family = plan_family(p);
-        return AUD_OK;
-    }
-    if (key == "r16_input") {  // 0 = operands straight from global memory, 1 = staged through LDS
-        if (p->fast_kind != aud_plan::kR16) return fail(c, AUD_EINVAL, "plan has no r16x16 kernel");
-        if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "r16_input: 0 (direct) or 1 (staged)");
-        aud::FastArgs cfg = p->r16;
-        if (!aud::melspec_r16_supported(p->d.win_samples, p->d.step_samples, p->d.compute_dtype, p->r16_chunks,
-                                        p->d.mel.n_filters, value == 0, &cfg))
-            return fail(c, AUD_EINVAL, "this r16x16 variant does not support the plan (odd step?)");
-        cfg.ntile = value == 0 ? p->r16.ntile : 1;
-        if (cfg.lds_bytes > 64u * 1024u && cfg.lds_bytes > p->r16.lds_bytes) {  // the staged float64 variant: ~93 KB
-            AUD_HIP(c, make_current(c));
-            if (aud::melspec_r16_prepare(cfg.lds_bytes) != hipSuccess) {
-                (void)hipGetLastError();
-                return fail(c, AUD_EHIP, "r16_input: the runtime refused the LDS size of this variant");
-            }
-        }
-        p->r16 = cfg;
-        select_tile_kernel(p);
-        return AUD_OK;
-    }
-    if (key == "r16_tiles") {  // 16-frame tiles per workgroup of the direct r16x16 kernel: 1 or 2 (second prefetched)
-        if (p->fast_kind != aud_plan::kR16) return fail(c, AUD_EINVAL, "plan has no r16x16 kernel");
-        if (value != 1 && value != 2) return fail(c, AUD_EINVAL, "r16_tiles: 1 or 2");
-        if (value == 2 && !p->r16.direct) return fail(c, AUD_EINVAL, "r16_tiles = 2 needs the direct input variant");
-        p->r16.ntile = value;
-        select_tile_kernel(p);
-        return AUD_OK;
-    }
-    if (key == "wave_variant") {  // A/B of the persistent wave kernels: 0 prefetch, 1 prefetch + capped registers, 2 no prefetch
-        if (p->wave_kind == aud_plan::kNoWave) return fail(c, AUD_EINVAL, "plan has no wave kernel");
-        if (value < 0 || value > 2) return fail(c, AUD_EINVAL, "wave_variant: 0, 1 or 2");
-        aud::FastArgs cfg = p->wv;
-        cfg.variant = value;
-        AUD_HIP(c, make_current(c));
-        if (aud::melspec_wave_prepare(p->wave_kind, p->d.compute_dtype, &cfg) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(c, AUD_EHIP, "wave_variant: the runtime refused the kernel attributes");
-        }
-        p->wv = cfg;
-        return AUD_OK;
-    }
-    if (key == "n400_geometry") {  // N = 400 wave kernel: 20 (default: 20 x 10, 6 frames per wave) or 25 (25 x 8, 8 frames per wave)
-        if (p->fast_kind != aud_plan::kR25 || p->h_bin_pts.empty()) return fail(c, AUD_EINVAL, "plan is not an N = 400 plan");
-        if (value != 20 && value != 25) return fail(c, AUD_EINVAL, "n400_geometry: 20 or 25");
-        AUD_HIP(c, make_current(c));
-        const int keep_grid = p->wv.persistent;
-        p->wave_kind = aud_plan::kNoWave;
-        const int rc = build_wave_tables(p, p->h_bin_pts.data(), p->h_mel_filters.data(), value == 20 ? 3 : 2);
-        if (rc != AUD_OK) return rc;
-        if (p->wave_kind == aud_plan::kNoWave) return fail(c, AUD_EINVAL, "n400_geometry: the tables of this plan do not fit that kernel");
-        p->wv.persistent = keep_grid;
-        p->family = plan_family(p);
-        return AUD_OK;
-    }
-    if (key == "wave_grid") {  // -1 (default): by launch size; 0: one wave tile per wave; 1: persistent grid of resident workgroups
-        if (p->wave_kind == aud_plan::kNoWave) return fail(c, AUD_EINVAL, "plan has no wave kernel");
-        if (value < -1 || value > 2) return fail(c, AUD_EINVAL, "wave_grid: -1, 0, 1 or 2");
-        if (value == 2) {  // the dynamic variant's attributes
-            aud::FastArgs cfg = p->wv;
-            cfg.variant = 3;
-            AUD_HIP(c, make_current(c));
-            if (aud::melspec_wave_prepare(p->wave_kind, p->d.compute_dtype, &cfg) != hipSuccess) {
-                (void)hipGetLastError();
-                return fail(c, AUD_EHIP, "wave_grid: the runtime refused the kernel attributes");
-            }
-            p->wv.max_wgs = cfg.max_wgs;
-            p->wv.wgs_per_cu = cfg.wgs_per_cu;
-        }
-        p->wv.persistent = value;
-        return AUD_OK;
-    }
-    if (key == "gabor_lds") {  // 0 (default): the global-memory gabor kernel; 1: LDS-tiled kernel where an item's mel matrix fits
-        // 2 / 4: the default FilterSet with two / four threads per output position (k_gabor_split)
-        if (value != 0 && value != 1 && value != 2 && value != 4) return fail(c, AUD_EINVAL, "gabor_lds: 0, 1, 2 or 4");
-        p->gabor_lds = value;
         return AUD_OK;
     }
     if (key == "xcd_remap") {  // 1 (default): every XCD walks a contiguous run of tiles; 0: tiles in workgroup-id order
         if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "xcd_remap: 0 or 1");
         p->xcd_remap = value;
-        return AUD_OK;
-    }
-    if (key == "r16_mel") {  // 0 = chunked reduction on the vector pipe, 1 = banded filter x bin GEMM on the matrix pipe
-        if (p->fast_kind != aud_plan::kR16) return fail(c, AUD_EINVAL, "plan has no r16x16 kernel");
-        if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "r16_mel: 0 (vector pipe) or 1 (matrix pipe)");
-        if (value == 1 && p->d.compute_dtype != AUD_F32)
-            return fail(c, AUD_EINVAL, "r16_mel = 1 is a float32 variant (v_mfma_f32_16x16x4_f32)");
-        p->r16.mel_mfma = value;
-        select_tile_kernel(p);
         return AUD_OK;
     }
 #ifdef AUD_STAMPS
@@ -933,9 +664,6 @@ int aud_melspec_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
     a.mel = mel;
     a.power = power;
     a.log_power = log_power;
-    // dynamic grid: every launch takes the next slot of the queue ring (launches of one plan may overlap on several
-    // streams; a captured launch keeps its slot, and replays of one graph are ordered)
-    a.queue = p->d_queue ? p->d_queue + 32 * (p->launch_seq++ & 63u) : nullptr;
     AUD_HIP(c, launch_frames(p, a, static_cast<hipStream_t>(stream)));
     if (smooth) {
         // dft.go:67-69: p_s = Prev*p_{s-1} + Cur*raw_s along the steps, then log-power and mel from it
@@ -1047,7 +775,6 @@ int aud_gabor_batch_dev(aud_plan* p, const float* mel, int n_items, int rows, in
     a.nF = nF;
     a.t_max_strides = strides;
     a.out = out;
-    a.use_lds = p->gabor_lds;
     AUD_HIP(c, aud::launch_gabor(a, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
     return AUD_OK;
 }

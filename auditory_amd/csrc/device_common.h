@@ -263,104 +263,135 @@ __device__ __forceinline__ TT pcm16_to(int v) {
     else return pcm16_to_double(v);
 }
 
-// First-pass operands of one frame for the register-resident kernels: the frame's N samples as N/2 packed
-// pairs z[n] = (x[2n], x[2n+1]); this lane takes z[lane + STRIDE n1], n1 = 0..NV-1.  Three routes:
-//   1 float32 samples, frame inside the stream: one 8-byte load per pair (two 4-byte loads where the frame starts on
-//     an odd sample), widened to the compute type in registers;
-//   2 int16 samples under the same conditions: one 4-byte load per pair (two 2-byte loads on odd starts), normalised
-//     on the fly (half the input bytes of the float route);
-//   0 anything else (stream edges, left zero pad, float64 samples, strided streams): guarded element loads.
-// Split in two so that a persistent kernel can request the next tile's operands before it computes the current
-// one: frame_pairs_issue() only issues the loads of routes 1 / 2 (raw words, no wait), frame_pairs_take() converts
-// them -- or runs route 0 on the spot.
-template <int NV>
-struct FrameRaw {
-    uint2 w[NV];  // route 1: the two float bit patterns; route 2: .x = the packed int16 pair
+// ---- first-pass operands of the wave kernels --------------------------------------------------------------------
+// A frame's N samples as N/2 packed pairs z[n] = (x[2n], x[2n+1]); a lane takes z[lane + STRIDE n1], n1 = 0..NV-1.  The
+// kernels are instantiated per SAMPLE TYPE (SRC = the launch's sig_dtype), and where a tile's samples come from is
+// wave-uniform (one item per wave tile), so the route is chosen on the scalar unit and no load sits under a lane condition:
+//   float32 / int16 PCM (SRC = AUD_F32 / AUD_I16): buffer loads through a descriptor over the part of the ITEM's stream the
+//     tile can touch -- the hardware returns 0 for any offset outside it, which is exactly the left zero pad of SndToWindow
+//     (sndenv.go:461-468); frames that run off the END are masked later (sndenv.go:458-460), whatever was loaded for them.
+//       pairs  contiguous stream, pairs on a 4-byte grid: ONE buffer_load_dwordx2 (int16: dword) per pair.  The hardware
+//              takes 8-byte loads at 4-byte alignment, so float32 frames that start on an odd sample (odd step lengths: 441
+//              at 44.1 kHz) need no second flavour;
+//       elems  otherwise (one channel of interleaved stereo: sig_stride 2; int16 frames that start on an odd sample; a
+//              left zero pad that would cut a pair in two): two element loads per pair;
+//   float64 (SRC = AUD_F64, what the host-buffer entry points upload): guarded element loads.
+enum { kRoutePairs = 1, kRouteElems = 2 };
+template <int SRC>
+struct SampleWindow {
+    __amdgpu_buffer_rsrc_t rsrc;
     int route;
+    int step;      // bytes between consecutive samples of the stream
+    int64_t lo;    // stream position of the descriptor's first sample
 };
-template <int NV, int STRIDE, int N, bool PCM16_ROUTE = true, bool ODD_ROUTE = false>
-__device__ __forceinline__ void frame_pairs_issue(const MelspecArgs& a, const aud_item& it, int sstep, int lane,
-                                                  FrameRaw<NV>& r) {
-    const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
-    const int64_t pos0 = start + 2 * lane;
-    // a frame that starts on an odd sample (odd step lengths: 441 at 44.1 kHz) has pairs that straddle the 8-byte
-    // (int16: 4-byte) grid.  ODD_ROUTE (the one-frame-per-wave kernel, where the parity is wave-uniform): its pairs are
-    // fetched as two element loads each -- same raw words, same conversion; otherwise such frames take route 0 (in the
-    // kernels with several frames per wave the second flavour of loads under a lane condition cost 5-10 % on even frames)
-    // A strided stream (one channel of interleaved stereo, sig_stride = 2) is the same case: element loads, stride apart.
-    const int64_t str = it.sig_stride > 1 ? it.sig_stride : 1;
-    const bool even = ((it.sig_off + start) & 1) == 0 && str == 1;
-    const bool inside = sstep < a.T && start >= 0 && start + N <= int64_t(it.sig_len) && (ODD_ROUTE || even);
-    r.route = 0;
-    if (inside && a.sig_dtype == AUD_F32 && (reinterpret_cast<uintptr_t>(a.sig) & 7) == 0) {
-        if (!ODD_ROUTE || even) {
-            const uint2* __restrict__ src =
-                reinterpret_cast<const uint2*>(static_cast<const float*>(a.sig) + it.sig_off + pos0);
-#pragma unroll
-            for (int n1 = 0; n1 < NV; ++n1) r.w[n1] = src[STRIDE * n1];
-        } else {
-            const uint32_t* __restrict__ src =
-                reinterpret_cast<const uint32_t*>(static_cast<const float*>(a.sig) + it.sig_off + pos0 * str);
-#pragma unroll
-            for (int n1 = 0; n1 < NV; ++n1) r.w[n1] = uint2{src[(2 * STRIDE * n1) * str], src[(2 * STRIDE * n1 + 1) * str]};
-        }
-        r.route = 1;
+template <>
+struct SampleWindow<AUD_F64> {};
+// first_start: start sample of the tile's FIRST frame; span: samples from there to the end of its last frame; every
+// argument wave-uniform
+template <int SRC>
+__device__ __forceinline__ SampleWindow<SRC> sample_window(const MelspecArgs& a, const aud_item& it, int64_t first_start,
+                                                           int span) {
+    SampleWindow<SRC> w;
+    if constexpr (SRC != AUD_F64) {
+        constexpr int esize = SRC == AUD_F32 ? 4 : 2;
+        const int str = it.sig_stride > 1 ? it.sig_stride : 1;
+        const int64_t lo = first_start > 0 ? first_start : 0;
+        int64_t n = int64_t(it.sig_len) - lo;  // samples of the stream from lo on, as far as the tile can reach
+        if (n > int64_t(span) + (first_start < 0 ? first_start : 0)) n = int64_t(span) + (first_start < 0 ? first_start : 0);
+        const int64_t bytes = n > 0 ? ((n - 1) * str + 1) * esize : 0;
+        const char* base = static_cast<const char*>(a.sig) + (int64_t(it.sig_off) + lo * str) * esize;
+        // a pair load needs the pair inside one 4-byte-aligned unit and whole pairs on either side of sample 0
+        const bool all_even = ((it.start0 | a.S) & 1) == 0;
+        const bool pairs = str == 1 && (reinterpret_cast<uintptr_t>(base) & 3) == 0 &&
+                           (SRC == AUD_F32 ? (first_start >= 0 || all_even) : (a.S & 1) == 0 && (first_start >= 0 || all_even));
+        w.route = pairs ? kRoutePairs : kRouteElems;
+        w.step = str * esize;
+        w.lo = lo;
+        w.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, bytes < (int64_t(1) << 30) ? int(bytes) : 0,
+                                                   0x00020000);
     }
-    if constexpr (PCM16_ROUTE) {
-        if (inside && a.sig_dtype == AUD_I16 && (reinterpret_cast<uintptr_t>(a.sig) & 3) == 0) {
-            if (!ODD_ROUTE || even) {
-                const uint32_t* __restrict__ src =
-                    reinterpret_cast<const uint32_t*>(static_cast<const int16_t*>(a.sig) + it.sig_off + pos0);
-#pragma unroll
-                for (int n1 = 0; n1 < NV; ++n1) r.w[n1].x = src[STRIDE * n1];
-            } else {
-                const unsigned short* __restrict__ src =
-                    reinterpret_cast<const unsigned short*>(static_cast<const int16_t*>(a.sig) + it.sig_off + pos0 * str);
-#pragma unroll
-                for (int n1 = 0; n1 < NV; ++n1)
-                    r.w[n1].x = uint32_t(src[(2 * STRIDE * n1) * str]) | (uint32_t(src[(2 * STRIDE * n1 + 1) * str]) << 16);
-            }
-            r.route = 2;
-        }
-    }
+    return w;
 }
-template <typename TT, int NV, int STRIDE, int N, bool PCM16_ROUTE = true>
-__device__ __forceinline__ void frame_pairs_take(const MelspecArgs& a, const aud_item& it, int sstep, int lane,
-                                                 const FrameRaw<NV>& r, C2<TT> (&v)[NV]) {
-    if (r.route == 1) {
-#pragma unroll
-        for (int n1 = 0; n1 < NV; ++n1)
-            v[n1] = C2<TT>{TT(__uint_as_float(r.w[n1].x)), TT(__uint_as_float(r.w[n1].y))};
-        return;
-    }
-    if constexpr (PCM16_ROUTE) {
-        if (r.route == 2) {
+template <int NV>
+struct PairRaw {
+    unsigned lo[NV], hi[NV];  // float32: the two bit patterns; int16: lo = the packed pair
+};
+// issue only (no wait): pos0 = the lane's first sample (frame start + 2 x lane-in-frame) as a stream position, may be negative
+template <int SRC, int NV, int STRIDE>
+__device__ __forceinline__ void pairs_issue(const SampleWindow<SRC>& w, int64_t pos0, PairRaw<NV>& r) {
+    if constexpr (SRC != AUD_F64) {
+        constexpr int esize = SRC == AUD_F32 ? 4 : 2;
+        const int rel = int(pos0 - w.lo);  // a negative position is a huge unsigned offset: out of range, reads 0
+        if (w.route == kRoutePairs) {
+            const int off = rel * esize;
 #pragma unroll
             for (int n1 = 0; n1 < NV; ++n1) {
-                v[n1].x = pcm16_to<TT>(int(int16_t(r.w[n1].x & 0xFFFFu)));
-                v[n1].y = pcm16_to<TT>(int(int16_t(r.w[n1].x >> 16)));
+                if constexpr (SRC == AUD_F32) {
+                    const auto q = __builtin_amdgcn_raw_buffer_load_b64(w.rsrc, off + 8 * STRIDE * n1, 0, 0);
+                    r.lo[n1] = q[0];
+                    r.hi[n1] = q[1];
+                } else {
+                    r.lo[n1] = __builtin_amdgcn_raw_buffer_load_b32(w.rsrc, off + 4 * STRIDE * n1, 0, 0);
+                    r.hi[n1] = 0u;  // (both routes write both words: otherwise hipcc merges the routes' last stores through
+                }                   //  a pointer select and the word ends up in scratch memory)
             }
-            return;
+        } else {
+            const int off = rel * w.step;
+#pragma unroll
+            for (int n1 = 0; n1 < NV; ++n1) {
+                if constexpr (SRC == AUD_F32) {
+                    r.lo[n1] = __builtin_amdgcn_raw_buffer_load_b32(w.rsrc, off + 2 * STRIDE * n1 * w.step, 0, 0);
+                    r.hi[n1] = __builtin_amdgcn_raw_buffer_load_b32(w.rsrc, off + (2 * STRIDE * n1 + 1) * w.step, 0, 0);
+                } else {
+                    const unsigned lo = __builtin_amdgcn_raw_buffer_load_b16(w.rsrc, off + 2 * STRIDE * n1 * w.step, 0, 0);
+                    const unsigned hi = __builtin_amdgcn_raw_buffer_load_b16(w.rsrc, off + (2 * STRIDE * n1 + 1) * w.step, 0, 0);
+                    r.lo[n1] = (lo & 0xFFFFu) | (hi << 16);
+                    r.hi[n1] = 0u;
+                }
+            }
         }
     }
-    const int64_t lim = it.sig_len;
-    const int64_t pos0 = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border) + 2 * lane;
-    const bool frame_on = sstep < a.T;
-    const int64_t str = it.sig_stride > 1 ? it.sig_stride : 1;
-#pragma unroll
-    for (int n1 = 0; n1 < NV; ++n1) {
-        const int64_t p = pos0 + 2 * STRIDE * n1;
-        v[n1].x = (frame_on && p >= 0 && p < lim) ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + p * str) : TT(0);
-        v[n1].y = (frame_on && p + 1 >= 0 && p + 1 < lim)
-                      ? load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + (p + 1) * str) : TT(0);
-    }
 }
-template <typename TT, int NV, int STRIDE, int N, bool PCM16_ROUTE = true, bool ODD_ROUTE = false>
-__device__ __forceinline__ void load_frame_pairs(const MelspecArgs& a, const aud_item& it, int sstep, int lane,
-                                                 C2<TT> (&v)[NV]) {
-    FrameRaw<NV> r;
-    frame_pairs_issue<NV, STRIDE, N, PCM16_ROUTE, ODD_ROUTE>(a, it, sstep, lane, r);
-    frame_pairs_take<TT, NV, STRIDE, N, PCM16_ROUTE>(a, it, sstep, lane, r, v);
+// convert what pairs_issue requested -- or, for float64 samples, load them here.  `amax` receives the largest sample
+// magnitude the lane holds (the frame's scale comes from it, frame_scale below).
+template <typename TT, int SRC, int NV, int STRIDE>
+__device__ __forceinline__ void pairs_take(const MelspecArgs& a, const aud_item& it, int64_t pos0, bool frame_on,
+                                           const PairRaw<NV>& r, C2<TT> (&v)[NV], TT& amax) {
+    if constexpr (SRC == AUD_F32) {
+        float m = 0.f;
+#pragma unroll
+        for (int n1 = 0; n1 < NV; ++n1) {
+            const float x = __uint_as_float(r.lo[n1]), y = __uint_as_float(r.hi[n1]);
+            v[n1] = C2<TT>{TT(x), TT(y)};
+            m = fmaxf(m, fmaxf(fabsf(x), fabsf(y)));
+        }
+        amax = TT(m);
+    } else if constexpr (SRC == AUD_I16) {
+        int m = 0;
+#pragma unroll
+        for (int n1 = 0; n1 < NV; ++n1) {
+            const int x = int(int16_t(r.lo[n1] & 0xFFFFu)), y = int(int16_t(r.lo[n1] >> 16));
+            v[n1].x = pcm16_to<TT>(x);
+            v[n1].y = pcm16_to<TT>(y);
+            m = max(m, max(x < 0 ? -x : x, y < 0 ? -y : y));
+        }
+        amax = pcm16_to<TT>(m);
+    } else {
+        const int64_t lim = it.sig_len;
+        const int64_t str = it.sig_stride > 1 ? it.sig_stride : 1;
+        const double* __restrict__ sig = static_cast<const double*>(a.sig) + it.sig_off;
+        TT m = TT(0);
+#pragma unroll
+        for (int n1 = 0; n1 < NV; ++n1) {
+            const int64_t p = pos0 + 2 * STRIDE * n1;
+            v[n1].x = (frame_on && p >= 0 && p < lim) ? TT(sig[p * str]) : TT(0);
+            v[n1].y = (frame_on && p + 1 >= 0 && p + 1 < lim) ? TT(sig[(p + 1) * str]) : TT(0);
+            const TT ax = v[n1].x < TT(0) ? -v[n1].x : v[n1].x, ay = v[n1].y < TT(0) ? -v[n1].y : v[n1].y;
+            m = ax > m ? ax : m;  // (a NaN sample never wins: the frame's outputs are NaN whatever the scale)
+            m = ay > m ? ay : m;
+        }
+        amax = m;
+    }
 }
 
 __device__ __forceinline__ float dev_log(float v) { return logf(v); }
@@ -407,321 +438,180 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 
-// ---- tile epilogue ------------------------------------------------------------------------------
-// P: LDS, [F][Hp] power spectrum of the tile's F frames (Hp a multiple of 4, pad bins zeroed);
-// w4: LDS copy of the chunked mel weights.  NT threads; F frames x (NT / F) filter groups.
-//   * dft/dft.go:70-83: PowerSegment / LogPowerSegment [item, H, T] (optional)
-//   * mel/mel.go:120-153: triangle sums (as aligned 4-bin chunks, bin order kept), + LogOff,
-//     ln / LogMin, optional renorm, MelFBankSegment [item, nf, T]
-// With lds_out set, mel values go to lds_out[flt * lds_pitch + lds_col0 + frame] instead of global memory
-// (kernels whose tiles are narrower than a 64-byte output run collect several tiles there first).
-template <typename TT, int NT, int F>
-__device__ __forceinline__ void tile_spectrum_outputs(const MelspecArgs& a, const TT* P, int Hp, const aud_item& it,
-                                                      int item, int t0, int tid, TT pscale = TT(1)) {
-    const int T = a.T, H = a.H, N = a.N;
-    const int64_t lim = it.sig_len;
-    if constexpr (NT == 64) {
-        // one wave: a lane keeps ONE frame (tid % F) and walks the bins k = tid / F, + 64 / F, ... -- step, liveness and the
-        // output addresses are per-lane constants and every iteration is one LDS read, the logarithm and two stores (the
-        // general form below re-derives frame, liveness and two 64-bit addresses for every element).  Lanes beyond
-        // F * (64 / F) repeat the last group and store nothing; reads past the last bin are clamped, not skipped.
-        if (a.power || a.log_power) {
-            constexpr int G = 64 / F;
-            const int ff = tid % F, g0 = tid / F;
-            const bool has = g0 < G;
-            const int g = has ? g0 : G - 1;
-            const int sstep = t0 + ff;
-            const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
-            const bool col_on = has && sstep < T;
-            const bool live = start + N <= lim;
-            const TT off = TT(a.dft_log_off), lmin = TT(a.dft_log_min);
-            const TT* prow = P + ff * Hp;
-            size_t o = (size_t(item) * H + g) * T + (col_on ? sstep : 0);
-            const size_t ostep = size_t(G) * T;
-            const bool want_lp = live && a.comp_log_pow;
-            const int n_it = (H + G - 1) / G;  // the same trip count for every lane
-            for (int i = 0; i < n_it; ++i) {
-                const int k = g + G * i;
-                const TT pw = pscale * prow[k < H ? k : H - 1];
-                if (col_on && k < H) {
-                    if (a.power) a.power[o] = live ? float(pw) : 0.f;
-                    if (a.log_power) {
-                        float lp = 0.f;
-                        if (want_lp) {
-                            const TT vv = pw + off;
-                            lp = float(vv == TT(0) ? lmin : feature_log(vv));
-                        }
-                        a.log_power[o] = lp;
-                    }
-                }
-                o += ostep;
-            }
-        }
-        return;
-    }
-    if (a.power || a.log_power) {
-        const TT off = TT(a.dft_log_off), lmin = TT(a.dft_log_min);
-        for (int w = tid; w < F * H; w += NT) {
-            const int k = w / F, ff = w - k * F;
-            const int sstep = t0 + ff;
-            if (sstep >= T) continue;
-            const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
-            const bool live = start + N <= lim;
-            const TT pw = pscale * P[ff * Hp + k];  // pscale: a power of two (exact)
-            const size_t o = (size_t(item) * H + k) * T + sstep;
-            if (a.power) a.power[o] = live ? float(pw) : 0.f;
-            if (a.log_power) {
-                float lp = 0.f;
-                if (live && a.comp_log_pow) {
-                    const TT vv = pw + off;
-                    lp = float(vv == TT(0) ? lmin : feature_log(vv));
-                }
-                a.log_power[o] = lp;
-            }
-        }
-    }
+// ---- a frame's power-of-two scale ------------------------------------------------------------------------------------
+// The wave kernels park the power spectrum in LDS as FLOAT32 for both compute types (half the epilogue's LDS traffic, its
+// multiply-adds at the float32 rate).  float64 plans must hold for every input a double can carry, so each frame's
+// spectrum is first divided by 2^sc, sc = 2 x the binary exponent of the frame's largest sample magnitude: with
+// 2^(e-1) <= max |x| < 2^e, 4 |X_k|^2 <= 4 N^2 2^(2e) and (Parseval) the largest of them >= 2^(2e), so the scaled peak lies in [1, 2^24] for
+// N <= 2048 and every bin down to 2^-126 of it (-370 dB; a float64 FFT's own floor is -320 dB) stays a NORMAL float32:
+// relative error 2^-24 per stored bin, no dependence on the input's overall level.  All terms of a mel sum are
+// non-negative, so the sum inherits that bound; exact zeros stay exact (LogMin rule, mel.go:135-137).  The scale goes
+// back in after the sum: as an addition to the logarithm's exponent (LogOff == 0) or by ldexp in float64.
+constexpr int kNoSignal = -(1 << 20);  // exponent of an all-zero lane
+template <typename TT>
+__device__ __forceinline__ int amax_exponent(TT amax) {
+    int ex = 0;
+    if constexpr (sizeof(TT) == 4) (void)frexpf(amax, &ex);
+    else (void)frexp(amax, &ex);
+    return amax > TT(0) ? ex : kNoSignal;  // (inf / NaN: exponent 0 -- the frame's outputs are inf / NaN anyway)
 }
+// the lanes of one frame agree on the frame's exponent through an LDS word: `slot` points at the frame's word (the same
+// for all its lanes).  float32 plans keep their spectrum unscaled (sc = 0).
+// the scale of the frame whose word `slot` is (the epilogue's lanes own other frames than the FFT's lanes)
+__device__ __forceinline__ int frame_scale_of(const int* slot) {
+    const int ex = *slot;
+    return ex == kNoSignal ? 0 : 2 * ex;
+}
+template <typename TT>
+__device__ __forceinline__ int frame_scale(int* slot, TT amax) {
+    if constexpr (sizeof(TT) == 4) return 0;
+    AUD_BENIGN_RACE_BEGIN();
+    *slot = kNoSignal;  // every lane of the frame stores the same word
+    AUD_BENIGN_RACE_END();
+    wave_lds_fence();
+    atomicMax(slot, amax_exponent<TT>(amax));  // ds_max_i32, no return
+    wave_lds_fence();
+    return frame_scale_of(slot);
+}
+// one bin of 4 x power into the float32 spectrum
+__device__ __forceinline__ float scaled_power(double p4, int sc) { return float(ldexp(p4, -sc)); }
+__device__ __forceinline__ float scaled_power(float p4, int) { return p4; }
 
-template <typename TT, int NT, int F, bool SCHED_LDS = true>
-__device__ __forceinline__ void tile_epilogue(const MelspecArgs& a, const FastArgs& e, const TT* P, int Hp,
-                                              const unsigned char* smem, const aud_item& it, int item, int t0,
-                                              int tid, float* lds_out = nullptr, int lds_pitch = 0,
-                                              int lds_col0 = 0) {
-    const int T = a.T, N = a.N;
-    const int64_t lim = it.sig_len;
-    tile_spectrum_outputs<TT, NT, F>(a, P, Hp, it, item, t0, tid);
-    const int ff = tid % F, grp = tid / F;
+// ---- epilogue of the wave-autonomous kernels ---------------------------------------------------------------------
+// P: this wave's [FPW][Hp] spectrum in LDS, float32, FOUR times the power divided by 2^sc of its frame (frame_scale; the
+// frames' sc in `exps`; the 1/4 lives in the mel weights).  64 lanes = FPW frames x (64 / FPW) filter groups.
+//   * dft/dft.go:70-83: PowerSegment / LogPowerSegment [item, H, T] (optional outputs)
+//   * mel/mel.go:120-153: triangle sums over aligned 4-bin chunks, + LogOff, ln / LogMin, optional renorm,
+//     MelFBankSegment [item, nf, T]
+// The mel reduction walks slot-uniform chunk steps (kernels.h WaveArgs): slot k takes the same number of steps in every
+// group, so the loop bounds are scalar and a step is two 16-byte LDS reads and four multiply-adds into four running sums
+// (one per position in the chunk: at most 2 x the slot's steps additions each, pairwise at the end).  No LDS access sits
+// under a lane condition: a masked frame still reads its -- valid -- row and drops the sums.
+template <typename TT, int FPW>
+__device__ __forceinline__ void wave_spectrum_outputs(const MelspecArgs& a, const float* P, int Hp, const int* exps,
+                                                      const aud_item& it, int item, int t0, int lane) {
+    if (!a.power && !a.log_power) return;
+    // a lane keeps ONE frame (lane % FPW) and walks the bins k = lane / FPW, + 64 / FPW, ...: step, liveness and the output
+    // addresses are per-lane constants, every iteration is one LDS read, the logarithm and two stores.  Lanes beyond
+    // FPW * (64 / FPW) repeat the last group and store nothing; reads past the last bin are clamped, not skipped.
+    constexpr int G = 64 / FPW;
+    const int T = a.T, H = a.H;
+    const int ff = lane % FPW, g0 = lane / FPW;
+    const bool has = g0 < G;
+    const int g = has ? g0 : G - 1;
     const int sstep = t0 + ff;
-    if (sstep >= T) return;
     const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
-    const bool live = start + N <= lim;
-    typedef Q4<TT> quad_t;
-    const quad_t* w4 = reinterpret_cast<const quad_t*>(smem + e.w4_off);
-    const quad_t* prow = reinterpret_cast<const quad_t*>(P + ff * Hp);
-    const TT loff = TT(a.mel_log_off), lmin = TT(a.mel_log_min);
-    float* mel_col = a.mel + (size_t(item) * a.nf * T + sstep);  // one 64-bit base, then flt * T per filter
-    // the filter-group schedule: the LDS copy made by stage_mel_weights (16-bit entries), or the plan's table in
-    // global memory for the kernel that has no LDS to spare for it
-    typedef typename std::conditional<SCHED_LDS, unsigned short, int>::type sched_t;
-    const sched_t* s_off;
-    const sched_t* s_flt;
-    const sched_t* s_chunk;
-    if constexpr (SCHED_LDS) {
-        s_off = reinterpret_cast<const sched_t*>(smem + e.sched_off);
-        s_flt = s_off + e.n_groups + 1;
-        s_chunk = s_flt + a.nf;
-    } else {
-        s_off = reinterpret_cast<const sched_t*>(e.grp_off);
-        s_flt = reinterpret_cast<const sched_t*>(e.grp_flt);
-        s_chunk = reinterpret_cast<const sched_t*>(e.chunk);
-    }
-    for (int idx = s_off[grp]; idx < int(s_off[grp + 1]); ++idx) {
-        const int flt = s_flt[idx];
-        float res = 0.f;
-        if (live) {
-            const int c0 = s_chunk[3 * flt], nc = s_chunk[3 * flt + 1], wo = s_chunk[3 * flt + 2];
-            TT sum = TT(0);
-#pragma unroll 4
-            for (int c = 0; c < nc; ++c) {
-                const quad_t pw = prow[c0 + c];
-                const quad_t ww = w4[wo + c];
-                sum += ww.x * pw.x;
-                sum += ww.y * pw.y;
-                sum += ww.z * pw.z;
-                sum += ww.w * pw.w;
+    const bool col_on = has && sstep < T;
+    const bool live = start + a.N <= int64_t(it.sig_len);
+    int sc = 0;
+    if constexpr (sizeof(TT) == 8) sc = frame_scale_of(exps + ff);
+    const float* prow = P + ff * Hp;
+    size_t o = (size_t(item) * H + g) * T + (col_on ? sstep : 0);
+    const size_t ostep = size_t(G) * T;
+    const bool want_lp = live && a.comp_log_pow;
+    const int n_it = (H + G - 1) / G;  // the same trip count for every lane
+    for (int i = 0; i < n_it; ++i) {
+        const int k = g + G * i;
+        const float p4 = prow[k < H ? k : H - 1];
+        float pw, lp = 0.f;
+        if constexpr (sizeof(TT) == 8) {
+            const double pd = ldexp(double(p4), sc - 2);
+            pw = float(pd);
+            if (want_lp) {
+                const double vv = pd + a.dft_log_off;
+                lp = float(vv == 0.0 ? a.dft_log_min : feature_log(vv));
             }
-            sum += loff;
-            TT val = (sum == TT(0)) ? lmin : feature_log(sum);
-            if (a.renorm) {
-                val -= TT(a.renorm_min);
-                if (val < TT(0)) val = TT(0);
-                val *= TT(a.renorm_scale);
-                if (val > TT(1)) val = TT(1);
+        } else {
+            pw = 0.25f * p4;
+            if (want_lp) {
+                const float vv = pw + float(a.dft_log_off);
+                lp = vv == 0.f ? float(a.dft_log_min) : feature_log(vv);
             }
-            res = float(val);
         }
-        if (lds_out)
-            lds_out[flt * lds_pitch + lds_col0 + ff] = res;
-        else
-            mel_col[size_t(flt) * T] = res;  // MelFBankSegment[item][flt][sstep]
+        if (col_on && k < H) {
+            if (a.power) a.power[o] = live ? pw : 0.f;
+            if (a.log_power) a.log_power[o] = lp;
+        }
+        o += ostep;
     }
 }
 
-// ---- epilogue of the wave-autonomous kernels ---------------------------------------------------------------
-// P: this wave's [FPW][Hp] power spectrum in LDS.  64 lanes = FPW frames x (64 / FPW) filter groups.  Optional
-// spectrum outputs as tile_epilogue.  The mel reduction (mel/mel.go:120-153) walks the group's padded list of chunk
-// steps (kernels.h FastArgs): every step is one 4-bin chunk of one filter, dot(w4 chunk, P chunk) added to a running
-// sum that a step flagged `first` restarts; a step flagged `last` parks the sum in its filter's slot.  The loop has
-// no data-dependent branch, so the LDS reads of four steps are in flight together (the first version walked one
-// dependent chain per filter and took 27 % of a wave's life, profiles/r02c_stamps_*); logarithms and stores follow
-// for all slots at once.  Products are the reference's; the additions are pairwise inside a chunk and in bin order
-// across chunks (float64: far below the float32 spacing of the stored value).
-template <typename TT, int FPW, int MAXS, bool COMPACT>
-__device__ __forceinline__ void wave_mel_steps_impl(const MelspecArgs& a, const FastArgs& e, const TT* P, int Hp,
-                                                    const unsigned char* smem, int item, int sstep, bool col_on,
-                                                    bool live, int ff, int grp) {
+template <typename TT, int FPW, int MAXS, bool COMPACT = false>
+__device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const WaveArgs& e, const float* P, int Hp,
+                                                  const unsigned char* smem, const int* exps, const aud_item& it,
+                                                  int item, int t0, int lane) {
+    wave_spectrum_outputs<TT, FPW>(a, P, Hp, exps, it, item, t0, lane);
+    // 64 is not a multiple of FPW = 6: lanes 60..63 have no filter group; they run group n_groups - 1 again and store nothing
     const int T = a.T;
-    // no LDS access below sits under a lane condition (a masked frame still reads its -- valid -- row and drops the sums)
+    const int ff = lane % FPW, g0 = lane / FPW;
+    const bool has = g0 < e.n_groups;
+    const int grp = has ? g0 : e.n_groups - 1;
+    const int sstep = t0 + ff;
+    const bool col_on = has && sstep < T;
+    const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
+    const bool live = col_on && start + a.N <= int64_t(it.sig_len);
+    int sc = 0;
+    if constexpr (sizeof(TT) == 8) sc = frame_scale_of(exps + ff);
     // COMPACT (one filter group per lane, w64x16): a filter's row holds only its own chunks, steps past its end read the
     // table's shared zero chunk; otherwise every group's row has the slot's full length
-    const Q4a<TT>* wrow = reinterpret_cast<const Q4a<TT>*>(smem + e.w4_off + (COMPACT ? 0 : grp * e.w_stride));
-    const Q4a<TT>* prow = reinterpret_cast<const Q4a<TT>*>(P + ff * Hp);  // rows are 16-byte aligned (float64 pitch: Hp = 2 mod 4)
+    const Q4a<float>* wrow = reinterpret_cast<const Q4a<float>*>(smem + e.w4_off + (COMPACT ? 0 : grp * e.w_stride));
+    const Q4a<float>* prow = reinterpret_cast<const Q4a<float>*>(P + ff * Hp);  // Hp is a multiple of 4: rows 16-byte aligned
     const unsigned* recs = reinterpret_cast<const unsigned*>(smem + e.slots_off) + grp * e.n_slots * (COMPACT ? 2 : 1);
-    const TT loff = TT(a.mel_log_off), lmin = TT(a.mel_log_min);
+    const bool plain = a.mel_log_off == 0.0 && !a.renorm;  // wave-uniform: the reference's defaults (mel.go:80, :175)
+    const float lminf = float(a.mel_log_min);
     float* mel_col = a.mel + (size_t(item) * a.nf * T + (col_on ? sstep : 0));
 #pragma unroll
     for (int k = 0; k < MAXS; ++k) {
         if (k < e.n_slots) {  // wave-uniform
             const unsigned rec = recs[COMPACT ? 2 * k : k];
             const int ns = e.slot_steps[k];  // wave-uniform trip count: slot k is equally long in every group
-            const Q4a<TT>* pp = prow + (rec & 0xFFFFu);
-            TT s0 = TT(0), s1 = TT(0);
+            const Q4a<float>* pp = prow + (rec & 0xFFFFu);
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
             if constexpr (COMPACT) {
                 const unsigned row = recs[2 * k + 1];
                 const int own = int(row >> 16);
-                const unsigned char* wown = reinterpret_cast<const unsigned char*>(wrow) + 16 * (row & 0xFFFFu);  // rows start on any 16-byte piece
+                const Q4a<float>* wown = wrow + (row & 0xFFFFu);  // rows start on any 16-byte piece
 #pragma unroll 2
                 for (int s = 0; s < ns; ++s) {
-                    const Q4a<TT> pw = pp[s];
-                    const Q4a<TT> ww = *(s < own ? reinterpret_cast<const Q4a<TT>*>(wown) + s : wrow);  // wrow[0] = the zero chunk
-                    s0 += ww.x * pw.x;
-                    s1 += ww.y * pw.y;
-                    s0 += ww.z * pw.z;
-                    s1 += ww.w * pw.w;
+                    const Q4a<float> pw = pp[s];
+                    const Q4a<float> ww = *(s < own ? wown + s : wrow);  // wrow[0] = the zero chunk
+                    s0 = fmaf(ww.x, pw.x, s0);
+                    s1 = fmaf(ww.y, pw.y, s1);
+                    s2 = fmaf(ww.z, pw.z, s2);
+                    s3 = fmaf(ww.w, pw.w, s3);
                 }
             } else {
 #pragma unroll 4
                 for (int s = 0; s < ns; ++s) {
-                    const Q4a<TT> pw = pp[s], ww = wrow[s];
-                    s0 += ww.x * pw.x;
-                    s1 += ww.y * pw.y;
-                    s0 += ww.z * pw.z;
-                    s1 += ww.w * pw.w;
+                    const Q4a<float> pw = pp[s], ww = wrow[s];
+                    s0 = fmaf(ww.x, pw.x, s0);
+                    s1 = fmaf(ww.y, pw.y, s1);
+                    s2 = fmaf(ww.z, pw.z, s2);
+                    s3 = fmaf(ww.w, pw.w, s3);
                 }
                 wrow += ns;
             }
             const int flt = int(rec >> 16);
-            const TT sum = (s0 + s1) + loff;
-            TT val = (sum == TT(0)) ? lmin : feature_log(sum);
-            if (a.renorm) {
-                val -= TT(a.renorm_min);
-                if (val < TT(0)) val = TT(0);
-                val *= TT(a.renorm_scale);
-                if (val > TT(1)) val = TT(1);
-            }
-            const float res = live ? float(val) : 0.f;
-            if (col_on && flt != 0xFFFF) mel_col[size_t(flt) * T] = res;  // MelFBankSegment[item][flt][sstep]
-        }
-    }
-}
-
-template <typename TT, int FPW, int MAXS, bool COMPACT = false>
-__device__ __forceinline__ void wave_mel_steps(const MelspecArgs& a, const FastArgs& e, const TT* P, int Hp,
-                                               const unsigned char* smem, const aud_item& it, int item, int t0,
-                                               int lane) {
-    tile_spectrum_outputs<TT, 64, FPW>(a, P, Hp, it, item, t0, lane, TT(0.25));  // the wave kernels keep 4 x power in LDS
-    // 64 is not a multiple of FPW = 6: lanes 60..63 have no filter group; they run group n_groups - 1 again and store nothing
-    const int ff = lane % FPW, g0 = lane / FPW;
-    const bool has = g0 < e.n_groups;
-    const int grp = has ? g0 : e.n_groups - 1;
-    const int sstep = t0 + ff;
-    const bool col_on = has && sstep < a.T;
-    const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
-    const bool live = col_on && start + a.N <= int64_t(it.sig_len);
-    wave_mel_steps_impl<TT, FPW, MAXS, COMPACT>(a, e, P, Hp, smem, item, sstep, col_on, live, ff, grp);  // e.n_slots <= MAXS (host)
-}
-
-// ---- mel on the matrix pipe (float32 only; an experiment the plan can switch on) -------------------
-// D[16 filters x 16 frames] += A[16 filters x 4 bins] * B[4 bins x 16 frames] per v_mfma_f32_16x16x4_f32:
-//   A: lane l holds W[16 b + (l & 15)][bin0 + (l >> 4)]   (pre-arranged on the host, 64 floats per K-step)
-//   B: lane l holds P[frame l & 15][bin0 + (l >> 4)]       (one 4-byte LDS read)
-//   D: register r of lane l = filter 16 b + 4 (l >> 4) + r, frame l & 15
-// The accumulation is a k-ordered fmaf chain (bins ascending), like the reference's sequential sum; bins
-// outside a triangle carry zero weights.  Filter block b runs on wave b mod 4.
-typedef float aud_f32x4 __attribute__((vector_size(16)));
-
-template <int NT, int F>
-__device__ __forceinline__ void tile_mel_mfma(const MelspecArgs& a, const FastArgs& e, const float* P, int Hp,
-                                              const aud_item& it, int item, int t0, int tid) {
-    static_assert(F == 16, "one MFMA column per frame of the tile");
-    const int wave = tid >> 6, lane = tid & 63;
-    const int frame = lane & 15, kq = lane >> 4;
-    const int T = a.T;
-    const int sstep = t0 + frame;
-    const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
-    const bool live = start + a.N <= int64_t(it.sig_len);
-    const float loff = float(a.mel_log_off), lmin = float(a.mel_log_min);
-    for (int b = wave; b < e.n_blocks; b += NT / 64) {
-        const int c0 = e.blk[3 * b], ns = e.blk[3 * b + 1], off = e.blk[3 * b + 2];
-        const float* __restrict__ arow = e.atab + size_t(off) * 64 + lane;
-        const float* prow = P + frame * Hp + 4 * c0 + kq;
-        aud_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        int s = 0;
-        for (; s + 4 <= ns; s += 4) {  // operands of four steps in flight, then the dependent accumulate chain
-            float wa[4], pb[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                wa[u] = arow[64 * (s + u)];
-                pb[u] = prow[4 * (s + u)];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[u], pb[u], acc, 0, 0, 0);
-        }
-        for (; s < ns; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[64 * s], prow[4 * s], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int flt = 16 * b + 4 * kq + r;
-            if (flt < a.nf && sstep < T) {
-                float res = 0.f;
-                if (live) {
-                    const float sum = acc[r] + loff;
-                    float val = (sum == 0.f) ? lmin : dev_log(sum);
-                    if (a.renorm) {
-                        val -= float(a.renorm_min);
-                        if (val < 0.f) val = 0.f;
-                        val *= float(a.renorm_scale);
-                        if (val > 1.f) val = 1.f;
-                    }
-                    res = val;
+            const float sum = (s0 + s1) + (s2 + s3);  // = (the reference's sum) / 2^sc
+            float res;
+            if (plain) {
+                int ex = 0;
+                const float m = frexpf(sum, &ex);  // m = sum for 0 and NaN, with ex = 0
+                res = sum == 0.f ? lminf : mantissa_log(m, ex + sc);
+            } else {
+                const double sd = ldexp(double(sum), sc) + a.mel_log_off;
+                double val = sd == 0.0 ? a.mel_log_min : feature_log(sd);
+                if (a.renorm) {
+                    val -= a.renorm_min;
+                    if (val < 0.0) val = 0.0;
+                    val *= a.renorm_scale;
+                    if (val > 1.0) val = 1.0;
                 }
-                a.mel[(size_t(item) * a.nf + flt) * T + sstep] = res;
+                res = float(val);
             }
+            if (col_on && flt != 0xFFFF) mel_col[size_t(flt) * T] = live ? res : 0.f;  // MelFBankSegment[item][flt][sstep]
         }
     }
-}
-
-// copy the chunked mel weights into LDS (visible after the next barrier)
-template <typename TT, int NT>
-__device__ __forceinline__ void stage_mel_weights(const FastArgs& e, unsigned char* smem, int tid) {
-    typedef Q4<TT> quad_t;
-    const quad_t* __restrict__ gw = static_cast<const quad_t*>(e.w4);
-    quad_t* lw = reinterpret_cast<quad_t*>(smem + e.w4_off);
-    for (int c = tid; c < e.n_chunks; c += NT) lw[c] = gw[c];
-}
-
-// The filter-group schedule ([groups + 1] offsets | [nf] filter ids | [nf][3] chunk info) goes into LDS as 16-bit
-// entries (filter ids, chunk indices and offsets into w4 all stay far below 65536: LDS bounds them).  The epilogue
-// walks it once per filter; from global memory every step of that walk is a dependent load behind an
-// s_waitcnt vmcnt(0) that also waits for the previous filter's store.  Two steps so that the kernel can put the
-// operand loads between them: the fetch is issued first and costs two registers, the store waits only for it
-// (loads return in order), and the operand loads are neither delayed nor squeezed for registers.
-struct SchedRegs {
-    int v0, v1;
-};
-template <int NT>
-__device__ __forceinline__ SchedRegs mel_schedule_fetch(const FastArgs& e, int tid) {
-    SchedRegs r;
-    r.v0 = tid < e.n_sched ? e.grp_off[tid] : 0;
-    r.v1 = tid + NT < e.n_sched ? e.grp_off[tid + NT] : 0;
-    return r;
-}
-template <int NT>
-__device__ __forceinline__ void mel_schedule_store(const FastArgs& e, unsigned char* smem, int tid, const SchedRegs& r) {
-    unsigned short* ls = reinterpret_cast<unsigned short*>(smem + e.sched_off);
-    if (tid < e.n_sched) ls[tid] = static_cast<unsigned short>(r.v0);
-    if (tid + NT < e.n_sched) ls[tid + NT] = static_cast<unsigned short>(r.v1);
-#pragma unroll 1
-    for (int c = tid + 2 * NT; c < e.n_sched; c += NT) ls[c] = static_cast<unsigned short>(e.grp_off[c]);  // nf > ~120
 }
 
 }  // namespace aud

@@ -119,157 +119,6 @@ __global__ __launch_bounds__(256) void k_gabor(const GaborArgs a) {
     }
 }
 
-// The default FilterSet (9 x 9 taps, 8 filters) into rank-4 [PY, PX, 2, 8] pools with PARTS threads per output position:
-// thread `part` of a position owns 8 / PARTS filters (their on / off values are 8 / PARTS consecutive floats each).
-// k_gabor's one thread per position is a serial chain of 81 loads and 648 FMAs in 1.4 waves per SIMD; more, shorter
-// threads hide the load latency (the mel matrix is L1/L2-resident, so the repeated loads cost little).
-template <typename TT, int PARTS>
-__global__ __launch_bounds__(256) void k_gabor_split(const GaborArgs a) {
-    constexpr int KF = 8 / PARTS;
-    const int per_item = a.nF * a.nT;
-    // a WAVE owns one part of 64 positions, so the taps stay wave-uniform scalar operands
-    const int64_t wave_id = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-    const int part = __builtin_amdgcn_readfirstlane(int(wave_id % PARTS));
-    const int64_t pos_id = (wave_id / PARTS) * 64 + (threadIdx.x & 63);
-    if (pos_id >= int64_t(a.n_items) * per_item) return;
-    const int item = int(pos_id / per_item);
-    const int r = int(pos_id - int64_t(item) * per_item);
-    const int f_idx = r / a.nT, t_idx = r - f_idx * a.nT;
-    const float* __restrict__ mel = a.mel + size_t(item) * a.rows * a.cols + size_t(f_idx * a.sty) * a.cols + t_idx * a.stx;
-    const TT* __restrict__ kf = static_cast<const TT*>(a.k) + part * KF * 81;
-    TT acc[KF];
-#pragma unroll
-    for (int c = 0; c < KF; ++c) acc[c] = TT(0);
-#pragma unroll
-    for (int ff = 0; ff < 9; ++ff) {
-        float mv[9];
-#pragma unroll
-        for (int ft = 0; ft < 9; ++ft) mv[ft] = mel[size_t(ff) * a.cols + ft];
-#pragma unroll
-        for (int ft = 0; ft < 9; ++ft) {
-            const float m = mv[ft] != mv[ft] ? 0.5f : mv[ft];  // math.IsNaN -> .5
-            const TT v = TT(m);
-#pragma unroll
-            for (int c = 0; c < KF; ++c) acc[c] += kf[c * 81 + ff * 9 + ft] * v;
-        }
-    }
-    const TT gain = TT(a.gain);
-    float on[KF], off[KF];
-#pragma unroll
-    for (int c = 0; c < KF; ++c) {
-        const bool pos = acc[c] >= TT(0);
-        const float act = float(gain * (acc[c] < TT(0) ? -acc[c] : acc[c]));
-        on[c] = pos ? act : 0.f;
-        off[c] = pos ? 0.f : act;
-    }
-    float* cell = a.out + size_t(item) * (size_t(a.d0) * a.d1 * 16) + (size_t(f_idx) * a.d1 + t_idx) * 16 + part * KF;
-#pragma unroll
-    for (int c = 0; c < KF; ++c) {
-        cell[c] = on[c];
-        cell[8 + c] = off[c];
-    }
-}
-
-// The LDS-tiled form (plan option "gabor_lds" = 1, where an item's mel matrix fits): a workgroup copies the item's whole
-// [rows, cols] mel matrix into LDS once -- coalesced 16-byte loads, NaN -> 0.5 applied on the way (:278-280) -- and
-// then works on kLdsPos output positions: a thread takes ONE position and kLdsChunk filters (taps wave-uniform scalar
-// operands), reading its 9 x 9 window from LDS (lane stride = StrideX floats: conflict-free).  Measured (profiles/
-// r02l_*, r02m_*): the mel reads were never the cost of this stage -- LDS-tiled and global-memory kernels take the same
-// 14 us at the bench size, and spreading the filters over 4x the waves made it slower; the cost is the OUTPUT: 16
-// scattered 4-byte stores per position (64 cache lines per wave-instruction).  Both kernels therefore write a
-// position's [2, 8] block as four 16-byte stores whenever the output has exactly that shape (store_pair_block).
-// Same flat-offset addressing, same summation order per filter, same index maps.
-constexpr int kLdsPos = 128;     // positions per workgroup
-constexpr int kLdsGroups = 1;    // filter groups per workgroup (waves of group g take filters g kLdsChunk ...)
-constexpr int kLdsChunk = 8;     // filters per thread
-
-template <typename TT, int KSX, int KSY, int KNG>
-__global__ __launch_bounds__(kLdsPos * kLdsGroups) void k_gabor_lds(const GaborArgs a, int n_split) {
-    constexpr int NT = kLdsPos * kLdsGroups;
-    float* lm = reinterpret_cast<float*>(dyn_lds());
-    const int tid = int(threadIdx.x);
-    const int item = int(blockIdx.x) / n_split, part = int(blockIdx.x) - item * n_split;
-    const int cells = a.rows * a.cols;
-    const float* __restrict__ mel = a.mel + size_t(item) * cells;
-    if ((cells & 3) == 0 && (reinterpret_cast<uintptr_t>(a.mel) & 15) == 0) {
-        const float4* __restrict__ m4 = reinterpret_cast<const float4*>(mel);
-        for (int i = tid; i < (cells >> 2); i += NT) {
-            float4 v = m4[i];
-            v.x = v.x != v.x ? 0.5f : v.x;
-            v.y = v.y != v.y ? 0.5f : v.y;
-            v.z = v.z != v.z ? 0.5f : v.z;
-            v.w = v.w != v.w ? 0.5f : v.w;
-            reinterpret_cast<float4*>(lm)[i] = v;
-        }
-    } else {
-        for (int i = tid; i < cells; i += NT) {
-            const float v = mel[i];
-            lm[i] = v != v ? 0.5f : v;
-        }
-    }
-    __syncthreads();
-
-    const int per_item = a.nF * a.nT;
-    const int grp = __builtin_amdgcn_readfirstlane(tid / kLdsPos);  // wave-uniform (kLdsPos is a multiple of 64): the taps stay scalar operands
-    const int r = part * kLdsPos + (tid - grp * kLdsPos);
-    if (r >= per_item) return;
-    const int f_idx = r / a.nT, t_idx = r - f_idx * a.nT;
-    const int f = f_idx * a.sty, t = t_idx * a.stx;
-    const int SX = KSX > 0 ? KSX : a.SX, SY = KSY > 0 ? KSY : a.SY, NG = KNG > 0 ? KNG : a.nG;
-    const TT* __restrict__ kf = static_cast<const TT*>(a.k);
-    const int area = SX * SY;
-    const TT gain = TT(a.gain);
-    const size_t out_item = a.rank == 2 ? size_t(a.d0) * a.d1 : size_t(a.d0) * a.d1 * a.d2 * a.d3;
-    float* out = a.out + size_t(item) * out_item;
-
-    for (int g0 = grp * kLdsChunk; g0 < NG; g0 += kLdsChunk * kLdsGroups) {
-        TT acc[kLdsChunk];
-#pragma unroll
-        for (int c = 0; c < kLdsChunk; ++c) acc[c] = TT(0);
-        const int gc = min(kLdsChunk, NG - g0);
-        auto tap_row = [&](const float* row, int ff, int ft) {
-            const TT v = TT(row[ft]);
-            const TT* tap = kf + size_t(g0) * area + ff * SX + ft;
-#pragma unroll
-            for (int c = 0; c < kLdsChunk; ++c)
-                if (c < gc) acc[c] += tap[size_t(c) * area] * v;
-        };
-        for (int ff = 0; ff < SY; ++ff) {
-            const float* row = lm + (f + ff) * a.cols + t;
-            if constexpr (KSX > 0) {
-#pragma unroll
-                for (int ft = 0; ft < KSX; ++ft) tap_row(row, ff, ft);
-            } else {
-                for (int ft = 0; ft < SX; ++ft) tap_row(row, ff, ft);
-            }
-        }
-        if (a.rank == 4 && a.d2 == 2 && a.d3 == 8 && NG == 8 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
-            store_pair_block<TT>(out + (size_t(f_idx) * a.d1 + t_idx) * 16, acc, gain);
-            continue;
-        }
-#pragma unroll
-        for (int c = 0; c < kLdsChunk; ++c) {
-            if (c >= gc) break;
-            const int flt = g0 + c;
-            const bool pos = acc[c] >= TT(0);
-            const float act = float(gain * (acc[c] < TT(0) ? -acc[c] : acc[c]));
-            size_t o_on, o_off;
-            if (a.rank == 2) {
-                const int y = f_idx * 2;
-                const int x = a.by_time ? t_idx + a.t_max_strides * flt : flt + t_idx * NG;
-                o_on = size_t(y) * a.d1 + x;
-                o_off = size_t(y + 1) * a.d1 + x;
-            } else {
-                const size_t cell = (size_t(f_idx) * a.d1 + t_idx) * a.d2;
-                o_on = cell * a.d3 + flt;
-                o_off = (cell + 1) * a.d3 + flt;
-            }
-            out[o_on] = pos ? act : 0.f;
-            out[o_off] = pos ? 0.f : act;
-        }
-    }
-}
-
 }  // namespace
 
 hipError_t launch_gabor(const GaborArgs& a, int compute_dtype, hipStream_t st) {
@@ -277,33 +126,6 @@ hipError_t launch_gabor(const GaborArgs& a, int compute_dtype, hipStream_t st) {
     if (total == 0) return hipSuccess;
     const dim3 grid(unsigned((total + 255) / 256));
     const bool dflt = a.SX == 9 && a.SY == 9 && a.nG == 8;  // processspeech.go:226-253
-    const size_t lds = size_t(a.rows) * a.cols * sizeof(float);
-    if (lds <= 60 * 1024 && a.use_lds == 1) {  // the item's mel matrix fits LDS (BASELINE configs[3]: 16.6 KB)
-        const int per_item = a.nF * a.nT;
-        const int n_split = (per_item + kLdsPos - 1) / kLdsPos;
-        const dim3 g2(unsigned(a.n_items) * unsigned(n_split)), b2(kLdsPos * kLdsGroups);
-        const bool d9 = dflt;
-        if (compute_dtype == AUD_F64) {
-            if (d9) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor_lds<double, 9, 9, 8>), g2, b2, lds, st, a, n_split);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor_lds<double, 0, 0, 0>), g2, b2, lds, st, a, n_split);
-        } else {
-            if (d9) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor_lds<float, 9, 9, 8>), g2, b2, lds, st, a, n_split);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor_lds<float, 0, 0, 0>), g2, b2, lds, st, a, n_split);
-        }
-        return hipGetLastError();
-    }
-    if (dflt && a.rank == 4 && a.d2 == 2 && a.d3 == 8 && a.use_lds >= 2) {  // plan option "gabor_lds" = 2 / 4: threads per position
-        const int parts = a.use_lds == 2 ? 2 : 4;
-        const dim3 gs(unsigned((((total + 63) / 64) * 64 * parts + 255) / 256));
-        if (compute_dtype == AUD_F64) {
-            if (parts == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor_split<double, 2>), gs, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor_split<double, 4>), gs, dim3(256), 0, st, a);
-        } else {
-            if (parts == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor_split<float, 2>), gs, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor_split<float, 4>), gs, dim3(256), 0, st, a);
-        }
-        return hipGetLastError();
-    }
     if (compute_dtype == AUD_F64) {
         if (dflt) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor<double, 9, 9, 8>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor<double, 0, 0, 0>), grid, dim3(256), 0, st, a);

@@ -63,10 +63,6 @@ struct MelspecArgs {
     // diagnostic builds only (-DAUD_STAMPS, tools/stamp_profile.py): [waves][16] s_memtime stamps of the wave
     // kernels' phases.  Never read by anything that computes an output.
     unsigned long long* stamps;
-    // persistent wave kernels with a dynamic tile queue (plan option "wave_grid" = 2): one slot of the plan's ring,
-    // queue[0] = tiles handed out beyond the first one of every wave, queue[16] = waves that have left; both are zero
-    // when a launch starts and the last wave to leave zeroes them again
-    unsigned* queue;
 };
 
 #ifdef AUD_STAMPS
@@ -92,6 +88,18 @@ struct MelspecArgs {
             (a).stamps[size_t(wave_tile) * 16 + 13] = __builtin_amdgcn_s_getreg((31 << 11) | 4); /* HW_ID */ \
         }                                                                                     \
     } while (0)
+#elif defined(AUD_PHASE_MARKERS)
+// static diagnostic (no GPU): "; AUD_PHASE n" comments in the assembly at the phase boundaries, fenced against the
+// scheduler, for tools/phase_count.py (instructions per phase of a wave kernel)
+#define AUD_STAMP_DECL
+#define AUD_STAMP(i)                                             \
+    do {                                                         \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        asm volatile("; AUD_PHASE " #i ::: "memory");            \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    } while (0)
+#define AUD_STAMP_REAL(i)
+#define AUD_STAMP_FLUSH(a, wave_tile, lane)
 #else
 #define AUD_STAMP_DECL
 #define AUD_STAMP(i)
@@ -110,52 +118,33 @@ struct GaborArgs {
     int by_time;
     int nT, nF, t_max_strides;
     float* out;
-    int use_lds;  // 1: the LDS-tiled kernel when the item's mel matrix fits (plan option "gabor_lds", default on)
 };
 
-// extra arguments of the register-resident two-pass kernels (r16x16 for N = 512, r25x8 for N = 400)
-struct FastArgs {
-    int direct;            // 1: pass-1 operands straight from global memory, 0: staged through LDS
-    int ntile;             // r16x16 direct: 16-frame tiles per workgroup (1, or 2 with the second prefetched)
-    int xch_off;           // byte offset of the transpose buffer inside dynamic LDS
-    int p_off;             // byte offset of the power spectrum (aliases the span or the transpose buffer)
-    int w4_off;            // byte offset of the LDS copy of the chunked mel weights
-    int out_off;           // byte offset of the LDS mel tile (kernels that collect several frame groups)
-    int sched_off;         // byte offset of the LDS copy of the filter-group schedule (grp_off | grp_flt | chunk)
-    int n_sched;           // its length in ints: groups + 1 + 4 nf
-    int n_groups;          // filter groups of the epilogue (threads per workgroup / frames per tile)
-    unsigned lds_bytes;    // dynamic LDS of the launch
-    int n_chunks;          // tile kernels: number of 4-element chunks in w4; w64x16 (compact weight rows): unused, the zero chunk is piece 0
-    const int* grp_off;    // [groups + 1] device: filter-group boundaries into grp_flt
-    const int* grp_flt;    // [nf] device: filter ids, grouped so that groups carry equal tap counts
-    const int* chunk;      // [nf][3] device: first 4-bin chunk, chunk count, offset into w4
-    const void* w4;        // device: triangle weights as aligned 4-bin chunks (compute type)
-    int mel_mfma;          // r16x16 f32: 1 = mel on the matrix pipe (tile_mel_mfma), 0 = chunked reduction
-    int n_blocks;          // filter blocks of 16 for the matrix-pipe variant
-    const int* blk;        // [n_blocks][3] device: first 4-bin chunk, K-steps, offset (in steps) into atab
-    const float* atab;     // [steps][64] device: A operands, lane-ordered
-    // wave-autonomous kernels (melspec_wave.hip): all read-only tables live in ONE device blob laid out exactly like
-    // its LDS copy -- [per-group weight rows | slot records | pass twiddles | split twiddles] -- so staging is a flat
-    // 16-byte-piece copy.  Offsets below are bytes from the start of dynamic LDS / the blob.
-    // The mel epilogue: a lane owns (frame, filter group); a group's filters sit in SLOTS, slot k of every group takes
-    // the same number of 4-bin chunk steps slot_steps[k] (filters are dealt to groups in order of width, so the padding
-    // is small), a filter's chunks are consecutive in P, its weights consecutive in the group's weight row.
+// Arguments of the wave-autonomous kernels (melspec_wave.hip).  All read-only tables live in ONE device blob laid out
+// exactly like its LDS copy -- [per-group weight rows | slot records | pass twiddles | split twiddles | column pairs] -- so
+// staging is a flat 16-byte-piece copy.  Offsets are bytes from the start of dynamic LDS / the blob.
+// The mel epilogue: a lane owns (frame, filter group); a group's filters sit in SLOTS, slot k of every group takes the
+// same number of 4-bin chunk steps slot_steps[k] (filters are dealt to groups in order of width, so the padding is
+// small), a filter's chunks are consecutive in P, its weights consecutive in the group's weight row.  Weights and the
+// power spectrum in LDS are float32 for both compute types (float64 plans scale every frame's spectrum by a power of two
+// first, device_common.h frame_scale), weights carry the 1/4 of the real-FFT split.
+struct WaveArgs {
     const void* blob;      // device
     int blob_bytes;        // multiple of 16
+    int w4_off;            // float32 weight rows
     int w_stride;          // bytes between the weight rows of two groups (an odd number of 16-byte pieces: bank spread)
-    int n_steps;           // chunk steps of a lane: sum of slot_steps
-    int slots_off;         // uint32 [n_groups][n_slots]: first P chunk | filter id << 16 (0xFFFF = empty)
+    int slots_off;         // uint32 [n_groups][n_slots]: first P chunk | filter id << 16 (0xFFFF = empty); w64x16: two words
     int n_slots;
+    int n_groups;          // filter groups of the epilogue (64 / frames per wave)
     unsigned char slot_steps[8];
     int twa_off;           // pass twiddles, C2<TT> [K1 - 1][lanes per frame]: W^(2 j k1)
     int tws_off;           // split twiddles, C2<TT> [N/4 + 1]: W_N^k
     int pairs_off;         // w64x16: uint16 [64][4]: base bins of the lane's two column pairs
-    const void* gtab;      // w64x16: device, lane-ordered twiddles read from global memory ([15][64] pass 1, [2][5][64] split)
+    const void* gtab;      // w64x16: device, lane-ordered twiddles read from global memory
+    int xch_off;           // byte offset of the first wave's private region inside dynamic LDS
+    unsigned lds_bytes;    // dynamic LDS of the launch
     int waves;             // waves per workgroup of the launch
-    int variant;           // A/B variant of the wave kernel (plan option "wave_variant")
-    int persistent;        // 1: grid capped at max_wgs, waves walk several tiles; 0: one tile per wave; -1: by launch size (plan option "wave_grid")
-    int max_wgs;           // persistent grid: workgroups resident on the device at once (occupancy x CUs)
-    int wgs_per_cu;        // the occupancy answer itself (aud_plan_get_info)
+    int wgs_per_cu;        // the runtime's occupancy answer (aud_plan_get_info)
 };
 
 // PrevSmooth != 0 mode: scan along the steps of a stored power tensor
@@ -196,32 +185,19 @@ int melspec_generic_bluestein_L(int M, int compute_dtype);
 hipError_t melspec_generic_prepare(size_t lds_bytes);
 hipError_t launch_melspec_generic(const MelspecArgs& a, int compute_dtype, hipStream_t st);
 
-// N = 512 fast path
-bool melspec_r16_supported(int N, int S, int compute_dtype, int n_chunks, int nf, bool direct, FastArgs* out);
-hipError_t melspec_r16_prepare(unsigned lds_bytes);
-hipError_t launch_melspec_r16(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
-
-// N = 400 fast path
-bool melspec_r25_supported(int N, int S, int compute_dtype, int n_chunks, int nf, FastArgs* out);
-hipError_t melspec_r25_prepare(unsigned lds_bytes);
-hipError_t launch_melspec_r25(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
-
-// wave-autonomous kernels (melspec_wave.hip): N = 512 as 16 x 16 and N = 400 as 25 x 8, one wave per 4 / 8 frames,
-// no workgroup barrier behind the weight staging.  FastArgs: w4_off / sched_off / xch_off (first wave region).
-// kind: 1 = w16x16 (N = 512), 2 = w25x8 (N = 400).  *_geometry: filter groups of the epilogue, lanes per frame and
-// twiddle rows of the pass table; *_finish: carve LDS behind a blob of blob_bytes, false if it cannot fit.
+// wave-autonomous kernels (melspec_wave.hip): N = 512 as 16 x 16 (kind 1), N = 400 as 20 x 10 (kind 3), N = 2048 as
+// 16 x 16 x 4 with one frame per wave (kind 4); no workgroup barrier behind the table staging.
+// *_geometry: filter groups of the epilogue, lanes per frame and twiddle rows of the pass table; *_finish: carve LDS
+// behind a blob of blob_bytes, false if it cannot fit; *_prepare: LDS opt-in + the runtime's occupancy answer.
 struct WaveGeometry {
     int n_groups, lanes_per_frame, k1_rows, split_count;
 };
+int melspec_wave_kind(int N);  // 0: this window length has no wave kernel
 bool melspec_wave_geometry(int kind, int N, WaveGeometry* g);
-bool melspec_wave_finish(int kind, int compute_dtype, FastArgs* e);
-hipError_t melspec_wave_prepare(int kind, int compute_dtype, FastArgs* e);  // LDS opt-in + resident workgroup count
-hipError_t launch_melspec_wave(int kind, const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
-
-// N = 2048 fast path (one wave per frame, 16 x 16 x 4)
-bool melspec_r1024_supported(int N, int S, int compute_dtype, int n_chunks, int nf, FastArgs* out);
-hipError_t melspec_r1024_prepare(unsigned lds_bytes);
-hipError_t launch_melspec_r1024(const MelspecArgs& a, const FastArgs& e, int compute_dtype, hipStream_t st);
+bool melspec_wave_finish(int kind, int compute_dtype, WaveArgs* e);
+hipError_t melspec_wave_prepare(int kind, int compute_dtype, WaveArgs* e);
+hipError_t launch_melspec_wave(int kind, const MelspecArgs& a, const WaveArgs& e, int compute_dtype, hipStream_t st);
+int melspec_wave_frames_per_wave(int kind);
 
 hipError_t launch_gabor(const GaborArgs& a, int compute_dtype, hipStream_t st);
 

@@ -1,0 +1,199 @@
+// N = 400 wave-autonomous kernel "w20x10" (see melspec_wave.hip for what the wave kernels have in common).
+// Reference semantics: sound/sndenv.go:438-478, dft/dft.go:53-85, mel/mel.go:120-153.
+#include "wave_common.h"
+
+namespace aud {
+
+// ================================================================================================
+// N = 400: 200-point complex FFT as 20 x 10, 10 lanes per frame, 6 frames per wave (60 of 64 lanes)
+// ================================================================================================
+// A lane takes 20 points in pass A and then exactly one row PAIR (r, 20 - r) of 10 columns: every lane has both halves of
+// its ten split pairs locally (lane 0 takes the two self-paired rows 0 and 10).  20 = 4 x 5 and 10 = 2 x 5 have coprime
+// factors, so both small DFTs are prime-factor transforms without inner twiddles.  128 registers and 5.9 KB of LDS per
+// wave in float64: four waves per SIMD.
+namespace w20 {
+constexpr int kH = 201;  // power bins (6 frames per wave, 10 lanes per frame: wave_common.h)
+constexpr int kHp = 204;  // P row pitch in floats: 51 16-byte pieces (odd)
+template <typename TT>
+struct Layout {
+    // The transposes move HALF the rows at a time (rows 0..9, then rows 10..19: a lane's row pair (j, 20 - j) has one row
+    // in each half, lane 0's (0, 10) too), one component at a time: a quarter of a frame's complex data is in LDS at any
+    // moment, 5.9 KB per wave in float64 -- with the tables 31 KB per workgroup, so that LDS admits the four workgroups
+    // per CU the register budget (128) allows.  Scalar rows of 10 (+2 pad in float32: 16-byte rows); pitches from a
+    // search over the hardware's lane groups (tools/lds_bank_model.py): float64 column stores conflict-free (frame pitch
+    // = 10 mod 16 elements: the ten-lane frames tile the 16-lane store groups), row reads 2-way -- ten-lane frames
+    // against ds_read_b128's 16-lane groups cannot be conflict-free
+    static constexpr int kRow = (sizeof(TT) == 4) ? 12 : 10;
+    static constexpr int kFrame = (sizeof(TT) == 4) ? 120 : 122;
+    static constexpr int kXchBytes = kFW * kFrame * int(sizeof(TT));
+    static constexpr int kPBytes = kFW * kHp * 4;
+    static constexpr int kExpOff = ((kXchBytes > kPBytes ? kXchBytes : kPBytes) + 15) & ~15;
+    static constexpr int kRegion = kExpOff + 32;  // bytes per wave
+};
+template <typename TT>
+__device__ __forceinline__ void read_row10(const TT* row, C2<TT> (&z)[10], bool imag) {
+    TT d[12];
+    if constexpr (sizeof(TT) == 4) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const Q4<TT> r4 = reinterpret_cast<const Q4<TT>*>(row)[q];
+            d[4 * q] = r4.x; d[4 * q + 1] = r4.y; d[4 * q + 2] = r4.z; d[4 * q + 3] = r4.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const C2<TT> r2 = reinterpret_cast<const C2<TT>*>(row)[q];
+            d[2 * q] = r2.x; d[2 * q + 1] = r2.y;
+        }
+    }
+#pragma unroll
+    for (int n2 = 0; n2 < 10; ++n2) {
+        if (imag) z[n2].y = d[n2];
+        else z[n2].x = d[n2];
+    }
+}
+}  // namespace w20
+
+namespace {
+
+template <typename TT, int SRC, int NW, int MAXS>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(sizeof(TT) == 8 ? 4 : 5, sizeof(TT) == 8 ? 4 : 5)))
+void k_melspec_w20(const MelspecArgs a, const WaveArgs e) {
+    using L = w20::Layout<TT>;
+    unsigned char* smem = dyn_lds();
+    const int tid = int(threadIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+
+    BlobRegs<64 * NW> blob;
+    blob_fetch<64 * NW>(e, tid, blob);
+
+    const int tiles = (a.T + w20::kFW - 1) / w20::kFW;  // wave tiles per item
+    const int64_t total = int64_t(a.n_items) * tiles;
+    const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
+    const int64_t wt = int64_t(wg) * NW + wave;
+    const bool active = wt < total;
+    const int item = active ? int(wt / tiles) : 0;
+    const int t0 = active ? int(wt - int64_t(item) * tiles) * w20::kFW : 0;
+    const aud_item it = a.items[item];
+    // lanes 60..63 have no frame of their own: they SHADOW lanes 50..53 (same frame, same column) through the whole FFT --
+    // same loads, same arithmetic, same values stored to the same LDS addresses -- so that no LDS access sits under a
+    // lane condition
+    const bool own = lane < w20::kFW * w20::kLPF;
+    const int f = own ? lane / w20::kLPF : w20::kFW - 1;
+    const int j = own ? lane - f * w20::kLPF : lane - w20::kFW * w20::kLPF;
+    AUD_STAMP_DECL;
+    AUD_STAMP(0);
+    AUD_STAMP_REAL(9);
+
+    // pass A operands: z[10 n1 + j] = (x[20 n1 + 2j], x[.. + 1]), n1 = 0..19
+    const int64_t first_start = int64_t(it.start0) + int64_t(a.S) * (t0 - a.border);
+    const SampleWindow<SRC> win = sample_window<SRC>(a, it, first_start, a.S * (w20::kFW - 1) + w20::kN);
+    const int64_t pos0 = first_start + int64_t(a.S) * f + 2 * j;
+    PairRaw<20> raw;
+    if (active) pairs_issue<SRC, 20, 10>(win, pos0, raw);
+
+    blob_store<64 * NW>(e, smem, tid, blob);
+    __syncthreads();  // the one barrier: tables visible to the workgroup's waves
+    if (!active) return;
+
+    C2<TT> v[20];
+    TT amax;
+    pairs_take<TT, SRC, 20, 10>(a, it, pos0, t0 + f < a.T, raw, v, amax);
+
+    unsigned char* region = smem + e.xch_off + wave * L::kRegion;
+    TT* xw = reinterpret_cast<TT*>(region);
+    int* exps = reinterpret_cast<int*>(region + L::kExpOff);
+    const C2<TT>* twa = reinterpret_cast<const C2<TT>*>(smem + e.twa_off);  // W_400^(2 j k1) at [(k1 - 1) 10 + j]
+    const C2<TT>* tws = reinterpret_cast<const C2<TT>*>(smem + e.tws_off);  // W_400^k, k <= 100
+    const int sc = frame_scale<TT>(exps + f, amax);
+    AUD_STAMP(3);
+
+    // ---- pass A: 20-point DFT over n1, twiddle W_200^(j k1) = W_400^(2 j k1) -------------------------------
+    SmallDft<TT, 20>::run(v, nullptr, 0);
+#pragma unroll
+    for (int k1 = 1; k1 < 20; ++k1) v[k1] = cmul(v[k1], twa[(k1 - 1) * w20::kLPF + j]);
+    AUD_STAMP(4);
+
+    // ---- transpose, half the rows at a time (real parts, then imaginary parts): element (row k1, column n2 = j) of frame f;
+    // afterwards the lane holds the row pair (j, 20 - j) -- lane 0 the self-paired rows 0 and 10 -- with all ten columns
+    // of each.  Half A = rows 0..9 (every lane's first row), half B = rows 10..19 stored at row k1 - 10 (its second row).
+    TT* col = xw + f * L::kFrame + j;
+    constexpr int cstep = L::kRow;
+    const TT* row_a = xw + f * L::kFrame + j * L::kRow;
+    const TT* row_b = xw + f * L::kFrame + (j == 0 ? 0 : 10 - j) * L::kRow;
+    const int ra = j, rb = j == 0 ? 10 : 20 - j;
+    C2<TT> za[10], zb[10];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {  // 0: real parts, 1: imaginary parts
+        AUD_BENIGN_RACE_BEGIN();
+#pragma unroll
+        for (int k1 = 0; k1 < 10; ++k1) col[k1 * cstep] = part ? v[k1].y : v[k1].x;
+        AUD_BENIGN_RACE_END();
+        wave_lds_fence();
+        w20::read_row10<TT>(row_a, za, part != 0);
+        wave_lds_fence();
+        AUD_BENIGN_RACE_BEGIN();
+#pragma unroll
+        for (int k1 = 0; k1 < 10; ++k1) col[k1 * cstep] = part ? v[10 + k1].y : v[10 + k1].x;
+        AUD_BENIGN_RACE_END();
+        wave_lds_fence();
+        w20::read_row10<TT>(row_b, zb, part != 0);
+        wave_lds_fence();  // (after the last one: every row has been read, the region may take the power spectrum)
+    }
+    AUD_STAMP(5);
+
+    // ---- pass B: 10-point DFT over n2 of both rows: Z[k1 + 20 k2] -----------------------------------------------
+    SmallDft<TT, 10>::run(za, nullptr, 0);
+    SmallDft<TT, 10>::run(zb, nullptr, 0);
+    AUD_STAMP(6);
+
+    // ---- real-FFT split + power: the partner of Z[k1 + 20 k2] is element (20 - k1, 9 - k2); pairs are evaluated from
+    // their k <= 100 side (A = Z[k], B = Z[200 - k])
+    float* Pw = reinterpret_cast<float*>(region);  // [6][kHp]
+    float* P = Pw + f * w20::kHp;
+    AUD_BENIGN_RACE_BEGIN();
+    {
+        // lanes 1..9: rows (j, 20 - j): k = j + 20 c pairs with (row 20 - j, column 9 - c) and vice versa, c = 0..4;
+        // lane 0: row 0: k = 20 c pairs with column 10 - c of the same row (c = 0: DC + Nyquist; c = 5: itself), row 10:
+        // k = 10 + 20 c pairs with column 9 - c of the same row.  One code path, partners selected by value.
+        const bool self = j == 0;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const C2<TT> pa = za[(10 - c) % 10], pb = zb[9 - c], pc = za[9 - c];
+            const C2<TT> b_first = {self ? pa.x : pb.x, self ? pa.y : pb.y};
+            const C2<TT> b_second = {self ? pb.x : pc.x, self ? pb.y : pc.y};
+            split_pair<TT>(P, tws[ra + 20 * c], w20::kM, ra + 20 * c, za[c], b_first, sc);
+            split_pair<TT>(P, tws[rb + 20 * c], w20::kM, rb + 20 * c, zb[c], b_second, sc);
+        }
+        // lane 0's eleventh pair, k = 100 (row 0, column 5, paired with itself); the other lanes repeat their k = j pair
+        const int k11 = self ? 100 : ra;
+        split_pair<TT>(P, tws[k11], w20::kM, k11, self ? za[5] : za[0], self ? za[5] : zb[9], sc);
+        P[w20::kH + (j < 3 ? j : 0)] = 0.f;  // pad bins 201..203 of the last 4-bin chunk
+    }
+    AUD_BENIGN_RACE_END();
+    wave_lds_fence();
+    AUD_STAMP(7);
+
+    // ---- optional spectrum outputs and the mel reduction: 6 frames x 10 filter groups on this wave ---------------
+    wave_mel_epilogue<TT, w20::kFW, MAXS>(a, e, Pw, w20::kHp, smem, exps, it, item, t0, lane);
+    AUD_STAMP(8);
+    AUD_STAMP_REAL(10);
+    AUD_STAMP_FLUSH(a, wt, lane);
+}
+
+}  // namespace
+
+size_t w20_region_bytes(bool f64) { return f64 ? size_t(w20::Layout<double>::kRegion) : size_t(w20::Layout<float>::kRegion); }
+
+#define AUD_W20_PICK(TT)                                                                                  \
+    (sig_dtype == AUD_F64   ? (s8 ? k_melspec_w20<TT, AUD_F64, 4, 8> : k_melspec_w20<TT, AUD_F64, 4, 4>)   \
+     : sig_dtype == AUD_I16 ? (s8 ? k_melspec_w20<TT, AUD_I16, 4, 8> : k_melspec_w20<TT, AUD_I16, 4, 4>)   \
+                            : (s8 ? k_melspec_w20<TT, AUD_F32, 4, 8> : k_melspec_w20<TT, AUD_F32, 4, 4>))
+wave_kernel_t w20_kernel(bool f64, int sig_dtype, int n_slots) {
+    const bool s8 = n_slots > 4;
+    return f64 ? AUD_W20_PICK(double) : AUD_W20_PICK(float);
+}
+#undef AUD_W20_PICK
+
+}  // namespace aud

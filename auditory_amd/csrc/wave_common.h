@@ -1,0 +1,70 @@
+// Shared by the wave-autonomous kernel files (melspec_w16.hip, melspec_w20.hip, melspec_w64.hip) and their host-side
+// dispatch (melspec_wave.hip).
+#pragma once
+#include "device_common.h"
+
+namespace aud {
+
+// what melspec_wave.hip needs from a kernel file: the instantiation for (compute type, sample type, epilogue slot
+// capacity) and the bytes of LDS one wave's private region takes
+typedef void (*wave_kernel_t)(const MelspecArgs, const WaveArgs);
+wave_kernel_t w16_kernel(bool f64, int sig_dtype, int n_slots);
+wave_kernel_t w20_kernel(bool f64, int sig_dtype, int n_slots);
+wave_kernel_t w64_kernel(bool f64, int sig_dtype, int n_slots);
+size_t w16_region_bytes(bool f64);
+size_t w20_region_bytes(bool f64);
+size_t w64_region_bytes(bool f64);
+namespace w16 { constexpr int kFW = 4, kN = 512, kM = 256; }
+namespace w20 { constexpr int kFW = 6, kLPF = 10, kN = 400, kM = 200; }
+namespace w64 { constexpr int kN = 2048, kM = 1024, kFPW = 4; }
+
+namespace {
+
+// The workgroup's table blob: loads first (kept in registers), stores after the caller has issued its operand loads.
+// NT threads, up to 4 x 16 bytes per thread in flight; larger blobs finish with a plain copy loop.
+template <int NT>
+struct BlobRegs {
+    uint4 v[4];
+};
+template <int NT>
+__device__ __forceinline__ void blob_fetch(const WaveArgs& e, int tid, BlobRegs<NT>& b) {
+    const uint4* __restrict__ g = static_cast<const uint4*>(e.blob);
+    const int n16 = e.blob_bytes >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = tid + NT * q;
+        b.v[q] = g[i < n16 ? i : 0];
+    }
+}
+template <int NT>
+__device__ __forceinline__ void blob_store(const WaveArgs& e, unsigned char* smem, int tid, const BlobRegs<NT>& b) {
+    uint4* l = reinterpret_cast<uint4*>(smem);
+    const uint4* __restrict__ g = static_cast<const uint4*>(e.blob);
+    const int n16 = e.blob_bytes >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = tid + NT * q;
+        if (i < n16) l[i] = b.v[q];
+    }
+#pragma unroll 1
+    for (int i = tid + 4 * NT; i < n16; i += NT) l[i] = g[i];
+}
+
+// One (Z[k], Z[M - k]) pair of the real-FFT split -> bins k and M - k of the float32 spectrum (FOUR times the power over
+// 2^sc; the 1/4 lives in the blob's mel weights): X[k] = (E + T)/2, X[M-k] = conj(E - T)/2, E = A + conj B,
+// T = -i W_N^k (A - conj B), evaluated from the pair's k <= M/2 side.  Squaring AFTER the subtraction keeps a weak bin
+// next to a strong partner at the FFT's own accuracy (squares first would not).
+template <typename TT>
+__device__ __forceinline__ void split_pair(float* P, C2<TT> w, int M, int k, C2<TT> A, C2<TT> B, int sc) {
+    const C2<TT> E = {A.x + B.x, A.y - B.y};
+    const C2<TT> D = {A.x - B.x, A.y + B.y};
+    const C2<TT> mD = {D.y, -D.x};
+    const C2<TT> Tm = cmul(mD, w);
+    const TT xr = E.x + Tm.x, xi = E.y + Tm.y;
+    const TT yr = E.x - Tm.x, yi = E.y - Tm.y;
+    P[k] = scaled_power(xr * xr + xi * xi, sc);
+    P[M - k] = scaled_power(yr * yr + yi * yi, sc);  // k = 0 -> the Nyquist bin M; k = M/2 -> the same bin, same value
+}
+
+}  // namespace
+}  // namespace aud

@@ -54,6 +54,42 @@ extern "C" void AnnotateIgnoreWritesEnd(const char*, int);
 #endif
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
 inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_ACQ_REL); }  // callers pass wave-uniform values
+inline int atomicMax(int* p, int v) {
+    int cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (cur < v && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED)) {}
+    return cur;
+}
+
+// Buffer descriptors (raw buffers, stride 0): base pointer + size in bytes; a load whose byte offset -- taken as an
+// UNSIGNED 32-bit number, so negative offsets are far out of range -- does not lie wholly inside [0, bytes) returns 0,
+// as the hardware's range check does.  (The kernels never depend on what a load that straddles an end returns.)
+struct __amdgpu_buffer_rsrc_t {
+    const unsigned char* base;
+    unsigned bytes;
+};
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short /*stride*/, int num_records, int /*flags*/) {
+    return __amdgpu_buffer_rsrc_t{static_cast<const unsigned char*>(p), unsigned(num_records)};
+}
+template <typename T>
+inline T emul_buffer_load(const __amdgpu_buffer_rsrc_t& r, int voffset, int soffset) {
+    const uint64_t off = uint64_t(uint32_t(voffset)) + uint64_t(uint32_t(soffset));
+    T v{};
+    if (off + sizeof(T) <= uint64_t(r.bytes)) std::memcpy(&v, r.base + off, sizeof(T));
+    return v;
+}
+struct emul_u32x2 {
+    unsigned v[2];
+    unsigned operator[](int i) const { return v[i]; }
+};
+inline emul_u32x2 __builtin_amdgcn_raw_buffer_load_b64(const __amdgpu_buffer_rsrc_t& r, int voffset, int soffset, int) {
+    return emul_buffer_load<emul_u32x2>(r, voffset, soffset);
+}
+inline unsigned __builtin_amdgcn_raw_buffer_load_b32(const __amdgpu_buffer_rsrc_t& r, int voffset, int soffset, int) {
+    return emul_buffer_load<unsigned>(r, voffset, soffset);
+}
+inline unsigned short __builtin_amdgcn_raw_buffer_load_b16(const __amdgpu_buffer_rsrc_t& r, int voffset, int soffset, int) {
+    return emul_buffer_load<unsigned short>(r, voffset, soffset);
+}
 
 
 typedef int hipError_t;

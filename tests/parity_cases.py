@@ -85,13 +85,10 @@ def case_workgroup_order(orc, cdt, with_n2048=True):
     not multiples of 8 and changes nothing in the results: every kernel family, remap on == off, bit for bit"""
     for name, seg_ms, dur, rows, seg_list, opts in [
             ("cfg2_16k_n512_nf40", 200.0, 0.25, 9, [0], {}),                  # w16x16: 54 wave tiles, 14 workgroups
-            ("cfg2_16k_n512_nf40", 200.0, 0.25, 9, [0], {"kernel": 2}),       # r16x16: 18 workgroups (18 % 8 = 2)
-            ("cfg2_16k_n512_nf40", 520.0, 0.55, 9, [0], {"r16_tiles": 2}),    # two-tile kernel: 18 workgroups
+            ("cfg2_16k_n512_nf40", 200.0, 0.25, 9, [0], {"kernel": 1}),       # generic, factorable N
             ("sndenv_16k_n400_nf32", None, 0.75, 3, list(range(7)), {}),      # w20x10: 21 items x 3 wave tiles
-            ("sndenv_16k_n400_nf32", None, 0.75, 3, list(range(7)), {"n400_geometry": 25}),  # w25x8: 21 items x 2 wave tiles
-            ("sndenv_16k_n400_nf32", None, 0.75, 3, list(range(7)), {"kernel": 2}),  # r25x8: 21 one-tile items
             ("cfg1_44k_n1103_nf32", None, 0.3, 3, [0, 1], {}),                # generic, prime N
-            ("cfg5_44k_n2048_nf128", 120.0, 0.5, 5, [0, 1, 2, 3], {})][:8 if with_n2048 else 7]:  # r16x16x4: 20 items
+            ("cfg5_44k_n2048_nf128", 120.0, 0.5, 5, [0, 1, 2, 3], {})][:5 if with_n2048 else 4]:  # w64x16: 20 items
         oc = W.OracleCfg(orc, name, seg_ms)
         L = int(dur * oc.sr)
         sig, _ = synth.batch(19, rows, L, oc.sr)
@@ -102,8 +99,7 @@ def case_workgroup_order(orc, cdt, with_n2048=True):
             plan = W.product_plan(oc, cdt)
             try:
                 for k, v in opts.items():
-                    if not (k.startswith("r16_") and plan.kernel_name not in ("r16x16", "w16x16")):
-                        plan.set_option(k, v)
+                    plan.set_option(k, v)
                 plan.set_option("xcd_remap", remap)
                 outs.append(plan.melspec_host(sig.ravel(), items, True, False))
             finally:
@@ -203,14 +199,6 @@ def case_gabor_4d_and_2d_vs_oracle(orc, cdt):
     plan.gabor_host(mel, out)
     ok, msg = W.close_enough(out, ref, tol)
     assert ok, msg
-    # the LDS-tiled kernel (plan option "gabor_lds" = 1) and the default global-memory one give the same bits
-    # (2 / 4: two / four threads per output position)
-    for variant in (1, 2, 4):
-        plan.set_option("gabor_lds", variant)
-        out_g = np.full((5, 11, 32, 2, 8), 7.0, np.float32)
-        plan.gabor_host(mel, out_g)
-        assert np.array_equal(out, out_g), variant
-    plan.set_option("gabor_lds", 0)
     # wider units than the kernel fills + fewer pools than the mel allows:
     # untouched cells keep their contents (the reference never zeroes rawOut)
     out = np.full((5, 9, 20, 3, 10), 7.0, np.float32)
@@ -266,11 +254,6 @@ def case_gabor_4d_and_2d_vs_oracle(orc, cdt):
         plan.gabor_host(mel, out, by_time)
         ok, msg = W.close_enough(out, ref, tol)
         assert ok, msg
-        plan.set_option("gabor_lds", 1)
-        out_g = np.zeros_like(out)
-        plan.gabor_host(mel, out_g, by_time)
-        assert np.array_equal(out, out_g)
-        plan.set_option("gabor_lds", 0)
     plan.close()
 
 
@@ -535,14 +518,8 @@ def case_prev_smooth(orc, name, cdt):
     assert np.abs(raw[0] - ref_mel[0]).max() > 1e-3
 
 
-# the kernel variants a 512-sample plan can run: all must agree with the oracle (and each other)
-N512_VARIANTS = {"w16_default": {}, "w16_persistent": {"wave_grid": 1}, "w16_dynamic_queue": {"wave_grid": 2},
-                 "w16_persistent_prefetch": {"wave_grid": 1, "wave_variant": 0},
-                 "w16_persistent_prefetch_capped": {"wave_grid": 1, "wave_variant": 1},
-                 "r16_tile_kernel": {"kernel": 2},
-                 "r16_direct": {"r16_input": 0}, "r16_direct_2tiles": {"r16_input": 0, "r16_tiles": 2},
-                 "r16_staged": {"r16_input": 1}, "r16_mel_mfma": {"r16_input": 0, "r16_mel": 1},
-                 "r16_mel_mfma_staged_2": {"r16_input": 1, "r16_mel": 1}, "generic": {"kernel": 1}}
+# the kernels a 512-sample plan can run: both must agree with the oracle
+N512_VARIANTS = {"w16_default": {}, "generic": {"kernel": 1}}
 
 
 def _fast_family(orc, name, cdt, seg_ms=None):
@@ -555,41 +532,25 @@ def _fast_family(orc, name, cdt, seg_ms=None):
 
 def case_n512_variants(orc, cdt, seg_ms=None, dur=1.0, rows=2, segs=(0,)):
     case = ("cfg2_16k_n512_nf40", dur, rows, list(segs))
-    have_fast = _fast_family(orc, case[0], cdt, seg_ms) in ("w16x16", "r16x16")
     for name, opts in N512_VARIANTS.items():
-        if ("r16_input" in opts or opts.get("kernel") == 2) and not have_fast:
-            continue
-        if opts.get("r16_mel") and cdt != capi.AUD_F32:
-            continue  # the matrix-pipe mel variant is float32 only (refusal checked below)
         case_melspec_vs_oracle(orc, case, cdt, seg_ms=seg_ms, options=opts)
-    # a plan reports what it runs, and odd steps fall back to the generic kernel by themselves
+    # a plan reports what it runs
     oc = W.OracleCfg(orc, "cfg2_16k_n512_nf40")
     plan = W.product_plan(oc, cdt)
-    # float64 needs > 64 KB of LDS per workgroup; a runtime that refuses it leaves the plan on "generic"
     assert plan.kernel_name == "w16x16"
-    auto = plan.kernel_name
     plan.set_option("kernel", 1)
     assert plan.kernel_name == "generic"
-    plan.set_option("kernel", 2)
-    assert plan.kernel_name == "r16x16"     # the workgroup-tile kernel of round 1
     plan.set_option("kernel", 0)
-    assert plan.kernel_name == auto
-    plan.set_option("r16_tiles", 2)         # the r16_* switches are variants of the workgroup-tile kernel
-    assert plan.kernel_name == "r16x16"
-    plan.set_option("kernel", 0)
-    with pytest.raises(capi.AuditoryError):
-        plan.set_option("kernel", 3)
-    with pytest.raises(capi.AuditoryError):
-        plan.set_option("nonsense", 1)
-    if cdt == capi.AUD_F64:
+    assert plan.kernel_name == "w16x16"
+    for bad in (("kernel", 2), ("nonsense", 1), ("wave_grid", 1), ("r16_tiles", 2)):   # (options of earlier rounds are gone)
         with pytest.raises(capi.AuditoryError):
-            plan.set_option("r16_mel", 1)
+            plan.set_option(*bad)
     plan.close()
 
 
 def case_n512_odd_step_and_sample_types(orc, cdt):
-    """N = 512 with an odd step (S = 161): direct variant handles unaligned pairs through its guarded
-    loads, the staged one is refused; int16 / float64 samples go through the same paths."""
+    """N = 512 with an odd step (S = 161): every other frame starts on an odd sample (8-byte pair loads at 4-byte
+    alignment; int16 frames take the element route)."""
     import ctypes as C
     from auditory_amd import mel as melmod
     lib = capi.load()
@@ -612,10 +573,8 @@ def case_n512_odd_step_and_sample_types(orc, cdt):
                         compute_dtype=cdt)
     try:
         assert plan.kernel_name == "w16x16"
-        with pytest.raises(capi.AuditoryError):
-            plan.set_option("r16_input", 1)                       # staged needs an even step (or no r16 at all)
         items = runtime.make_items([0, L], [L, L], [0, 0])
-        for kern in (0, 2):                                       # wave-autonomous and workgroup-tile kernels
+        for kern in (0, 1):                                       # wave-autonomous and generic kernels
             plan.set_option("kernel", kern)
             got, _, _ = plan.melspec_host(sig.ravel(), items)
             ok, msg = W.feature_close(got, ref, cdt, lin_axis=1)
@@ -626,26 +585,20 @@ def case_n512_odd_step_and_sample_types(orc, cdt):
 
 
 def case_n400_variants(orc, cdt, seg_ms=None, dur=1.0, rows=2, segs=(0,)):
-    """25 ms @ 16 kHz (N = 400): the r25x8 kernel and the generic kernel, both against the oracle"""
+    """25 ms @ 16 kHz (N = 400): the w20x10 kernel and the generic kernel, both against the oracle"""
     for name in ("cfg2_16k_n400_nf40", "sndenv_16k_n400_nf32"):
         fam = _fast_family(orc, name, cdt, seg_ms)
         assert fam == "w20x10"
-        # wave-autonomous 20 x 10 (default; persistent and dynamic-queue grids), 25 x 8 (and its variants), workgroup-tile
-        # (r25x8), generic
-        for opts in ({}, {"wave_grid": 1}, {"wave_grid": 1, "wave_variant": 0}, {"wave_grid": 2}, {"n400_geometry": 25},
-                     {"n400_geometry": 25, "wave_grid": 1},
-                     {"n400_geometry": 25, "wave_grid": 2}, {"n400_geometry": 25, "wave_grid": 1, "wave_variant": 0},
-                     {"n400_geometry": 25, "wave_grid": 1, "wave_variant": 1}, {"kernel": 2}, {"kernel": 1}):
+        for opts in ({}, {"kernel": 1}):
             case_melspec_vs_oracle(orc, (name, dur, rows, list(segs)), cdt, seg_ms=seg_ms, options=opts)
 
 
 def case_n2048_variants(orc, cdt, seg_ms=300.0, dur=0.4, rows=2):
-    """BASELINE config 5 parameters (44.1 kHz, N = 2048, 128 mel, NaN row): w64x16 (default), r16x16x4 (the round-1
-    workgroup-tile kernel, option kernel = 2) and generic"""
+    """BASELINE config 5 parameters (44.1 kHz, N = 2048, 128 mel, NaN row): w64x16 (default) and generic"""
     name = "cfg5_44k_n2048_nf128"
     fam = _fast_family(orc, name, cdt, seg_ms)
     assert fam == "w64x16"
-    for opts in ({}, {"kernel": 2}, {"kernel": 1}):
+    for opts in ({}, {"kernel": 1}):
         case_melspec_vs_oracle(orc, (name, dur, rows, [0, 1]), cdt, seg_ms=seg_ms, options=opts)
 
 

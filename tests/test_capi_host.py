@@ -179,12 +179,11 @@ def test_kernels_use_no_scratch_and_fit_their_occupancy():
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not installed")
     from auditory_amd import build as B
-    # waves per SIMD each float32 kernel's launch geometry assumes (LDS allows no more than this anyway)
-    need_occupancy = {"k_melspec_r16IfLb1ELi1": 4, "k_melspec_r16IfLb1ELi2": 4, "k_melspec_r16IfLb0ELi1": 3,
-                      "k_melspec_r25If": 3, "k_melspec_r1024If": 3, "k_melspec_genericIf": 2}
+    # waves per SIMD each kernel's launch geometry assumes (its LDS allows no more than this anyway)
+    need_occupancy = {"k_melspec_w16IfL": 5, "k_melspec_w20IfL": 5, "k_melspec_w64IfL": 5, "k_melspec_w16IdL": 3,
+                      "k_melspec_w20IdL": 4, "k_melspec_w64IdL": 3, "k_melspec_genericIf": 2}
     seen = {}
-    for src in ("melspec_r16.hip", "melspec_r25.hip", "melspec_r1024.hip", "melspec_generic.hip", "gabor.hip",
-                "kwta.hip"):
+    for src in ("melspec_w16.hip", "melspec_w20.hip", "melspec_w64.hip", "melspec_generic.hip", "smooth_mel.hip", "mfcc.hip", "gabor.hip", "kwta.hip"):
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17",
                             "-I" + B.INCLUDE, "-I" + B.CSRC, "-c", os.path.join(B.CSRC, src), "-o", "/dev/null",
                             "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd="/tmp")
@@ -201,15 +200,16 @@ def test_kernels_use_no_scratch_and_fit_their_occupancy():
                 if m and name:
                     seen.setdefault(name, {})[key] = int(m.group(1))
     assert len(seen) >= 20
+    checked = set()
     for name, res in seen.items():
         assert res["scratch"] == 0, (name, res)
-        # (the register file is unified on gfx950, so hipcc's occupancy counts accumulation registers too: an
-        # unused MFMA code path inside a kernel once took a wave per SIMD from it this way)
+        # (the register file is unified on gfx950, so hipcc's occupancy counts accumulation registers too)
         for key, need in need_occupancy.items():
             if key in name:
                 assert res["occupancy"] >= need, (name, res, need)
-        if "k_melspec_r16" in name and "ELb1EEEv" not in name:
-            assert res["agpr"] == 0, (name, res)   # only the matrix-pipe mel instantiations use AGPRs
+                checked.add(key)
+        assert res["agpr"] == 0, (name, res)   # no kernel uses the matrix pipe
+    assert checked == set(need_occupancy)
 
 
 def test_header_is_plain_c(tmp_path):

@@ -1,0 +1,42 @@
+#!/bin/bash
+# One gpurun call = a sequence of bounded steps (run from the repo root on the GPU box):
+#   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/gpu_call.sh TAG step [step ...]'
+# Every step is bounded by its own `timeout -k`, writes gpurun_out/TAG_<step>.log, and a step that times out or dies by a
+# signal ends the sequence (no GPU step after it); an ordinary failure (rc 1) does not.
+# Steps: smoke | pytest | bench | bench:<extra bench.py args joined by ','> | ab | profile[:<bench args>] | stamps
+set -u
+TAG=${1:?tag}; shift
+mkdir -p gpurun_out
+run() {  # run <name> <seconds> <command...>
+    local name=$1 secs=$2; shift 2
+    echo "[gpu_call] $name"
+    timeout -k 10 "$secs" "$@" > "gpurun_out/${TAG}_${name}.log" 2>&1
+    local rc=$?
+    echo "[gpu_call] $name rc=$rc"; tail -4 "gpurun_out/${TAG}_${name}.log" | cut -c1-600
+    if [ $rc -eq 124 ] || [ $rc -ge 128 ]; then echo "[gpu_call] stopping after a timeout/crash"; exit $rc; fi
+    return 0
+}
+i=0
+for step in "$@"; do
+    i=$((i + 1))
+    case "$step" in
+        smoke) run smoke 240 python -c "import __graft_entry__ as g; g.smoke()" ;;
+        pytest) run pytest 900 python -m pytest tests -q -m gpu -x ;;
+        pytest_all) run pytest 900 python -m pytest tests -q -m gpu ;;
+        bench) run bench$i 400 python bench.py
+               grep '^{' "gpurun_out/${TAG}_bench$i.log" | tail -1 > "gpurun_out/${TAG}_bench$i.json" ;;
+        bench:*) args=$(echo "${step#bench:}" | tr ',' ' ')
+               run bench$i 400 python bench.py $args
+               grep '^{' "gpurun_out/${TAG}_bench$i.log" | tail -1 > "gpurun_out/${TAG}_bench$i.json" ;;
+        ab) run ab$i 300 python tools/ab_bench.py ;;
+        ab:*) args=$(echo "${step#ab:}" | tr ',' ' ')
+               run ab$i 300 python tools/ab_bench.py $args ;;
+        profile) run profile$i 900 bash tools/profile_bench.sh "${TAG}" ;;
+        profile:*) args=$(echo "${step#profile:}" | tr ',' ' ')
+               run profile$i 900 bash tools/profile_bench.sh "${TAG}_$i" $args ;;
+        ubench) (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_rates valu_rates.hip) &&
+                run ubench 120 /tmp/valu_rates ;;
+        *) echo "unknown step $step"; exit 2 ;;
+    esac
+done
+echo "[gpu_call] done"

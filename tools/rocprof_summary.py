@@ -46,7 +46,7 @@ def main():
                 note = "  => HBM read  ~ %.3f MB/launch (x2 gfx950 correction, KB units)" % (2 * mean * 1024 / 1e6)
                 if "melspec" in k:
                     traffic.setdefault(k, {})["read_bytes"] = 2 * mean * 1024
-                    # the guide calibrates the x2 for 16 B/lane streaming reads; the r16x16 / r25x8 kernels read
+                    # the guide calibrates the x2 for 16 B/lane streaming reads; the wave kernels read
                     # 8 B per lane, which it lists as uncalibrated -- keep the raw figure next to the corrected one
                     traffic[k]["read_bytes_raw_fetch_size"] = mean * 1024
             if n == "WRITE_SIZE":
@@ -56,8 +56,7 @@ def main():
             print("%-70s %-12s %7d %14.1f%s" % (k[:70], n, cnt, mean, note))
     # what bench.py reports as roofline.traffic: HBM bytes per launch of the frame->mel kernel
     best = None
-    fams = {"k_melspec_w20": "w20x10", "k_melspec_w25": "w25x8", "k_melspec_w16": "w16x16", "k_melspec_r16": "r16x16", "k_melspec_r25": "r25x8",
-            "k_melspec_w64": "w64x16", "k_melspec_r1024": "r16x16x4", "k_melspec_generic": "generic"}
+    fams = {"k_melspec_w20": "w20x10", "k_melspec_w16": "w16x16", "k_melspec_w64": "w64x16", "k_melspec_generic": "generic"}
     avg_ns = {r.get("Name", ""): float(r.get("AverageNs", r.get("Average", 0)) or 0) for r in stats}
     for k, v in traffic.items():
         if "read_bytes" in v and "write_bytes" in v:
