@@ -29,9 +29,17 @@ struct alignas(16) C2x2 {
     C2<TT> a, b;
 };
 
+// Every fused multiply-add of the frame->mel kernels is written out (mad), and the compiler's own contraction is off
+// for these files: which of two products a contraction fuses is the compiler's choice per instantiation, and a kernel
+// is instantiated per sample type and compute type -- results must not depend on which instantiation ran (int16 PCM
+// and the same samples as float32 give the same bits), nor differ between the GPU and the CPU thread emulator.
+#pragma clang fp contract(off)
+__device__ __forceinline__ float mad(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double mad(double a, double b, double c) { return fma(a, b, c); }
+
 template <typename TT>
 __device__ __forceinline__ C2<TT> cmul(C2<TT> a, C2<TT> b) {
-    return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+    return {mad(a.x, b.x, -(a.y * b.y)), mad(a.x, b.y, a.y * b.x)};
 }
 
 template <typename TT>
@@ -54,7 +62,7 @@ template <typename TT>
 __device__ __forceinline__ void dft3(C2<TT>& u0, C2<TT>& u1, C2<TT>& u2) {
     const TT hs = TT(0.86602540378443864676L);  // sin(2 pi / 3)
     const C2<TT> t = cadd(u1, u2);
-    const C2<TT> mm = {u0.x - TT(0.5) * t.x, u0.y - TT(0.5) * t.y};
+    const C2<TT> mm = {mad(TT(-0.5), t.x, u0.x), mad(TT(-0.5), t.y, u0.y)};
     const C2<TT> n = {hs * (u1.x - u2.x), hs * (u1.y - u2.y)};
     u0 = cadd(u0, t);
     u1 = cadd(mm, mul_mi(n));
@@ -74,10 +82,10 @@ __device__ __forceinline__ void dft5(C2<TT>& u0, C2<TT>& u1, C2<TT>& u2, C2<TT>&
     const TT c1 = TT(0.30901699437494742410L), c2 = TT(-0.80901699437494742410L);
     const TT s1 = TT(0.95105651629515357212L), s2 = TT(0.58778525229247312917L);
     const C2<TT> t1 = cadd(u1, u4), t2 = cadd(u2, u3), t3 = csub(u1, u4), t4 = csub(u2, u3);
-    const C2<TT> m1 = {u0.x + c1 * t1.x + c2 * t2.x, u0.y + c1 * t1.y + c2 * t2.y};
-    const C2<TT> m2 = {u0.x + c2 * t1.x + c1 * t2.x, u0.y + c2 * t1.y + c1 * t2.y};
-    const C2<TT> n1 = {s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y};
-    const C2<TT> n2 = {s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y};
+    const C2<TT> m1 = {mad(c2, t2.x, mad(c1, t1.x, u0.x)), mad(c2, t2.y, mad(c1, t1.y, u0.y))};
+    const C2<TT> m2 = {mad(c1, t2.x, mad(c2, t1.x, u0.x)), mad(c1, t2.y, mad(c2, t1.y, u0.y))};
+    const C2<TT> n1 = {mad(s2, t4.x, s1 * t3.x), mad(s2, t4.y, s1 * t3.y)};
+    const C2<TT> n2 = {mad(s2, t3.x, -(s1 * t4.x)), mad(s2, t3.y, -(s1 * t4.y))};
     u0 = {u0.x + t1.x + t2.x, u0.y + t1.y + t2.y};
     u1 = cadd(m1, mul_mi(n1));
     u4 = cadd(m1, mul_pi(n1));

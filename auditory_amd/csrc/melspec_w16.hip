@@ -146,12 +146,12 @@ void k_melspec_w16(const MelspecArgs a, const WaveArgs e) {
             const C2<TT> Tm = cmul(mD, w);
             const TT xr = E.x + Tm.x, xi = E.y + Tm.y;  // 2 X[k]
             const TT yr = E.x - Tm.x, yi = E.y - Tm.y;  // 2 conj X[256-k]
-            P[k] = scaled_power(xr * xr + xi * xi, sc);  // FOUR times the power (the 1/4 lives in the mel weights)
-            if (k != 0) P[w16::kM - k] = scaled_power(yr * yr + yi * yi, sc);
-            else P[w16::kM] = scaled_power(yr * yr + yi * yi, sc);  // k = 0 also yields the Nyquist bin
+            P[k] = scaled_power(mad(xr, xr, xi * xi), sc);  // FOUR times the power (the 1/4 lives in the mel weights)
+            if (k != 0) P[w16::kM - k] = scaled_power(mad(yr, yr, yi * yi), sc);
+            else P[w16::kM] = scaled_power(mad(yr, yr, yi * yi), sc);  // k = 0 also yields the Nyquist bin
         }
         // k = 128 (lane 0, register 8) pairs with itself: X[128] = conj(Z[128])
-        if (j == 0) P[128] = scaled_power(TT(4) * (v[8].x * v[8].x + v[8].y * v[8].y), sc);  // (x 4 like every bin of P)
+        if (j == 0) P[128] = scaled_power(TT(4) * mad(v[8].x, v[8].x, v[8].y * v[8].y), sc);  // (x 4 like every bin of P)
         // bins 257..259 only pad the last 4-bin chunk; their weights are zero but 0 * garbage must stay 0
         if (j >= 13) P[w16::kH + (j - 13)] = 0.f;
     }

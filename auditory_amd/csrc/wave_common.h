@@ -62,8 +62,8 @@ __device__ __forceinline__ void split_pair(float* P, C2<TT> w, int M, int k, C2<
     const C2<TT> Tm = cmul(mD, w);
     const TT xr = E.x + Tm.x, xi = E.y + Tm.y;
     const TT yr = E.x - Tm.x, yi = E.y - Tm.y;
-    P[k] = scaled_power(xr * xr + xi * xi, sc);
-    P[M - k] = scaled_power(yr * yr + yi * yi, sc);  // k = 0 -> the Nyquist bin M; k = M/2 -> the same bin, same value
+    P[k] = scaled_power(mad(xr, xr, xi * xi), sc);
+    P[M - k] = scaled_power(mad(yr, yr, yi * yi), sc);  // k = 0 -> the Nyquist bin M; k = M/2 -> the same bin, same value
 }
 
 }  // namespace

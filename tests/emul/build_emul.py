@@ -10,12 +10,14 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from auditory_amd import build as product_build  # noqa: E402  (source list only)
 
+# -mfma: the kernels spell their fused multiply-adds out (device_common.h mad) and switch the compiler's own contraction
+# off, so with the instruction available the emulator computes what the GPU computes up to the hardware's log / rcp
 FLAGS = {
-    "plain": ["-O2"],
-    "asan": ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+    "plain": ["-O2", "-mfma"],
+    "asan": ["-O1", "-g", "-mfma", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
              "-fno-sanitize-recover=undefined"],
-    "tsan": ["-O1", "-g", "-fsanitize=thread"],
-    # contracted multiply-adds, closer to what hipcc emits for the device (fp-contract=fast)
+    "tsan": ["-O1", "-g", "-mfma", "-fsanitize=thread"],
+    # contraction left to the compiler where the sources do not fix it (gabor, mfcc, k-WTA)
     "fma": ["-O2", "-mfma", "-ffp-contract=fast"],
 }
 
@@ -41,7 +43,7 @@ def _build(variant, force):
              if f.endswith((".h", ".hpp", ".inc"))]
     if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
-    common = ["g++", "-std=c++17", "-fPIC", "-pthread", "-ffp-contract=off",
+    common = ["g++", "-std=c++17", "-fPIC", "-pthread"] + ([] if variant == "fma" else ["-ffp-contract=off"]) + [
               "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-function", "-Wno-attributes"] + FLAGS[variant] + [
               "-I" + HERE, "-I" + product_build.INCLUDE, "-I" + product_build.CSRC]
     # one compile job per source, a few at a time (the sanitizer variants take a minute otherwise), then one link
