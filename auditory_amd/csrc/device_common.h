@@ -446,6 +446,23 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 
+// Largest value of an int over the wave (every lane gets it, as a wave-uniform scalar) and over each aligned 16-lane row,
+// by data-parallel-primitive moves: no LDS traffic, six / four vector instructions.  max() is idempotent, so mirrored
+// lanes meeting twice does no harm.
+__device__ __forceinline__ int row16_max_i32(int x) {
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false));  // row_half_mirror
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false));  // row_mirror: all 16 lanes of a row agree
+    return x;
+}
+__device__ __forceinline__ int wave_max_i32(int x) {
+    x = row16_max_i32(x);
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1 and 3
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
 // ---- a frame's power-of-two scale ------------------------------------------------------------------------------------
 // The wave kernels park the power spectrum in LDS as FLOAT32 for both compute types (half the epilogue's LDS traffic, its
 // multiply-adds at the float32 rate).  float64 plans must hold for every input a double can carry, so each frame's
@@ -486,8 +503,8 @@ __device__ __forceinline__ float scaled_power(double p4, int sc) { return float(
 __device__ __forceinline__ float scaled_power(float p4, int) { return p4; }
 
 // ---- epilogue of the wave-autonomous kernels ---------------------------------------------------------------------
-// P: this wave's [FPW][Hp] spectrum in LDS, float32, FOUR times the power divided by 2^sc of its frame (frame_scale; the
-// frames' sc in `exps`; the 1/4 lives in the mel weights).  64 lanes = FPW frames x (64 / FPW) filter groups.
+// P: this wave's [FPW][Hp] spectrum in LDS, float32, FOUR times the power divided by 2^sc of its frame (frame_scale; `sc`
+// = the scale of the frame THIS lane reduces, lane % FPW; the 1/4 lives in the mel weights).  64 lanes = FPW frames x (64 / FPW) filter groups.
 //   * dft/dft.go:70-83: PowerSegment / LogPowerSegment [item, H, T] (optional outputs)
 //   * mel/mel.go:120-153: triangle sums over aligned 4-bin chunks, + LogOff, ln / LogMin, optional renorm,
 //     MelFBankSegment [item, nf, T]
@@ -496,7 +513,7 @@ __device__ __forceinline__ float scaled_power(float p4, int) { return p4; }
 // (one per position in the chunk: at most 2 x the slot's steps additions each, pairwise at the end).  No LDS access sits
 // under a lane condition: a masked frame still reads its -- valid -- row and drops the sums.
 template <typename TT, int FPW>
-__device__ __forceinline__ void wave_spectrum_outputs(const MelspecArgs& a, const float* P, int Hp, const int* exps,
+__device__ __forceinline__ void wave_spectrum_outputs(const MelspecArgs& a, const float* P, int Hp, int sc,
                                                       const aud_item& it, int item, int t0, int lane) {
     if (!a.power && !a.log_power) return;
     // a lane keeps ONE frame (lane % FPW) and walks the bins k = lane / FPW, + 64 / FPW, ...: step, liveness and the output
@@ -511,8 +528,6 @@ __device__ __forceinline__ void wave_spectrum_outputs(const MelspecArgs& a, cons
     const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
     const bool col_on = has && sstep < T;
     const bool live = start + a.N <= int64_t(it.sig_len);
-    int sc = 0;
-    if constexpr (sizeof(TT) == 8) sc = frame_scale_of(exps + ff);
     const float* prow = P + ff * Hp;
     size_t o = (size_t(item) * H + g) * T + (col_on ? sstep : 0);
     const size_t ostep = size_t(G) * T;
@@ -546,9 +561,9 @@ __device__ __forceinline__ void wave_spectrum_outputs(const MelspecArgs& a, cons
 
 template <typename TT, int FPW, int MAXS, bool COMPACT = false>
 __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const WaveArgs& e, const float* P, int Hp,
-                                                  const unsigned char* smem, const int* exps, const aud_item& it,
+                                                  const unsigned char* smem, int sc, const aud_item& it,
                                                   int item, int t0, int lane) {
-    wave_spectrum_outputs<TT, FPW>(a, P, Hp, exps, it, item, t0, lane);
+    wave_spectrum_outputs<TT, FPW>(a, P, Hp, sc, it, item, t0, lane);
     // 64 is not a multiple of FPW = 6: lanes 60..63 have no filter group; they run group n_groups - 1 again and store nothing
     const int T = a.T;
     const int ff = lane % FPW, g0 = lane / FPW;
@@ -558,8 +573,6 @@ __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const Wa
     const bool col_on = has && sstep < T;
     const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
     const bool live = col_on && start + a.N <= int64_t(it.sig_len);
-    int sc = 0;
-    if constexpr (sizeof(TT) == 8) sc = frame_scale_of(exps + ff);
     // COMPACT (one filter group per lane, w64x16): a filter's row holds only its own chunks, steps past its end read the
     // table's shared zero chunk; otherwise every group's row has the slot's full length
     const Q4a<float>* wrow = reinterpret_cast<const Q4a<float>*>(smem + e.w4_off + (COMPACT ? 0 : grp * e.w_stride));

@@ -26,19 +26,29 @@ constexpr int kRow = 68;           // transpose rows: 64 (= 16 x 4) elements + 4
 constexpr int kPlane = 16 * kRow;  // 1088 elements, also holds the power row
 template <typename TT>
 struct Layout {
-    static constexpr int kExpOff = kPlane * int(sizeof(TT));
-    static constexpr int kRegion = kExpOff + 16;  // bytes per wave
+    static constexpr int kRegion = kPlane * int(sizeof(TT));  // bytes per wave
 };
 }  // namespace w64
 
 namespace {
 
+// the operands of frame `wt` (one frame per wave tile): requested into `raw`, nothing awaited
+template <int SRC>
+__device__ __forceinline__ void w64_issue(const MelspecArgs& a, int lane, int64_t wt, PairRaw<16>& raw) {
+    const int item = int(wt / a.T);
+    const int sstep = int(wt - int64_t(item) * a.T);
+    const aud_item it = a.items[item];
+    const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
+    const SampleWindow<SRC> win = sample_window<SRC>(a, it, start, w64::kN);
+    pairs_issue<SRC, 16, 64>(win, start + 2 * lane, raw);
+}
+
+// One frame.  `raw` holds its operands (w64_issue); the NEXT frame's are requested into it before this frame's epilogue
+// (the load phase was 38 % of a wave's life without it: profiles/r05e_stamps_n46.44_f64_b64.txt).
 template <typename TT, int SRC, int MAXS>
 __device__ __forceinline__ void w64_tile(const MelspecArgs& a, const WaveArgs& e, unsigned char* smem, unsigned char* region,
-                                         int lane_in, int64_t wt) {
-    using L = w64::Layout<TT>;
+                                         int lane_in, int64_t wt, bool more, PairRaw<16>& raw) {
     TT* xw = reinterpret_cast<TT*>(region);
-    int* exps = reinterpret_cast<int*>(region + L::kExpOff);
     int lane = lane_in;  // opaque per frame: otherwise the compiler hoists what only depends on it out of the frame loop
     asm volatile("" : "+v"(lane));
     const int item = int(wt / a.T);
@@ -49,15 +59,14 @@ __device__ __forceinline__ void w64_tile(const MelspecArgs& a, const WaveArgs& e
     AUD_STAMP_REAL(9);
     C2<TT> v[16];
     TT amax;
-    {
-        const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
-        const SampleWindow<SRC> win = sample_window<SRC>(a, it, start, w64::kN);
-        const int64_t pos0 = start + 2 * lane;
-        PairRaw<16> raw;
-        pairs_issue<SRC, 16, 64>(win, pos0, raw);
-        pairs_take<TT, SRC, 16, 64>(a, it, pos0, true, raw, v, amax);
+    if constexpr (sizeof(TT) == 4) w64_issue<SRC>(a, lane, wt, raw);  // (float32 plans: no prefetch, see below)
+    pairs_take<TT, SRC, 16, 64>(a, it, int64_t(it.start0) + int64_t(a.S) * (sstep - a.border) + 2 * lane, true, raw, v, amax);
+    // the frame is the whole wave: its scale is a wave-wide maximum (six data-parallel moves, no LDS)
+    int sc = 0;
+    if constexpr (sizeof(TT) == 8) {
+        const int ex = wave_max_i32(amax_exponent<TT>(amax));
+        sc = ex == kNoSignal ? 0 : 2 * ex;
     }
-    const int sc = frame_scale<TT>(exps, amax);
     AUD_STAMP(3);
 
     // ---- pass 1 ------------------------------------------------------------------------------------------------
@@ -192,7 +201,12 @@ __device__ __forceinline__ void w64_tile(const MelspecArgs& a, const WaveArgs& e
     }
     wave_lds_fence();
     AUD_STAMP(7);
-    wave_mel_epilogue<TT, 1, MAXS, true>(a, e, P, w64::kHp, smem, exps, it, item, sstep, lane);
+    // the next frame's operands land during the epilogue (a fifth of the frame's time); requested here, not at the top,
+    // because the FFT passes are where the registers run out.  float64 plans only: their three waves per SIMD leave the
+    // 32 registers free, in float32 plans they would cost a wave per SIMD
+    if constexpr (sizeof(TT) == 8)
+        if (more) w64_issue<SRC>(a, lane, wt + 1, raw);
+    wave_mel_epilogue<TT, 1, MAXS, true>(a, e, P, w64::kHp, smem, sc, it, item, sstep, lane);
     AUD_STAMP(8);
     AUD_STAMP_REAL(10);
     AUD_STAMP_FLUSH(a, wt, lane);
@@ -214,9 +228,13 @@ __global__ __launch_bounds__(64 * NW) void k_melspec_w64(const MelspecArgs a, co
     const int64_t total = int64_t(a.n_items) * a.T;  // one frame per wave tile
     const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
     const int64_t wt0 = (int64_t(wg) * NW + wave) * w64::kFPW;
+    PairRaw<16> raw;
+    if constexpr (sizeof(TT) == 8)
+        if (wt0 < total) w64_issue<SRC>(a, lane, wt0, raw);
 #pragma unroll 1
     for (int i = 0; i < w64::kFPW; ++i)
-        if (wt0 + i < total) w64_tile<TT, SRC, MAXS>(a, e, smem, region, lane, wt0 + i);
+        if (wt0 + i < total)
+            w64_tile<TT, SRC, MAXS>(a, e, smem, region, lane, wt0 + i, i + 1 < w64::kFPW && wt0 + i + 1 < total, raw);
 }
 
 }  // namespace

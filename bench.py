@@ -1,37 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- audio-seconds/sec of the frame -> FFT -> power -> mel hot path on MI355X.
+"""bench.py -- audio-seconds/sec of the frame -> FFT -> power -> mel (-> gabor) hot path on MI355X.
 
-Headline workload = the metric's own parameter set on BASELINE.json configs[1]'s batch: 256 synthetic 16 kHz mono
-utterances of 1 s per GPU and step, WinMs 25 (N = 400, no taper), StepMs 10 (S = 160), one segment per utterance with
-BorderSteps 2 (T = 104 frames), 40 mel filters 0-8000 Hz, mel output only.  configs[1]'s "512-pt FFT" variant (WinMs 32)
-is measured in the same run and nested under "also".  A step = one launch of the fused kernel over one resident batch;
-consecutive steps walk a ring of resident batches larger than the 256 MB Infinity Cache, so the input really comes
-from HBM.
+One GPU (`python bench.py`): the headline is the metric's own parameter set on BASELINE.json configs[1]'s batch: 256
+synthetic 16 kHz mono utterances of 1 s per step, WinMs 25 (N = 400, no taper), StepMs 10 (S = 160), one segment per
+utterance with BorderSteps 2 (T = 104 frames), 40 mel filters 0-8000 Hz, mel output only, float64 arithmetic (the
+reference's).  A step = one launch of the fused kernel over one resident batch; consecutive steps walk a ring of resident
+batches larger than the 256 MB Infinity Cache, so the input really comes from HBM.  The other BASELINE configurations are
+measured in the same run and nested under `also`, each with its own strict parity object: configs[1] as worded (WinMs 32,
+N = 512), configs[2] on one GPU (4096 utterances per step), configs[3] (+ agabor.Convolve) and configs[4] (44.1 kHz 5 s
+streams, N = 2048, 128 mel, 1.13 GB per batch); the float32 instantiations are under `modes`.
 
-Headline dtype is float64: the reference computes in float64 and BASELINE.json asks for 1e-5 relative on the float32
-tensors; the float32 instantiation misses that bound on a few elements per million, so it is measured
-and reported beside the headline ("modes"), never as `value`.  Every mode carries a `parity` object: the timed
-outputs of several ring buffers checked against the oracle under the strict criterion |d| <= 1e-5 max(1, |ref|); a
-headline mode with an element past it makes the run exit non-zero without a JSON line.
+Several GPUs (`python -m torch.distributed.run --nnodes=1 --nproc-per-node G --master-addr 127.0.0.1 --master-port P
+bench.py --gpus G --steps K --warmup W`, one rank per GPU): `value` is BASELINE configs[2] AS STATED -- 4096 utterances per
+step in total, a contiguous shard of 4096 / G per rank (auditory_amd.batch.shard_range), and the path's one collective,
+the RCCL all-gather that reassembles the [4096, 40, 104] float32 feature tensor on every rank, issued on a second stream
+and overlapped with the next step's kernel; strong scaling.  Rank 0 checks the GATHERED tensor against the oracle.  The
+collective-free sharded step (256 utterances per rank) is reported beside it as `no_collective`.
 
-The K steps asked for are captured into one hipGraph (a ~20 us kernel is otherwise bound by the Python launch path) --
-repeated inside the graph until it holds at least --graph-steps (200) steps, so that the fork / join of the streams at
-the ends of a replay is not what is timed -- and that graph is replayed back to back until at least --min-seconds of
-device time have passed; `steps` in the JSON line is the number of steps actually timed (graph steps x repeats),
-bracketed by a barrier + synchronize on both sides, max over ranks.
-Inside the graph consecutive steps alternate between two streams (--streams 2, the default): the steps are independent
-batches with their own output buffers, and a launch of 256 utterances is a burst of 1.5 rounds of resident waves whose
-load phase and tail leave the chip half idle -- overlapping step i+1's start with step i's tail is what a double-buffered
-pipeline does (27.1 -> 16.3 us per step).  `roofline` is priced on the kernel ALONE (a one-stream region of the same run).
+Every timed region is captured into one hipGraph (a ~12 us kernel is otherwise bound by the Python launch path) --
+the K steps asked for, repeated until the graph holds at least --graph-steps steps, so that the fork / join of the
+streams at the ends of a replay is not what is timed -- and replayed back to back until at least --min-seconds of device
+time have passed; `steps` is the number of steps actually timed, bracketed by a barrier + synchronize on both sides,
+max over ranks.  Inside a graph consecutive steps alternate between two streams (independent batches with their own
+output buffers): a launch of 256 utterances is a burst of little more than one round of resident waves whose load phase
+and tail leave the chip half idle, and overlapping step i+1's start with step i's tail is what a double-buffered pipeline
+does.  `roofline` is priced on the kernel ALONE (a one-stream region of the same run).
 
-  python bench.py                                    # 1 GPU
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
-         bench.py --gpus N --steps K --warmup W      # one rank per GPU, RCCL
-
-Multi-GPU: utterances are sharded in contiguous blocks (auditory_amd.batch.shard_range), `value` is the sharded step
-with no collective in it (weak scaling, 256 utterances per rank); "with_allgather" repeats the steps with the path's one
-collective -- the RCCL all-gather that reassembles the [B, 40, 104] feature tensor on every rank -- overlapped on a
-second stream, and "cfg3" is BASELINE configs[2] as stated: 4096 utterances in total, 4096 / G per rank.
+Every mode carries a `parity` object: timed outputs checked against the oracle under |d| <= 1e-5 max(1, |ref|) on every
+element; a headline mode with an element past it makes the run exit non-zero without a JSON line.
 """
 import argparse
 import json
@@ -51,7 +47,7 @@ memguard.install()
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 METRIC = "audio-seconds/sec (16 kHz, 25 ms/10 ms, 40 mel) at 1/2/4/8 MI355X"
-TOL = 1e-5              # BASELINE.json north_star: 1e-5 relative on the float32 mel tensor
+TOL = 1e-5              # BASELINE.json north_star: 1e-5 relative on the float32 mel / gabor tensors
 
 # name: sample rate, WinMs, StepMs, SegmentMs (= StrideMs), BorderSteps, mel filters, LoHz, HiHz, seconds of audio per stream
 WORKLOADS = {
@@ -64,6 +60,7 @@ WORKLOADS = {
 }
 GABOR_SPECS = [dict(WaveLen=2.0, Orientation=o, SigmaWidth=0.5, SigmaLength=0.5, PhaseOffset=ph, CircleEdge=True)
                for o in (0, 45, 90, 135) for ph in (0, 1.5708)]        # processspeech.go:236-252
+GABOR_POOLS = (11, 32)                                                 # [PoolsY, PoolsX] of the [.., 2, 8] output
 
 
 class Workload:
@@ -127,13 +124,19 @@ class OracleSide:
         assert (self.sp.win_samples, self.sp.step_samples, self.sp.segment_steps) == (wl.N, wl.S, wl.T), \
             "product and oracle derive different geometry"
 
-    def mel(self, rows64):
-        """[n, L] float64 rows -> [n, nf, T] oracle mel"""
+    def mel(self, rows64, gabor=False):
+        """[n, L] float64 rows -> [n, nf, T] oracle mel (and the [n, 11, 32, 2, 8] gabor tensor of the oracle's mel)"""
         n, L = rows64.shape
-        rc, mel, _ = self.orc.process_batch(self.sp, self.d, self.m, self.bins, self.filt, rows64.reshape(-1),
-                                            np.arange(n) * L, np.full(n, L), np.zeros(n))
+        g = None
+        if gabor:
+            g = dict(k=self.orc.gabor_to_tensor([dict(wave_len=s["WaveLen"], orientation=s["Orientation"],
+                                                      sigma_width=s["SigmaWidth"], sigma_length=s["SigmaLength"],
+                                                      phase_offset=s["PhaseOffset"], circle_edge=1) for s in GABOR_SPECS], 9, 9),
+                     stride_x=3, stride_y=3, gain=2.0, py=GABOR_POOLS[0], px=GABOR_POOLS[1])
+        rc, mel, gab = self.orc.process_batch(self.sp, self.d, self.m, self.bins, self.filt, rows64.reshape(-1),
+                                              np.arange(n) * L, np.full(n, L), np.zeros(n), gabor=g)
         assert rc == 0
-        return mel
+        return (mel, gab) if gabor else mel
 
 
 def cpu_baseline(wl, pcm, target_s=12.0, max_threads=16, chunk=8):
@@ -202,13 +205,16 @@ def strict_parity(got, ref):
 class Ring:
     """R resident batches of B streams each ([B, L] float32 or int16 on the device) + their outputs"""
 
-    def __init__(self, torch, wl, B, R, rank, dev, sig_dtype, need_bytes=None, stereo=False):
+    def __init__(self, torch, wl, B, R, rank, dev, sig_dtype, stereo=False, distinct=None):
         from auditory_amd import runtime, synth
         self.B, self.R, self.wl = B, R, wl
         assert not stereo or B % 2 == 0
-        self.pcm = np.zeros((R * B, wl.L), np.int16)                  # host copy (parity / cpu_baseline), 2 B per sample
-        for i in range(R * B):
-            self.pcm[i, :wl.dur] = synth.utterance_pcm(2, rank * R * B + i, wl.dur, wl.sr)
+        n_rows = R * B
+        distinct = min(n_rows, distinct or n_rows)                    # long streams: `distinct` seeded streams, repeated
+        base = np.zeros((distinct, wl.L), np.int16)                   # host copy (parity / cpu_baseline), 2 B per sample
+        for i in range(distinct):
+            base[i, :wl.dur] = synth.utterance_pcm(2, rank * n_rows + i, wl.dur, wl.sr)
+        self.pcm = base if distinct == n_rows else base[np.arange(n_rows) % distinct]
         self.sig = []
         for r in range(R):
             blk = self.pcm[r * B:(r + 1) * B]
@@ -238,12 +244,12 @@ def main():  # noqa: C901
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
     ap.add_argument("--workload", choices=["headline", "cfg4", "cfg5", "cfg1", "sndenv"], default="headline",
-                    help="headline: the judged line (N = 400, with the N = 512 variant under `also`).  Secondary lines for "
-                         "BASELINE.md's table: cfg4 = headline + agabor.Convolve (default FilterSet, [11,32,2,8] pools); "
-                         "cfg5 = 44.1 kHz 5 s streams, N = 2048, 128 mel (use --batch 1280 for >= 1 GB resident input); "
-                         "sndenv = the headline parameters with everything the unmodified SndEnv.ProcessSegment loop produces "
-                         "(SURVEY 8 f-1 + f-2): mel + Power + LogPower tensors + the MFCC tail (13 coefficients, deltas, "
-                         "delta-deltas, Energy)")
+                    help="headline: the judged line (N = 400; the other BASELINE configurations nested under `also`).  "
+                         "Stand-alone lines for BASELINE.md's table: cfg4 = headline + agabor.Convolve (default FilterSet, "
+                         "[11,32,2,8] pools); cfg5 = 44.1 kHz 5 s streams, N = 2048, 128 mel (use --batch 1280 for >= 1 GB "
+                         "resident input); cfg1 = configs[0]'s parameters (N = 1103, prime); sndenv = the headline parameters "
+                         "with everything the unmodified SndEnv.ProcessSegment loop produces (SURVEY 8 f-1 + f-2): mel + Power "
+                         "+ LogPower tensors + the MFCC tail (13 coefficients, deltas, delta-deltas, Energy)")
     ap.add_argument("--compute", choices=["f64", "f32"], default="f64", help="arithmetic of the headline mode")
     ap.add_argument("--sig-dtype", choices=["f32", "i16"], default="f32",
                     help="resident sample format: float32 (the metric's definition) or int16 PCM normalised on the device "
@@ -252,7 +258,8 @@ def main():  # noqa: C901
                     help="the resident streams are the channels of interleaved stereo clips (BASELINE configs[4] as worded): "
                          "two strided work items per clip over one buffer, no de-interleaving copy")
     ap.add_argument("--ring-mb", type=float, default=320.0, help="resident input ring per GPU (> the 256 MB Infinity Cache)")
-    ap.add_argument("--min-seconds", type=float, default=0.5, help="minimum device time of a timed region")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="minimum device time of the headline's timed regions")
+    ap.add_argument("--also-seconds", type=float, default=0.15, help="the same for the modes under `also` / `modes`")
     ap.add_argument("--launch", choices=["graph", "eager"], default="graph")
     ap.add_argument("--graph-steps", type=int, default=200,
                     help="steps one captured hipGraph holds: the requested --steps repeated until at least this many, so "
@@ -260,25 +267,25 @@ def main():  # noqa: C901
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the steps are dealt over round-robin inside the graph (independent resident batches, "
                          "own output buffers): 1 = every step waits for the previous one; 2 (default) = consecutive launches "
-                         "overlap their load burst with the previous launch's tail, as a double-buffered pipeline does "
-                         "(measured 27.1 -> 16.3 us per step; 3 and 4 add nothing).  Default for --workload cfg4: 4 -- a step is "
-                         "two dependent launches there and the short gabor launch fills the chip badly (measured 25.4 us per "
-                         "step on 2 streams, 19.8 on 3, 19.4 on 4).  `roofline` is always taken from a 1-stream region: one "
-                         "kernel alone on the chip, the duration rocprofv3 reports")
+                         "overlap their load burst with the previous launch's tail, as a double-buffered pipeline does.  Default "
+                         "for cfg4 / sndenv: 4 -- a step is two dependent launches there.  `roofline` is always taken from a "
+                         "1-stream region: one kernel alone on the chip, the duration rocprofv3 reports")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
-                    help="aud_plan_set_option switches for A/B runs, e.g. kernel=2 (workgroup-tile family) or kernel=1 (generic)")
+                    help="aud_plan_set_option switches, e.g. kernel=1 (the generic kernel)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for CPU dry runs)")
-    ap.add_argument("--only-headline", action="store_true", help="skip the float32 / N = 512 modes and the cfg3 region")
+    ap.add_argument("--dist-single", action="store_true",
+                    help="validation only: run the multi-GPU code path (shard + RCCL all-gather inside the graph) on ONE rank")
+    ap.add_argument("--only-headline", action="store_true", help="skip `modes` and `also`")
     ap.add_argument("--cfg3-total", type=int, default=4096, help="total utterances of the configs[2] region (CPU dry runs shrink it)")
+    ap.add_argument("--cfg5-batch", type=int, default=1280, help="streams per step of the configs[4] region (1280 x 5 s = 1.13 GB)")
     ap.add_argument("--report-anyway", action="store_true",
-                    help="secondary rows only: print the line (with parity.pass = false) when the mode misses the criterion")
+                    help="stand-alone secondary rows only: print the line (with parity.pass = false) when the mode misses the criterion")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-allgather", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from auditory_amd import capi
+    from auditory_amd import capi, runtime
     from auditory_amd.batch import allgather_features, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -289,18 +296,16 @@ def main():  # noqa: C901
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.dist_single
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
-    if args.streams <= 0:
-        args.streams = 4 if args.workload in ("cfg4", "sndenv") else 2
     B, K = args.batch, max(1, args.steps)
     sig_code = capi.AUD_I16 if args.sig_dtype == "i16" else capi.AUD_F32
-    gabor = args.workload == "cfg4"
-    full = args.workload == "sndenv"
 
     def sync_all():
         if world > 1:
@@ -314,50 +319,28 @@ def main():  # noqa: C901
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def upload_items(n, L):
+        it = runtime.make_items(np.arange(n) * L, [L] * n, [0] * n)
+        return torch.from_numpy(np.frombuffer(np.ascontiguousarray(it).tobytes(), np.uint8).copy()).to(dev)
+
     rings = {}
 
-    def ring_for(wl):
-        if wl.name not in rings:
-            per_batch = B * wl.L * (2 if args.sig_dtype == "i16" else 4)
+    def ring_for(wl, nb=None):
+        nb = nb or B
+        key = (wl.name, nb)
+        if key not in rings:
+            per_batch = nb * wl.L * (2 if args.sig_dtype == "i16" else 4)
             R = max(2, int(math.ceil(args.ring_mb * 1e6 / per_batch)))
-            rings[wl.name] = Ring(torch, wl, B, R, rank, dev, args.sig_dtype, stereo=args.stereo)
-        return rings[wl.name]
+            rings[key] = Ring(torch, wl, nb, R, rank, dev, args.sig_dtype, stereo=args.stereo,
+                              distinct=64 if wl.dur_s > 1.0 else None)
+        return rings[key]
 
-    def time_mode(wl, compute, check=True, n_streams=None):
-        """one timed region of K x repeats steps of the fused kernel; returns the per-mode result dict"""
-        n_streams = max(1, n_streams or args.streams)
+    cur = lambda: torch.cuda.current_stream(dev).cuda_stream  # noqa: E731
+
+    def timed_region(launch, n_streams, min_seconds, audio_s_per_step):
+        """K x repeats steps of launch(i, stream handle); the steps dealt over n_streams streams inside one hipGraph"""
+        n_streams = max(1, n_streams)
         side = [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
-        ring = ring_for(wl)
-        plan = wl.plan(compute, local_rank, gabor=gabor, mfcc=13 if full else 0)
-        for kv in args.option:
-            k, v = kv.split("=")
-            plan.set_option(k, int(v))
-        lib, ph = plan.lib, plan.handle
-        gout = [torch.zeros((B, 11, 32, 2, 8), dtype=torch.float32, device=dev) for _ in range(ring.R)] if gabor else None
-        if full:  # Power / LogPower [B, H, T] and the MFCC tensors: four rotating sets (a stream reuses a set four steps later)
-            f32buf = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
-            sets = [dict(pw=f32buf(B, wl.H, wl.T), lp=f32buf(B, wl.H, wl.T), mfcc=f32buf(B, 13, wl.T), d1=f32buf(B, 13, wl.T),
-                         d2=f32buf(B, 13, wl.T), en=f32buf(B, wl.T)) for _ in range(4)]
-
-        def launch(i, st):
-            r = i % ring.R
-            if gabor:
-                rc = lib.aud_process_batch_dev(ph, ring.sig[r].data_ptr(), sig_code, ring.items.data_ptr(), B,
-                                               ring.mel[r].data_ptr(), 11, 32, gout[r].data_ptr(), st)
-            elif full:
-                o = sets[i % 4]
-                rc = lib.aud_melspec_batch_dev(ph, ring.sig[r].data_ptr(), sig_code, ring.items.data_ptr(), B,
-                                               ring.mel[r].data_ptr(), o["pw"].data_ptr(), o["lp"].data_ptr(), st)
-                if rc == 0:
-                    rc = lib.aud_mfcc_batch_dev(ph, ring.items.data_ptr(), B, ring.mel[r].data_ptr(), o["lp"].data_ptr(),
-                                                o["mfcc"].data_ptr(), o["d1"].data_ptr(), o["d2"].data_ptr(), o["en"].data_ptr(), st)
-            else:
-                rc = lib.aud_melspec_batch_dev(ph, ring.sig[r].data_ptr(), sig_code, ring.items.data_ptr(), B,
-                                               ring.mel[r].data_ptr(), None, None, st)
-            if rc != 0:
-                raise RuntimeError("hot path launch: %d %s" % (rc, lib.aud_last_error(plan.ctx.handle)))
-
-        cur = lambda: torch.cuda.current_stream(dev).cuda_stream  # noqa: E731
         GK = K * max(1, -(-args.graph_steps // K)) if args.launch == "graph" else K   # steps per replay: a multiple of K
         for i in range(args.warmup):
             launch(i, cur())
@@ -367,14 +350,15 @@ def main():  # noqa: C901
             try:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    main = torch.cuda.current_stream(dev)
+                    main_s = torch.cuda.current_stream(dev)
                     for sst in side:
-                        sst.wait_stream(main)
-                    lanes = [main] + side
+                        sst.wait_stream(main_s)
+                    lanes = [main_s] + side
                     for i in range(GK):
-                        launch(i, lanes[i % n_streams].cuda_stream)
+                        with torch.cuda.stream(lanes[i % n_streams]):
+                            launch(i, lanes[i % n_streams].cuda_stream)
                     for sst in side:
-                        main.wait_stream(sst)
+                        main_s.wait_stream(sst)
                 graph.replay()
                 torch.cuda.synchronize(dev)
                 launch_mode = "hipGraph of %d steps" % GK + (" (%d x the %d requested)" % (GK // K, K) if GK != K else "")
@@ -391,14 +375,14 @@ def main():  # noqa: C901
                 for i in range(GK):
                     launch(i, cur())
 
-        # calibrate the number of replays: >= --min-seconds of device time, the same count on every rank
+        # calibrate the number of replays: >= min_seconds of device time, the same count on every rank
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         replay()
         e1.record()
         torch.cuda.synchronize(dev)
         one = max(1e-6, e0.elapsed_time(e1) * 1e-3)
-        reps = int(max_over_ranks(float(min(20000, max(1, math.ceil(args.min_seconds / one))))))
+        reps = int(max_over_ranks(float(min(20000, max(1, math.ceil(min_seconds / one))))))
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
         sync_all()
         t0 = time.perf_counter()
@@ -410,149 +394,209 @@ def main():  # noqa: C901
         elapsed = max_over_ranks(time.perf_counter() - t0)
         per_step_us = np.array([evs[r].elapsed_time(evs[r + 1]) for r in range(reps)]) * 1e3 / GK
         steps = GK * reps
-        audio_s = B * world * wl.dur_s
-        alg = B * (ring.sample_bytes * wl.dur + 4 * wl.nf * wl.T)       # each sample read once + each mel value written once
-        if gabor:  # unfused gabor: re-read the mel tensor, write the pooled on/off pairs
-            alg += B * (4 * wl.nf * wl.T + 4 * 11 * 32 * 2 * 8)
-        if full:   # Power + LogPower written, mel + LogPower re-read by the MFCC tail, its four small tensors written
-            alg += B * (2 * 4 * wl.H * wl.T + 4 * wl.nf * wl.T + 4 * wl.H * wl.T + 4 * (3 * 13 + 1) * wl.T)
         mean_us = float(per_step_us.mean())
-        res = {"workload": wl.name, "compute": compute, "kernel": plan.kernel_name, "launch": launch_mode, "streams": n_streams,
-               "value": round(audio_s * steps / elapsed, 1), "steps": steps, "repeats": reps,
-               "ms_per_step": round(1e3 * elapsed / steps, 5),
-               "us_per_step_device": {"mean": round(mean_us, 3), "median": round(float(np.median(per_step_us)), 3),
-                                      "p10": round(float(np.percentile(per_step_us, 10)), 3),
-                                      "p90": round(float(np.percentile(per_step_us, 90)), 3)},
-               "ring": {"buffers": ring.R, "input_MB": round(ring.R * B * wl.L * ring.sample_bytes / 1e6, 1)},
-               "algorithmic_bytes_per_launch": alg,
-               "achieved_GBps": round(alg / (mean_us * 1e-6) / 1e9, 2)}
-        if check and rank == 0:
-            # parity of the TIMED outputs: all of ring buffer 0, plus 16 streams of two other buffers
-            osd = OracleSide(wl)
-            touched = min(ring.R, GK)                                  # ring buffers the timed steps wrote
-            n0 = min(B, 256 if wl.dur_s <= 1.0 else 24)                 # long streams: a smaller sample (the oracle is ~150 audio-s/s)
-            picks = [(0, np.arange(n0))] + [(r, np.arange(0, B, max(1, B // 16))[:16 if wl.dur_s <= 1.0 else 4])
-                                            for r in sorted({touched // 2, touched - 1} - {0})]
-            got = np.concatenate([ring.mel[r].cpu().numpy()[idx] for r, idx in picks])
+        return {"launch": launch_mode, "streams": n_streams, "value": round(audio_s_per_step * steps / elapsed, 1),
+                "steps": steps, "repeats": reps, "graph_steps": GK, "ms_per_step": round(1e3 * elapsed / steps, 5),
+                "us_per_step_device": {"mean": round(mean_us, 3), "median": round(float(np.median(per_step_us)), 3),
+                                       "p10": round(float(np.percentile(per_step_us, 10)), 3),
+                                       "p90": round(float(np.percentile(per_step_us, 90)), 3)}}
+
+    def check_ring(wl, ring, touched, gout=None):
+        """parity of the TIMED outputs: the first streams of ring buffer 0, plus a few streams of two other buffers"""
+        osd = OracleSide(wl)
+        nb = ring.B
+        n0 = min(nb, 256 if wl.dur_s <= 1.0 else 8)                  # long streams: a smaller sample (the oracle is ~150 audio-s/s)
+        picks = [(0, np.arange(n0))] + [(r, np.arange(0, nb, max(1, nb // 16))[:16 if wl.dur_s <= 1.0 else 2])
+                                        for r in sorted({touched // 2, touched - 1} - {0})]
+        got = np.concatenate([ring.mel[r].cpu().numpy()[idx] for r, idx in picks])
+        if gout is None:
             ref = np.concatenate([osd.mel(ring.host_rows64(r, idx)) for r, idx in picks])
-            res["parity"] = strict_parity(got, ref)
-            res["parity"]["checked"] = "first %d streams of ring buffer 0 + %d streams each of buffers %s" % (
-                n0, len(picks[1][1]) if len(picks) > 1 else 0, [r for r, _ in picks[1:]])
+            par = strict_parity(got, ref)
+        else:
+            refs = [osd.mel(ring.host_rows64(r, idx), gabor=True) for r, idx in picks]
+            par = strict_parity(got, np.concatenate([m for m, _ in refs]))
+            par["gabor"] = strict_parity(np.concatenate([gout[r].cpu().numpy()[idx] for r, idx in picks]),
+                                         np.concatenate([g for _, g in refs]))
+            par["pass"] = bool(par["pass"] and par["gabor"]["pass"])
+        par["checked"] = "first %d streams of ring buffer 0 + %d streams each of buffers %s" % (
+            n0, len(picks[1][1]) if len(picks) > 1 else 0, [r for r, _ in picks[1:]])
+        return par
+
+    def time_mode(wl, compute, kind="mel", check=True, n_streams=None, nb=None, min_seconds=None):
+        """one timed region of the fused kernel on workload wl; kind: mel | gabor (configs[3]) | full (the SndEnv loop)"""
+        nb = nb or B
+        n_streams = n_streams or (args.streams if args.streams > 0 else (4 if kind in ("gabor", "full") else 2))
+        ring = ring_for(wl, nb)
+        gabor, full = kind == "gabor", kind == "full"
+        plan = wl.plan(compute, local_rank, gabor=gabor, mfcc=13 if full else 0)
+        for kv in args.option:
+            k, v = kv.split("=")
+            plan.set_option(k, int(v))
+        lib, ph = plan.lib, plan.handle
+        gout = [torch.zeros((nb,) + GABOR_POOLS + (2, 8), dtype=torch.float32, device=dev) for _ in range(ring.R)] if gabor else None
+        if full:  # Power / LogPower [B, H, T] and the MFCC tensors: four rotating sets (a stream reuses a set four steps later)
+            f32buf = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
+            sets = [dict(pw=f32buf(nb, wl.H, wl.T), lp=f32buf(nb, wl.H, wl.T), mfcc=f32buf(nb, 13, wl.T), d1=f32buf(nb, 13, wl.T),
+                         d2=f32buf(nb, 13, wl.T), en=f32buf(nb, wl.T)) for _ in range(4)]
+
+        def launch(i, st):
+            r = i % ring.R
+            if gabor:
+                rc = lib.aud_process_batch_dev(ph, ring.sig[r].data_ptr(), sig_code, ring.items.data_ptr(), nb,
+                                               ring.mel[r].data_ptr(), GABOR_POOLS[0], GABOR_POOLS[1], gout[r].data_ptr(), st)
+            elif full:
+                o = sets[i % 4]
+                rc = lib.aud_melspec_batch_dev(ph, ring.sig[r].data_ptr(), sig_code, ring.items.data_ptr(), nb,
+                                               ring.mel[r].data_ptr(), o["pw"].data_ptr(), o["lp"].data_ptr(), st)
+                if rc == 0:
+                    rc = lib.aud_mfcc_batch_dev(ph, ring.items.data_ptr(), nb, ring.mel[r].data_ptr(), o["lp"].data_ptr(),
+                                                o["mfcc"].data_ptr(), o["d1"].data_ptr(), o["d2"].data_ptr(), o["en"].data_ptr(), st)
+            else:
+                rc = lib.aud_melspec_batch_dev(ph, ring.sig[r].data_ptr(), sig_code, ring.items.data_ptr(), nb,
+                                               ring.mel[r].data_ptr(), None, None, st)
+            if rc != 0:
+                raise RuntimeError("hot path launch: %d %s" % (rc, lib.aud_last_error(plan.ctx.handle)))
+
+        res = timed_region(launch, n_streams, args.min_seconds if min_seconds is None else min_seconds,
+                           nb * world * wl.dur_s)
+        alg = nb * (ring.sample_bytes * wl.dur + 4 * wl.nf * wl.T)      # each sample read once + each mel value written once
+        if gabor:  # unfused gabor: re-read the mel tensor, write the pooled on/off pairs
+            alg += nb * (4 * wl.nf * wl.T + 4 * GABOR_POOLS[0] * GABOR_POOLS[1] * 2 * 8)
+        if full:   # Power + LogPower written, mel + LogPower re-read by the MFCC tail, its four small tensors written
+            alg += nb * (2 * 4 * wl.H * wl.T + 4 * wl.nf * wl.T + 4 * wl.H * wl.T + 4 * (3 * 13 + 1) * wl.T)
+        res.update({"workload": wl.name, "compute": compute, "kernel": plan.kernel_name, "batch": nb,
+                    "ring": {"buffers": ring.R, "input_MB": round(ring.R * nb * wl.L * ring.sample_bytes / 1e6, 1)},
+                    "algorithmic_bytes_per_launch": alg,
+                    "achieved_GBps": round(alg / (res["us_per_step_device"]["mean"] * 1e-6) / 1e9, 2)})
+        res["frac_of_hbm_peak"] = round(res["achieved_GBps"] / HBM_PEAK_GBPS, 5)
+        if check and rank == 0:
+            res["parity"] = check_ring(wl, ring, min(ring.R, res["graph_steps"]), gout)
+        plan.close()
+        return res
+
+    def cfg3_region(wl, compute, total, min_seconds):
+        """BASELINE configs[2] as stated: `total` utterances per step, this rank's contiguous shard through the kernel, then
+        (several ranks) the RCCL all-gather of its [nb, nf, T] slab on a second stream while the next step's kernel runs;
+        two output slabs alternate, a kernel waits for the gather that last read its slab.  One rank: nothing to gather."""
+        ring = ring_for(wl)
+        lo, hi = shard_range(total, rank, world)
+        nb = hi - lo
+        reps3 = (nb + B - 1) // B
+        # this rank's shard of the batch: ring buffers back to back (rank-seeded streams); two input copies so that
+        # consecutive steps do not read the same HBM lines
+        bufs = [[(r + o * reps3) % ring.R for r in range(reps3)] for o in (0, 1)]
+        sig3 = [torch.cat([ring.sig[b] for b in bl])[:nb * wl.L].contiguous() for bl in bufs]
+        ring_row = [np.concatenate([np.arange(B) + b * B for b in bl])[:nb] for bl in bufs]   # shard row -> row of the ring
+        items3 = upload_items(nb, wl.L)
+        mel3 = [torch.empty((nb, wl.nf, wl.T), dtype=torch.float32, device=dev) for _ in range(2)]
+        plan = wl.plan(compute, local_rank)
+        lib, ph = plan.lib, plan.handle
+        gather = world > 1 or args.dist_single
+        use_streams = gather and args.dist_backend == "nccl"
+        comm = torch.cuda.Stream(dev) if use_streams else None
+        full = [torch.empty((total,) + tuple(mel3[0].shape[1:]), dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
+        even = total % world == 0
+        done = [None, None]
+
+        def launch(i, st):
+            s = i % 2
+            if use_streams and done[s] is not None:
+                torch.cuda.current_stream(dev).wait_event(done[s])
+            rc = lib.aud_melspec_batch_dev(ph, sig3[s].data_ptr(), sig_code, items3.data_ptr(), nb, mel3[s].data_ptr(), None, None, st)
+            if rc != 0:
+                raise RuntimeError("hot path launch: %d" % rc)
+            if not gather:
+                return
+            if use_streams:
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(comm):
+                    comm.wait_event(ev)
+                    if even:
+                        dist.all_gather_into_tensor(full[s], mel3[s])
+                    else:
+                        full[s] = allgather_features(mel3[s], world, n_total=total)
+                    done[s] = torch.cuda.Event()
+                    done[s].record()
+            else:
+                full[s] = allgather_features(mel3[s], world, n_total=total)
+
+        # a region of its own: the gather's stream handling lives in launch(); one lane (the comm stream is the second)
+        res = timed_region(launch, 1 if gather else 2, min_seconds, total * wl.dur_s)
+        if use_streams:
+            torch.cuda.current_stream(dev).wait_stream(comm)
+            torch.cuda.synchronize(dev)
+        res.update({"workload": wl.name, "compute": compute, "kernel": plan.kernel_name, "total_batch": total,
+                    "streams_this_rank": nb, "rccl_ranks": world if gather else 0,
+                    "collective": ("ncclAllGather (torch.distributed all_gather_into_tensor, RCCL) of this rank's [%d, %d, %d] "
+                                   "float32 slab, on a second stream, overlapped with the next step's kernel" % (nb, wl.nf, wl.T))
+                    if gather else "none (one rank)"})
+        if gather:
+            res["gathered_shape"] = list(full[0].shape)
+        if rank == 0:  # the (gathered) tensors of the last two steps against the oracle, strict: rows of EVERY rank's block
+            from auditory_amd import synth
+            osd = OracleSide(wl)
+            got, ref, per_rank = [], [], max(4, 48 // world)
+            for r in range(world if gather else 1):
+                rlo, rhi = shard_range(total, r, world)
+                idx = np.arange(0, rhi - rlo, max(1, (rhi - rlo) // per_rank))[:per_rank]
+                for s in (0, 1):
+                    src = full[s][rlo:rhi] if gather else mel3[s]
+                    got.append(src.cpu().numpy()[idx])
+                    if r == 0:
+                        pcm = ring.pcm[ring_row[s][idx]]
+                    else:  # another rank's input streams, regenerated from that rank's seeds (Ring: rank * R * B + row)
+                        pcm = np.zeros((len(idx), wl.L), np.int16)
+                        for q, row in enumerate(ring_row[s][idx]):
+                            pcm[q, :wl.dur] = synth.utterance_pcm(2, r * ring.R * B + int(row), wl.dur, wl.sr)
+                    r64 = pcm.astype(np.float64) / 32767.0
+                    ref.append(osd.mel(r64 if ring.sample_bytes == 2 else r64.astype(np.float32).astype(np.float64)))
+            res["parity"] = strict_parity(np.concatenate(got), np.concatenate(ref))
+            res["parity"]["checked"] = "%d streams of every rank's block (%d ranks) in each of the two %s" % (
+                per_rank, world if gather else 1, "gathered tensors" if gather else "output slabs")
         plan.close()
         return res
 
     # ---------------------------------------------------------------------------------------------------
-    head_wl = Workload(args.workload if args.workload in ("cfg5", "cfg1") else "n400")
-    head = time_mode(head_wl, args.compute)
-    solo = head if args.streams == 1 else time_mode(head_wl, args.compute, check=False, n_streams=1)  # the kernel alone: roofline
+    stand_alone = args.workload if args.workload in ("cfg5", "cfg1") else "n400"
+    head_wl = Workload(stand_alone)
+    kind = {"cfg4": "gabor", "sndenv": "full"}.get(args.workload, "mel")
+    head = time_mode(head_wl, args.compute, kind=kind)
+    solo = head if head["streams"] == 1 else time_mode(head_wl, args.compute, kind=kind, check=False, n_streams=1)  # the kernel alone
     if rank == 0 and "parity" in head and not head["parity"]["pass"] and not args.report_anyway:
         print("FATAL: headline mode %s/%s fails the parity criterion: %s" % (head_wl.name, args.compute, head["parity"]),
               file=sys.stderr)
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         raise SystemExit(3)
-    modes, also = {}, None
-    if args.workload == "headline" and world == 1 and not args.only_headline:
-        if args.streams != 1:
+    modes, also, cfg3 = {}, {}, None
+    extras = args.workload == "headline" and not args.only_headline
+    if extras and not multi:
+        a_s = args.also_seconds if args.min_seconds > 0 else 0.0
+        if head["streams"] != 1:
             modes["n400_%s_1stream" % args.compute] = solo
         other = "f32" if args.compute == "f64" else "f64"
-        modes["n400_" + other] = time_mode(head_wl, other)
+        modes["n400_" + other] = time_mode(head_wl, other, min_seconds=a_s)
         wl512 = Workload("n512")
-        also = {"n512_" + args.compute: time_mode(wl512, args.compute), "n512_" + other: time_mode(wl512, other)}
-
-    # ---- multi-GPU: the same steps followed by the path's one collective, overlapped on a second stream ------------
-    with_ag = cfg3 = None
-    if world > 1 and not args.no_allgather:
-        ring = ring_for(head_wl)
-        plan = head_wl.plan(args.compute, local_rank)
-        lib, ph = plan.lib, plan.handle
-        use_streams = args.dist_backend == "nccl"
-        comm = torch.cuda.Stream(dev) if use_streams else None
-
-        def gather_region(nb, sigs, items, mels, steps):
-            """steps x (kernel over this rank's nb streams, then all-gather of its [nb, nf, T] slab on the comm stream while
-            the next step's kernel runs); two output slabs alternate, a kernel waits for the gather that last read its slab"""
-            done = [None, None]
-            full = None
-
-            def one(i):
-                nonlocal full
-                s = i % 2
-                if use_streams and done[s] is not None:
-                    torch.cuda.current_stream(dev).wait_event(done[s])
-                rc = lib.aud_melspec_batch_dev(ph, sigs[i % len(sigs)].data_ptr(), sig_code, items.data_ptr(), nb,
-                                               mels[s].data_ptr(), None, None, torch.cuda.current_stream(dev).cuda_stream)
-                if rc != 0:
-                    raise RuntimeError("hot path launch: %d" % rc)
-                if use_streams:
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    with torch.cuda.stream(comm):
-                        comm.wait_event(ev)
-                        full = allgather_features(mels[s], world, n_total=nb * world)
-                        done[s] = torch.cuda.Event()
-                        done[s].record()
-                else:
-                    full = allgather_features(mels[s], world, n_total=nb * world)
-
-            for i in range(3 if steps > 2 else 1):
-                one(i)
-            sync_all()
-            t0 = time.perf_counter()
-            for i in range(steps):
-                one(i)
-            sync_all()
-            el = max_over_ranks(time.perf_counter() - t0)
-            return el, list(full.shape)
-
-        k2 = max(10, min(K, 200)) if args.min_seconds > 0 else 2
-        el, shape = gather_region(B, ring.sig, ring.items, ring.mel[:2], k2)
-        with_ag = {"value": round(B * world * head_wl.dur_s * k2 / el, 1), "unit": "audio-seconds/sec", "steps": k2,
-                   "ms_per_step": round(1e3 * el / k2, 4), "gathered_shape": shape,
-                   "note": "every step = kernel + one all-gather (torch.distributed all_gather_into_tensor = ncclAllGather, "
-                           "RCCL) of this rank's [B, %d, %d] f32 slab, issued on a second stream and overlapped with the "
-                           "next step's kernel; eager launches" % (head_wl.nf, head_wl.T)}
-        if not args.only_headline:
-            # BASELINE configs[2]: 4096 utterances in total, contiguous shards (auditory_amd.batch.shard_range)
-            from auditory_amd import runtime
-            lo, hi = shard_range(args.cfg3_total, rank, world)
-            nb = hi - lo
-            reps3 = (nb + B - 1) // B
-            sig3 = torch.cat([ring.sig[r % ring.R] for r in range(reps3)])[:nb * head_wl.L].contiguous()
-            it3 = runtime.make_items(np.arange(nb) * head_wl.L, [head_wl.L] * nb, [0] * nb)
-            items3 = torch.from_numpy(np.frombuffer(np.ascontiguousarray(it3).tobytes(), np.uint8).copy()).to(dev)
-            mel3 = [torch.empty((nb, head_wl.nf, head_wl.T), dtype=torch.float32, device=dev) for _ in range(2)]
-            n3 = 40 if args.cfg3_total >= 1024 else 2
-            el3, shape3 = gather_region(nb, [sig3], items3, mel3, n3)
-            cfg3 = {"value": round(args.cfg3_total * head_wl.dur_s * n3 / el3, 1), "unit": "audio-seconds/sec", "steps": n3,
-                    "ms_per_step": round(1e3 * el3 / n3, 4), "total_batch": args.cfg3_total, "streams_this_rank": nb,
-                    "gathered_shape": shape3, "note": "BASELINE configs[2] as stated, strong scaling; kernel + overlapped all-gather"}
-        plan.close()
-    elif world == 1 and args.workload == "headline" and not args.only_headline:
-        # the 1-GPU point of configs[2]'s strong-scaling curve: all 4096 utterances on this GPU, nothing to gather
-        ring = ring_for(head_wl)
-        from auditory_amd import runtime
-        nb = args.cfg3_total
-        plan = head_wl.plan(args.compute, local_rank)
-        reps3 = (nb + B - 1) // B
-        sig3 = torch.cat([ring.sig[r % ring.R] for r in range(reps3)])[:nb * head_wl.L].contiguous()
-        it3 = runtime.make_items(np.arange(nb) * head_wl.L, [head_wl.L] * nb, [0] * nb)
-        items3 = torch.from_numpy(np.frombuffer(np.ascontiguousarray(it3).tobytes(), np.uint8).copy()).to(dev)
-        mel3 = torch.empty((nb, head_wl.nf, head_wl.T), dtype=torch.float32, device=dev)
-        st = torch.cuda.current_stream(dev).cuda_stream
-        for _ in range(3 if nb >= 1024 else 1):
-            plan.melspec_dev(sig3.data_ptr(), sig_code, items3.data_ptr(), nb, mel3.data_ptr(), 0, 0, st)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        n3 = 40 if nb >= 1024 else 2
-        for _ in range(n3):
-            plan.melspec_dev(sig3.data_ptr(), sig_code, items3.data_ptr(), nb, mel3.data_ptr(), 0, 0, st)
-        torch.cuda.synchronize(dev)
-        el3 = time.perf_counter() - t0
-        cfg3 = {"value": round(nb * head_wl.dur_s * n3 / el3, 1), "unit": "audio-seconds/sec", "steps": n3,
-                "ms_per_step": round(1e3 * el3 / n3, 4), "total_batch": nb, "streams_this_rank": nb,
-                "note": "BASELINE configs[2] on one GPU (the G = 1 point of its strong-scaling curve; no collective)"}
-        plan.close()
+        also["n512_" + args.compute] = time_mode(wl512, args.compute, min_seconds=a_s)     # configs[1] as worded
+        modes["n512_" + other] = time_mode(wl512, other, min_seconds=a_s)
+        also["cfg3"] = cfg3_region(head_wl, args.compute, args.cfg3_total, a_s)           # configs[2] on one GPU
+        also["cfg4"] = time_mode(head_wl, args.compute, kind="gabor", min_seconds=a_s)     # configs[3]
+        for key in list(rings):                                                           # free the 16 kHz rings first
+            if key[0] != "n400" or key[1] != B:
+                del rings[key]
+        torch.cuda.empty_cache()
+        also["cfg5"] = time_mode(Workload("cfg5"), args.compute, nb=args.cfg5_batch, min_seconds=a_s)   # configs[4]
+        for key in list(rings):
+            if key[0] == "cfg5":
+                del rings[key]
+        torch.cuda.empty_cache()
+    if multi and args.workload == "headline":
+        cfg3 = cfg3_region(head_wl, args.compute, args.cfg3_total, args.min_seconds)
+        if rank == 0 and not cfg3["parity"]["pass"] and not args.report_anyway:
+            print("FATAL: the gathered tensor fails the parity criterion: %s" % cfg3["parity"], file=sys.stderr)
+            dist.destroy_process_group()
+            raise SystemExit(3)
 
     # roofline.traffic: HBM bytes per launch from the PMC passes (tools/profile_bench.sh), if they were taken for this
     # kernel and batch; null otherwise (it cannot be measured inside this process)
@@ -564,26 +608,37 @@ def main():  # noqa: C901
             traffic = round(float(pmc["hbm_bytes_per_launch"]), 1)
     except (OSError, ValueError, KeyError):
         pass
+    what = {"headline": "BASELINE configs[1] batch on the metric's parameters: ",
+            "cfg4": "BASELINE configs[3] (configs[1] + agabor.Convolve, default FilterSet 9x9/3 x 8, [11,32,2,8] pools): ",
+            "sndenv": "the whole unmodified SndEnv.ProcessSegment loop on the metric's parameters (mel + Power + LogPower "
+                      "tensors + MFCC tail with deltas and Energy: SURVEY 8 f-1, f-2): ",
+            "cfg1": "BASELINE configs[0] parameters (N = 1103), one 100 ms segment per item: ",
+            "cfg5": "BASELINE configs[4]: "}[args.workload]
+    top = cfg3 if cfg3 is not None else head      # several GPUs: configs[2] as stated is the line's value
     line = {
-        "metric": METRIC, "value": head["value"], "unit": "audio-seconds/sec",
-        "n_gpus": world, "steps": head["steps"], "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.compute, "data": "synthetic",
-        "config": {"workload": ("BASELINE configs[1] batch on the metric's parameters: " if args.workload == "headline" else
-                                "BASELINE configs[3] (configs[1] + agabor.Convolve, default FilterSet 9x9/3 x 8, [11,32,2,8] pools): "
-                                if gabor else "the whole unmodified SndEnv.ProcessSegment loop on the metric's parameters (mel + Power + "
-                                "LogPower tensors + MFCC tail with deltas and Energy: SURVEY 8 f-1, f-2): "
-                                if full else "BASELINE configs[0] parameters (N = 1103), one 100 ms segment per item: "
-                                if args.workload == "cfg1" else "BASELINE configs[4]: ") + head_wl.describe(B) +
-                               ("" if gabor or full else ", mel output only"),
-                   "batch_per_gpu": B, "win_samples": head_wl.N, "step_samples": head_wl.S, "segment_steps": head_wl.T,
-                   "n_mel": head_wl.nf, "kernel": head["kernel"], "launch": head["launch"], "streams": head["streams"],
-                   "steps_requested": K,
-                   "repeats": head["repeats"], "ring": head["ring"], "options": args.option, "sig_dtype": args.sig_dtype,
+        "metric": METRIC, "value": top["value"], "unit": "audio-seconds/sec",
+        "n_gpus": world, "steps": top["steps"], "warmup": args.warmup, "ms_per_step": top["ms_per_step"],
+        "higher_is_better": True, "scaling": "strong" if cfg3 is not None else "weak", "vs_baseline": None,
+        "dtype": args.compute, "data": "synthetic",
+        "steps_note": "the %d steps asked for are captured %d x into one hipGraph, replayed %d x" % (
+            K, top["graph_steps"] // K, top["repeats"]),
+        "config": {"workload": (("BASELINE configs[2] as stated: %d synthetic 16 kHz mono utterances of 1 s per step in total, "
+                                 "contiguous shards of %d per rank, kernel + one overlapped RCCL all-gather of the [%d, %d, %d] "
+                                 "float32 mel tensor; the metric's parameters: " % (args.cfg3_total, cfg3["streams_this_rank"],
+                                                                                  args.cfg3_total, head_wl.nf, head_wl.T))
+                                if cfg3 is not None else what) + head_wl.describe(B) +
+                               ("" if kind != "mel" else ", mel output only"),
+                   "batch_per_gpu": B if cfg3 is None else cfg3["streams_this_rank"], "win_samples": head_wl.N,
+                   "step_samples": head_wl.S, "segment_steps": head_wl.T,
+                   "n_mel": head_wl.nf, "kernel": head["kernel"], "launch": top["launch"], "streams": top["streams"],
+                   "steps_requested": K, "repeats": top["repeats"], "ring": head["ring"], "options": args.option,
+                   "sig_dtype": args.sig_dtype,
                    "layout": ("interleaved stereo clips: two strided work items (sig_stride 2) per clip over one buffer" if args.stereo
                               else "one contiguous mono stream per work item"),
-                   "sharding": "utterances, contiguous block per rank; no collective inside `value`"},
-        "us_per_step_device": head["us_per_step_device"],
-        "parity": head.get("parity"),
+                   "sharding": "utterances, contiguous block per rank" + ("; one all-gather per step inside `value`" if cfg3 is not None
+                                                                          else "; no collective (one rank)")},
+        "us_per_step_device": top["us_per_step_device"],
+        "parity": top.get("parity"),
         "roofline": {"bound": "hbm", "achieved": solo["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(solo["achieved_GBps"] / HBM_PEAK_GBPS, 5), "traffic": traffic,
                      "kernel": "frame->FFT->power->mel (%s, %s)" % (head["kernel"], args.compute),
@@ -591,24 +646,27 @@ def main():  # noqa: C901
                      "avg_launch_us": solo["us_per_step_device"]["mean"],
                      "pipelined_GBps": head["achieved_GBps"],
                      "note": "achieved = algorithmic bytes (every sample read once, every mel value written once) / mean device "
-                             "time per launch between HIP events in a ONE-stream region (the kernel alone on the chip, kernel-to-"
-                             "kernel boundary included; rocprofv3's average duration for this kernel is the same number); "
-                             "pipelined_GBps = the same bytes / time per step of the %d-stream region `value` comes from; the "
-                             "kernel is vector-ALU / LDS / latency bound, not HBM bound (DESIGN.md 4)" % max(1, args.streams)},
+                             "time per launch between HIP events in a ONE-stream region of %d utterances per launch (the kernel "
+                             "alone on the chip, kernel-to-kernel boundary included; rocprofv3's average duration for this kernel "
+                             "is the same number); pipelined_GBps = the same bytes / time per step of the %d-stream region; the "
+                             "kernel is vector-ALU (float64 issue) bound, not HBM bound (DESIGN.md 4)" % (B, head["streams"])},
     }
+    if cfg3 is not None:
+        line["rccl_ranks"] = cfg3["rccl_ranks"]
+        line["collective"] = cfg3["collective"]
+        line["gathered_shape"] = cfg3.get("gathered_shape")
+        line["no_collective"] = {k: head[k] for k in ("value", "steps", "ms_per_step", "us_per_step_device", "launch", "streams",
+                                                      "batch", "parity") if k in head}
+        line["no_collective"]["note"] = "the sharded step without the collective: %d utterances per rank and step (weak scaling)" % B
     if modes:
         line["modes"] = modes
     if also:
         line["also"] = also
-    if with_ag:
-        line["with_allgather"] = with_ag
-    if cfg3:
-        line["cfg3"] = cfg3
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(head_wl, ring_for(head_wl).pcm)
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

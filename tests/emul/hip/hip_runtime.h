@@ -175,6 +175,26 @@ inline T __shfl_up(T v, unsigned d, int width = 64) {
     return emul_shfl_any(v, (src >= 0 && (src & ~(width - 1)) == (lane & ~(width - 1))) ? src : lane);
 }
 
+// Data-parallel-primitive moves (the controls the kernels use): every lane publishes `src`, then takes the value of the
+// lane the control names; lanes the row mask leaves out, and lanes whose source does not exist, keep `old`.
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int /*bank_mask*/, bool /*bound_ctrl*/) {
+    const int l = emul_lane(), row = l >> 4, in_row = l & 15;
+    uint64_t packed = uint32_t(src);
+    const uint64_t* all = aud_emul::wave_publish(packed);
+    int from = -1;
+    if (ctrl >= 0 && ctrl <= 0xFF) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);   // quad_perm
+    else if (ctrl == 0x140) from = (l & ~15) | (15 - in_row);                          // row_mirror
+    else if (ctrl == 0x141) from = (l & ~7) | (7 - (l & 7));                           // row_half_mirror
+    else if (ctrl == 0x142) from = (row == 1 || row == 3) ? 16 * row - 1 : -1;         // row_bcast:15
+    else if (ctrl == 0x143) from = row >= 2 ? 31 : -1;                                 // row_bcast:31
+    else std::abort();
+    int out = old;
+    if (((row_mask >> row) & 1) && from >= 0) out = int(uint32_t(all[from]));
+    aud_emul::wave_release();
+    return out;
+}
+inline int __builtin_amdgcn_readlane(int v, int lane) { return emul_shfl_any(v, lane); }
+
 // v_mfma_f32_16x16x4_f32 as the guide documents it: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15],
 // D register r of lane l = row 4 (l >> 4) + r, column l & 15; one k-ordered fmaf chain per element.
 template <typename V>

@@ -70,11 +70,13 @@ def test_bench_dry_run_two_ranks(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs[0][1][-2000:] + outs[1][1][-2000:]
     line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]   # only rank 0 prints the JSON line
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "cpu_baseline" not in line
-    assert line["with_allgather"]["gathered_shape"] == [4, 40, 104]          # kernel + overlapped all-gather region
-    assert line["cfg3"]["total_batch"] == 6 and line["cfg3"]["streams_this_rank"] == 3   # configs[2] region, shrunk
-    assert line["cfg3"]["gathered_shape"] == [6, 40, 104]
-    assert line["parity"]["pass"] and line["parity"]["n_past_1e-5"] == 0
+    # several ranks: `value` is BASELINE configs[2] as stated (a fixed total batch, sharded, kernel + all-gather): strong scaling
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "cpu_baseline" not in line
+    assert line["rccl_ranks"] == 2 and line["gathered_shape"] == [6, 40, 104]           # configs[2] region, shrunk to 6 in total
+    assert line["config"]["batch_per_gpu"] == 3 and "all-gather" in line["config"]["sharding"]
+    assert line["parity"]["pass"] and line["parity"]["n_past_1e-5"] == 0 and "every rank" in line["parity"]["checked"]
+    assert line["no_collective"]["batch"] == 2 and line["no_collective"]["parity"]["pass"]   # the collective-free sharded step
+    assert "also" not in line and "modes" not in line
 
 
 class _SideStream(_Stream):
@@ -85,7 +87,7 @@ class _SideStream(_Stream):
         pass
 
 
-@pytest.mark.parametrize("extra", [["--only-headline"], ["--workload", "cfg4"], ["--sig-dtype", "i16", "--only-headline"],
+@pytest.mark.parametrize("extra", [[], ["--only-headline"], ["--workload", "cfg4"], ["--sig-dtype", "i16", "--only-headline"],
                                    ["--compute", "f32", "--launch", "eager", "--only-headline"],
                                    ["--workload", "sndenv"], ["--stereo", "--only-headline"]])
 def test_bench_dry_run(monkeypatch, capsys, extra):
@@ -95,7 +97,7 @@ def test_bench_dry_run(monkeypatch, capsys, extra):
     monkeypatch.setattr(bench, "cpu_baseline",
                         lambda wl, pcm: bench.__dict__["_real_cpu_baseline"](wl, pcm, target_s=0.2))
     monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--batch", "2", "--ring-mb", "0.2",
-                                      "--min-seconds", "0", "--cfg3-total", "4"] + extra)
+                                      "--min-seconds", "0", "--cfg3-total", "4", "--cfg5-batch", "2"] + extra)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
     with backend.emulated("plain"):
@@ -114,6 +116,12 @@ def test_bench_dry_run(monkeypatch, capsys, extra):
     assert line["cpu_baseline"]["cores"] <= 16 and line["cpu_baseline"]["kind"] == "port"
     assert "workload" in line["config"] and "model" not in line["config"]
     assert line["value"] > 0 and line["roofline"]["achieved"] >= 0
+    if not extra:   # the default line nests the other BASELINE configurations, each with its own strict parity object
+        assert set(line["also"]) == {"n512_f64", "cfg3", "cfg4", "cfg5"} and set(line["modes"]) >= {"n400_f32", "n512_f32"}
+        for k, v in line["also"].items():
+            assert v["parity"]["pass"], (k, v["parity"])
+        assert line["also"]["cfg4"]["parity"]["gabor"]["pass"] and line["also"]["cfg3"]["total_batch"] == 4
+        assert line["also"]["cfg5"]["kernel"] == "w64x16" and line["also"]["cfg5"]["batch"] == 2
 
 
 @pytest.mark.parametrize("extra", [["--win-ms", "32", "--compute", "f32"], ["--win-ms", "25", "--streams", "2"]])

@@ -34,6 +34,8 @@ for step in "$@"; do
         profile) run profile$i 900 bash tools/profile_bench.sh "${TAG}" ;;
         profile:*) args=$(echo "${step#profile:}" | tr ',' ' ')
                run profile$i 900 bash tools/profile_bench.sh "${TAG}_$i" $args ;;
+        stamps:*) args=$(echo "${step#stamps:}" | tr ',' ' ')
+               run stamps$i 400 python tools/stamp_profile.py $args ;;
         ubench) (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_rates valu_rates.hip) &&
                 run ubench 120 /tmp/valu_rates ;;
         *) echo "unknown step $step"; exit 2 ;;

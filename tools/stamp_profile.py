@@ -21,12 +21,17 @@ import memguard  # noqa: E402
 
 memguard.install()
 
-PHASES = ["0-1 issue loads + stage weights", "1-2 workgroup barrier", "2-3 operands land (vmcnt 0)",
-          "3-4 pass-1 DFT + twiddle", "4-5 LDS transpose re/im", "5-6 pass-2 DFT", "6-7 split + power -> LDS",
-          "7-8 mel epilogue + stores"]
-PHASES_W25 = ["0-1 issue loads + stage weights", "1-2 workgroup barrier", "2-3 operands land (vmcnt 0)",
-              "3-4 pass-A DFT25 + twiddle", "4-5 LDS transpose re/im", "5-6 pass-B DFT8 rows", "6-7 split + power -> LDS",
-              "7-8 mel epilogue + stores"]
+# stamps of the wave kernels: 0 at the top, 3 operands converted + frame scale, 4 first-pass DFT + twiddle, 5 transposes,
+# 6 second pass, 7 split + power -> LDS, 8 epilogue + stores
+MARKS = {400: [(0, 3, "0-3 tables staged, operands landed + converted, frame scale"), (3, 4, "3-4 pass-A DFT20 + twiddle"),
+               (4, 5, "4-5 LDS transposes (half rows, re / im)"), (5, 6, "5-6 pass-B DFT10 x 2"),
+               (6, 7, "6-7 split + power -> LDS (float32, scaled)"), (7, 8, "7-8 mel epilogue + stores")],
+         512: [(0, 3, "0-3 tables staged, operands landed + converted, frame scale"), (3, 4, "3-4 pass-1 DFT16 + twiddle"),
+               (4, 5, "4-5 LDS transpose re / im"), (5, 6, "5-6 pass-2 DFT16"),
+               (6, 7, "6-7 split (shuffles) + power -> LDS"), (7, 8, "7-8 mel epilogue + stores")],
+         2048: [(0, 3, "0-3 operands issued, landed + converted, frame scale"), (3, 4, "3-4 pass-1 DFT16 + twiddle (global table)"),
+                (4, 5, "4-5 LDS transpose 1 re/im"), (5, 6, "5-6 pass-2 DFT16 + twiddle + transpose 2"),
+                (6, 7, "6-7 pass-3 DFT4 + split + power -> LDS"), (7, 8, "7-8 mel epilogue + stores")]}
 
 
 def main():
@@ -85,22 +90,12 @@ def main():
     t = s[:, :9]
     ok = (t[:, 8] > 0)
     t = t[ok]
-    d = np.diff(t, axis=1)
     life = t[:, 8] - t[:, 0]
-    names = PHASES if oc.N == 512 else PHASES_W25
-    print("%-36s %9s %9s %9s  %6s" % ("phase (s_memtime ticks = shader cycles)", "median", "p10", "p90", "share"))
-    if oc.N == 2048:   # w64x16 stamps 0, 3..8 only
-        marks = [(0, 3, "0-3 operands issued and landed"), (3, 4, "3-4 pass-1 DFT16 + twiddle (global table)"),
-                 (4, 5, "4-5 LDS transpose 1 re/im"), (5, 6, "5-6 pass-2 DFT16 + twiddle + transpose 2"),
-                 (6, 7, "6-7 pass-3 DFT4 + split + power -> LDS"), (7, 8, "7-8 mel epilogue + stores")]
-        for lo, hi, nm in marks:
-            dd = t[:, hi] - t[:, lo]
-            print("%-44s %9.0f %9.0f %9.0f  %5.1f%%" % (nm, np.median(dd), np.percentile(dd, 10), np.percentile(dd, 90),
-                                                         100.0 * float(dd.sum()) / float(life.sum())))
-    else:
-        for i, nm in enumerate(names):
-            print("%-36s %9.0f %9.0f %9.0f  %5.1f%%" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 10),
-                                                     np.percentile(d[:, i], 90), 100 * d[:, i].sum() / life.sum()))
+    print("%-60s %9s %9s %9s  %6s" % ("phase (s_memtime ticks = shader cycles)", "median", "p10", "p90", "share"))
+    for lo, hi, nm in MARKS[oc.N]:
+        dd = t[:, hi] - t[:, lo]
+        print("%-60s %9.0f %9.0f %9.0f  %5.1f%%" % (nm, np.median(dd), np.percentile(dd, 10), np.percentile(dd, 90),
+                                                     100.0 * float(dd.sum()) / float(life.sum())))
     print("%-36s %9.0f %9.0f %9.0f" % ("wave lifetime", np.median(life), np.percentile(life, 10), np.percentile(life, 90)))
     # launch timeline from the chip-wide 100 MHz counter (s_memrealtime; s_memtime is not comparable between CUs)
     xcc = s[ok, 12] & 15
