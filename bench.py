@@ -337,8 +337,10 @@ def main():  # noqa: C901
 
     cur = lambda: torch.cuda.current_stream(dev).cuda_stream  # noqa: E731
 
-    def timed_region(launch, n_streams, min_seconds, audio_s_per_step):
-        """K x repeats steps of launch(i, stream handle); the steps dealt over n_streams streams inside one hipGraph"""
+    def timed_region(launch, n_streams, min_seconds, audio_s_per_step, extra_streams=(), reset=None):
+        """K x repeats steps of launch(i, stream handle); the steps dealt over n_streams streams inside one hipGraph.
+        extra_streams: streams launch() itself puts work on (forked from / joined to the capturing stream with the lanes);
+        reset(): forget cross-step state (events) recorded outside the graph that is about to be captured"""
         n_streams = max(1, n_streams)
         side = [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
         GK = K * max(1, -(-args.graph_steps // K)) if args.launch == "graph" else K   # steps per replay: a multiple of K
@@ -348,25 +350,29 @@ def main():  # noqa: C901
         graph, launch_mode = None, "eager"
         if args.launch == "graph":
             try:
+                if reset:
+                    reset()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     main_s = torch.cuda.current_stream(dev)
-                    for sst in side:
+                    for sst in side + list(extra_streams):
                         sst.wait_stream(main_s)
                     lanes = [main_s] + side
                     for i in range(GK):
                         with torch.cuda.stream(lanes[i % n_streams]):
                             launch(i, lanes[i % n_streams].cuda_stream)
-                    for sst in side:
+                    for sst in side + list(extra_streams):
                         main_s.wait_stream(sst)
                 graph.replay()
                 torch.cuda.synchronize(dev)
                 launch_mode = "hipGraph of %d steps" % GK + (" (%d x the %d requested)" % (GK // K, K) if GK != K else "")
             except Exception as ex:  # capture unsupported here (CPU dry run): say so and time eager launches
-                print("WARNING: hipGraph capture failed (%s); timing eager launches" % ex, file=sys.stderr)
+                print("WARNING: hipGraph capture failed (%s); timing eager launches" % str(ex).splitlines()[0], file=sys.stderr)
                 graph = None
                 GK = K
                 torch.cuda.synchronize(dev)
+                if reset:
+                    reset()
 
         def replay():
             if graph is not None:
@@ -521,8 +527,12 @@ def main():  # noqa: C901
             else:
                 full[s] = allgather_features(mel3[s], world, n_total=total)
 
-        # a region of its own: the gather's stream handling lives in launch(); one lane (the comm stream is the second)
-        res = timed_region(launch, 1 if gather else 2, min_seconds, total * wl.dur_s)
+        def reset():
+            done[0] = done[1] = None
+
+        # the gather's stream handling lives in launch(): one lane, the comm stream is the second
+        res = timed_region(launch, 1 if gather else 2, min_seconds, total * wl.dur_s,
+                           extra_streams=[comm] if use_streams else (), reset=reset)
         if use_streams:
             torch.cuda.current_stream(dev).wait_stream(comm)
             torch.cuda.synchronize(dev)
