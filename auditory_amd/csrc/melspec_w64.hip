@@ -32,11 +32,11 @@ struct Layout {
 
 namespace {
 
-// the operands of frame `wt` (one frame per wave tile): requested into `raw`, nothing awaited
+// the operands of frame (item, sstep) (one frame per wave tile): requested into `raw`, nothing awaited.  item and sstep
+// are SCALAR values (the caller keeps them in scalar registers): the buffer descriptor must be wave-uniform to the
+// compiler, or every load is wrapped in a loop over the descriptor's values
 template <int SRC>
-__device__ __forceinline__ void w64_issue(const MelspecArgs& a, int lane, int64_t wt, PairRaw<16>& raw) {
-    const int item = int(wt / a.T);
-    const int sstep = int(wt - int64_t(item) * a.T);
+__device__ __forceinline__ void w64_issue(const MelspecArgs& a, int lane, int item, int sstep, PairRaw<16>& raw) {
     const aud_item it = a.items[item];
     const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
     const SampleWindow<SRC> win = sample_window<SRC>(a, it, start, w64::kN);
@@ -47,19 +47,19 @@ __device__ __forceinline__ void w64_issue(const MelspecArgs& a, int lane, int64_
 // (the load phase was 38 % of a wave's life without it: profiles/r05e_stamps_n46.44_f64_b64.txt).
 template <typename TT, int SRC, int MAXS>
 __device__ __forceinline__ void w64_tile(const MelspecArgs& a, const WaveArgs& e, unsigned char* smem, unsigned char* region,
-                                         int lane_in, int64_t wt, bool more, PairRaw<16>& raw) {
+                                         int lane_in, int item, int sstep, bool more, PairRaw<16>& raw) {
     TT* xw = reinterpret_cast<TT*>(region);
     int lane = lane_in;  // opaque per frame: otherwise the compiler hoists what only depends on it out of the frame loop
     asm volatile("" : "+v"(lane));
-    const int item = int(wt / a.T);
-    const int sstep = int(wt - int64_t(item) * a.T);
     const aud_item it = a.items[item];
+    const int64_t wt = int64_t(item) * a.T + sstep;  // (the stamps' index)
+    (void)wt;
     AUD_STAMP_DECL;
     AUD_STAMP(0);
     AUD_STAMP_REAL(9);
     C2<TT> v[16];
     TT amax;
-    if constexpr (sizeof(TT) == 4) w64_issue<SRC>(a, lane, wt, raw);  // (float32 plans: no prefetch, see below)
+    if constexpr (sizeof(TT) == 4) w64_issue<SRC>(a, lane, item, sstep, raw);  // (float32 plans: no prefetch, see below)
     pairs_take<TT, SRC, 16, 64>(a, it, int64_t(it.start0) + int64_t(a.S) * (sstep - a.border) + 2 * lane, true, raw, v, amax);
     // the frame is the whole wave: its scale is a wave-wide maximum (six data-parallel moves, no LDS)
     int sc = 0;
@@ -205,7 +205,10 @@ __device__ __forceinline__ void w64_tile(const MelspecArgs& a, const WaveArgs& e
     // because the FFT passes are where the registers run out.  float64 plans only: their three waves per SIMD leave the
     // 32 registers free, in float32 plans they would cost a wave per SIMD
     if constexpr (sizeof(TT) == 8)
-        if (more) w64_issue<SRC>(a, lane, wt + 1, raw);
+        if (more) {  // the next frame of the wave: the next step, or step 0 of the next item
+            const bool wrap = sstep + 1 == a.T;
+            w64_issue<SRC>(a, lane, wrap ? item + 1 : item, wrap ? 0 : sstep + 1, raw);
+        }
     wave_mel_epilogue<TT, 1, MAXS, true>(a, e, P, w64::kHp, smem, sc, it, item, sstep, lane);
     AUD_STAMP(8);
     AUD_STAMP_REAL(10);
@@ -228,13 +231,21 @@ __global__ __launch_bounds__(64 * NW) void k_melspec_w64(const MelspecArgs a, co
     const int64_t total = int64_t(a.n_items) * a.T;  // one frame per wave tile
     const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
     const int64_t wt0 = (int64_t(wg) * NW + wave) * w64::kFPW;
+    // (item, step) of the wave's frames, kept on the scalar unit
+    int item = __builtin_amdgcn_readfirstlane(int(wt0 / a.T));
+    int sstep = __builtin_amdgcn_readfirstlane(int(wt0 - int64_t(item) * a.T));
     PairRaw<16> raw;
     if constexpr (sizeof(TT) == 8)
-        if (wt0 < total) w64_issue<SRC>(a, lane, wt0, raw);
+        if (wt0 < total) w64_issue<SRC>(a, lane, item, sstep, raw);
 #pragma unroll 1
-    for (int i = 0; i < w64::kFPW; ++i)
-        if (wt0 + i < total)
-            w64_tile<TT, SRC, MAXS>(a, e, smem, region, lane, wt0 + i, i + 1 < w64::kFPW && wt0 + i + 1 < total, raw);
+    for (int i = 0; i < w64::kFPW; ++i) {
+        if (wt0 + i >= total) break;
+        w64_tile<TT, SRC, MAXS>(a, e, smem, region, lane, item, sstep, i + 1 < w64::kFPW && wt0 + i + 1 < total, raw);
+        if (++sstep == a.T) {
+            sstep = 0;
+            ++item;
+        }
+    }
 }
 
 }  // namespace
