@@ -41,19 +41,19 @@ def main():
 
     assert torch.cuda.is_available()
     dev = torch.device("cuda", 0)
-    name = {32.0: "cfg2_16k_n512_nf40", 25.0: "cfg2_16k_n400_nf40"}[args.win_ms]
+    name = {32.0: "cfg2_16k_n512_nf40", 25.0: "cfg2_16k_n400_nf40", 46.44: "cfg5_44k_n2048_nf128"}[args.win_ms]
     oc = W.OracleCfg(orc, name)
     B = args.batch
     L = (oc.full_len() + 63) // 64 * 64
     R = max(2, int(np.ceil(320e6 / (B * L * 4))))   # ring of resident batches beyond the Infinity Cache, as bench.py
-    sig64, _ = synth.batch(2, min(B, 256), 16000, oc.sr, row_len=L)
+    sig64, _ = synth.batch(2, min(B, 256 if oc.sr == 16000 else 32), int(oc.sr * (1.0 if oc.sr == 16000 else 5.0)), oc.sr, row_len=L)
     reps = (B + sig64.shape[0] - 1) // sig64.shape[0]
     sig = np.tile(sig64.astype(np.float32), (reps, 1))[:B]
     ring = [torch.from_numpy(np.roll(sig, r, axis=0)).to(dev).view(-1) for r in range(R)]
     cdt = capi.AUD_F32 if args.compute == "f32" else capi.AUD_F64
     shipped = capi.LIB_PATH
     plans = {}
-    for tag in args.libs.split(","):
+    for tag in args.libs.replace(":", ",").split(","):
         if tag:  # (the empty tag keeps whatever binding the process has: the shipped library, or a test's emulator build)
             capi.LIB_PATH = shipped.replace(".so", "_%s.so" % tag)
             capi._LIB, runtime._CTX = None, {}
@@ -113,14 +113,14 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1) * 1e3 / args.launches)   # us per launch (incl. kernel boundaries)
-    alg = B * (4 * 16000 + 4 * oc.nf * oc.T)
+    alg = B * (4 * int(oc.sr * (1.0 if oc.sr == 16000 else 5.0)) + 4 * oc.nf * oc.T)
     print("workload: %s, batch %d, %s; %d rounds x %d launches on %d stream(s); algorithmic bytes/launch %.2f MB"
           % (name, B, args.compute, args.rounds, args.launches, args.streams, alg / 1e6))
     for v, ts in times.items():
         med, mn = statistics.median(ts), min(ts)
         print("%-24s kernel=%-8s lds %6d B, %d wg/CU  median %8.2f us  min %8.2f us  -> %6.3f of 8 TB/s, %7.2f M audio-s/s"
               % (v, plans[v].kernel_name, plans[v].info("lds_bytes"), plans[v].info("wgs_per_cu"), med, mn,
-                 alg / (med * 1e-6) / 8e12, B / med))
+                 alg / (med * 1e-6) / 8e12, B * (1.0 if oc.sr == 16000 else 5.0) / med))
     for p in plans.values():
         p.close()
 
