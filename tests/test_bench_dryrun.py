@@ -153,7 +153,8 @@ def test_smoke_dry_run(monkeypatch, capsys):
     monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
     with backend.emulated("plain"):
         G.smoke()
-    assert "smoke ok: kernel=w16x16" in capsys.readouterr().out
+    out = capsys.readouterr().out
+    assert "smoke ok: strict float64 w20x10" in out and "smoke strict float64 w20x10 mel" in out and "RELAXED float32 w16x16" in out
 
 
 def test_device_api_tests_dry_run(monkeypatch, orc):
