@@ -130,6 +130,10 @@ SYMBOLS = {
     "aud_comm_init": (C.c_int, [_VP, C.c_int, C.c_int, _VP]),
     "aud_comm_destroy": (C.c_int, [_VP]),
     "aud_allgather_dev": (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP]),
+    "aud_gather_create": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int64, C.POINTER(_VP), _VP]),
+    "aud_gather_open_peer": (C.c_int, [_VP, C.c_int, _VP]),
+    "aud_allgather_direct_dev": (C.c_int, [_VP, _VP, C.c_int64, _VP]),
+    "aud_gather_destroy": (C.c_int, [_VP]),
 }
 
 _LIB = None

@@ -27,6 +27,16 @@ struct aud_ctx {
     void* rccl_lib = nullptr;
     void* comm = nullptr;
     int n_ranks = 0, rank = 0;
+    // direct all-gather (aud_gather_*): this rank's receive buffer, the peers' mapped ones, one stream + event per peer
+    struct Gather {
+        int n_ranks = 0, rank = 0;
+        int64_t slab = 0;
+        float* recv = nullptr;
+        std::vector<float*> peer;          // [n_ranks], peer[rank] = recv
+        std::vector<hipStream_t> streams;  // [n_ranks], null at `rank`
+        std::vector<hipEvent_t> done;      // [n_ranks]
+        hipEvent_t fork = nullptr;
+    } gather;
 };
 
 struct aud_plan {
@@ -408,6 +418,7 @@ int aud_shutdown(aud_ctx* c) {
     if (!c) return AUD_EINVAL;
     (void)hipSetDevice(c->device);
     aud_comm_destroy(c);
+    aud_gather_destroy(c);
     for (int i = 0; i < 4; ++i)
         if (c->ws[i]) (void)hipFree(c->ws[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1302,6 +1313,100 @@ int aud_comm_destroy(aud_ctx* c) {
         if (destroy) destroy(c->comm);
     }
     c->comm = nullptr;
+    return AUD_OK;
+}
+
+int aud_gather_create(aud_ctx* c, int n_ranks, int rank, int64_t slab_floats, float** recv, char handle[64]) {
+    if (!c || !recv || !handle || n_ranks < 1 || rank < 0 || rank >= n_ranks || slab_floats < 1) return AUD_EINVAL;
+    if (c->gather.recv) return fail(c, AUD_EINVAL, "gather buffer already created");
+    AUD_HIP(c, make_current(c));
+    aud_ctx::Gather& g = c->gather;
+    AUD_HIP(c, hipMalloc(reinterpret_cast<void**>(&g.recv), size_t(n_ranks) * size_t(slab_floats) * sizeof(float)));
+    hipIpcMemHandle_t h;
+    static_assert(sizeof(h) == 64, "hipIpcMemHandle_t is 64 bytes");
+    if (hipIpcGetMemHandle(&h, g.recv) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(g.recv);
+        g.recv = nullptr;
+        return fail(c, AUD_EHIP, "hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)");
+    }
+    std::memcpy(handle, &h, 64);
+    g.n_ranks = n_ranks;
+    g.rank = rank;
+    g.slab = slab_floats;
+    g.peer.assign(size_t(n_ranks), nullptr);
+    g.peer[size_t(rank)] = g.recv;
+    g.streams.assign(size_t(n_ranks), nullptr);
+    g.done.assign(size_t(n_ranks), nullptr);
+    AUD_HIP(c, hipEventCreateWithFlags(&g.fork, hipEventDisableTiming));
+    for (int p = 0; p < n_ranks; ++p) {
+        if (p == rank) continue;
+        AUD_HIP(c, hipStreamCreateWithFlags(&g.streams[size_t(p)], hipStreamNonBlocking));
+        AUD_HIP(c, hipEventCreateWithFlags(&g.done[size_t(p)], hipEventDisableTiming));
+    }
+    *recv = g.recv;
+    return AUD_OK;
+}
+
+int aud_gather_open_peer(aud_ctx* c, int peer, const char handle[64]) {
+    if (!c || !handle) return AUD_EINVAL;
+    aud_ctx::Gather& g = c->gather;
+    if (!g.recv) return fail(c, AUD_EINVAL, "aud_gather_create has not been called");
+    if (peer < 0 || peer >= g.n_ranks || peer == g.rank) return fail(c, AUD_EINVAL, "peer must be another rank of the gather");
+    if (g.peer[size_t(peer)]) return fail(c, AUD_EINVAL, "peer already opened");
+    AUD_HIP(c, make_current(c));
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, 64);
+    void* p = nullptr;
+    AUD_HIP(c, hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    g.peer[size_t(peer)] = static_cast<float*>(p);
+    return AUD_OK;
+}
+
+int aud_allgather_direct_dev(aud_ctx* c, const float* send, int64_t count, void* stream) {
+    if (!c || count < 0) return AUD_EINVAL;
+    aud_ctx::Gather& g = c->gather;
+    if (!g.recv) return fail(c, AUD_EINVAL, "aud_gather_create has not been called");
+    if (count > g.slab) return fail(c, AUD_EINVAL, "count exceeds the slab the gather was created for");
+    for (int p = 0; p < g.n_ranks; ++p)
+        if (!g.peer[size_t(p)]) return fail(c, AUD_EINVAL, "a peer's receive buffer has not been opened");
+    if (count == 0) return AUD_OK;
+    if (!send) return fail(c, AUD_EINVAL, "null buffer");
+    AUD_HIP(c, make_current(c));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t bytes = size_t(count) * sizeof(float), slot = size_t(g.rank) * size_t(g.slab);
+    // own slot on the caller's stream; one push per peer, each on its own stream (its own xGMI link), forked from and
+    // joined back into the caller's stream
+    AUD_HIP(c, hipMemcpyAsync(g.recv + slot, send, bytes, hipMemcpyDeviceToDevice, st));
+    if (g.n_ranks > 1) AUD_HIP(c, hipEventRecord(g.fork, st));
+    for (int p = 0; p < g.n_ranks; ++p) {
+        if (p == g.rank) continue;
+        hipStream_t sp = g.streams[size_t(p)];
+        AUD_HIP(c, hipStreamWaitEvent(sp, g.fork, 0));
+        AUD_HIP(c, hipMemcpyAsync(g.peer[size_t(p)] + slot, send, bytes, hipMemcpyDeviceToDevice, sp));
+        AUD_HIP(c, hipEventRecord(g.done[size_t(p)], sp));
+        AUD_HIP(c, hipStreamWaitEvent(st, g.done[size_t(p)], 0));
+    }
+    return AUD_OK;
+}
+
+int aud_gather_destroy(aud_ctx* c) {
+    if (!c) return AUD_EINVAL;
+    aud_ctx::Gather& g = c->gather;
+    if (!g.recv) return AUD_OK;
+    (void)hipSetDevice(c->device);
+    for (int p = 0; p < g.n_ranks; ++p) {
+        if (p == g.rank) continue;
+        if (g.streams[size_t(p)]) {
+            (void)hipStreamSynchronize(g.streams[size_t(p)]);
+            (void)hipStreamDestroy(g.streams[size_t(p)]);
+        }
+        if (g.done[size_t(p)]) (void)hipEventDestroy(g.done[size_t(p)]);
+        if (g.peer[size_t(p)]) (void)hipIpcCloseMemHandle(g.peer[size_t(p)]);
+    }
+    if (g.fork) (void)hipEventDestroy(g.fork);
+    (void)hipFree(g.recv);
+    g = aud_ctx::Gather();
     return AUD_OK;
 }
 

@@ -273,6 +273,10 @@ def main():  # noqa: C901
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="aud_plan_set_option switches, e.g. kernel=1 (the generic kernel)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for CPU dry runs)")
+    ap.add_argument("--gather-mode", choices=["rccl", "direct"], default="rccl",
+                    help="the multi-GPU region's collective: rccl = ncclAllGather (the reported default); direct = the library's "
+                         "direct pattern (aud_gather_*: one device-to-device push per peer over its own xGMI link, SURVEY 5) -- the "
+                         "fallback if RCCL picks a ring for these 8.5 MB slabs")
     ap.add_argument("--dist-single", action="store_true",
                     help="validation only: run the multi-GPU code path (shard + RCCL all-gather inside the graph) on ONE rank")
     ap.add_argument("--only-headline", action="store_true", help="skip `modes` and `also`")
@@ -500,9 +504,27 @@ def main():  # noqa: C901
         gather = world > 1 or args.dist_single
         use_streams = gather and args.dist_backend == "nccl"
         comm = torch.cuda.Stream(dev) if use_streams else None
-        full = [torch.empty((total,) + tuple(mel3[0].shape[1:]), dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
         even = total % world == 0
+        direct = None
+        if gather and args.gather_mode == "direct":
+            if not even:
+                raise SystemExit("--gather-mode direct needs the total batch to divide evenly over the ranks")
+            from auditory_amd.batch import DirectGather
+            direct = DirectGather(plan.ctx, world, rank, nb * wl.nf * wl.T)
+            direct.exchange()
+            recv = direct.recv(dev).view(total, wl.nf, wl.T)   # one receive buffer: consecutive steps overwrite it
+            full = [recv, recv]
+        else:
+            full = [torch.empty((total,) + tuple(mel3[0].shape[1:]), dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
         done = [None, None]
+
+        def collect(s, st):
+            if direct is not None:
+                direct.allgather(mel3[s].data_ptr(), nb * wl.nf * wl.T, st)
+            elif even:
+                dist.all_gather_into_tensor(full[s], mel3[s])
+            else:
+                full[s] = allgather_features(mel3[s], world, n_total=total)
 
         def launch(i, st):
             s = i % 2
@@ -518,14 +540,11 @@ def main():  # noqa: C901
                 ev.record()
                 with torch.cuda.stream(comm):
                     comm.wait_event(ev)
-                    if even:
-                        dist.all_gather_into_tensor(full[s], mel3[s])
-                    else:
-                        full[s] = allgather_features(mel3[s], world, n_total=total)
+                    collect(s, comm.cuda_stream)
                     done[s] = torch.cuda.Event()
                     done[s].record()
             else:
-                full[s] = allgather_features(mel3[s], world, n_total=total)
+                collect(s, st)
 
         def reset():
             done[0] = done[1] = None
@@ -538,9 +557,11 @@ def main():  # noqa: C901
             torch.cuda.synchronize(dev)
         res.update({"workload": wl.name, "compute": compute, "kernel": plan.kernel_name, "total_batch": total,
                     "streams_this_rank": nb, "rccl_ranks": world if gather else 0,
-                    "collective": ("ncclAllGather (torch.distributed all_gather_into_tensor, RCCL) of this rank's [%d, %d, %d] "
-                                   "float32 slab, on a second stream, overlapped with the next step's kernel" % (nb, wl.nf, wl.T))
-                    if gather else "none (one rank)"})
+                    "collective": (("direct pattern (aud_allgather_direct_dev: one device-to-device push per peer on its own "
+                                    "stream)" if direct is not None else
+                                    "ncclAllGather (torch.distributed all_gather_into_tensor, RCCL)") +
+                                   " of this rank's [%d, %d, %d] float32 slab, on a second stream, overlapped with the next "
+                                   "step's kernel" % (nb, wl.nf, wl.T)) if gather else "none (one rank)"})
         if gather:
             res["gathered_shape"] = list(full[0].shape)
         if rank == 0:  # the (gathered) tensors of the last two steps against the oracle, strict: rows of EVERY rank's block
@@ -550,7 +571,7 @@ def main():  # noqa: C901
             for r in range(world if gather else 1):
                 rlo, rhi = shard_range(total, r, world)
                 idx = np.arange(0, rhi - rlo, max(1, (rhi - rlo) // per_rank))[:per_rank]
-                for s in (0, 1):
+                for s in ((0, 1) if direct is None else ((res["graph_steps"] - 1) % 2,)):
                     src = full[s][rlo:rhi] if gather else mel3[s]
                     got.append(src.cpu().numpy()[idx])
                     if r == 0:
@@ -564,6 +585,9 @@ def main():  # noqa: C901
             res["parity"] = strict_parity(np.concatenate(got), np.concatenate(ref))
             res["parity"]["checked"] = "%d streams of every rank's block (%d ranks) in each of the two %s" % (
                 per_rank, world if gather else 1, "gathered tensors" if gather else "output slabs")
+        if direct is not None:
+            sync_all()
+            direct.close()
         plan.close()
         return res
 

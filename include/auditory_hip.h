@@ -392,6 +392,24 @@ int aud_comm_destroy(aud_ctx* ctx);
 /* in-place capable all-gather of `count` float32 per rank: recv[rank*count ...] <- send */
 int aud_allgather_dev(aud_ctx* ctx, const float* send, float* recv, int64_t count, void* stream);
 
+/* The same reassembly as DIRECT device-to-device copies (the 8 GPUs of a node are fully connected, 7 xGMI
+ * links per GPU, so an all-gather is one push per peer, each on its own link and its own stream -- what a ring collective,
+ * per-link bound with 7 serial hops, cannot do for messages of a few MB).  Set-up, once per (context, shape):
+ *   aud_gather_create   allocates this rank's receive buffer [n_ranks][slab_floats] float32 on the device and exports
+ *                       its 64-byte inter-process handle; the host program distributes the handles (any channel)
+ *   aud_gather_open_peer  maps peer `peer`'s receive buffer from its handle (not needed, and refused, for peer == rank)
+ * Per batch:
+ *   aud_allgather_direct_dev  copies send[0 .. count) into slot `rank` of EVERY rank's receive buffer (its own included):
+ *                       n_ranks - 1 peer copies on n_ranks - 1 internal streams forked from and joined back into `stream`
+ *                       (capturable into a hipGraph).  count <= slab_floats.  When `stream` has passed the call, THIS
+ *                       rank's pushes are done; a rank's receive buffer is complete once EVERY rank's call has completed --
+ *                       the host program orders that (a barrier, or the next step's own synchronisation).
+ *   aud_gather_destroy  unmaps the peers, frees the buffer. */
+int aud_gather_create(aud_ctx* ctx, int n_ranks, int rank, int64_t slab_floats, float** recv, char handle[64]);
+int aud_gather_open_peer(aud_ctx* ctx, int peer, const char handle[64]);
+int aud_allgather_direct_dev(aud_ctx* ctx, const float* send, int64_t count, void* stream);
+int aud_gather_destroy(aud_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,6 +117,24 @@ hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipGetLastError();
+// events and inter-process handles: everything the emulator runs is synchronous and lives in one process, so an event is
+// a token and a "handle" carries the pointer itself (the direct all-gather's indexing is what the CPU tier checks)
+typedef struct emul_event* hipEvent_t;
+enum { hipEventDisableTiming = 2, hipIpcMemLazyEnablePeerAccess = 1 };
+struct hipIpcMemHandle_t {
+    char reserved[64];
+};
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinterpret_cast<hipEvent_t>(new char); return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete reinterpret_cast<char*>(e); return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
+inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) {
+    std::memset(h, 0, sizeof(*h));
+    std::memcpy(h->reserved, &p, sizeof(p));
+    return 0;
+}
+inline hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) { std::memcpy(p, h.reserved, sizeof(*p)); return 0; }
+inline hipError_t hipIpcCloseMemHandle(void*) { return 0; }
 const char* hipGetErrorString(hipError_t e);
 
 namespace aud_emul {

@@ -87,6 +87,31 @@ class _SideStream(_Stream):
         pass
 
 
+@pytest.mark.parametrize("mode", ["rccl", "direct"])
+def test_bench_dry_run_single_rank_collective(monkeypatch, capsys, mode):
+    """--dist-single: the multi-GPU region (shard + collective per step, gathered tensor checked) on ONE rank, both gather
+    modes -- gloo stands in for RCCL, the emulator's handles for the inter-process ones"""
+    import socket
+    import backend
+    import bench
+    _patch(monkeypatch)
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    monkeypatch.setenv("MASTER_PORT", str(sk.getsockname()[1]))
+    sk.close()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--batch", "2", "--ring-mb", "0.2",
+                                      "--min-seconds", "0", "--cfg3-total", "4", "--dist-single", "--dist-backend", "gloo",
+                                      "--gather-mode", mode, "--no-cpu-baseline"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    with backend.emulated("plain"):
+        bench.main()
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line["scaling"] == "strong" and line["rccl_ranks"] == 1 and line["gathered_shape"] == [4, 40, 104]
+    assert line["parity"]["pass"] and ("direct pattern" in line["collective"]) == (mode == "direct")
+    assert line["no_collective"]["parity"]["pass"]
+
+
 @pytest.mark.parametrize("extra", [[], ["--only-headline"], ["--workload", "cfg4"], ["--sig-dtype", "i16", "--only-headline"],
                                    ["--compute", "f32", "--launch", "eager", "--only-headline"],
                                    ["--workload", "sndenv"], ["--stereo", "--only-headline"]])

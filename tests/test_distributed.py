@@ -49,3 +49,42 @@ def test_sharded_melspec_allgather_gloo(world, n_total):
         outs.append((p.returncode, o, e))
     for rc, o, e in outs:
         assert rc == 0 and "RANK-OK" in o, e[-3000:]
+
+
+def test_direct_allgather_indexing_emulated():
+    """aud_gather_* (the direct-pattern all-gather: one device-to-device push per peer) on the CPU emulator: three ranks as
+    three contexts of one process (the emulator's inter-process handle carries the pointer), uneven counts, two rounds --
+    every rank's receive buffer ends up [slot r] = rank r's slab, nothing beyond a slab's count is touched, and the
+    misuse paths are AUD_EINVAL"""
+    import ctypes as C
+    import numpy as np
+    sys.path.insert(0, os.path.join(HERE, "emul"))
+    import backend
+    from auditory_amd import capi, runtime
+    from auditory_amd.batch import DirectGather
+    G, slab = 3, 1000
+    with backend.emulated("plain"):
+        ctxs = [runtime.Context(0) for _ in range(G)]
+        gs = [DirectGather(ctxs[r], G, r, slab) for r in range(G)]
+        with pytest.raises(capi.AuditoryError):                       # peers not opened yet
+            gs[0].allgather(0, 10)
+        for g in gs:
+            g.open_peers([x.handle for x in gs])
+        with pytest.raises(capi.AuditoryError):
+            gs[0].open_peers([x.handle for x in gs])                  # twice
+        bufs = [np.ctypeslib.as_array(C.cast(g.recv_ptr, C.POINTER(C.c_float)), shape=(G, slab)) for g in gs]
+        for rnd, counts in enumerate(([1000, 700, 1], [5, 1000, 999])):
+            for b in bufs:
+                b[:] = -1.0
+            sends = [np.arange(counts[r], dtype=np.float32) + 1000.0 * (r + 1) + rnd for r in range(G)]
+            for r in range(G):
+                gs[r].allgather(sends[r].ctypes.data, counts[r])
+            for b in bufs:
+                for r in range(G):
+                    assert np.array_equal(b[r, :counts[r]], sends[r]) and (b[r, counts[r]:] == -1.0).all()
+        with pytest.raises(capi.AuditoryError):
+            gs[1].allgather(sends[1].ctypes.data, slab + 1)           # more than the slab
+        for g in gs:
+            g.close()
+        for c in ctxs:
+            c.close()

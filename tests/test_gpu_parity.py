@@ -5,6 +5,8 @@ Tolerances (BASELINE.json north_star: 1e-5 relative on the float32 tensors):
   f32 compute : |got - ref| <= 1e-5 * max(1, |ref|)  on broadband inputs
   f64 compute : |got - ref| <= 3e-7 * max(1, |ref|)  (float32 output rounding only)
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -324,3 +326,17 @@ def test_rccl_allgather_single_rank(torch_cuda):
         assert torch.equal(send, recv)
     finally:
         lib.aud_comm_destroy(ctx.handle)
+
+
+def test_direct_allgather_two_processes_one_gpu(torch_cuda, tmp_path):
+    """aud_gather_* with REAL inter-process handles: two processes on this one GPU exchange their receive buffers' handles
+    through files, push their slabs into each other (hipIpcOpenMemHandle + device-to-device copies on the per-peer
+    streams, inside a captured hipGraph on one of them) and check both buffers"""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gather_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0 and "GATHER-OK" in o, (o[-1000:], e[-3000:])
