@@ -17,7 +17,8 @@
 
 struct aud_ctx {
     int device = -1;
-    std::string err = "";
+    std::string err = "";          // last error message, under err_mutex (entry points may fail concurrently)
+    std::mutex err_mutex;
     hipStream_t stream = nullptr;  // used by the _host entry points
     std::mutex host_mutex;         // ... which serialise on it (HostCallGuard)
     // grow-only device workspaces for the _host entry points
@@ -77,7 +78,10 @@ int64_t item_last(const aud_item& it) {
 }
 
 int fail(aud_ctx* c, int code, const std::string& msg) {
-    if (c) c->err = msg;
+    if (c) {
+        std::lock_guard<std::mutex> lk(c->err_mutex);
+        c->err = msg;
+    }
     return code;
 }
 
@@ -427,7 +431,13 @@ int aud_shutdown(aud_ctx* c) {
     return AUD_OK;
 }
 
-const char* aud_last_error(const aud_ctx* c) { return c ? c->err.c_str() : "null context"; }
+const char* aud_last_error(const aud_ctx* c) {
+    if (!c) return "null context";
+    static thread_local std::string copy;  // valid until this thread's next call
+    std::lock_guard<std::mutex> lk(const_cast<aud_ctx*>(c)->err_mutex);
+    copy = c->err;
+    return copy.c_str();
+}
 int aud_device_id(const aud_ctx* c) { return c ? c->device : -1; }
 
 int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, const double* mel_filters,

@@ -405,14 +405,13 @@ __device__ __forceinline__ void pairs_take(const MelspecArgs& a, const aud_item&
 __device__ __forceinline__ float dev_log(float v) { return logf(v); }
 __device__ __forceinline__ double dev_log(double v) { return log(v); }
 
-// ln of a float64 band power whose result is stored as float32 (mel.go:133-139, dft.go:76-82): mantissa and exponent
-// are split in float64 (two instructions), the logarithm of the mantissa is taken in float32 and the exponent's
-// share added with one fused multiply-add.  Error: the float32 rounding of the mantissa (6e-8), logf's last place
-// on a value in [-0.7, 0] and the rounding of the result -- all below the float32 spacing of the stored value --
-// instead of ~100 float64 instructions and their constants.  Any magnitude a double can hold takes this route
-// (no range branch); zero, negative and NaN inputs behave as in log().
-// v = m 2^ex with 0.5 <= m < 1 (frexp), ln v = ex ln 2 + log2(m) ln 2 with log2 from the hardware's v_log_f32 (1 ulp):
-// no range or denormal fix-ups are needed because m is always in [0.5, 1) -- 8 instructions instead of logf's 25.
+// ln of a band power whose result is stored as float32 (mel.go:133-139, dft.go:76-82): v = m 2^ex with 0.5 <= m < 1
+// (frexp; exact in either type), ln v = ex ln 2 + log2(m) ln 2 with log2 from the hardware's v_log_f32 (1 ulp) and one
+// fused multiply-add -- 8 instructions instead of logf's 25 or log()'s ~100; no range or denormal fix-ups because m is
+// always in [0.5, 1).  Error: ABSOLUTE, about 1e-7 (the float32 rounding of m, of log2(m) ln 2 in [-0.7, 0] and of the
+// result) -- below the float32 spacing of the stored value once |ln v| >= 1, but a relative error of up to ~1e-7 / |ln v|
+// for v close to 1 (where ex ln 2 and log2(m) ln 2 cancel): inside the 1e-5 max(1, |ref|) criterion everywhere.
+// Zero, negative and NaN inputs behave as in log().
 __device__ __forceinline__ float mantissa_log(float m, int ex) {
     const float ln2 = 0.693147180559945309417f;
     return fmaf(float(ex), ln2, __builtin_amdgcn_logf(m) * ln2);

@@ -306,8 +306,9 @@ size_t kwta_lds_bytes(int n, int lay_n, bool compact) {
 }
 
 hipError_t kwta_prepare(unsigned lds_bytes) {
+    // the attribute belongs to the kernel, not to a call: only ever raised, to the device's limit
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kwta), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               int(lds_bytes));
+                               lds_bytes > 0 ? 160 * 1024 : 0);
 }
 
 hipError_t launch_kwta(const KwtaArgs& a, hipStream_t st) {

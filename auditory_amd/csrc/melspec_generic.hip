@@ -267,7 +267,8 @@ hipError_t melspec_generic_prepare(size_t lds_bytes) {
     const void* fns[2] = {reinterpret_cast<const void*>(&k_melspec_generic<double>),
                           reinterpret_cast<const void*>(&k_melspec_generic<float>)};
     for (const void* fn : fns) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
+        // the attribute belongs to the kernel, not to a plan: only ever raised, to the device's limit
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes > 0 ? 160 * 1024 : 0);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

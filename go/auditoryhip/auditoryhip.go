@@ -20,6 +20,7 @@ import (
 	"github.com/emer/vision/kwta"
 	"errors"
 	"fmt"
+	"sync"
 	"unsafe"
 )
 
@@ -301,17 +302,15 @@ func SndToWindow(signal []float64, start, winSamples int, window []float64) erro
 }
 
 // Default is the process-wide context the drop-in packages (go/dft, go/mel, go/agabor, go/sound) share.
-var defaultCtx *Ctx
+var (
+	defaultCtx  *Ctx
+	defaultErr  error
+	defaultOnce sync.Once
+)
 
 func Default() (*Ctx, error) {
-	if defaultCtx == nil {
-		c, err := Init(0)
-		if err != nil {
-			return nil, err
-		}
-		defaultCtx = c
-	}
-	return defaultCtx, nil
+	defaultOnce.Do(func() { defaultCtx, defaultErr = Init(0) }) // goroutines race to the first call
+	return defaultCtx, defaultErr
 }
 
 // ---- plain-Go mirrors of the C parameter blocks, for the drop-in packages (no C types in their signatures) -------

@@ -117,16 +117,41 @@ func (se *SndEnv) Init() (err error) {
 	se.Params.WinSamples, se.Params.StepSamples = d.WinSamples, d.StepSamples
 	se.Params.SegmentSamples, se.Params.StrideSamples, se.Params.SegmentSteps = d.SegmentSamples, d.StrideSamples, d.SegmentSteps
 	T, H, nf := se.Params.SegmentSteps, se.Params.WinSamples/2+1, se.Mel.FBank.NFilters
+
+	// the gabor set and the output tensors' shapes (sndenv.go:209-227): active specs -> taps, 2-D or 4-D output
+	specs := agabor.Active(se.GaborSpecs)
+	nfilters := len(specs)
+	se.GaborFilters.Filters.SetShape([]int{nfilters, se.GaborFilters.SizeY, se.GaborFilters.SizeX}, nil, nil)
+	agabor.ToTensor(specs, &se.GaborFilters)
+	se.GaborFilters.ToTable(se.GaborFilters, &se.GaborTab)
+	if se.GborOutPoolsX == 0 && se.GborOutPoolsY == 0 { // 2D
+		se.GborOutput.SetShape([]int{se.GborOutUnitsY, se.GborOutUnitsX}, nil, nil)
+		se.ExtGi.SetShape([]int{se.GborOutUnitsY, se.GborOutUnitsX}, nil, nil)
+	} else if se.GborOutPoolsX > 0 && se.GborOutPoolsY > 0 { // 4D
+		se.GborOutput.SetShape([]int{se.GborOutPoolsY, se.GborOutPoolsX, se.GborOutUnitsY, se.GborOutUnitsX}, nil, nil)
+		se.ExtGi.SetShape([]int{se.GborOutPoolsY, se.GborOutPoolsX, 2, nfilters}, nil, nil)
+	} else {
+		log.Println("GborOutPoolsX & GborOutPoolsY must both be == 0 or > 0 (i.e. 2D or 4D)")
+		return err // (nil, as in the reference: :224-226)
+	}
+	se.GborOutput.SetMetaData("odd-row", "true")
+	se.GborOutput.SetMetaData("grid-fill", ".9")
+	se.GborKwta.CopyShapeFrom(&se.GborOutput)
+	se.GborKwta.CopyMetaData(&se.GborOutput)
+
+	se.DFT.Defaults() // sndenv.go:230: Init RESETS the DFT parameters (a user's PrevSmooth etc. must be set after Init)
+	se.Mel.InitFilters(se.Params.WinSamples, sr, &se.MelFilters)
+	se.Window.SetShape([]int{se.Params.WinSamples}, nil, nil)
+	se.Power.SetShape([]int{H}, nil, nil)
+	se.LogPower.CopyShapeFrom(&se.Power)
+	se.PowerSegment.SetShape([]int{H, T}, nil, nil)
+	if se.DFT.CompLogPow {
+		se.LogPowerSegment.CopyShapeFrom(&se.PowerSegment)
+	}
 	se.Params.Steps = make([]int, T)
 	for i := range se.Params.Steps {
 		se.Params.Steps[i] = se.Params.StepSamples * (i - se.Params.BorderSteps)
 	}
-	se.Window.SetShape([]int{se.Params.WinSamples}, nil, nil)
-	se.Power.SetShape([]int{H}, nil, nil)
-	se.LogPower.SetShape([]int{H}, nil, nil)
-	se.PowerSegment.SetShape([]int{H, T}, nil, nil)
-	se.LogPowerSegment.SetShape([]int{H, T}, nil, nil)
-	se.Mel.InitFilters(se.Params.WinSamples, sr, &se.MelFilters)
 	se.MelFBank.SetShape([]int{nf}, nil, nil)
 	se.MelFBankSegment.SetShape([]int{nf, T}, nil, nil)
 	se.Energy.SetShape([]int{T}, nil, nil)
@@ -164,8 +189,12 @@ func (se *SndEnv) item(segment, add int) auditoryhip.Item {
 }
 
 // ProcessSegment: sound/sndenv.go:342-435 -- one launch for the T steps of the segment.  A window that runs past the
-// signal leaves that step and all later ones zero, as the reference's print-and-break does (:354-358).
+// signal leaves that step and all later ones zero, as the reference's print-and-break does (:354-358).  The per-step
+// tensors Power / LogPower are zeroed like the segment tensors (:343-351; the device path never fills them: they are the
+// reference's per-step scratch), and Energy is computed whether or not Mel.MFCC is set (:360-366).
 func (se *SndEnv) ProcessSegment(segment, add int) {
+	se.Power.SetZeros()
+	se.LogPower.SetZeros()
 	items := []auditoryhip.Item{se.item(segment, add)}
 	var err error
 	if se.Mel.MFCC {
@@ -173,6 +202,15 @@ func (se *SndEnv) ProcessSegment(segment, add int) {
 			se.LogPowerSegment.Values, se.MFCCSegment.Values, se.MFCCDeltas.Values, se.MFCCDeltaDeltas.Values, se.Energy.Values)
 	} else {
 		err = se.plan.MelSpec(se.Signal.Values, items, se.MelFBankSegment.Values, se.PowerSegment.Values, se.LogPowerSegment.Values)
+		// Energy[s] = sum over f < SegmentSteps of LogPowerSegment row s (the reference's axis, SURVEY Q8)
+		T := se.Params.SegmentSteps
+		for s := 0; s < T; s++ {
+			e := 0.0
+			for f := 0; f < T; f++ {
+				e += se.LogPowerSegment.Values[s*T+f]
+			}
+			se.Energy.Values[s] = e
+		}
 	}
 	if err != nil {
 		fmt.Println(err)
