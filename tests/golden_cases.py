@@ -60,3 +60,69 @@ def check_library_against_golden(name, compute_dtype):
             assert np.array_equal(act, gold["kwta"]), (name, "kwta")
     finally:
         plan.close()
+
+
+REF_DIR = os.path.join(HERE, "golden", "ref")
+
+
+def reference_dumps(name):
+    """[(row, segment, {kind: path})] of what go/cmd/refdump wrote for fixture `name` (empty where it has not been run)"""
+    cfg, seg_ms, dur, rows, segs, seed, gab = G.FIXTURES[name]
+    found = []
+    for r in range(rows):
+        for s in segs:
+            files = {k: os.path.join(REF_DIR, "%s_r%d_s%d_%s" % (name, r, s, ext))
+                     for k, ext in (("mel", "mel.f64"), ("logpower", "logpower.f64"), ("gabor", "gabor.f32"))}
+            files = {k: p for k, p in files.items() if os.path.exists(p)}
+            if "mel" in files:
+                found.append((r, s, files))
+    return found
+
+
+def check_oracle_against_reference(name):
+    """THE pin: outputs of the real reference (emer/auditory, dumped by go/cmd/refdump from the WAVs of
+    tests/golden/make_ref_inputs.py) against the oracle on the same samples -- two float64 implementations of the same
+    arithmetic with different FFTs: 1e-9 of max(1, |ref|)"""
+    from oracle import oracle as orc
+    oc, sig, pcm, items, gab = G.inputs(name)
+    n = 0
+    for r, s, files in reference_dumps(name):
+        o = orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig[r], segment=s)
+        ref_mel = np.fromfile(files["mel"], "<f8").reshape(oc.nf, oc.T)
+        ok, msg = W.close_enough(o["mel_seg"], ref_mel, 1e-9)
+        assert ok, (name, r, s, "mel", msg)
+        if "logpower" in files:
+            ref_lp = np.fromfile(files["logpower"], "<f8").reshape(oc.H, oc.T)
+            ok, msg = W.close_enough(o["log_power_seg"], ref_lp, 1e-9)
+            assert ok, (name, r, s, "log_power", msg)
+        if gab and "gabor" in files:
+            py, px = G.GABOR[gab]
+            ref_g = np.fromfile(files["gabor"], "<f4").reshape(py, px, 2, 8)
+            g = np.zeros((py, px, 2, 8), np.float32)
+            assert orc.gabor_convolve(o["mel_seg"], orc.gabor_to_tensor(W.DEFAULT_GABOR_SPECS, 9, 9), 3, 3, 2.0, g) == 0
+            ok, msg = W.close_enough(g, ref_g, 1e-6)
+            assert ok, (name, r, s, "gabor", msg)
+        n += 1
+    return n
+
+
+def check_library_against_reference(name, compute_dtype):
+    """the shipped C ABI (GPU, or the emulator build) against the real reference's dumps, north-star criterion"""
+    oc, sig, pcm, items, gab = G.inputs(name)
+    dumps = reference_dumps(name)
+    if not dumps:
+        return 0
+    L = sig.shape[1]
+    its = runtime.make_items([r * L for r, s, _ in dumps], [L] * len(dumps), [s * oc.sp.stride_samples for r, s, _ in dumps])
+    plan = W.product_plan(oc, compute_dtype)
+    try:
+        mel, _, _ = plan.melspec_host(sig.ravel(), its)
+    finally:
+        plan.close()
+    ref = np.stack([np.fromfile(f["mel"], "<f8").reshape(oc.nf, oc.T) for _, _, f in dumps])
+    if compute_dtype == capi.AUD_F64:
+        ok, msg = W.close_enough(mel, ref, 1e-5)
+    else:
+        ok, msg = W.feature_close(mel, ref, compute_dtype, lin_axis=1)
+    assert ok, (name, "mel vs the reference", msg)
+    return len(dumps)
