@@ -243,7 +243,7 @@ def main():  # noqa: C901
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
-    ap.add_argument("--workload", choices=["headline", "cfg4", "cfg5", "cfg1", "sndenv"], default="headline",
+    ap.add_argument("--workload", choices=["headline", "n512", "cfg4", "cfg5", "cfg1", "sndenv"], default="headline",
                     help="headline: the judged line (N = 400; the other BASELINE configurations nested under `also`).  "
                          "Stand-alone lines for BASELINE.md's table: cfg4 = headline + agabor.Convolve (default FilterSet, "
                          "[11,32,2,8] pools); cfg5 = 44.1 kHz 5 s streams, N = 2048, 128 mel (use --batch 1280 for >= 1 GB "
@@ -592,7 +592,7 @@ def main():  # noqa: C901
         return res
 
     # ---------------------------------------------------------------------------------------------------
-    stand_alone = args.workload if args.workload in ("cfg5", "cfg1") else "n400"
+    stand_alone = args.workload if args.workload in ("cfg5", "cfg1", "n512") else "n400"
     head_wl = Workload(stand_alone)
     kind = {"cfg4": "gabor", "sndenv": "full"}.get(args.workload, "mel")
     head = time_mode(head_wl, args.compute, kind=kind)
@@ -647,6 +647,7 @@ def main():  # noqa: C901
             "sndenv": "the whole unmodified SndEnv.ProcessSegment loop on the metric's parameters (mel + Power + LogPower "
                       "tensors + MFCC tail with deltas and Energy: SURVEY 8 f-1, f-2): ",
             "cfg1": "BASELINE configs[0] parameters (N = 1103), one 100 ms segment per item: ",
+            "n512": "BASELINE configs[1] as worded (512-point FFT: WinMs 32): ",
             "cfg5": "BASELINE configs[4]: "}[args.workload]
     top = cfg3 if cfg3 is not None else head      # several GPUs: configs[2] as stated is the line's value
     line = {

@@ -207,7 +207,7 @@ def test_rocprof_summary_on_synthetic_csvs(tmp_path):
     """tools/rocprof_summary.py against CSVs laid out like rocprofv3's (<dir>/<pass>/<host>/<pid>_*.csv): the
     per-launch HBM bytes it hands to bench.py (FETCH_SIZE doubled and in KB, WRITE_SIZE in KB, per the guide)"""
     import subprocess
-    k = "void aud::(anonymous namespace)::k_melspec_w16<float, 4, 4>(aud::MelspecArgs, aud::WaveArgs)"
+    k = "void aud::(anonymous namespace)::k_melspec_w20<double, 0, 4, 4>(aud::MelspecArgs, aud::WaveArgs)"
     d = tmp_path / "prof"
     (d / "stats" / "box" ).mkdir(parents=True)
     (d / "stats" / "box" / "77_kernel_stats.csv").write_text(
@@ -226,8 +226,10 @@ def test_rocprof_summary_on_synthetic_csvs(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), str(d), "rXX", str(out)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert "k_melspec_w16" in r.stdout and "5000.0" in r.stdout
+    assert "k_melspec_w20" in r.stdout and "5000.0" in r.stdout
     t = json.load(open(out / "pmc_traffic.json"))
     assert t["read_bytes"] == 2 * 8000.0 * 1024 and t["write_bytes"] == 4160.0 * 1024
     assert t["read_bytes_raw_fetch_size"] == 8000.0 * 1024
-    assert t["hbm_bytes_per_launch"] == t["read_bytes"] + t["write_bytes"] and "w16" in t["kernel"]
+    assert t["hbm_bytes_per_launch"] == t["read_bytes"] + t["write_bytes"] and "w20" in t["kernel"]
+    kj = json.load(open(out / "rXX_kernels.json"))["kernels"][k]
+    assert kj["family"] == "w20x10" and kj["compute"] == "f64" and kj["avg_duration_ns"] == 5000.0 and kj["write_bytes"] == 4160.0 * 1024

@@ -36,6 +36,11 @@ for step in "$@"; do
                run profile$i 900 bash tools/profile_bench.sh "${TAG}_$i" $args ;;
         stamps:*) args=$(echo "${step#stamps:}" | tr ',' ' ')
                run stamps$i 400 python tools/stamp_profile.py $args ;;
+        trace) mkdir -p "gpurun_out/trace_${TAG}"
+               (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OLDPWD/gpurun_out/trace_${TAG}" -- \
+                    python3 "$OLDPWD/bench.py" --only-headline --no-cpu-baseline --min-seconds 0.05 > "$OLDPWD/gpurun_out/${TAG}_trace.log" 2>&1)
+               rc=$?; echo "[gpu_call] trace rc=$rc"; if [ $rc -eq 124 ] || [ $rc -ge 128 ]; then exit $rc; fi
+               python3 tools/trace_overlap.py "gpurun_out/trace_${TAG}" > "gpurun_out/${TAG}_graph_overlap.txt" 2>&1; cat "gpurun_out/${TAG}_graph_overlap.txt" ;;
         ubench) (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_rates valu_rates.hip) &&
                 run ubench 120 /tmp/valu_rates ;;
         *) echo "unknown step $step"; exit 2 ;;

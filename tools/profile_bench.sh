@@ -12,6 +12,8 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT" "$ROOT/profiles"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --only-headline --launch eager --min-seconds 0.02 $*"
+export AUD_PROFILE_ARGS="$*"
+case " $* " in *" --batch "*) export AUD_PROFILE_BATCH=$(echo " $* " | sed -e 's/.* --batch \([0-9]*\) .*/\1/');; esac
 pass() {  # pass <name> <rocprofv3 args...>: a timeout or a death by signal ends the script (no GPU step after it)
     local name=$1; shift
     echo "[profile] $name pass"
@@ -30,5 +32,5 @@ python3 "$ROOT/tools/rocprof_summary.py" "$OUT" "$TAG" > "$ROOT/profiles/${TAG}_
 cat "$ROOT/profiles/${TAG}_summary.txt"
 for f in $(find "$OUT/stats" -name "*kernel_stats.csv" | head -1); do cp "$f" "$ROOT/profiles/${TAG}_kernel_stats.csv"; done
 # only gpurun_out/ travels back from the GPU box: copy what has to be committed under profiles/
-cp "$ROOT/profiles/${TAG}_summary.txt" "$ROOT/profiles/${TAG}_kernel_stats.csv" "$ROOT/profiles/pmc_traffic.json" "$ROOT/gpurun_out/" 2>/dev/null
+cp "$ROOT/profiles/${TAG}_summary.txt" "$ROOT/profiles/${TAG}_kernel_stats.csv" "$ROOT/profiles/${TAG}_kernels.json" "$ROOT/profiles/pmc_traffic.json" "$ROOT/gpurun_out/" 2>/dev/null
 true

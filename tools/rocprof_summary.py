@@ -44,27 +44,50 @@ def main():
             note = ""
             if n == "FETCH_SIZE":
                 note = "  => HBM read  ~ %.3f MB/launch (x2 gfx950 correction, KB units)" % (2 * mean * 1024 / 1e6)
-                if "melspec" in k:
+                if "k_" in k:
                     traffic.setdefault(k, {})["read_bytes"] = 2 * mean * 1024
                     # the guide calibrates the x2 for 16 B/lane streaming reads; the wave kernels read
                     # 8 B per lane, which it lists as uncalibrated -- keep the raw figure next to the corrected one
                     traffic[k]["read_bytes_raw_fetch_size"] = mean * 1024
             if n == "WRITE_SIZE":
                 note = "  => HBM write ~ %.3f MB/launch (KB units)" % (mean * 1024 / 1e6)
-                if "melspec" in k:
+                if "k_" in k:
                     traffic.setdefault(k, {})["write_bytes"] = mean * 1024
             print("%-70s %-12s %7d %14.1f%s" % (k[:70], n, cnt, mean, note))
-    # what bench.py reports as roofline.traffic: HBM bytes per launch of the frame->mel kernel
-    best = None
-    fams = {"k_melspec_w20": "w20x10", "k_melspec_w16": "w16x16", "k_melspec_w64": "w64x16", "k_melspec_generic": "generic"}
+    # per hot kernel: average duration, HBM bytes per launch and the SQ counters per launch -> profiles/<tag>_kernels.json
+    # (tools/roofline_table.py builds profiles/ROOFLINE.md from these); the headline kernel's traffic also goes to
+    # profiles/pmc_traffic.json, what bench.py reports as roofline.traffic
+    fams = {"k_melspec_w20": "w20x10", "k_melspec_w16": "w16x16", "k_melspec_w64": "w64x16", "k_melspec_generic": "generic",
+            "k_gabor": "gabor", "k_mfcc_fused": "mfcc", "k_kwta": "kwta"}
     avg_ns = {r.get("Name", ""): float(r.get("AverageNs", r.get("Average", 0)) or 0) for r in stats}
+    calls = {r.get("Name", ""): int(float(r.get("Calls", 0) or 0)) for r in stats}
+    sq = {}
+    for ctr in ("sqa", "sqb"):
+        for r in rows(os.path.join(out, ctr, "**", "*counter_collection.csv")):
+            k = r.get("Kernel_Name", r.get("Kernel Name", "?"))
+            d = sq.setdefault(k, {}).setdefault(r.get("Counter_Name", r.get("Counter Name", "?")), [0, 0.0])
+            d[0] += 1
+            d[1] += float(r.get("Counter_Value", r.get("Counter Value", "0")) or 0)
+    kernels = {}
+    for k, ns in avg_ns.items():
+        fam = next((f for key, f in fams.items() if key in k), None)
+        if fam is None:
+            continue
+        v = traffic.get(k, {})
+        kernels[k] = {"family": fam, "compute": "f64" if "<double" in k else "f32", "calls": calls.get(k), "avg_duration_ns": ns,
+                      "read_bytes": v.get("read_bytes"), "write_bytes": v.get("write_bytes"),
+                      "read_bytes_raw_fetch_size": v.get("read_bytes_raw_fetch_size"),
+                      "counters_per_launch": {n: round(t / max(c, 1), 1) for n, (c, t) in sq.get(k, {}).items()}}
+    with open(os.path.join(prof_dir, "%s_kernels.json" % tag), "w") as fh:
+        json.dump({"tag": tag, "bench_args": os.environ.get("AUD_PROFILE_ARGS", ""), "kernels": kernels}, fh, indent=1)
+    best = None
     for k, v in traffic.items():
-        if "read_bytes" in v and "write_bytes" in v:
+        if "read_bytes" in v and "write_bytes" in v and "k_melspec" in k:
             fam = next((f for key, f in fams.items() if key in k), "?")
             best = {"kernel": k, "family": fam, "compute": "f64" if "<double" in k else "f32",
                     "batch": int(os.environ.get("AUD_PROFILE_BATCH", "256")),
                     "avg_duration_ns": avg_ns.get(k), "hbm_bytes_per_launch": v["read_bytes"] + v["write_bytes"], "tag": tag, **v}
-    if best:
+    if best and best["family"] == "w20x10" and best["compute"] == "f64" and best["batch"] == 256:
         with open(os.path.join(prof_dir, "pmc_traffic.json"), "w") as fh:
             json.dump(best, fh, indent=1)
         print("## wrote profiles/pmc_traffic.json:", best)
