@@ -360,6 +360,18 @@ __device__ __forceinline__ void pairs_issue(const SampleWindow<SRC>& w, int64_t 
         }
     }
 }
+// max(m, |x|, |y|) as ONE instruction (v_max3_f32 with the abs source modifiers; a NaN operand is ignored).  hipcc turns
+// fmaxf(m, fmaxf(fabsf(x), fabsf(y))) into 3.5 instructions per pair (canonicalising self-maxes): 70 instead of 20 per
+// tile of the N = 400 kernel.  (tests/emul/hip/hip_runtime.h defines AUD_EMUL_ABSMAX3 with the same semantics for the CPU
+// thread emulator, which cannot assemble it.)
+#ifndef AUD_EMUL_ABSMAX3
+__device__ __forceinline__ float absmax3(float m, float x, float y) {
+    float r;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(x), "v"(y));
+    return r;
+}
+#endif
+
 // convert what pairs_issue requested -- or, for float64 samples, load them here.  `amax` receives the largest sample
 // magnitude the lane holds (the frame's scale comes from it, frame_scale below).
 template <typename TT, int SRC, int NV, int STRIDE>
@@ -371,7 +383,7 @@ __device__ __forceinline__ void pairs_take(const MelspecArgs& a, const aud_item&
         for (int n1 = 0; n1 < NV; ++n1) {
             const float x = __uint_as_float(r.lo[n1]), y = __uint_as_float(r.hi[n1]);
             v[n1] = C2<TT>{TT(x), TT(y)};
-            m = fmaxf(m, fmaxf(fabsf(x), fabsf(y)));
+            m = absmax3(m, x, y);
         }
         amax = TT(m);
     } else if constexpr (SRC == AUD_I16) {

@@ -44,6 +44,9 @@ struct alignas(16) uint4 {
     unsigned x, y, z, w;
 };
 inline void __builtin_amdgcn_sched_barrier(int) {}
+// device_common.h absmax3 (one v_max3_f32 with abs modifiers on the GPU): NaN operands are ignored, as the instruction does
+#define AUD_EMUL_ABSMAX3 1
+inline float absmax3(float m, float x, float y) { return fmaxf(m, fmaxf(fabsf(x), fabsf(y))); }
 inline float __builtin_amdgcn_logf(float v) { return log2f(v); }  // v_log_f32 is a base-2 logarithm
 // same-value races the 20 x 10 wave kernel has by design (shadow lanes): ThreadSanitizer is told to look away
 #if defined(__SANITIZE_THREAD__)

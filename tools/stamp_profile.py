@@ -39,6 +39,11 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--win-ms", type=float, default=32.0)
     ap.add_argument("--compute", choices=["f32", "f64"], default="f64")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="N > 0: instead of one launch, a hipGraph of N launches dealt over two streams as bench.py does (two "
+                         "plans, each with its own stamp buffer); prints when, on the chip-wide 100 MHz counter, the waves of "
+                         "the LAST launch of each stream started and ended -- the overlap the two-stream step time comes from "
+                         "(rocprofv3's kernel trace serialises the launches of a graph, so it cannot show this)")
     args = ap.parse_args()
 
     import torch
@@ -74,6 +79,61 @@ def main():
     plan.set_option("stamps_hi", C.c_int32((ptr >> 32) & 0xFFFFFFFF).value)
     bp = BatchProcessor(plan, dev)
     items = bp.upload_items(runtime.make_items(np.arange(B) * L, [L] * B, [0] * B))
+    if args.pipeline > 0:
+        n = args.pipeline
+        plans, bufs = [plan], [stamps]
+        for _ in range(n - 1):   # one plan (= one stamp buffer) per launch of the graph
+            p2 = W.product_plan(oc, cdt)
+            sb = torch.zeros((n_waves, 16), dtype=torch.int64, device=dev)
+            p2.set_option("stamps_lo", C.c_int32(sb.data_ptr() & 0xFFFFFFFF).value)
+            p2.set_option("stamps_hi", C.c_int32((sb.data_ptr() >> 32) & 0xFFFFFFFF).value)
+            plans.append(p2)
+            bufs.append(sb)
+        mels = [torch.empty((B, oc.nf, oc.T), dtype=torch.float32, device=dev) for _ in range(2)]
+        side = torch.cuda.Stream(dev)
+        for p in plans:
+            p.melspec_dev(dsig.data_ptr(), capi.AUD_F32, items.data_ptr(), B, mels[0].data_ptr(), 0, 0,
+                          torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            main_s = torch.cuda.current_stream(dev)
+            side.wait_stream(main_s)
+            for i in range(n):
+                st = (main_s, side)[i % 2]
+                plans[i].melspec_dev(dsig.data_ptr(), capi.AUD_F32, items.data_ptr(), B, mels[i % 2].data_ptr(), 0, 0, st.cuda_stream)
+            main_s.wait_stream(side)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        print("kernel %s, %s, batch %d: hipGraph of %d launches alternating between two streams: %.2f us per launch (diagnostic "
+              "build: the stamps cost time; every launch has its own stamp buffer)" % (plan.kernel_name, args.compute, B, n,
+                                                                                   e0.elapsed_time(e1) * 1e3 / n))
+        spans = []
+        for i, sb in enumerate(bufs):
+            sv = sb.cpu().numpy().astype(np.int64)
+            ok = sv[:, 8] > 0
+            spans.append((i, sv[ok, 9].min(), np.median(sv[ok, 9]), np.median(sv[ok, 10]), sv[ok, 10].max()))
+        base = min(sp[1] for sp in spans)
+        print("launch  stream   first wave start   median start   median end   last wave end   (us, chip-wide 100 MHz counter)")
+        for i, a0, am, bm, b1 in spans:
+            print("%5d   %s     %12.2f   %12.2f   %10.2f   %12.2f" % (i, "AB"[i % 2], (a0 - base) / 100.0, (am - base) / 100.0,
+                                                                 (bm - base) / 100.0, (b1 - base) / 100.0))
+        order = sorted(spans, key=lambda sp: sp[1])
+        ov = [max(0, order[k][4] - order[k + 1][1]) / max(1, order[k][4] - order[k][1]) for k in range(len(order) - 1)]
+        print("consecutive launches (by first wave start) share the chip for %s of the earlier one's span"
+              % ", ".join("%.0f %%" % (100 * x) for x in ov))
+        print("mean start-to-start interval %.2f us, mean span of one launch %.2f us" % (
+            (order[-1][1] - order[0][1]) / 100.0 / max(1, len(order) - 1), np.mean([(sp[4] - sp[1]) / 100.0 for sp in spans])))
+        for p in plans[1:]:
+            p.close()
+        plan.close()
+        return
     mel = torch.empty((B, oc.nf, oc.T), dtype=torch.float32, device=dev)
     st = torch.cuda.current_stream(dev).cuda_stream
     for _ in range(20):
