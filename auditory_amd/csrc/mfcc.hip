@@ -75,8 +75,12 @@ __global__ __launch_bounds__(256) void k_mfcc_deltas(const MfccArgs a, const flo
 // matrix and the DCT rows are staged in LDS once (coalesced), the DCT reads them from there (the three-kernel form re-read
 // every mel value 13 times through L1), the Energy rows are summed by a wave each with lanes along the steps (coalesced;
 // the one-thread-per-row form walked 104 cache lines per load instruction), and the deltas / delta-deltas read the
-// float32-ROUNDED coefficients back from LDS, as the reference reads its float32 tensors.  Same arithmetic and the same
-// summation order as the kernels above, except that an Energy row is a tree sum of its float64-widened values.
+// float32-ROUNDED coefficients back from LDS.  That rounding is THIS library's, not the reference's: MelFBankSegment,
+// LogPowerSegment, MFCCSegment and MFCCDeltas are etensor.Float64 in the reference (sound/sndenv.go:106-136), the boundary
+// here carries float32 tensors (north star: "1e-5 relative on the float32 mel / gabor tensors"), so the tail's inputs
+// differ from the reference's by their float32 rounding (deviations) -- what the tail's tolerances cover.
+// Same arithmetic and the same summation order as the kernels above, except that an Energy row is a tree sum of its
+// float64-widened values.
 constexpr int kFusedThreads = 512;
 
 template <typename TT>
