@@ -1,0 +1,187 @@
+// C ABI, the reassembly collective of the sharded path: RCCL (bound lazily) and the direct device-to-device all-gather.
+// See include/auditory_hip.h.
+#include "capi_internal.h"
+
+using namespace audc;
+
+// ---- RCCL, bound lazily so that single-GPU users never load it ---------------------
+
+namespace {
+struct uid128 {
+    char b[128];
+};
+typedef int (*rccl_get_uid_t)(uid128*);
+typedef int (*rccl_comm_init_t)(void**, int, uid128, int);
+typedef int (*rccl_comm_destroy_t)(void*);
+typedef int (*rccl_allgather_t)(const void*, void*, size_t, int /*dtype*/, void*, hipStream_t);
+typedef const char* (*rccl_errstr_t)(int);
+
+void* rccl_open() {
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    return h;
+}
+constexpr int kNcclFloat32 = 7;  // ncclFloat32 in nccl.h / rccl.h
+}  // namespace
+
+
+extern "C" {
+
+int aud_comm_unique_id(char id[128]) {
+    if (!id) return AUD_EINVAL;
+    void* h = rccl_open();
+    if (!h) return AUD_ERCCL;
+    auto get = reinterpret_cast<rccl_get_uid_t>(dlsym(h, "ncclGetUniqueId"));
+    if (!get) return AUD_ERCCL;
+    uid128 u;
+    std::memset(&u, 0, sizeof(u));
+    if (get(&u) != 0) return AUD_ERCCL;
+    std::memcpy(id, u.b, 128);
+    return AUD_OK;
+}
+
+int aud_comm_init(aud_ctx* c, int n_ranks, int rank, const char id[128]) {
+    if (!c || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return AUD_EINVAL;
+    if (c->comm) return fail(c, AUD_EINVAL, "communicator already initialised");
+    AUD_HIP(c, make_current(c));
+    if (!c->rccl_lib) c->rccl_lib = rccl_open();
+    if (!c->rccl_lib) return fail(c, AUD_ERCCL, "cannot load librccl.so");
+    auto init = reinterpret_cast<rccl_comm_init_t>(dlsym(c->rccl_lib, "ncclCommInitRank"));
+    if (!init) return fail(c, AUD_ERCCL, "ncclCommInitRank not found");
+    uid128 u;
+    std::memcpy(u.b, id, 128);
+    void* comm = nullptr;
+    const int r = init(&comm, n_ranks, u, rank);
+    if (r != 0) {
+        auto es = reinterpret_cast<rccl_errstr_t>(dlsym(c->rccl_lib, "ncclGetErrorString"));
+        return fail(c, AUD_ERCCL, std::string("ncclCommInitRank: ") + (es ? es(r) : "error"));
+    }
+    c->comm = comm;
+    c->n_ranks = n_ranks;
+    c->rank = rank;
+    return AUD_OK;
+}
+
+int aud_comm_destroy(aud_ctx* c) {
+    if (!c) return AUD_EINVAL;
+    if (c->comm && c->rccl_lib) {
+        auto destroy = reinterpret_cast<rccl_comm_destroy_t>(dlsym(c->rccl_lib, "ncclCommDestroy"));
+        if (destroy) destroy(c->comm);
+    }
+    c->comm = nullptr;
+    return AUD_OK;
+}
+
+int aud_gather_create(aud_ctx* c, int n_ranks, int rank, int64_t slab_floats, float** recv, char handle[64]) {
+    if (!c || !recv || !handle || n_ranks < 1 || rank < 0 || rank >= n_ranks || slab_floats < 1) return AUD_EINVAL;
+    if (c->gather.recv) return fail(c, AUD_EINVAL, "gather buffer already created");
+    AUD_HIP(c, make_current(c));
+    aud_ctx::Gather& g = c->gather;
+    AUD_HIP(c, hipMalloc(reinterpret_cast<void**>(&g.recv), size_t(n_ranks) * size_t(slab_floats) * sizeof(float)));
+    hipIpcMemHandle_t h;
+    static_assert(sizeof(h) == 64, "hipIpcMemHandle_t is 64 bytes");
+    if (hipIpcGetMemHandle(&h, g.recv) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(g.recv);
+        g.recv = nullptr;
+        return fail(c, AUD_EHIP, "hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)");
+    }
+    std::memcpy(handle, &h, 64);
+    g.n_ranks = n_ranks;
+    g.rank = rank;
+    g.slab = slab_floats;
+    g.peer.assign(size_t(n_ranks), nullptr);
+    g.peer[size_t(rank)] = g.recv;
+    g.streams.assign(size_t(n_ranks), nullptr);
+    g.done.assign(size_t(n_ranks), nullptr);
+    AUD_HIP(c, hipEventCreateWithFlags(&g.fork, hipEventDisableTiming));
+    for (int p = 0; p < n_ranks; ++p) {
+        if (p == rank) continue;
+        AUD_HIP(c, hipStreamCreateWithFlags(&g.streams[size_t(p)], hipStreamNonBlocking));
+        AUD_HIP(c, hipEventCreateWithFlags(&g.done[size_t(p)], hipEventDisableTiming));
+    }
+    *recv = g.recv;
+    return AUD_OK;
+}
+
+int aud_gather_open_peer(aud_ctx* c, int peer, const char handle[64]) {
+    if (!c || !handle) return AUD_EINVAL;
+    aud_ctx::Gather& g = c->gather;
+    if (!g.recv) return fail(c, AUD_EINVAL, "aud_gather_create has not been called");
+    if (peer < 0 || peer >= g.n_ranks || peer == g.rank) return fail(c, AUD_EINVAL, "peer must be another rank of the gather");
+    if (g.peer[size_t(peer)]) return fail(c, AUD_EINVAL, "peer already opened");
+    AUD_HIP(c, make_current(c));
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, 64);
+    void* p = nullptr;
+    AUD_HIP(c, hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    g.peer[size_t(peer)] = static_cast<float*>(p);
+    return AUD_OK;
+}
+
+int aud_allgather_direct_dev(aud_ctx* c, const float* send, int64_t count, void* stream) {
+    if (!c || count < 0) return AUD_EINVAL;
+    aud_ctx::Gather& g = c->gather;
+    if (!g.recv) return fail(c, AUD_EINVAL, "aud_gather_create has not been called");
+    if (count > g.slab) return fail(c, AUD_EINVAL, "count exceeds the slab the gather was created for");
+    for (int p = 0; p < g.n_ranks; ++p)
+        if (!g.peer[size_t(p)]) return fail(c, AUD_EINVAL, "a peer's receive buffer has not been opened");
+    if (count == 0) return AUD_OK;
+    if (!send) return fail(c, AUD_EINVAL, "null buffer");
+    AUD_HIP(c, make_current(c));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t bytes = size_t(count) * sizeof(float), slot = size_t(g.rank) * size_t(g.slab);
+    // own slot on the caller's stream; one push per peer, each on its own stream (its own xGMI link), forked from and
+    // joined back into the caller's stream
+    AUD_HIP(c, hipMemcpyAsync(g.recv + slot, send, bytes, hipMemcpyDeviceToDevice, st));
+    if (g.n_ranks > 1) AUD_HIP(c, hipEventRecord(g.fork, st));
+    for (int p = 0; p < g.n_ranks; ++p) {
+        if (p == g.rank) continue;
+        hipStream_t sp = g.streams[size_t(p)];
+        AUD_HIP(c, hipStreamWaitEvent(sp, g.fork, 0));
+        AUD_HIP(c, hipMemcpyAsync(g.peer[size_t(p)] + slot, send, bytes, hipMemcpyDeviceToDevice, sp));
+        AUD_HIP(c, hipEventRecord(g.done[size_t(p)], sp));
+        AUD_HIP(c, hipStreamWaitEvent(st, g.done[size_t(p)], 0));
+    }
+    return AUD_OK;
+}
+
+int aud_gather_destroy(aud_ctx* c) {
+    if (!c) return AUD_EINVAL;
+    aud_ctx::Gather& g = c->gather;
+    if (!g.recv) return AUD_OK;
+    (void)hipSetDevice(c->device);
+    for (int p = 0; p < g.n_ranks; ++p) {
+        if (p == g.rank) continue;
+        if (g.streams[size_t(p)]) {
+            (void)hipStreamSynchronize(g.streams[size_t(p)]);
+            (void)hipStreamDestroy(g.streams[size_t(p)]);
+        }
+        if (g.done[size_t(p)]) (void)hipEventDestroy(g.done[size_t(p)]);
+        if (g.peer[size_t(p)]) (void)hipIpcCloseMemHandle(g.peer[size_t(p)]);
+    }
+    if (g.fork) (void)hipEventDestroy(g.fork);
+    (void)hipFree(g.recv);
+    g = aud_ctx::Gather();
+    return AUD_OK;
+}
+
+int aud_allgather_dev(aud_ctx* c, const float* send, float* recv, int64_t count, void* stream) {
+    if (!c || count < 0) return AUD_EINVAL;
+    if (!c->comm) return fail(c, AUD_ERCCL, "aud_comm_init has not been called");
+    if (count == 0) return AUD_OK;
+    if (!send || !recv) return fail(c, AUD_EINVAL, "null buffer");
+    AUD_HIP(c, make_current(c));
+    auto ag = reinterpret_cast<rccl_allgather_t>(dlsym(c->rccl_lib, "ncclAllGather"));
+    if (!ag) return fail(c, AUD_ERCCL, "ncclAllGather not found");
+    const int r = ag(send, recv, size_t(count), kNcclFloat32, c->comm, static_cast<hipStream_t>(stream));
+    if (r != 0) {
+        auto es = reinterpret_cast<rccl_errstr_t>(dlsym(c->rccl_lib, "ncclGetErrorString"));
+        return fail(c, AUD_ERCCL, std::string("ncclAllGather: ") + (es ? es(r) : "error"));
+    }
+    return AUD_OK;
+}
+
+}  // extern "C"
+

@@ -1,0 +1,324 @@
+// C ABI, host-staged entry points: the reference's per-step and per-segment calls on caller-owned host buffers, staged
+// through the context's workspaces and stream (HostCallGuard).  See include/auditory_hip.h.
+#include "capi_internal.h"
+
+using namespace audc;
+
+extern "C" {
+
+int aud_melspec_batch_host(aud_plan* p, const double* sig, int64_t sig_total, const aud_item* items,
+                           int n_items, double* mel, double* power, double* log_power) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    if (n_items < 0 || sig_total < 0 || (n_items > 0 && (!sig || !items || !mel)))
+        return fail(c, AUD_EINVAL, "null buffer");
+    if (n_items == 0) return AUD_OK;
+    for (int i = 0; i < n_items; ++i)
+        if (items[i].sig_off < 0 || items[i].sig_len < 0 || items[i].sig_stride < 0 || item_last(items[i]) >= sig_total)
+            return fail(c, AUD_EINVAL, "item outside the signal buffer");
+    AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
+    const int nf = p->d.mel.n_filters, T = p->d.segment_steps, H = p->H;
+    const size_t n_mel = size_t(n_items) * nf * T, n_pow = size_t(n_items) * H * T;
+    const size_t sig_bytes = size_t(sig_total) * 8, item_bytes = size_t(n_items) * sizeof(aud_item);
+    const bool smooth = p->d.dft.prev_smooth != 0.0;  // the scan needs a device power buffer
+    const bool want_p = power != nullptr || smooth, want_lp = log_power != nullptr;
+    const size_t out_floats = n_mel + (want_p ? n_pow : 0) + (want_lp ? n_pow : 0);
+    int rc;
+    if ((rc = ensure_ws(c, 0, sig_bytes + 16)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 1, item_bytes)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 2, out_floats * 4)) != AUD_OK) return rc;
+    float* d_mel = static_cast<float*>(c->ws[2]);
+    float* d_pow = want_p ? d_mel + n_mel : nullptr;
+    float* d_lp = want_lp ? d_mel + n_mel + (want_p ? n_pow : 0) : nullptr;
+    AUD_HIP(c, hipMemcpyAsync(c->ws[0], sig, sig_bytes, hipMemcpyHostToDevice, c->stream));
+    AUD_HIP(c, hipMemcpyAsync(c->ws[1], items, item_bytes, hipMemcpyHostToDevice, c->stream));
+    rc = aud_melspec_batch_dev(p, c->ws[0], AUD_F64, static_cast<const aud_item*>(c->ws[1]), n_items,
+                               d_mel, d_pow, d_lp, c->stream);
+    if (rc != AUD_OK) return rc;
+    std::vector<float> h(out_floats);
+    AUD_HIP(c, hipMemcpyAsync(h.data(), d_mel, out_floats * 4, hipMemcpyDeviceToHost, c->stream));
+    AUD_HIP(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n_mel; ++i) mel[i] = double(h[i]);
+    size_t o = n_mel;
+    if (want_p) {
+        if (power)
+            for (size_t i = 0; i < n_pow; ++i) power[i] = double(h[o + i]);
+        o += n_pow;
+    }
+    if (want_lp)
+        for (size_t i = 0; i < n_pow; ++i) log_power[i] = double(h[o + i]);
+    return AUD_OK;
+}
+
+int aud_snd_to_window(const double* signal, int64_t sig_len, int64_t start, int win_samples, double* window) {
+    if (!signal || !window || win_samples < 1 || sig_len < 0) return AUD_EINVAL;
+    const int64_t end = start + win_samples;
+    if (end > sig_len) return AUD_ESHORT;  // "SndToWindow: end beyond signal length!!"
+    for (int64_t i = 0; i < win_samples; ++i) {
+        const int64_t pos = start + i;
+        window[i] = pos < 0 ? 0.0 : signal[pos];
+    }
+    return AUD_OK;
+}
+
+int aud_dft_filter_host(aud_plan* p, int step, const double* window, double* power, double* log_power,
+                        double* power_seg, double* log_power_seg) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    const int N = p->d.win_samples, T = p->d.segment_steps, H = p->H, nf = p->d.mel.n_filters;
+    if (!window || !power || !power_seg || step < 0 || step >= T) return fail(c, AUD_EINVAL, "bad argument");
+    AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
+    // the window becomes a one-frame stream: frame 0 of the item covers [0, N), every later frame is dead
+    const aud_item it{0, N, p->d.step_samples * p->d.border_steps};
+    const size_t n_mel = size_t(nf) * T, n_pow = size_t(H) * T;
+    int rc;
+    if ((rc = ensure_ws(c, 0, size_t(N) * 8 + 16)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 1, sizeof(aud_item) + size_t(H) * 8 * 3)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 2, (n_mel + n_pow) * 4)) != AUD_OK) return rc;
+    unsigned char* w1 = static_cast<unsigned char*>(c->ws[1]);
+    double* d_carry = reinterpret_cast<double*>(w1 + sizeof(aud_item));
+    double* d_p = d_carry + H;
+    double* d_lp = d_p + H;
+    float* d_mel = static_cast<float*>(c->ws[2]);
+    float* d_pow = d_mel + n_mel;
+    AUD_HIP(c, hipMemcpyAsync(c->ws[0], window, size_t(N) * 8, hipMemcpyHostToDevice, c->stream));
+    AUD_HIP(c, hipMemcpyAsync(w1, &it, sizeof(it), hipMemcpyHostToDevice, c->stream));
+    AUD_HIP(c, hipMemcpyAsync(d_carry, power, size_t(H) * 8, hipMemcpyHostToDevice, c->stream));
+    aud::MelspecArgs a;
+    fill_melspec_args(p, &a);
+    a.sig = c->ws[0];
+    a.sig_dtype = AUD_F64;
+    a.items = reinterpret_cast<const aud_item*>(w1);
+    a.n_items = 1;
+    a.mel = d_mel;
+    a.power = d_pow;
+    AUD_HIP(c, launch_frames(p, a, c->stream));
+    AUD_HIP(c, aud::launch_frame_blend(d_pow, T, d_carry, H, step, p->d.dft.prev_smooth, p->d.dft.cur_smooth,
+                                       p->d.dft.comp_log_pow, p->d.dft.log_offset, p->d.dft.log_min, d_p, d_lp,
+                                       p->d.compute_dtype, c->stream));
+    std::vector<double> hp(size_t(H) * 2);
+    AUD_HIP(c, hipMemcpyAsync(hp.data(), d_p, size_t(H) * 16, hipMemcpyDeviceToHost, c->stream));
+    AUD_HIP(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < H; ++k) {  // the tensor stores of dft.go:70-83
+        power[k] = hp[k];
+        power_seg[size_t(k) * T + step] = hp[k];
+        if (p->d.dft.comp_log_pow) {
+            if (log_power) log_power[k] = hp[size_t(H) + k];
+            if (log_power_seg) log_power_seg[size_t(k) * T + step] = hp[size_t(H) + k];
+        }
+    }
+    return AUD_OK;
+}
+
+int aud_dft_power_host(aud_plan* p, int step, const double* fft_coefs, double* power, double* log_power,
+                       double* power_seg, double* log_power_seg) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    const int T = p->d.segment_steps, H = p->H;
+    if (!fft_coefs || !power || !power_seg || step < 0 || step >= T) return fail(c, AUD_EINVAL, "bad argument");
+    AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
+    int rc;
+    if ((rc = ensure_ws(c, 0, size_t(H) * 16 + 16)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 1, size_t(H) * 8 * 3 + size_t(H) * 4 + 16)) != AUD_OK) return rc;
+    double* d_carry = static_cast<double*>(c->ws[1]);
+    double* d_p = d_carry + H;
+    double* d_lp = d_p + H;
+    float* d_raw = reinterpret_cast<float*>(d_lp + H);
+    AUD_HIP(c, hipMemcpyAsync(c->ws[0], fft_coefs, size_t(H) * 16, hipMemcpyHostToDevice, c->stream));
+    AUD_HIP(c, hipMemcpyAsync(d_carry, power, size_t(H) * 8, hipMemcpyHostToDevice, c->stream));
+    AUD_HIP(c, aud::launch_power_from_coefs(static_cast<const double*>(c->ws[0]), H, d_raw, p->d.compute_dtype,
+                                            c->stream));
+    AUD_HIP(c, aud::launch_frame_blend(d_raw, 1, d_carry, H, step, p->d.dft.prev_smooth, p->d.dft.cur_smooth,
+                                       p->d.dft.comp_log_pow, p->d.dft.log_offset, p->d.dft.log_min, d_p, d_lp,
+                                       p->d.compute_dtype, c->stream));
+    std::vector<double> hp(size_t(H) * 2);
+    AUD_HIP(c, hipMemcpyAsync(hp.data(), d_p, size_t(H) * 16, hipMemcpyDeviceToHost, c->stream));
+    AUD_HIP(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < H; ++k) {  // the tensor stores of dft.go:70-83
+        power[k] = hp[k];
+        power_seg[size_t(k) * T + step] = hp[k];
+        if (p->d.dft.comp_log_pow) {
+            if (log_power) log_power[k] = hp[size_t(H) + k];
+            if (log_power_seg) log_power_seg[size_t(k) * T + step] = hp[size_t(H) + k];
+        }
+    }
+    return AUD_OK;
+}
+
+int aud_cepstrum_dct_host(aud_plan* p, int step, const double* fbank, double* mfcc_seg, double* mfcc_dct) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    const int N = p->d.win_samples, T = p->d.segment_steps, nf = p->d.mel.n_filters, nc = p->d.mfcc_coefs;
+    if (nc < 1 || !p->d_dct) return fail(c, AUD_EINVAL, "plan was created without mfcc_coefs");
+    if (!fbank || !mfcc_seg || step < 0 || step >= T) return fail(c, AUD_EINVAL, "bad argument");
+    AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
+    int rc;
+    if ((rc = ensure_ws(c, 1, sizeof(aud_item))) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 2, size_t(nf + nc) * 4 + 16)) != AUD_OK) return rc;
+    const aud_item it{0, N, p->d.step_samples * p->d.border_steps};  // a one-step segment whose only step is live
+    float* d_mel = static_cast<float*>(c->ws[2]);
+    float* d_mfcc = d_mel + nf;
+    std::vector<float> hm(static_cast<size_t>(nf));
+    for (int j = 0; j < nf; ++j) hm[size_t(j)] = float(fbank[j]);
+    AUD_HIP(c, hipMemcpyAsync(c->ws[1], &it, sizeof(it), hipMemcpyHostToDevice, c->stream));
+    AUD_HIP(c, hipMemcpyAsync(d_mel, hm.data(), size_t(nf) * 4, hipMemcpyHostToDevice, c->stream));
+    aud::MfccArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.items = static_cast<const aud_item*>(c->ws[1]);
+    a.n_items = 1;
+    a.N = N;
+    a.S = p->d.step_samples;
+    a.T = 1;
+    a.border = p->d.border_steps;
+    a.H = p->H;
+    a.nf = nf;
+    a.n_coefs = nc;
+    a.dct = p->d_dct;
+    a.mel = d_mel;
+    a.mfcc = d_mfcc;
+    AUD_HIP(c, aud::launch_mfcc_dct(a, p->d.compute_dtype, c->stream));
+    std::vector<float> out(static_cast<size_t>(nc));
+    AUD_HIP(c, hipMemcpyAsync(out.data(), d_mfcc, size_t(nc) * 4, hipMemcpyDeviceToHost, c->stream));
+    AUD_HIP(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < nc; ++i) mfcc_seg[size_t(i) * T + step] = double(out[size_t(i)]);  // mel.go:207-209
+    if (mfcc_dct)
+        for (int j = 0; j < nf; ++j) mfcc_dct[j] = fbank[j];  // mel.go:193: the work tensor ends up a copy of the input
+    return AUD_OK;
+}
+
+int aud_mel_filter_dft_host(aud_plan* p, int step, const double* power, double* segment, double* fbank) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    const int N = p->d.win_samples, T = p->d.segment_steps, H = p->H, nf = p->d.mel.n_filters;
+    if (!power || !segment || step < 0 || step >= T) return fail(c, AUD_EINVAL, "bad argument");
+    AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
+    const aud_item it{0, N, p->d.step_samples * p->d.border_steps};  // only column 0 is live
+    const size_t n_mel = size_t(nf) * T, n_pow = size_t(H) * T;
+    int rc;
+    if ((rc = ensure_ws(c, 1, sizeof(aud_item))) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 2, (n_mel + n_pow) * 4)) != AUD_OK) return rc;
+    float* d_mel = static_cast<float*>(c->ws[2]);
+    float* d_pow = d_mel + n_mel;
+    std::vector<float> hpow(n_pow, 0.f);
+    for (int k = 0; k < H; ++k) hpow[size_t(k) * T] = float(power[k]);
+    AUD_HIP(c, hipMemcpyAsync(c->ws[1], &it, sizeof(it), hipMemcpyHostToDevice, c->stream));
+    AUD_HIP(c, hipMemcpyAsync(d_pow, hpow.data(), n_pow * 4, hipMemcpyHostToDevice, c->stream));
+    aud::MelspecArgs a;
+    fill_melspec_args(p, &a);
+    a.items = static_cast<const aud_item*>(c->ws[1]);
+    a.n_items = 1;
+    a.mel = d_mel;
+    a.power = d_pow;
+    AUD_HIP(c, aud::launch_mel_from_power(a, p->d.compute_dtype, c->stream));
+    std::vector<float> hm(n_mel);
+    AUD_HIP(c, hipMemcpyAsync(hm.data(), d_mel, n_mel * 4, hipMemcpyDeviceToHost, c->stream));
+    AUD_HIP(c, hipStreamSynchronize(c->stream));
+    for (int f = 0; f < nf; ++f) {  // mel.go:150-151
+        const double v = double(hm[size_t(f) * T]);
+        if (fbank) fbank[f] = v;
+        segment[size_t(f) * T + step] = v;
+    }
+    return AUD_OK;
+}
+
+int aud_melspec_mfcc_batch_host(aud_plan* p, const double* sig, int64_t sig_total, const aud_item* items,
+                                int n_items, double* mel, double* power, double* log_power, double* mfcc,
+                                double* deltas, double* delta_deltas, double* energy) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    if (p->d.mfcc_coefs <= 0) return fail(c, AUD_EINVAL, "plan was created without mfcc_coefs");
+    if (!p->d.dft.comp_log_pow) return fail(c, AUD_EINVAL, "the MFCC tail reads LogPowerSegment: needs CompLogPow");
+    if (n_items < 0 || sig_total < 0 || (n_items > 0 && (!sig || !items || !mel || !mfcc)))
+        return fail(c, AUD_EINVAL, "null buffer");
+    if (delta_deltas && !deltas) return fail(c, AUD_EINVAL, "delta_deltas needs deltas");
+    if (n_items == 0) return AUD_OK;
+    for (int i = 0; i < n_items; ++i)
+        if (items[i].sig_off < 0 || items[i].sig_len < 0 || items[i].sig_stride < 0 || item_last(items[i]) >= sig_total)
+            return fail(c, AUD_EINVAL, "item outside the signal buffer");
+    AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
+    const int nf = p->d.mel.n_filters, T = p->d.segment_steps, H = p->H, nc = p->d.mfcc_coefs;
+    const size_t n_mel = size_t(n_items) * nf * T, n_pow = size_t(n_items) * H * T;
+    const size_t n_cc = size_t(n_items) * nc * T, n_en = size_t(n_items) * T;
+    // device layout: mel | power | log_power | mfcc | deltas | delta_deltas | energy
+    const size_t total = n_mel + 2 * n_pow + 3 * n_cc + n_en;
+    const size_t sig_bytes = size_t(sig_total) * 8, item_bytes = size_t(n_items) * sizeof(aud_item);
+    int rc;
+    if ((rc = ensure_ws(c, 0, sig_bytes + 16)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 1, item_bytes)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 2, total * 4)) != AUD_OK) return rc;
+    float* d_mel = static_cast<float*>(c->ws[2]);
+    float* d_pow = d_mel + n_mel;
+    float* d_lp = d_pow + n_pow;
+    float* d_cc = d_lp + n_pow;
+    float* d_dl = d_cc + n_cc;
+    float* d_ddl = d_dl + n_cc;
+    float* d_en = d_ddl + n_cc;
+    AUD_HIP(c, hipMemcpyAsync(c->ws[0], sig, sig_bytes, hipMemcpyHostToDevice, c->stream));
+    AUD_HIP(c, hipMemcpyAsync(c->ws[1], items, item_bytes, hipMemcpyHostToDevice, c->stream));
+    const aud_item* d_items = static_cast<const aud_item*>(c->ws[1]);
+    rc = aud_melspec_batch_dev(p, c->ws[0], AUD_F64, d_items, n_items, d_mel, d_pow, d_lp, c->stream);
+    if (rc == AUD_OK)
+        rc = aud_mfcc_batch_dev(p, d_items, n_items, d_mel, d_lp, d_cc, deltas ? d_dl : nullptr,
+                                delta_deltas ? d_ddl : nullptr, d_en, c->stream);
+    if (rc != AUD_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        return rc;
+    }
+    std::vector<float> h(total);
+    AUD_HIP(c, hipMemcpyAsync(h.data(), d_mel, total * 4, hipMemcpyDeviceToHost, c->stream));
+    AUD_HIP(c, hipStreamSynchronize(c->stream));
+    auto widen = [&](double* dst, const float* src, size_t n) {
+        if (dst)
+            for (size_t i = 0; i < n; ++i) dst[i] = double(src[i]);
+    };
+    const float* hp = h.data();
+    widen(mel, hp, n_mel);
+    widen(power, hp + n_mel, n_pow);
+    widen(log_power, hp + n_mel + n_pow, n_pow);
+    widen(mfcc, hp + n_mel + 2 * n_pow, n_cc);
+    widen(deltas, hp + n_mel + 2 * n_pow + n_cc, n_cc);
+    widen(delta_deltas, hp + n_mel + 2 * n_pow + 2 * n_cc, n_cc);
+    widen(energy, hp + n_mel + 2 * n_pow + 3 * n_cc, n_en);
+    return AUD_OK;
+}
+
+int aud_gabor_batch_host(aud_plan* p, const double* mel, int n_items, int rows, int cols, int out_rank,
+                         const int32_t* out_shape, int by_time, float* out) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    if (n_items < 0 || rows < 1 || cols < 1 || !out_shape || (out_rank != 2 && out_rank != 4))
+        return fail(c, AUD_EINVAL, "bad shape");
+    if (n_items == 0) return AUD_OK;
+    if (!mel || !out) return fail(c, AUD_EINVAL, "null buffer");
+    AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
+    size_t out_cells = 1;
+    for (int i = 0; i < out_rank; ++i) out_cells *= size_t(out_shape[i] > 0 ? out_shape[i] : 0);
+    const size_t n_mel = size_t(n_items) * rows * cols, n_out = size_t(n_items) * out_cells;
+    int rc;
+    if ((rc = ensure_ws(c, 2, n_mel * 4)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 3, n_out * 4 + 16)) != AUD_OK) return rc;
+    std::vector<float> hm(n_mel);
+    for (size_t i = 0; i < n_mel; ++i) hm[i] = float(mel[i]);
+    AUD_HIP(c, hipMemcpyAsync(c->ws[2], hm.data(), n_mel * 4, hipMemcpyHostToDevice, c->stream));
+    // in/out semantics: cells the reference leaves alone keep the caller's values
+    AUD_HIP(c, hipMemcpyAsync(c->ws[3], out, n_out * 4, hipMemcpyHostToDevice, c->stream));
+    rc = aud_gabor_batch_dev(p, static_cast<const float*>(c->ws[2]), n_items, rows, cols, out_rank,
+                             out_shape, by_time, static_cast<float*>(c->ws[3]), c->stream);
+    if (rc != AUD_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        return rc;
+    }
+    AUD_HIP(c, hipMemcpyAsync(out, c->ws[3], n_out * 4, hipMemcpyDeviceToHost, c->stream));
+    AUD_HIP(c, hipStreamSynchronize(c->stream));
+    return AUD_OK;
+}
+
+}  // extern "C"
+

@@ -1,0 +1,159 @@
+// Shared by the translation units of the C ABI (capi.hip: contexts, plans, device entry points; capi_host.hip: the
+// host-staged entry points; capi_comm.hip: RCCL and the direct all-gather; wave_tables.hip: the wave kernels' tables).
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <climits>
+#include <cstring>
+#include <new>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+struct aud_ctx {
+    int device = -1;
+    std::string err = "";          // last error message, under err_mutex (entry points may fail concurrently)
+    std::mutex err_mutex;
+    hipStream_t stream = nullptr;  // used by the _host entry points
+    std::mutex host_mutex;         // ... which serialise on it (HostCallGuard)
+    // grow-only device workspaces for the _host entry points
+    void* ws[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t ws_cap[4] = {0, 0, 0, 0};
+    // RCCL (loaded lazily)
+    void* rccl_lib = nullptr;
+    void* comm = nullptr;
+    int n_ranks = 0, rank = 0;
+    // direct all-gather (aud_gather_*): this rank's receive buffer, the peers' mapped ones, one stream + event per peer
+    struct Gather {
+        int n_ranks = 0, rank = 0;
+        int64_t slab = 0;
+        float* recv = nullptr;
+        std::vector<float*> peer;          // [n_ranks], peer[rank] = recv
+        std::vector<hipStream_t> streams;  // [n_ranks], null at `rank`
+        std::vector<hipEvent_t> done;      // [n_ranks]
+        hipEvent_t fork = nullptr;
+    } gather;
+};
+
+struct aud_plan {
+    aud_ctx* ctx = nullptr;
+    aud_plan_desc d{};
+    int H = 0, M = 0, ratio = 0;
+    int nfac = 0;
+    int fac[aud::kMaxFactors] = {0};
+    int F_generic = 0;
+    // generic kernel, Bluestein route (kernels.h MelspecArgs::bl_*): 0 = not used
+    int bl_L = 0, bl_nfac = 0;
+    int bl_fac[aud::kMaxFactors] = {0};
+    void* d_bl_chirp = nullptr;
+    void* d_bl_bhat = nullptr;
+    void* d_bl_tw = nullptr;
+    int xcd_remap = 1;         // workgroup -> tile order keeps an XCD on one run of tiles (kernels.h)
+    // wave-autonomous kernel of this window length (melspec_wave.hip), the default where it exists
+    int wave_kind = 0;         // = the kind number of melspec_wave.hip (0: none)
+    bool use_wave = false;     // false: the generic kernel (no wave kernel, or plan option "kernel" = 1)
+    aud::WaveArgs wv{};
+    void* d_blob = nullptr;   // wave kernels: every read-only table, laid out like its LDS copy (kernels.h WaveArgs)
+    void* d_gtab = nullptr;   // w64x16: lane-ordered pass-1 and split twiddles read from global memory
+    void* d_tw = nullptr;
+    void* d_filt = nullptr;
+    int32_t* d_bin_pts = nullptr;
+    void* d_gabor = nullptr;
+    void* d_dct = nullptr;  // [mfcc_coefs][nf] DCT-I rows
+    unsigned long long stamps = 0;  // diagnostic builds (-DAUD_STAMPS): device buffer for the phase stamps
+    const char* family = "generic";
+};
+
+namespace audc {
+
+// buffer element holding the last sample of an item's stream (-1 for an empty stream)
+inline int64_t item_last(const aud_item& it) {
+    if (it.sig_len <= 0) return it.sig_off - 1;
+    return it.sig_off + int64_t(it.sig_len - 1) * (it.sig_stride > 1 ? it.sig_stride : 1);
+}
+
+inline int fail(aud_ctx* c, int code, const std::string& msg) {
+    if (c) {
+        std::lock_guard<std::mutex> lk(c->err_mutex);
+        c->err = msg;
+    }
+    return code;
+}
+
+inline int hip_fail(aud_ctx* c, hipError_t e, const char* what) {
+    return fail(c, AUD_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// Host entry points queue asynchronous copies from / to caller-owned (pageable) memory on the context's stream: on EVERY
+// exit behind the first such copy the stream is drained, so the caller may free or reuse its buffers whatever the status.
+// They also serialise on the context: its workspaces and stream are shared state (two goroutines on one aud_ctx).
+struct HostCallGuard {
+    aud_ctx* c;
+    explicit HostCallGuard(aud_ctx* ctx) : c(ctx) { c->host_mutex.lock(); }
+    ~HostCallGuard() {
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        c->host_mutex.unlock();
+    }
+};
+
+#define AUD_HIP(c, call)                                   \
+    do {                                                   \
+        hipError_t e__ = (call);                           \
+        if (e__ != hipSuccess) return hip_fail(c, e__, #call); \
+    } while (0)
+
+// Goroutines / Python threads migrate between OS threads, so every entry point makes its device
+// current -- but only when it is not already (the device entry points may run under stream
+// capture, where needless runtime calls are best avoided).
+inline hipError_t make_current(const aud_ctx* c) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == c->device) return hipSuccess;
+    return hipSetDevice(c->device);
+}
+
+inline int ensure_ws(aud_ctx* c, int slot, size_t bytes) {
+    if (c->ws_cap[slot] >= bytes) return AUD_OK;
+    if (c->ws[slot]) {
+        AUD_HIP(c, hipFree(c->ws[slot]));
+        c->ws[slot] = nullptr;
+        c->ws_cap[slot] = 0;
+    }
+    const size_t cap = bytes + bytes / 4 + 4096;
+    AUD_HIP(c, hipMalloc(&c->ws[slot], cap));
+    c->ws_cap[slot] = cap;
+    return AUD_OK;
+}
+
+template <typename TT>
+inline std::vector<TT> convert(const double* src, size_t n) {
+    std::vector<TT> v(n);
+    for (size_t i = 0; i < n; ++i) v[i] = TT(src[i]);
+    return v;
+}
+
+inline int upload(aud_ctx* c, void** dst, const void* src, size_t bytes) {
+    AUD_HIP(c, hipMalloc(dst, bytes ? bytes : 16));
+    if (bytes) AUD_HIP(c, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return AUD_OK;
+}
+
+inline int upload_real(aud_ctx* c, void** dst, const double* src, size_t n, int dt) {
+    if (dt == AUD_F64) return upload(c, dst, src, n * 8);
+    std::vector<float> v = convert<float>(src, n);
+    return upload(c, dst, v.data(), n * 4);
+}
+
+// capi.hip
+void fill_melspec_args(const aud_plan* p, aud::MelspecArgs* a);
+hipError_t launch_frames(const aud_plan* p, const aud::MelspecArgs& a, hipStream_t st);
+const char* plan_family(const aud_plan* p);
+// wave_tables.hip
+int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_filters);
+
+}  // namespace audc

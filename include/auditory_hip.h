@@ -208,36 +208,26 @@ int aud_device_id(const aud_ctx* ctx);
 int aud_plan_create(aud_ctx* ctx, const aud_plan_desc* desc, const int32_t* bin_pts, const double* mel_filters,
                     const double* gabor_filters, aud_plan** plan);
 int aud_plan_destroy(aud_plan* plan);
-/* which frame->mel kernel family the plan selected: "generic", "w20x10", "r16x16", ... (diagnostic) */
+/* which frame->mel kernel family the plan selected: "w16x16" (N = 512), "w20x10" (N = 400), "w64x16" (N = 2048) or
+ * "generic" (any other N, and any plan with "kernel" = 1) -- diagnostic */
 const char* aud_plan_kernel_name(const aud_plan* plan);
 /* Tuning / diagnostic switches; results are identical whatever they are set to (up to the last-place effects of a
- * different summation order between kernel families).
- *   "kernel"    0 automatic (default: the wave-autonomous kernels where they exist: w16x16 for N = 512, w20x10 for
- *               N = 400, w64x16 for N = 2048), 1 force the generic any-N kernel, 2 the workgroup-tile kernels of round 1
- *               (r16x16 / r25x8 / r16x16x4)
- *   "n400_geometry" 20 (default): the 200-point FFT of N = 400 as 20 x 10 (ten lanes per frame, six frames per wave,
- *               three waves per SIMD in float64), 25: as 25 x 8 (w25x8: eight lanes per frame, eight frames per wave)
- *   "wave_grid" -1 (default) w16x16 / w25x8: persistent grid when a launch holds >= 4 rounds of resident waves (w20x10 and
- *               w64x16: never), 0 one tile per wave, 1 persistent, 2 persistent with a dynamic tile queue (A/B only)
- *   "wave_variant" 2 (default) / 0 / 1: operand prefetch variants of the persistent loop (A/B)
- *   "gabor_lds" 0 (default) the gabor kernel reads the mel matrix through L1/L2, 1 it stages the item's matrix in LDS first
- *               (where it fits 60 KB); measured on the MI355X: 9.4 vs 11.9 us per 256 items in float64, so off by default;
- *               2 / 4: the default 9 x 9 x 8 FilterSet with two / four threads per output position (measured: within 2 %
- *               of the default when launches overlap, 4 % faster alone)
+ * different summation order between the two kernel families).
+ *   "kernel"    0 automatic (default: the wave-autonomous kernel of the plan's N where there is one), 1 the generic any-N
+ *               kernel (the A/B and parity baseline of the wave kernels)
  *   "xcd_remap" 1 (default) workgroups that share an XCD take one contiguous run of tiles (L2 reuse of the
  *               samples neighbouring tiles share), 0 tiles in workgroup-id order
- *   the "r16_*" switches are variants of the round-1 N = 512 tile kernel; setting one selects that kernel
- *   "r16_input" 0 operands straight from global memory (default), 1 staged through LDS
- *   "r16_tiles" 1 (default) or 2 sixteen-frame tiles per workgroup, the second one's operands prefetched
- *   "r16_mel"   0 mel triangles on the vector pipe (default), 1 as a banded filter x bin GEMM on the matrix
- *               pipe (float32 plans only; same products, the sum also takes the zero weights of the band) */
+ *   "stamps_lo" / "stamps_hi"  the two halves of a device address for the s_memtime stamps of the DIAGNOSTIC build
+ *               (-DAUD_STAMPS, tools/stamp_profile.py); unknown to the product build
+ * AUD_EINVAL for an unknown name. */
 int aud_plan_set_option(aud_plan* plan, const char* name, int value);
 
 /* Launch facts of the kernel the plan will run for the mel path (diagnostics: profiles/, bench.py).
  *   "lds_bytes"        LDS per workgroup
  *   "waves_per_wg"     waves of 64 lanes per workgroup
  *   "wgs_per_cu"       workgroups resident per compute unit (the runtime's occupancy answer at plan time)
- *   "frames_per_wave"  frames one wave transforms together (0: a workgroup-tile or generic kernel)
+ *   "frames_per_wave"  frames one wave transforms together (0: the generic kernel)
+ *   "epilogue_steps"   wave kernels: filter steps of the mel epilogue, summed over its slots (padding included)
  *   "bluestein_L"      generic kernel: length of the power-of-two FFTs of its Bluestein route (0: direct factorisation)
  * AUD_EINVAL for an unknown name. */
 int aud_plan_get_info(const aud_plan* plan, const char* name, int64_t* value);
