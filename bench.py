@@ -634,12 +634,13 @@ def main():  # noqa: C901
 
     # roofline.traffic: HBM bytes per launch from the PMC passes (tools/profile_bench.sh), if they were taken for this
     # kernel and batch; null otherwise (it cannot be measured inside this process)
-    traffic = None
+    traffic, rocprof_us = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             pmc = json.load(fh)
         if pmc.get("batch") == B and pmc.get("family") == head["kernel"] and pmc.get("compute") == args.compute:
             traffic = round(float(pmc["hbm_bytes_per_launch"]), 1)
+            rocprof_us = round(float(pmc["avg_duration_ns"]) / 1e3, 3)
     except (OSError, ValueError, KeyError):
         pass
     what = {"headline": "BASELINE configs[1] batch on the metric's parameters: ",
@@ -678,12 +679,13 @@ def main():  # noqa: C901
                      "frac": round(solo["achieved_GBps"] / HBM_PEAK_GBPS, 5), "traffic": traffic,
                      "kernel": "frame->FFT->power->mel (%s, %s)" % (head["kernel"], args.compute),
                      "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"],
-                     "avg_launch_us": solo["us_per_step_device"]["mean"],
+                     "avg_launch_us": solo["us_per_step_device"]["mean"], "rocprofv3_avg_launch_us": rocprof_us,
                      "pipelined_GBps": head["achieved_GBps"],
                      "note": "achieved = algorithmic bytes (every sample read once, every mel value written once) / mean device "
                              "time per launch between HIP events in a ONE-stream region of %d utterances per launch (the kernel "
-                             "alone on the chip, kernel-to-kernel boundary included; rocprofv3's average duration for this kernel "
-                             "is the same number); pipelined_GBps = the same bytes / time per step of the %d-stream region; the "
+                             "alone on the chip, kernel-to-kernel boundary included); rocprofv3_avg_launch_us = the average duration "
+                             "rocprofv3 --kernel-trace --stats gave the same kernel in the committed profile (profiles/"
+                             "pmc_traffic.json; its eager, traced launches run about 1 us longer); pipelined_GBps = the same bytes / time per step of the %d-stream region; the "
                              "kernel is vector-ALU (float64 issue) bound, not HBM bound (DESIGN.md 4)" % (B, head["streams"])},
     }
     if cfg3 is not None:

@@ -87,7 +87,8 @@ def main():
             best = {"kernel": k, "family": fam, "compute": "f64" if "<double" in k else "f32",
                     "batch": int(os.environ.get("AUD_PROFILE_BATCH", "256")),
                     "avg_duration_ns": avg_ns.get(k), "hbm_bytes_per_launch": v["read_bytes"] + v["write_bytes"], "tag": tag, **v}
-    if best and best["family"] == "w20x10" and best["compute"] == "f64" and best["batch"] == 256:
+    headline = not os.environ.get("AUD_PROFILE_ARGS", "").strip()  # the default bench command, nothing else
+    if headline and best and best["family"] == "w20x10" and best["compute"] == "f64" and best["batch"] == 256:
         with open(os.path.join(prof_dir, "pmc_traffic.json"), "w") as fh:
             json.dump(best, fh, indent=1)
         print("## wrote profiles/pmc_traffic.json:", best)
