@@ -523,32 +523,34 @@ __device__ __forceinline__ float scaled_power(float p4, int) { return p4; }
 // group, so the loop bounds are scalar and a step is two 16-byte LDS reads and four multiply-adds into four running sums
 // (one per position in the chunk: at most 2 x the slot's steps additions each, pairwise at the end).  No LDS access sits
 // under a lane condition: a masked frame still reads its -- valid -- row and drops the sums.
-template <typename TT, int FPW>
-__device__ __forceinline__ void wave_spectrum_outputs(const MelspecArgs& a, const float* P, int Hp, int sc,
-                                                      const aud_item& it, int item, int t0, int lane) {
-    if (!a.power && !a.log_power) return;
-    // a lane keeps ONE frame (lane % FPW) and walks the bins k = lane / FPW, + 64 / FPW, ...: step, liveness and the output
-    // addresses are per-lane constants, every iteration is one LDS read, the logarithm and two stores.  Lanes beyond
-    // FPW * (64 / FPW) repeat the last group and store nothing; reads past the last bin are clamped, not skipped.
+// MODE (wave-uniform, chosen once per tile): 0 = LogOffSet == 0: float32 throughout (p4 2^(sc-2) rounds once either way,
+// and its logarithm is the mantissa's plus the shifted exponent); 1 = an ordinary positive LogOffSet (the reference's
+// default is 1.0, dft.go:37) and every frame's scale small enough for the sum to be a normal float32: one float64
+// multiply-add, then the float32 logarithm; 2 = anything else: float64 ldexp / add / frexp as the definition reads.
+template <typename TT, int FPW, int MODE>
+__device__ __forceinline__ void wave_spectrum_loop(const MelspecArgs& a, const float* prow, int sc, int g, size_t o,
+                                                   bool col_on, bool live) {
     constexpr int G = 64 / FPW;
-    const int T = a.T, H = a.H;
-    const int ff = lane % FPW, g0 = lane / FPW;
-    const bool has = g0 < G;
-    const int g = has ? g0 : G - 1;
-    const int sstep = t0 + ff;
-    const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
-    const bool col_on = has && sstep < T;
-    const bool live = start + a.N <= int64_t(it.sig_len);
-    const float* prow = P + ff * Hp;
-    size_t o = (size_t(item) * H + g) * T + (col_on ? sstep : 0);
-    const size_t ostep = size_t(G) * T;
+    const int H = a.H;
+    const size_t ostep = size_t(G) * a.T;
     const bool want_lp = live && a.comp_log_pow;
     const int n_it = (H + G - 1) / G;  // the same trip count for every lane
+    const double scale_d = MODE == 1 ? ldexp(1.0, sc - 2) : 1.0;
     for (int i = 0; i < n_it; ++i) {
         const int k = g + G * i;
         const float p4 = prow[k < H ? k : H - 1];
         float pw, lp = 0.f;
-        if constexpr (sizeof(TT) == 8) {
+        if constexpr (sizeof(TT) == 8 && MODE == 0) {
+            pw = ldexpf(p4, sc - 2);
+            if (want_lp) {
+                int ex = 0;
+                const float m = frexpf(p4, &ex);
+                lp = p4 == 0.f ? float(a.dft_log_min) : mantissa_log(m, ex + sc - 2);
+            }
+        } else if constexpr (sizeof(TT) == 8 && MODE == 1) {
+            pw = ldexpf(p4, sc - 2);
+            if (want_lp) lp = feature_log(float(mad(double(p4), scale_d, a.dft_log_off)));  // > 0: never the LogMin case
+        } else if constexpr (sizeof(TT) == 8) {
             const double pd = ldexp(double(p4), sc - 2);
             pw = float(pd);
             if (want_lp) {
@@ -567,6 +569,36 @@ __device__ __forceinline__ void wave_spectrum_outputs(const MelspecArgs& a, cons
             if (a.log_power) a.log_power[o] = lp;
         }
         o += ostep;
+    }
+}
+
+template <typename TT, int FPW>
+__device__ __forceinline__ void wave_spectrum_outputs(const MelspecArgs& a, const float* P, int Hp, int sc,
+                                                      const aud_item& it, int item, int t0, int lane) {
+    if (!a.power && !a.log_power) return;
+    // a lane keeps ONE frame (lane % FPW) and walks the bins k = lane / FPW, + 64 / FPW, ...: step, liveness and the output
+    // addresses are per-lane constants, every iteration is one LDS read, the logarithm and two stores.  Lanes beyond
+    // FPW * (64 / FPW) repeat the last group and store nothing; reads past the last bin are clamped, not skipped.
+    constexpr int G = 64 / FPW;
+    const int T = a.T, H = a.H;
+    const int ff = lane % FPW, g0 = lane / FPW;
+    const bool has = g0 < G;
+    const int g = has ? g0 : G - 1;
+    const int sstep = t0 + ff;
+    const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
+    const bool col_on = has && sstep < T;
+    const bool live = start + a.N <= int64_t(it.sig_len);
+    const float* prow = P + ff * Hp;
+    const size_t o = (size_t(item) * H + g) * T + (col_on ? sstep : 0);
+    if constexpr (sizeof(TT) == 8) {
+        const double off = a.dft_log_off;
+        // the scaled peak of a frame is below 2^26 (frame_scale), so with sc < 96 the sum is below 2^123
+        const bool small = __builtin_amdgcn_ballot_w64(sc >= 96 || sc < -900) == 0;
+        if (off == 0.0) wave_spectrum_loop<TT, FPW, 0>(a, prow, sc, g, o, col_on, live);
+        else if (small && off >= 1e-30 && off <= 1e30) wave_spectrum_loop<TT, FPW, 1>(a, prow, sc, g, o, col_on, live);
+        else wave_spectrum_loop<TT, FPW, 2>(a, prow, sc, g, o, col_on, live);
+    } else {
+        wave_spectrum_loop<TT, FPW, 2>(a, prow, sc, g, o, col_on, live);
     }
 }
 

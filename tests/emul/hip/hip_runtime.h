@@ -215,6 +215,14 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
     return out;
 }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return emul_shfl_any(v, lane); }
+// mask of the wave's lanes whose predicate holds (every lane of the wave calls it)
+inline uint64_t __builtin_amdgcn_ballot_w64(bool pred) {
+    const uint64_t* all = aud_emul::wave_publish(pred ? 1u : 0u);
+    uint64_t m = 0;
+    for (int l = 0; l < 64; ++l) m |= (all[l] & 1u) << l;
+    aud_emul::wave_release();
+    return m;
+}
 
 // v_mfma_f32_16x16x4_f32 as the guide documents it: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15],
 // D register r of lane l = row 4 (l >> 4) + r, column l & 15; one k-ordered fmaf chain per element.

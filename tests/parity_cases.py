@@ -80,6 +80,57 @@ def case_melspec_vs_oracle(orc, case, cdt, seg_ms=None, options=None):
         assert np.isnan(mel[:, 0, :3]).all()
 
 
+
+def case_input_levels(orc, name, cdt, seg_ms=None):
+    """Float64 plans must hold at EVERY input level a double carries (the wave kernels keep the spectrum in float32 behind a
+    per-frame power-of-two scale, device_common.h frame_scale): rows from 1e-150 to 1e150, a band of 1e-30, an all-zero
+    row and a row whose first frames are all zero (exact zeros -> LogMin, mel.go:135-137) -- mel and log-power under the
+    strict criterion, with LogOffSet = 1 (the reference's default), 0 and 1e-40 (the three routes of the spectrum outputs).
+    Float32 plans: moderate levels, the relaxed float32 criterion."""
+    oc = W.OracleCfg(orc, name, seg_ms)
+    L = oc.full_len()
+    f64 = cdt == capi.AUD_F64
+    levels = [1.0, 1e-30, 2.0 ** 60, 1e-150, 1e150, 3.0e-7] if f64 else [1.0, 1e-3, 1e3]
+    base, _ = synth.batch(23, len(levels) + 2, L, oc.sr)
+    sig = base.copy()
+    for r, lv in enumerate(levels):
+        sig[r] *= lv
+    sig[len(levels)] = 0.0                               # silence: every band sum is exactly 0
+    half = len(levels) + 1
+    sig[half, :L // 2] = 0.0                             # zero frames first, then signal (scaled: a band of 1e-30)
+    sig[half] *= 1e-30 if f64 else 1.0
+    segs = [(r, 0) for r in range(sig.shape[0])]
+    for off in ((1.0, 0.0, 1e-40) if f64 else (1.0,)):
+        oc.d.log_offset = off
+        ref_mel, ref_pw, ref_lp = oracle_items(orc, oc, sig, segs)
+        plan = W.product_plan(oc, cdt, dft_log_offset=off)
+        try:
+            mel, pw, lp = plan.melspec_host(sig.ravel(), make_items(oc, L, segs), True, True)
+        finally:
+            plan.close()
+        if f64:
+            ok, msg = W.close_enough(mel, ref_mel, 1e-5)
+            assert ok, "mel, LogOffSet %g: %s" % (off, msg)
+            for r in range(sig.shape[0]):
+                ok, msg = W.close_enough(lp[r], ref_lp[r], 1e-5)
+                assert ok, "log_power row %d (level %s), LogOffSet %g: %s" % (r, levels[r] if r < len(levels) else "zeros", off, msg)
+                if np.nanmax(ref_pw[r]) < 1e37:          # the float32 Power tensor overflows above that, by definition
+                    ok, msg = W.spectrum_close(pw[r:r + 1], ref_pw[r:r + 1], 3e-7)
+                    assert ok, "power row %d: %s" % (r, msg)
+        else:
+            ok, msg = W.feature_close(mel, ref_mel, cdt, lin_axis=1)
+            assert ok, "mel " + msg
+            ok, msg = W.spectrum_close(pw, ref_pw, 4e-6)
+            assert ok, "power " + msg
+        # exact zeros keep the LogMin rule whatever the scale machinery does
+        live = ~((ref_pw == 0).all(axis=1) & (ref_mel == 0).all(axis=1))        # [items, T]
+        silent = live & (ref_pw == 0).all(axis=1)
+        assert silent[len(levels)].any() and silent[half].any()
+        finite_rows = ~np.isnan(ref_mel).any(axis=2)                              # (filters without taps: NaN rows, Q3)
+        want = np.broadcast_to(silent[:, None, :], mel.shape) & finite_rows[:, :, None]
+        assert np.all(mel[want] == float(oc.m.log_min)), "LogMin rule"
+
+
 def case_workgroup_order(orc, cdt, with_n2048=True):
     """the XCD-contiguous workgroup -> tile order (option "xcd_remap") is a bijection for grid sizes that are
     not multiples of 8 and changes nothing in the results: every kernel family, remap on == off, bit for bit"""

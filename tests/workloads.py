@@ -44,7 +44,8 @@ class OracleCfg:
         return self.S * (self.T - 1 - self.border) + self.N
 
 
-def product_plan(ocfg, compute_dtype=0, gabor=None, device=0, dft_override=None, mfcc_coefs=0):  # noqa: C901
+def product_plan(ocfg, compute_dtype=0, gabor=None, device=0, dft_override=None, mfcc_coefs=0,  # noqa: C901
+                 dft_log_offset=None):
     """runtime.Plan built from the PRODUCT's own host setup for the same configuration"""
     from auditory_amd import agabor, capi, mel, runtime
     sr, win, step, seg, stride, border, nf, lo, hi = CONFIGS[ocfg.name]
@@ -56,6 +57,8 @@ def product_plan(ocfg, compute_dtype=0, gabor=None, device=0, dft_override=None,
     capi.load().aud_dft_defaults(dftp)
     if dft_override is not None:
         dftp.prev_smooth, dftp.cur_smooth = dft_override
+    if dft_log_offset is not None:
+        dftp.log_offset = dft_log_offset
     gset = gk = None
     if gabor is not None:
         fs = agabor.FilterSet()
