@@ -61,6 +61,27 @@ class BatchProcessor:
                       mel.data_ptr(), pools_y, pools_x, gabor.data_ptr(), self._stream())
         return mel, gabor
 
+    def segment(self, sig, items_dev, n_items, want_spectrum=True, deltas=True):
+        """SndEnv.ProcessSegment with Mel.MFCC on (sound/sndenv.go:342-431) for n_items segments, device-resident:
+        returns dict(mel, power, log_power, mfcc, deltas, delta_deltas, energy) of float32 tensors (None where not asked)"""
+        p = self.plan
+        if sig.device != self.device or not sig.is_contiguous():
+            raise ValueError("signal must be a contiguous tensor on %s" % self.device)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=self.device)  # noqa: E731
+        nc = p.mfcc_coefs
+        out = dict(mel=new(n_items, p.nf, p.T), power=new(n_items, p.H, p.T) if want_spectrum else None,
+                   log_power=new(n_items, p.H, p.T) if want_spectrum else None, mfcc=new(n_items, nc, p.T),
+                   deltas=new(n_items, nc, p.T) if deltas else None, delta_deltas=new(n_items, nc, p.T) if deltas else None,
+                   energy=new(n_items, p.T))
+        nbytes = p.segment_workspace_bytes(n_items)
+        ws = torch.empty(nbytes + 16, dtype=torch.uint8, device=self.device)
+        ptr = lambda t: t.data_ptr() if t is not None else 0  # noqa: E731
+        p.segment_dev(sig.data_ptr(), _SIG_DTYPES[sig.dtype], items_dev.data_ptr(), n_items, ptr(out["mel"]), ptr(out["power"]),
+                      ptr(out["log_power"]), ptr(out["mfcc"]), ptr(out["deltas"]), ptr(out["delta_deltas"]), ptr(out["energy"]),
+                      ws.data_ptr(), nbytes, self._stream())
+        self._ws = ws  # stays alive until the next call (the launches are asynchronous)
+        return out
+
     def kwta(self, gabor, params, act=None, pool=True, state=None, cycles=None, sum_order=0):
         """SndEnv.ApplyKwta on a device-resident gabor tensor [n, PY, PX, UY, UX] (settling starts from the raw
         values); `params` is an auditory_amd.kwta.KWTA.  Returns the settled tensor."""

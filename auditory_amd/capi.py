@@ -110,6 +110,8 @@ SYMBOLS = {
     "aud_plan_get_info": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int64)]),
     "aud_melspec_batch_dev": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, _VP, _VP, _VP, _VP]),
     "aud_mfcc_batch_dev": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "aud_segment_workspace_bytes": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int64)]),
+    "aud_segment_batch_dev": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
     "aud_melspec_mfcc_batch_host": (C.c_int, [_VP, _VP, C.c_int64, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "aud_gabor_batch_dev": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, C.c_int,
                                       _VP, _VP]),

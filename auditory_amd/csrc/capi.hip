@@ -421,6 +421,85 @@ int aud_mfcc_batch_dev(aud_plan* p, const aud_item* items, int n_items, const fl
     return AUD_OK;
 }
 
+namespace {
+// the plan's mel kernel can carry the tail's DCT and Energy sums itself (kernels.h MelspecArgs::mfcc_acc)
+bool segment_fused(const aud_plan* p) {
+    return p->use_wave && p->wave_kind && p->wv.dct_off >= 0 && p->d.dft.prev_smooth == 0.0 &&
+           aud::segment_finish_lds_bytes(p->d.mfcc_coefs, p->d.segment_steps, p->d.compute_dtype) <= 64 * 1024;
+}
+size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+}  // namespace
+
+int aud_segment_workspace_bytes(const aud_plan* p, int n_items, int64_t* bytes) {
+    if (!p || !bytes || n_items < 0) return AUD_EINVAL;
+    const size_t T = size_t(p->d.segment_steps), n = size_t(n_items);
+    if (segment_fused(p)) {
+        const int fw = aud::melspec_wave_frames_per_wave(p->wave_kind);
+        const size_t tiles = (T + fw - 1) / fw, tsz = p->d.compute_dtype == AUD_F64 ? 8 : 4;
+        *bytes = int64_t(align256(n * p->d.mfcc_coefs * T * tsz) + align256(n * tiles * T * tsz));
+    } else {
+        *bytes = int64_t(align256(n * p->H * T * 4));  // a LogPowerSegment of its own when the caller keeps none
+    }
+    return AUD_OK;
+}
+
+int aud_segment_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud_item* items, int n_items, float* mel,
+                          float* power, float* log_power, float* mfcc, float* deltas, float* delta_deltas, float* energy,
+                          void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    if (p->d.mfcc_coefs <= 0 || !p->d_dct) return fail(c, AUD_EINVAL, "plan was created without mfcc_coefs");
+    if (!p->d.dft.comp_log_pow) return fail(c, AUD_EINVAL, "the MFCC tail reads LogPowerSegment: needs CompLogPow");
+    if (p->d.segment_steps > p->H)
+        return fail(c, AUD_EINVAL, "Energy reads LogPowerSegment row s < SegmentSteps: needs SegmentSteps <= bins (Go panics)");
+    if (delta_deltas && !deltas) return fail(c, AUD_EINVAL, "delta_deltas needs deltas");
+    if (n_items < 0 || (n_items > 0 && (!sig || !items || !mel || !mfcc))) return fail(c, AUD_EINVAL, "null buffer");
+    int64_t need = 0;
+    (void)aud_segment_workspace_bytes(p, n_items, &need);
+    if (n_items > 0 && (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15)))
+        return fail(c, AUD_EINVAL, "workspace: 16-byte aligned, aud_segment_workspace_bytes() bytes");
+    if (n_items == 0) return AUD_OK;
+    if (!segment_fused(p)) {  // (generic kernel, w64x16, PrevSmooth, more than 13 coefficients): the two launches of the parts
+        float* lp = log_power ? log_power : static_cast<float*>(workspace);
+        int rc = aud_melspec_batch_dev(p, sig, sig_dtype, items, n_items, mel, power, lp, stream);
+        if (rc != AUD_OK) return rc;
+        return aud_mfcc_batch_dev(p, items, n_items, mel, lp, mfcc, deltas, delta_deltas, energy, stream);
+    }
+    if (sig_dtype != AUD_F32 && sig_dtype != AUD_F64 && sig_dtype != AUD_I16) return fail(c, AUD_EINVAL, "bad sig_dtype");
+    if (int64_t(n_items) * int64_t(p->d.segment_steps) > (int64_t(1) << 30))
+        return fail(c, AUD_EINVAL, "n_items x segment_steps too large for one launch; split the batch");
+    AUD_HIP(c, make_current(c));
+    const size_t T = size_t(p->d.segment_steps), tsz = p->d.compute_dtype == AUD_F64 ? 8 : 4;
+    aud::MelspecArgs a;
+    fill_melspec_args(p, &a);
+    a.sig = sig;
+    a.sig_dtype = sig_dtype;
+    a.items = items;
+    a.n_items = n_items;
+    a.mel = mel;
+    a.power = power;
+    a.log_power = log_power;
+    a.mfcc_acc = workspace;
+    a.energy_part = static_cast<unsigned char*>(workspace) + align256(size_t(n_items) * p->d.mfcc_coefs * T * tsz);
+    a.n_coefs = p->d.mfcc_coefs;
+    AUD_HIP(c, launch_frames(p, a, static_cast<hipStream_t>(stream)));
+    aud::SegmentFinishArgs f;
+    std::memset(&f, 0, sizeof(f));
+    f.n_items = n_items;
+    f.T = p->d.segment_steps;
+    f.n_coefs = p->d.mfcc_coefs;
+    const int fw = aud::melspec_wave_frames_per_wave(p->wave_kind);
+    f.tiles = (p->d.segment_steps + fw - 1) / fw;
+    f.mfcc_acc = a.mfcc_acc;
+    f.energy_part = a.energy_part;
+    f.mfcc = mfcc;
+    f.deltas = deltas;
+    f.delta_deltas = delta_deltas;
+    f.energy = energy;
+    AUD_HIP(c, aud::launch_segment_finish(f, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
+    return AUD_OK;
+}
+
 int aud_gabor_batch_dev(aud_plan* p, const float* mel, int n_items, int rows, int cols, int out_rank,
                         const int32_t* out_shape, int by_time, float* out, void* stream) {
     if (!p) return AUD_EINVAL;

@@ -262,10 +262,11 @@ int aud_melspec_mfcc_batch_host(aud_plan* p, const double* sig, int64_t sig_tota
     AUD_HIP(c, hipMemcpyAsync(c->ws[0], sig, sig_bytes, hipMemcpyHostToDevice, c->stream));
     AUD_HIP(c, hipMemcpyAsync(c->ws[1], items, item_bytes, hipMemcpyHostToDevice, c->stream));
     const aud_item* d_items = static_cast<const aud_item*>(c->ws[1]);
-    rc = aud_melspec_batch_dev(p, c->ws[0], AUD_F64, d_items, n_items, d_mel, d_pow, d_lp, c->stream);
-    if (rc == AUD_OK)
-        rc = aud_mfcc_batch_dev(p, d_items, n_items, d_mel, d_lp, d_cc, deltas ? d_dl : nullptr,
-                                delta_deltas ? d_ddl : nullptr, d_en, c->stream);
+    int64_t ws_bytes = 0;
+    (void)aud_segment_workspace_bytes(p, n_items, &ws_bytes);
+    if ((rc = ensure_ws(c, 3, size_t(ws_bytes) + 16)) != AUD_OK) return rc;
+    rc = aud_segment_batch_dev(p, c->ws[0], AUD_F64, d_items, n_items, d_mel, d_pow, d_lp, d_cc, deltas ? d_dl : nullptr,
+                               delta_deltas ? d_ddl : nullptr, d_en, c->ws[3], ws_bytes, c->stream);
     if (rc != AUD_OK) {
         (void)hipStreamSynchronize(c->stream);
         return rc;

@@ -428,6 +428,11 @@ __device__ __forceinline__ float mantissa_log(float m, int ex) {
     const float ln2 = 0.693147180559945309417f;
     return fmaf(float(ex), ln2, __builtin_amdgcn_logf(m) * ln2);
 }
+// the same logarithm before its float32 rounding (what a float64 consumer of the value reads): absolute error ~4e-8
+__device__ __forceinline__ double mantissa_log_wide(float m, int ex) {
+    const double ln2 = 0.693147180559945309417;
+    return mad(double(ex), ln2, double(__builtin_amdgcn_logf(m)) * ln2);
+}
 __device__ __forceinline__ float feature_log(float v) {
     int ex = 0;
     const float m = frexpf(v, &ex);  // m = v for 0, inf and NaN, with ex = 0
@@ -523,13 +528,36 @@ __device__ __forceinline__ float scaled_power(float p4, int) { return p4; }
 // group, so the loop bounds are scalar and a step is two 16-byte LDS reads and four multiply-adds into four running sums
 // (one per position in the chunk: at most 2 x the slot's steps additions each, pairwise at the end).  No LDS access sits
 // under a lane condition: a masked frame still reads its -- valid -- row and drops the sums.
+// Sums over the lanes of a wave that hold one value per (frame, group): lane = group * FPW + frame.
+//   frames_sum: over the FPW frames of a group; valid in the group's frame-0 lane.  Order ((0+1)+(2+3))+(4+5).
+//   groups_sum: over the G groups of a frame; valid in the lanes of group 0.  Pairwise tree, the same order on every run.
+// (ds_bpermute moves: the lane groups are not aligned to anything a DPP control could name.)
+template <int FPW, typename V>
+__device__ __forceinline__ V frames_sum(V v) {
+    static_assert(FPW == 4 || FPW == 6, "frames per wave");
+    const V a1 = v + __shfl_down(v, 1, 64);
+    const V a2 = a1 + __shfl_down(a1, 2, 64);
+    if constexpr (FPW == 4) return a2;
+    else return a2 + __shfl_down(a1, 4, 64);
+}
+template <int FPW, typename V>
+__device__ __forceinline__ V groups_sum(V v) {
+    constexpr int G = 64 / FPW;
+    static_assert(G == 16 || G == 10, "filter groups per wave");
+    const V a1 = v + __shfl_down(v, FPW, 64);
+    const V a2 = a1 + __shfl_down(a1, 2 * FPW, 64);
+    const V a4 = a2 + __shfl_down(a2, 4 * FPW, 64);
+    if constexpr (G == 16) return a4 + __shfl_down(a4, 8 * FPW, 64);
+    else return a4 + __shfl_down(a1, 8 * FPW, 64);  // groups 8 and 9
+}
+
 // MODE (wave-uniform, chosen once per tile): 0 = LogOffSet == 0: float32 throughout (p4 2^(sc-2) rounds once either way,
 // and its logarithm is the mantissa's plus the shifted exponent); 1 = an ordinary positive LogOffSet (the reference's
 // default is 1.0, dft.go:37) and every frame's scale small enough for the sum to be a normal float32: one float64
 // multiply-add, then the float32 logarithm; 2 = anything else: float64 ldexp / add / frexp as the definition reads.
 template <typename TT, int FPW, int MODE>
 __device__ __forceinline__ void wave_spectrum_loop(const MelspecArgs& a, const float* prow, int sc, int g, size_t o,
-                                                   bool col_on, bool live) {
+                                                   bool col_on, bool live, TT* epart, bool first_frame) {
     constexpr int G = 64 / FPW;
     const int H = a.H;
     const size_t ostep = size_t(G) * a.T;
@@ -539,43 +567,55 @@ __device__ __forceinline__ void wave_spectrum_loop(const MelspecArgs& a, const f
     for (int i = 0; i < n_it; ++i) {
         const int k = g + G * i;
         const float p4 = prow[k < H ? k : H - 1];
-        float pw, lp = 0.f;
+        // the logarithm's argument as mantissa and exponent (`none`: the exact-zero case, LogMin)
+        float pw, m = 1.f;
+        int ex = 0;
+        bool none = false;
         if constexpr (sizeof(TT) == 8 && MODE == 0) {
             pw = ldexpf(p4, sc - 2);
-            if (want_lp) {
-                int ex = 0;
-                const float m = frexpf(p4, &ex);
-                lp = p4 == 0.f ? float(a.dft_log_min) : mantissa_log(m, ex + sc - 2);
-            }
+            m = frexpf(p4, &ex);
+            ex += sc - 2;
+            none = p4 == 0.f;
         } else if constexpr (sizeof(TT) == 8 && MODE == 1) {
             pw = ldexpf(p4, sc - 2);
-            if (want_lp) lp = feature_log(float(mad(double(p4), scale_d, a.dft_log_off)));  // > 0: never the LogMin case
+            m = frexpf(float(mad(double(p4), scale_d, a.dft_log_off)), &ex);  // > 0: never the LogMin case
         } else if constexpr (sizeof(TT) == 8) {
             const double pd = ldexp(double(p4), sc - 2);
             pw = float(pd);
-            if (want_lp) {
-                const double vv = pd + a.dft_log_off;
-                lp = float(vv == 0.0 ? a.dft_log_min : feature_log(vv));
-            }
+            const double vv = pd + a.dft_log_off;
+            m = float(frexp(vv, &ex));
+            none = vv == 0.0;
         } else {
             pw = 0.25f * p4;
-            if (want_lp) {
-                const float vv = pw + float(a.dft_log_off);
-                lp = vv == 0.f ? float(a.dft_log_min) : feature_log(vv);
-            }
+            const float vv = pw + float(a.dft_log_off);
+            m = frexpf(vv, &ex);
+            none = vv == 0.f;
         }
+        const float lp = !want_lp ? 0.f : none ? float(a.dft_log_min) : mantissa_log(m, ex);
         if (col_on && k < H) {
             if (a.power) a.power[o] = live ? pw : 0.f;
             if (a.log_power) a.log_power[o] = lp;
         }
         o += ostep;
+        if constexpr (FPW == 4 || FPW == 6) {
+            // fused segment tail: Energy[s] sums LogPowerSegment(s, f) over the steps f -- bin s < T of every frame
+            // (sndenv.go:360-366), a float64 tensor in the reference: the same logarithm before its float32
+            // rounding.  This tile's share goes to its row of energy_part.
+            if (epart && G * i < a.T) {  // wave-uniform
+                TT wide;
+                if constexpr (sizeof(TT) == 8) wide = none ? a.dft_log_min : mantissa_log_wide(m, ex);
+                else wide = lp;
+                const TT part = frames_sum<FPW>(want_lp && col_on ? wide : TT(0));
+                if (first_frame && k < a.T) epart[k] = part;
+            }
+        }
     }
 }
 
 template <typename TT, int FPW>
 __device__ __forceinline__ void wave_spectrum_outputs(const MelspecArgs& a, const float* P, int Hp, int sc,
                                                       const aud_item& it, int item, int t0, int lane) {
-    if (!a.power && !a.log_power) return;
+    if (!a.power && !a.log_power && !a.energy_part) return;
     // a lane keeps ONE frame (lane % FPW) and walks the bins k = lane / FPW, + 64 / FPW, ...: step, liveness and the output
     // addresses are per-lane constants, every iteration is one LDS read, the logarithm and two stores.  Lanes beyond
     // FPW * (64 / FPW) repeat the last group and store nothing; reads past the last bin are clamped, not skipped.
@@ -590,15 +630,18 @@ __device__ __forceinline__ void wave_spectrum_outputs(const MelspecArgs& a, cons
     const bool live = start + a.N <= int64_t(it.sig_len);
     const float* prow = P + ff * Hp;
     const size_t o = (size_t(item) * H + g) * T + (col_on ? sstep : 0);
+    const int tiles = (T + FPW - 1) / FPW;
+    TT* epart = a.energy_part ? static_cast<TT*>(a.energy_part) + (size_t(item) * tiles + t0 / FPW) * T : nullptr;
+    const bool first_frame = has && ff == 0;
     if constexpr (sizeof(TT) == 8) {
         const double off = a.dft_log_off;
         // the scaled peak of a frame is below 2^26 (frame_scale), so with sc < 96 the sum is below 2^123
         const bool small = __builtin_amdgcn_ballot_w64(sc >= 96 || sc < -900) == 0;
-        if (off == 0.0) wave_spectrum_loop<TT, FPW, 0>(a, prow, sc, g, o, col_on, live);
-        else if (small && off >= 1e-30 && off <= 1e30) wave_spectrum_loop<TT, FPW, 1>(a, prow, sc, g, o, col_on, live);
-        else wave_spectrum_loop<TT, FPW, 2>(a, prow, sc, g, o, col_on, live);
+        if (off == 0.0) wave_spectrum_loop<TT, FPW, 0>(a, prow, sc, g, o, col_on, live, epart, first_frame);
+        else if (small && off >= 1e-30 && off <= 1e30) wave_spectrum_loop<TT, FPW, 1>(a, prow, sc, g, o, col_on, live, epart, first_frame);
+        else wave_spectrum_loop<TT, FPW, 2>(a, prow, sc, g, o, col_on, live, epart, first_frame);
     } else {
-        wave_spectrum_loop<TT, FPW, 2>(a, prow, sc, g, o, col_on, live);
+        wave_spectrum_loop<TT, FPW, 2>(a, prow, sc, g, o, col_on, live, epart, first_frame);
     }
 }
 
@@ -624,6 +667,14 @@ __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const Wa
     const bool plain = a.mel_log_off == 0.0 && !a.renorm;  // wave-uniform: the reference's defaults (mel.go:80, :175)
     const float lminf = float(a.mel_log_min);
     float* mel_col = a.mel + (size_t(item) * a.nf * T + (col_on ? sstep : 0));
+    // fused segment tail: this lane's share of the frame's CepstrumDct (mel.go:192-212), coefficients 1 .. kDctCoefs - 1
+    // (coefficient 0 is never seen: ProcessSegment overwrites MFCC row 0 with Energy, sndenv.go:368-372)
+    constexpr bool kCanFuse = !COMPACT && (FPW == 4 || FPW == 6);
+    const bool fuse = kCanFuse && a.mfcc_acc != nullptr && e.dct_off >= 0;  // wave-uniform
+    TT cc[kDctCoefs];
+#pragma unroll
+    for (int c = 0; c < kDctCoefs; ++c) cc[c] = TT(0);
+    const TT* dct_t = reinterpret_cast<const TT*>(smem + (e.dct_off >= 0 ? e.dct_off : 0));
 #pragma unroll
     for (int k = 0; k < MAXS; ++k) {
         if (k < e.n_slots) {  // wave-uniform
@@ -658,10 +709,13 @@ __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const Wa
             const int flt = int(rec >> 16);
             const float sum = (s0 + s1) + (s2 + s3);  // = (the reference's sum) / 2^sc
             float res;
+            TT wide;  // the same value before its float32 rounding (what the reference's DCT reads is a float64)
             if (plain) {
                 int ex = 0;
                 const float m = frexpf(sum, &ex);  // m = sum for 0 and NaN, with ex = 0
                 res = sum == 0.f ? lminf : mantissa_log(m, ex + sc);
+                if constexpr (sizeof(TT) == 8) wide = sum == 0.f ? a.mel_log_min : mantissa_log_wide(m, ex + sc);
+                else wide = res;
             } else {
                 const double sd = ldexp(double(sum), sc) + a.mel_log_off;
                 double val = sd == 0.0 ? a.mel_log_min : feature_log(sd);
@@ -672,8 +726,29 @@ __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const Wa
                     if (val > 1.0) val = 1.0;
                 }
                 res = float(val);
+                wide = TT(val);
             }
             if (col_on && flt != 0xFFFF) mel_col[size_t(flt) * T] = live ? res : 0.f;  // MelFBankSegment[item][flt][sstep]
+            if constexpr (kCanFuse) {
+                if (fuse) {
+                    const bool on = live && flt != 0xFFFF;
+                    const TT x = on ? wide : TT(0);  // a step the loop never reached keeps MFCC = 0
+                    const TT* drow = dct_t + (on ? flt : 0) * kDctPitch;
+#pragma unroll
+                    for (int c = 1; c < kDctCoefs; ++c) cc[c] = mad(drow[c], x, cc[c]);
+                }
+            }
+        }
+    }
+    if constexpr (kCanFuse) {
+        if (fuse) {
+            TT* out = static_cast<TT*>(a.mfcc_acc) + size_t(item) * a.n_coefs * T + (col_on ? sstep : 0);
+            const bool writer = has && g0 == 0 && col_on;  // the frame's lane of group 0
+#pragma unroll
+            for (int c = 1; c < kDctCoefs; ++c) {
+                const TT tot = groups_sum<FPW>(has ? cc[c] : TT(0));
+                if (writer && c < a.n_coefs) out[size_t(c) * T] = tot;
+            }
         }
     }
 }

@@ -60,6 +60,12 @@ struct MelspecArgs {
     const void* bl_bhat;   // [L] complex<TT>: FFT_L of the wrapped conjugate chirp, / L
     const void* bl_tw;     // [L] complex<TT>: exp(-2 pi i k / L)
     int xcd_remap;     // 1: tile_of_workgroup() order (plan option "xcd_remap", default on)
+    // fused segment tail (aud_segment_batch_dev): the wave kernels w16x16 / w20x10 of a plan with WaveArgs::dct_off >= 0
+    // also leave, per item, the CepstrumDct rows 1.. of the UNROUNDED log-mel values and per-tile Energy sums for
+    // launch_segment_finish; both null otherwise
+    void* mfcc_acc;      // [n_items][n_coefs][T] compute type (row 0 is not written: ProcessSegment overwrites it with Energy)
+    void* energy_part;   // [n_items][tiles][T] compute type: sum over the tile's frames of LogPower[bin s < T][frame] (Q8 axis quirk)
+    int n_coefs;
     // diagnostic builds only (-DAUD_STAMPS, tools/stamp_profile.py): [waves][16] s_memtime stamps of the wave
     // kernels' phases.  Never read by anything that computes an output.
     unsigned long long* stamps;
@@ -145,7 +151,11 @@ struct WaveArgs {
     unsigned lds_bytes;    // dynamic LDS of the launch
     int waves;             // waves per workgroup of the launch
     int wgs_per_cu;        // the runtime's occupancy answer (aud_plan_get_info)
+    int dct_off;           // fused segment tail: TT [nf][kDctPitch], row f = column f of the DCT-I matrix (coefficient c at
+                           // [c], zero beyond n_coefs); -1: the plan has no fused tail
 };
+constexpr int kDctCoefs = 13;  // coefficients the fused tail carries per lane (the reference's default NCoefs, mel.go:71)
+constexpr int kDctPitch = 14;  // row pitch of the table (16-byte rows in float64)
 
 // PrevSmooth != 0 mode: scan along the steps of a stored power tensor
 struct SmoothArgs {
@@ -176,6 +186,19 @@ struct MfccArgs {
     float* energy;           // [n_items, T] or null
 };
 hipError_t launch_mfcc(const MfccArgs& a, int compute_dtype, hipStream_t st);
+// what is left of the tail behind a mel launch that carried mfcc_acc / energy_part: Energy from the per-tile sums, MFCC
+// row 0 <- Energy, deltas and delta-deltas from the unrounded coefficients (one workgroup per item)
+struct SegmentFinishArgs {
+    int n_items, T, n_coefs, tiles;
+    const void* mfcc_acc;      // MelspecArgs::mfcc_acc
+    const void* energy_part;   // MelspecArgs::energy_part
+    float* mfcc;               // [n_items, n_coefs, T]
+    float* deltas;             // or null
+    float* delta_deltas;       // or null
+    float* energy;             // [n_items, T] or null
+};
+size_t segment_finish_lds_bytes(int n_coefs, int T, int compute_dtype);
+hipError_t launch_segment_finish(const SegmentFinishArgs& a, int compute_dtype, hipStream_t st);
 hipError_t launch_mfcc_dct(const MfccArgs& a, int compute_dtype, hipStream_t st);
 
 // generic any-N kernel (Stockham in LDS, radix 2/4 + per-output generic radix)

@@ -171,7 +171,67 @@ __global__ __launch_bounds__(kFusedThreads) void k_mfcc_fused(const MfccArgs a) 
     }
 }
 
+// What is left of the tail behind a mel launch that carried MelspecArgs::mfcc_acc / energy_part (aud_segment_batch_dev): one
+// workgroup per item.  The coefficients arrive UNROUNDED in the compute type and stay so in LDS: deltas and delta-deltas
+// are computed from them as the reference computes them from its float64 tensors (sndenv.go:378-431); float32 only at the
+// stores.  Energy[s] = the per-tile sums added in tile order (sndenv.go:360-366), MFCC row 0 <- Energy (:368-372).
+constexpr int kFinishThreads = 256;
+
+template <typename TT>
+__global__ __launch_bounds__(kFinishThreads) void k_segment_finish(const SegmentFinishArgs a) {
+    TT* cofL = reinterpret_cast<TT*>(dyn_lds());  // [nc][T]
+    TT* dltL = cofL + a.n_coefs * a.T;            // [nc][T]
+    const int T = a.T, nc = a.n_coefs, tid = int(threadIdx.x), item = int(blockIdx.x);
+    const TT* __restrict__ acc = static_cast<const TT*>(a.mfcc_acc) + size_t(item) * nc * T;
+    for (int i = tid + T; i < nc * T; i += kFinishThreads) cofL[i] = acc[i];  // rows 1..: the mel kernel's DCT
+    const TT* __restrict__ ep = static_cast<const TT*>(a.energy_part) + size_t(item) * a.tiles * T;
+    for (int s = tid; s < T; s += kFinishThreads) {
+        TT e = TT(0);
+        for (int t = 0; t < a.tiles; ++t) e += ep[size_t(t) * T + s];
+        if (a.energy) a.energy[size_t(item) * T + s] = float(e);
+        cofL[s] = e;  // SetFloatRowCell(0, s, Energy[s])
+    }
+    __syncthreads();
+    float* mf = a.mfcc + size_t(item) * nc * T;
+    for (int i = tid; i < nc * T; i += kFinishThreads) mf[i] = float(cofL[i]);
+    if (!a.deltas) return;  // uniform
+    for (int pass = 0; pass < 2; ++pass) {
+        const TT* in = pass ? dltL : cofL;
+        float* out = (pass ? a.delta_deltas : a.deltas) + size_t(item) * nc * T;
+        for (int s = tid; s < T; s += kFinishThreads) {
+            TT prv = TT(0), nxt = TT(0);
+            for (int i = 0; i < nc; ++i) {
+                TT nume = TT(0), d = TT(0);
+                for (int n = 1; n <= 2; ++n) {
+                    const int sprv = max(s - n, 0), snxt = min(s + n, T - 1);
+                    prv += in[i * T + sprv];
+                    nxt += in[i * T + snxt];
+                    nume += TT(n) * (nxt - prv);
+                    d = nume / TT(2 * n * n);
+                }
+                out[i * T + s] = float(d);
+                if (!pass) dltL[i * T + s] = d;
+            }
+        }
+        if (!a.delta_deltas) return;  // uniform
+        __syncthreads();
+    }
+}
+
 }  // namespace
+
+size_t segment_finish_lds_bytes(int n_coefs, int T, int compute_dtype) {
+    return 2 * size_t(n_coefs) * T * (compute_dtype == AUD_F64 ? 8 : 4);
+}
+
+hipError_t launch_segment_finish(const SegmentFinishArgs& a, int compute_dtype, hipStream_t st) {
+    if (a.n_items == 0) return hipSuccess;
+    const size_t lds = segment_finish_lds_bytes(a.n_coefs, a.T, compute_dtype);
+    if (compute_dtype == AUD_F64)
+        hipLaunchKernelGGL(k_segment_finish<double>, dim3(unsigned(a.n_items)), dim3(kFinishThreads), lds, st, a);
+    else hipLaunchKernelGGL(k_segment_finish<float>, dim3(unsigned(a.n_items)), dim3(kFinishThreads), lds, st, a);
+    return hipGetLastError();
+}
 
 // mel.Params.CepstrumDct alone (the reference's per-step entry point)
 hipError_t launch_mfcc_dct(const MfccArgs& a, int compute_dtype, hipStream_t st) {

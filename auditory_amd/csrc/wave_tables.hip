@@ -145,6 +145,21 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
     e.pairs_off = int(e.tws_off + align32(tws.size() * tsz));
     e.blob_bytes = int(e.pairs_off + align32(pairs.size() * 2));
     e.n_groups = G;
+    // fused segment tail (w16x16 / w20x10, up to kDctCoefs coefficients): the transposed DCT-I rows, one row per filter
+    // (the same formula as the plan's d_dct table, capi.hip)
+    std::vector<double> dct_t;
+    e.dct_off = -1;
+    if (kind != 4 && d.mfcc_coefs >= 1 && d.mfcc_coefs <= aud::kDctCoefs && d.segment_steps <= N / 2 + 1) {
+        dct_t.assign(size_t(nf) * aud::kDctPitch, 0.0);
+        const long double pi = 3.14159265358979323846264338327950288L;
+        for (int k = 0; k < d.mfcc_coefs; ++k)
+            for (int j = 0; j < nf; ++j)
+                dct_t[size_t(j) * aud::kDctPitch + k] =
+                    j == 0 ? 1.0 : j == nf - 1 ? ((k & 1) ? -1.0 : 1.0)
+                                               : double(2.0L * cosl(pi * (long double)j * (long double)k / (long double)(nf - 1)));
+        e.dct_off = e.blob_bytes;
+        e.blob_bytes += int(align32(dct_t.size() * tsz));
+    }
     std::vector<unsigned char> blob(size_t(e.blob_bytes), 0);
     auto put_real = [&](size_t off, const std::vector<double>& v) {
         if (v.empty()) return;
@@ -162,6 +177,7 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
     put_real(size_t(e.twa_off), twa);
     put_real(size_t(e.tws_off), tws);
     if (!pairs.empty()) std::memcpy(&blob[size_t(e.pairs_off)], pairs.data(), pairs.size() * 2);
+    if (e.dct_off >= 0) put_real(size_t(e.dct_off), dct_t);
     if (!aud::melspec_wave_finish(kind, dt, &e)) return AUD_OK;  // does not fit LDS
     if (aud::melspec_wave_prepare(kind, dt, &e) != hipSuccess) {
         (void)hipGetLastError();

@@ -92,7 +92,7 @@ class Plan:
         return int(v.value)
 
     def set_option(self, name, value):
-        """aud_plan_set_option: "kernel" (0 auto / 1 generic), "r16_input" (0 direct / 1 staged)"""
+        """aud_plan_set_option: "kernel" (0 auto / 1 generic), "xcd_remap" (1 / 0)"""
         self.ctx.check(self.lib.aud_plan_set_option(self.handle, name.encode(), int(value)))
 
     # ---- device-pointer calls (ints are raw device addresses; stream is a hipStream_t) ----
@@ -115,6 +115,20 @@ class Plan:
                                                       stream or None))
 
     # ---- host-buffer calls (float64 in / float64+float32 out, like the Go tensors) ---------
+    def segment_workspace_bytes(self, n_items):
+        n = C.c_int64(0)
+        self.ctx.check(self.lib.aud_segment_workspace_bytes(self.handle, n_items, C.byref(n)))
+        return n.value
+
+    def segment_dev(self, sig_ptr, sig_dtype, items_ptr, n_items, mel_ptr, power_ptr, log_power_ptr, mfcc_ptr,
+                    deltas_ptr, delta_deltas_ptr, energy_ptr, workspace_ptr, workspace_bytes, stream=0):
+        """SndEnv.ProcessSegment with Mel.MFCC on for n_items segments (aud_segment_batch_dev); 0 = NULL for the optional
+        outputs"""
+        self.ctx.check(self.lib.aud_segment_batch_dev(self.handle, sig_ptr, sig_dtype, items_ptr, n_items, mel_ptr,
+                                                      power_ptr or None, log_power_ptr or None, mfcc_ptr,
+                                                      deltas_ptr or None, delta_deltas_ptr or None, energy_ptr or None,
+                                                      workspace_ptr, workspace_bytes, stream or None))
+
     def melspec_host(self, sig, items, want_power=False, want_log_power=False):
         sig = np.ascontiguousarray(sig, np.float64)
         items = np.ascontiguousarray(items, dtype=ITEM_DTYPE)

@@ -270,6 +270,8 @@ def main():  # noqa: C901
                          "overlap their load burst with the previous launch's tail, as a double-buffered pipeline does.  Default "
                          "for cfg4 / sndenv: 4 -- a step is two dependent launches there.  `roofline` is always taken from a "
                          "1-stream region: one kernel alone on the chip, the duration rocprofv3 reports")
+    ap.add_argument("--tail", choices=["fused", "parts"], default="fused",
+                    help="--workload sndenv: aud_segment_batch_dev (default) or aud_melspec_batch_dev + aud_mfcc_batch_dev")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="aud_plan_set_option switches, e.g. kernel=1 (the generic kernel)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for CPU dry runs)")
@@ -448,6 +450,9 @@ def main():  # noqa: C901
             f32buf = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
             sets = [dict(pw=f32buf(nb, wl.H, wl.T), lp=f32buf(nb, wl.H, wl.T), mfcc=f32buf(nb, 13, wl.T), d1=f32buf(nb, 13, wl.T),
                          d2=f32buf(nb, 13, wl.T), en=f32buf(nb, wl.T)) for _ in range(4)]
+            ws_bytes = plan.segment_workspace_bytes(nb)
+            for o in sets:
+                o["ws"] = torch.empty(ws_bytes + 16, dtype=torch.uint8, device=dev)
 
         def launch(i, st):
             r = i % ring.R
@@ -456,11 +461,18 @@ def main():  # noqa: C901
                                                ring.mel[r].data_ptr(), GABOR_POOLS[0], GABOR_POOLS[1], gout[r].data_ptr(), st)
             elif full:
                 o = sets[i % 4]
-                rc = lib.aud_melspec_batch_dev(ph, ring.sig[r].data_ptr(), sig_code, ring.items.data_ptr(), nb,
-                                               ring.mel[r].data_ptr(), o["pw"].data_ptr(), o["lp"].data_ptr(), st)
-                if rc == 0:
-                    rc = lib.aud_mfcc_batch_dev(ph, ring.items.data_ptr(), nb, ring.mel[r].data_ptr(), o["lp"].data_ptr(),
-                                                o["mfcc"].data_ptr(), o["d1"].data_ptr(), o["d2"].data_ptr(), o["en"].data_ptr(), st)
+                if args.tail == "fused":  # SndEnv.ProcessSegment as one call (the tail rides in the mel kernel where it can)
+                    rc = lib.aud_segment_batch_dev(ph, ring.sig[r].data_ptr(), sig_code, ring.items.data_ptr(), nb,
+                                                   ring.mel[r].data_ptr(), o["pw"].data_ptr(), o["lp"].data_ptr(),
+                                                   o["mfcc"].data_ptr(), o["d1"].data_ptr(), o["d2"].data_ptr(), o["en"].data_ptr(),
+                                                   o["ws"].data_ptr(), ws_bytes, st)
+                else:                     # its two parts on the stored tensors (A/B)
+                    rc = lib.aud_melspec_batch_dev(ph, ring.sig[r].data_ptr(), sig_code, ring.items.data_ptr(), nb,
+                                                   ring.mel[r].data_ptr(), o["pw"].data_ptr(), o["lp"].data_ptr(), st)
+                    if rc == 0:
+                        rc = lib.aud_mfcc_batch_dev(ph, ring.items.data_ptr(), nb, ring.mel[r].data_ptr(), o["lp"].data_ptr(),
+                                                    o["mfcc"].data_ptr(), o["d1"].data_ptr(), o["d2"].data_ptr(),
+                                                    o["en"].data_ptr(), st)
             else:
                 rc = lib.aud_melspec_batch_dev(ph, ring.sig[r].data_ptr(), sig_code, ring.items.data_ptr(), nb,
                                                ring.mel[r].data_ptr(), None, None, st)
@@ -472,8 +484,10 @@ def main():  # noqa: C901
         alg = nb * (ring.sample_bytes * wl.dur + 4 * wl.nf * wl.T)      # each sample read once + each mel value written once
         if gabor:  # unfused gabor: re-read the mel tensor, write the pooled on/off pairs
             alg += nb * (4 * wl.nf * wl.T + 4 * GABOR_POOLS[0] * GABOR_POOLS[1] * 2 * 8)
-        if full:   # Power + LogPower written, mel + LogPower re-read by the MFCC tail, its four small tensors written
-            alg += nb * (2 * 4 * wl.H * wl.T + 4 * wl.nf * wl.T + 4 * wl.H * wl.T + 4 * (3 * 13 + 1) * wl.T)
+        if full:   # Power + LogPower and the tail's four small tensors written; the unfused tail also re-reads mel + LogPower
+            alg += nb * (2 * 4 * wl.H * wl.T + 4 * (3 * 13 + 1) * wl.T)
+            if args.tail != "fused":
+                alg += nb * (4 * wl.nf * wl.T + 4 * wl.H * wl.T)
         res.update({"workload": wl.name, "compute": compute, "kernel": plan.kernel_name, "batch": nb,
                     "ring": {"buffers": ring.R, "input_MB": round(ring.R * nb * wl.L * ring.sample_bytes / 1e6, 1)},
                     "algorithmic_bytes_per_launch": alg,

@@ -274,6 +274,22 @@ int aud_mfcc_batch_dev(aud_plan* plan, const aud_item* items, int n_items, const
                        const float* log_power, float* mfcc, float* deltas, float* delta_deltas,
                        float* energy, void* stream);
 
+/* The whole of SndEnv.ProcessSegment (sound/sndenv.go:342-431) with Mel.MFCC on, device-resident: the frame loop of
+ * aud_melspec_batch_dev and the tail of aud_mfcc_batch_dev as ONE pass over the spectrum.  Where the plan runs a wave
+ * kernel for N = 400 / N = 512, has at most 13 coefficients and dft.PrevSmooth == 0, the frame->mel kernel itself leaves
+ * the CepstrumDct of the UNROUNDED log-mel values (the reference's tensors are float64, sndenv.go:106-136; the float32
+ * mel tensor of this boundary is only what is stored) and per-tile Energy sums in `workspace`, and a small second launch
+ * finishes Energy, the row-0 overwrite, deltas and delta-deltas from them; any other plan runs the two calls above.
+ *   mel as in aud_melspec_batch_dev; power / log_power [n_items, H, T] or NULL; mfcc [n_items, NCoefs, T];
+ *   deltas / delta_deltas [n_items, NCoefs, T] or NULL; energy [n_items, T] or NULL;
+ *   workspace: device, 16-byte aligned, aud_segment_workspace_bytes(plan, n_items) bytes, contents undefined afterwards
+ *   (caller-owned so that the call can sit inside a stream capture).
+ * Needs desc.mfcc_coefs > 0 and dft.CompLogPow; AUD_EINVAL if T > H (the Go code indexes out of range). */
+int aud_segment_workspace_bytes(const aud_plan* plan, int n_items, int64_t* bytes);
+int aud_segment_batch_dev(aud_plan* plan, const void* sig, int sig_dtype, const aud_item* items, int n_items,
+                          float* mel, float* power, float* log_power, float* mfcc, float* deltas,
+                          float* delta_deltas, float* energy, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- hot path, host buffers (what the cgo shim binds) ---------------------------- */
 
 /* Same as aud_melspec_batch_dev on host memory: sig float64 (SndEnv.Signal values), items on
@@ -282,7 +298,7 @@ int aud_melspec_batch_host(aud_plan* plan, const double* sig, int64_t sig_total,
                            const aud_item* items, int n_items, double* mel, double* power,
                            double* log_power);
 
-/* aud_melspec_batch_host + aud_mfcc_batch_dev in one call (SndEnv.ProcessSegment with Mel.MFCC on):
+/* aud_segment_batch_dev on host memory (SndEnv.ProcessSegment with Mel.MFCC on):
  * outputs float64; power / log_power / deltas / delta_deltas / energy may be NULL. */
 int aud_melspec_mfcc_batch_host(aud_plan* plan, const double* sig, int64_t sig_total, const aud_item* items,
                                 int n_items, double* mel, double* power, double* log_power, double* mfcc,

@@ -653,37 +653,42 @@ def case_n2048_variants(orc, cdt, seg_ms=300.0, dur=0.4, rows=2):
         case_melspec_vs_oracle(orc, (name, dur, rows, [0, 1]), cdt, seg_ms=seg_ms, options=opts)
 
 
-def case_mfcc_tail(orc, name, cdt):
-    """CepstrumDct + Energy (axis quirk Q8) + deltas (carried sums) vs the oracle"""
+def case_mfcc_tail(orc, name, cdt, options=None):
+    """CepstrumDct + Energy (axis quirk Q8) + deltas (carried sums) vs the oracle, through the one-call
+    ProcessSegment entry (aud_melspec_mfcc_batch_host -> aud_segment_batch_dev).  Every tensor under the per-element
+    criterion |d| <= tol max(1, |ref|).  Where the plan runs the w16x16 / w20x10 kernel the tail is FUSED: the DCT reads the
+    unrounded log-mel values and the deltas the unrounded coefficients, as the reference's float64 tensors do; what is
+    left is the float32 spectrum behind the mel sums (log-mel within ~1e-7 absolute).  Any other plan computes the tail
+    from the float32-STORED mel / log-power tensors (aud_mfcc_batch_dev): one more rounding of every input.  The
+    delta-deltas difference running sums that are carried across ALL coefficients (sndenv.go:385-431), Energy row
+    (~T x 5) included: their error is that of the sums, their own size is whatever is left after the cancellation."""
     oc = W.OracleCfg(orc, name)
     L = int(0.5 * oc.sr)
     sig, _ = synth.batch(19, 2, L, oc.sr)
     segs = [(r, s) for r in range(2) for s in (0, 1, 3)]
     plan = W.product_plan(oc, cdt, mfcc_coefs=13)
     try:
+        for k, v in (options or {}).items():
+            plan.set_option(k, v)
+        fused = plan.kernel_name in ("w16x16", "w20x10")
         got = plan.melspec_mfcc_host(sig.ravel(), make_items(oc, L, segs))
-        plain, _, _ = plan.melspec_host(sig.ravel(), make_items(oc, L, segs))
+        plain, pw, lp = plan.melspec_host(sig.ravel(), make_items(oc, L, segs), True, True)
     finally:
         plan.close()
-    assert np.array_equal(got["mel"], plain, equal_nan=True)
+    assert np.array_equal(got["mel"], plain, equal_nan=True)          # the fused tail does not change the stored tensors
+    assert np.array_equal(got["power"], pw) and np.array_equal(got["log_power"], lp)
+    if cdt == capi.AUD_F64:
+        tols = dict(mfcc=4e-6, deltas=6e-6, delta_deltas=5e-5, energy=3e-7) if fused else \
+            dict(mfcc=8e-6, deltas=4e-5, delta_deltas=2e-4, energy=3e-7)
+    else:
+        tols = dict(mfcc=5e-5, deltas=2e-4, delta_deltas=1e-3, energy=1e-6)
     for i, (r, sg) in enumerate(segs):
         o = orc.process_segment_mfcc(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig[r], segment=sg)
         ok, msg = W.feature_close(got["mel"][i], o["mel_seg"], cdt, lin_axis=0)
         assert ok, "mel " + msg
-        if cdt == capi.AUD_F64:
-            # the DCT sums ~nf float32-STORED mel values (the tensors at the boundary are float32): 3e-6
-            ok, msg = W.close_enough(got["mfcc"][i], o["mfcc"], 6e-6)
-        else:
-            ok, msg = W.feature_close(got["mfcc"][i], o["mfcc"], cdt)
-        assert ok, "mfcc item %d: %s" % (i, msg)
-        # deltas are differences of running sums of MFCC values (the Energy row alone is ~T*5), stored in
-        # float32: they are accurate relative to the size of what is being differenced, not to their own
-        scale = max(1.0, float(np.nanmax(np.abs(o["mfcc"]))))
-        for key in ("deltas", "delta_deltas"):
-            err = float(np.nanmax(np.abs(got[key][i] - o[key]))) / scale
-            assert err <= (1e-5 if cdt == capi.AUD_F32 else 2e-6), "%s item %d: %.3g of the MFCC scale" % (key, i, err)
-        ok, msg = W.close_enough(got["energy"][i], o["energy"], 1e-5 if cdt == capi.AUD_F32 else 1e-6)
-        assert ok, "energy " + msg
+        for key, tol in tols.items():
+            ok, msg = W.close_enough(got[key][i], o[key], tol)
+            assert ok, "%s item %d (%s): %s" % (key, i, "fused" if fused else "from stored tensors", msg)
         assert np.array_equal(got["mfcc"][i][0], got["energy"][i])          # row 0 is the Energy row
         dead = o["done"]
         assert np.all(got["mfcc"][i][1:, dead:] == 0)                       # unprocessed steps stay zero

@@ -107,6 +107,11 @@ def test_emul_mfcc_tail(orc, emu, name, cdt):
 
 
 @pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_emul_mfcc_tail_from_stored_tensors(orc, emu, cdt):
+    PC.case_mfcc_tail(orc, "sndenv_16k_n400_nf32", cdt, options={"kernel": 1})     # generic kernel: the unfused tail
+
+
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
 def test_emul_per_step_api(orc, emu, cdt):
     PC.case_per_step_api(orc, cdt)
 

@@ -93,6 +93,11 @@ def test_mfcc_tail(orc, torch_cuda, name, cdt):
 
 
 @pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_mfcc_tail_from_stored_tensors(orc, torch_cuda, cdt):
+    PC.case_mfcc_tail(orc, "sndenv_16k_n400_nf32", cdt, options={"kernel": 1})     # generic kernel: the unfused tail
+
+
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
 def test_per_step_api(orc, torch_cuda, cdt):
     PC.case_per_step_api(orc, cdt)
 
@@ -209,6 +214,36 @@ def test_process_batch_mel_plus_gabor(orc, torch_cuda):
     ok, msg = W.feature_close(gab.cpu().numpy(), ref_g, capi.AUD_F32)
     assert ok, "gabor " + msg
     plan.close()
+
+
+@pytest.mark.parametrize("name", ["cfg2_16k_n400_nf40", "cfg2_16k_n512_nf40", "cfg1_44k_n1103_nf32"])
+def test_segment_device_resident(orc, torch_cuda, name):
+    """aud_segment_batch_dev on tensors in HBM (float32 samples, float64 plan): the same values as the host-staged entry
+    gives for the same float32 samples, with and without the optional outputs; w20x10 / w16x16 run the fused tail, the
+    generic kernel (N = 1103) the two launches of its parts."""
+    torch = torch_cuda
+    from auditory_amd.batch import BatchProcessor
+    oc = W.OracleCfg(orc, name)
+    L = oc.full_len() - 3 * oc.S                  # the last frames run off the end: masked steps (Q7)
+    n = 5
+    sig, _ = synth.batch(29, n, L, oc.sr)
+    sig32 = sig.astype(np.float32)
+    plan = W.product_plan(oc, capi.AUD_F64, mfcc_coefs=13)
+    try:
+        host_items = runtime.make_items(np.arange(n) * L, [L] * n, [0] * n)
+        want = plan.melspec_mfcc_host(sig32.astype(np.float64).ravel(), host_items)
+        bp = BatchProcessor(plan, "cuda:0")
+        items = bp.upload_items(host_items)
+        dsig = torch.from_numpy(sig32).cuda().view(-1)
+        full = bp.segment(dsig, items, n)
+        lean = bp.segment(dsig, items, n, want_spectrum=False, deltas=False)
+        torch.cuda.synchronize()
+        for key in ("mel", "power", "log_power", "mfcc", "deltas", "delta_deltas", "energy"):
+            assert np.array_equal(full[key].cpu().numpy().astype(np.float64), want[key], equal_nan=True), key
+        for key in ("mel", "mfcc", "energy"):
+            assert np.array_equal(lean[key].cpu().numpy(), full[key].cpu().numpy(), equal_nan=True), key
+    finally:
+        plan.close()
 
 
 def test_process_then_kwta_device_resident(orc, torch_cuda, n=6):

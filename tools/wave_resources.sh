@@ -1,9 +1,9 @@
 #!/bin/bash
 # VGPRs / scratch / occupancy of the wave kernels (static, no GPU):  bash tools/wave_resources.sh [extra hipcc flags]
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -I"$ROOT/include" \
-    -I"$ROOT/auditory_amd/csrc" -c "$ROOT/auditory_amd/csrc/melspec_wave.hip" -o /dev/null \
-    -Rpass-analysis=kernel-resource-usage "$@" 2>&1 | python3 -c '
+cd /tmp && for f in melspec_w16 melspec_w20 melspec_w64; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -I"$ROOT/include" \
+    -I"$ROOT/auditory_amd/csrc" -c "$ROOT/auditory_amd/csrc/$f.hip" -o /dev/null \
+    -Rpass-analysis=kernel-resource-usage "$@" 2>&1; done | python3 -c '
 import re, sys, subprocess
 row = {}
 for l in sys.stdin:
