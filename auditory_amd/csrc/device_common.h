@@ -528,44 +528,78 @@ __device__ __forceinline__ float scaled_power(float p4, int) { return p4; }
 // group, so the loop bounds are scalar and a step is two 16-byte LDS reads and four multiply-adds into four running sums
 // (one per position in the chunk: at most 2 x the slot's steps additions each, pairwise at the end).  No LDS access sits
 // under a lane condition: a masked frame still reads its -- valid -- row and drops the sums.
-// Sums over the lanes of a wave that hold one value per (frame, group): lane = group * FPW + frame.
-//   frames_sum: over the FPW frames of a group; valid in the group's frame-0 lane.  Order ((0+1)+(2+3))+(4+5).
-//   groups_sum: over the G groups of a frame; valid in the lanes of group 0.  Pairwise tree, the same order on every run.
-// (ds_bpermute moves: the lane groups are not aligned to anything a DPP control could name.)
-template <int FPW, typename V>
-__device__ __forceinline__ V frames_sum(V v) {
-    static_assert(FPW == 4 || FPW == 6, "frames per wave");
-    const V a1 = v + __shfl_down(v, 1, 64);
-    const V a2 = a1 + __shfl_down(a1, 2, 64);
-    if constexpr (FPW == 4) return a2;
-    else return a2 + __shfl_down(a1, 4, 64);
+// Sum of a value over an ALIGNED block of W = 4 or 8 lanes by data-parallel-primitive moves (no LDS traffic); every lane of
+// the block gets it.  Order ((0+1)+(2+3)) + ((4+5)+(6+7)): the same on every run.
+template <int W>
+__device__ __forceinline__ float block_sum(float v) {
+    static_assert(W == 4 || W == 8, "aligned lane block");
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+    if constexpr (W == 8)
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+    return v;
 }
-template <int FPW, typename V>
-__device__ __forceinline__ V groups_sum(V v) {
-    constexpr int G = 64 / FPW;
-    static_assert(G == 16 || G == 10, "filter groups per wave");
-    const V a1 = v + __shfl_down(v, FPW, 64);
-    const V a2 = a1 + __shfl_down(a1, 2 * FPW, 64);
-    const V a4 = a2 + __shfl_down(a2, 4 * FPW, 64);
-    if constexpr (G == 16) return a4 + __shfl_down(a4, 8 * FPW, 64);
-    else return a4 + __shfl_down(a1, 8 * FPW, 64);  // groups 8 and 9
+__device__ __forceinline__ double dpp_move(double v, int ctrl_b1_4e_141) {
+    const long long bits = __builtin_bit_cast(long long, v);
+    int lo = int(bits), hi = int(bits >> 32);
+    if (ctrl_b1_4e_141 == 0) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
+    } else if (ctrl_b1_4e_141 == 1) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, false);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, false);
+    }
+    return __builtin_bit_cast(double, (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+template <int W>
+__device__ __forceinline__ double block_sum(double v) {
+    static_assert(W == 4 || W == 8, "aligned lane block");
+    v += dpp_move(v, 0);
+    v += dpp_move(v, 1);
+    if constexpr (W == 8) v += dpp_move(v, 2);
+    return v;
 }
 
+// ---- optional spectrum outputs of the wave kernels (dft/dft.go:70-83: PowerSegment / LogPowerSegment [item, H, T]) ----
+// Bins [k_lo, k_hi) of the wave's FPW frames.  A lane keeps ONE frame and walks the bins of its group: lane = group * W +
+// frame with W lanes per group -- W = FPW (every lane busy; FPW = 6: ten groups, lanes 60..63 repeat the last one and
+// store nothing) or, for the bins the fused segment tail sums over the frames, the next power of two (W = 8 for FPW = 6:
+// eight groups, two idle lanes each), so that the frames of a bin sit in one aligned lane block and block_sum adds them
+// without LDS traffic.  Step, liveness and the output addresses are per-lane constants; every iteration is one LDS read,
+// the logarithm and two stores; reads past the last bin are clamped, not skipped.
 // MODE (wave-uniform, chosen once per tile): 0 = LogOffSet == 0: float32 throughout (p4 2^(sc-2) rounds once either way,
 // and its logarithm is the mantissa's plus the shifted exponent); 1 = an ordinary positive LogOffSet (the reference's
 // default is 1.0, dft.go:37) and every frame's scale small enough for the sum to be a normal float32: one float64
 // multiply-add, then the float32 logarithm; 2 = anything else: float64 ldexp / add / frexp as the definition reads.
-template <typename TT, int FPW, int MODE>
-__device__ __forceinline__ void wave_spectrum_loop(const MelspecArgs& a, const float* prow, int sc, int g, size_t o,
-                                                   bool col_on, bool live, TT* epart, bool first_frame) {
-    constexpr int G = 64 / FPW;
-    const int H = a.H;
-    const size_t ostep = size_t(G) * a.T;
+// esum (fused segment tail, k_hi <= T): Energy[s] sums LogPowerSegment(s, f) over the steps f -- bin s < T of every frame
+// (sndenv.go:360-366), a float64 tensor in the reference: the same logarithm BEFORE its float32 rounding,
+// summed over the tile's frames into this tile's row of energy_part.
+template <typename TT, int FPW, int W, int MODE>
+__device__ __forceinline__ void wave_spectrum_range(const MelspecArgs& a, const float* P, int Hp, const int* exps, int sc1,
+                                                    const aud_item& it, int item, int t0, int lane, int k_lo, int k_hi,
+                                                    TT* esum) {
+    constexpr int G = 64 / W;
+    const int T = a.T, H = a.H;
+    const int f0 = lane % W, g0 = lane / W;
+    const bool has = g0 < G && f0 < FPW;
+    const int ff = f0 < FPW ? f0 : FPW - 1, g = g0 < G ? g0 : G - 1;
+    // the scale of THIS lane's frame: the frames' words (exps), or the one frame's scale (sc1: one frame per wave)
+    const int sc = sizeof(TT) == 8 ? (exps ? frame_scale_of(exps + ff) : sc1) : 0;
+    const int sstep = t0 + ff;
+    const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
+    const bool col_on = has && sstep < T;
+    const bool live = start + a.N <= int64_t(it.sig_len);
+    const float* prow = P + ff * Hp;
+    size_t o = (size_t(item) * H + k_lo + g) * T + (col_on ? sstep : 0);
+    const size_t ostep = size_t(G) * T;
     const bool want_lp = live && a.comp_log_pow;
-    const int n_it = (H + G - 1) / G;  // the same trip count for every lane
+    const int n_it = (k_hi - k_lo + G - 1) / G;  // the same trip count for every lane
     const double scale_d = MODE == 1 ? ldexp(1.0, sc - 2) : 1.0;
     for (int i = 0; i < n_it; ++i) {
-        const int k = g + G * i;
+        const int k = k_lo + g + G * i;
         const float p4 = prow[k < H ? k : H - 1];
         // the logarithm's argument as mantissa and exponent (`none`: the exact-zero case, LogMin)
         float pw, m = 1.f;
@@ -592,64 +626,65 @@ __device__ __forceinline__ void wave_spectrum_loop(const MelspecArgs& a, const f
             none = vv == 0.f;
         }
         const float lp = !want_lp ? 0.f : none ? float(a.dft_log_min) : mantissa_log(m, ex);
-        if (col_on && k < H) {
+        if (col_on && k < k_hi) {
             if (a.power) a.power[o] = live ? pw : 0.f;
             if (a.log_power) a.log_power[o] = lp;
         }
         o += ostep;
-        if constexpr (FPW == 4 || FPW == 6) {
-            // fused segment tail: Energy[s] sums LogPowerSegment(s, f) over the steps f -- bin s < T of every frame
-            // (sndenv.go:360-366), a float64 tensor in the reference: the same logarithm before its float32
-            // rounding.  This tile's share goes to its row of energy_part.
-            if (epart && G * i < a.T) {  // wave-uniform
+        if constexpr (W == 4 || W == 8) {
+            if (esum) {  // wave-uniform
                 TT wide;
                 if constexpr (sizeof(TT) == 8) wide = none ? a.dft_log_min : mantissa_log_wide(m, ex);
                 else wide = lp;
-                const TT part = frames_sum<FPW>(want_lp && col_on ? wide : TT(0));
-                if (first_frame && k < a.T) epart[k] = part;
+                const TT tot = block_sum<W>(want_lp && col_on ? wide : TT(0));
+                if (f0 == 0 && g0 < G && k < k_hi) esum[k] = tot;
             }
         }
     }
 }
 
-template <typename TT, int FPW>
-__device__ __forceinline__ void wave_spectrum_outputs(const MelspecArgs& a, const float* P, int Hp, int sc,
-                                                      const aud_item& it, int item, int t0, int lane) {
-    if (!a.power && !a.log_power && !a.energy_part) return;
-    // a lane keeps ONE frame (lane % FPW) and walks the bins k = lane / FPW, + 64 / FPW, ...: step, liveness and the output
-    // addresses are per-lane constants, every iteration is one LDS read, the logarithm and two stores.  Lanes beyond
-    // FPW * (64 / FPW) repeat the last group and store nothing; reads past the last bin are clamped, not skipped.
-    constexpr int G = 64 / FPW;
-    const int T = a.T, H = a.H;
-    const int ff = lane % FPW, g0 = lane / FPW;
-    const bool has = g0 < G;
-    const int g = has ? g0 : G - 1;
-    const int sstep = t0 + ff;
-    const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
-    const bool col_on = has && sstep < T;
-    const bool live = start + a.N <= int64_t(it.sig_len);
-    const float* prow = P + ff * Hp;
-    const size_t o = (size_t(item) * H + g) * T + (col_on ? sstep : 0);
-    const int tiles = (T + FPW - 1) / FPW;
-    TT* epart = a.energy_part ? static_cast<TT*>(a.energy_part) + (size_t(item) * tiles + t0 / FPW) * T : nullptr;
-    const bool first_frame = has && ff == 0;
+template <typename TT, int FPW, int W>
+__device__ __forceinline__ void wave_spectrum_pick(const MelspecArgs& a, const float* P, int Hp, const int* exps, int sc1,
+                                                   const aud_item& it, int item, int t0, int lane, int k_lo, int k_hi,
+                                                   TT* esum) {
     if constexpr (sizeof(TT) == 8) {
         const double off = a.dft_log_off;
         // the scaled peak of a frame is below 2^26 (frame_scale), so with sc < 96 the sum is below 2^123
+        const int sc = exps ? frame_scale_of(exps + lane % FPW) : sc1;
         const bool small = __builtin_amdgcn_ballot_w64(sc >= 96 || sc < -900) == 0;
-        if (off == 0.0) wave_spectrum_loop<TT, FPW, 0>(a, prow, sc, g, o, col_on, live, epart, first_frame);
-        else if (small && off >= 1e-30 && off <= 1e30) wave_spectrum_loop<TT, FPW, 1>(a, prow, sc, g, o, col_on, live, epart, first_frame);
-        else wave_spectrum_loop<TT, FPW, 2>(a, prow, sc, g, o, col_on, live, epart, first_frame);
+        if (off == 0.0) wave_spectrum_range<TT, FPW, W, 0>(a, P, Hp, exps, sc1, it, item, t0, lane, k_lo, k_hi, esum);
+        else if (small && off >= 1e-30 && off <= 1e30)
+            wave_spectrum_range<TT, FPW, W, 1>(a, P, Hp, exps, sc1, it, item, t0, lane, k_lo, k_hi, esum);
+        else wave_spectrum_range<TT, FPW, W, 2>(a, P, Hp, exps, sc1, it, item, t0, lane, k_lo, k_hi, esum);
     } else {
-        wave_spectrum_loop<TT, FPW, 2>(a, prow, sc, g, o, col_on, live, epart, first_frame);
+        wave_spectrum_range<TT, FPW, W, 2>(a, P, Hp, exps, sc1, it, item, t0, lane, k_lo, k_hi, esum);
     }
 }
 
+template <typename TT, int FPW>
+__device__ __forceinline__ void wave_spectrum_outputs(const MelspecArgs& a, const float* P, int Hp, const int* exps, int sc1,
+                                                      const aud_item& it, int item, int t0, int lane) {
+    if (!a.power && !a.log_power && !a.energy_part) return;
+    if constexpr (FPW == 4 || FPW == 6) {
+        if (a.energy_part) {  // fused segment tail (T <= H: plan-time check)
+            constexpr int W = FPW == 4 ? 4 : 8;
+            const int tiles = (a.T + FPW - 1) / FPW;
+            TT* esum = static_cast<TT*>(a.energy_part) + (size_t(item) * tiles + t0 / FPW) * a.T;
+            wave_spectrum_pick<TT, FPW, W>(a, P, Hp, exps, sc1, it, item, t0, lane, 0, a.T, esum);
+            if (a.power || a.log_power)
+                wave_spectrum_pick<TT, FPW, FPW>(a, P, Hp, exps, sc1, it, item, t0, lane, a.T, a.H, static_cast<TT*>(nullptr));
+            return;
+        }
+    }
+    wave_spectrum_pick<TT, FPW, FPW>(a, P, Hp, exps, sc1, it, item, t0, lane, 0, a.H, static_cast<TT*>(nullptr));
+}
+
+// `sc` = the scale of the frame THIS lane reduces (lane % FPW); `exps` = the frames' scale words (null: one frame per wave).
 template <typename TT, int FPW, int MAXS, bool COMPACT = false>
 __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const WaveArgs& e, const float* P, int Hp,
                                                   const unsigned char* smem, int sc, const aud_item& it,
-                                                  int item, int t0, int lane) {
-    wave_spectrum_outputs<TT, FPW>(a, P, Hp, sc, it, item, t0, lane);
+                                                  int item, int t0, int lane, const int* exps = nullptr) {
+    wave_spectrum_outputs<TT, FPW>(a, P, Hp, exps, sc, it, item, t0, lane);
     // 64 is not a multiple of FPW = 6: lanes 60..63 have no filter group; they run group n_groups - 1 again and store nothing
     const int T = a.T;
     const int ff = lane % FPW, g0 = lane / FPW;
@@ -742,12 +777,32 @@ __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const Wa
     }
     if constexpr (kCanFuse) {
         if (fuse) {
-            TT* out = static_cast<TT*>(a.mfcc_acc) + size_t(item) * a.n_coefs * T + (col_on ? sstep : 0);
-            const bool writer = has && g0 == 0 && col_on;  // the frame's lane of group 0
+            // a frame's coefficient = the sum over its filter groups.  The spectrum has been consumed: its LDS rows take
+            // the partial sums, [coefficient][frame][group], six coefficients at a time (2.9 KB in float64); lane q of
+            // the first 6 FPW then adds the G consecutive values of (coefficient q / FPW, frame q % FPW), in group order.
+            constexpr int G = 64 / FPW, CH = (kDctCoefs - 1) / 2, TASKS = CH * FPW;
+            static_assert(2 * CH == kDctCoefs - 1 && TASKS <= 64 && G % 2 == 0, "chunking of the DCT sums");
+            TT* S = reinterpret_cast<TT*>(const_cast<float*>(P));
+            TT* out = static_cast<TT*>(a.mfcc_acc) + size_t(item) * a.n_coefs * T;
+            const int q = lane < TASKS ? lane : 0;
+            const C2<TT>* mine = reinterpret_cast<const C2<TT>*>(S + q * G);
+            wave_lds_fence();  // every lane is done with the spectrum
 #pragma unroll
-            for (int c = 1; c < kDctCoefs; ++c) {
-                const TT tot = groups_sum<FPW>(has ? cc[c] : TT(0));
-                if (writer && c < a.n_coefs) out[size_t(c) * T] = tot;
+            for (int r = 0; r < 2; ++r) {
+                // (lanes without a group -- 60..63 of FPW = 6 -- carry zeros: they store into cells of their own behind the sums)
+#pragma unroll
+                for (int cl = 0; cl < CH; ++cl) S[has ? (cl * FPW + ff) * G + grp : CH * FPW * G + (lane & 3)] = cc[1 + r * CH + cl];
+                wave_lds_fence();
+                TT tot = TT(0);
+#pragma unroll
+                for (int h = 0; h < G / 2; ++h) {
+                    const C2<TT> two = mine[h];
+                    tot += two.x;
+                    tot += two.y;
+                }
+                const int c = 1 + r * CH + q / FPW, s2 = t0 + q % FPW;
+                if (lane < TASKS && s2 < T && c < a.n_coefs) out[size_t(c) * T + s2] = tot;
+                wave_lds_fence();
             }
         }
     }

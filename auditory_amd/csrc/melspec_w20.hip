@@ -27,7 +27,7 @@ struct Layout {
     static constexpr int kFrame = (sizeof(TT) == 4) ? 120 : 122;
     static constexpr int kXchBytes = kFW * kFrame * int(sizeof(TT));
     static constexpr int kPBytes = kFW * kHp * 4;
-    static constexpr int kExpOff = ((kXchBytes > kPBytes ? kXchBytes : kPBytes) + 15) & ~15;
+    static constexpr int kExpOff = ((kXchBytes > kPBytes ? kXchBytes : kPBytes) + 15) & ~15;  // the frames' scale words
     static constexpr int kRegion = kExpOff + 32;  // bytes per wave
 };
 template <typename TT>
@@ -177,7 +177,7 @@ void k_melspec_w20(const MelspecArgs a, const WaveArgs e) {
 
     // ---- optional spectrum outputs and the mel reduction: 6 frames x 10 filter groups on this wave ---------------
     wave_mel_epilogue<TT, w20::kFW, MAXS>(a, e, Pw, w20::kHp, smem,
-                                          sizeof(TT) == 8 ? frame_scale_of(exps + lane % w20::kFW) : 0, it, item, t0, lane);
+                                          sizeof(TT) == 8 ? frame_scale_of(exps + lane % w20::kFW) : 0, it, item, t0, lane, exps);
     AUD_STAMP(8);
     AUD_STAMP_REAL(10);
     AUD_STAMP_FLUSH(a, wt, lane);
