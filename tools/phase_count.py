@@ -1,7 +1,8 @@
-"""Static instruction counts per phase of a wave kernel (no GPU): compiles melspec_wave.hip with -DAUD_PHASE_MARKERS
+"""Static instruction counts per phase of a wave kernel (no GPU): compiles the kernel's file with -DAUD_PHASE_MARKERS
 (kernels.h puts '; AUD_PHASE n' comments at the kernels' phase boundaries) and counts the instructions between them.
 Counts are static: a loop body counts once, every sample route is listed.
-usage: python tools/phase_count.py [kernel-name-substring, default k_melspec_w20IdLi4ELi4E] [--ops]"""
+usage: python tools/phase_count.py [kernel-name-substring, default k_melspec_w20IdLi0ELi4ELi4E] [--ops]
+(the source file is melspec_w16 / w20 / w64.hip by the name's w16 / w20 / w64)"""
 import collections
 import os
 import re
@@ -25,13 +26,14 @@ def cat(op):
 
 
 def main():
-    key = next((a for a in sys.argv[1:] if not a.startswith("--")), "k_melspec_w20IdLi4ELi4E")
+    key = next((a for a in sys.argv[1:] if not a.startswith("--")), "k_melspec_w20IdLi0ELi4ELi4E")
+    src = "melspec_%s.hip" % next(w for w in ("w16", "w20", "w64") if w in key)
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "wave.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17",
                                "-DAUD_PHASE_MARKERS", "-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(ROOT, "auditory_amd", "csrc"), "-x", "hip", "--cuda-device-only", "-S",
-                               os.path.join(ROOT, "auditory_amd", "csrc", "melspec_wave.hip"), "-o", out],
+                               os.path.join(ROOT, "auditory_amd", "csrc", src), "-o", out],
                               stderr=subprocess.DEVNULL)
         s = open(out).read().split('\n')
     start = next(i for i, l in enumerate(s) if re.match(r"^_Z\w*%s\w*:" % key, l))
