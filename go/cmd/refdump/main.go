@@ -1,7 +1,8 @@
 // refdump -- NOT COMPILED IN THIS PIPELINE (no Go toolchain, modules not vendored).  The one program that can PIN the
 // oracle: it drives the REAL reference (github.com/emer/auditory v0.9.8) over the WAV inputs written by
 // tests/golden/make_ref_inputs.py and dumps what tests/test_golden.py compares the oracle and the HIP path with.
-// On a machine with Go and the module cache:  cd go/cmd/refdump && go run . @../../../tests/golden/ref_in/jobs.txt
+// On a machine with Go and the module cache, FROM THE REPOSITORY ROOT (the paths inside jobs.txt are relative to it):
+//     go run ./go/cmd/refdump tests/golden/ref_in/jobs.txt
 // (one job per line: wav out-prefix winMs stepMs segMs strideMs border nf loHz hiHz poolsY poolsX seg[,seg...]).
 package main
 

@@ -1,4 +1,4 @@
-"""Static LDS bank-conflict model of the kernels' main access patterns, following the lane groups
+"""Static LDS bank-conflict model of the wave kernels' main access patterns, following the lane groups
 and bank moduli of MI355X_MICROARCH.md (LDS section):
 
   ds_read_b32  / ds_write_b32 : 2 groups {0-31}, {32-63};                   bank = (addr/4) % 32
@@ -49,53 +49,34 @@ def report(title, kind, fn, sweep):
 
 
 def main():
-    # ---- r16x16 (N = 512, f32): lane = 16 f + j ------------------------------------------------------
-    RP, FP = 18 * 8, 16 * 18 * 8            # transpose row / frame pitch in bytes
-    report("r16 pass-1 column writes  xch[f][k1][j]", "write_b64",
-           lambda l, k1: (l >> 4) * FP + k1 * RP + (l & 15) * 8, range(16))
-    report("r16 pass-2 row reads      xch[f][j][2c..2c+1]", "read_b128",
-           lambda l, c: (l >> 4) * FP + (l & 15) * RP + c * 16, range(8))
-    report("r16 staged pass-1 reads   span[f*160 + 2j + 32 n1] (S = 160)", "read_b64",
-           lambda l, n1: ((l >> 4) * 160 + 2 * (l & 15) + 32 * n1) * 4, range(16))
-    report("r16 power writes          P[f][j + 16 q] (pitch 260)", "write_b32",
-           lambda l, q: ((l >> 4) * 260 + (l & 15) + 16 * q) * 4, range(8))
-    report("r16 power writes          P[f][256 - j - 16 q]", "write_b32",
-           lambda l, q: ((l >> 4) * 260 + 256 - (l & 15) - 16 * q) * 4, range(8))
-    report("epilogue P chunk reads    P[ff = l & 15][chunk c] (4 groups read 4 different chunks)", "read_b128",
-           lambda l, c: ((l & 15) * 260 + 4 * ((c * 7 + (l >> 4) * 13) % 65)) * 4, range(16))
-    # ---- r25x8 (N = 400, f32): lane = 8 f + j --------------------------------------------------------
-    RP, FP = 10 * 8, 264 * 8
-    report("r25 pass-A column writes  xch[f][k1][j]", "write_b64",
-           lambda l, k1: (l >> 3) * FP + k1 * RP + (l & 7) * 8, range(25))
-    for r in range(3):
-        report("r25 pass-B row reads      xch[f][j + 8*%d][2c..2c+1]" % r, "read_b128",
-               lambda l, c, r=r: (l >> 3) * FP + ((l & 7) + 8 * r) * RP + c * 16, range(4))
-    report("r25 pass-B row writes     xch[f][j][k2]", "write_b64",
-           lambda l, k2: (l >> 3) * FP + (l & 7) * RP + k2 * 8, range(8))
-
-    def zloc25(k):
-        return (k % 25) * 10 + k // 25
-    report("r25 split reads           Z[k = j + 8 i]", "read_b64",
-           lambda l, i: ((l >> 3) * 264 + zloc25((l & 7) + 8 * i)) * 8 if (l & 7) + 8 * i <= 100 else None, range(13))
-    report("r25 split reads           Z[200 - k]", "read_b64",
-           lambda l, i: ((l >> 3) * 264 + zloc25((200 - ((l & 7) + 8 * i)) % 200)) * 8
-           if (l & 7) + 8 * i <= 100 else None, range(13))
-    # ---- r16x16x4 (N = 2048, f32): one wave per frame, lane l ------------------------------------------
-    report("r1024 stage-1 row writes  fr[k1*68 + l]", "write_b64", lambda l, k1: (k1 * 68 + l) * 8, range(16))
-    report("r1024 stage-2 col reads   fr[(l>>2)*68 + (l&3) + 4 n2]", "read_b64",
-           lambda l, n2: ((l >> 2) * 68 + (l & 3) + 4 * n2) * 8, range(16))
-
-    def zpos(k):
-        return k + 4 * (k >> 8)
-
-    def k3(l):
-        n3 = l & 3
-        return ((n3 & 1) << 1) | (n3 >> 1)
-    report("r1024 spectrum scatter    fr[zpos(k1 + 16 k2 + 256 k3)]", "write_b64",
-           lambda l, k2: zpos((l >> 2) + 16 * k2 + 256 * k3(l)) * 8, range(16))
-    report("r1024 pair reads          fr[zpos(l + 64 i)]", "read_b64", lambda l, i: zpos(l + 64 * i) * 8, range(8))
-    report("r1024 pair reads          fr[zpos(1024 - l - 64 i)]", "read_b64",
-           lambda l, i: zpos((1024 - l - 64 * i) % 1024) * 8, range(8))
+    # ---- w20x10 (N = 400; melspec_w20.hip Layout): FFT phases lane = 10 f + j (lanes 60..63 shadow 50..53); the
+    # transposes move half the rows at a time, one component at a time: element (row k1 < 10, column j) of frame f
+    for name, sz, row, frame in (("f64", 8, 10, 122), ("f32", 4, 12, 120)):
+        fj = lambda l: ((l // 10, l % 10) if l < 60 else (5, l - 60))  # noqa: E731
+        wr, rd = ("write_b64", "read_b128") if sz == 8 else ("write_b32", "read_b128")
+        report("w20 %s half-row column stores  xw[f*%d + k1*%d + j]" % (name, frame, row), wr,
+               lambda l, k1: (fj(l)[0] * frame + k1 * row + fj(l)[1]) * sz, range(10))
+        report("w20 %s row reads               xw[f*%d + j*%d + q]" % (name, frame, row), rd,
+               lambda l, q: (fj(l)[0] * frame + fj(l)[1] * row) * sz + q * 16, range(5 if sz == 8 else 3))
+    # split: P[f*204 + k] float32, k = j + 20 c and its partners
+    report("w20 split power stores          P[f*204 + j + 20 c]", "write_b32",
+           lambda l, c: ((l // 10 if l < 60 else 5) * 204 + (l % 10 if l < 60 else l - 60) + 20 * c) * 4, range(5))
+    report("w20 split power stores          P[f*204 + 200 - (j + 20 c)]", "write_b32",
+           lambda l, c: ((l // 10 if l < 60 else 5) * 204 + 200 - ((l % 10 if l < 60 else l - 60) + 20 * c)) * 4, range(5))
+    # epilogue: lane = 6 g + ff; slot k of group g starts at a P chunk that depends on the group (filters dealt by width):
+    # model the bench table's slot 0 (filters 39..30 dealt to groups 0..9: first chunks roughly 46 - 4 g)
+    for first in ([46 - 4 * g for g in range(10)], [30 - 2 * g for g in range(10)], [12 - g for g in range(10)]):
+        report("w20 epilogue P reads            P[ff*204 + 4 (first[g] + s)], first = %s.." % first[:3], "read_b128",
+               lambda l, s, first=first: ((l % 6) * 204 + 4 * (first[min(l // 6, 9)] + s)) * 4, range(4))
+    report("w20 epilogue weight reads       w[g*stride + 16 s] (stride 17 x 16 B)", "read_b128",
+           lambda l, s: min(l // 6, 9) * 17 * 16 + 16 * s, range(4))
+    # ---- w16x16 (N = 512): lane = 16 f + j, 4 frames; half rows (8 of 16), row pitch / frame pitch from melspec_w16.hip
+    # ---- w64x16 (N = 2048): one frame per wave, plane row pitch 68 elements
+    for name, sz in (("f64", 8), ("f32", 4)):
+        wr = "write_b64" if sz == 8 else "write_b32"
+        report("w64 %s pass-1 row stores       plane[k1*68 + l]" % name, wr, lambda l, k1: (k1 * 68 + l) * sz, range(16))
+        report("w64 %s pass-2 column reads     plane[(l>>2)*68 + (l&3) + 4 n2]" % name, "read_b64" if sz == 8 else "read_b32",
+               lambda l, n2: ((l >> 2) * 68 + (l & 3) + 4 * n2) * sz, range(16))
 
 
 if __name__ == "__main__":
