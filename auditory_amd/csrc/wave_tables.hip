@@ -45,6 +45,49 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
         n_steps += mx;
     }
     const bool compact = kind == 4;  // one filter group per lane: per-group rows of slot_steps chunks would be 2x the LDS
+    // ds_read_b128 serves a wave in four groups of 16 lanes; lanes of one group that read 16-byte pieces with the same
+    // index mod 16 conflict.  With one filter per lane and slot (w64x16) WHICH lane takes which filter of a slot is free:
+    // deal the slot's filters so that the first P chunks of a lane group differ mod 16 wherever the table allows it (the
+    // epilogue's P reads were 3-way on average with filters in width order)
+    static const unsigned char kGroupOfLane[32] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0,
+                                                   1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1};
+    auto lane_group = [&](int gi) { return 2 * (gi >> 5) + kGroupOfLane[gi & 31]; };
+    if (compact && G == 64) {
+        for (int k = 0; k < n_slots; ++k) {
+            const int lo_r = k * G, hi_r = std::min(nf, (k + 1) * G), ns = e.slot_steps[k];
+            std::vector<int> fl(order.begin() + lo_r, order.begin() + hi_r);
+            auto residue = [&](int f) { return std::min(c0[f], p_chunks - ns) & 15; };
+            int count[16] = {0};
+            for (int f : fl) ++count[residue(f)];
+            // the most crowded residues choose their lane groups first
+            std::stable_sort(fl.begin(), fl.end(), [&](int x, int y) { return count[residue(x)] > count[residue(y)]; });
+            int have[4][16] = {{0}}, filled[4] = {0, 0, 0, 0};
+            std::vector<int> lanes_of[4];
+            for (int gi = 0; gi < G; ++gi) lanes_of[lane_group(gi)].push_back(gi);
+            std::vector<int> at(G, -1);
+            for (int f : fl) {
+                int best = -1;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    if (filled[g4] >= int(lanes_of[g4].size())) continue;
+                    if (best < 0 || have[g4][residue(f)] < have[best][residue(f)] ||
+                        (have[g4][residue(f)] == have[best][residue(f)] && filled[g4] < filled[best]))
+                        best = g4;
+                }
+                at[lanes_of[best][filled[best]++]] = f;
+                ++have[best][residue(f)];
+            }
+            // a short last slot leaves lanes empty: keep the filters on the lowest lanes of their groups, holes last
+            int r = lo_r;
+            std::vector<int> rest;
+            for (int gi = 0; gi < G; ++gi)
+                if (at[gi] >= 0) rest.push_back(at[gi]);
+            if (hi_r - lo_r == G) {
+                for (int gi = 0; gi < G; ++gi) order[r++] = at[gi];
+            } else {
+                for (int f : rest) order[r++] = f;
+            }
+        }
+    }
     size_t w_stride = 0;
     std::vector<double> wrows;
     std::vector<uint32_t> slots;
@@ -78,9 +121,7 @@ int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_fil
             // a row may start on any 16-byte piece; its start is pushed forward (<= 15 pieces) until its piece index mod 16
             // differs from that of every earlier row of the same slot whose lane shares one of ds_read_b128's 16-lane
             // groups -- the lanes of a group then read 16 different bank quads at every step (modelled 11.7 -> 4 cycles)
-            static const unsigned char kGroupOfLane[32] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0,
-                                                           1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1};
-            const int grp16 = 2 * (gi >> 5) + kGroupOfLane[gi & 31];
+            const int grp16 = lane_group(gi);
             size_t piece = wpieces;
             for (int tries = 0; tries < 16 && (used[k][grp16] >> (piece & 15) & 1u); ++tries) ++piece;
             used[k][grp16] |= 1u << (piece & 15);
