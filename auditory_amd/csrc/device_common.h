@@ -661,11 +661,11 @@ __device__ __forceinline__ void wave_spectrum_pick(const MelspecArgs& a, const f
     }
 }
 
-template <typename TT, int FPW>
+template <typename TT, int FPW, bool FUSE>
 __device__ __forceinline__ void wave_spectrum_outputs(const MelspecArgs& a, const float* P, int Hp, const int* exps, int sc1,
                                                       const aud_item& it, int item, int t0, int lane) {
-    if (!a.power && !a.log_power && !a.energy_part) return;
-    if constexpr (FPW == 4 || FPW == 6) {
+    if (!a.power && !a.log_power && !(FUSE && a.energy_part)) return;
+    if constexpr (FUSE && (FPW == 4 || FPW == 6)) {
         if (a.energy_part) {  // fused segment tail (T <= H: plan-time check)
             constexpr int W = FPW == 4 ? 4 : 8;
             const int tiles = (a.T + FPW - 1) / FPW;
@@ -680,11 +680,13 @@ __device__ __forceinline__ void wave_spectrum_outputs(const MelspecArgs& a, cons
 }
 
 // `sc` = the scale of the frame THIS lane reduces (lane % FPW); `exps` = the frames' scale words (null: one frame per wave).
-template <typename TT, int FPW, int MAXS, bool COMPACT = false>
+// FUSE: the instantiation that also carries the segment tail (MelspecArgs::mfcc_acc / energy_part); the kernels branch to
+// it once per wave (wave_mel_epilogue_pick), so the plain path pays nothing for it.
+template <typename TT, int FPW, int MAXS, bool COMPACT = false, bool FUSE = false>
 __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const WaveArgs& e, const float* P, int Hp,
                                                   const unsigned char* smem, int sc, const aud_item& it,
                                                   int item, int t0, int lane, const int* exps = nullptr) {
-    wave_spectrum_outputs<TT, FPW>(a, P, Hp, exps, sc, it, item, t0, lane);
+    wave_spectrum_outputs<TT, FPW, FUSE>(a, P, Hp, exps, sc, it, item, t0, lane);
     // 64 is not a multiple of FPW = 6: lanes 60..63 have no filter group; they run group n_groups - 1 again and store nothing
     const int T = a.T;
     const int ff = lane % FPW, g0 = lane / FPW;
@@ -704,8 +706,8 @@ __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const Wa
     float* mel_col = a.mel + (size_t(item) * a.nf * T + (col_on ? sstep : 0));
     // fused segment tail: this lane's share of the frame's CepstrumDct (mel.go:192-212), coefficients 1 .. kDctCoefs - 1
     // (coefficient 0 is never seen: ProcessSegment overwrites MFCC row 0 with Energy, sndenv.go:368-372)
-    constexpr bool kCanFuse = !COMPACT && (FPW == 4 || FPW == 6);
-    const bool fuse = kCanFuse && a.mfcc_acc != nullptr && e.dct_off >= 0;  // wave-uniform
+    constexpr bool kCanFuse = FUSE && !COMPACT && (FPW == 4 || FPW == 6);
+    constexpr bool fuse = kCanFuse;
     TT cc[kDctCoefs];
 #pragma unroll
     for (int c = 0; c < kDctCoefs; ++c) cc[c] = TT(0);
@@ -806,6 +808,15 @@ __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const Wa
             }
         }
     }
+}
+
+template <typename TT, int FPW, int MAXS>
+__device__ __forceinline__ void wave_mel_epilogue_pick(const MelspecArgs& a, const WaveArgs& e, const float* P, int Hp,
+                                                       const unsigned char* smem, int sc, const aud_item& it,
+                                                       int item, int t0, int lane, const int* exps) {
+    if (a.mfcc_acc != nullptr && e.dct_off >= 0)  // wave-uniform
+        wave_mel_epilogue<TT, FPW, MAXS, false, true>(a, e, P, Hp, smem, sc, it, item, t0, lane, exps);
+    else wave_mel_epilogue<TT, FPW, MAXS, false, false>(a, e, P, Hp, smem, sc, it, item, t0, lane, exps);
 }
 
 }  // namespace aud

@@ -159,7 +159,7 @@ void k_melspec_w16(const MelspecArgs a, const WaveArgs e) {
     AUD_STAMP(7);
 
     // ---- optional spectrum outputs and the mel reduction: 4 frames x 16 filter groups on this wave ----------
-    wave_mel_epilogue<TT, w16::kFW, MAXS>(a, e, Pw, w16::kHp, smem,
+    wave_mel_epilogue_pick<TT, w16::kFW, MAXS>(a, e, Pw, w16::kHp, smem,
                                           sizeof(TT) == 8 ? frame_scale_of(exps + lane % w16::kFW) : 0, it, item, t0, lane, exps);
     AUD_STAMP(8);
     AUD_STAMP_REAL(10);

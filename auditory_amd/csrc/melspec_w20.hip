@@ -176,7 +176,7 @@ void k_melspec_w20(const MelspecArgs a, const WaveArgs e) {
     AUD_STAMP(7);
 
     // ---- optional spectrum outputs and the mel reduction: 6 frames x 10 filter groups on this wave ---------------
-    wave_mel_epilogue<TT, w20::kFW, MAXS>(a, e, Pw, w20::kHp, smem,
+    wave_mel_epilogue_pick<TT, w20::kFW, MAXS>(a, e, Pw, w20::kHp, smem,
                                           sizeof(TT) == 8 ? frame_scale_of(exps + lane % w20::kFW) : 0, it, item, t0, lane, exps);
     AUD_STAMP(8);
     AUD_STAMP_REAL(10);
