@@ -44,6 +44,8 @@ for step in "$@"; do
                python3 tools/trace_overlap.py "gpurun_out/trace_${TAG}" > "gpurun_out/${TAG}_graph_overlap.txt" 2>&1; cat "gpurun_out/${TAG}_graph_overlap.txt" ;;
         ubench) (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_rates valu_rates.hip) &&
                 run ubench 120 /tmp/valu_rates ;;
+        dispatch) (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/dispatch_rate dispatch_rate.hip) &&
+                run dispatch 120 /tmp/dispatch_rate ;;
         *) echo "unknown step $step"; exit 2 ;;
     esac
 done
