@@ -131,6 +131,41 @@ def case_input_levels(orc, name, cdt, seg_ms=None):
         assert np.all(mel[want] == float(oc.m.log_min)), "LogMin rule"
 
 
+
+def case_mel_logoff_renorm(orc, name, cdt, seg_ms=None):
+    """mel.go:133-149 beyond the defaults: LogOff != 0 (the sum never hits the LogMin case) and Renorm re-enabled after
+    InitFilters with a hand-set scale -- the wave kernels' float64 route behind the float32 band sums -- alone
+    and with the segment tail riding on the renormalised values."""
+    oc = W.OracleCfg(orc, name, seg_ms)
+    L = int(0.4 * oc.sr)
+    sig, _ = synth.batch(31, 2, L, oc.sr)
+    sig[1] *= 1e-4                                                   # a quiet row: values inside the renorm clamp's lower end
+    segs = [(r, s) for r in range(2) for s in (0, 1)]
+    for log_off, renorm in ((1.0, False), (0.0, True), (0.5, True)):
+        oc.m.log_off = log_off
+        oc.m.renorm = int(renorm)
+        oc.m.renorm_scale = 1.0 / (oc.m.renorm_max - oc.m.renorm_min) if renorm else 0.0
+        plan = W.product_plan(oc, cdt, mfcc_coefs=13, mel_log_off=log_off,
+                              mel_renorm_scale=oc.m.renorm_scale if renorm else None)
+        try:
+            mel, _, _ = plan.melspec_host(sig.ravel(), make_items(oc, L, segs))
+            got = plan.melspec_mfcc_host(sig.ravel(), make_items(oc, L, segs))
+        finally:
+            plan.close()
+        assert np.array_equal(mel, got["mel"], equal_nan=True)
+        for i, (r, sg) in enumerate(segs):
+            o = orc.process_segment_mfcc(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig[r], segment=sg)
+            tol = 1e-5 if cdt == capi.AUD_F64 else 2e-4
+            ok, msg = W.close_enough(mel[i], o["mel_seg"], tol)
+            assert ok, "mel, LogOff %g renorm %s, item %d: %s" % (log_off, renorm, i, msg)
+            ok, msg = W.close_enough(got["mfcc"][i], o["mfcc"], 1e-5 if cdt == capi.AUD_F64 else 1e-3)
+            assert ok, "mfcc, LogOff %g renorm %s, item %d: %s" % (log_off, renorm, i, msg)
+        if renorm:
+            live = mel[(mel != 0)]
+            assert np.nanmin(live) >= 0.0 and np.nanmax(live) <= 1.0    # clamped to [0, 1] (NaN rows: Q3)
+    oc.m.log_off, oc.m.renorm, oc.m.renorm_scale = 0.0, 0, 0.0
+
+
 def case_workgroup_order(orc, cdt, with_n2048=True):
     """the XCD-contiguous workgroup -> tile order (option "xcd_remap") is a bijection for grid sizes that are
     not multiples of 8 and changes nothing in the results: every kernel family, remap on == off, bit for bit"""

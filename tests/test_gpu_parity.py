@@ -121,6 +121,13 @@ def test_input_levels(orc, torch_cuda, name, seg_ms, cdt):
     PC.case_input_levels(orc, name, cdt, seg_ms)
 
 
+@pytest.mark.parametrize("name,seg_ms", [("cfg2_16k_n400_nf40", None), ("cfg2_16k_n512_nf40", None),
+                                         ("cfg5_44k_n2048_nf128", 200.0), ("cfg1_44k_n1103_nf32", None)])
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_mel_logoff_renorm(orc, torch_cuda, name, seg_ms, cdt):
+    PC.case_mel_logoff_renorm(orc, name, cdt, seg_ms)
+
+
 def test_recreated_tone_fixtures_f64(orc, torch_cuda):
     PC.case_recreated_tone_fixtures_f64(orc)
 

@@ -45,7 +45,7 @@ class OracleCfg:
 
 
 def product_plan(ocfg, compute_dtype=0, gabor=None, device=0, dft_override=None, mfcc_coefs=0,  # noqa: C901
-                 dft_log_offset=None):
+                 dft_log_offset=None, mel_log_off=None, mel_renorm_scale=None):
     """runtime.Plan built from the PRODUCT's own host setup for the same configuration"""
     from auditory_amd import agabor, capi, mel, runtime
     sr, win, step, seg, stride, border, nf, lo, hi = CONFIGS[ocfg.name]
@@ -53,6 +53,10 @@ def product_plan(ocfg, compute_dtype=0, gabor=None, device=0, dft_override=None,
     mp.Defaults()
     mp.FBank.NFilters, mp.FBank.LoHz, mp.FBank.HiHz = nf, lo, hi
     filt = mp.InitFilters(ocfg.N, sr)
+    if mel_log_off is not None:
+        mp.FBank.LogOff = mel_log_off
+    if mel_renorm_scale is not None:            # the user re-enables Renorm after InitFilters forced it off (Q5)
+        mp.FBank.Renorm, mp.FBank.RenormScale = True, mel_renorm_scale
     dftp = capi.DftParams()
     capi.load().aud_dft_defaults(dftp)
     if dft_override is not None:
