@@ -1,7 +1,8 @@
-// Device-side building blocks shared by the frame->mel kernel families: complex helpers, small
-// in-register DFTs (2, 3, 4, 5, 8, 16, 25 points), sample loads, and the tile epilogue (optional
-// power / log-power outputs, mel triangle reduction + log) that runs once the tile's power
-// spectrum is parked in LDS.
+// Device-side building blocks shared by the frame->mel kernel families: complex helpers, small in-register DFTs (2, 3, 4,
+// 5, 8, 10, 16, 20, 25 points), the sample routes (buffer-descriptor pairs with the frame's largest magnitude taken on
+// the way), the per-frame power-of-two scale behind the wave kernels' float32 spectrum, and their epilogue: optional
+// power / log-power outputs, slot-uniform mel reduction + log, and -- as an instantiation of its own -- the fused
+// segment tail (CepstrumDct of the unrounded log-mel values, per-tile Energy sums).
 #pragma once
 #include <type_traits>
 #include "kernels.h"
