@@ -166,6 +166,82 @@ def case_mel_logoff_renorm(orc, name, cdt, seg_ms=None):
     oc.m.log_off, oc.m.renorm, oc.m.renorm_scale = 0.0, 0, 0.0
 
 
+
+def case_random_wave_config(orc, seed, N):
+    """The wave kernels (N = 400 / 512 / 2048) under seeded random geometry: step (odd steps give odd-start frames),
+    segment length (tiles that end inside an item), border, filter count (4- and 8-slot epilogues, groups without a
+    filter), band edges, stream lengths that mask trailing frames, sample type of the device buffer via the host entry
+    (float64), both compute types -- mel / power / log-power against the oracle, and the segment tail (fused where the
+    plan allows: <= 13 coefficients, T <= H) with a random coefficient count."""
+    from auditory_amd import mel as melmod
+    rng = np.random.default_rng(9000 + 17 * seed + N)
+    sr = int(rng.choice([16000, 22050, 44100]))
+    S = int(rng.integers(max(8, N // 6), N // 2 + 7))
+    T = int(rng.integers(1, 30 if N < 2048 else 9))
+    border = int(rng.integers(0, 4))
+    cdt = capi.AUD_F64 if seed % 2 == 0 else capi.AUD_F32
+    mp = filt = None
+    for _ in range(300):
+        nf = int(rng.integers(4, 81 if N < 2048 else 129))
+        cand = melmod.Params()
+        cand.Defaults()
+        cand.FBank.NFilters, cand.FBank.LoHz, cand.FBank.HiHz = nf, float(rng.uniform(0, 0.05) * sr), float(rng.uniform(0.3, 0.5) * sr)
+        try:
+            f = cand.InitFilters(N, sr)
+        except capi.AuditoryError:
+            continue
+        if cand.BinPts[-1] <= N // 2 and (np.diff(cand.BinPts) >= 0).all():
+            mp, filt = cand, f
+            break
+    if mp is None:
+        return "no mel table"
+    nf = mp.FBank.NFilters
+    nc = int(rng.integers(2, min(14, nf)))
+    L = int(rng.integers(N, N + S * (T + 2)))                                     # often shorter than the segment: masked frames
+    sig, _ = synth.batch(700 + seed, 2, L, sr)
+    sig[1] *= float(10.0 ** rng.uniform(-6, 2)) if cdt == capi.AUD_F64 else 1.0
+    sp = orc.SndParams(sr, N, S, S * int(rng.integers(1, 3)), T, border)
+    d, m = orc.dft_defaults(), orc.mel_defaults()
+    m.n_filters, m.lo_hz, m.hi_hz = nf, mp.FBank.LoHz, mp.FBank.HiHz
+    rc, bins, hz, ofilt = orc.mel_init_filters(m, N, sr)
+    assert rc == 0 and np.array_equal(bins, mp.BinPts)
+    segs = [(r, s) for r in range(2) for s in (0, 1)]
+    dftp = capi.DftParams()
+    capi.load().aud_dft_defaults(dftp)
+    tail = T <= N // 2 + 1
+    plan = runtime.Plan(runtime.get_ctx(0), N, S, T, border, dftp, mp.FBank.to_c(), mp.BinPts, filt, compute_dtype=cdt,
+                        mfcc_coefs=nc if tail else 0)
+    what = "seed %d N=%d sr=%d S=%d T=%d border=%d nf=%d nc=%d L=%d %s" % (seed, N, sr, S, T, border, nf, nc, L,
+                                                                         "f64" if cdt == capi.AUD_F64 else "f32")
+    try:
+        assert plan.kernel_name in ("w20x10", "w16x16", "w64x16"), what + ": " + plan.kernel_name
+        items = runtime.make_items([r * L for r, s in segs], [L] * len(segs), [s * sp.stride_samples for r, s in segs])
+        mel, pw, lp = plan.melspec_host(sig.ravel(), items, True, True)
+        got = plan.melspec_mfcc_host(sig.ravel(), items) if tail else None
+    finally:
+        plan.close()
+    for i, (r, sg) in enumerate(segs):
+        o = orc.process_segment_mfcc(sp, d, m, bins, ofilt, sig[r], segment=sg, n_coefs=nc) if tail else \
+            orc.process_segment(sp, d, m, bins, ofilt, sig[r], segment=sg)
+        ok, msg = W.feature_close(mel[i], o["mel_seg"], cdt, lin_axis=0)
+        assert ok, what + " item %d: mel %s" % (i, msg)
+        ok, msg = W.spectrum_close(pw[i:i + 1], o["power_seg"][None], 4e-6 if cdt == capi.AUD_F32 else 3e-7)
+        assert ok, what + " item %d: power %s" % (i, msg)
+        if cdt == capi.AUD_F64:
+            ok, msg = W.close_enough(lp[i], o["log_power_seg"], 3e-7)
+            assert ok, what + " item %d: log_power %s" % (i, msg)
+        if tail:
+            assert np.array_equal(got["mel"][i], mel[i], equal_nan=True), what
+            scale = max(1.0, float(np.nanmax(np.abs(o["mfcc"]))))
+            for key, tol in (("mfcc", 6e-6), ("deltas", 1e-5), ("delta_deltas", 5e-5), ("energy", 3e-7)):
+                tol = tol if cdt == capi.AUD_F64 else 300 * tol
+                # (Energy sums T log-power values that each carry the float32 spectrum's ~6e-8: absolute T x 1e-7 on top)
+                err = np.abs(got[key][i] - o[key]) / (scale if key != "energy" else np.maximum(1.0, np.abs(o[key])) + T / 3.0)
+                assert np.array_equal(np.isnan(got[key][i]), np.isnan(o[key])), what + " " + key + ": NaN pattern"
+                assert not np.any(err > tol), what + " item %d: %s %.3g of the MFCC scale (tol %.1g)" % (i, key, float(np.nanmax(err)), tol)
+    return what
+
+
 def case_workgroup_order(orc, cdt, with_n2048=True):
     """the XCD-contiguous workgroup -> tile order (option "xcd_remap") is a bijection for grid sizes that are
     not multiples of 8 and changes nothing in the results: every kernel family, remap on == off, bit for bit"""

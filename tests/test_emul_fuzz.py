@@ -77,6 +77,15 @@ def test_random_configs_vs_oracle(orc, seed):
     assert ok, "N=%d S=%d T=%d: power %s" % (N, S, T, msg)
 
 
+@pytest.mark.parametrize("N", [400, 512, 2048])
+@pytest.mark.parametrize("seed", range(8))
+def test_random_wave_kernel_configs(orc, seed, N):
+    import backend
+    import parity_cases as PC
+    with backend.emulated("plain"):
+        print(PC.case_random_wave_config(orc, seed, N))
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_random_kwta_params_vs_oracle(orc, seed):
     """random k-WTA parameter sets and tensor shapes: every branch of FFFB (on/off, MaxVsAvg, FF0 above / below

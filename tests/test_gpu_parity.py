@@ -128,6 +128,13 @@ def test_mel_logoff_renorm(orc, torch_cuda, name, seg_ms, cdt):
     PC.case_mel_logoff_renorm(orc, name, cdt, seg_ms)
 
 
+@pytest.mark.parametrize("N", [400, 512, 2048])
+def test_random_wave_kernel_configs(orc, torch_cuda, N):
+    """48 seeded random geometries per wave kernel (the emulator tier runs the first 8 of each)"""
+    for seed in range(48):
+        PC.case_random_wave_config(orc, seed, N)
+
+
 def test_recreated_tone_fixtures_f64(orc, torch_cuda):
     PC.case_recreated_tone_fixtures_f64(orc)
 
