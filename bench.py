@@ -279,6 +279,8 @@ def main():  # noqa: C901
                     help="the multi-GPU region's collective: rccl = ncclAllGather (the reported default); direct = the library's "
                          "direct pattern (aud_gather_*: one device-to-device push per peer over its own xGMI link, SURVEY 5) -- the "
                          "fallback if RCCL picks a ring for these 8.5 MB slabs")
+    ap.add_argument("--no-direct-alt", action="store_true",
+                    help="N > 1: do not also time the step with the direct-pattern reassembly (side key `direct_gather`)")
     ap.add_argument("--dist-single", action="store_true",
                     help="validation only: run the multi-GPU code path (shard + RCCL all-gather inside the graph) on ONE rank")
     ap.add_argument("--only-headline", action="store_true", help="skip `modes` and `also`")
@@ -498,7 +500,15 @@ def main():  # noqa: C901
         plan.close()
         return res
 
-    def cfg3_region(wl, compute, total, min_seconds):
+    def all_ranks_ok(ok):
+        """True only if every rank says so (a setup step that can fail on one rank must not leave the others in a collective)"""
+        if world == 1:
+            return bool(ok)
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    def cfg3_region(wl, compute, total, min_seconds, mode=None):
         """BASELINE configs[2] as stated: `total` utterances per step, this rank's contiguous shard through the kernel, then
         (several ranks) the RCCL all-gather of its [nb, nf, T] slab on a second stream while the next step's kernel runs;
         two output slabs alternate, a kernel waits for the gather that last read its slab.  One rank: nothing to gather."""
@@ -520,12 +530,29 @@ def main():  # noqa: C901
         comm = torch.cuda.Stream(dev) if use_streams else None
         even = total % world == 0
         direct = None
-        if gather and args.gather_mode == "direct":
+        mode = mode or args.gather_mode
+        if gather and mode == "direct":
             if not even:
                 raise SystemExit("--gather-mode direct needs the total batch to divide evenly over the ranks")
             from auditory_amd.batch import DirectGather
-            direct = DirectGather(plan.ctx, world, rank, nb * wl.nf * wl.T)
-            direct.exchange()
+            err = None
+            try:
+                direct = DirectGather(plan.ctx, world, rank, nb * wl.nf * wl.T)
+            except Exception as ex:  # (no IPC export on this box)
+                err = ex
+            if not all_ranks_ok(err is None):
+                if direct is not None:
+                    direct.close()
+                plan.close()
+                raise RuntimeError("direct gather: receive buffer / IPC export failed on a rank (%s)" % err)
+            try:
+                direct.exchange()
+            except Exception as ex:
+                err = ex
+            if not all_ranks_ok(err is None):
+                direct.close()
+                plan.close()
+                raise RuntimeError("direct gather: mapping a peer's buffer failed on a rank (%s)" % err)
             recv = direct.recv(dev).view(total, wl.nf, wl.T)   # one receive buffer: consecutive steps overwrite it
             full = [recv, recv]
         else:
@@ -639,12 +666,20 @@ def main():  # noqa: C901
             if key[0] == "cfg5":
                 del rings[key]
         torch.cuda.empty_cache()
+    direct_alt = None
     if multi and args.workload == "headline":
         cfg3 = cfg3_region(head_wl, args.compute, args.cfg3_total, args.min_seconds)
         if rank == 0 and not cfg3["parity"]["pass"] and not args.report_anyway:
             print("FATAL: the gathered tensor fails the parity criterion: %s" % cfg3["parity"], file=sys.stderr)
             dist.destroy_process_group()
             raise SystemExit(3)
+        # the same step with the OTHER reassembly (side key, never `value`): xGMI is point to point, so whether RCCL's
+        # schedule or one push per peer moves the 8.5 MB slabs faster is a measurement
+        if args.gather_mode == "rccl" and args.cfg3_total % world == 0 and not args.no_direct_alt:
+            try:
+                direct_alt = cfg3_region(head_wl, args.compute, args.cfg3_total, args.also_seconds, mode="direct")
+            except Exception as ex:
+                direct_alt = {"error": str(ex).splitlines()[0][:300]}
 
     # roofline.traffic: HBM bytes per launch from the PMC passes (tools/profile_bench.sh), if they were taken for this
     # kernel and batch; null otherwise (it cannot be measured inside this process)
@@ -708,6 +743,10 @@ def main():  # noqa: C901
         line["gathered_shape"] = cfg3.get("gathered_shape")
         line["no_collective"] = {k: head[k] for k in ("value", "steps", "ms_per_step", "us_per_step_device", "launch", "streams",
                                                       "batch", "parity") if k in head}
+        if direct_alt is not None:
+            line["direct_gather"] = ({k: direct_alt[k] for k in ("value", "steps", "ms_per_step", "us_per_step_device", "launch",
+                                                                 "collective", "parity") if k in direct_alt}
+                                     if "error" not in direct_alt else direct_alt)
         line["no_collective"]["note"] = "the sharded step without the collective: %d utterances per rank and step (weak scaling)" % B
     if modes:
         line["modes"] = modes

@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <functional>
 
 #define __global__
@@ -131,12 +132,22 @@ inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinte
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete reinterpret_cast<char*>(e); return 0; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
+// (the handle also carries the exporting process: "device" memory here is a process's own heap, so a handle of ANOTHER
+// process cannot be mapped -- opening it fails the way a box without IPC support fails, instead of handing out a wild pointer)
 inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) {
     std::memset(h, 0, sizeof(*h));
     std::memcpy(h->reserved, &p, sizeof(p));
+    const long long pid = (long long)getpid();
+    std::memcpy(h->reserved + 8, &pid, sizeof(pid));
     return 0;
 }
-inline hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) { std::memcpy(p, h.reserved, sizeof(*p)); return 0; }
+inline hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) {
+    long long pid = 0;
+    std::memcpy(&pid, h.reserved + 8, sizeof(pid));
+    if (pid != (long long)getpid()) return 1;  // hipErrorInvalidValue
+    std::memcpy(p, h.reserved, sizeof(*p));
+    return 0;
+}
 inline hipError_t hipIpcCloseMemHandle(void*) { return 0; }
 const char* hipGetErrorString(hipError_t e);
 

@@ -77,6 +77,9 @@ def test_bench_dry_run_two_ranks(tmp_path):
     assert line["parity"]["pass"] and line["parity"]["n_past_1e-5"] == 0 and "every rank" in line["parity"]["checked"]
     assert line["no_collective"]["batch"] == 2 and line["no_collective"]["parity"]["pass"]   # the collective-free sharded step
     assert "also" not in line and "modes" not in line
+    # the direct-pattern reassembly is timed as a side key; between two emulator PROCESSES a peer's buffer cannot be mapped,
+    # which every rank must agree on and survive (on the GPU box the key carries a value and a parity object)
+    assert "error" in line["direct_gather"] and "peer" in line["direct_gather"]["error"]
 
 
 class _SideStream(_Stream):
