@@ -188,11 +188,15 @@ __device__ __forceinline__ void w64_tile(const MelspecArgs& a, const WaveArgs& e
             split_pair<TT>(P, w1, w64::kM, ka + 256, za[s][1], p1, sc);
             split_pair<TT>(P, w2, w64::kM, kb, zb[s][0], p2, sc);
             split_pair<TT>(P, w3, w64::kM, kb + 256, zb[s][1], p3, sc);
-            if (s == 1) {  // the special slot's fifth pair, k = 512 with itself; every other lane repeats its first pair
-                const C2<TT> q = {sp ? zb[s][2].x : za[s][0].x, sp ? zb[s][2].y : za[s][0].y};
-                const C2<TT> r = {sp ? zb[s][2].x : p0.x, sp ? zb[s][2].y : p0.y};
-                const C2<TT> w4 = {sp ? TT(0) : w0.x, sp ? TT(-1) : w0.y};
-                split_pair<TT>(P, w4, w64::kM, sp ? 512 : ka, q, r, sc);
+            if (s == 1) {
+                // bin 512 pairs with itself: X[512] = conj Z[512], so 4 |X|^2 = 4 |Z|^2 -- Z[512] is element k3 = 2 of the
+                // special slot's b column.  Every other lane stores a zero into the last pad bin (no LDS access under a
+                // lane condition; the pad bins are zeroed below anyway)
+                const C2<TT> z512 = zb[s][2];
+                const float p512 = scaled_power(TT(4) * mad(z512.x, z512.x, z512.y * z512.y), sc);
+                AUD_BENIGN_RACE_BEGIN();
+                P[sp ? 512 : w64::kH + 2] = sp ? p512 : 0.f;
+                AUD_BENIGN_RACE_END();
             }
         }
         AUD_BENIGN_RACE_BEGIN();  // lanes 3..63 repeat lane 0's store (no LDS access under a lane condition)
