@@ -183,11 +183,24 @@ __global__ __launch_bounds__(kFinishThreads) void k_segment_finish(const Segment
     TT* dltL = cofL + a.n_coefs * a.T;            // [nc][T]
     const int T = a.T, nc = a.n_coefs, tid = int(threadIdx.x), item = int(blockIdx.x);
     const TT* __restrict__ acc = static_cast<const TT*>(a.mfcc_acc) + size_t(item) * nc * T;
-    for (int i = tid + T; i < nc * T; i += kFinishThreads) cofL[i] = acc[i];  // rows 1..: the mel kernel's DCT
+    for (int i0 = tid + T; i0 < nc * T; i0 += 8 * kFinishThreads) {  // rows 1..: the mel kernel's DCT (eight loads in flight)
+        TT part[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) part[u] = i0 + u * kFinishThreads < nc * T ? acc[i0 + u * kFinishThreads] : TT(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * kFinishThreads < nc * T) cofL[i0 + u * kFinishThreads] = part[u];
+    }
     const TT* __restrict__ ep = static_cast<const TT*>(a.energy_part) + size_t(item) * a.tiles * T;
     for (int s = tid; s < T; s += kFinishThreads) {
         TT e = TT(0);
-        for (int t = 0; t < a.tiles; ++t) e += ep[size_t(t) * T + s];
+        for (int t0 = 0; t0 < a.tiles; t0 += 8) {  // eight loads in flight, added in tile order
+            TT part[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) part[u] = t0 + u < a.tiles ? ep[size_t(t0 + u) * T + s] : TT(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) e += part[u];
+        }
         if (a.energy) a.energy[size_t(item) * T + s] = float(e);
         cofL[s] = e;  // SetFloatRowCell(0, s, Energy[s])
     }
@@ -200,15 +213,18 @@ __global__ __launch_bounds__(kFinishThreads) void k_segment_finish(const Segment
         float* out = (pass ? a.delta_deltas : a.deltas) + size_t(item) * nc * T;
         for (int s = tid; s < T; s += kFinishThreads) {
             TT prv = TT(0), nxt = TT(0);
+            const int p1 = max(s - 1, 0), p2 = max(s - 2, 0), n1 = min(s + 1, T - 1), n2 = min(s + 2, T - 1);
+#pragma unroll 4
             for (int i = 0; i < nc; ++i) {
-                TT nume = TT(0), d = TT(0);
-                for (int n = 1; n <= 2; ++n) {
-                    const int sprv = max(s - n, 0), snxt = min(s + n, T - 1);
-                    prv += in[i * T + sprv];
-                    nxt += in[i * T + snxt];
-                    nume += TT(n) * (nxt - prv);
-                    d = nume / TT(2 * n * n);
-                }
+                const TT a1 = in[i * T + p1], b1 = in[i * T + n1], a2 = in[i * T + p2], b2 = in[i * T + n2];
+                TT nume = TT(0);
+                prv += a1;  // n = 1 (its quotient nume / 2 is overwritten by the n = 2 one, sndenv.go:399-402)
+                nxt += b1;
+                nume += nxt - prv;
+                prv += a2;  // n = 2
+                nxt += b2;
+                nume += TT(2) * (nxt - prv);
+                const TT d = nume / TT(8);
                 out[i * T + s] = float(d);
                 if (!pass) dltL[i * T + s] = d;
             }
