@@ -500,10 +500,11 @@ __device__ __forceinline__ int amax_exponent(TT amax) {
 // the lanes of one frame agree on the frame's exponent through an LDS word: `slot` points at the frame's word (the same
 // for all its lanes).  float32 plans keep their spectrum unscaled (sc = 0).
 // the scale of the frame whose word `slot` is (the epilogue's lanes own other frames than the FFT's lanes)
-__device__ __forceinline__ int frame_scale_of(const int* slot) {
-    const int ex = *slot;
-    return ex == kNoSignal ? 0 : 2 * ex;
-}
+// Frames at ordinary levels -- largest sample between 2^-20 and 2^30, i.e. scaled or not the spectrum's peak lies within
+// [2^-40, 2^86] and every bin down to 2^-86 of it is a normal float32 (a float64 FFT's own floor is 2^-100 of the peak) --
+// keep scale 0: a wave whose frames all do skips the ldexp of every bin (split_pair<TT, false>).
+__device__ __forceinline__ int scale_of_exponent(int ex) { return (ex == kNoSignal || (ex >= -20 && ex <= 30)) ? 0 : 2 * ex; }
+__device__ __forceinline__ int frame_scale_of(const int* slot) { return scale_of_exponent(*slot); }
 template <typename TT>
 __device__ __forceinline__ int frame_scale(int* slot, TT amax) {
     if constexpr (sizeof(TT) == 4) return 0;
@@ -516,7 +517,9 @@ __device__ __forceinline__ int frame_scale(int* slot, TT amax) {
     return frame_scale_of(slot);
 }
 // one bin of 4 x power into the float32 spectrum
-__device__ __forceinline__ float scaled_power(double p4, int sc) { return float(ldexp(p4, -sc)); }
+template <bool SCALED = true>
+__device__ __forceinline__ float scaled_power(double p4, int sc) { return SCALED ? float(ldexp(p4, -sc)) : float(p4); }
+template <bool SCALED = true>
 __device__ __forceinline__ float scaled_power(float p4, int) { return p4; }
 
 // ---- epilogue of the wave-autonomous kernels ---------------------------------------------------------------------

@@ -52,6 +52,26 @@ __device__ __forceinline__ void read_row10(const TT* row, C2<TT> (&z)[10], bool 
         else z[n2].x = d[n2];
     }
 }
+// Real-FFT split + power of a lane's row pair.  Lanes 1..9: rows (j, 20 - j): k = j + 20 c pairs with (row 20 - j, column
+// 9 - c) and vice versa, c = 0..4; lane 0: row 0: k = 20 c pairs with column 10 - c of the same row (c = 0: DC + Nyquist;
+// c = 5: itself), row 10: k = 10 + 20 c pairs with column 9 - c of the same row.  One code path, partners selected by value.
+template <typename TT, bool SCALED>
+__device__ __forceinline__ void split_rows(float* P, const C2<TT>* tws, const C2<TT> (&za)[10], const C2<TT> (&zb)[10], int j,
+                                           int ra, int rb, int sc) {
+    const bool self = j == 0;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const C2<TT> pa = za[(10 - c) % 10], pb = zb[9 - c], pc = za[9 - c];
+        const C2<TT> b_first = {self ? pa.x : pb.x, self ? pa.y : pb.y};
+        const C2<TT> b_second = {self ? pb.x : pc.x, self ? pb.y : pc.y};
+        split_pair<TT, SCALED>(P, tws[ra + 20 * c], kM, ra + 20 * c, za[c], b_first, sc);
+        split_pair<TT, SCALED>(P, tws[rb + 20 * c], kM, rb + 20 * c, zb[c], b_second, sc);
+    }
+    // lane 0's eleventh pair, k = 100 (row 0, column 5, paired with itself); the other lanes repeat their k = j pair
+    const int k11 = self ? 100 : ra;
+    split_pair<TT, SCALED>(P, tws[k11], kM, k11, self ? za[5] : za[0], self ? za[5] : zb[9], sc);
+    P[kH + (j < 3 ? j : 0)] = 0.f;  // pad bins 201..203 of the last 4-bin chunk
+}
 }  // namespace w20
 
 namespace {
@@ -153,24 +173,9 @@ void k_melspec_w20(const MelspecArgs a, const WaveArgs e) {
     float* Pw = reinterpret_cast<float*>(region);  // [6][kHp]
     float* P = Pw + f * w20::kHp;
     AUD_BENIGN_RACE_BEGIN();
-    {
-        // lanes 1..9: rows (j, 20 - j): k = j + 20 c pairs with (row 20 - j, column 9 - c) and vice versa, c = 0..4;
-        // lane 0: row 0: k = 20 c pairs with column 10 - c of the same row (c = 0: DC + Nyquist; c = 5: itself), row 10:
-        // k = 10 + 20 c pairs with column 9 - c of the same row.  One code path, partners selected by value.
-        const bool self = j == 0;
-#pragma unroll
-        for (int c = 0; c < 5; ++c) {
-            const C2<TT> pa = za[(10 - c) % 10], pb = zb[9 - c], pc = za[9 - c];
-            const C2<TT> b_first = {self ? pa.x : pb.x, self ? pa.y : pb.y};
-            const C2<TT> b_second = {self ? pb.x : pc.x, self ? pb.y : pc.y};
-            split_pair<TT>(P, tws[ra + 20 * c], w20::kM, ra + 20 * c, za[c], b_first, sc);
-            split_pair<TT>(P, tws[rb + 20 * c], w20::kM, rb + 20 * c, zb[c], b_second, sc);
-        }
-        // lane 0's eleventh pair, k = 100 (row 0, column 5, paired with itself); the other lanes repeat their k = j pair
-        const int k11 = self ? 100 : ra;
-        split_pair<TT>(P, tws[k11], w20::kM, k11, self ? za[5] : za[0], self ? za[5] : zb[9], sc);
-        P[w20::kH + (j < 3 ? j : 0)] = 0.f;  // pad bins 201..203 of the last 4-bin chunk
-    }
+    // (frames at ordinary levels carry scale 0, device_common.h scale_of_exponent: a wave of them skips every bin's ldexp)
+    if (sizeof(TT) == 4 || __builtin_amdgcn_ballot_w64(sc != 0) == 0) w20::split_rows<TT, false>(P, tws, za, zb, j, ra, rb, sc);
+    else w20::split_rows<TT, true>(P, tws, za, zb, j, ra, rb, sc);
     AUD_BENIGN_RACE_END();
     wave_lds_fence();
     AUD_STAMP(7);

@@ -65,7 +65,7 @@ __device__ __forceinline__ void w64_tile(const MelspecArgs& a, const WaveArgs& e
     int sc = 0;
     if constexpr (sizeof(TT) == 8) {
         const int ex = wave_max_i32(amax_exponent<TT>(amax));
-        sc = ex == kNoSignal ? 0 : 2 * ex;
+        sc = scale_of_exponent(ex);
     }
     AUD_STAMP(3);
 

@@ -54,7 +54,7 @@ __device__ __forceinline__ void blob_store(const WaveArgs& e, unsigned char* sme
 // 2^sc; the 1/4 lives in the blob's mel weights): X[k] = (E + T)/2, X[M-k] = conj(E - T)/2, E = A + conj B,
 // T = -i W_N^k (A - conj B), evaluated from the pair's k <= M/2 side.  Squaring AFTER the subtraction keeps a weak bin
 // next to a strong partner at the FFT's own accuracy (squares first would not).
-template <typename TT>
+template <typename TT, bool SCALED = true>
 __device__ __forceinline__ void split_pair(float* P, C2<TT> w, int M, int k, C2<TT> A, C2<TT> B, int sc) {
     const C2<TT> E = {A.x + B.x, A.y - B.y};
     const C2<TT> D = {A.x - B.x, A.y + B.y};
@@ -62,8 +62,8 @@ __device__ __forceinline__ void split_pair(float* P, C2<TT> w, int M, int k, C2<
     const C2<TT> Tm = cmul(mD, w);
     const TT xr = E.x + Tm.x, xi = E.y + Tm.y;
     const TT yr = E.x - Tm.x, yi = E.y - Tm.y;
-    P[k] = scaled_power(mad(xr, xr, xi * xi), sc);
-    P[M - k] = scaled_power(mad(yr, yr, yi * yi), sc);  // k = 0 -> the Nyquist bin M; k = M/2 -> the same bin, same value
+    P[k] = scaled_power<SCALED>(mad(xr, xr, xi * xi), sc);
+    P[M - k] = scaled_power<SCALED>(mad(yr, yr, yi * yi), sc);  // k = 0 -> the Nyquist bin M; k = M/2 -> the same bin, same value
 }
 
 }  // namespace
