@@ -60,6 +60,11 @@ struct MelspecArgs {
     const void* bl_bhat;   // [L] complex<TT>: FFT_L of the wrapped conjugate chirp, / L
     const void* bl_tw;     // [L] complex<TT>: exp(-2 pi i k / L)
     int xcd_remap;     // 1: tile_of_workgroup() order (plan option "xcd_remap", default on)
+    // wave kernels: wave tiles per item (N = 2048: frames per item) and its reciprocal, set by launch_melspec_wave -- a
+    // wave finds its item with one scalar multiply (tile_div) instead of the 64-bit division's twenty vector instructions
+    int tiles;
+    unsigned tile_mul;
+    int tile_shift;    // < 0: tiles == 1
     // fused segment tail (aud_segment_batch_dev): the wave kernels w16x16 / w20x10 of a plan with WaveArgs::dct_off >= 0
     // also leave, per item, the CepstrumDct rows 1.. of the UNROUNDED log-mel values and per-tile Energy sums for
     // launch_segment_finish; both null otherwise
@@ -112,6 +117,12 @@ struct MelspecArgs {
 #define AUD_STAMP_REAL(i)
 #define AUD_STAMP_FLUSH(a, wave_tile, lane)
 #endif
+
+// n / a.tiles for n < 2^31 (Granlund-Montgomery round-up reciprocal: tile_mul = ceil(2^(31 + l) / tiles), l = ceil(log2 tiles),
+// tile_shift = l - 1; launch_melspec_wave)
+__device__ __forceinline__ unsigned tile_div(const MelspecArgs& a, unsigned n) {
+    return a.tile_shift < 0 ? n : __umulhi(n, a.tile_mul) >> a.tile_shift;
+}
 
 struct GaborArgs {
     const float* mel;  // [n_items, rows, cols]

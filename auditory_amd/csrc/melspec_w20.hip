@@ -88,13 +88,12 @@ void k_melspec_w20(const MelspecArgs a, const WaveArgs e) {
     BlobRegs<64 * NW> blob;
     blob_fetch<64 * NW>(e, tid, blob);
 
-    const int tiles = (a.T + w20::kFW - 1) / w20::kFW;  // wave tiles per item
-    const int64_t total = int64_t(a.n_items) * tiles;
+    const unsigned total = unsigned(a.n_items) * unsigned(a.tiles);  // (< 2^31: launch_melspec_wave checks)
     const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
-    const int64_t wt = int64_t(wg) * NW + wave;
+    const unsigned wt = wg * NW + wave;
     const bool active = wt < total;
-    const int item = active ? int(wt / tiles) : 0;
-    const int t0 = active ? int(wt - int64_t(item) * tiles) * w20::kFW : 0;
+    const int item = active ? int(tile_div(a, wt)) : 0;
+    const int t0 = active ? int(wt - unsigned(item) * unsigned(a.tiles)) * w20::kFW : 0;
     const aud_item it = a.items[item];
     // lanes 60..63 have no frame of their own: they SHADOW lanes 50..53 (same frame, same column) through the whole FFT --
     // same loads, same arithmetic, same values stored to the same LDS addresses -- so that no LDS access sits under a

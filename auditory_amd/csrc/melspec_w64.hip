@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64 * NW) void k_melspec_w64(const MelspecArgs a, co
     const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
     const int64_t wt0 = (int64_t(wg) * NW + wave) * w64::kFPW;
     // (item, step) of the wave's frames, kept on the scalar unit
-    int item = __builtin_amdgcn_readfirstlane(int(wt0 / a.T));
+    int item = __builtin_amdgcn_readfirstlane(int(tile_div(a, unsigned(wt0))));  // (a.tiles == a.T here; wt0 < 2^31)
     int sstep = __builtin_amdgcn_readfirstlane(int(wt0 - int64_t(item) * a.T));
     PairRaw<16> raw;
     if constexpr (sizeof(TT) == 8)

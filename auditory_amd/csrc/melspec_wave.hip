@@ -101,9 +101,15 @@ hipError_t launch_melspec_wave(int kind, const MelspecArgs& a, const WaveArgs& e
     const int64_t tiles = (int64_t(a.T) + fw - 1) / fw;
     const int64_t per_wg = int64_t(e.waves) * (kind == 4 ? w64::kFPW : 1);  // wave tiles per workgroup
     const int64_t wgs64 = (int64_t(a.n_items) * tiles + per_wg - 1) / per_wg;
-    if (wgs64 > 0x7FFFFFFF) return hipErrorInvalidValue;
+    if (wgs64 > 0x7FFFFFFF || int64_t(a.n_items) * tiles >= (int64_t(1) << 31) - 64 * per_wg) return hipErrorInvalidValue;
+    MelspecArgs b = a;
+    b.tiles = int(tiles);
+    int l = 0;
+    while ((int64_t(1) << l) < tiles) ++l;
+    b.tile_shift = l - 1;
+    b.tile_mul = l == 0 ? 0u : unsigned(((uint64_t(1) << (31 + l)) + uint64_t(tiles) - 1) / uint64_t(tiles));
     hipLaunchKernelGGL(wave_kernel(kind, compute_dtype == AUD_F64, a.sig_dtype, e.n_slots), dim3(unsigned(wgs64)),
-                       dim3(64 * e.waves), e.lds_bytes, st, a, e);
+                       dim3(64 * e.waves), e.lds_bytes, st, b, e);
     return hipGetLastError();
 }
 

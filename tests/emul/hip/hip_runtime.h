@@ -58,6 +58,7 @@ extern "C" void AnnotateIgnoreWritesEnd(const char*, int);
 #endif
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
 inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_ACQ_REL); }  // callers pass wave-uniform values
+inline unsigned __umulhi(unsigned a, unsigned b) { return unsigned((uint64_t(a) * uint64_t(b)) >> 32); }
 inline int atomicMax(int* p, int v) {
     int cur = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (cur < v && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED)) {}
