@@ -26,6 +26,8 @@
 //     (wave_mel_epilogue, device_common.h); the final logarithm is taken in float32 (the stored value is a float32).
 //
 // Reference semantics: sound/sndenv.go:438-478, dft/dft.go:53-85, mel/mel.go:120-153.
+#include <algorithm>
+
 #include "wave_common.h"
 
 namespace aud {
@@ -69,7 +71,8 @@ static wave_kernel_t wave_kernel(int kind, bool f64, int sig_dtype, int n_slots)
 bool melspec_wave_finish(int kind, int compute_dtype, WaveArgs* e) {
     const int nw = wave_kernel_waves(kind, compute_dtype);
     const size_t first = (size_t(e->blob_bytes) + 255) & ~size_t(255);
-    const size_t total = first + size_t(nw) * wave_region_bytes(kind, compute_dtype == AUD_F64);
+    size_t total = first + size_t(nw) * wave_region_bytes(kind, compute_dtype == AUD_F64);
+    total = std::max(total, size_t(64) * 64 * nw);  // blob_store writes 4 x 16 bytes per thread whatever the blob's size
     if (total > 160 * 1024) return false;
     e->xch_off = int(first);
     e->lds_bytes = unsigned(total);

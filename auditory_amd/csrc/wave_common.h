@@ -21,19 +21,21 @@ namespace w64 { constexpr int kN = 2048, kM = 1024, kFPW = 4; }
 namespace {
 
 // The workgroup's table blob: loads first (kept in registers), stores after the caller has issued its operand loads.
-// NT threads, up to 4 x 16 bytes per thread in flight; larger blobs finish with a plain copy loop.
+// NT threads, 4 x 16 bytes per thread through a buffer descriptor over the blob: pieces past its end come back as zeros
+// from the hardware's range check (no index clamps, no memory traffic) and are stored like the others -- the first
+// 64 NT bytes of dynamic LDS belong to the blob and the waves' scratch regions, which nobody has written yet
+// (melspec_wave_finish keeps the launch's LDS at least that large).  Larger blobs finish with a plain copy loop.
 template <int NT>
 struct BlobRegs {
     uint4 v[4];
 };
 template <int NT>
 __device__ __forceinline__ void blob_fetch(const WaveArgs& e, int tid, BlobRegs<NT>& b) {
-    const uint4* __restrict__ g = static_cast<const uint4*>(e.blob);
-    const int n16 = e.blob_bytes >> 4;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(e.blob), 0, e.blob_bytes, 0x00020000);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int i = tid + NT * q;
-        b.v[q] = g[i < n16 ? i : 0];
+        const auto r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (tid + NT * q) * 16, 0, 0);
+        b.v[q] = uint4{r[0], r[1], r[2], r[3]};
     }
 }
 template <int NT>
@@ -42,10 +44,7 @@ __device__ __forceinline__ void blob_store(const WaveArgs& e, unsigned char* sme
     const uint4* __restrict__ g = static_cast<const uint4*>(e.blob);
     const int n16 = e.blob_bytes >> 4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = tid + NT * q;
-        if (i < n16) l[i] = b.v[q];
-    }
+    for (int q = 0; q < 4; ++q) l[tid + NT * q] = b.v[q];
 #pragma unroll 1
     for (int i = tid + 4 * NT; i < n16; i += NT) l[i] = g[i];
 }

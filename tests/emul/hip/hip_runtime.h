@@ -89,6 +89,13 @@ struct emul_u32x2 {
 inline emul_u32x2 __builtin_amdgcn_raw_buffer_load_b64(const __amdgpu_buffer_rsrc_t& r, int voffset, int soffset, int) {
     return emul_buffer_load<emul_u32x2>(r, voffset, soffset);
 }
+struct emul_u32x4 {
+    unsigned v[4];
+    unsigned operator[](int i) const { return v[i]; }
+};
+inline emul_u32x4 __builtin_amdgcn_raw_buffer_load_b128(const __amdgpu_buffer_rsrc_t& r, int voffset, int soffset, int) {
+    return emul_buffer_load<emul_u32x4>(r, voffset, soffset);
+}
 inline unsigned __builtin_amdgcn_raw_buffer_load_b32(const __amdgpu_buffer_rsrc_t& r, int voffset, int soffset, int) {
     return emul_buffer_load<unsigned>(r, voffset, soffset);
 }
