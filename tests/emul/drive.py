@@ -32,7 +32,7 @@ def main():
             PC.case_prev_smooth(orc, "sndenv_16k_n400_nf32", capi.AUD_F32)
             PC.case_mfcc_tail(orc, "sndenv_16k_n400_nf32", capi.AUD_F32)
             PC.case_mfcc_tail(orc, "cfg2_16k_n512_nf40", capi.AUD_F64)        # fused tail, float64 scratch in the spectrum rows
-            PC.case_input_levels(orc, "cfg2_16k_n400_nf40", capi.AUD_F64)     # scaled and unscaled splits, three LogOffSet routes
+            PC.case_input_levels(orc, "cfg2_16k_n400_nf40", capi.AUD_F64, quick=True)   # scaled and unscaled splits
             PC.case_gabor_4d_and_2d_vs_oracle(orc, capi.AUD_F32)
             PC.case_kwta_quick(orc)
         else:
