@@ -84,14 +84,14 @@ def test_emul_sndenv_mirror(orc, emu):
 
 
 @pytest.mark.parametrize("name,seg_ms", [("cfg2_16k_n400_nf40", None), ("cfg2_16k_n512_nf40", None),
-                                         ("cfg5_44k_n2048_nf128", 200.0), ("cfg1_44k_n1103_nf32", None)])
+                                         ("cfg5_44k_n2048_nf128", 200.0), ("odd_15k_n375_nf32", None)])   # (generic kernel: a small N here, N = 1103 on the GPU)
 @pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
 def test_emul_input_levels(orc, emu, name, seg_ms, cdt):
     PC.case_input_levels(orc, name, cdt, seg_ms)
 
 
 @pytest.mark.parametrize("name,seg_ms", [("cfg2_16k_n400_nf40", None), ("cfg2_16k_n512_nf40", None),
-                                         ("cfg5_44k_n2048_nf128", 200.0), ("cfg1_44k_n1103_nf32", None)])
+                                         ("cfg5_44k_n2048_nf128", 200.0), ("odd_15k_n375_nf32", None)])   # (generic kernel: a small N here, N = 1103 on the GPU)
 @pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
 def test_emul_mel_logoff_renorm(orc, emu, name, seg_ms, cdt):
     PC.case_mel_logoff_renorm(orc, name, cdt, seg_ms)
