@@ -34,7 +34,8 @@ def _flags():
     # -fno-slp-vectorize: hipcc otherwise packs neighbouring f32 adds/muls of the butterflies into
     # v_pk_* instructions, which on gfx950 issue no faster than two scalar ops (measured: profiles/
     # r02_valu_issue_rates.txt) and cost ~90 extra v_mov per wave to pair registers up -- see DESIGN.md 4.1
-    return ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC",
+    # -amdgpu-kernarg-preload-count: leading scalar kernel arguments arrive in SGPRs with the wave (wave_common.h wave_kernel_t)
+    return ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-kernarg-preload-count=" + os.environ.get("AUD_KERNARG_PRELOAD", "16"),
             "-Xarch_host", "-ffp-contract=off", "-I" + INCLUDE, "-I" + CSRC]
 
 
@@ -81,6 +82,8 @@ if __name__ == "__main__":
     argv = sys.argv[1:]
     if "--tag" in argv:  # python -m auditory_amd.build --tag exp1 -DAUD_EXP_FOO=1
         t = argv[argv.index("--tag") + 1]
-        print(build(tag=t, defines=[a for a in argv if a.startswith("-D")], verbose=True))
+        # -D... defines and, for compiler experiments, any other flag after a literal "--" (e.g. -- -mllvm -amdgpu-foo=1)
+        extra = argv[argv.index("--") + 1:] if "--" in argv else []
+        print(build(tag=t, defines=[a for a in argv if a.startswith("-D")] + extra, verbose=True))
     else:
         print(build(force=True, verbose=True))

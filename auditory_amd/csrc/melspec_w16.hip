@@ -26,7 +26,8 @@ namespace {
 
 template <typename TT, int SRC, int NW, int MAXS>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(sizeof(TT) == 8 ? 3 : 5, sizeof(TT) == 8 ? 3 : 5)))
-void k_melspec_w16(const MelspecArgs a, const WaveArgs e) {
+void k_melspec_w16(const aud_item* items, unsigned total, unsigned tiles, unsigned tile_mul, int tile_shift, const void* blob_ptr,
+                   int blob_bytes, const MelspecArgs a, const WaveArgs e) {
     using L = w16::Layout<TT>;
     unsigned char* smem = dyn_lds();
     const int tid = int(threadIdx.x);
@@ -35,15 +36,14 @@ void k_melspec_w16(const MelspecArgs a, const WaveArgs e) {
 
     // the workgroup's tables: requested before anything else so that a counted wait can pick them out
     BlobRegs<64 * NW> blob;
-    blob_fetch<64 * NW>(e, tid, blob);
+    blob_fetch<64 * NW>(blob_ptr, blob_bytes, tid, blob);
 
-    const unsigned total = unsigned(a.n_items) * unsigned(a.tiles);  // (< 2^31: launch_melspec_wave checks)
     const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
     const unsigned wt = wg * NW + wave;
     const bool active = wt < total;
-    const int item = active ? int(tile_div(a, wt)) : 0;
-    const int t0 = active ? int(wt - unsigned(item) * unsigned(a.tiles)) * w16::kFW : 0;
-    const aud_item it = a.items[item];
+    const int item = active ? int(tile_div(tile_mul, tile_shift, wt)) : 0;  // (total = n_items x tiles < 2^31: launch_melspec_wave checks)
+    const int t0 = active ? int(wt - unsigned(item) * tiles) * w16::kFW : 0;
+    const aud_item it = items[item];
     const int f = lane >> 4;   // frame within the wave
     const int j = lane & 15;   // lane within the frame's 16-lane group
     AUD_STAMP_DECL;

@@ -78,7 +78,8 @@ namespace {
 
 template <typename TT, int SRC, int NW, int MAXS>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(sizeof(TT) == 8 ? 4 : 5, sizeof(TT) == 8 ? 4 : 5)))
-void k_melspec_w20(const MelspecArgs a, const WaveArgs e) {
+void k_melspec_w20(const aud_item* items, unsigned total, unsigned tiles, unsigned tile_mul, int tile_shift, const void* blob_ptr,
+                   int blob_bytes, const MelspecArgs a, const WaveArgs e) {
     using L = w20::Layout<TT>;
     unsigned char* smem = dyn_lds();
     const int tid = int(threadIdx.x);
@@ -86,15 +87,14 @@ void k_melspec_w20(const MelspecArgs a, const WaveArgs e) {
     const int lane = tid & 63;
 
     BlobRegs<64 * NW> blob;
-    blob_fetch<64 * NW>(e, tid, blob);
+    blob_fetch<64 * NW>(blob_ptr, blob_bytes, tid, blob);
 
-    const unsigned total = unsigned(a.n_items) * unsigned(a.tiles);  // (< 2^31: launch_melspec_wave checks)
     const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
     const unsigned wt = wg * NW + wave;
     const bool active = wt < total;
-    const int item = active ? int(tile_div(a, wt)) : 0;
-    const int t0 = active ? int(wt - unsigned(item) * unsigned(a.tiles)) * w20::kFW : 0;
-    const aud_item it = a.items[item];
+    const int item = active ? int(tile_div(tile_mul, tile_shift, wt)) : 0;  // (total = n_items x tiles < 2^31: launch_melspec_wave checks)
+    const int t0 = active ? int(wt - unsigned(item) * tiles) * w20::kFW : 0;
+    const aud_item it = items[item];
     // lanes 60..63 have no frame of their own: they SHADOW lanes 50..53 (same frame, same column) through the whole FFT --
     // same loads, same arithmetic, same values stored to the same LDS addresses -- so that no LDS access sits under a
     // lane condition

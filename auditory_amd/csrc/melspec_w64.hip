@@ -221,14 +221,15 @@ __device__ __forceinline__ void w64_tile(const MelspecArgs& a, const WaveArgs& e
 }
 
 template <typename TT, int SRC, int NW, int MAXS>
-__global__ __launch_bounds__(64 * NW) void k_melspec_w64(const MelspecArgs a, const WaveArgs e) {
+__global__ __launch_bounds__(64 * NW) void k_melspec_w64(const aud_item*, unsigned, unsigned, unsigned, int, const void* blob_ptr, int blob_bytes, const MelspecArgs a,
+                   const WaveArgs e) {
     using L = w64::Layout<TT>;
     unsigned char* smem = dyn_lds();
     const int tid = int(threadIdx.x);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     BlobRegs<64 * NW> blob;
-    blob_fetch<64 * NW>(e, tid, blob);
+    blob_fetch<64 * NW>(blob_ptr, blob_bytes, tid, blob);
     blob_store<64 * NW>(e, smem, tid, blob);
     __syncthreads();  // the one barrier: tables visible to the workgroup's waves
     unsigned char* region = smem + e.xch_off + wave * L::kRegion;

@@ -7,7 +7,14 @@ namespace aud {
 
 // what melspec_wave.hip needs from a kernel file: the instantiation for (compute type, sample type, epilogue slot
 // capacity) and the bytes of LDS one wave's private region takes
-typedef void (*wave_kernel_t)(const MelspecArgs, const WaveArgs);
+// The first seven parameters repeat what a wave needs FIRST -- where the work items are and how tiles map to them -- as
+// plain scalars ahead of the two argument structs: the build preloads leading scalar kernel arguments into SGPRs
+// (-amdgpu-kernarg-preload-count), so a wave's first dependent load (its item record) leaves without waiting for the
+// argument segment.  items / total_tiles / tiles / tile_mul / tile_shift: as MelspecArgs::items, n_items x tiles, tiles,
+// tile_mul, tile_shift.
+// blob / blob_bytes: as WaveArgs::blob, blob_bytes (the table staging's loads are the very first a wave issues).
+typedef void (*wave_kernel_t)(const aud_item*, unsigned, unsigned, unsigned, int, const void*, int, const MelspecArgs, const WaveArgs);
+__device__ __forceinline__ unsigned tile_div(unsigned mul, int shift, unsigned n) { return shift < 0 ? n : __umulhi(n, mul) >> shift; }
 wave_kernel_t w16_kernel(bool f64, int sig_dtype, int n_slots);
 wave_kernel_t w20_kernel(bool f64, int sig_dtype, int n_slots);
 wave_kernel_t w64_kernel(bool f64, int sig_dtype, int n_slots);
@@ -30,8 +37,8 @@ struct BlobRegs {
     uint4 v[4];
 };
 template <int NT>
-__device__ __forceinline__ void blob_fetch(const WaveArgs& e, int tid, BlobRegs<NT>& b) {
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(e.blob), 0, e.blob_bytes, 0x00020000);
+__device__ __forceinline__ void blob_fetch(const void* blob_ptr, int blob_bytes, int tid, BlobRegs<NT>& b) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(blob_ptr), 0, blob_bytes, 0x00020000);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const auto r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (tid + NT * q) * 16, 0, 0);
