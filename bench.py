@@ -557,11 +557,29 @@ def main():  # noqa: C901
             full = [recv, recv]
         else:
             full = [torch.empty((total,) + tuple(mel3[0].shape[1:]), dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
+        # RCCL through the library's OWN communicator (aud_comm_* / aud_allgather_dev: ncclAllGather on the stream it is
+        # given), not through torch's process group: a collective that torch's ProcessGroupNCCL issues inside a stream capture
+        # pulls its internal stream into the capture, and its watchdog thread then queries events of that stream from the
+        # side -- "operation not permitted on an event last recorded in a capturing stream" aborts the process when the
+        # timing is unlucky (seen once in this round's runs).  torch.distributed stays the control plane (ids, barriers).
+        own_comm = gather and direct is None and even and use_streams
+        if own_comm:
+            import ctypes as C
+            uid = [None]
+            if rank == 0:
+                buf = C.create_string_buffer(128)
+                plan.ctx.check(lib.aud_comm_unique_id(buf))
+                uid[0] = buf.raw
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            plan.ctx.check(lib.aud_comm_init(plan.ctx.handle, world, rank, uid[0]))
         done = [None, None]
 
         def collect(s, st):
             if direct is not None:
                 direct.allgather(mel3[s].data_ptr(), nb * wl.nf * wl.T, st)
+            elif own_comm:
+                plan.ctx.check(lib.aud_allgather_dev(plan.ctx.handle, mel3[s].data_ptr(), full[s].data_ptr(), nb * wl.nf * wl.T, st))
             elif even:
                 dist.all_gather_into_tensor(full[s], mel3[s])
             else:
@@ -600,7 +618,8 @@ def main():  # noqa: C901
                     "streams_this_rank": nb, "rccl_ranks": world if gather else 0,
                     "collective": (("direct pattern (aud_allgather_direct_dev: one device-to-device push per peer on its own "
                                     "stream)" if direct is not None else
-                                    "ncclAllGather (torch.distributed all_gather_into_tensor, RCCL)") +
+                                    "ncclAllGather (RCCL, on the library's own communicator: aud_comm_* / aud_allgather_dev)" if own_comm else
+                                    "all_gather_into_tensor (torch.distributed)") +
                                    " of this rank's [%d, %d, %d] float32 slab, on a second stream, overlapped with the next "
                                    "step's kernel" % (nb, wl.nf, wl.T)) if gather else "none (one rank)"})
         if gather:
@@ -629,6 +648,9 @@ def main():  # noqa: C901
         if direct is not None:
             sync_all()
             direct.close()
+        if own_comm:
+            sync_all()
+            plan.ctx.check(lib.aud_comm_destroy(plan.ctx.handle))
         plan.close()
         return res
 
