@@ -27,7 +27,7 @@ namespace {
 template <typename TT, int SRC, int NW, int MAXS>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(sizeof(TT) == 8 ? 3 : 5, sizeof(TT) == 8 ? 3 : 5)))
 void k_melspec_w16(const aud_item* items, unsigned total, unsigned tiles, unsigned tile_mul, int tile_shift, const void* blob_ptr,
-                   int blob_bytes, const MelspecArgs a, const WaveArgs e) {
+                   int blob_bytes, unsigned n_wgs, int xcd_remap, const MelspecArgs a, const WaveArgs e) {
     using L = w16::Layout<TT>;
     unsigned char* smem = dyn_lds();
     const int tid = int(threadIdx.x);
@@ -38,7 +38,7 @@ void k_melspec_w16(const aud_item* items, unsigned total, unsigned tiles, unsign
     BlobRegs<64 * NW> blob;
     blob_fetch<64 * NW>(blob_ptr, blob_bytes, tid, blob);
 
-    const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
+    const unsigned wg = tile_of_workgroup(blockIdx.x, n_wgs, xcd_remap);
     const unsigned wt = wg * NW + wave;
     const bool active = wt < total;
     const int item = active ? int(tile_div(tile_mul, tile_shift, wt)) : 0;  // (total = n_items x tiles < 2^31: launch_melspec_wave checks)

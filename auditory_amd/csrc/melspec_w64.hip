@@ -221,8 +221,8 @@ __device__ __forceinline__ void w64_tile(const MelspecArgs& a, const WaveArgs& e
 }
 
 template <typename TT, int SRC, int NW, int MAXS>
-__global__ __launch_bounds__(64 * NW) void k_melspec_w64(const aud_item*, unsigned, unsigned, unsigned, int, const void* blob_ptr, int blob_bytes, const MelspecArgs a,
-                   const WaveArgs e) {
+__global__ __launch_bounds__(64 * NW) void k_melspec_w64(const aud_item*, unsigned, unsigned, unsigned, int, const void* blob_ptr, int blob_bytes, unsigned n_wgs,
+                   int xcd_remap, const MelspecArgs a, const WaveArgs e) {
     using L = w64::Layout<TT>;
     unsigned char* smem = dyn_lds();
     const int tid = int(threadIdx.x);
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64 * NW) void k_melspec_w64(const aud_item*, unsign
     __syncthreads();  // the one barrier: tables visible to the workgroup's waves
     unsigned char* region = smem + e.xch_off + wave * L::kRegion;
     const int64_t total = int64_t(a.n_items) * a.T;  // one frame per wave tile
-    const unsigned wg = tile_of_workgroup(blockIdx.x, gridDim.x, a.xcd_remap);
+    const unsigned wg = tile_of_workgroup(blockIdx.x, n_wgs, xcd_remap);
     const int64_t wt0 = (int64_t(wg) * NW + wave) * w64::kFPW;
     // (item, step) of the wave's frames, kept on the scalar unit
     int item = __builtin_amdgcn_readfirstlane(int(tile_div(a, unsigned(wt0))));  // (a.tiles == a.T here; wt0 < 2^31)

@@ -113,7 +113,7 @@ hipError_t launch_melspec_wave(int kind, const MelspecArgs& a, const WaveArgs& e
     b.tile_mul = l == 0 ? 0u : unsigned(((uint64_t(1) << (31 + l)) + uint64_t(tiles) - 1) / uint64_t(tiles));
     hipLaunchKernelGGL(wave_kernel(kind, compute_dtype == AUD_F64, a.sig_dtype, e.n_slots), dim3(unsigned(wgs64)),
                        dim3(64 * e.waves), e.lds_bytes, st, b.items, unsigned(a.n_items) * unsigned(tiles), unsigned(tiles),
-                       b.tile_mul, b.tile_shift, e.blob, e.blob_bytes, b, e);
+                       b.tile_mul, b.tile_shift, e.blob, e.blob_bytes, unsigned(wgs64), a.xcd_remap, b, e);
     return hipGetLastError();
 }
 

@@ -7,13 +7,16 @@ namespace aud {
 
 // what melspec_wave.hip needs from a kernel file: the instantiation for (compute type, sample type, epilogue slot
 // capacity) and the bytes of LDS one wave's private region takes
-// The first seven parameters repeat what a wave needs FIRST -- where the work items are and how tiles map to them -- as
+// The first nine parameters repeat what a wave needs FIRST -- where the work items are and how tiles map to them -- as
 // plain scalars ahead of the two argument structs: the build preloads leading scalar kernel arguments into SGPRs
 // (-amdgpu-kernarg-preload-count), so a wave's first dependent load (its item record) leaves without waiting for the
 // argument segment.  items / total_tiles / tiles / tile_mul / tile_shift: as MelspecArgs::items, n_items x tiles, tiles,
 // tile_mul, tile_shift.
-// blob / blob_bytes: as WaveArgs::blob, blob_bytes (the table staging's loads are the very first a wave issues).
-typedef void (*wave_kernel_t)(const aud_item*, unsigned, unsigned, unsigned, int, const void*, int, const MelspecArgs, const WaveArgs);
+// blob / blob_bytes: as WaveArgs::blob, blob_bytes (the table staging's loads are the very first a wave issues);
+// n_wgs / xcd_remap: the grid's size and MelspecArgs::xcd_remap (gridDim itself would be one more load in front of the
+// item record's).
+typedef void (*wave_kernel_t)(const aud_item*, unsigned, unsigned, unsigned, int, const void*, int, unsigned, int, const MelspecArgs,
+                              const WaveArgs);
 __device__ __forceinline__ unsigned tile_div(unsigned mul, int shift, unsigned n) { return shift < 0 ? n : __umulhi(n, mul) >> shift; }
 wave_kernel_t w16_kernel(bool f64, int sig_dtype, int n_slots);
 wave_kernel_t w20_kernel(bool f64, int sig_dtype, int n_slots);
