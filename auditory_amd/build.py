@@ -77,6 +77,18 @@ def _build(force, verbose, objdir, LIB, extra):
     return LIB
 
 
+UBENCH_SRC = os.path.join(os.path.dirname(HERE), "tools", "ubench", "stream_read.hip")
+UBENCH_LIB = os.path.join(os.path.dirname(HERE), "tools", "ubench", "libstream_read.so")
+
+
+def build_stream_read(force=False):
+    """tools/ubench/libstream_read.so: the plain float32 read kernel bench.py times for `roofline.measured_read_GBps` (SURVEY 8d's
+    measured HBM-read roof).  Measurement only: the product library neither contains nor loads it."""
+    if force or not os.path.exists(UBENCH_LIB) or os.path.getmtime(UBENCH_LIB) < os.path.getmtime(UBENCH_SRC):
+        subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", UBENCH_LIB, UBENCH_SRC])
+    return UBENCH_LIB
+
+
 if __name__ == "__main__":
     import sys
     argv = sys.argv[1:]

@@ -438,7 +438,9 @@ int aud_segment_workspace_bytes(const aud_plan* p, int n_items, int64_t* bytes) 
         const size_t tiles = (T + fw - 1) / fw, tsz = p->d.compute_dtype == AUD_F64 ? 8 : 4;
         *bytes = int64_t(align256(n * p->d.mfcc_coefs * T * tsz) + align256(n * tiles * T * tsz));
     } else {
-        *bytes = int64_t(align256(n * p->H * T * 4));  // a LogPowerSegment of its own when the caller keeps none
+        // a LogPowerSegment of its own when the caller keeps none, and -- PrevSmooth != 0: the scan runs on the stored
+        // power tensor -- a PowerSegment too
+        *bytes = int64_t(align256(n * p->H * T * 4) * (p->d.dft.prev_smooth != 0.0 ? 2 : 1));
     }
     return AUD_OK;
 }
@@ -461,7 +463,10 @@ int aud_segment_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
     if (n_items == 0) return AUD_OK;
     if (!segment_fused(p)) {  // (generic kernel, w64x16, PrevSmooth, more than 13 coefficients): the two launches of the parts
         float* lp = log_power ? log_power : static_cast<float*>(workspace);
-        int rc = aud_melspec_batch_dev(p, sig, sig_dtype, items, n_items, mel, power, lp, stream);
+        float* pw = power;
+        if (!pw && p->d.dft.prev_smooth != 0.0)  // `power` stays optional: the scan's tensor comes out of the workspace
+            pw = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + align256(size_t(n_items) * p->H * p->d.segment_steps * 4));
+        int rc = aud_melspec_batch_dev(p, sig, sig_dtype, items, n_items, mel, pw, lp, stream);
         if (rc != AUD_OK) return rc;
         return aud_mfcc_batch_dev(p, items, n_items, mel, lp, mfcc, deltas, delta_deltas, energy, stream);
     }

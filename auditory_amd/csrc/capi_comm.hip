@@ -95,11 +95,19 @@ int aud_gather_create(aud_ctx* c, int n_ranks, int rank, int64_t slab_floats, fl
     g.peer[size_t(rank)] = g.recv;
     g.streams.assign(size_t(n_ranks), nullptr);
     g.done.assign(size_t(n_ranks), nullptr);
-    AUD_HIP(c, hipEventCreateWithFlags(&g.fork, hipEventDisableTiming));
-    for (int p = 0; p < n_ranks; ++p) {
+    // all or nothing: a failure behind the allocation takes everything down again (aud_gather_destroy walks the
+    // half-built state: null streams / events are skipped), so a later create does not find "already created"
+    hipError_t e = hipEventCreateWithFlags(&g.fork, hipEventDisableTiming);
+    for (int p = 0; p < n_ranks && e == hipSuccess; ++p) {
         if (p == rank) continue;
-        AUD_HIP(c, hipStreamCreateWithFlags(&g.streams[size_t(p)], hipStreamNonBlocking));
-        AUD_HIP(c, hipEventCreateWithFlags(&g.done[size_t(p)], hipEventDisableTiming));
+        e = hipStreamCreateWithFlags(&g.streams[size_t(p)], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g.done[size_t(p)], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        g.peer[size_t(rank)] = nullptr;  // (not an opened handle)
+        (void)aud_gather_destroy(c);
+        return fail(c, AUD_EHIP, std::string("aud_gather_create: ") + hipGetErrorString(e));
     }
     *recv = g.recv;
     return AUD_OK;

@@ -247,8 +247,21 @@ class SndEnv:
             self.MFCCDeltaDeltas = np.zeros((self.Mel.NCoefs, p.SegmentSteps))
         self.SegCnt = lib.aud_seg_cnt(len(self.Signal), p.SegmentSamples, p.StrideSamples,
                                       self.Channels)
-        self._make_plan()
+        self._plan_key = None
+        self._ensure_plan()
         return None
+
+    def _ensure_plan(self):
+        """The device plan bakes the DFT and mel-bank parameters in, while the reference reads se.DFT / se.Mel.FBank at CALL
+        time (Init resets se.DFT, sndenv.go:230, so PrevSmooth etc. can only be set after it): the plan is keyed on them and
+        rebuilt lazily when a call finds them changed."""
+        d, fb = self.DFT, self.Mel.FBank
+        key = (bool(d.CompLogPow), d.LogMin, d.LogOffSet, d.PrevSmooth, d.CurSmooth, fb.LogOff, fb.LogMin, bool(fb.Renorm),
+               fb.RenormMin, fb.RenormMax, fb.RenormScale, bool(self.Mel.MFCC), self.Mel.NCoefs, self._compute_dtype)
+        if self._plan is None or key != self._plan_key:
+            self._make_plan()
+            self._plan_key = key
+        return self._plan
 
     def _make_plan(self):
         if self._plan is not None:
@@ -284,9 +297,10 @@ class SndEnv:
         offset = p.Steps[step] + MSecToSamples(add, self.SampleRate)
         err = self.SndToWindow(segment * p.StrideSamples + offset)
         if err is None:
+            plan = self._ensure_plan()
             self.DFT.Filter(step, self.Window, p.WinSamples, self.Power, self.LogPower, self.PowerSegment,
-                            self.LogPowerSegment, self._plan)
-            self.Mel.FilterDft(step, self.Power, self.MelFBankSegment, self.MelFBank, self.MelFilters, self._plan)
+                            self.LogPowerSegment, plan)
+            self.Mel.FilterDft(step, self.Power, self.MelFBankSegment, self.MelFBank, self.MelFilters, plan)
         return err
 
     def ProcessSegment(self, segment, add=0):
@@ -301,6 +315,7 @@ class SndEnv:
         MFCCSegment / MFCCDeltas / MFCCDeltaDeltas / Energy."""
         its = [self._item(s, add) for s in segments]
         items = runtime.make_items([i[0] for i in its], [i[1] for i in its], [i[2] for i in its])
+        self._ensure_plan()
         if self.Mel.MFCC and self.DFT.CompLogPow:
             o = self._plan.melspec_mfcc_host(self.Signal, items, deltas=bool(self.Mel.Deltas))
             m, pw, lp = o["mel"], o["power"], o["log_power"]
@@ -346,7 +361,7 @@ class SndEnv:
         """sound/sndenv.go:481-497.  NeighInhib is not built: ExtGi stays zero, which is the reference's
         state whenever NeighInhib.On is false (its zero value; SndEnv.Defaults never turns it on)."""
         agabor.Convolve(self.MelFBankSegment, self.GaborFilters, self.GborOutput, self.ByTime,
-                        plan=self._plan)
+                        plan=self._ensure_plan())
         self.ExtGi[...] = 0
         if self.Kwta.On:
             self.ApplyKwta()

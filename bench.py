@@ -46,6 +46,7 @@ import memguard  # noqa: E402  resident-memory ceiling (tools/memguard.py)
 memguard.install()
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+VECTOR_PEAK_TF = {"f64": 78.6, "f32": 157.3}  # MI355X_MICROARCH.md: vector (non-matrix) peaks of the arithmetic types
 METRIC = "audio-seconds/sec (16 kHz, 25 ms/10 ms, 40 mel) at 1/2/4/8 MI355X"
 TOL = 1e-5              # BASELINE.json north_star: 1e-5 relative on the float32 mel / gabor tensors
 
@@ -190,6 +191,46 @@ def cpu_baseline(wl, pcm, target_s=12.0, max_threads=16, chunk=8):
 _real_cpu_baseline = cpu_baseline
 
 
+def frame_flops(wl):
+    """SURVEY 8d's algorithmic flops of one frame hop: real-to-complex FFT 2.5 N log2 N + power 3 H + mel 2 x (sum of the
+    triangles' widths) + one logarithm per filter"""
+    widths = sum(int(wl.mp.BinPts[f + 2]) - int(wl.mp.BinPts[f]) + 1 for f in range(wl.nf))
+    return 2.5 * wl.N * math.log2(wl.N) + 3.0 * wl.H + 2.0 * widths + wl.nf
+
+
+def measured_stream_read(torch, dev, gib=2.0, reps=10):
+    """SURVEY 8d's denominator: GB/s of a plain float32 read kernel (tools/ubench/stream_read.hip, built by
+    auditory_amd.build.build_stream_read) over `gib` GiB -- eight times the 256 MB Infinity Cache -- in THIS process, on this
+    box, timed between HIP events on the stream it is launched on.  None (with the reason) when the helper is missing."""
+    import ctypes as C
+    path = os.path.join(ROOT, "tools", "ubench", "libstream_read.so")
+    if dev.type != "cuda":
+        return None, "no GPU (CPU dry run)"
+    if not os.path.exists(path):
+        return None, "tools/ubench/libstream_read.so not built"
+    lib = C.CDLL(path)
+    lib.ubench_stream_read.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.ubench_stream_read.restype = C.c_int
+    nbytes = int(gib * (1 << 30)) // 16 * 16
+    buf = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev)
+    sink = torch.zeros(256 * 32, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
+    best, out = None, {}
+    for wgs in (4, 8, 16):  # workgroups of 256 threads per CU: the best of three launch shapes is the roof
+        gbps, ms = C.c_double(0.0), C.c_double(0.0)
+        rc = lib.ubench_stream_read(buf.data_ptr(), nbytes, reps, wgs, torch.cuda.current_stream(dev).cuda_stream,
+                                    sink.data_ptr(), C.byref(gbps), C.byref(ms))
+        if rc != 0:
+            return None, "ubench_stream_read rc %d" % rc
+        out["%d_wgs_per_cu" % wgs] = round(gbps.value, 1)
+        best = gbps.value if best is None else max(best, gbps.value)
+    del buf, sink
+    torch.cuda.empty_cache()
+    return best, {"bytes_per_pass": nbytes, "passes": reps, "GBps_by_launch_shape": out,
+                  "kernel": "k_stream_read (tools/ubench/stream_read.hip): 16-byte loads, 8 in flight per lane, nothing written"}
+
+
 def strict_parity(got, ref):
     """north-star criterion on every element; returns the `parity` object"""
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
@@ -289,6 +330,7 @@ def main():  # noqa: C901
     ap.add_argument("--report-anyway", action="store_true",
                     help="stand-alone secondary rows only: print the line (with parity.pass = false) when the mode misses the criterion")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stream-read", action="store_true", help="skip roofline.measured_read_GBps (2 GiB read kernel)")
     args = ap.parse_args()
 
     import torch
@@ -722,6 +764,38 @@ def main():  # noqa: C901
             "n512": "BASELINE configs[1] as worded (512-point FFT: WinMs 32): ",
             "cfg5": "BASELINE configs[4]: "}[args.workload]
     top = cfg3 if cfg3 is not None else head      # several GPUs: configs[2] as stated is the line's value
+    # ---- roofline of the dominant kernel (the frame -> mel kernel alone: the one-stream region)
+    read_gbps, read_info = (None, "skipped") if (args.no_stream_read or rank != 0) else measured_stream_read(torch, dev)
+    flops = head["batch"] * head_wl.T * frame_flops(head_wl)
+    solo_s = solo["us_per_step_device"]["mean"] * 1e-6
+    ach_tf, peak_tf = flops / solo_s / 1e12, VECTOR_PEAK_TF[args.compute]
+    roof = {"bound": "valu_" + args.compute, "achieved": solo["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(solo["achieved_GBps"] / HBM_PEAK_GBPS, 5), "traffic": traffic,
+            "measured_read_GBps": round(read_gbps, 1) if read_gbps else None,
+            "frac_of_measured": round(solo["achieved_GBps"] / read_gbps, 5) if read_gbps else None,
+            "measured_read": read_info,
+            "algorithmic_flops_per_launch": round(flops), "achieved_TFLOPs": round(ach_tf, 2), "vector_peak_TFLOPs": peak_tf,
+            "frac_of_%s_vector_peak" % args.compute: round(ach_tf / peak_tf, 4),
+            "pipelined": {"GBps": head["achieved_GBps"], "frac": round(head["achieved_GBps"] / HBM_PEAK_GBPS, 5),
+                          "frac_of_measured": round(head["achieved_GBps"] / read_gbps, 5) if read_gbps else None,
+                          "frac_of_%s_vector_peak" % args.compute: round(
+                              flops / (head["us_per_step_device"]["mean"] * 1e-6) / 1e12 / peak_tf, 4),
+                          "us_per_launch": head["us_per_step_device"]["mean"], "streams": head["streams"]},
+            "kernel": "frame->FFT->power->mel (%s, %s)" % (head["kernel"], args.compute),
+            "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"],
+            "avg_launch_us": solo["us_per_step_device"]["mean"], "rocprofv3_avg_launch_us": rocprof_us,
+            "pipelined_GBps": head["achieved_GBps"],
+            "note": "bound: what limits the kernel -- vector-ALU issue in the compute type (DESIGN.md 4.1: %s of the vector peak at "
+                    "the pipelined rate with HBM at %s of 8 TB/s), not HBM; `achieved` / `peak` / `frac` still price it against HBM as "
+                    "the contract asks: algorithmic bytes (every sample read once, every mel value written once) / mean device time per "
+                    "launch between HIP events in a ONE-stream region of %d utterances per launch (the kernel alone on the chip, "
+                    "kernel-to-kernel boundary included); frac_of_measured = the same over measured_read_GBps (a plain float32 read "
+                    "kernel over 2 GiB in this process: SURVEY 8d's denominator); achieved_TFLOPs = SURVEY 8d's algorithmic flops "
+                    "(2.5 N log2 N + 3 H + 2 sum of widths + nf per frame) / the same time; rocprofv3_avg_launch_us = the average "
+                    "duration rocprofv3 --kernel-trace --stats gave the same kernel in the committed profile (profiles/"
+                    "pmc_traffic.json); pipelined = the same bytes and flops / time per step of the %d-stream region (`value`)"
+                    % ("%.2f" % (flops / (head["us_per_step_device"]["mean"] * 1e-6) / 1e12 / peak_tf),
+                       "%.2f" % (head["achieved_GBps"] / HBM_PEAK_GBPS), B, head["streams"])}
     line = {
         "metric": METRIC, "value": top["value"], "unit": "audio-seconds/sec",
         "n_gpus": world, "steps": top["steps"], "warmup": args.warmup, "ms_per_step": top["ms_per_step"],
@@ -746,18 +820,7 @@ def main():  # noqa: C901
                                                                           else "; no collective (one rank)")},
         "us_per_step_device": top["us_per_step_device"],
         "parity": top.get("parity"),
-        "roofline": {"bound": "hbm", "achieved": solo["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(solo["achieved_GBps"] / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                     "kernel": "frame->FFT->power->mel (%s, %s)" % (head["kernel"], args.compute),
-                     "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"],
-                     "avg_launch_us": solo["us_per_step_device"]["mean"], "rocprofv3_avg_launch_us": rocprof_us,
-                     "pipelined_GBps": head["achieved_GBps"],
-                     "note": "achieved = algorithmic bytes (every sample read once, every mel value written once) / mean device "
-                             "time per launch between HIP events in a ONE-stream region of %d utterances per launch (the kernel "
-                             "alone on the chip, kernel-to-kernel boundary included); rocprofv3_avg_launch_us = the average duration "
-                             "rocprofv3 --kernel-trace --stats gave the same kernel in the committed profile (profiles/"
-                             "pmc_traffic.json; its eager, traced launches run about 1 us longer); pipelined_GBps = the same bytes / time per step of the %d-stream region; the "
-                             "kernel is vector-ALU (float64 issue) bound, not HBM bound (DESIGN.md 4)" % (B, head["streams"])},
+        "roofline": roof,
     }
     if cfg3 is not None:
         line["rccl_ranks"] = cfg3["rccl_ranks"]
@@ -769,6 +832,12 @@ def main():  # noqa: C901
             line["direct_gather"] = ({k: direct_alt[k] for k in ("value", "steps", "ms_per_step", "us_per_step_device", "launch",
                                                                  "collective", "parity") if k in direct_alt}
                                      if "error" not in direct_alt else direct_alt)
+            if "error" not in direct_alt:
+                line["direct_gather"]["note"] = (
+                    "pushes only: every step writes the ONE receive buffer, a rank's graph joins its own pushes but never waits "
+                    "for its peers' data to ARRIVE (no per-step arrival flag), while ncclAllGather returns with every rank's slab "
+                    "in place -- so this side key flatters the direct pattern by the cross-rank completion a consumer needs; "
+                    "parity is checked on the last step's buffer after a barrier")
         line["no_collective"]["note"] = "the sharded step without the collective: %d utterances per rank and step (weak scaling)" % B
     if modes:
         line["modes"] = modes

@@ -83,8 +83,10 @@ type SndEnv struct {
 	// The zero value keeps the reference's arithmetic: float64.
 	ComputeF32 bool
 
-	ctx  *auditoryhip.Ctx
-	plan *auditoryhip.Plan
+	ctx     *auditoryhip.Ctx
+	plan    *auditoryhip.Plan       // device plan of planKey's parameters (segmentPlan rebuilds it when they change)
+	planKey planKey
+	derived auditoryhip.SoundParams // what Init derived (sample counts, steps)
 }
 
 // ParamDefaults: sound/sndenv.go:64-71.
@@ -139,7 +141,7 @@ func (se *SndEnv) Init() (err error) {
 	se.GborKwta.CopyShapeFrom(&se.GborOutput)
 	se.GborKwta.CopyMetaData(&se.GborOutput)
 
-	se.DFT.Defaults() // sndenv.go:230: Init RESETS the DFT parameters (a user's PrevSmooth etc. must be set after Init)
+	se.DFT.Defaults() // sndenv.go:230: Init RESETS the DFT parameters (a user's PrevSmooth etc. must be set after Init; segmentPlan picks them up)
 	se.Mel.InitFilters(se.Params.WinSamples, sr, &se.MelFilters)
 	se.Window.SetShape([]int{se.Params.WinSamples}, nil, nil)
 	se.Power.SetShape([]int{H}, nil, nil)
@@ -170,17 +172,57 @@ func (se *SndEnv) Init() (err error) {
 	}
 	if se.plan != nil {
 		se.plan.Close()
+		se.plan = nil
 	}
+	se.derived = d
+	_, err = se.segmentPlan()
+	return err
+}
+
+// planKey: every parameter the device plan bakes in that the reference reads at CALL time.  Init resets se.DFT
+// (sndenv.go:230), so a user's PrevSmooth / CurSmooth / LogOffSet / LogMin can only be set AFTER Init -- and
+// ProcessSegment must see them, as the reference's loop does (dft.go:62-85 reads dft.* per step).
+type planKey struct {
+	compLogPow                                      bool
+	logMin, logOffSet, prevSmooth, curSmooth        float64
+	melLogOff, melLogMin                            float64
+	renorm                                          bool
+	renormMin, renormMax, renormScale               float64
+	nCoefs                                          int
+	f32                                             bool
+}
+
+func (se *SndEnv) curPlanKey() planKey {
 	nc := 0
 	if se.Mel.MFCC {
 		nc = se.Mel.NCoefs
 	}
-	se.plan, err = se.ctx.NewSndEnvPlan(d, se.DFT.CompLogPow, se.DFT.LogMin, se.DFT.LogOffSet, se.DFT.PrevSmooth, se.DFT.CurSmooth,
+	fb := &se.Mel.FBank
+	return planKey{se.DFT.CompLogPow, se.DFT.LogMin, se.DFT.LogOffSet, se.DFT.PrevSmooth, se.DFT.CurSmooth, fb.LogOff, fb.LogMin,
+		fb.Renorm, fb.RenormMin, fb.RenormMax, fb.RenormScale, nc, se.ComputeF32}
+}
+
+// segmentPlan returns the device plan of the CURRENT parameters, rebuilding it when they differ from the ones it was
+// created with (go/dft keys its per-step plan the same way, dft.go stepPlan).
+func (se *SndEnv) segmentPlan() (*auditoryhip.Plan, error) {
+	key := se.curPlanKey()
+	if se.plan != nil && key == se.planKey {
+		return se.plan, nil
+	}
+	if se.plan != nil {
+		se.plan.Close()
+		se.plan = nil
+	}
+	p, err := se.ctx.NewSndEnvPlan(se.derived, se.DFT.CompLogPow, se.DFT.LogMin, se.DFT.LogOffSet, se.DFT.PrevSmooth, se.DFT.CurSmooth,
 		se.Mel.FBank.NFilters, se.Mel.FBank.LoHz, se.Mel.FBank.HiHz, se.Mel.FBank.LogOff, se.Mel.FBank.LogMin, se.Mel.FBank.Renorm,
 		se.Mel.FBank.RenormMin, se.Mel.FBank.RenormMax, se.Mel.FBank.RenormScale, se.Mel.BinPts, se.MelFilters.Values,
 		se.GaborFilters.SizeX, se.GaborFilters.SizeY, se.GaborFilters.StrideX, se.GaborFilters.StrideY, se.GaborFilters.Gain,
-		se.GaborFilters.Filters.Values, nc, !se.ComputeF32)
-	return err
+		se.GaborFilters.Filters.Values, key.nCoefs, !se.ComputeF32)
+	if err != nil {
+		return nil, err
+	}
+	se.plan, se.planKey = p, key
+	return p, nil
 }
 
 func (se *SndEnv) item(segment, add int) auditoryhip.Item {
@@ -196,12 +238,16 @@ func (se *SndEnv) ProcessSegment(segment, add int) {
 	se.Power.SetZeros()
 	se.LogPower.SetZeros()
 	items := []auditoryhip.Item{se.item(segment, add)}
-	var err error
+	plan, err := se.segmentPlan() // the parameters as they are NOW (a PrevSmooth set after Init counts)
+	if err != nil {
+		fmt.Println(err)
+		return
+	}
 	if se.Mel.MFCC {
-		err = se.plan.MelSpecMFCC(se.Signal.Values, items, se.MelFBankSegment.Values, se.PowerSegment.Values,
+		err = plan.MelSpecMFCC(se.Signal.Values, items, se.MelFBankSegment.Values, se.PowerSegment.Values,
 			se.LogPowerSegment.Values, se.MFCCSegment.Values, se.MFCCDeltas.Values, se.MFCCDeltaDeltas.Values, se.Energy.Values)
 	} else {
-		err = se.plan.MelSpec(se.Signal.Values, items, se.MelFBankSegment.Values, se.PowerSegment.Values, se.LogPowerSegment.Values)
+		err = plan.MelSpec(se.Signal.Values, items, se.MelFBankSegment.Values, se.PowerSegment.Values, se.LogPowerSegment.Values)
 		// Energy[s] = sum over f < SegmentSteps of LogPowerSegment row s (the reference's axis, SURVEY Q8)
 		T := se.Params.SegmentSteps
 		for s := 0; s < T; s++ {
@@ -223,7 +269,11 @@ func (se *SndEnv) ProcessSegments(first, n, add int, mel []float64) error {
 	for i := range items {
 		items[i] = se.item(first+i, add)
 	}
-	return se.plan.MelSpec(se.Signal.Values, items, mel, nil, nil)
+	plan, err := se.segmentPlan()
+	if err != nil {
+		return err
+	}
+	return plan.MelSpec(se.Signal.Values, items, mel, nil, nil)
 }
 
 // ProcessStep: sound/sndenv.go:438-452 (one step: SndToWindow, DFT.Filter, Mel.FilterDft, CepstrumDct).
@@ -252,7 +302,12 @@ func (se *SndEnv) ApplyGabor() (tsr *etensor.Float32) {
 	for i := range shp {
 		shp[i] = int32(se.GborOutput.Dim(i))
 	}
-	if err := se.plan.Convolve(se.MelFBankSegment.Values, 1, se.MelFBankSegment.Dim(0), se.MelFBankSegment.Dim(1), shp, se.ByTime, se.GborOutput.Values); err != nil {
+	plan, perr := se.segmentPlan()
+	if perr != nil {
+		log.Println(perr)
+		return &se.GborOutput
+	}
+	if err := plan.Convolve(se.MelFBankSegment.Values, 1, se.MelFBankSegment.Dim(0), se.MelFBankSegment.Dim(1), shp, se.ByTime, se.GborOutput.Values); err != nil {
 		log.Println(err) // Convolve logs and returns with rawOut untouched (gabor.go:226-229, :259-262)
 	}
 	if se.NeighInhib.On {

@@ -273,6 +273,7 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
     bool ByTime = false;
     int ComputeDtype = AUD_F32;
     PlanHandle plan;
+    aud_plan_desc plan_desc_{};  // what `plan` was created from (ensure_plan)
 
     void ParamDefaults() {  // sndenv.go:64-71
         aud_sound_params c{};
@@ -328,6 +329,25 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
         SegCnt = aud_seg_cnt(int(Signal.Values.size()), Params_.SegmentSamples, Params_.StrideSamples, Channels);
 
         if (ensure_ctx() != AUD_OK) return "no HIP device (libauditory_hip has no CPU fallback)";
+        if (plan.p) { aud_plan_destroy(plan.p); plan.p = nullptr; }
+        return ensure_plan() ? "" : aud_last_error(default_ctx());
+    }
+
+    // The device plan bakes the DFT and mel-bank parameters in, while the reference reads se.DFT / se.Mel.FBank at CALL time
+    // (Init resets se.DFT, sndenv.go:230, so PrevSmooth etc. can only be set after it): the plan is keyed on them and
+    // rebuilt lazily by the call that finds them changed.
+    static bool same_plan(const aud_plan_desc& a, const aud_plan_desc& b) {  // field by field: the structs carry padding
+        const aud_dft_params &x = a.dft, &y = b.dft;
+        const aud_mel_fbank &m = a.mel, &n = b.mel;
+        return a.win_samples == b.win_samples && a.step_samples == b.step_samples && a.segment_steps == b.segment_steps &&
+               a.border_steps == b.border_steps && x.comp_log_pow == y.comp_log_pow && x.log_min == y.log_min &&
+               x.log_offset == y.log_offset && x.prev_smooth == y.prev_smooth && x.cur_smooth == y.cur_smooth &&
+               m.n_filters == n.n_filters && m.lo_hz == n.lo_hz && m.hi_hz == n.hi_hz && m.log_off == n.log_off &&
+               m.log_min == n.log_min && m.renorm == n.renorm && m.renorm_min == n.renorm_min && m.renorm_max == n.renorm_max &&
+               m.renorm_scale == n.renorm_scale && a.n_gabor == b.n_gabor && a.compute_dtype == b.compute_dtype &&
+               a.mfcc_coefs == b.mfcc_coefs;  // (the gabor set and the tables only change in Init, which drops the plan)
+    }
+    bool ensure_plan() {
         aud_plan_desc d{};
         d.win_samples = Params_.WinSamples; d.step_samples = Params_.StepSamples;
         d.segment_steps = Params_.SegmentSteps; d.border_steps = Params_.BorderSteps;
@@ -336,11 +356,13 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
         d.gabor = GaborFilters.c();
         d.compute_dtype = ComputeDtype;
         d.mfcc_coefs = Mel.MFCC ? Mel.NCoefs : 0;
+        if (plan.p && same_plan(d, plan_desc_)) return true;
         if (plan.p) { aud_plan_destroy(plan.p); plan.p = nullptr; }
         if (aud_plan_create(default_ctx(), &d, Mel.BinPts.data(), MelFilters.Values.data(),
                             d.n_gabor ? GaborFilters.Filters.Values.data() : nullptr, &plan.p) != AUD_OK)
-            return aud_last_error(default_ctx());
-        return "";
+            return false;
+        plan_desc_ = d;
+        return true;
     }
 
     // sndenv.go:342-359 (frame loop): PowerSegment, LogPowerSegment, MelFBankSegment of one segment
@@ -348,6 +370,10 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
         aud_item it{0, int32_t(Signal.Values.size()),
                     int32_t(segment * Params_.StrideSamples + MSecToSamples(double(add), SampleRate))};  // :440-441
         int rc;
+        if (!ensure_plan()) {
+            std::printf("%s\n", aud_last_error(default_ctx()));
+            return;
+        }
         if (Mel.MFCC && DFT.CompLogPow)  // the MFCC tail of the loop too: CepstrumDct, Energy, deltas (:360-432)
             rc = aud_melspec_mfcc_batch_host(plan.p, Signal.Values.data(), int64_t(Signal.Values.size()), &it, 1,
                                              MelFBankSegment.Values.data(), PowerSegment.Values.data(),
@@ -378,6 +404,7 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
 
     // sndenv.go:481-497; NeighInhib is not built (ExtGi stays zero, the reference's state when it is off)
     Float32* ApplyGabor() {
+        (void)ensure_plan();
         agabor::Convolve(plan.p, MelFBankSegment, GaborFilters, &GborOutput, ByTime);
         std::fill(ExtGi.Values.begin(), ExtGi.Values.end(), 0.f);
         if (Kwta.On()) {

@@ -283,7 +283,8 @@ int aud_mfcc_batch_dev(aud_plan* plan, const aud_item* items, int n_items, const
  *   mel as in aud_melspec_batch_dev; power / log_power [n_items, H, T] or NULL; mfcc [n_items, NCoefs, T];
  *   deltas / delta_deltas [n_items, NCoefs, T] or NULL; energy [n_items, T] or NULL;
  *   workspace: device, 16-byte aligned, aud_segment_workspace_bytes(plan, n_items) bytes, contents undefined afterwards
- *   (caller-owned so that the call can sit inside a stream capture).
+ *   (caller-owned so that the call can sit inside a stream capture); it also holds the LogPowerSegment and -- with
+ *   dft.PrevSmooth != 0, whose scan runs on the stored tensor -- the PowerSegment a caller passing NULL does not keep.
  * Needs desc.mfcc_coefs > 0 and dft.CompLogPow; AUD_EINVAL if T > H (the Go code indexes out of range). */
 int aud_segment_workspace_bytes(const aud_plan* plan, int n_items, int64_t* bytes);
 int aud_segment_batch_dev(aud_plan* plan, const void* sig, int sig_dtype, const aud_item* items, int n_items,

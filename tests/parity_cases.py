@@ -819,9 +819,8 @@ def case_per_step_api(orc, cdt):
         se.SampleRate, se.Signal = 16000, sig[0]
         se.GborOutUnitsX = se.GborOutUnitsY = 1
         assert se.Init() is None
-        if prev:
+        if prev:   # set AFTER Init, as the reference requires (Init resets se.DFT, sndenv.go:230): the plan re-keys itself
             se.DFT.PrevSmooth, se.DFT.CurSmooth = prev, 1.0 - prev
-            se._make_plan()
         oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
         oc.d.prev_smooth, oc.d.cur_smooth = prev, 1.0 - prev
         ref = orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig[0], segment=0)
@@ -843,11 +842,22 @@ def case_per_step_api(orc, cdt):
         ok, msg = W.spectrum_close(se.PowerSegment[None], ref["power_seg"][None], tol)
         assert ok, "prev=%g power %s" % (prev, msg)
         assert np.all(se.MelFBankSegment[:, done:] == 0)
-        # and the batched ProcessSegment gives the same tensors
-        se2_mel = se.MelFBankSegment.copy()
+        # and the batched ProcessSegment gives the same tensors -- with the parameters as they are at CALL time (a
+        # PrevSmooth set after Init must reach it: ADVICE r3) -- and agrees with the oracle's segment itself
+        se2_mel, se2_pw = se.MelFBankSegment.copy(), se.PowerSegment.copy()
         se.ProcessSegment(0, 0)
         ok, msg = W.feature_close(se.MelFBankSegment, se2_mel, cdt, lin_axis=0)
         assert ok, "batched vs per-step " + msg
+        ok, msg = W.spectrum_close(se.PowerSegment[None], se2_pw[None], tol)
+        assert ok, "batched vs per-step power " + msg
+        ok, msg = W.feature_close(se.MelFBankSegment, ref["mel_seg"], cdt, lin_axis=0)
+        assert ok, "prev=%g ProcessSegment mel %s" % (prev, msg)
+        ok, msg = W.spectrum_close(se.PowerSegment[None], ref["power_seg"][None], tol)
+        assert ok, "prev=%g ProcessSegment power %s" % (prev, msg)
+        if prev:   # switching it off again is seen too
+            se.DFT.PrevSmooth, se.DFT.CurSmooth = 0.0, 1.0
+            se.ProcessSegment(0, 0)
+            assert np.abs(se.PowerSegment - se2_pw).max() > 1e-6 * np.abs(se2_pw).max()
         se._plan.close()
     # dft.Params.Power on coefficients the caller computed (numpy's FFT stands in for gonum's), with the carry;
     # mel.Params.CepstrumDct on one step's filterbank values
@@ -857,7 +867,7 @@ def case_per_step_api(orc, cdt):
     se.GborOutUnitsX = se.GborOutUnitsY = 1
     assert se.Init() is None
     se.DFT.PrevSmooth, se.DFT.CurSmooth = 0.3, 0.7
-    se._make_plan()
+    se._ensure_plan()
     N, T, H = se.Params.WinSamples, se.Params.SegmentSteps, se.Params.WinSamples // 2 + 1
     power, logp = np.zeros(H), np.zeros(H)
     pseg, lseg = np.zeros((H, T)), np.zeros((H, T))

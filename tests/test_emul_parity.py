@@ -187,3 +187,32 @@ def test_emul_plan_info(orc, emu):
                 assert plan.kernel_name == "generic" and plan.info("bluestein_L") == 0
         finally:
             plan.close()
+
+
+def test_emul_segment_prev_smooth_power_is_optional(orc, emu):
+    """aud_segment_batch_dev with dft.PrevSmooth != 0 and power == NULL: the scan's PowerSegment comes out of the
+    workspace, the results equal the ones of the call that keeps a power buffer.  (The emulator's "device" pointers are
+    host pointers, so the _dev entry is driven with numpy arrays here.)"""
+    import numpy as np
+    import workloads as W
+    from auditory_amd import synth
+    oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
+    L = int(0.3 * oc.sr)
+    sig, _ = synth.batch(31, 2, L, oc.sr)
+    items = PC.make_items(oc, L, [(0, 0), (1, 1)])
+    plan = W.product_plan(oc, capi.AUD_F64, mfcc_coefs=13, dft_override=(0.35, 0.65))
+    try:
+        want = plan.melspec_mfcc_host(sig.ravel(), items)
+        n, T = len(items), oc.T
+        ws_bytes = plan.segment_workspace_bytes(n)
+        assert ws_bytes >= 2 * n * oc.H * T * 4           # LogPowerSegment + PowerSegment
+        ws = np.zeros(ws_bytes + 16, np.uint8)
+        wsp = (ws.ctypes.data + 15) & ~15
+        flat = np.ascontiguousarray(sig.ravel())
+        out = dict(mel=np.zeros((n, oc.nf, T), np.float32), mfcc=np.zeros((n, 13, T), np.float32), energy=np.zeros((n, T), np.float32))
+        plan.segment_dev(flat.ctypes.data, capi.AUD_F64, items.ctypes.data, n, out["mel"].ctypes.data, 0, 0, out["mfcc"].ctypes.data,
+                         0, 0, out["energy"].ctypes.data, wsp, ws_bytes)
+        for key in out:
+            assert np.array_equal(out[key].astype(np.float64), want[key], equal_nan=True), key
+    finally:
+        plan.close()

@@ -256,6 +256,22 @@ def test_segment_device_resident(orc, torch_cuda, name):
             assert np.array_equal(full[key].cpu().numpy().astype(np.float64), want[key], equal_nan=True), key
         for key in ("mel", "mfcc", "energy"):
             assert np.array_equal(lean[key].cpu().numpy(), full[key].cpu().numpy(), equal_nan=True), key
+        # both entries route through aud_segment_batch_dev, so the above is self-consistency: the device-resident result
+        # against the ORACLE too, item by item, incl. the masked final steps (the streams end three steps early: Q7)
+        fused = plan.kernel_name in ("w16x16", "w20x10")
+        tols = dict(mfcc=4e-6, deltas=6e-6, delta_deltas=5e-5, energy=3e-7) if fused else \
+            dict(mfcc=8e-6, deltas=4e-5, delta_deltas=2e-4, energy=3e-7)
+        x64 = sig32.astype(np.float64)
+        for r in range(n):
+            o = orc.process_segment_mfcc(oc.sp, oc.d, oc.m, oc.bins, oc.filt, x64[r], segment=0)
+            assert o["done"] < oc.T                                    # some final steps really are masked
+            ok, msg = W.feature_close(full["mel"][r].cpu().numpy(), o["mel_seg"], capi.AUD_F64, lin_axis=0)
+            assert ok, "mel item %d: %s" % (r, msg)
+            for key, tol in tols.items():
+                ok, msg = W.close_enough(full[key][r].cpu().numpy(), o[key], tol)
+                assert ok, "%s item %d vs oracle: %s" % (key, r, msg)
+            assert np.all(full["mfcc"][r].cpu().numpy()[1:, o["done"]:] == 0)
+            assert np.all(full["mel"][r].cpu().numpy()[:, o["done"]:] == 0)
     finally:
         plan.close()
 
@@ -393,6 +409,61 @@ def test_direct_allgather_two_processes_one_gpu(torch_cuda, tmp_path):
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gather_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                               text=True) for r in range(2)]
-    outs = [p.communicate(timeout=300) for p in procs]
+    outs = _join_workers(procs, 300)
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0 and "GATHER-OK" in o, (o[-1000:], e[-3000:])
+
+
+def _join_workers(procs, timeout):
+    """communicate() with every worker under ONE deadline; whatever is still alive when it passes (a peer stuck waiting
+    for the other's handle file, say) is killed -- exactly these pids -- so that nothing stays on the GPU after a failure"""
+    import subprocess
+    import time
+    deadline = time.monotonic() + timeout
+    outs = []
+    try:
+        for p in procs:
+            try:
+                outs.append(p.communicate(timeout=max(1.0, deadline - time.monotonic())))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                o, e = p.communicate()
+                outs.append((o, (e or "") + "\n[killed after %d s]" % timeout))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    return outs
+
+
+def test_two_ranks_one_gpu_bench_flow(torch_cuda, tmp_path):
+    """bench.py's N > 1 flow as TWO processes on this box's one GPU (tools/two_ranks_one_gpu.sh made a test): gloo as the
+    control plane, the library's direct device-to-device reassembly as the collective (RCCL refuses two ranks on one
+    device).  Timing means nothing here; what it checks on hardware is the two-rank control flow: shards, inter-process
+    buffer export, graph-captured pushes, rank 0's strict parity check of BOTH ranks' blocks, and the line's N > 1 keys."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+                                       "--gather-mode", "direct", "--no-cpu-baseline", "--no-stream-read", "--steps", "20",
+                                       "--warmup", "5", "--min-seconds", "0.05", "--cfg3-total", "1024"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root))
+    outs = _join_workers(procs, 420)
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, (o[-1000:], e[-3000:])
+    line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["rccl_ranks"] == 2
+    assert line["gathered_shape"] == [1024, 40, 104] and "direct pattern" in line["collective"]
+    assert line["parity"]["pass"] and line["parity"]["n_past_1e-5"] == 0 and "every rank" in line["parity"]["checked"]
+    assert line["no_collective"]["parity"]["pass"]

@@ -3,7 +3,7 @@
 #   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/gpu_call.sh TAG step [step ...]'
 # Every step is bounded by its own `timeout -k`, writes gpurun_out/TAG_<step>.log, and a step that times out or dies by a
 # signal ends the sequence (no GPU step after it); an ordinary failure (rc 1) does not.
-# Steps: smoke | pytest | bench | bench:<extra bench.py args joined by ','> | ab | profile[:<bench args>] | stamps
+# Steps: smoke | pytest | bench | bench:<extra bench.py args joined by ','> | ab | profile[:<bench args>] | stamps | mfma | stream | two_ranks | hostcall
 set -u
 TAG=${1:?tag}; shift
 mkdir -p gpurun_out
@@ -44,6 +44,12 @@ for step in "$@"; do
                python3 tools/trace_overlap.py "gpurun_out/trace_${TAG}" > "gpurun_out/${TAG}_graph_overlap.txt" 2>&1; cat "gpurun_out/${TAG}_graph_overlap.txt" ;;
         ubench) (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_rates valu_rates.hip) &&
                 run ubench 120 /tmp/valu_rates ;;
+        mfma) (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/mfma_beside_valu mfma_beside_valu.hip) &&
+                run mfma 120 /tmp/mfma_beside_valu ;;
+        stream) (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -DSTREAM_READ_MAIN -o /tmp/stream_read stream_read.hip) &&
+                run stream 120 /tmp/stream_read ;;
+        two_ranks) run two_ranks 500 bash tools/two_ranks_one_gpu.sh "${TAG}_two" ;;
+        hostcall) run hostcall 300 python tools/host_call_time.py ;;
         dispatch) (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/dispatch_rate dispatch_rate.hip) &&
                 run dispatch 120 /tmp/dispatch_rate ;;
         *) echo "unknown step $step"; exit 2 ;;
