@@ -217,7 +217,7 @@ def measured_stream_read(torch, dev, gib=2.0, reps=10):
     sink = torch.zeros(256 * 32, dtype=torch.float32, device=dev)
     torch.cuda.synchronize(dev)
     best, out = None, {}
-    for wgs in (4, 8, 16):  # workgroups of 256 threads per CU: the best of three launch shapes is the roof
+    for wgs in (1, 2, 4, 16):  # workgroups of 256 threads per CU: the best of four launch shapes is the roof
         gbps, ms = C.c_double(0.0), C.c_double(0.0)
         rc = lib.ubench_stream_read(buf.data_ptr(), nbytes, reps, wgs, torch.cuda.current_stream(dev).cuda_stream,
                                     sink.data_ptr(), C.byref(gbps), C.byref(ms))

@@ -15,10 +15,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PEAK_GBPS, PEAK_TF = 8000.0, {"f64": 78.6, "f32": 157.3}
+# the measured HBM-read roof (SURVEY 8d's denominator): best launch shape of tools/ubench/stream_read.hip over 2 GiB on the
+# same pool (profiles/round4_stream_read.txt; bench.py measures it live as roofline.measured_read_GBps)
+MEASURED_READ_GBPS = 6047.0
 
-# workload -> samples per stream, frames per stream, mel filters, bins, kFLOP per frame (2.5 N log2 N + 3 H + 2 sum of widths + logs)
-WL = {"headline": (16000, 104, 40, 201, 13.4), "n512": (16000, 104, 40, 257, 13.4), "cfg4": (16000, 104, 40, 201, 13.4),
-      "sndenv": (16000, 104, 40, 201, 13.4), "cfg5": (220500, 504, 128, 1025, 63.0), "cfg1": (4410, 14, 32, 552, 0.0)}
+# workload -> samples per stream, frames per stream, mel filters, bins, kFLOP per frame (2.5 N log2 N + 3 H + 2 sum of
+# the triangles' widths + nf logarithms, evaluated on the product's own mel table: bench.py frame_flops gives the same figure)
+WL = {"headline": (16000, 104, 40, 201, 10.14), "n512": (16000, 104, 40, 257, 13.43), "cfg4": (16000, 104, 40, 201, 10.14),
+      "sndenv": (16000, 104, 40, 201, 10.14), "cfg5": (220500, 504, 128, 1025, 63.7), "cfg1": (4410, 14, 32, 552, 0.0)}
 
 
 def algorithmic(fam, wl, B):
@@ -59,6 +63,7 @@ def main():
             rows.append({
                 "kernel": k.replace("void aud::(anonymous namespace)::", "").split("(")[0], "tag": tag, "workload": wl, "batch": B,
                 "avg_us": ns / 1e3, "alg_MB": nbytes / 1e6, "GBps": nbytes / ns, "frac": nbytes / ns / PEAK_GBPS,
+                "frac_meas": nbytes / ns / MEASURED_READ_GBPS, "us_per_256": ns / 1e3 * 256.0 / B,
                 "hbm_MB": hbm / 1e6 if hbm else None, "TF": flops / ns / 1e3 if flops else None,
                 "tf_frac": flops / ns / 1e3 / PEAK_TF[v["compute"]] if flops else None,
                 "valu_per_wave": c["SQ_INSTS_VALU"] / waves if waves and "SQ_INSTS_VALU" in c else None,
@@ -74,12 +79,17 @@ def main():
            "every output value written once; the unfused stages' re-reads counted).  `HBM MB` = FETCH_SIZE x 2 (gfx950 "
            "correction) + WRITE_SIZE per launch.  `TF` = algorithmic flops / duration against 78.6 TF (float64) / 157.3 TF "
            "(float32) vector peak.", "",
-           "| kernel | workload, batch | avg us | algorithmic MB | GB/s | **frac of 8 TB/s** | HBM MB (PMC) | TF (of peak) | VALU / wave | "
+           "`of measured` = the same GB/s over the MEASURED read roof, %.0f GB/s (a plain float32 read kernel over 2 GiB, "
+           "`tools/ubench/stream_read.hip`, `profiles/round4_stream_read.txt`).  `us / 256` = the duration scaled to 256 items: the "
+           "row of a launch of 4096 utterances is the counter-backed steady-state rate of the headline kernel (one launch keeps "
+           "every CU busy for 16 rounds of waves, so ramp and tail are 1/16 of it) -- compare with bench.py's `ms_per_step`." % MEASURED_READ_GBPS, "",
+           "| kernel | workload, batch | avg us | us / 256 | algorithmic MB | GB/s | **frac of 8 TB/s** | of measured | HBM MB (PMC) | TF (of peak) | VALU / wave | "
            "LDS cycles / wave | LDS conflict share | SQ_WAIT_ANY share | profile |",
-           "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+           "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for r in rows:
-        out.append("| `%s` | %s, %d | %.2f | %.2f | %.0f | **%.3f** | %s | %s | %s | %s | %s | %s | `%s_*` |" % (
-            r["kernel"], r["workload"], r["batch"], r["avg_us"], r["alg_MB"], r["GBps"], r["frac"], fmt(r["hbm_MB"], "%.2f"),
+        out.append("| `%s` | %s, %d | %.2f | %.2f | %.2f | %.0f | **%.3f** | %.3f | %s | %s | %s | %s | %s | %s | `%s_*` |" % (
+            r["kernel"], r["workload"], r["batch"], r["avg_us"], r["us_per_256"], r["alg_MB"], r["GBps"], r["frac"], r["frac_meas"],
+            fmt(r["hbm_MB"], "%.2f"),
             "—" if r["TF"] is None else "%.1f (%.2f)" % (r["TF"], r["tf_frac"]), fmt(r["valu_per_wave"], "%.0f"),
             fmt(r["lds_cyc_per_wave"], "%.0f"), fmt(r["conflict"], "%.2f"), fmt(r["wait_any"], "%.2f"), r["tag"]))
     text = "\n".join(out) + "\n"
