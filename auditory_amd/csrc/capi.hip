@@ -270,6 +270,15 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
     // kernel family: the wave-autonomous kernel of this window length where one exists and its tables fit, else the
     // generic any-N kernel
     if (rc == AUD_OK) rc = build_wave_tables(p, bin_pts, mel_filters);
+    if (rc == AUD_OK && p->wave_kind == 3) {  // the workgroup-per-item variant, where the item's mel matrix fits LDS beside the rest
+        p->has_item = aud::melspec_item_finish(p->wave_kind, d->compute_dtype, p->wv, nf, d->segment_steps, &p->itm) &&
+                      aud::melspec_item_prepare(p->wave_kind, d->compute_dtype, p->wv, &p->itm) == hipSuccess;
+        (void)hipGetLastError();
+        if (p->has_item && d->n_gabor > 0) {
+            std::vector<float> k32 = convert<float>(gabor_filters, size_t(d->n_gabor) * d->gabor.size_x * d->gabor.size_y);
+            rc = upload(c, reinterpret_cast<void**>(&p->d_gabor32), k32.data(), k32.size() * 4);
+        }
+    }
     if (rc != AUD_OK) {
         aud_plan_destroy(p);
         return rc;
@@ -288,6 +297,7 @@ int aud_plan_destroy(aud_plan* p) {
     if (p->d_filt) (void)hipFree(p->d_filt);
     if (p->d_bin_pts) (void)hipFree(p->d_bin_pts);
     if (p->d_gabor) (void)hipFree(p->d_gabor);
+    if (p->d_gabor32) (void)hipFree(p->d_gabor32);
     if (p->d_dct) (void)hipFree(p->d_dct);
     if (p->d_blob) (void)hipFree(p->d_blob);
     if (p->d_gtab) (void)hipFree(p->d_gtab);
@@ -305,6 +315,10 @@ int aud_plan_get_info(const aud_plan* p, const char* name, int64_t* value) {
     else if (key == "waves_per_wg") *value = wave ? p->wv.waves : 4;
     else if (key == "wgs_per_cu") *value = wave ? p->wv.wgs_per_cu : 0;
     else if (key == "bluestein_L") *value = wave ? 0 : p->bl_L;
+    else if (key == "item_kernel") *value = wave && p->has_item ? 1 : 0;        // the workgroup-per-item variant exists for this plan
+    else if (key == "item_waves") *value = wave && p->has_item ? p->itm.waves : 0;
+    else if (key == "item_lds_bytes") *value = wave && p->has_item ? int64_t(p->itm.lds_bytes) : 0;
+    else if (key == "item_wgs_per_cu") *value = wave && p->has_item ? p->itm.wgs_per_cu : 0;
     else if (key == "frames_per_wave") *value = wave ? aud::melspec_wave_frames_per_wave(p->wave_kind) : 0;
     else if (key == "epilogue_steps") {
         int n = 0;
@@ -322,6 +336,11 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
         if (value < 0 || value > 1) return fail(c, AUD_EINVAL, "kernel: 0 (auto) or 1 (generic)");
         p->use_wave = value == 0 && p->wave_kind != 0;
         p->family = plan_family(p);
+        return AUD_OK;
+    }
+    if (key == "item_kernel") {  // -1 (default): fused mel + gabor calls only; 0: never; 1: every call the variant can serve
+        if (value < -1 || value > 1) return fail(c, AUD_EINVAL, "item_kernel: -1 (auto), 0 (off) or 1 (on)");
+        p->item_opt = value;
         return AUD_OK;
     }
     if (key == "xcd_remap") {  // 1 (default): every XCD walks a contiguous run of tiles; 0: tiles in workgroup-id order
@@ -362,6 +381,12 @@ int aud_melspec_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
     a.mel = mel;
     a.power = power;
     a.log_power = log_power;
+    if (p->item_opt == 1 && p->has_item && p->use_wave && !smooth) {  // the workgroup-per-item variant, no gabor phase
+        aud::ItemArgs g = p->itm;
+        g.nG = 0;
+        AUD_HIP(c, aud::launch_melspec_item(p->wave_kind, a, p->wv, g, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
+        return AUD_OK;
+    }
     AUD_HIP(c, launch_frames(p, a, static_cast<hipStream_t>(stream)));
     if (smooth) {
         // dft.go:67-69: p_s = Prev*p_{s-1} + Cur*raw_s along the steps, then log-power and mel from it
@@ -505,9 +530,11 @@ int aud_segment_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
     return AUD_OK;
 }
 
-int aud_gabor_batch_dev(aud_plan* p, const float* mel, int n_items, int rows, int cols, int out_rank,
-                        const int32_t* out_shape, int by_time, float* out, void* stream) {
-    if (!p) return AUD_EINVAL;
+namespace {
+// Convolve's iteration space and envelope for one call (gabor.go:226-262): fills everything of GaborArgs but the
+// buffers.  AUD_OK with nT == 0 or nF == 0: nothing to do.
+int gabor_geometry(aud_plan* p, int n_items, int rows, int cols, int out_rank, const int32_t* out_shape, int by_time,
+                   aud::GaborArgs* out) {
     aud_ctx* c = p->ctx;
     if (p->d.n_gabor <= 0 || !p->d_gabor) return fail(c, AUD_EINVAL, "plan has no gabor filters");
     if (n_items < 0 || rows < 1 || cols < 1 || !out_shape) return fail(c, AUD_EINVAL, "bad shape");
@@ -515,16 +542,19 @@ int aud_gabor_batch_dev(aud_plan* p, const float* mel, int n_items, int rows, in
     int32_t nT = 0, nF = 0, strides = 1;
     if (aud_gabor_iter_space(&g, rows, cols, out_rank, out_shape, &nT, &nF, &strides) != AUD_OK)
         return fail(c, AUD_EINVAL, "Convolve rejects this shape (gabor.go:226-229, :259-262)");
+    aud::GaborArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.nT = nT;
+    a.nF = nF;
+    a.n_items = n_items;
+    *out = a;
     if (n_items == 0 || nT == 0 || nF == 0) return AUD_OK;
-    if (!mel || !out) return fail(c, AUD_EINVAL, "null buffer");
     const int nG = p->d.n_gabor;
     // reads: the reference indexes melData by flat offset; past the end it panics
     const int64_t last_read = int64_t((nF - 1) * g.stride_y + g.size_y - 1) * cols +
                               int64_t(nT - 1) * g.stride_x + g.size_x - 1;
     if (last_read >= int64_t(rows) * cols)
         return fail(c, AUD_EINVAL, "gabor pools reach past the mel matrix (SURVEY Q10)");
-    aud::GaborArgs a;
-    std::memset(&a, 0, sizeof(a));
     if (out_rank == 2) {
         const int x_max = by_time ? (nT - 1) + strides * (nG - 1) : (nG - 1) + (nT - 1) * nG;
         if (2 * nF > out_shape[0] || x_max >= out_shape[1])
@@ -539,9 +569,6 @@ int aud_gabor_batch_dev(aud_plan* p, const float* mel, int n_items, int rows, in
         a.d2 = out_shape[2];
         a.d3 = out_shape[3];
     }
-    AUD_HIP(c, make_current(c));
-    a.mel = mel;
-    a.n_items = n_items;
     a.rows = rows;
     a.cols = cols;
     a.k = p->d_gabor;
@@ -553,9 +580,23 @@ int aud_gabor_batch_dev(aud_plan* p, const float* mel, int n_items, int rows, in
     a.gain = g.gain;
     a.rank = out_rank;
     a.by_time = by_time;
-    a.nT = nT;
-    a.nF = nF;
     a.t_max_strides = strides;
+    *out = a;
+    return AUD_OK;
+}
+}  // namespace
+
+int aud_gabor_batch_dev(aud_plan* p, const float* mel, int n_items, int rows, int cols, int out_rank,
+                        const int32_t* out_shape, int by_time, float* out, void* stream) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    aud::GaborArgs a;
+    const int rc = gabor_geometry(p, n_items, rows, cols, out_rank, out_shape, by_time, &a);
+    if (rc != AUD_OK) return rc;
+    if (n_items == 0 || a.nT == 0 || a.nF == 0) return AUD_OK;
+    if (!mel || !out) return fail(c, AUD_EINVAL, "null buffer");
+    AUD_HIP(c, make_current(c));
+    a.mel = mel;
     a.out = out;
     AUD_HIP(c, aud::launch_gabor(a, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
     return AUD_OK;
@@ -565,9 +606,46 @@ int aud_process_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
                           int n_items, float* mel, int pools_y, int pools_x, float* gabor,
                           void* stream) {
     if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    const int32_t shape[4] = {pools_y, pools_x, 2, p->d.n_gabor};
+    // ONE launch where the plan has the workgroup-per-item kernel (N = 400): the item's mel matrix stays in LDS behind the
+    // frame loop and Convolve runs on it there (melspec_w20.hip k_melspec_w20_item); otherwise the two launches
+    const bool fused = p->has_item && p->use_wave && p->item_opt != 0 && p->d.dft.prev_smooth == 0.0 && p->d_gabor32 &&
+                       shape[3] == p->d.n_gabor && shape[2] == 2;
+    if (fused) {
+        aud::GaborArgs ga;
+        int rc = gabor_geometry(p, n_items, p->d.mel.n_filters, p->d.segment_steps, 4, shape, 0, &ga);
+        if (rc != AUD_OK) return rc;
+        if (n_items < 0 || (n_items > 0 && (!sig || !items || !mel))) return fail(c, AUD_EINVAL, "null buffer");
+        if (sig_dtype != AUD_F32 && sig_dtype != AUD_F64 && sig_dtype != AUD_I16) return fail(c, AUD_EINVAL, "bad sig_dtype");
+        if (n_items == 0) return AUD_OK;
+        if (ga.nT > 0 && ga.nF > 0 && !gabor) return fail(c, AUD_EINVAL, "null buffer");
+        AUD_HIP(c, make_current(c));
+        aud::MelspecArgs a;
+        fill_melspec_args(p, &a);
+        a.sig = sig;
+        a.sig_dtype = sig_dtype;
+        a.items = items;
+        a.n_items = n_items;
+        a.mel = mel;
+        aud::ItemArgs g = p->itm;
+        g.k32 = p->d_gabor32;
+        g.nG = (ga.nT > 0 && ga.nF > 0) ? p->d.n_gabor : 0;  // an empty iteration space: Convolve writes nothing
+        g.SX = ga.SX;
+        g.SY = ga.SY;
+        g.stx = ga.stx;
+        g.sty = ga.sty;
+        g.gain = ga.gain;
+        g.d0 = ga.d0;
+        g.d1 = ga.d1;
+        g.nT = ga.nT;
+        g.nF = ga.nF;
+        g.out = gabor;
+        AUD_HIP(c, aud::launch_melspec_item(p->wave_kind, a, p->wv, g, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
+        return AUD_OK;
+    }
     int rc = aud_melspec_batch_dev(p, sig, sig_dtype, items, n_items, mel, nullptr, nullptr, stream);
     if (rc != AUD_OK) return rc;
-    const int32_t shape[4] = {pools_y, pools_x, 2, p->d.n_gabor};
     return aud_gabor_batch_dev(p, mel, n_items, p->d.mel.n_filters, p->d.segment_steps, 4, shape, 0,
                                gabor, stream);
 }

@@ -65,6 +65,13 @@ struct aud_plan {
     void* d_filt = nullptr;
     int32_t* d_bin_pts = nullptr;
     void* d_gabor = nullptr;
+    float* d_gabor32 = nullptr;  // float32 copy of the taps (the fused gabor phase of the item kernel, gabor_tile.h)
+    // workgroup-per-item variant of the N = 400 kernel (kernels.h ItemArgs): launch shape, whether it exists for this plan,
+    // and plan option "item_kernel": -1 = automatic (aud_process_batch_dev runs it with the gabor phase fused in; the
+    // mel-only entry points keep the tile kernel), 0 = never, 1 = wherever it exists (mel-only calls too)
+    aud::ItemArgs itm{};
+    bool has_item = false;
+    int item_opt = -1;
     void* d_dct = nullptr;  // [mfcc_coefs][nf] DCT-I rows
     unsigned long long stamps = 0;  // diagnostic builds (-DAUD_STAMPS): device buffer for the phase stamps
     const char* family = "generic";

@@ -686,10 +686,13 @@ __device__ __forceinline__ void wave_spectrum_outputs(const MelspecArgs& a, cons
 // `sc` = the scale of the frame THIS lane reduces (lane % FPW); `exps` = the frames' scale words (null: one frame per wave).
 // FUSE: the instantiation that also carries the segment tail (MelspecArgs::mfcc_acc / energy_part); the kernels branch to
 // it once per wave (wave_mel_epilogue_pick), so the plain path pays nothing for it.
-template <typename TT, int FPW, int MAXS, bool COMPACT = false, bool FUSE = false>
+// TOLDS: the workgroup-per-item kernel also keeps every mel value in the item's LDS matrix mel_lds [nf][T] (what the fused
+// agabor.Convolve reads: a NaN value is stored as 0.5 there, gabor.go:278-280; the tensor in memory keeps the NaN).
+template <typename TT, int FPW, int MAXS, bool COMPACT = false, bool FUSE = false, bool TOLDS = false>
 __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const WaveArgs& e, const float* P, int Hp,
                                                   const unsigned char* smem, int sc, const aud_item& it,
-                                                  int item, int t0, int lane, const int* exps = nullptr) {
+                                                  int item, int t0, int lane, const int* exps = nullptr,
+                                                  float* mel_lds = nullptr) {
     wave_spectrum_outputs<TT, FPW, FUSE>(a, P, Hp, exps, sc, it, item, t0, lane);
     // 64 is not a multiple of FPW = 6: lanes 60..63 have no filter group; they run group n_groups - 1 again and store nothing
     const int T = a.T;
@@ -770,6 +773,10 @@ __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const Wa
                 wide = TT(val);
             }
             if (col_on && flt != 0xFFFF) mel_col[size_t(flt) * T] = live ? res : 0.f;  // MelFBankSegment[item][flt][sstep]
+            if constexpr (TOLDS) {
+                const float kept = live ? res : 0.f;
+                if (col_on && flt != 0xFFFF) mel_lds[flt * T + sstep] = kept != kept ? 0.5f : kept;
+            }
             if constexpr (kCanFuse) {
                 if (fuse) {
                     const bool on = live && flt != 0xFFFF;
@@ -814,13 +821,17 @@ __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const Wa
     }
 }
 
-template <typename TT, int FPW, int MAXS>
+template <typename TT, int FPW, int MAXS, bool TOLDS = false>
 __device__ __forceinline__ void wave_mel_epilogue_pick(const MelspecArgs& a, const WaveArgs& e, const float* P, int Hp,
                                                        const unsigned char* smem, int sc, const aud_item& it,
-                                                       int item, int t0, int lane, const int* exps) {
-    if (a.mfcc_acc != nullptr && e.dct_off >= 0)  // wave-uniform
-        wave_mel_epilogue<TT, FPW, MAXS, false, true>(a, e, P, Hp, smem, sc, it, item, t0, lane, exps);
-    else wave_mel_epilogue<TT, FPW, MAXS, false, false>(a, e, P, Hp, smem, sc, it, item, t0, lane, exps);
+                                                       int item, int t0, int lane, const int* exps, float* mel_lds = nullptr) {
+    if constexpr (TOLDS) {
+        wave_mel_epilogue<TT, FPW, MAXS, false, false, true>(a, e, P, Hp, smem, sc, it, item, t0, lane, exps, mel_lds);
+    } else {
+        if (a.mfcc_acc != nullptr && e.dct_off >= 0)  // wave-uniform
+            wave_mel_epilogue<TT, FPW, MAXS, false, true>(a, e, P, Hp, smem, sc, it, item, t0, lane, exps);
+        else wave_mel_epilogue<TT, FPW, MAXS, false, false>(a, e, P, Hp, smem, sc, it, item, t0, lane, exps);
+    }
 }
 
 }  // namespace aud

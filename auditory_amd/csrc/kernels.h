@@ -79,6 +79,9 @@ struct MelspecArgs {
 #ifdef AUD_STAMPS
 // one stamp = s_memtime behind a drained LDS queue, fenced against the scheduler (cdna_hip_programming.md 7)
 #define AUD_STAMP_DECL unsigned long long aud_stamp_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+// a kernel's phases that live in a device function of their own take / pass the stamp array
+#define AUD_STAMP_PARAM , unsigned long long (&aud_stamp_)[12]
+#define AUD_STAMP_ARG , aud_stamp_
 #define AUD_STAMP(i)                                                                          \
     do {                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                    \
@@ -103,6 +106,8 @@ struct MelspecArgs {
 // static diagnostic (no GPU): "; AUD_PHASE n" comments in the assembly at the phase boundaries, fenced against the
 // scheduler, for tools/phase_count.py (instructions per phase of a wave kernel)
 #define AUD_STAMP_DECL
+#define AUD_STAMP_PARAM
+#define AUD_STAMP_ARG
 #define AUD_STAMP(i)                                             \
     do {                                                         \
         __builtin_amdgcn_sched_barrier(0);                       \
@@ -113,6 +118,8 @@ struct MelspecArgs {
 #define AUD_STAMP_FLUSH(a, wave_tile, lane)
 #else
 #define AUD_STAMP_DECL
+#define AUD_STAMP_PARAM
+#define AUD_STAMP_ARG
 #define AUD_STAMP(i)
 #define AUD_STAMP_REAL(i)
 #define AUD_STAMP_FLUSH(a, wave_tile, lane)
@@ -164,6 +171,23 @@ struct WaveArgs {
     int wgs_per_cu;        // the runtime's occupancy answer (aud_plan_get_info)
     int dct_off;           // fused segment tail: TT [nf][kDctPitch], row f = column f of the DCT-I matrix (coefficient c at
                            // [c], zero beyond n_coefs); -1: the plan has no fused tail
+};
+// Arguments of the workgroup-per-item variant of the N = 400 kernel (melspec_w20.hip k_melspec_w20_item): one workgroup takes
+// ALL frames of one work item -- its waves walk the item's tiles -- so the item's whole mel matrix [nf, T] can stay in LDS
+// behind the frame loop and agabor.Convolve (agabor/gabor.go:225-315) runs on it without a second launch or a re-read from
+// memory.  nG == 0: no gabor stage (the mel-only item kernel, plan option "item_kernel").
+struct ItemArgs {
+    int waves;           // waves per workgroup of the launch
+    int mel_off;         // byte offset of the item's [nf][T] float32 mel matrix inside dynamic LDS (NaN already read as 0.5)
+    unsigned lds_bytes;  // dynamic LDS of the launch
+    int wgs_per_cu;      // the runtime's occupancy answer
+    // gabor stage (rank-4 output [d0, d1, 2, nG], the shape aud_process_batch_dev asks for)
+    const float* k32;    // [nG][SY][SX] taps, float32 copy
+    int nG, SX, SY, stx, sty;
+    double gain;
+    int d0, d1;          // pools
+    int nT, nF;          // iteration space (aud_gabor_iter_space)
+    float* out;          // [n_items, d0, d1, 2, nG]
 };
 constexpr int kDctCoefs = 13;  // coefficients the fused tail carries per lane (the reference's default NCoefs, mel.go:71)
 constexpr int kDctPitch = 14;  // row pitch of the table (16-byte rows in float64)
@@ -232,6 +256,11 @@ bool melspec_wave_finish(int kind, int compute_dtype, WaveArgs* e);
 hipError_t melspec_wave_prepare(int kind, int compute_dtype, WaveArgs* e);
 hipError_t launch_melspec_wave(int kind, const MelspecArgs& a, const WaveArgs& e, int compute_dtype, hipStream_t st);
 int melspec_wave_frames_per_wave(int kind);
+// workgroup-per-item variant (N = 400 only): carve LDS behind the plan's blob for `nf x T` mel values, false if it cannot fit;
+// `it` keeps the launch shape; the launch
+bool melspec_item_finish(int kind, int compute_dtype, const WaveArgs& e, int nf, int T, ItemArgs* it);
+hipError_t melspec_item_prepare(int kind, int compute_dtype, const WaveArgs& e, ItemArgs* it);
+hipError_t launch_melspec_item(int kind, const MelspecArgs& a, const WaveArgs& e, const ItemArgs& it, int compute_dtype, hipStream_t st);
 
 hipError_t launch_gabor(const GaborArgs& a, int compute_dtype, hipStream_t st);
 

@@ -99,6 +99,57 @@ hipError_t melspec_wave_prepare(int kind, int compute_dtype, WaveArgs* e) {
     return hipSuccess;
 }
 
+// ---- the workgroup-per-item variant (N = 400: k_melspec_w20_item) ---------------------------------------------------
+// LDS = the plan's blob + one region per wave + the item's [nf][T] float32 mel matrix.  Waves per workgroup: five where
+// three such workgroups fit a CU's 160 KB (15 waves per CU; 18 tiles of an item are four rounds of five), else six (two
+// workgroups, 12 waves per CU).
+bool melspec_item_finish(int kind, int compute_dtype, const WaveArgs& e, int nf, int T, ItemArgs* it) {
+    if (kind != 3) return false;
+    const size_t first = size_t(e.xch_off), region = wave_region_bytes(kind, compute_dtype == AUD_F64);
+    const size_t mel = (size_t(nf) * size_t(T) * 4 + 15) & ~size_t(15);
+    for (int nw : {5, 6}) {
+        size_t total = first + size_t(nw) * region + mel;
+        total = std::max(total, size_t(64) * 64 * nw);
+        const size_t per_cu = nw == 5 ? 3 : 2;
+        if (total * per_cu > 160 * 1024 && nw == 5) continue;
+        if (total > 160 * 1024) return false;
+        it->waves = nw;
+        it->mel_off = int(first + size_t(nw) * region);
+        it->lds_bytes = unsigned(total);
+        it->wgs_per_cu = 0;
+        return true;
+    }
+    return false;
+}
+
+hipError_t melspec_item_prepare(int kind, int compute_dtype, const WaveArgs& e, ItemArgs* it) {
+    if (kind != 3 || e.n_slots > 8) return hipErrorInvalidValue;
+    int per_cu = 0;
+    for (int sig_dtype : {AUD_F64, AUD_I16, AUD_F32}) {
+        const void* fn = reinterpret_cast<const void*>(w20_item_kernel(compute_dtype == AUD_F64, sig_dtype, e.n_slots, it->waves));
+        if (!fn) return hipErrorInvalidValue;
+        if (it->lds_bytes > 64u * 1024u) {
+            hipError_t rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (rc != hipSuccess) return rc;
+        }
+        hipError_t rc = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * it->waves, it->lds_bytes);
+        if (rc != hipSuccess) return rc;
+    }
+    it->wgs_per_cu = per_cu;
+    return hipSuccess;
+}
+
+hipError_t launch_melspec_item(int kind, const MelspecArgs& a, const WaveArgs& e, const ItemArgs& it, int compute_dtype,
+                               hipStream_t st) {
+    if (kind != 3 || a.n_items <= 0) return kind != 3 ? hipErrorInvalidValue : hipSuccess;
+    const int tiles = (a.T + w20::kFW - 1) / w20::kFW;
+    item_kernel_t fn = w20_item_kernel(compute_dtype == AUD_F64, a.sig_dtype, e.n_slots, it.waves);
+    if (!fn) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fn, dim3(unsigned(a.n_items)), dim3(64 * it.waves), it.lds_bytes, st, a.items, unsigned(a.n_items),
+                       unsigned(tiles), e.blob, e.blob_bytes, a, e, it);
+    return hipGetLastError();
+}
+
 hipError_t launch_melspec_wave(int kind, const MelspecArgs& a, const WaveArgs& e, int compute_dtype, hipStream_t st) {
     const int fw = kind == 4 ? 1 : melspec_wave_frames_per_wave(kind);
     const int64_t tiles = (int64_t(a.T) + fw - 1) / fw;

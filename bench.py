@@ -523,11 +523,17 @@ def main():  # noqa: C901
             if rc != 0:
                 raise RuntimeError("hot path launch: %d %s" % (rc, lib.aud_last_error(plan.ctx.handle)))
 
+        # configs[3]: ONE launch where the plan has the workgroup-per-item kernel (the item's mel matrix stays in LDS between
+        # the frame loop and Convolve) and no option switched it off; else mel kernel + k_gabor
+        one_launch = bool(gabor and plan.info("item_kernel") == 1 and "item_kernel=0" not in args.option)
         res = timed_region(launch, n_streams, args.min_seconds if min_seconds is None else min_seconds,
                            nb * world * wl.dur_s)
         alg = nb * (ring.sample_bytes * wl.dur + 4 * wl.nf * wl.T)      # each sample read once + each mel value written once
-        if gabor:  # unfused gabor: re-read the mel tensor, write the pooled on/off pairs
-            alg += nb * (4 * wl.nf * wl.T + 4 * GABOR_POOLS[0] * GABOR_POOLS[1] * 2 * 8)
+        if gabor:  # the pooled on/off pairs written; the unfused path also re-reads the mel tensor
+            alg += nb * 4 * GABOR_POOLS[0] * GABOR_POOLS[1] * 2 * 8 + (0 if one_launch else nb * 4 * wl.nf * wl.T)
+            res["launches_per_step"] = 1 if one_launch else 2
+            res["gabor_path"] = ("fused: k_melspec_w20_item (workgroup per item, mel matrix in LDS, Convolve behind one barrier)"
+                                 if one_launch else "two launches: mel kernel, then k_gabor on the stored mel tensor")
         if full:   # Power + LogPower and the tail's four small tensors written; the unfused tail also re-reads mel + LogPower
             alg += nb * (2 * 4 * wl.H * wl.T + 4 * (3 * 13 + 1) * wl.T)
             if args.tail != "fused":

@@ -421,6 +421,101 @@ def case_gabor_4d_and_2d_vs_oracle(orc, cdt):
     plan.close()
 
 
+class HostMem:
+    """'device' buffers of the CPU thread emulator: its device pointers are host pointers"""
+    def put(self, a):
+        return np.ascontiguousarray(a)
+
+    def ptr(self, h):
+        return h.ctypes.data
+
+    def get(self, h):
+        return h
+
+    stream = 0
+
+
+class TorchMem:
+    """device buffers on cuda:0 (GPU tier)"""
+    def __init__(self):
+        import torch
+        self.torch = torch
+
+    def put(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def ptr(self, h):
+        return h.data_ptr()
+
+    def get(self, h):
+        self.torch.cuda.synchronize()
+        return h.cpu().numpy()
+
+    @property
+    def stream(self):
+        return self.torch.cuda.current_stream().cuda_stream
+
+
+def case_process_fused_vs_oracle(orc, cdt, mem, name="cfg2_16k_n400_nf40", n=3, pools=(11, 32)):
+    """aud_process_batch_dev where the plan has the workgroup-per-item kernel (N = 400): mel + agabor.Convolve as ONE launch,
+    the item's mel matrix held in LDS between the two (melspec_w20.hip k_melspec_w20_item, gabor_tile.h).  Against the oracle
+    (mel from the samples, Convolve on the ORACLE's float64 mel) and against the two-launch path of the same plan
+    (option item_kernel = 0); the mel tensor must be the tile kernel's bit for bit.  The last item ends early (masked final
+    steps: zeros in the matrix the gabor phase reads), one item is silent (LogMin rows)."""
+    oc = W.OracleCfg(orc, name)
+    L = oc.full_len()
+    sig, _ = synth.batch(41, n, L - 5 * oc.S, oc.sr, row_len=L)
+    sig[0] = 0.0
+    lens = [L] * n
+    lens[-1] = L - 4 * oc.S                       # its last frames run off the end (Q7)
+    items = runtime.make_items(np.arange(n) * L, lens, [0] * n)
+    sig32 = sig.astype(np.float32)
+    plan = W.product_plan(oc, cdt, GABOR_DEFAULT)
+    k = orc.gabor_to_tensor(W.DEFAULT_GABOR_SPECS, 9, 9)
+    py, px = pools
+    try:
+        assert plan.kernel_name == "w20x10" and plan.info("item_kernel") == 1
+        assert plan.info("item_waves") in (5, 6) and 0 < plan.info("item_lds_bytes") <= 160 * 1024
+        d_sig, d_items = mem.put(sig32.ravel()), mem.put(np.frombuffer(items.tobytes(), np.uint8).copy())
+        outs = {}
+        for mode in (-1, 0):                      # fused (default), then the two launches
+            plan.set_option("item_kernel", mode)
+            d_mel = mem.put(np.full((n, oc.nf, oc.T), 3.0, np.float32))
+            d_gab = mem.put(np.full((n, py, px, 2, 8), 7.0, np.float32))
+            plan.process_dev(mem.ptr(d_sig), capi.AUD_F32, mem.ptr(d_items), n, mem.ptr(d_mel), py, px, mem.ptr(d_gab), mem.stream)
+            outs[mode] = (np.array(mem.get(d_mel)), np.array(mem.get(d_gab)))
+        # mel-only through the item kernel (option 1), with the optional spectrum outputs
+        plan.set_option("item_kernel", 1)
+        d_mel = mem.put(np.zeros((n, oc.nf, oc.T), np.float32))
+        d_pw, d_lp = mem.put(np.zeros((n, oc.H, oc.T), np.float32)), mem.put(np.zeros((n, oc.H, oc.T), np.float32))
+        plan.melspec_dev(mem.ptr(d_sig), capi.AUD_F32, mem.ptr(d_items), n, mem.ptr(d_mel), mem.ptr(d_pw), mem.ptr(d_lp), mem.stream)
+        item_mel, item_pw, item_lp = np.array(mem.get(d_mel)), np.array(mem.get(d_pw)), np.array(mem.get(d_lp))
+        plan.set_option("item_kernel", 0)
+        d_mel2 = mem.put(np.zeros((n, oc.nf, oc.T), np.float32))
+        d_pw2, d_lp2 = mem.put(np.zeros((n, oc.H, oc.T), np.float32)), mem.put(np.zeros((n, oc.H, oc.T), np.float32))
+        plan.melspec_dev(mem.ptr(d_sig), capi.AUD_F32, mem.ptr(d_items), n, mem.ptr(d_mel2), mem.ptr(d_pw2), mem.ptr(d_lp2), mem.stream)
+        assert np.array_equal(item_mel, mem.get(d_mel2), equal_nan=True)
+        assert np.array_equal(item_pw, mem.get(d_pw2)) and np.array_equal(item_lp, mem.get(d_lp2))
+    finally:
+        plan.close()
+    (mel_f, gab_f), (mel_u, gab_u) = outs[-1], outs[0]
+    assert np.array_equal(mel_f, mel_u, equal_nan=True) and np.array_equal(mel_f, item_mel, equal_nan=True)
+    x64 = sig32.astype(np.float64)
+    tol_g = 1e-5 if cdt == capi.AUD_F32 else 1e-6
+    for r in range(n):
+        o = orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, x64[r, :lens[r]], segment=0)
+        ok, msg = W.feature_close(mel_f[r], o["mel_seg"], cdt, lin_axis=0)
+        assert ok, "mel item %d: %s" % (r, msg)
+        ref = np.full((py, px, 2, 8), 7.0, np.float32)
+        assert orc.gabor_convolve(o["mel_seg"], k, 3, 3, 2.0, ref) == 0
+        for what, got in (("fused", gab_f[r]), ("two launches", gab_u[r])):
+            ok, msg = W.close_enough(got, ref, tol_g)
+            assert ok, "gabor (%s) item %d: %s" % (what, r, msg)
+    assert o["done"] < oc.T and np.all(mel_f[-1][:, o["done"]:] == 0)
+    assert np.all(mel_f[0] == -10.0)              # the silent item: LogMin everywhere (Q2)
+    return float(np.abs(gab_f - gab_u).max())
+
+
 def case_sndenv_mirror_reads_like_the_reference(orc):
     """drive the host-side SndEnv mirror the way an emergent sim drives sound.SndEnv"""
     from auditory_amd import agabor, sound

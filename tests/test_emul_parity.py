@@ -216,3 +216,11 @@ def test_emul_segment_prev_smooth_power_is_optional(orc, emu):
             assert np.array_equal(out[key].astype(np.float64), want[key], equal_nan=True), key
     finally:
         plan.close()
+
+
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_emul_process_fused_item_kernel(orc, emu, cdt):
+    """mel + gabor as one launch (workgroup-per-item kernel) on the metric's parameters, and on a short segment whose gabor
+    windows wrap into the next mel row (flat offsets)"""
+    PC.case_process_fused_vs_oracle(orc, cdt, PC.HostMem(), n=2)
+    PC.case_process_fused_vs_oracle(orc, cdt, PC.HostMem(), name="sndenv_16k_n400_nf32", n=2, pools=(8, 4))

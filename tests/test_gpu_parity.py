@@ -76,6 +76,13 @@ def test_gabor_4d_and_2d_vs_oracle(orc, torch_cuda, cdt):
     PC.case_gabor_4d_and_2d_vs_oracle(orc, cdt)
 
 
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_process_fused_item_kernel(orc, torch_cuda, cdt):
+    """mel + gabor as ONE launch (workgroup-per-item kernel, the item's mel matrix in LDS) vs the oracle and vs the two launches"""
+    PC.case_process_fused_vs_oracle(orc, cdt, PC.TorchMem(), n=7)
+    PC.case_process_fused_vs_oracle(orc, cdt, PC.TorchMem(), name="sndenv_16k_n400_nf32", n=5, pools=(8, 4))
+
+
 def test_sndenv_mirror_reads_like_the_reference(orc, torch_cuda):
     PC.case_sndenv_mirror_reads_like_the_reference(orc)
 

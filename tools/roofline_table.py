@@ -32,6 +32,10 @@ def algorithmic(fam, wl, B):
     if fam in ("w20x10", "w16x16", "w64x16", "generic"):
         extra = 2 * 4 * H * T if wl == "sndenv" else 0            # Power + LogPower tensors
         return B * (4 * dur + mel_out + extra), B * T * kflop * 1e3
+    if fam == "w20item":  # workgroup per item; cfg4: + the fused Convolve (no re-read of mel), [11, 32, 2, 8] written
+        gab = wl == "cfg4"
+        return (B * (4 * dur + mel_out + (4 * 11 * 32 * 16 if gab else 0)),
+                B * T * kflop * 1e3 + (B * 2 * 11 * 32 * 8 * 81 if gab else 0))
     if fam == "finish":                                            # fused tail: unrounded DCT rows + per-tile Energy sums read (float64
         tiles = (T + 5) // 6                                       # workspace), mfcc / deltas / delta-deltas / Energy written
         return B * (8 * 13 * T + 8 * tiles * T + 4 * (3 * 13 + 1) * T), B * T * (2 * tiles + 8 * 13 * 2)
