@@ -118,6 +118,11 @@ SYMBOLS = {
     "aud_process_batch_dev": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, _VP, C.c_int, C.c_int,
                                         _VP, _VP]),
     "aud_melspec_batch_host": (C.c_int, [_VP, _VP, C.c_int64, _VP, C.c_int, _VP, _VP, _VP]),
+    "aud_signal_upload": (C.c_int, [_VP, _VP, C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
+    "aud_signal_destroy": (C.c_int, [_VP]),
+    "aud_signal_len": (C.c_int64, [_VP]),
+    "aud_melspec_batch_sig": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP]),
+    "aud_melspec_mfcc_batch_sig": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "aud_snd_to_window": (C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int, _VP]),
     "aud_dft_filter_host": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, _VP, _VP]),
     "aud_mel_filter_dft_host": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),

@@ -58,6 +58,38 @@ namespace {
 
 // as few Stockham stages as possible out of the radices the kernel has in registers
 // (16, 8, 4, 2 | 25, 5 | 3), then whatever primes are left
+// forward DFT of (re, im) in place, any length: decimation in time over the smallest prime factor (O(n sum of factors));
+// long double throughout -- plan-time tables only
+void fft_long_double(std::vector<long double>& re, std::vector<long double>& im) {
+    const size_t n = re.size();
+    if (n <= 1) return;
+    size_t p = 2;
+    while (p * p <= n && n % p != 0) ++p;
+    if (n % p != 0) p = n;
+    const long double pi = 3.14159265358979323846264338327950288L;
+    const size_t m = n / p;
+    std::vector<std::vector<long double>> sr(p, std::vector<long double>(m)), si(p, std::vector<long double>(m));
+    for (size_t r = 0; r < p; ++r) {
+        for (size_t j = 0; j < m; ++j) {
+            sr[r][j] = re[j * p + r];
+            si[r][j] = im[j * p + r];
+        }
+        if (m > 1) fft_long_double(sr[r], si[r]);
+    }
+    for (size_t k = 0; k < n; ++k) {  // X[k] = sum_r W_n^(r k) S_r[k mod m]
+        long double ar = 0.0L, ai = 0.0L;
+        for (size_t r = 0; r < p; ++r) {
+            const long double ang = -2.0L * pi * (long double)((r * k) % n) / (long double)n;
+            const long double c = cosl(ang), s = sinl(ang);
+            const long double xr = sr[r][k % m], xi = si[r][k % m];
+            ar += xr * c - xi * s;
+            ai += xr * s + xi * c;
+        }
+        re[k] = ar;
+        im[k] = ai;
+    }
+}
+
 void factorize(int m, int* fac, int* nfac) {
     int n = 0;
     while (m % 16 == 0) { fac[n++] = 16; m /= 16; }
@@ -103,6 +135,9 @@ int aud_shutdown(aud_ctx* c) {
     for (int i = 0; i < 4; ++i)
         if (c->ws[i]) (void)hipFree(c->ws[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->pin) (void)hipHostFree(c->pin);
+    for (auto& e : c->pin_ev)
+        if (e) (void)hipEventDestroy(e);
     if (c->rccl_lib) dlclose(c->rccl_lib);
     delete c;
     return AUD_OK;
@@ -172,7 +207,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
     }
     // A prime factor the register radices do not cover costs O(p) per output (N = 1103, what 25 ms at 44.1 kHz gives, is
     // prime: 0.6 M complex multiply-adds per frame).  Such lengths go through Bluestein's chirp convolution instead: two
-    // power-of-two FFTs of length L >= 2 M - 1 (melspec_generic.hip).  Tables in long double.
+    // FFTs of a 2-3-5-smooth length L >= 2 M - 1 (melspec_generic.hip).  Tables in long double.
     {
         bool awkward = false;
         for (int i = 0; i < p->nfac; ++i) awkward = awkward || p->fac[i] > 25;
@@ -187,7 +222,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
                 wr[size_t(n)] = cosl(ang);
                 wi[size_t(n)] = sinl(ang);
             }
-            // b[m] = conj(w[|m|]) wrapped to length L, bhat = FFT_L(b) / L by an iterative radix-2 FFT in long double
+            // b[m] = conj(w[|m|]) wrapped to length L, bhat = FFT_L(b) / L by a recursive mixed-radix FFT in long double (any L)
             std::vector<long double> br(Lz, 0.0L), bi(Lz, 0.0L);
             for (int m = 0; m < M; ++m) {
                 br[size_t(m)] = wr[size_t(m)];
@@ -197,28 +232,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
                     bi[size_t(L - m)] = -wi[size_t(m)];
                 }
             }
-            for (int i = 1, j = 0; i < L; ++i) {  // bit reversal
-                int bit = L >> 1;
-                for (; j & bit; bit >>= 1) j ^= bit;
-                j ^= bit;
-                if (i < j) {
-                    std::swap(br[size_t(i)], br[size_t(j)]);
-                    std::swap(bi[size_t(i)], bi[size_t(j)]);
-                }
-            }
-            for (int len = 2; len <= L; len <<= 1) {
-                const long double ang = -2.0L * pi / (long double)len;
-                for (int i0 = 0; i0 < L; i0 += len)
-                    for (int k = 0; k < len / 2; ++k) {
-                        const long double cr = cosl(ang * k), ci = sinl(ang * k);
-                        const size_t u = size_t(i0 + k), v = size_t(i0 + k + len / 2);
-                        const long double tr = br[v] * cr - bi[v] * ci, ti = br[v] * ci + bi[v] * cr;
-                        br[v] = br[u] - tr;
-                        bi[v] = bi[u] - ti;
-                        br[u] += tr;
-                        bi[u] += ti;
-                    }
-            }
+            fft_long_double(br, bi);
             std::vector<double> chirp(Mz * 2), bhat(Lz * 2), twl(Lz * 2);
             for (int n = 0; n < M; ++n) {
                 chirp[2 * size_t(n)] = double(wr[size_t(n)]);
@@ -242,7 +256,9 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
             if (rc == AUD_OK) {
                 p->bl_L = L;
                 factorize(L, p->bl_fac, &p->bl_nfac);
-                p->F_generic = 1;
+                // odd window lengths, float64 plans: two real frames per complex transform (float32 transforms keep one frame
+                // each: separating a pair adds the partner's rounding floor, 4.2e-6 of the frame peak against 3e-6 measured)
+                p->F_generic = (p->ratio == 1 && d->compute_dtype == AUD_F64) ? 2 : 1;
             }
         }
     }
@@ -274,10 +290,15 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
         p->has_item = aud::melspec_item_finish(p->wave_kind, d->compute_dtype, p->wv, nf, d->segment_steps, &p->itm) &&
                       aud::melspec_item_prepare(p->wave_kind, d->compute_dtype, p->wv, &p->itm) == hipSuccess;
         (void)hipGetLastError();
-        if (p->has_item && d->n_gabor > 0) {
-            std::vector<float> k32 = convert<float>(gabor_filters, size_t(d->n_gabor) * d->gabor.size_x * d->gabor.size_y);
-            rc = upload(c, reinterpret_cast<void**>(&p->d_gabor32), k32.data(), k32.size() * 4);
-        }
+    }
+    if (rc == AUD_OK && d->n_gabor > 0) {
+        // float32 copy of the taps for the LDS-staged gabor kernels, QUAD-INTERLEAVED [quads][SY][SX][4] (gabor_tile.h: the
+        // filter pairs of one tap position are adjacent scalar-register pairs), zero rows past the last filter
+        const size_t area = size_t(d->gabor.size_x) * d->gabor.size_y, quads = (size_t(d->n_gabor) + 3) / 4;
+        std::vector<float> k32(quads * area * 4, 0.f);
+        for (int gi = 0; gi < d->n_gabor; ++gi)
+            for (size_t t = 0; t < area; ++t) k32[((size_t(gi) / 4) * area + t) * 4 + size_t(gi) % 4] = float(gabor_filters[size_t(gi) * area + t]);
+        rc = upload(c, reinterpret_cast<void**>(&p->d_gabor32), k32.data(), k32.size() * 4);
     }
     if (rc != AUD_OK) {
         aud_plan_destroy(p);
@@ -341,6 +362,11 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
     if (key == "item_kernel") {  // -1 (default): fused mel + gabor calls only; 0: never; 1: every call the variant can serve
         if (value < -1 || value > 1) return fail(c, AUD_EINVAL, "item_kernel: -1 (auto), 0 (off) or 1 (on)");
         p->item_opt = value;
+        return AUD_OK;
+    }
+    if (key == "gabor_kernel") {  // 0 (default): the LDS-staged kernel where the item fits; 1: one thread per position
+        if (value < 0 || value > 4 || value == 2) return fail(c, AUD_EINVAL, "gabor_kernel: 0 (LDS-staged), 1 (one thread per position); 3, 4: timing experiments");
+        p->gabor_opt = value;
         return AUD_OK;
     }
     if (key == "xcd_remap") {  // 1 (default): every XCD walks a contiguous run of tiles; 0: tiles in workgroup-id order
@@ -572,6 +598,8 @@ int gabor_geometry(aud_plan* p, int n_items, int rows, int cols, int out_rank, c
     a.rows = rows;
     a.cols = cols;
     a.k = p->d_gabor;
+    a.k32 = p->d_gabor32;
+    a.mode = p->gabor_opt;
     a.nG = nG;
     a.SX = g.size_x;
     a.SY = g.size_y;
@@ -610,7 +638,9 @@ int aud_process_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
     const int32_t shape[4] = {pools_y, pools_x, 2, p->d.n_gabor};
     // ONE launch where the plan has the workgroup-per-item kernel (N = 400): the item's mel matrix stays in LDS behind the
     // frame loop and Convolve runs on it there (melspec_w20.hip k_melspec_w20_item); otherwise the two launches
-    const bool fused = p->has_item && p->use_wave && p->item_opt != 0 && p->d.dft.prev_smooth == 0.0 && p->d_gabor32 &&
+    // (option "item_kernel" = 1; the default is the two launches: at 256 items per launch the workgroup-per-item kernel keeps a
+    // CU's vector ALUs less busy than the tile kernel does -- DESIGN.md 4.5 has the measurements)
+    const bool fused = p->has_item && p->use_wave && p->item_opt == 1 && p->d.dft.prev_smooth == 0.0 && p->d_gabor32 &&
                        shape[3] == p->d.n_gabor && shape[2] == 2;
     if (fused) {
         aud::GaborArgs ga;
@@ -636,8 +666,11 @@ int aud_process_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
         g.stx = ga.stx;
         g.sty = ga.sty;
         g.gain = ga.gain;
+        g.rank = 4;
         g.d0 = ga.d0;
         g.d1 = ga.d1;
+        g.d2 = ga.d2;
+        g.d3 = ga.d3;
         g.nT = ga.nT;
         g.nF = ga.nF;
         g.out = gabor;

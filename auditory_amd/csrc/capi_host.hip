@@ -6,6 +6,76 @@ using namespace audc;
 
 extern "C" {
 
+namespace {
+
+int check_items(aud_ctx* c, const aud_item* items, int n_items, int64_t sig_total) {
+    for (int i = 0; i < n_items; ++i)
+        if (items[i].sig_off < 0 || items[i].sig_len < 0 || items[i].sig_stride < 0 || item_last(items[i]) >= sig_total)
+            return fail(c, AUD_EINVAL, "item outside the signal buffer");
+    return AUD_OK;
+}
+
+// the frame loop on a signal that is already on the device (d_sig; the caller holds the HostCallGuard): items up, one
+// launch, float32 results back through pinned staging, widened into the caller's float64 tensors
+int melspec_host_run(aud_plan* p, const void* d_sig, int sig_dtype, const aud_item* items, int n_items, double* mel,
+                     double* power, double* log_power) {
+    aud_ctx* c = p->ctx;
+    const int nf = p->d.mel.n_filters, T = p->d.segment_steps, H = p->H;
+    const size_t n_mel = size_t(n_items) * nf * T, n_pow = size_t(n_items) * H * T;
+    const size_t item_bytes = size_t(n_items) * sizeof(aud_item);
+    const bool smooth = p->d.dft.prev_smooth != 0.0;  // the scan needs a device power buffer
+    const bool want_p = power != nullptr || smooth, want_lp = log_power != nullptr;
+    const size_t out_floats = n_mel + (want_p ? n_pow : 0) + (want_lp ? n_pow : 0);
+    int rc;
+    if ((rc = ensure_ws(c, 1, item_bytes)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 2, out_floats * 4)) != AUD_OK) return rc;
+    float* d_mel = static_cast<float*>(c->ws[2]);
+    float* d_pow = want_p ? d_mel + n_mel : nullptr;
+    float* d_lp = want_lp ? d_mel + n_mel + (want_p ? n_pow : 0) : nullptr;
+    AUD_HIP(c, hipMemcpyAsync(c->ws[1], items, item_bytes, hipMemcpyHostToDevice, c->stream));
+    rc = aud_melspec_batch_dev(p, d_sig, sig_dtype, static_cast<const aud_item*>(c->ws[1]), n_items, d_mel, d_pow, d_lp, c->stream);
+    if (rc != AUD_OK) return rc;
+    const WidenPart parts[3] = {{mel, n_mel}, {power, want_p ? n_pow : 0}, {log_power, want_lp ? n_pow : 0}};
+    return fetch_widened(c, d_mel, parts, 3);
+}
+
+// SndEnv.ProcessSegment with Mel.MFCC on, the same way
+int melspec_mfcc_host_run(aud_plan* p, const void* d_sig, int sig_dtype, const aud_item* items, int n_items, double* mel,
+                          double* power, double* log_power, double* mfcc, double* deltas, double* delta_deltas, double* energy) {
+    aud_ctx* c = p->ctx;
+    const int nf = p->d.mel.n_filters, T = p->d.segment_steps, H = p->H, nc = p->d.mfcc_coefs;
+    const size_t n_mel = size_t(n_items) * nf * T, n_pow = size_t(n_items) * H * T;
+    const size_t n_cc = size_t(n_items) * nc * T, n_en = size_t(n_items) * T;
+    // device layout: mel | power | log_power | mfcc | deltas | delta_deltas | energy
+    const size_t total = n_mel + 2 * n_pow + 3 * n_cc + n_en;
+    const size_t item_bytes = size_t(n_items) * sizeof(aud_item);
+    int rc;
+    if ((rc = ensure_ws(c, 1, item_bytes)) != AUD_OK) return rc;
+    if ((rc = ensure_ws(c, 2, total * 4)) != AUD_OK) return rc;
+    float* d_mel = static_cast<float*>(c->ws[2]);
+    float* d_pow = d_mel + n_mel;
+    float* d_lp = d_pow + n_pow;
+    float* d_cc = d_lp + n_pow;
+    float* d_dl = d_cc + n_cc;
+    float* d_ddl = d_dl + n_cc;
+    float* d_en = d_ddl + n_cc;
+    AUD_HIP(c, hipMemcpyAsync(c->ws[1], items, item_bytes, hipMemcpyHostToDevice, c->stream));
+    const aud_item* d_items = static_cast<const aud_item*>(c->ws[1]);
+    int64_t ws_bytes = 0;
+    (void)aud_segment_workspace_bytes(p, n_items, &ws_bytes);
+    if ((rc = ensure_ws(c, 3, size_t(ws_bytes) + 16)) != AUD_OK) return rc;
+    rc = aud_segment_batch_dev(p, d_sig, sig_dtype, d_items, n_items, d_mel, d_pow, d_lp, d_cc, deltas ? d_dl : nullptr,
+                               delta_deltas ? d_ddl : nullptr, d_en, c->ws[3], ws_bytes, c->stream);
+    if (rc != AUD_OK) return rc;
+    const WidenPart parts[7] = {{mel, n_mel}, {power, n_pow}, {log_power, n_pow}, {mfcc, n_cc}, {deltas, n_cc},
+                                {delta_deltas, n_cc}, {energy, n_en}};
+    return fetch_widened(c, d_mel, parts, 7);
+}
+
+size_t sample_bytes(int dtype) { return dtype == AUD_F64 ? 8 : dtype == AUD_F32 ? 4 : 2; }
+
+}  // namespace
+
 int aud_melspec_batch_host(aud_plan* p, const double* sig, int64_t sig_total, const aud_item* items,
                            int n_items, double* mel, double* power, double* log_power) {
     if (!p) return AUD_EINVAL;
@@ -13,42 +83,83 @@ int aud_melspec_batch_host(aud_plan* p, const double* sig, int64_t sig_total, co
     if (n_items < 0 || sig_total < 0 || (n_items > 0 && (!sig || !items || !mel)))
         return fail(c, AUD_EINVAL, "null buffer");
     if (n_items == 0) return AUD_OK;
-    for (int i = 0; i < n_items; ++i)
-        if (items[i].sig_off < 0 || items[i].sig_len < 0 || items[i].sig_stride < 0 || item_last(items[i]) >= sig_total)
-            return fail(c, AUD_EINVAL, "item outside the signal buffer");
+    int rc = check_items(c, items, n_items, sig_total);
+    if (rc != AUD_OK) return rc;
     AUD_HIP(c, make_current(c));
     HostCallGuard guard(c);
-    const int nf = p->d.mel.n_filters, T = p->d.segment_steps, H = p->H;
-    const size_t n_mel = size_t(n_items) * nf * T, n_pow = size_t(n_items) * H * T;
-    const size_t sig_bytes = size_t(sig_total) * 8, item_bytes = size_t(n_items) * sizeof(aud_item);
-    const bool smooth = p->d.dft.prev_smooth != 0.0;  // the scan needs a device power buffer
-    const bool want_p = power != nullptr || smooth, want_lp = log_power != nullptr;
-    const size_t out_floats = n_mel + (want_p ? n_pow : 0) + (want_lp ? n_pow : 0);
-    int rc;
+    const size_t sig_bytes = size_t(sig_total) * 8;
     if ((rc = ensure_ws(c, 0, sig_bytes + 16)) != AUD_OK) return rc;
-    if ((rc = ensure_ws(c, 1, item_bytes)) != AUD_OK) return rc;
-    if ((rc = ensure_ws(c, 2, out_floats * 4)) != AUD_OK) return rc;
-    float* d_mel = static_cast<float*>(c->ws[2]);
-    float* d_pow = want_p ? d_mel + n_mel : nullptr;
-    float* d_lp = want_lp ? d_mel + n_mel + (want_p ? n_pow : 0) : nullptr;
     AUD_HIP(c, hipMemcpyAsync(c->ws[0], sig, sig_bytes, hipMemcpyHostToDevice, c->stream));
-    AUD_HIP(c, hipMemcpyAsync(c->ws[1], items, item_bytes, hipMemcpyHostToDevice, c->stream));
-    rc = aud_melspec_batch_dev(p, c->ws[0], AUD_F64, static_cast<const aud_item*>(c->ws[1]), n_items,
-                               d_mel, d_pow, d_lp, c->stream);
-    if (rc != AUD_OK) return rc;
-    std::vector<float> h(out_floats);
-    AUD_HIP(c, hipMemcpyAsync(h.data(), d_mel, out_floats * 4, hipMemcpyDeviceToHost, c->stream));
-    AUD_HIP(c, hipStreamSynchronize(c->stream));
-    for (size_t i = 0; i < n_mel; ++i) mel[i] = double(h[i]);
-    size_t o = n_mel;
-    if (want_p) {
-        if (power)
-            for (size_t i = 0; i < n_pow; ++i) power[i] = double(h[o + i]);
-        o += n_pow;
+    return melspec_host_run(p, c->ws[0], AUD_F64, items, n_items, mel, power, log_power);
+}
+
+int aud_signal_upload(aud_ctx* c, const void* samples, int sample_dtype, int64_t n_samples, aud_signal** out) {
+    if (!c || !out) return AUD_EINVAL;
+    *out = nullptr;
+    if (sample_dtype != AUD_F64 && sample_dtype != AUD_F32 && sample_dtype != AUD_I16) return fail(c, AUD_EINVAL, "bad sample_dtype");
+    if (n_samples < 0 || (n_samples > 0 && !samples)) return fail(c, AUD_EINVAL, "null buffer");
+    AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
+    aud_signal* s = new (std::nothrow) aud_signal();
+    if (!s) return AUD_ENOMEM;
+    s->ctx = c;
+    s->dtype = sample_dtype;
+    s->n = n_samples;
+    const size_t bytes = size_t(n_samples) * sample_bytes(sample_dtype);
+    hipError_t e = hipMalloc(&s->d, bytes + 16);
+    if (e == hipSuccess && bytes) e = hipMemcpyAsync(s->d, samples, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        if (s->d) (void)hipFree(s->d);
+        delete s;
+        return hip_fail(c, e, "aud_signal_upload");
     }
-    if (want_lp)
-        for (size_t i = 0; i < n_pow; ++i) log_power[i] = double(h[o + i]);
+    *out = s;
     return AUD_OK;
+}
+
+int aud_signal_destroy(aud_signal* s) {
+    if (!s) return AUD_EINVAL;
+    (void)hipSetDevice(s->ctx->device);
+    {
+        HostCallGuard guard(s->ctx);  // (drains the context's stream: no call still reads the buffer)
+        if (s->d) (void)hipFree(s->d);
+    }
+    delete s;
+    return AUD_OK;
+}
+
+int64_t aud_signal_len(const aud_signal* s) { return s ? s->n : -1; }
+
+int aud_melspec_batch_sig(aud_plan* p, const aud_signal* s, const aud_item* items, int n_items, double* mel, double* power,
+                          double* log_power) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    if (!s || s->ctx != c) return fail(c, AUD_EINVAL, "signal of another context (or null)");
+    if (n_items < 0 || (n_items > 0 && (!items || !mel))) return fail(c, AUD_EINVAL, "null buffer");
+    if (n_items == 0) return AUD_OK;
+    int rc = check_items(c, items, n_items, s->n);
+    if (rc != AUD_OK) return rc;
+    AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
+    return melspec_host_run(p, s->d, s->dtype, items, n_items, mel, power, log_power);
+}
+
+int aud_melspec_mfcc_batch_sig(aud_plan* p, const aud_signal* s, const aud_item* items, int n_items, double* mel, double* power,
+                               double* log_power, double* mfcc, double* deltas, double* delta_deltas, double* energy) {
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    if (!s || s->ctx != c) return fail(c, AUD_EINVAL, "signal of another context (or null)");
+    if (p->d.mfcc_coefs <= 0) return fail(c, AUD_EINVAL, "plan was created without mfcc_coefs");
+    if (!p->d.dft.comp_log_pow) return fail(c, AUD_EINVAL, "the MFCC tail reads LogPowerSegment: needs CompLogPow");
+    if (n_items < 0 || (n_items > 0 && (!items || !mel || !mfcc))) return fail(c, AUD_EINVAL, "null buffer");
+    if (delta_deltas && !deltas) return fail(c, AUD_EINVAL, "delta_deltas needs deltas");
+    if (n_items == 0) return AUD_OK;
+    int rc = check_items(c, items, n_items, s->n);
+    if (rc != AUD_OK) return rc;
+    AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
+    return melspec_mfcc_host_run(p, s->d, s->dtype, items, n_items, mel, power, log_power, mfcc, deltas, delta_deltas, energy);
 }
 
 int aud_snd_to_window(const double* signal, int64_t sig_len, int64_t start, int win_samples, double* window) {
@@ -237,56 +348,14 @@ int aud_melspec_mfcc_batch_host(aud_plan* p, const double* sig, int64_t sig_tota
         return fail(c, AUD_EINVAL, "null buffer");
     if (delta_deltas && !deltas) return fail(c, AUD_EINVAL, "delta_deltas needs deltas");
     if (n_items == 0) return AUD_OK;
-    for (int i = 0; i < n_items; ++i)
-        if (items[i].sig_off < 0 || items[i].sig_len < 0 || items[i].sig_stride < 0 || item_last(items[i]) >= sig_total)
-            return fail(c, AUD_EINVAL, "item outside the signal buffer");
+    int rc = check_items(c, items, n_items, sig_total);
+    if (rc != AUD_OK) return rc;
     AUD_HIP(c, make_current(c));
     HostCallGuard guard(c);
-    const int nf = p->d.mel.n_filters, T = p->d.segment_steps, H = p->H, nc = p->d.mfcc_coefs;
-    const size_t n_mel = size_t(n_items) * nf * T, n_pow = size_t(n_items) * H * T;
-    const size_t n_cc = size_t(n_items) * nc * T, n_en = size_t(n_items) * T;
-    // device layout: mel | power | log_power | mfcc | deltas | delta_deltas | energy
-    const size_t total = n_mel + 2 * n_pow + 3 * n_cc + n_en;
-    const size_t sig_bytes = size_t(sig_total) * 8, item_bytes = size_t(n_items) * sizeof(aud_item);
-    int rc;
+    const size_t sig_bytes = size_t(sig_total) * 8;
     if ((rc = ensure_ws(c, 0, sig_bytes + 16)) != AUD_OK) return rc;
-    if ((rc = ensure_ws(c, 1, item_bytes)) != AUD_OK) return rc;
-    if ((rc = ensure_ws(c, 2, total * 4)) != AUD_OK) return rc;
-    float* d_mel = static_cast<float*>(c->ws[2]);
-    float* d_pow = d_mel + n_mel;
-    float* d_lp = d_pow + n_pow;
-    float* d_cc = d_lp + n_pow;
-    float* d_dl = d_cc + n_cc;
-    float* d_ddl = d_dl + n_cc;
-    float* d_en = d_ddl + n_cc;
     AUD_HIP(c, hipMemcpyAsync(c->ws[0], sig, sig_bytes, hipMemcpyHostToDevice, c->stream));
-    AUD_HIP(c, hipMemcpyAsync(c->ws[1], items, item_bytes, hipMemcpyHostToDevice, c->stream));
-    const aud_item* d_items = static_cast<const aud_item*>(c->ws[1]);
-    int64_t ws_bytes = 0;
-    (void)aud_segment_workspace_bytes(p, n_items, &ws_bytes);
-    if ((rc = ensure_ws(c, 3, size_t(ws_bytes) + 16)) != AUD_OK) return rc;
-    rc = aud_segment_batch_dev(p, c->ws[0], AUD_F64, d_items, n_items, d_mel, d_pow, d_lp, d_cc, deltas ? d_dl : nullptr,
-                               delta_deltas ? d_ddl : nullptr, d_en, c->ws[3], ws_bytes, c->stream);
-    if (rc != AUD_OK) {
-        (void)hipStreamSynchronize(c->stream);
-        return rc;
-    }
-    std::vector<float> h(total);
-    AUD_HIP(c, hipMemcpyAsync(h.data(), d_mel, total * 4, hipMemcpyDeviceToHost, c->stream));
-    AUD_HIP(c, hipStreamSynchronize(c->stream));
-    auto widen = [&](double* dst, const float* src, size_t n) {
-        if (dst)
-            for (size_t i = 0; i < n; ++i) dst[i] = double(src[i]);
-    };
-    const float* hp = h.data();
-    widen(mel, hp, n_mel);
-    widen(power, hp + n_mel, n_pow);
-    widen(log_power, hp + n_mel + n_pow, n_pow);
-    widen(mfcc, hp + n_mel + 2 * n_pow, n_cc);
-    widen(deltas, hp + n_mel + 2 * n_pow + n_cc, n_cc);
-    widen(delta_deltas, hp + n_mel + 2 * n_pow + 2 * n_cc, n_cc);
-    widen(energy, hp + n_mel + 2 * n_pow + 3 * n_cc, n_en);
-    return AUD_OK;
+    return melspec_mfcc_host_run(p, c->ws[0], AUD_F64, items, n_items, mel, power, log_power, mfcc, deltas, delta_deltas, energy);
 }
 
 int aud_gabor_batch_host(aud_plan* p, const double* mel, int n_items, int rows, int cols, int out_rank,

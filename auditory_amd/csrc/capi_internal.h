@@ -25,6 +25,11 @@ struct aud_ctx {
     // grow-only device workspaces for the _host entry points
     void* ws[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t ws_cap[4] = {0, 0, 0, 0};
+    // pinned host staging for the _host entry points' result copies (grow-only): device-to-host copies into pinned memory
+    // run at the link's rate and overlap with the widening of the previous chunk
+    void* pin = nullptr;
+    size_t pin_cap = 0;
+    hipEvent_t pin_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // RCCL (loaded lazily)
     void* rccl_lib = nullptr;
     void* comm = nullptr;
@@ -39,6 +44,14 @@ struct aud_ctx {
         std::vector<hipEvent_t> done;      // [n_ranks]
         hipEvent_t fork = nullptr;
     } gather;
+};
+
+// a signal resident on the device between calls (aud_signal_upload)
+struct aud_signal {
+    aud_ctx* ctx = nullptr;
+    void* d = nullptr;
+    int dtype = 0;
+    int64_t n = 0;
 };
 
 struct aud_plan {
@@ -67,11 +80,12 @@ struct aud_plan {
     void* d_gabor = nullptr;
     float* d_gabor32 = nullptr;  // float32 copy of the taps (the fused gabor phase of the item kernel, gabor_tile.h)
     // workgroup-per-item variant of the N = 400 kernel (kernels.h ItemArgs): launch shape, whether it exists for this plan,
-    // and plan option "item_kernel": -1 = automatic (aud_process_batch_dev runs it with the gabor phase fused in; the
-    // mel-only entry points keep the tile kernel), 0 = never, 1 = wherever it exists (mel-only calls too)
+    // and plan option "item_kernel": -1 / 0 = not used (the default: measured slower than the tile kernel at 256 items per
+    // launch), 1 = wherever it exists: aud_process_batch_dev becomes ONE launch with Convolve fused in, mel-only calls too
     aud::ItemArgs itm{};
     bool has_item = false;
     int item_opt = -1;
+    int gabor_opt = 0;  // plan option "gabor_kernel" (kernels.h GaborArgs::mode)
     void* d_dct = nullptr;  // [mfcc_coefs][nf] DCT-I rows
     unsigned long long stamps = 0;  // diagnostic builds (-DAUD_STAMPS): device buffer for the phase stamps
     const char* family = "generic";
@@ -134,6 +148,65 @@ inline int ensure_ws(aud_ctx* c, int slot, size_t bytes) {
     const size_t cap = bytes + bytes / 4 + 4096;
     AUD_HIP(c, hipMalloc(&c->ws[slot], cap));
     c->ws_cap[slot] = cap;
+    return AUD_OK;
+}
+
+inline int ensure_pin(aud_ctx* c, size_t bytes) {
+    if (c->pin_cap >= bytes) return AUD_OK;
+    if (c->pin) {
+        AUD_HIP(c, hipHostFree(c->pin));
+        c->pin = nullptr;
+        c->pin_cap = 0;
+    }
+    const size_t cap = bytes + bytes / 4 + 4096;
+    AUD_HIP(c, hipHostMalloc(&c->pin, cap, hipHostMallocDefault));
+    c->pin_cap = cap;
+    for (auto& e : c->pin_ev)
+        if (!e) AUD_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return AUD_OK;
+}
+
+// Device float32 results -> the caller's float64 tensors: up to four chunks copied into pinned staging back to back on the
+// context's stream, each widened by this thread as soon as ITS copy has landed, while the later ones are still in flight.
+// `parts`: destination (null: skipped), element count, in device order starting at d_src.
+struct WidenPart {
+    double* dst;
+    size_t n;
+};
+inline int fetch_widened(aud_ctx* c, const float* d_src, const WidenPart* parts, int n_parts) {
+    size_t total = 0;
+    for (int i = 0; i < n_parts; ++i) total += parts[i].n;
+    if (total == 0) return AUD_OK;
+    int rc = ensure_pin(c, total * 4);
+    if (rc != AUD_OK) return rc;
+    float* h = static_cast<float*>(c->pin);
+    const int chunks = total >= (size_t(1) << 18) ? 4 : 1;
+    const size_t per = (total + chunks - 1) / chunks;
+    for (int k = 0; k < chunks; ++k) {
+        const size_t lo = size_t(k) * per, hi = std::min(total, lo + per);
+        if (hi > lo) AUD_HIP(c, hipMemcpyAsync(h + lo, d_src + lo, (hi - lo) * 4, hipMemcpyDeviceToHost, c->stream));
+        AUD_HIP(c, hipEventRecord(c->pin_ev[k], c->stream));
+    }
+    size_t part_lo = 0;
+    int k_done = -1;
+    for (int i = 0; i < n_parts; ++i) {
+        const size_t part_hi = part_lo + parts[i].n;
+        if (parts[i].dst) {
+            size_t pos = part_lo;
+            while (pos < part_hi) {
+                const int k = int(pos / per);
+                if (k > k_done) {
+                    AUD_HIP(c, hipEventSynchronize(c->pin_ev[k]));
+                    k_done = k;
+                }
+                const size_t end = std::min(part_hi, size_t(k + 1) * per);
+                double* dst = parts[i].dst + (pos - part_lo);
+                for (size_t q = pos; q < end; ++q) dst[q - pos] = double(h[q]);
+                pos = end;
+            }
+        }
+        part_lo = part_hi;
+    }
     return AUD_OK;
 }
 

@@ -692,7 +692,7 @@ template <typename TT, int FPW, int MAXS, bool COMPACT = false, bool FUSE = fals
 __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const WaveArgs& e, const float* P, int Hp,
                                                   const unsigned char* smem, int sc, const aud_item& it,
                                                   int item, int t0, int lane, const int* exps = nullptr,
-                                                  float* mel_lds = nullptr) {
+                                                  float* mel_lds = nullptr, float* stash = nullptr, int stash_i = 0) {
     wave_spectrum_outputs<TT, FPW, FUSE>(a, P, Hp, exps, sc, it, item, t0, lane);
     // 64 is not a multiple of FPW = 6: lanes 60..63 have no filter group; they run group n_groups - 1 again and store nothing
     const int T = a.T;
@@ -772,7 +772,15 @@ __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const Wa
                 res = float(val);
                 wide = TT(val);
             }
-            if (col_on && flt != 0xFFFF) mel_col[size_t(flt) * T] = live ? res : 0.f;  // MelFBankSegment[item][flt][sstep]
+            if constexpr (COMPACT) {
+                // one frame per wave (w64x16): a frame's values would be n_filters 4-byte stores into as many cache lines; with a
+                // stash the wave parks them in LDS, [slot][lane][4 frames], and writes 16-byte [filter][4 steps] pieces behind
+                // its fourth frame (wave_mel_flush4)
+                if (stash) stash[(k * 64 + lane) * 4 + stash_i] = live ? res : 0.f;
+                else if (col_on && flt != 0xFFFF) mel_col[size_t(flt) * T] = live ? res : 0.f;
+            } else {
+                if (col_on && flt != 0xFFFF) mel_col[size_t(flt) * T] = live ? res : 0.f;  // MelFBankSegment[item][flt][sstep]
+            }
             if constexpr (TOLDS) {
                 const float kept = live ? res : 0.f;
                 if (col_on && flt != 0xFFFF) mel_lds[flt * T + sstep] = kept != kept ? 0.5f : kept;
@@ -817,6 +825,24 @@ __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const Wa
                 if (lane < TASKS && s2 < T && c < a.n_coefs) out[size_t(c) * T + s2] = tot;
                 wave_lds_fence();
             }
+        }
+    }
+}
+
+// The stash of a one-frame-per-wave kernel after four consecutive steps t0 .. t0 + 3 of ONE item (t0 a multiple of 4, T a
+// multiple of 4, the mel tensor 16-byte aligned: the caller checks): MelFBankSegment[item][flt][t0 .. t0 + 3] as one 16-byte
+// store per filter.
+template <int MAXS>
+__device__ __forceinline__ void wave_mel_flush4(const MelspecArgs& a, const WaveArgs& e, const unsigned char* smem, const float* stash,
+                                                int item, int t0, int lane) {
+    const unsigned* recs = reinterpret_cast<const unsigned*>(smem + e.slots_off) + lane * e.n_slots * 2;
+    float* base = a.mel + size_t(item) * a.nf * a.T + t0;
+#pragma unroll
+    for (int k = 0; k < MAXS; ++k) {
+        if (k < e.n_slots) {  // wave-uniform
+            const int flt = int(recs[2 * k] >> 16);
+            const float4 v = *reinterpret_cast<const float4*>(stash + (k * 64 + lane) * 4);
+            if (flt != 0xFFFF) *reinterpret_cast<float4*>(base + size_t(flt) * a.T) = v;
         }
     }
 }

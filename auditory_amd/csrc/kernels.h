@@ -134,7 +134,8 @@ __device__ __forceinline__ unsigned tile_div(const MelspecArgs& a, unsigned n) {
 struct GaborArgs {
     const float* mel;  // [n_items, rows, cols]
     int n_items, rows, cols;
-    const void* k;  // [nG, SY, SX] TT
+    const void* k;     // [nG, SY, SX] TT
+    const float* k32;  // the same taps as float32 (the LDS-staged kernel)
     int nG, SX, SY, stx, sty;
     double gain;
     int rank;  // 2 or 4
@@ -142,6 +143,7 @@ struct GaborArgs {
     int by_time;
     int nT, nF, t_max_strides;
     float* out;
+    int mode;  // plan option "gabor_kernel": 0 = automatic (LDS-staged where it fits), 1 = one thread per position (k_gabor)
 };
 
 // Arguments of the wave-autonomous kernels (melspec_wave.hip).  All read-only tables live in ONE device blob laid out
@@ -169,6 +171,7 @@ struct WaveArgs {
     unsigned lds_bytes;    // dynamic LDS of the launch
     int waves;             // waves per workgroup of the launch
     int wgs_per_cu;        // the runtime's occupancy answer (aud_plan_get_info)
+    int stash_off;         // w64x16: byte offset of the first wave's [n_slots][64][4] float32 output stash inside dynamic LDS; -1: none
     int dct_off;           // fused segment tail: TT [nf][kDctPitch], row f = column f of the DCT-I matrix (coefficient c at
                            // [c], zero beyond n_coefs); -1: the plan has no fused tail
 };
@@ -181,13 +184,16 @@ struct ItemArgs {
     int mel_off;         // byte offset of the item's [nf][T] float32 mel matrix inside dynamic LDS (NaN already read as 0.5)
     unsigned lds_bytes;  // dynamic LDS of the launch
     int wgs_per_cu;      // the runtime's occupancy answer
-    // gabor stage (rank-4 output [d0, d1, 2, nG], the shape aud_process_batch_dev asks for)
-    const float* k32;    // [nG][SY][SX] taps, float32 copy
+    // gabor stage (the fused kernel: rank-4 output [d0, d1, 2, nG], the shape aud_process_batch_dev asks for; the LDS-staged
+    // stand-alone kernel of gabor.hip: any output Convolve accepts)
+    const float* k32;    // [nG][SY][SX] taps, float32 copy (the kernels take it as a direct restrict parameter: scalar loads)
     int nG, SX, SY, stx, sty;
     double gain;
-    int d0, d1;          // pools
+    int rank;            // 2 or 4
+    int d0, d1, d2, d3;  // output shape (rank 2: d0, d1)
+    int by_time, t_max_strides;
     int nT, nF;          // iteration space (aud_gabor_iter_space)
-    float* out;          // [n_items, d0, d1, 2, nG]
+    float* out;          // [n_items, output shape]
 };
 constexpr int kDctCoefs = 13;  // coefficients the fused tail carries per lane (the reference's default NCoefs, mel.go:71)
 constexpr int kDctPitch = 14;  // row pitch of the table (16-byte rows in float64)

@@ -7,17 +7,22 @@
 // split pass); odd N (e.g. the prime 1103 that 25 ms @ 44.1 kHz produces) runs a full
 // N-point complex FFT.  Radix 2, 3, 4, 5, 8, 16 and 25 stages run whole butterflies in registers
 // (the host factorises M into as few of them as possible).  A length with any other prime factor
-// p takes Bluestein's chirp convolution (two power-of-two FFTs of length L >= 2 M - 1, one frame per
-// workgroup) where its two buffers fit LDS, and an O(p) per-output pass otherwise, so every N is
+// p takes Bluestein's chirp convolution (two FFTs of a 2-3-5-smooth length L >= 2 M - 1 per workgroup; on odd window
+// lengths they carry TWO real frames) where its two buffers fit LDS, and an O(p) per-output pass otherwise, so every N is
 // supported.  This is the universal path; the common sizes have faster specialised kernels.
 //
 // Reference semantics implemented here: sound/sndenv.go:438-478 (window extraction,
 // left zero pad, short-signal masking), dft/dft.go:53-85 (DFT of the raw window, power,
 // log(power+offset)), mel/mel.go:120-153 (triangle sums, log, renorm).
+#include <cstdlib>
+
 #include "device_common.h"
 
 namespace aud {
 namespace {
+
+__device__ __forceinline__ float scale2(float v, int e) { return ldexpf(v, e); }
+__device__ __forceinline__ double scale2(double v, int e) { return ldexp(v, e); }
 
 // one autosort Stockham stage of radix P: every thread takes whole butterflies
 template <typename TT, int P>
@@ -40,9 +45,9 @@ __device__ __forceinline__ void stage(const C2<TT>* src, C2<TT>* dst, const C2<T
     }
 }
 
-// the power-of-two FFT of the Bluestein route: radix 16 / 8 / 4 / 2 stages of one frame of length L, result in `src`
+// the FFT of the Bluestein route: radix 16 / 8 / 4 / 2 / 25 / 5 / 3 stages of one transform of length L (2-3-5-smooth), result in `src`
 template <typename TT>
-__device__ __forceinline__ void pow2_fft(C2<TT>*& src, C2<TT>*& dst, const MelspecArgs& a, int tid) {
+__device__ __forceinline__ void smooth_fft(C2<TT>*& src, C2<TT>*& dst, const MelspecArgs& a, int tid) {
     const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.bl_tw);
     const int L = a.bl_L;
     int ncur = L, s = 1;
@@ -52,6 +57,9 @@ __device__ __forceinline__ void pow2_fft(C2<TT>*& src, C2<TT>*& dst, const Melsp
             case 16: stage<TT, 16>(src, dst, tw, 1, L, L, 1, ncur, s, tid); break;
             case 8: stage<TT, 8>(src, dst, tw, 1, L, L, 1, ncur, s, tid); break;
             case 4: stage<TT, 4>(src, dst, tw, 1, L, L, 1, ncur, s, tid); break;
+            case 25: stage<TT, 25>(src, dst, tw, 1, L, L, 1, ncur, s, tid); break;
+            case 5: stage<TT, 5>(src, dst, tw, 1, L, L, 1, ncur, s, tid); break;
+            case 3: stage<TT, 3>(src, dst, tw, 1, L, L, 1, ncur, s, tid); break;
             default: stage<TT, 2>(src, dst, tw, 1, L, L, 1, ncur, s, tid); break;
         }
         __syncthreads();
@@ -78,6 +86,18 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
     const int t0 = (wg - item * tiles) * F;
     const aud_item it = a.items[item];
     const bool even = (a.ratio == 2);
+    // Bluestein route on an odd window length: TWO real frames ride one complex transform, z[n] = x_0[n] + i x_1[n]; they are
+    // separated behind it: X_0[k] = (Z[k] + conj Z[M - k]) / 2, X_1[k] = (Z[k] - conj Z[M - k]) / 2i
+    const bool pair = a.bl_L != 0 && !even && F == 2;
+    // ... each frame first divided by 2^(exponent of its largest sample), so that both components of z are O(1): what leaks
+    // from one frame into the other through rounding is then 2^-53 of the frame's OWN peak, as in a transform of its own (a
+    // quiet frame beside a loud one would otherwise inherit the loud one's floor); the powers are scaled back exactly, and a
+    // frame of exact zeros keeps an exactly zero spectrum (LogMin rule, mel.go:135-137)
+    int* pair_exp = reinterpret_cast<int*>(smem + 2 * size_t(a.bl_L ? a.bl_L : F * M) * sizeof(C2<TT>));  // [2]
+    if (pair) {
+        if (tid < 2) pair_exp[tid] = kNoSignal;
+        __syncthreads();
+    }
 
     // ---- gather the F windows (sndenv.go:455-478) -------------------------------------
     for (int i = tid; i < F * N; i += blockDim.x) {
@@ -90,6 +110,10 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
         if (live && pos >= 0) v = load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + pos * (it.sig_stride > 1 ? it.sig_stride : 1));
         if (even) {
             reinterpret_cast<TT*>(src)[size_t(f) * N + n] = v;  // z[n/2] = (x[2j], x[2j+1])
+        } else if (pair) {
+            reinterpret_cast<TT*>(src)[2 * size_t(n) + f] = v;   // frame 0: real parts, frame 1: imaginary parts
+            const int ex = amax_exponent<TT>(v < TT(0) ? -v : v);
+            if (ex != kNoSignal) atomicMax(pair_exp + f, ex);
         } else {
             src[size_t(f) * M + n] = {v, TT(0)};
         }
@@ -104,15 +128,20 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
         const int L = a.bl_L;
         const C2<TT>* __restrict__ chirp = static_cast<const C2<TT>*>(a.bl_chirp);
         const C2<TT>* __restrict__ bhat = static_cast<const C2<TT>*>(a.bl_bhat);
-        for (int i = tid; i < L; i += blockDim.x) src[i] = i < M ? cmul<TT>(src[i], chirp[i]) : C2<TT>{TT(0), TT(0)};
+        const int e0 = pair && pair_exp[0] != kNoSignal ? pair_exp[0] : 0, e1 = pair && pair_exp[1] != kNoSignal ? pair_exp[1] : 0;
+        for (int i = tid; i < L; i += blockDim.x) {
+            C2<TT> z = i < M ? src[i] : C2<TT>{TT(0), TT(0)};
+            if (pair) z = C2<TT>{scale2(z.x, -e0), scale2(z.y, -e1)};
+            src[i] = i < M ? cmul<TT>(z, chirp[i]) : z;
+        }
         __syncthreads();
-        pow2_fft<TT>(src, dst, a, tid);
+        smooth_fft<TT>(src, dst, a, tid);
         for (int i = tid; i < L; i += blockDim.x) {
             const C2<TT> c = cmul<TT>(src[i], bhat[i]);
             src[i] = C2<TT>{c.x, -c.y};
         }
         __syncthreads();
-        pow2_fft<TT>(src, dst, a, tid);
+        smooth_fft<TT>(src, dst, a, tid);
         for (int k = tid; k < M; k += blockDim.x) src[k] = cmul<TT>(chirp[k], C2<TT>{src[k].x, -src[k].y});
         __syncthreads();
     }
@@ -185,6 +214,19 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
             // -i * (dr + i di) = di - i dr
             re = er + (di * wk.x + dr * wk.y);
             im = ei + (di * wk.y - dr * wk.x);
+        } else if (pair) {
+            const C2<TT> A = src[k], B = src[k == 0 ? 0 : M - k];
+            if (f == 0) {
+                re = (A.x + B.x) * TT(0.5);
+                im = (A.y - B.y) * TT(0.5);
+            } else {
+                re = (A.y + B.y) * TT(0.5);
+                im = (B.x - A.x) * TT(0.5);
+            }
+            const int ex = pair_exp[f];
+            const TT p = ex == kNoSignal ? TT(0) : scale2(re * re + im * im, 2 * ex);
+            P[size_t(f) * Hp + k] = p;
+            continue;
         } else {
             re = Z[k].x;
             im = Z[k].y;
@@ -253,14 +295,45 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
 
 size_t melspec_generic_lds_bytes(int M, int F, int compute_dtype) {
     const size_t c = compute_dtype == AUD_F64 ? 16 : 8;
-    return size_t(2) * F * M * c;
+    return size_t(2) * F * M * c + 16;  // two complex buffers + the frame pair's two exponent words (Bluestein route)
 }
 
-// Bluestein: L = the power of two >= 2 M - 1 if two complex buffers of that length fit LDS, else 0
+// Bluestein: the transform length L >= 2 M - 1.  Any 2-3-5-smooth L the stage radices (16, 8, 4, 2, 25, 5, 3) cover will do;
+// the cheapest by (length x number of stages) whose two complex buffers fit LDS is taken -- for M = 1103 that is
+// 2304 = 16 x 16 x 3 x 3 (four stages over 2304 points, 74 KB in float64: two workgroups per CU) rather than the next
+// power of two 4096 (three stages over 4096 points, 128 KB: one).  0: no length fits.
 int melspec_generic_bluestein_L(int M, int compute_dtype) {
-    int L = 1;
-    while (L < 2 * M - 1) L <<= 1;
-    return melspec_generic_lds_bytes(L, 1, compute_dtype) <= 160 * 1024 ? L : 0;
+    const int64_t need = 2 * int64_t(M) - 1;
+#ifdef AUD_TUNE_BLUESTEIN  // (tuning builds only: pick the length by hand)
+    if (const char* env = getenv("AUD_BLUESTEIN_L")) {
+        const int forced = atoi(env);
+        if (forced >= need && melspec_generic_lds_bytes(forced, 1, compute_dtype) <= 160 * 1024) return forced;
+    }
+#endif
+    int best = 0;
+    double best_cost = 0.0;
+    for (int64_t p5 = 1; p5 <= 4 * need; p5 *= 5)
+        for (int64_t p3 = p5; p3 <= 4 * need; p3 *= 3)
+            for (int64_t L = p3; L <= 4 * need; L *= 2) {
+                if (L < need || L > (int64_t(1) << 20)) continue;
+                if (melspec_generic_lds_bytes(int(L), 1, compute_dtype) > 160 * 1024) continue;
+                double stages = 0;  // as capi.hip's factorize() will cut it; a radix-25 stage weighs 1.75 of the others
+                int64_t m = L;
+                for (int r : {16, 8, 4, 2, 25, 5, 3})
+                    while (m % r == 0) {
+                        m /= r;
+                        stages += r == 25 ? 1.75 : 1.0;
+                    }
+                // two workgroups per CU when the buffers fit twice.  Fitted to N = 1103 in float64 on an MI355X (us per 256
+                // segments of 14 frames): L 2304 101, 2560 106, 2400 120, 2500 122, 3072 191, 4096 194
+                const double fit2 = 2 * melspec_generic_lds_bytes(int(L), 1, compute_dtype) <= 160 * 1024 ? 0.55 : 1.0;
+                const double cost = double(L) * stages * fit2;
+                if (best == 0 || cost < best_cost) {
+                    best = int(L);
+                    best_cost = cost;
+                }
+            }
+    return best;
 }
 
 hipError_t melspec_generic_prepare(size_t lds_bytes) {

@@ -210,7 +210,7 @@ void k_melspec_w20(const aud_item* items, unsigned total, unsigned tiles, unsign
 template <typename TT, int SRC, int NW, int MAXS>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(sizeof(TT) == 8 ? 4 : 5, sizeof(TT) == 8 ? 4 : 5)))
 void k_melspec_w20_item(const aud_item* items, unsigned n_items, unsigned tiles, const void* blob_ptr, int blob_bytes,
-                        const MelspecArgs a, const WaveArgs e, const ItemArgs g) {
+                        const float* __restrict__ k32, const MelspecArgs a, const WaveArgs e, const ItemArgs g) {
     using L = w20::Layout<TT>;
     unsigned char* smem = dyn_lds();
     const int tid = int(threadIdx.x);
@@ -279,11 +279,9 @@ void k_melspec_w20_item(const aud_item* items, unsigned n_items, unsigned tiles,
     }
     AUD_STAMP(8);
     if (g.nG <= 0) return;  // uniform: the mel-only item kernel
-    __syncthreads();        // the item's mel matrix is complete
-#ifndef AUD_EXP_NOGAB
-    if (g.SX == 9 && g.SY == 9) gabor_from_lds<TT, 9, 9>(g, melL, a.T, item, wave, NW, lane);  // processspeech.go:226-253
-    else gabor_from_lds<TT, 0, 0>(g, melL, a.T, item, wave, NW, lane);
-#endif
+    __syncthreads();  // the item's mel matrix is complete
+    if (g.SX == 9 && g.SY == 9) gabor_from_lds<TT, 9, 9>(g, melL, k32, a.T, item, wave, NW, lane);  // processspeech.go:226-253
+    else gabor_from_lds<TT, 0, 0>(g, melL, k32, a.T, item, wave, NW, lane);
     AUD_STAMP_REAL(10);
     AUD_STAMP_FLUSH(a, unsigned(item) * NW + wave, lane);
 }

@@ -47,7 +47,7 @@ __device__ __forceinline__ void w64_issue(const MelspecArgs& a, int lane, int it
 // (the load phase was 38 % of a wave's life without it: profiles/r05e_stamps_n46.44_f64_b64.txt).
 template <typename TT, int SRC, int MAXS>
 __device__ __forceinline__ void w64_tile(const MelspecArgs& a, const WaveArgs& e, unsigned char* smem, unsigned char* region,
-                                         int lane_in, int item, int sstep, bool more, PairRaw<16>& raw) {
+                                         int lane_in, int item, int sstep, bool more, PairRaw<16>& raw, float* stash, int stash_i) {
     TT* xw = reinterpret_cast<TT*>(region);
     int lane = lane_in;  // opaque per frame: otherwise the compiler hoists what only depends on it out of the frame loop
     asm volatile("" : "+v"(lane));
@@ -213,7 +213,7 @@ __device__ __forceinline__ void w64_tile(const MelspecArgs& a, const WaveArgs& e
             const bool wrap = sstep + 1 == a.T;
             w64_issue<SRC>(a, lane, wrap ? item + 1 : item, wrap ? 0 : sstep + 1, raw);
         }
-    wave_mel_epilogue<TT, 1, MAXS, true>(a, e, P, w64::kHp, smem, sc, it, item, sstep, lane);
+    wave_mel_epilogue<TT, 1, MAXS, true>(a, e, P, w64::kHp, smem, sc, it, item, sstep, lane, nullptr, nullptr, stash, stash_i);
     AUD_STAMP(8);
     AUD_STAMP_REAL(10);
     AUD_STAMP_FLUSH(a, wt, lane);
@@ -242,14 +242,24 @@ __global__ __launch_bounds__(64 * NW) void k_melspec_w64(const aud_item*, unsign
     PairRaw<16> raw;
     if constexpr (sizeof(TT) == 8)
         if (wt0 < total) w64_issue<SRC>(a, lane, item, sstep, raw);
+    // the wave's four frames are steps t0 .. t0 + 3 of ONE item whenever T is a multiple of 4 (wt0 is): their mel values then
+    // leave as 16-byte [filter][4 steps] pieces from an LDS stash instead of 4 x n_filters scattered 4-byte stores
+    static_assert(w64::kFPW == 4, "wave_mel_flush4 writes four steps");
+    const bool quad = e.stash_off >= 0 && (a.T & 3) == 0 && wt0 + w64::kFPW <= total && (reinterpret_cast<uintptr_t>(a.mel) & 15) == 0;
+    float* stash = quad ? reinterpret_cast<float*>(smem + e.stash_off) + size_t(wave) * e.n_slots * 64 * 4 : nullptr;
+    const int item0 = item, t0 = sstep;
 #pragma unroll 1
     for (int i = 0; i < w64::kFPW; ++i) {
         if (wt0 + i >= total) break;
-        w64_tile<TT, SRC, MAXS>(a, e, smem, region, lane, item, sstep, i + 1 < w64::kFPW && wt0 + i + 1 < total, raw);
+        w64_tile<TT, SRC, MAXS>(a, e, smem, region, lane, item, sstep, i + 1 < w64::kFPW && wt0 + i + 1 < total, raw, stash, i);
         if (++sstep == a.T) {
             sstep = 0;
             ++item;
         }
+    }
+    if (quad) {
+        wave_lds_fence();
+        wave_mel_flush4<MAXS>(a, e, smem, stash, item0, t0, lane);
     }
 }
 

@@ -17,8 +17,10 @@ namespace aud {
 // item record's).
 typedef void (*wave_kernel_t)(const aud_item*, unsigned, unsigned, unsigned, int, const void*, int, unsigned, int, const MelspecArgs,
                               const WaveArgs);
-// the workgroup-per-item variant (melspec_w20.hip): items, n_items, tiles per item, blob, blob bytes, the three argument structs
-typedef void (*item_kernel_t)(const aud_item*, unsigned, unsigned, const void*, int, const MelspecArgs, const WaveArgs, const ItemArgs);
+// the workgroup-per-item variant (melspec_w20.hip): items, n_items, tiles per item, blob, blob bytes, the float32 gabor taps (a
+// direct restrict parameter: gabor_tile.h), the three argument structs
+typedef void (*item_kernel_t)(const aud_item*, unsigned, unsigned, const void*, int, const float*, const MelspecArgs, const WaveArgs,
+                              const ItemArgs);
 item_kernel_t w20_item_kernel(bool f64, int sig_dtype, int n_slots, int waves);  // waves: 5 or 6, else null
 __device__ __forceinline__ unsigned tile_div(unsigned mul, int shift, unsigned n) { return shift < 0 ? n : __umulhi(n, mul) >> shift; }
 wave_kernel_t w16_kernel(bool f64, int sig_dtype, int n_slots);

@@ -36,6 +36,28 @@ class Context:
             self.handle = None
 
 
+class Signal:
+    """aud_signal: a signal kept resident on the device between calls (SndEnv.Signal: ProcessSegment runs once per segment
+    on the same tensor).  samples: float64 (the Signal tensor), float32, or int16 PCM (normalised /0x7FFF on the device)."""
+
+    _DT = {np.dtype(np.float64): capi.AUD_F64, np.dtype(np.float32): capi.AUD_F32, np.dtype(np.int16): capi.AUD_I16}
+
+    def __init__(self, ctx, samples):
+        samples = np.ascontiguousarray(samples)
+        if samples.dtype not in self._DT:
+            raise TypeError("samples must be float64, float32 or int16")
+        self.ctx, self.n = ctx, int(samples.size)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.aud_signal_upload(ctx.handle, samples.ctypes.data_as(C.c_void_p), self._DT[samples.dtype],
+                                            samples.size, C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.aud_signal_destroy(self.handle)
+            self.handle = None
+
+
 def get_ctx(device=0):
     if device not in _CTX:
         _CTX[device] = Context(device)
@@ -140,6 +162,31 @@ class Plan:
         self.ctx.check(self.lib.aud_melspec_batch_host(self.handle, vp(sig), sig.size, vp(items), n,
                                                        vp(mel), vp(power), vp(logp)))
         return mel, power, logp
+
+    def melspec_sig(self, signal, items, want_power=False, want_log_power=False):
+        """melspec_host on a resident Signal (aud_melspec_batch_sig): only the items go up, only the results come back"""
+        items = np.ascontiguousarray(items, dtype=ITEM_DTYPE)
+        n = len(items)
+        mel = np.zeros((n, self.nf, self.T), np.float64)
+        power = np.zeros((n, self.H, self.T), np.float64) if want_power else None
+        logp = np.zeros((n, self.H, self.T), np.float64) if want_log_power else None
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        self.ctx.check(self.lib.aud_melspec_batch_sig(self.handle, signal.handle, vp(items), n, vp(mel), vp(power), vp(logp)))
+        return mel, power, logp
+
+    def melspec_mfcc_sig(self, signal, items, deltas=True):
+        """melspec_mfcc_host on a resident Signal (aud_melspec_mfcc_batch_sig)"""
+        items = np.ascontiguousarray(items, dtype=ITEM_DTYPE)
+        n, nc = len(items), self.mfcc_coefs
+        out = dict(mel=np.zeros((n, self.nf, self.T)), power=np.zeros((n, self.H, self.T)),
+                   log_power=np.zeros((n, self.H, self.T)), mfcc=np.zeros((n, nc, self.T)),
+                   deltas=np.zeros((n, nc, self.T)) if deltas else None,
+                   delta_deltas=np.zeros((n, nc, self.T)) if deltas else None, energy=np.zeros((n, self.T)))
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        self.ctx.check(self.lib.aud_melspec_mfcc_batch_sig(
+            self.handle, signal.handle, vp(items), n, vp(out["mel"]), vp(out["power"]), vp(out["log_power"]),
+            vp(out["mfcc"]), vp(out["deltas"]), vp(out["delta_deltas"]), vp(out["energy"])))
+        return out
 
     def melspec_mfcc_host(self, sig, items, deltas=True):
         """ProcessSegment with Mel.MFCC on, for all items at once.  Returns a dict of float64 arrays:

@@ -185,6 +185,7 @@ class SndEnv:
         self._device = device
         self._compute_dtype = compute_dtype
         self._plan = None
+        self._dev_sig = self._dev_sig_of = None
 
     def ToTensor(self):
         """sound/sndenv.go:297-300: Signal <- Sound.SoundToTensor()"""
@@ -248,6 +249,9 @@ class SndEnv:
         self.SegCnt = lib.aud_seg_cnt(len(self.Signal), p.SegmentSamples, p.StrideSamples,
                                       self.Channels)
         self._plan_key = None
+        if self._dev_sig is not None:      # (a resident copy belongs to the Signal it was taken from)
+            self._dev_sig.close()
+            self._dev_sig = None
         self._ensure_plan()
         return None
 
@@ -274,6 +278,19 @@ class SndEnv:
                                   self.GaborFilters.to_c() if has_g else None,
                                   self.GaborFilters.Filters if has_g else None, self._compute_dtype,
                                   mfcc_coefs=self.Mel.NCoefs if self.Mel.MFCC else 0)
+
+    def SignalToDevice(self):
+        """New, opt-in: keep a copy of self.Signal on the device (aud_signal_upload) so that ProcessSegment(s) send only the
+        work items and fetch only the results -- the reference's loop calls ProcessSegment once per segment on the same
+        Signal.  A SNAPSHOT: call it again whenever self.Signal changes; Init drops it."""
+        if self._dev_sig is not None:
+            self._dev_sig.close()
+        self._dev_sig = runtime.Signal(runtime.get_ctx(self._device), np.ascontiguousarray(self.Signal, np.float64))
+        self._dev_sig_of = self.Signal
+
+    def _resident(self):
+        ok = self._dev_sig is not None and self._dev_sig_of is self.Signal and self._dev_sig.n == len(self.Signal)
+        return self._dev_sig if ok else None
 
     def _item(self, segment, add):
         start0 = segment * self.Params.StrideSamples + MSecToSamples(add, self.SampleRate)
@@ -316,15 +333,18 @@ class SndEnv:
         its = [self._item(s, add) for s in segments]
         items = runtime.make_items([i[0] for i in its], [i[1] for i in its], [i[2] for i in its])
         self._ensure_plan()
+        res = self._resident()
         if self.Mel.MFCC and self.DFT.CompLogPow:
-            o = self._plan.melspec_mfcc_host(self.Signal, items, deltas=bool(self.Mel.Deltas))
+            o = (self._plan.melspec_mfcc_sig(res, items, deltas=bool(self.Mel.Deltas)) if res is not None else
+                 self._plan.melspec_mfcc_host(self.Signal, items, deltas=bool(self.Mel.Deltas)))
             m, pw, lp = o["mel"], o["power"], o["log_power"]
             self.MFCCSegment, self.Energy = o["mfcc"][-1], o["energy"][-1]
             if self.Mel.Deltas:
                 self.MFCCDeltas, self.MFCCDeltaDeltas = o["deltas"][-1], o["delta_deltas"][-1]
             self._last_mfcc = o
         else:
-            m, pw, lp = self._plan.melspec_host(self.Signal, items, True, bool(self.DFT.CompLogPow))
+            m, pw, lp = (self._plan.melspec_sig(res, items, True, bool(self.DFT.CompLogPow)) if res is not None else
+                         self._plan.melspec_host(self.Signal, items, True, bool(self.DFT.CompLogPow)))
         self.MelFBankSegment = m[-1]
         self.PowerSegment = pw[-1]
         if lp is not None:

@@ -522,3 +522,78 @@ func (p *Plan) MelSpecMFCC(sig []float64, items []Item, mel, power, logPower, mf
 		C.int(len(items)), ptr(mel), ptr(power), ptr(logPower), ptr(mfcc), ptr(deltas), ptr(deltaDeltas), ptr(energy))
 	return status(p.ctx, rc)
 }
+
+// Signal is a signal kept resident on the device between calls (aud_signal_upload): SndEnv.ProcessSegment runs once per
+// segment on the SAME Signal tensor (sound/sndenv.go:342-359), so the host-buffer calls above move the whole tensor over
+// the link again for every segment.  A snapshot: upload again after changing the samples.
+type Signal struct {
+	h   *C.aud_signal
+	ctx *Ctx
+}
+
+// UploadSignal copies SndEnv.Signal.Values to the device once.
+func (c *Ctx) UploadSignal(sig []float64) (*Signal, error) {
+	s := &Signal{ctx: c}
+	var p unsafe.Pointer
+	if len(sig) > 0 {
+		p = unsafe.Pointer(&sig[0])
+	}
+	if err := status(c, C.aud_signal_upload(c.h, p, C.AUD_F64, C.int64_t(len(sig)), &s.h)); err != nil {
+		return nil, err
+	}
+	return s, nil
+}
+
+// UploadPCM16 copies the WAV's own 16-bit samples (2 bytes per sample over the link); the device normalises them by
+// 0x7FFF exactly as Wave.SoundToTensor does in float64 (sound/sound.go:138).
+func (c *Ctx) UploadPCM16(pcm []int16) (*Signal, error) {
+	s := &Signal{ctx: c}
+	var p unsafe.Pointer
+	if len(pcm) > 0 {
+		p = unsafe.Pointer(&pcm[0])
+	}
+	if err := status(c, C.aud_signal_upload(c.h, p, C.AUD_I16, C.int64_t(len(pcm)), &s.h)); err != nil {
+		return nil, err
+	}
+	return s, nil
+}
+
+func (s *Signal) Close() {
+	if s != nil && s.h != nil {
+		C.aud_signal_destroy(s.h)
+		s.h = nil
+	}
+}
+
+func (s *Signal) Len() int { return int(C.aud_signal_len(s.h)) }
+
+// MelSpecSig is MelSpec on a resident signal: only the items go up, only the results come back.
+func (p *Plan) MelSpecSig(sig *Signal, items []Item, mel, power, logPower []float64) error {
+	if len(items) == 0 {
+		return nil
+	}
+	if len(mel) < len(items)*p.NFilters*p.Steps {
+		return errors.New("auditory_hip: mel buffer too small")
+	}
+	ptr := func(s []float64) *C.double {
+		if len(s) == 0 {
+			return nil
+		}
+		return (*C.double)(unsafe.Pointer(&s[0]))
+	}
+	rc := C.aud_melspec_batch_sig(p.h, sig.h, (*C.aud_item)(unsafe.Pointer(&items[0])), C.int(len(items)), ptr(mel), ptr(power), ptr(logPower))
+	return status(p.ctx, rc)
+}
+
+// MelSpecMFCCSig is MelSpecMFCC on a resident signal.
+func (p *Plan) MelSpecMFCCSig(sig *Signal, items []Item, mel, power, logPower, mfcc, deltas, deltaDeltas, energy []float64) error {
+	ptr := func(s []float64) *C.double {
+		if len(s) == 0 {
+			return nil
+		}
+		return (*C.double)(unsafe.Pointer(&s[0]))
+	}
+	rc := C.aud_melspec_mfcc_batch_sig(p.h, sig.h, (*C.aud_item)(unsafe.Pointer(&items[0])), C.int(len(items)), ptr(mel),
+		ptr(power), ptr(logPower), ptr(mfcc), ptr(deltas), ptr(deltaDeltas), ptr(energy))
+	return status(p.ctx, rc)
+}

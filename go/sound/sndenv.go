@@ -87,6 +87,7 @@ type SndEnv struct {
 	plan    *auditoryhip.Plan       // device plan of planKey's parameters (segmentPlan rebuilds it when they change)
 	planKey planKey
 	derived auditoryhip.SoundParams // what Init derived (sample counts, steps)
+	devSig  *auditoryhip.Signal     // SignalToDevice: the resident copy of Signal ProcessSegment reads (nil: upload per call)
 }
 
 // ParamDefaults: sound/sndenv.go:64-71.
@@ -174,6 +175,8 @@ func (se *SndEnv) Init() (err error) {
 		se.plan.Close()
 		se.plan = nil
 	}
+	se.devSig.Close() // (a resident copy belongs to the Signal it was taken from)
+	se.devSig = nil
 	se.derived = d
 	_, err = se.segmentPlan()
 	return err
@@ -225,6 +228,21 @@ func (se *SndEnv) segmentPlan() (*auditoryhip.Plan, error) {
 	return p, nil
 }
 
+// SignalToDevice (new, opt-in): keep a copy of se.Signal on the device so that ProcessSegment / ProcessSegments send only
+// the work items and fetch only the results -- the reference's loop calls ProcessSegment once per segment on the same
+// Signal, and without this every call moves the whole tensor over the link again.  The copy is a SNAPSHOT: call it after
+// ToTensor / Pad / AdjustForSilence, and again whenever se.Signal.Values changes; Init drops it.
+func (se *SndEnv) SignalToDevice() (err error) {
+	if se.ctx == nil {
+		if se.ctx, err = auditoryhip.Default(); err != nil {
+			return err
+		}
+	}
+	se.devSig.Close()
+	se.devSig, err = se.ctx.UploadSignal(se.Signal.Values)
+	return err
+}
+
 func (se *SndEnv) item(segment, add int) auditoryhip.Item {
 	start0 := segment*se.Params.StrideSamples + MSecToSamples(float64(add), se.Sound.SampleRate()) // sndenv.go:440-441
 	return auditoryhip.Item{SigOff: 0, SigLen: int32(len(se.Signal.Values)), Start0: int32(start0), SigStride: 1}
@@ -243,11 +261,21 @@ func (se *SndEnv) ProcessSegment(segment, add int) {
 		fmt.Println(err)
 		return
 	}
+	resident := se.devSig != nil && se.devSig.Len() == len(se.Signal.Values)
 	if se.Mel.MFCC {
-		err = plan.MelSpecMFCC(se.Signal.Values, items, se.MelFBankSegment.Values, se.PowerSegment.Values,
-			se.LogPowerSegment.Values, se.MFCCSegment.Values, se.MFCCDeltas.Values, se.MFCCDeltaDeltas.Values, se.Energy.Values)
+		if resident {
+			err = plan.MelSpecMFCCSig(se.devSig, items, se.MelFBankSegment.Values, se.PowerSegment.Values,
+				se.LogPowerSegment.Values, se.MFCCSegment.Values, se.MFCCDeltas.Values, se.MFCCDeltaDeltas.Values, se.Energy.Values)
+		} else {
+			err = plan.MelSpecMFCC(se.Signal.Values, items, se.MelFBankSegment.Values, se.PowerSegment.Values,
+				se.LogPowerSegment.Values, se.MFCCSegment.Values, se.MFCCDeltas.Values, se.MFCCDeltaDeltas.Values, se.Energy.Values)
+		}
 	} else {
-		err = plan.MelSpec(se.Signal.Values, items, se.MelFBankSegment.Values, se.PowerSegment.Values, se.LogPowerSegment.Values)
+		if resident {
+			err = plan.MelSpecSig(se.devSig, items, se.MelFBankSegment.Values, se.PowerSegment.Values, se.LogPowerSegment.Values)
+		} else {
+			err = plan.MelSpec(se.Signal.Values, items, se.MelFBankSegment.Values, se.PowerSegment.Values, se.LogPowerSegment.Values)
+		}
 		// Energy[s] = sum over f < SegmentSteps of LogPowerSegment row s (the reference's axis, SURVEY Q8)
 		T := se.Params.SegmentSteps
 		for s := 0; s < T; s++ {
@@ -272,6 +300,9 @@ func (se *SndEnv) ProcessSegments(first, n, add int, mel []float64) error {
 	plan, err := se.segmentPlan()
 	if err != nil {
 		return err
+	}
+	if se.devSig != nil && se.devSig.Len() == len(se.Signal.Values) {
+		return plan.MelSpecSig(se.devSig, items, mel, nil, nil)
 	}
 	return plan.MelSpec(se.Signal.Values, items, mel, nil, nil)
 }

@@ -274,6 +274,17 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
     int ComputeDtype = AUD_F32;
     PlanHandle plan;
     aud_plan_desc plan_desc_{};  // what `plan` was created from (ensure_plan)
+    aud_signal* dev_sig_ = nullptr;  // SignalToDevice: the resident copy of Signal ProcessSegment reads (null: upload per call)
+    ~SndEnv() { if (dev_sig_) aud_signal_destroy(dev_sig_); }
+
+    // New, opt-in: keep a copy of Signal on the device (aud_signal_upload) so that ProcessSegment sends only the work item and
+    // fetches only the results -- the reference's loop calls ProcessSegment once per segment on the same Signal.  A SNAPSHOT:
+    // call it again whenever Signal.Values changes; Init drops it.
+    bool SignalToDevice() {
+        if (ensure_ctx() != AUD_OK) return false;
+        if (dev_sig_) { aud_signal_destroy(dev_sig_); dev_sig_ = nullptr; }
+        return aud_signal_upload(default_ctx(), Signal.Values.data(), AUD_F64, int64_t(Signal.Values.size()), &dev_sig_) == AUD_OK;
+    }
 
     void ParamDefaults() {  // sndenv.go:64-71
         aud_sound_params c{};
@@ -330,6 +341,7 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
 
         if (ensure_ctx() != AUD_OK) return "no HIP device (libauditory_hip has no CPU fallback)";
         if (plan.p) { aud_plan_destroy(plan.p); plan.p = nullptr; }
+        if (dev_sig_) { aud_signal_destroy(dev_sig_); dev_sig_ = nullptr; }  // (belongs to the Signal it was taken from)
         return ensure_plan() ? "" : aud_last_error(default_ctx());
     }
 
@@ -374,16 +386,21 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
             std::printf("%s\n", aud_last_error(default_ctx()));
             return;
         }
-        if (Mel.MFCC && DFT.CompLogPow)  // the MFCC tail of the loop too: CepstrumDct, Energy, deltas (:360-432)
-            rc = aud_melspec_mfcc_batch_host(plan.p, Signal.Values.data(), int64_t(Signal.Values.size()), &it, 1,
-                                             MelFBankSegment.Values.data(), PowerSegment.Values.data(),
-                                             LogPowerSegment.Values.data(), MFCCSegment.Values.data(),
-                                             Mel.Deltas ? MFCCDeltas.Values.data() : nullptr,
-                                             Mel.Deltas ? MFCCDeltaDeltas.Values.data() : nullptr, Energy.Values.data());
-        else
-            rc = aud_melspec_batch_host(plan.p, Signal.Values.data(), int64_t(Signal.Values.size()), &it, 1,
-                                        MelFBankSegment.Values.data(), PowerSegment.Values.data(),
-                                        DFT.CompLogPow ? LogPowerSegment.Values.data() : nullptr);
+        const bool resident = dev_sig_ && aud_signal_len(dev_sig_) == int64_t(Signal.Values.size());
+        double* lp = DFT.CompLogPow ? LogPowerSegment.Values.data() : nullptr;
+        if (Mel.MFCC && DFT.CompLogPow) {  // the MFCC tail of the loop too: CepstrumDct, Energy, deltas (:360-432)
+            double* dl = Mel.Deltas ? MFCCDeltas.Values.data() : nullptr;
+            double* ddl = Mel.Deltas ? MFCCDeltaDeltas.Values.data() : nullptr;
+            rc = resident ? aud_melspec_mfcc_batch_sig(plan.p, dev_sig_, &it, 1, MelFBankSegment.Values.data(), PowerSegment.Values.data(),
+                                                       lp, MFCCSegment.Values.data(), dl, ddl, Energy.Values.data())
+                          : aud_melspec_mfcc_batch_host(plan.p, Signal.Values.data(), int64_t(Signal.Values.size()), &it, 1,
+                                                        MelFBankSegment.Values.data(), PowerSegment.Values.data(), lp,
+                                                        MFCCSegment.Values.data(), dl, ddl, Energy.Values.data());
+        } else {
+            rc = resident ? aud_melspec_batch_sig(plan.p, dev_sig_, &it, 1, MelFBankSegment.Values.data(), PowerSegment.Values.data(), lp)
+                          : aud_melspec_batch_host(plan.p, Signal.Values.data(), int64_t(Signal.Values.size()), &it, 1,
+                                                   MelFBankSegment.Values.data(), PowerSegment.Values.data(), lp);
+        }
         if (rc != AUD_OK) std::printf("%s\n", aud_last_error(default_ctx()));  // fmt.Println(err), sndenv.go:356
     }
 

@@ -299,6 +299,24 @@ int aud_melspec_batch_host(aud_plan* plan, const double* sig, int64_t sig_total,
                            const aud_item* items, int n_items, double* mel, double* power,
                            double* log_power);
 
+/* A signal kept RESIDENT on the device between calls.  SndEnv.ProcessSegment runs once per segment on the SAME Signal
+ * tensor (sound/sndenv.go:342-359: every step reads se.Signal.Values), and the host entry points above move the whole
+ * tensor over the link again on every call -- for 256 s of float64 audio that is 0.6 of the call's 0.9 ms.  Upload once
+ * (after ToTensor / Pad / AdjustForSilence, sound/sndenv.go:274-300), then call the _sig variants per segment or batch.
+ *   samples: host; sample_dtype AUD_F64 (the Signal tensor's values), AUD_F32, or AUD_I16: the WAV's own 16-bit PCM,
+ *   normalised /0x7FFF on the device exactly as sound.go:138 does in float64 (2 bytes per sample over the link).
+ * The copy is a snapshot: re-upload after changing the samples.  aud_signal_destroy waits for the context's stream. */
+typedef struct aud_signal aud_signal;
+int aud_signal_upload(aud_ctx* ctx, const void* samples, int sample_dtype, int64_t n_samples, aud_signal** out);
+int aud_signal_destroy(aud_signal* sig);
+int64_t aud_signal_len(const aud_signal* sig);
+/* aud_melspec_batch_host / aud_melspec_mfcc_batch_host on a resident signal (items index ITS samples) */
+int aud_melspec_batch_sig(aud_plan* plan, const aud_signal* sig, const aud_item* items, int n_items, double* mel,
+                          double* power, double* log_power);
+int aud_melspec_mfcc_batch_sig(aud_plan* plan, const aud_signal* sig, const aud_item* items, int n_items, double* mel,
+                               double* power, double* log_power, double* mfcc, double* deltas, double* delta_deltas,
+                               double* energy);
+
 /* aud_segment_batch_dev on host memory (SndEnv.ProcessSegment with Mel.MFCC on):
  * outputs float64; power / log_power / deltas / delta_deltas / energy may be NULL. */
 int aud_melspec_mfcc_batch_host(aud_plan* plan, const double* sig, int64_t sig_total, const aud_item* items,

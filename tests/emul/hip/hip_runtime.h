@@ -139,6 +139,10 @@ struct hipIpcMemHandle_t {
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinterpret_cast<hipEvent_t>(new char); return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete reinterpret_cast<char*>(e); return 0; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }  // (the emulator's launches and copies are synchronous)
+enum { hipHostMallocDefault = 0 };
+inline hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
+inline hipError_t hipHostFree(void* p) { return hipFree(p); }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 // (the handle also carries the exporting process: "device" memory here is a process's own heap, so a handle of ANOTHER
 // process cannot be mapped -- opening it fails the way a box without IPC support fails, instead of handing out a wild pointer)

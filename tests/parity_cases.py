@@ -352,7 +352,9 @@ def case_gabor_4d_and_2d_vs_oracle(orc, cdt):
     mel[1, 0, :] = np.nan                               # NaN -> 0.5
     mel[2] = 3.25                                       # constant -> fSum ~ 0
     mel = mel.astype(np.float32).astype(np.float64)     # what the GPU mel stage hands over
-    tol = 1e-5 if cdt == capi.AUD_F32 else 3e-7
+    # float64 plans: the default LDS-staged kernel sums a row of taps in float32 (gabor_tile.h): ~1e-6 of the all-float64
+    # sum; the one-thread-per-position kernel (option gabor_kernel = 1) sums everything in float64: 3e-7
+    tol = 1e-5 if cdt == capi.AUD_F32 else 2.5e-6
     # 4-D pooled output, processspeech default filter set
     k = orc.gabor_to_tensor(W.DEFAULT_GABOR_SPECS, 9, 9)
     plan = W.product_plan(oc, cdt, GABOR_DEFAULT)
@@ -363,6 +365,12 @@ def case_gabor_4d_and_2d_vs_oracle(orc, cdt):
     plan.gabor_host(mel, out)
     ok, msg = W.close_enough(out, ref, tol)
     assert ok, msg
+    plan.set_option("gabor_kernel", 1)
+    out1 = np.full((5, 11, 32, 2, 8), 7.0, np.float32)
+    plan.gabor_host(mel, out1)
+    ok, msg = W.close_enough(out1, ref, 1e-5 if cdt == capi.AUD_F32 else 3e-7)
+    assert ok, "per-position kernel: " + msg
+    plan.set_option("gabor_kernel", 0)
     # wider units than the kernel fills + fewer pools than the mel allows:
     # untouched cells keep their contents (the reference never zeroes rawOut)
     out = np.full((5, 9, 20, 3, 10), 7.0, np.float32)
@@ -421,6 +429,56 @@ def case_gabor_4d_and_2d_vs_oracle(orc, cdt):
     plan.close()
 
 
+def case_resident_signal(orc, cdt):
+    """aud_signal_upload + the _sig entry points: the same bits as the host-buffer entry points give, for the float64 Signal
+    tensor, and -- for int16 PCM / float32 samples -- as the host call gives on the float64 values those samples stand for
+    (sound.go:138: PCM / 0x7FFF); items outside the signal are AUD_EINVAL; a signal of another context is refused."""
+    oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
+    L = int(0.45 * oc.sr)
+    sig, pcm = synth.batch(37, 2, L, oc.sr)
+    segs = [(0, 0), (0, 2), (1, 1), (1, 3)]
+    items = make_items(oc, L, segs)
+    plan = W.product_plan(oc, cdt, mfcc_coefs=13)
+    try:
+        want = plan.melspec_host(sig.ravel(), items, True, True)
+        want_m = plan.melspec_mfcc_host(sig.ravel(), items)
+        s64 = runtime.Signal(plan.ctx, sig.ravel())
+        got = plan.melspec_sig(s64, items, True, True)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b, equal_nan=True)
+        got_m = plan.melspec_mfcc_sig(s64, items)
+        for key in want_m:
+            assert np.array_equal(got_m[key], want_m[key], equal_nan=True), key
+        mel_only = plan.melspec_sig(s64, items)
+        assert np.array_equal(mel_only[0], want[0], equal_nan=True) and mel_only[1] is None
+        # the WAV's own PCM: 2 bytes per sample up, normalised on the device; the float64 plan must give what the host call
+        # gives on pcm / 32767 computed in float64 (the reference's conversion)
+        as64 = pcm.astype(np.float64) / 32767.0
+        s16 = runtime.Signal(plan.ctx, pcm.ravel())
+        ref16 = plan.melspec_host(as64.ravel(), items, True, True)
+        got16 = plan.melspec_sig(s16, items, True, True)
+        if cdt == capi.AUD_F64:
+            for a, b in zip(got16, ref16):
+                assert np.array_equal(a, b, equal_nan=True)
+        else:
+            ok, msg = W.feature_close(got16[0], ref16[0], cdt, lin_axis=1)
+            assert ok, msg
+        s32 = runtime.Signal(plan.ctx, sig.ravel().astype(np.float32))
+        got32 = plan.melspec_sig(s32, items)
+        ref32 = plan.melspec_host(sig.ravel().astype(np.float32).astype(np.float64), items)
+        if cdt == capi.AUD_F64:
+            assert np.array_equal(got32[0], ref32[0], equal_nan=True)
+        bad = items.copy()
+        bad["sig_len"][0] = 2 * L + 1
+        with pytest.raises(capi.AuditoryError):
+            plan.melspec_sig(s64, bad)
+        assert plan.lib.aud_signal_len(s64.handle) == 2 * L
+        for s in (s64, s16, s32):
+            s.close()
+    finally:
+        plan.close()
+
+
 class HostMem:
     """'device' buffers of the CPU thread emulator: its device pointers are host pointers"""
     def put(self, a):
@@ -457,10 +515,11 @@ class TorchMem:
 
 
 def case_process_fused_vs_oracle(orc, cdt, mem, name="cfg2_16k_n400_nf40", n=3, pools=(11, 32)):
-    """aud_process_batch_dev where the plan has the workgroup-per-item kernel (N = 400): mel + agabor.Convolve as ONE launch,
-    the item's mel matrix held in LDS between the two (melspec_w20.hip k_melspec_w20_item, gabor_tile.h).  Against the oracle
-    (mel from the samples, Convolve on the ORACLE's float64 mel) and against the two-launch path of the same plan
-    (option item_kernel = 0); the mel tensor must be the tile kernel's bit for bit.  The last item ends early (masked final
+    """aud_process_batch_dev three ways on a plan that has the workgroup-per-item kernel (N = 400): mel + agabor.Convolve as ONE
+    launch, the item's mel matrix held in LDS between the two (option item_kernel = 1: melspec_w20.hip k_melspec_w20_item,
+    gabor_tile.h); the default two launches (tile kernel, then the LDS-staged k_gabor_lds); and the two launches with the
+    one-thread-per-position k_gabor.  All against the oracle (mel from the samples, Convolve on the ORACLE's float64 mel);
+    the mel tensor must be the tile kernel's bit for bit.  The last item ends early (masked final
     steps: zeros in the matrix the gabor phase reads), one item is silent (LogMin rows)."""
     oc = W.OracleCfg(orc, name)
     L = oc.full_len()
@@ -478,12 +537,16 @@ def case_process_fused_vs_oracle(orc, cdt, mem, name="cfg2_16k_n400_nf40", n=3, 
         assert plan.info("item_waves") in (5, 6) and 0 < plan.info("item_lds_bytes") <= 160 * 1024
         d_sig, d_items = mem.put(sig32.ravel()), mem.put(np.frombuffer(items.tobytes(), np.uint8).copy())
         outs = {}
-        for mode in (-1, 0):                      # fused (default), then the two launches
-            plan.set_option("item_kernel", mode)
+        # fused (one launch, option item_kernel = 1); the default two launches (tile kernel + LDS-staged gabor kernel); the two
+        # launches with the one-thread-per-position gabor kernel (all-float64 sums in float64 plans)
+        for mode, (ik, gk) in {"fused": (1, 0), "lds": (-1, 0), "per_position": (-1, 1)}.items():
+            plan.set_option("item_kernel", ik)
+            plan.set_option("gabor_kernel", gk)
             d_mel = mem.put(np.full((n, oc.nf, oc.T), 3.0, np.float32))
             d_gab = mem.put(np.full((n, py, px, 2, 8), 7.0, np.float32))
             plan.process_dev(mem.ptr(d_sig), capi.AUD_F32, mem.ptr(d_items), n, mem.ptr(d_mel), py, px, mem.ptr(d_gab), mem.stream)
             outs[mode] = (np.array(mem.get(d_mel)), np.array(mem.get(d_gab)))
+        plan.set_option("gabor_kernel", 0)
         # mel-only through the item kernel (option 1), with the optional spectrum outputs
         plan.set_option("item_kernel", 1)
         d_mel = mem.put(np.zeros((n, oc.nf, oc.T), np.float32))
@@ -498,22 +561,25 @@ def case_process_fused_vs_oracle(orc, cdt, mem, name="cfg2_16k_n400_nf40", n=3, 
         assert np.array_equal(item_pw, mem.get(d_pw2)) and np.array_equal(item_lp, mem.get(d_lp2))
     finally:
         plan.close()
-    (mel_f, gab_f), (mel_u, gab_u) = outs[-1], outs[0]
+    (mel_f, gab_f), (mel_u, gab_u), (mel_p, gab_p) = outs["fused"], outs["lds"], outs["per_position"]
     assert np.array_equal(mel_f, mel_u, equal_nan=True) and np.array_equal(mel_f, item_mel, equal_nan=True)
+    assert np.array_equal(mel_p, mel_u, equal_nan=True)
+    assert np.array_equal(gab_f, gab_u)            # the same device function on the same float32 matrix: bit for bit
     x64 = sig32.astype(np.float64)
-    tol_g = 1e-5 if cdt == capi.AUD_F32 else 1e-6
+    # float64 plans: the LDS-staged forms sum a row of taps in float32 (gabor_tile.h): ~1e-6; the per-position kernel 3e-7
+    tol_lds, tol_pp = (1e-5, 1e-5) if cdt == capi.AUD_F32 else (2.5e-6, 1e-6)
     for r in range(n):
         o = orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, x64[r, :lens[r]], segment=0)
         ok, msg = W.feature_close(mel_f[r], o["mel_seg"], cdt, lin_axis=0)
         assert ok, "mel item %d: %s" % (r, msg)
         ref = np.full((py, px, 2, 8), 7.0, np.float32)
         assert orc.gabor_convolve(o["mel_seg"], k, 3, 3, 2.0, ref) == 0
-        for what, got in (("fused", gab_f[r]), ("two launches", gab_u[r])):
+        for what, got, tol_g in (("fused", gab_f[r], tol_lds), ("two launches", gab_u[r], tol_lds), ("per position", gab_p[r], tol_pp)):
             ok, msg = W.close_enough(got, ref, tol_g)
             assert ok, "gabor (%s) item %d: %s" % (what, r, msg)
     assert o["done"] < oc.T and np.all(mel_f[-1][:, o["done"]:] == 0)
     assert np.all(mel_f[0] == -10.0)              # the silent item: LogMin everywhere (Q2)
-    return float(np.abs(gab_f - gab_u).max())
+    return float(np.abs(gab_f - gab_p).max())
 
 
 def case_sndenv_mirror_reads_like_the_reference(orc):
@@ -538,6 +604,9 @@ def case_sndenv_mirror_reads_like_the_reference(orc):
     assert se.Kwta.On and se.KwtaPool          # sndenv.go:189-190
     kw, kw_state = orc.kwta_defaults(), np.zeros((8 * 2, 2), np.float32)
     for seg in range(se.SegCnt):
+        if seg == 2:
+            se.SignalToDevice()                # from here on the segments run on the resident copy (same results)
+            assert se._resident() is not None
         se.ProcessSegment(seg, 0)
         tsr = se.ApplyGabor()
         assert tsr is se.GborKwta              # :492-494

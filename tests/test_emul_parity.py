@@ -175,8 +175,8 @@ def test_emul_plan_info(orc, emu):
         try:
             assert plan.kernel_name == fam
             assert plan.info("frames_per_wave") == fpw and plan.info("waves_per_wg") == waves
-            if fam == "generic":   # the prime window length takes the Bluestein route: L = the power of two >= 2 N - 1
-                assert plan.info("bluestein_L") == 4096 and plan.info("lds_bytes") == 0
+            if fam == "generic":   # the prime window length takes the Bluestein route: L = the cheapest 2-3-5-smooth length
+                assert plan.info("bluestein_L") == 2304 and plan.info("lds_bytes") == 0   # >= 2 N - 1 (16 x 16 x 3 x 3)
             else:
                 assert 0 < plan.info("lds_bytes") <= 160 * 1024 and plan.info("wgs_per_cu") >= 1
                 assert plan.info("bluestein_L") == 0
@@ -224,3 +224,14 @@ def test_emul_process_fused_item_kernel(orc, emu, cdt):
     windows wrap into the next mel row (flat offsets)"""
     PC.case_process_fused_vs_oracle(orc, cdt, PC.HostMem(), n=2)
     PC.case_process_fused_vs_oracle(orc, cdt, PC.HostMem(), name="sndenv_16k_n400_nf32", n=2, pools=(8, 4))
+
+
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_emul_resident_signal(orc, emu, cdt):
+    PC.case_resident_signal(orc, cdt)
+
+
+def test_emul_input_levels_bluestein_pair(orc, emu):
+    """N = 1103 (prime): two real frames ride one Bluestein transform, each behind its own power-of-two scale -- a silent
+    frame beside a loud one must keep its exactly-zero spectrum (LogMin rule), rows from 1e-150 to 2^60 their own floor"""
+    PC.case_input_levels(orc, "cfg1_44k_n1103_nf32", capi.AUD_F64, quick=True)

@@ -474,3 +474,8 @@ def test_two_ranks_one_gpu_bench_flow(torch_cuda, tmp_path):
     assert line["gathered_shape"] == [1024, 40, 104] and "direct pattern" in line["collective"]
     assert line["parity"]["pass"] and line["parity"]["n_past_1e-5"] == 0 and "every rank" in line["parity"]["checked"]
     assert line["no_collective"]["parity"]["pass"]
+
+
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_resident_signal(orc, torch_cuda, cdt):
+    PC.case_resident_signal(orc, cdt)

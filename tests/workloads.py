@@ -112,7 +112,12 @@ TAIL_FRAC = 5e-4    # f32 compute: share of elements allowed past TOL (at least 
 TAIL_TOL = 2e-4     # ... and the bound those must still meet
 
 
-TOL_F64_DERIVED = 1e-6  # float64 plans, tensors built on the stored float32 mel values (gabor sums 81 of them)
+# float64 plans, the gabor tensor: built on the float32-STORED mel values (81 of them per sum), by the default LDS-staged kernel
+# with float32 taps and float32 row sums added in float64 (gabor_tile.h): measured <= 1.7e-6 of the oracle's all-float64
+# Convolve on ITS float64 mel; the one-thread-per-position kernel (option gabor_kernel = 1, all-float64 sums) stays within
+# 4e-7 and is checked at 1e-6 (parity_cases.case_gabor_4d_and_2d_vs_oracle, case_process_fused_vs_oracle).  The north star's
+# criterion for this tensor is 1e-5.
+TOL_F64_DERIVED = 2.5e-6
 
 
 def feature_close(got, ref, compute_dtype, lin_axis=None, tol_f64=None):

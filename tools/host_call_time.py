@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
-"""Run ON THE GPU BOX: what the host-buffer entry point costs end to end (pageable float64 Go-tensor-like input copied in,
-kernel, float32 result copied out and widened) -- the PCIe-inclusive rate DESIGN.md 6 quotes.  It is never bench.py's `value`."""
+"""Run ON THE GPU BOX: what the host-facing entry points cost end to end for 256 utterances of 1 s (the PCIe-inclusive rates
+DESIGN.md 6 and BASELINE.md quote; never bench.py's `value`):
+  host      aud_melspec_batch_host: the float64 Signal tensor (33.9 MB, pageable) copied in on every call, kernel, float32
+            results back through pinned staging, widened into the caller's float64 tensors
+  sig_f64   aud_melspec_batch_sig on a signal uploaded once (aud_signal_upload): items up, results back
+  sig_i16   the same on int16 PCM uploaded once (8.5 MB, normalised on the device)
+  upload_*  the one-time uploads themselves"""
 import os
 import sys
 import time
@@ -9,16 +14,38 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
-import workloads as W
-from auditory_amd import capi, runtime, synth
-from oracle import oracle as orc
-oc=W.OracleCfg(orc,"cfg2_16k_n400_nf40")
-L=oc.full_len(); n=256
-sig,_=synth.batch(3,n,16000,oc.sr,row_len=L)
-plan=W.product_plan(oc,capi.AUD_F64)
-items=runtime.make_items(np.arange(n)*L,[L]*n,[0]*n)
-for _ in range(3): plan.melspec_host(sig.ravel(),items)
-t=time.perf_counter(); reps=20
-for _ in range(reps): plan.melspec_host(sig.ravel(),items)
-dt=(time.perf_counter()-t)/reps
-print("aud_melspec_batch_host, 256 utterances of 1 s (float64 host signal %.1f MB in, float64 mel %.1f MB out): %.2f ms per call = %.0f audio-s/s" % (sig.nbytes/1e6, n*40*104*8/1e6, dt*1e3, n/dt))
+import workloads as W  # noqa: E402
+from auditory_amd import capi, runtime, synth  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+oc = W.OracleCfg(orc, "cfg2_16k_n400_nf40")
+L = oc.full_len()
+n = 256
+sig, pcm = synth.batch(3, n, 16000, oc.sr, row_len=L)
+plan = W.product_plan(oc, capi.AUD_F64)
+items = runtime.make_items(np.arange(n) * L, [L] * n, [0] * n)
+flat = sig.ravel()
+
+
+def timed(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    t = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t) / reps
+
+
+res = {}
+res["host"] = timed(lambda: plan.melspec_host(flat, items))
+t0 = time.perf_counter(); s64 = runtime.Signal(plan.ctx, flat); res["upload_f64"] = time.perf_counter() - t0
+t0 = time.perf_counter(); s16 = runtime.Signal(plan.ctx, pcm.ravel()); res["upload_i16"] = time.perf_counter() - t0
+res["sig_f64"] = timed(lambda: plan.melspec_sig(s64, items))
+res["sig_i16"] = timed(lambda: plan.melspec_sig(s16, items))
+a, b = plan.melspec_host(flat, items)[0], plan.melspec_sig(s64, items)[0]
+assert np.array_equal(a, b)
+print("256 utterances of 1 s, float64 plan (w20x10), float64 mel %.1f MB out" % (n * 40 * 104 * 8 / 1e6))
+for k in ("host", "sig_f64", "sig_i16"):
+    print("  %-8s %.3f ms per call = %.0f audio-s/s" % (k, res[k] * 1e3, n / res[k]))
+print("  one-time uploads: float64 signal (%.1f MB) %.2f ms, int16 PCM (%.1f MB) %.2f ms"
+      % (flat.nbytes / 1e6, res["upload_f64"] * 1e3, pcm.nbytes / 1e6, res["upload_i16"] * 1e3))
