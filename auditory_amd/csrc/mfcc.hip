@@ -175,6 +175,8 @@ __global__ __launch_bounds__(kFusedThreads) void k_mfcc_fused(const MfccArgs a) 
 // workgroup per item.  The coefficients arrive UNROUNDED in the compute type and stay so in LDS: deltas and delta-deltas
 // are computed from them as the reference computes them from its float64 tensors (sndenv.go:378-431); float32 only at the
 // stores.  Energy[s] = the per-tile sums added in tile order (sndenv.go:360-366), MFCC row 0 <- Energy (:368-372).
+// (threads per item: 64 / 128 / 256 measured 29.3 / 28.9 / 28.8 us per whole-ProcessSegment step of 256 items on four streams --
+// the step is bound by the mel kernel's spectrum outputs, not by this launch: profiles/round4_segment_finish_threads.txt)
 constexpr int kFinishThreads = 256;
 
 template <typename TT>
