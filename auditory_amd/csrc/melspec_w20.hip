@@ -311,7 +311,6 @@ wave_kernel_t w20_kernel(bool f64, int sig_dtype, int n_slots) {
 item_kernel_t w20_item_kernel(bool f64, int sig_dtype, int n_slots, int waves) {
     const bool s8 = n_slots > 4;
     if (waves == 5) return f64 ? AUD_W20_ITEM_PICK(double, 5) : AUD_W20_ITEM_PICK(float, 5);
-    if (waves == 6) return f64 ? AUD_W20_ITEM_PICK(double, 6) : AUD_W20_ITEM_PICK(float, 6);
     return nullptr;
 }
 #undef AUD_W20_ITEM_PICK

@@ -113,26 +113,21 @@ hipError_t melspec_wave_prepare(int kind, int compute_dtype, WaveArgs* e) {
 }
 
 // ---- the workgroup-per-item variant (N = 400: k_melspec_w20_item) ---------------------------------------------------
-// LDS = the plan's blob + one region per wave + the item's [nf][T] float32 mel matrix.  Waves per workgroup: five where
-// three such workgroups fit a CU's 160 KB (15 waves per CU; 18 tiles of an item are four rounds of five), else six (two
-// workgroups, 12 waves per CU).
+// LDS = the plan's blob + one region per wave + the item's [nf][T] float32 mel matrix.  Five waves per workgroup: three such
+// workgroups fit a CU's 160 KB for the metric's table (15 waves per CU; the 18 tiles of an item are four rounds of five).
 bool melspec_item_finish(int kind, int compute_dtype, const WaveArgs& e, int nf, int T, ItemArgs* it) {
     if (kind != 3) return false;
+    constexpr int nw = 5;
     const size_t first = size_t(e.xch_off), region = wave_region_bytes(kind, compute_dtype == AUD_F64);
     const size_t mel = (size_t(nf) * size_t(T) * 4 + 15) & ~size_t(15);
-    for (int nw : {5, 6}) {
-        size_t total = first + size_t(nw) * region + mel;
-        total = std::max(total, size_t(64) * 64 * nw);
-        const size_t per_cu = nw == 5 ? 3 : 2;
-        if (total * per_cu > 160 * 1024 && nw == 5) continue;
-        if (total > 160 * 1024) return false;
-        it->waves = nw;
-        it->mel_off = int(first + size_t(nw) * region);
-        it->lds_bytes = unsigned(total);
-        it->wgs_per_cu = 0;
-        return true;
-    }
-    return false;
+    size_t total = first + size_t(nw) * region + mel;
+    total = std::max(total, size_t(64) * 64 * nw);
+    if (total > 160 * 1024) return false;
+    it->waves = nw;
+    it->mel_off = int(first + size_t(nw) * region);
+    it->lds_bytes = unsigned(total);
+    it->wgs_per_cu = 0;
+    return true;
 }
 
 hipError_t melspec_item_prepare(int kind, int compute_dtype, const WaveArgs& e, ItemArgs* it) {

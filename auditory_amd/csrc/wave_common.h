@@ -21,7 +21,7 @@ typedef void (*wave_kernel_t)(const aud_item*, unsigned, unsigned, unsigned, int
 // direct restrict parameter: gabor_tile.h), the three argument structs
 typedef void (*item_kernel_t)(const aud_item*, unsigned, unsigned, const void*, int, const float*, const MelspecArgs, const WaveArgs,
                               const ItemArgs);
-item_kernel_t w20_item_kernel(bool f64, int sig_dtype, int n_slots, int waves);  // waves: 5 or 6, else null
+item_kernel_t w20_item_kernel(bool f64, int sig_dtype, int n_slots, int waves);  // waves: 5, else null
 __device__ __forceinline__ unsigned tile_div(unsigned mul, int shift, unsigned n) { return shift < 0 ? n : __umulhi(n, mul) >> shift; }
 wave_kernel_t w16_kernel(bool f64, int sig_dtype, int n_slots);
 wave_kernel_t w20_kernel(bool f64, int sig_dtype, int n_slots);

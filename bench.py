@@ -523,9 +523,10 @@ def main():  # noqa: C901
             if rc != 0:
                 raise RuntimeError("hot path launch: %d %s" % (rc, lib.aud_last_error(plan.ctx.handle)))
 
-        # configs[3]: ONE launch where the plan has the workgroup-per-item kernel (the item's mel matrix stays in LDS between
-        # the frame loop and Convolve) and no option switched it off; else mel kernel + k_gabor
-        one_launch = bool(gabor and plan.info("item_kernel") == 1 and "item_kernel=0" not in args.option)
+        # configs[3]: two launches by default (tile kernel, then the LDS-staged k_gabor_lds); ONE launch with --option
+        # item_kernel=1 (workgroup-per-item kernel: the item's mel matrix stays in LDS between the frame loop and Convolve --
+        # measured slower at 256 items per launch)
+        one_launch = bool(gabor and plan.info("item_kernel") == 1 and "item_kernel=1" in args.option)
         res = timed_region(launch, n_streams, args.min_seconds if min_seconds is None else min_seconds,
                            nb * world * wl.dur_s)
         alg = nb * (ring.sample_bytes * wl.dur + 4 * wl.nf * wl.T)      # each sample read once + each mel value written once
@@ -533,7 +534,8 @@ def main():  # noqa: C901
             alg += nb * 4 * GABOR_POOLS[0] * GABOR_POOLS[1] * 2 * 8 + (0 if one_launch else nb * 4 * wl.nf * wl.T)
             res["launches_per_step"] = 1 if one_launch else 2
             res["gabor_path"] = ("fused: k_melspec_w20_item (workgroup per item, mel matrix in LDS, Convolve behind one barrier)"
-                                 if one_launch else "two launches: mel kernel, then k_gabor on the stored mel tensor")
+                                 if one_launch else "two launches: mel kernel (w20x10 tiles), then the LDS-staged gabor kernel "
+                                 "(k_gabor_lds: the item's mel matrix copied to LDS, float32 taps through the scalar path)")
         if full:   # Power + LogPower and the tail's four small tensors written; the unfused tail also re-reads mel + LogPower
             alg += nb * (2 * 4 * wl.H * wl.T + 4 * (3 * 13 + 1) * wl.T)
             if args.tail != "fused":

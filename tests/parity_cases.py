@@ -534,7 +534,7 @@ def case_process_fused_vs_oracle(orc, cdt, mem, name="cfg2_16k_n400_nf40", n=3, 
     py, px = pools
     try:
         assert plan.kernel_name == "w20x10" and plan.info("item_kernel") == 1
-        assert plan.info("item_waves") in (5, 6) and 0 < plan.info("item_lds_bytes") <= 160 * 1024
+        assert plan.info("item_waves") == 5 and 0 < plan.info("item_lds_bytes") <= 160 * 1024
         d_sig, d_items = mem.put(sig32.ravel()), mem.put(np.frombuffer(items.tobytes(), np.uint8).copy())
         outs = {}
         # fused (one launch, option item_kernel = 1); the default two launches (tile kernel + LDS-staged gabor kernel); the two
