@@ -461,8 +461,8 @@ def main():  # noqa: C901
         """parity of the TIMED outputs: the first streams of ring buffer 0, plus a few streams of two other buffers"""
         osd = OracleSide(wl)
         nb = ring.B
-        n0 = min(nb, 256 if wl.dur_s <= 1.0 else 8)                  # long streams: a smaller sample (the oracle is ~150 audio-s/s)
-        picks = [(0, np.arange(n0))] + [(r, np.arange(0, nb, max(1, nb // 16))[:16 if wl.dur_s <= 1.0 else 2])
+        n0 = min(nb, 256 if wl.dur_s <= 1.0 else 32)                 # long streams: a smaller sample (the oracle is ~150 audio-s/s)
+        picks = [(0, np.arange(n0))] + [(r, np.arange(0, nb, max(1, nb // 16))[:16 if wl.dur_s <= 1.0 else 4])
                                         for r in sorted({touched // 2, touched - 1} - {0})]
         got = np.concatenate([ring.mel[r].cpu().numpy()[idx] for r, idx in picks])
         if gout is None:

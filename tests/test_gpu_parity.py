@@ -380,8 +380,10 @@ def test_full_size_properties_metric_config_f64(orc, torch_cuda, B=256):
     _full_size_properties(orc, torch_cuda, "cfg2_16k_n400_nf40", B, 16000, capi.AUD_F64, 17, (0, 1, 2, 50, 103), 1e-6)
 
 
-def test_full_size_properties_cfg5(orc, torch_cuda, B=96):
-    """BASELINE configs[4] (44.1 kHz, 5 s streams, N = 2048, 128 mel with its NaN row) at 96 streams = 85 MB of input"""
+def test_full_size_properties_cfg5(orc, torch_cuda, B=320):
+    """BASELINE configs[4] (44.1 kHz, 5 s streams, N = 2048, 128 mel with its NaN row) at 320 streams = 282 MB of input -- past
+    the 256 MB Infinity Cache; the full 1280-stream batch (1.13 GB) runs in bench.py's also.cfg5 with 40 streams checked
+    against the oracle (the float64 host copies this test keeps for its Parseval and invariance checks bound it here)"""
     mel = _full_size_properties(orc, torch_cuda, "cfg5_44k_n2048_nf128", B, 5 * 44100, capi.AUD_F64, 31, (0, 2, 250, 503), 1e-6)
     assert np.isnan(mel[:, 0, :]).all()                 # filter 0 is a degenerate triangle (Q3)
 
