@@ -365,7 +365,7 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
         return AUD_OK;
     }
     if (key == "gabor_kernel") {  // 0 (default): the LDS-staged kernel where the item fits; 1: one thread per position
-        if (value < 0 || value > 4 || value == 2) return fail(c, AUD_EINVAL, "gabor_kernel: 0 (LDS-staged), 1 (one thread per position); 3, 4: timing experiments");
+        if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "gabor_kernel: 0 (LDS-staged where the item fits) or 1 (one thread per position)");
         p->gabor_opt = value;
         return AUD_OK;
     }

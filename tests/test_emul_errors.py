@@ -97,3 +97,36 @@ def test_per_step_and_comm_errors(orc, emu):
     assert lib.aud_comm_init(plan.ctx.handle, 2, 5, _vp(win)) == capi.AUD_EINVAL            # rank >= n_ranks
     assert lib.aud_comm_destroy(plan.ctx.handle) == 0
     plan.close()
+
+
+def test_resident_signal_argument_errors(orc, emu):
+    """aud_signal_* / the _sig entry points: misuse is a status code, nothing is written"""
+    oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
+    plan = W.product_plan(oc)
+    lib, h, ctx = plan.lib, plan.handle, plan.ctx.handle
+    sig = np.zeros(4000)
+    hs = C.c_void_p()
+    assert lib.aud_signal_upload(ctx, _vp(sig), 7, 4000, C.byref(hs)) == capi.AUD_EINVAL          # bad sample type
+    assert lib.aud_signal_upload(ctx, None, capi.AUD_F64, 4000, C.byref(hs)) == capi.AUD_EINVAL  # null samples
+    assert lib.aud_signal_upload(ctx, _vp(sig), capi.AUD_F64, -1, C.byref(hs)) == capi.AUD_EINVAL
+    assert lib.aud_signal_upload(None, _vp(sig), capi.AUD_F64, 4000, C.byref(hs)) == capi.AUD_EINVAL
+    assert not hs.value
+    assert lib.aud_signal_upload(ctx, _vp(sig), capi.AUD_F64, 4000, C.byref(hs)) == capi.AUD_OK and hs.value
+    assert lib.aud_signal_len(hs) == 4000 and lib.aud_signal_len(None) == -1
+    items = runtime.make_items([0], [4000], [0])
+    mel = np.full((1, 32, 14), 7.0)
+    assert lib.aud_melspec_batch_sig(h, None, _vp(items), 1, _vp(mel), None, None) == capi.AUD_EINVAL      # null signal
+    assert lib.aud_melspec_batch_sig(h, hs, None, 1, _vp(mel), None, None) == capi.AUD_EINVAL
+    assert lib.aud_melspec_batch_sig(h, hs, _vp(items), 1, None, None, None) == capi.AUD_EINVAL
+    bad = runtime.make_items([1], [4000], [0])                                                            # one sample past its end
+    assert lib.aud_melspec_batch_sig(h, hs, _vp(bad), 1, _vp(mel), None, None) == capi.AUD_EINVAL
+    assert b"outside" in lib.aud_last_error(ctx)
+    # the MFCC form on a plan created without mfcc_coefs
+    assert lib.aud_melspec_mfcc_batch_sig(h, hs, _vp(items), 1, _vp(mel), None, None, _vp(mel), None, None, None) == capi.AUD_EINVAL
+    assert (mel == 7.0).all()
+    assert lib.aud_melspec_batch_sig(h, hs, _vp(items), 0, None, None, None) == capi.AUD_OK               # empty batch
+    assert lib.aud_signal_destroy(hs) == capi.AUD_OK and lib.aud_signal_destroy(None) == capi.AUD_EINVAL
+    # an empty signal is a valid (useless) one
+    assert lib.aud_signal_upload(ctx, None, capi.AUD_I16, 0, C.byref(hs)) == capi.AUD_OK
+    assert lib.aud_signal_len(hs) == 0 and lib.aud_signal_destroy(hs) == capi.AUD_OK
+    plan.close()
