@@ -677,6 +677,12 @@ int aud_process_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
         AUD_HIP(c, aud::launch_melspec_item(p->wave_kind, a, p->wv, g, p->d.compute_dtype, static_cast<hipStream_t>(stream)));
         return AUD_OK;
     }
+    {  // the Convolve shape is checked BEFORE anything is launched: a rejected call writes nothing, mel included
+        aud::GaborArgs ga;
+        const int rc = gabor_geometry(p, n_items, p->d.mel.n_filters, p->d.segment_steps, 4, shape, 0, &ga);
+        if (rc != AUD_OK) return rc;
+        if (n_items > 0 && ga.nT > 0 && ga.nF > 0 && !gabor) return fail(c, AUD_EINVAL, "null buffer");
+    }
     int rc = aud_melspec_batch_dev(p, sig, sig_dtype, items, n_items, mel, nullptr, nullptr, stream);
     if (rc != AUD_OK) return rc;
     return aud_gabor_batch_dev(p, mel, n_items, p->d.mel.n_filters, p->d.segment_steps, 4, shape, 0,

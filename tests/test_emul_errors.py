@@ -130,3 +130,24 @@ def test_resident_signal_argument_errors(orc, emu):
     assert lib.aud_signal_upload(ctx, None, capi.AUD_I16, 0, C.byref(hs)) == capi.AUD_OK
     assert lib.aud_signal_len(hs) == 0 and lib.aud_signal_destroy(hs) == capi.AUD_OK
     plan.close()
+
+
+def test_process_batch_rejects_before_writing(orc, emu):
+    """aud_process_batch_dev with pools that reach past the mel matrix (the Go code would panic in Convolve):
+    AUD_EINVAL and NOTHING written -- the mel tensor included -- on the two-launch path and on the fused one"""
+    import parity_cases as PC
+    oc = W.OracleCfg(orc, "cfg2_16k_n400_nf40")
+    L = oc.full_len()
+    plan = W.product_plan(oc, capi.AUD_F64, PC.GABOR_DEFAULT)
+    sig = np.zeros(L, np.float32)
+    items = runtime.make_items([0], [L], [0])
+    try:
+        for ik in (-1, 1):
+            plan.set_option("item_kernel", ik)
+            mel = np.full((1, oc.nf, oc.T), 7.0, np.float32)
+            gab = np.full((1, 12, 40, 2, 8), 7.0, np.float32)
+            rc = plan.lib.aud_process_batch_dev(plan.handle, _vp(sig), capi.AUD_F32, _vp(items), 1, _vp(mel), 12, 40, _vp(gab), None)
+            assert rc == capi.AUD_EINVAL and b"reach past" in plan.lib.aud_last_error(plan.ctx.handle)
+            assert (mel == 7.0).all() and (gab == 7.0).all()
+    finally:
+        plan.close()
