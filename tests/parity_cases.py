@@ -479,6 +479,52 @@ def case_resident_signal(orc, cdt):
         plan.close()
 
 
+def case_gabor_fuzz(orc, seed, cdt):
+    """agabor.Convolve on a seeded random geometry -- matrix shape, filter size, strides, filter count (not a multiple of 4:
+    zero-padded quads), NaN cells, rank-4 pools of any width and rank-2 outputs in both orders -- through BOTH kernels
+    (LDS-staged default with its generic tap loop, one thread per position) against the oracle; shapes the Go code rejects
+    or panics on must be refused by both, with nothing written."""
+    rng = np.random.default_rng(1000 + seed)
+    rows, cols = int(rng.integers(8, 48)), int(rng.integers(10, 110))
+    sx, sy = int(rng.integers(2, min(10, cols) + 1)), int(rng.integers(2, min(10, rows) + 1))
+    stx, sty = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+    n_g = int(rng.integers(1, 11))
+    specs = [dict(wave_len=float(rng.uniform(1.5, 4.0)), orientation=float(rng.uniform(0, 180)), sigma_width=0.5, sigma_length=0.5,
+                  phase_offset=float(rng.choice([0.0, 1.5708])), circle_edge=int(rng.integers(0, 2))) for _ in range(n_g)]
+    gain = float(rng.uniform(0.5, 3.0))
+    oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
+    k = orc.gabor_to_tensor(specs, sx, sy)
+    assert k.shape[0] == n_g
+    mel = rng.normal(2.0, 2.5, size=(3, rows, cols))
+    mel[rng.integers(0, 3), rng.integers(0, rows), rng.integers(0, cols)] = np.nan
+    mel = mel.astype(np.float32).astype(np.float64)
+    nfy, nfx = max(0, (rows - sy) // sty) + 1, max(0, (cols - sx) // stx) + 1
+    outs = [np.full((3, int(rng.integers(1, nfy + 2)), int(rng.integers(1, nfx + 2)), int(rng.integers(2, 4)), n_g + int(rng.integers(0, 3))),
+                    7.0, np.float32)]
+    for by_time in (False, True):
+        outs.append((np.full((3, 2 * nfy + int(rng.integers(0, 2)), nfx * n_g + int(rng.integers(0, 3))), 7.0, np.float32), by_time))
+    plan = W.product_plan(oc, cdt, dict(size=(sx, sy), stride=(stx, sty), gain=gain, specs=specs))
+    try:
+        for gk, tol in ((0, 1e-5 if cdt == capi.AUD_F32 else W.TOL_F64_DERIVED), (1, 1e-5 if cdt == capi.AUD_F32 else 1e-6)):
+            plan.set_option("gabor_kernel", gk)
+            for o in outs:
+                tmpl, by_time = (o, False) if isinstance(o, np.ndarray) else o
+                ref, got = tmpl.copy(), tmpl.copy()
+                rcs = [orc.gabor_convolve(mel[i], k, stx, sty, gain, ref[i], by_time=by_time) for i in range(3)]
+                what = "seed %d kernel %d: mel %dx%d, taps %dx%d stride %d,%d, %d filters, out %s by_time %s" % (
+                    seed, gk, rows, cols, sy, sx, sty, stx, n_g, tmpl.shape[1:], by_time)
+                if rcs[0] != 0:
+                    with pytest.raises(capi.AuditoryError):
+                        plan.gabor_host(mel, got, by_time)
+                    assert (got == 7.0).all(), what
+                    continue
+                plan.gabor_host(mel, got, by_time)
+                ok, msg = W.close_enough(got, ref, tol)
+                assert ok, what + ": " + msg
+    finally:
+        plan.close()
+
+
 class HostMem:
     """'device' buffers of the CPU thread emulator: its device pointers are host pointers"""
     def put(self, a):

@@ -122,3 +122,13 @@ def test_random_kwta_params_vs_oracle(orc, seed):
                 assert cyc[i] == c
             if st is not None:
                 assert np.array_equal(st, st_o)
+
+
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_emul_gabor_geometry_fuzz(orc, cdt):
+    """16 seeded random Convolve geometries through both gabor kernels (the GPU tier runs 64)"""
+    import backend
+    import parity_cases as PC
+    with backend.emulated("plain"):
+        for seed in range(16):
+            PC.case_gabor_fuzz(orc, seed, cdt)

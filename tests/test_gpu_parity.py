@@ -481,3 +481,11 @@ def test_two_ranks_one_gpu_bench_flow(torch_cuda, tmp_path):
 @pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
 def test_resident_signal(orc, torch_cuda, cdt):
     PC.case_resident_signal(orc, cdt)
+
+
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_gabor_geometry_fuzz(orc, torch_cuda, cdt):
+    """64 seeded random Convolve geometries (matrix shape, taps, strides, filter counts off the quad grid, NaN cells, rank-4 pools
+    and rank-2 outputs in both orders, shapes the Go code rejects) through both gabor kernels against the oracle"""
+    for seed in range(64):
+        PC.case_gabor_fuzz(orc, seed, cdt)
