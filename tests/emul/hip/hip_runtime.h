@@ -99,6 +99,11 @@ inline emul_u32x4 __builtin_amdgcn_raw_buffer_load_b128(const __amdgpu_buffer_rs
 inline unsigned __builtin_amdgcn_raw_buffer_load_b32(const __amdgpu_buffer_rsrc_t& r, int voffset, int soffset, int) {
     return emul_buffer_load<unsigned>(r, voffset, soffset);
 }
+// stores: dropped when they do not lie wholly inside the descriptor's range, as the hardware drops them
+inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned v, const __amdgpu_buffer_rsrc_t& r, int voffset, int soffset, int) {
+    const uint64_t off = uint64_t(uint32_t(voffset)) + uint64_t(uint32_t(soffset));
+    if (off + 4 <= uint64_t(r.bytes)) std::memcpy(const_cast<unsigned char*>(r.base) + off, &v, 4);
+}
 inline unsigned short __builtin_amdgcn_raw_buffer_load_b16(const __amdgpu_buffer_rsrc_t& r, int voffset, int soffset, int) {
     return emul_buffer_load<unsigned short>(r, voffset, soffset);
 }
@@ -275,6 +280,11 @@ inline float __int_as_float(int v) {
     float f;
     std::memcpy(&f, &v, 4);
     return f;
+}
+inline unsigned __float_as_uint(float v) {
+    unsigned u;
+    std::memcpy(&u, &v, 4);
+    return u;
 }
 inline float __uint_as_float(unsigned v) {
     float f;
