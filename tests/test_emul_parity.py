@@ -235,3 +235,28 @@ def test_emul_input_levels_bluestein_pair(orc, emu):
     """N = 1103 (prime): two real frames ride one Bluestein transform, each behind its own power-of-two scale -- a silent
     frame beside a loud one must keep its exactly-zero spectrum (LogMin rule), rows from 1e-150 to 2^60 their own floor"""
     PC.case_input_levels(orc, "cfg1_44k_n1103_nf32", capi.AUD_F64, quick=True)
+
+
+def test_emul_host_results_chunked_copy(orc, emu):
+    """The host entry points fetch their float32 results in up to eight pinned chunks, widening each while the next is in
+    flight (capi_internal.h fetch_widened): a call large enough to be chunked (>= 2^18 values, three output tensors whose
+    boundaries fall inside chunks) must give exactly what per-item calls (one chunk each) give."""
+    import numpy as np
+    import workloads as W
+    from auditory_amd import synth
+    oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
+    n, L = 48, int(0.3 * oc.sr)
+    sig, _ = synth.batch(47, n, L, oc.sr)
+    segs = [(r, r % 2) for r in range(n)]
+    items = PC.make_items(oc, L, segs)
+    plan = W.product_plan(oc, capi.AUD_F64)
+    try:
+        assert n * (oc.nf + 2 * oc.H) * oc.T >= 1 << 18
+        mel, pw, lp = plan.melspec_host(sig.ravel(), items, True, True)
+        for i in (0, 1, 17, n - 1):
+            m1, p1, l1 = plan.melspec_host(sig.ravel(), items[i:i + 1], True, True)
+            assert np.array_equal(mel[i], m1[0]) and np.array_equal(pw[i], p1[0]) and np.array_equal(lp[i], l1[0]), i
+        mel2, pw2, _ = plan.melspec_host(sig.ravel(), items, True, False)      # a skipped part in the middle of the layout
+        assert np.array_equal(mel2, mel) and np.array_equal(pw2, pw)
+    finally:
+        plan.close()
