@@ -68,9 +68,10 @@ __device__ __forceinline__ void split_rows(float* P, const C2<TT>* tws, const C2
         split_pair<TT, SCALED>(P, tws[ra + 20 * c], kM, ra + 20 * c, za[c], b_first, sc);
         split_pair<TT, SCALED>(P, tws[rb + 20 * c], kM, rb + 20 * c, zb[c], b_second, sc);
     }
-    // lane 0's eleventh pair, k = 100 (row 0, column 5, paired with itself); the other lanes repeat their k = j pair
-    const int k11 = self ? 100 : ra;
-    split_pair<TT, SCALED>(P, tws[k11], kM, k11, self ? za[5] : za[0], self ? za[5] : zb[9], sc);
+    // bin 100 (row 0, column 5: lane 0) pairs with itself: X[100] = conj Z[100], so FOUR times its power is 4 |Z[100]|^2
+    // directly -- the same bits the split gives (its operands are 2 Re Z and -2 Im Z: an exact factor).  Every other lane
+    // parks the value of ITS column 5 in pad bin 203, which the next store zeroes (a wave's LDS stores execute in order)
+    P[self ? 100 : kH + 2] = scaled_power<SCALED>(TT(4) * mad(za[5].x, za[5].x, za[5].y * za[5].y), sc);
     P[kH + (j < 3 ? j : 0)] = 0.f;  // pad bins 201..203 of the last 4-bin chunk
 }
 }  // namespace w20
