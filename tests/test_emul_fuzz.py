@@ -19,62 +19,12 @@ WINDOWS = [4, 6, 8, 10, 16, 18, 25, 27, 30, 32, 49, 50, 64, 75, 96, 100, 121, 12
            514, 600, 625, 640, 729, 750, 800, 882, 1000, 1024]
 
 
-def _valid_mel(n_fft, sr, rng):
-    """pick (nf, lo, hi) whose triangles fit the [nf, nf+2] table (the reference's own envelope)"""
-    for _ in range(200):
-        nf = int(rng.integers(3, 48))
-        hi = float(rng.uniform(0.25, 0.5) * sr)
-        lo = float(rng.uniform(0, 0.1) * sr)
-        mp = melmod.Params()
-        mp.Defaults()
-        mp.FBank.NFilters, mp.FBank.LoHz, mp.FBank.HiHz = nf, lo, hi
-        try:
-            filt = mp.InitFilters(n_fft, sr)
-        except capi.AuditoryError:
-            continue
-        if mp.BinPts[-1] <= n_fft // 2 and (np.diff(mp.BinPts) >= 0).all():
-            return mp, filt
-    return None, None
-
-
 @pytest.mark.parametrize("seed", range(48))
 def test_random_configs_vs_oracle(orc, seed):
     import backend
-    rng = np.random.default_rng(1000 + seed)
-    N = int(WINDOWS[int(rng.integers(0, len(WINDOWS)))])
-    sr = int(rng.choice([8000, 11025, 16000, 22050]))
-    S = int(rng.integers(max(1, N // 8), N + 3))
-    T = int(rng.integers(1, 23))
-    border = int(rng.integers(0, 4))
-    cdt = capi.AUD_F64 if seed % 3 == 0 else capi.AUD_F32
-    mp, filt = _valid_mel(N, sr, rng)
-    if mp is None:
-        pytest.skip("no mel table fits the reference's [nf, nf+2] envelope for N=%d" % N)
-    nf = mp.FBank.NFilters
-    L = int(rng.integers(N, N + S * (T + 2)))
-    sig, _ = synth.batch(500 + seed, 2, L, sr)
-    # oracle with the same numbers
-    sp = orc.SndParams(sr, N, S, int(rng.integers(1, 3)) * S, T, border)
-    d, m = orc.dft_defaults(), orc.mel_defaults()
-    m.n_filters, m.lo_hz, m.hi_hz = nf, mp.FBank.LoHz, mp.FBank.HiHz
-    rc, bins, hz, ofilt = orc.mel_init_filters(m, N, sr)
-    assert rc == 0 and np.array_equal(bins, mp.BinPts)
-    segs = [(r, s) for r in range(2) for s in (0, 1)]
-    ref = [orc.process_segment(sp, d, m, bins, ofilt, sig[r], segment=s) for r, s in segs]
-    dftp = capi.DftParams()
-    capi.load().aud_dft_defaults(dftp)
+    import parity_cases as PC
     with backend.emulated("plain"):
-        plan = runtime.Plan(runtime.get_ctx(0), N, S, T, border, dftp, mp.FBank.to_c(), mp.BinPts, filt,
-                            compute_dtype=cdt)
-        items = runtime.make_items([r * L for r, s in segs], [L] * len(segs), [s * sp.stride_samples for r, s in segs])
-        mel, pw, lp = plan.melspec_host(sig.ravel(), items, True, True)
-        plan.close()
-    ref_mel = np.stack([o["mel_seg"] for o in ref])
-    ref_pw = np.stack([o["power_seg"] for o in ref])
-    ok, msg = W.feature_close(mel, ref_mel, cdt, lin_axis=1)
-    assert ok, "N=%d S=%d T=%d border=%d nf=%d: mel %s" % (N, S, T, border, nf, msg)
-    ok, msg = W.spectrum_close(pw, ref_pw, 4e-6 if cdt == capi.AUD_F32 else 3e-7)
-    assert ok, "N=%d S=%d T=%d: power %s" % (N, S, T, msg)
+        PC.case_random_any_n(orc, seed, WINDOWS)
 
 
 @pytest.mark.parametrize("N", [400, 512, 2048])

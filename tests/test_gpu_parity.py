@@ -489,3 +489,21 @@ def test_gabor_geometry_fuzz(orc, torch_cuda, cdt):
     and rank-2 outputs in both orders, shapes the Go code rejects) through both gabor kernels against the oracle"""
     for seed in range(64):
         PC.case_gabor_fuzz(orc, seed, cdt)
+
+
+# window lengths of every kind for the any-N claim on hardware: powers of two, 3/5-smooth, primes and prime x small (Bluestein:
+# 211, 514 = 2 x 257, 1009, 1103, 2027, 2206 = 2 x 1103), prime squares (169, 289: the O(p) radix pass), long smooth ones
+ANY_N = [6, 25, 49, 96, 121, 169, 200, 211, 243, 289, 343, 375, 441, 480, 514, 625, 729, 882, 1000, 1009, 1024, 1103, 1200, 1323,
+         1500, 1764, 2000, 2027, 2048, 2206, 2400]
+
+
+def test_random_any_n_configs(orc, torch_cuda):
+    """96 seeded random parameter sets (window length, step, segment, border, mel table, compute type) through whatever kernel
+    the plan selects -- the emulator tier runs 48 with lengths up to 1024"""
+    seen = set()
+    for seed in range(96):
+        try:
+            seen.add(PC.case_random_any_n(orc, seed, ANY_N).split()[5])
+        except pytest.skip.Exception:
+            pass
+    assert "generic" in seen
