@@ -34,6 +34,10 @@ def main():
             PC.case_mfcc_tail(orc, "cfg2_16k_n512_nf40", capi.AUD_F64)        # fused tail, float64 scratch in the spectrum rows
             PC.case_input_levels(orc, "cfg2_16k_n400_nf40", capi.AUD_F64, quick=True)   # scaled and unscaled splits
             PC.case_gabor_4d_and_2d_vs_oracle(orc, capi.AUD_F32)
+            # the workgroup-per-item kernel (tile loop, the item's mel matrix in LDS, Convolve behind its barrier), the LDS-staged
+            # and per-position gabor kernels, a resident signal
+            PC.case_process_fused_vs_oracle(orc, capi.AUD_F64, PC.HostMem(), name="sndenv_16k_n400_nf32", n=2, pools=(8, 4))
+            PC.case_resident_signal(orc, capi.AUD_F32)
             PC.case_kwta_quick(orc)
         else:
             PC.case_melspec_vs_oracle(orc, by_name[which], capi.AUD_F32)
