@@ -10,7 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libauditory_hip.so")
 
 AUD_OK, AUD_EINVAL, AUD_EHIP, AUD_ERCCL, AUD_ENOMEM, AUD_ESHORT = 0, 1, 2, 3, 4, 5
-AUD_F32, AUD_F64, AUD_I16 = 0, 1, 2
+AUD_F64, AUD_F32, AUD_I16 = 0, 1, 2   # AUD_F64 == 0: a zeroed PlanDesc is the float64 (conforming) plan
+AUD_FAST_F32 = AUD_F32                # compute_dtype opt-in: the float32 kernels (never a default)
 
 
 class SoundParams(C.Structure):

@@ -248,7 +248,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
             rc = upload_real(c, &p->d_bl_chirp, chirp.data(), chirp.size(), d->compute_dtype);
             if (rc == AUD_OK) rc = upload_real(c, &p->d_bl_bhat, bhat.data(), bhat.size(), d->compute_dtype);
             if (rc == AUD_OK) rc = upload_real(c, &p->d_bl_tw, twl.data(), twl.size(), d->compute_dtype);
-            const size_t lds = aud::melspec_generic_lds_bytes(L, 1, d->compute_dtype);
+            const size_t lds = aud::melspec_generic_lds_bytes(L, 1, d->compute_dtype, true);
             if (rc == AUD_OK && lds > 64u * 1024u && aud::melspec_generic_prepare(lds) != hipSuccess) {
                 (void)hipGetLastError();
                 rc = fail(c, AUD_EHIP, "the runtime refused the LDS size of the Bluestein route");
@@ -336,6 +336,7 @@ int aud_plan_get_info(const aud_plan* p, const char* name, int64_t* value) {
     else if (key == "waves_per_wg") *value = wave ? p->wv.waves : 4;
     else if (key == "wgs_per_cu") *value = wave ? p->wv.wgs_per_cu : 0;
     else if (key == "bluestein_L") *value = wave ? 0 : p->bl_L;
+    else if (key == "generic_frames_per_wg") *value = p->F_generic;  // frames a workgroup of the any-N kernel transforms at once
     else if (key == "item_kernel") *value = wave && p->has_item ? 1 : 0;        // the workgroup-per-item variant exists for this plan
     else if (key == "item_waves") *value = wave && p->has_item ? p->itm.waves : 0;
     else if (key == "item_lds_bytes") *value = wave && p->has_item ? int64_t(p->itm.lds_bytes) : 0;
@@ -364,8 +365,11 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
         p->item_opt = value;
         return AUD_OK;
     }
-    if (key == "gabor_kernel") {  // 0 (default): the LDS-staged kernel where the item fits; 1: one thread per position
-        if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "gabor_kernel: 0 (LDS-staged where the item fits) or 1 (one thread per position)");
+    // -1 (default): float64 plans take k_gabor (float64 taps, every multiply-add in float64: gabor.go:268-283 as written), float32
+    // plans the LDS-staged kernel where the item fits; 0: the LDS-staged kernel (float32 taps and row sums: for a float64 plan an
+    // explicit opt-in, ~1e-6 of the all-float64 sum and a sign that can differ where fSum ~ 0); 1: one thread per position
+    if (key == "gabor_kernel") {
+        if (value < -1 || value > 1) return fail(c, AUD_EINVAL, "gabor_kernel: -1 (auto), 0 (LDS-staged, float32 taps) or 1 (one thread per position)");
         p->gabor_opt = value;
         return AUD_OK;
     }

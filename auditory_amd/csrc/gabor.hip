@@ -172,7 +172,13 @@ hipError_t launch_gabor(const GaborArgs& a, int compute_dtype, hipStream_t st) {
     const int64_t total = int64_t(a.n_items) * a.nF * a.nT;
     if (total == 0) return hipSuccess;
     const size_t lds = gabor_lds_bytes(a.rows, a.cols, a.nG, a.SX, a.SY);
-    if (a.k32 && a.mode != 1 && lds <= 64 * 1024 && int64_t(a.rows) * a.cols < (int64_t(1) << 24)) {
+    // float64 plans default to k_gabor: float64 taps and float64 multiply-adds throughout, as FilterSet.Filters (etensor.Float64)
+    // and fSum (float64) are in the reference (gabor.go:66, :272-283).  The LDS-staged kernel rounds the taps to float32 and sums a
+    // row of them in float32 -- gabor taps cancel, so near fSum = 0 that can land a value in the other on / off channel than the
+    // reference does; it is the float32 plans' default and a float64 plan's explicit opt-in (mode 0).  Cost of the conforming
+    // choice beside the mel kernel: 15.3 against 15.1 us per 256 items (profiles/round4_cfg4_gabor_variants.txt).
+    const int mode = a.mode < 0 ? (compute_dtype == AUD_F64 ? 1 : 0) : a.mode;
+    if (a.k32 && mode != 1 && lds <= 64 * 1024 && int64_t(a.rows) * a.cols < (int64_t(1) << 24)) {
         ItemArgs g;
         std::memset(&g, 0, sizeof(g));
         g.k32 = a.k32;

@@ -143,7 +143,7 @@ struct GaborArgs {
     int by_time;
     int nT, nF, t_max_strides;
     float* out;
-    int mode;  // plan option "gabor_kernel": 0 = automatic (LDS-staged where it fits), 1 = one thread per position (k_gabor)
+    int mode;  // plan option "gabor_kernel": -1 = float64 plans k_gabor, float32 plans LDS-staged; 0 = LDS-staged where it fits; 1 = k_gabor
 };
 
 // Arguments of the wave-autonomous kernels (melspec_wave.hip).  All read-only tables live in ONE device blob laid out
@@ -243,7 +243,7 @@ hipError_t launch_segment_finish(const SegmentFinishArgs& a, int compute_dtype, 
 hipError_t launch_mfcc_dct(const MfccArgs& a, int compute_dtype, hipStream_t st);
 
 // generic any-N kernel (Stockham in LDS, radix 2/4 + per-output generic radix)
-size_t melspec_generic_lds_bytes(int M, int F, int compute_dtype);
+size_t melspec_generic_lds_bytes(int M, int F, int compute_dtype, bool bluestein);
 int melspec_generic_pick_F(int M, int compute_dtype);
 int melspec_generic_bluestein_L(int M, int compute_dtype);
 hipError_t melspec_generic_prepare(size_t lds_bytes);

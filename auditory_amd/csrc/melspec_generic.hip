@@ -21,6 +21,7 @@
 namespace aud {
 namespace {
 
+constexpr int kNonFinite = 1 << 20;  // pair route: sentinel exponent of a frame that holds an Inf / NaN sample
 __device__ __forceinline__ float scale2(float v, int e) { return ldexpf(v, e); }
 __device__ __forceinline__ double scale2(double v, int e) { return ldexp(v, e); }
 
@@ -112,7 +113,9 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
             reinterpret_cast<TT*>(src)[size_t(f) * N + n] = v;  // z[n/2] = (x[2j], x[2j+1])
         } else if (pair) {
             reinterpret_cast<TT*>(src)[2 * size_t(n) + f] = v;   // frame 0: real parts, frame 1: imaginary parts
-            const int ex = amax_exponent<TT>(v < TT(0) ? -v : v);
+            // an Inf / NaN sample takes its frame OUT of the pair (sentinel exponent): the frame's bins are NaN, as a transform of
+            // its own would leave them, and its partner -- an independent frame in the reference (dft.go:42-50) -- runs alone
+            const int ex = (v - v == TT(0)) ? amax_exponent<TT>(v < TT(0) ? -v : v) : kNonFinite;
             if (ex != kNoSignal) atomicMax(pair_exp + f, ex);
         } else {
             src[size_t(f) * M + n] = {v, TT(0)};
@@ -128,10 +131,11 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
         const int L = a.bl_L;
         const C2<TT>* __restrict__ chirp = static_cast<const C2<TT>*>(a.bl_chirp);
         const C2<TT>* __restrict__ bhat = static_cast<const C2<TT>*>(a.bl_bhat);
-        const int e0 = pair && pair_exp[0] != kNoSignal ? pair_exp[0] : 0, e1 = pair && pair_exp[1] != kNoSignal ? pair_exp[1] : 0;
+        const int x0 = pair ? pair_exp[0] : 0, x1 = pair ? pair_exp[1] : 0;
+        const int e0 = (x0 == kNoSignal || x0 == kNonFinite) ? 0 : x0, e1 = (x1 == kNoSignal || x1 == kNonFinite) ? 0 : x1;
         for (int i = tid; i < L; i += blockDim.x) {
             C2<TT> z = i < M ? src[i] : C2<TT>{TT(0), TT(0)};
-            if (pair) z = C2<TT>{scale2(z.x, -e0), scale2(z.y, -e1)};
+            if (pair) z = C2<TT>{x0 == kNonFinite ? TT(0) : scale2(z.x, -e0), x1 == kNonFinite ? TT(0) : scale2(z.y, -e1)};
             src[i] = i < M ? cmul<TT>(z, chirp[i]) : z;
         }
         __syncthreads();
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
                 im = (B.x - A.x) * TT(0.5);
             }
             const int ex = pair_exp[f];
-            const TT p = ex == kNoSignal ? TT(0) : scale2(re * re + im * im, 2 * ex);
+            const TT p = ex == kNoSignal ? TT(0) : ex == kNonFinite ? TT(__builtin_nan("")) : scale2(re * re + im * im, 2 * ex);
             P[size_t(f) * Hp + k] = p;
             continue;
         } else {
@@ -293,9 +297,11 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
 
 }  // namespace
 
-size_t melspec_generic_lds_bytes(int M, int F, int compute_dtype) {
+size_t melspec_generic_lds_bytes(int M, int F, int compute_dtype, bool bluestein) {
     const size_t c = compute_dtype == AUD_F64 ? 16 : 8;
-    return size_t(2) * F * M * c + 16;  // two complex buffers + the frame pair's two exponent words (Bluestein route)
+    // two complex buffers; the Bluestein route (M = its transform length L, F = 1) adds the frame pair's two exponent words.
+    // Plain Stockham plans stay at exactly 2 F M c: M = 2048 in float64 / 4096 in float32 fill the 64 KB to the byte.
+    return size_t(2) * F * M * c + (bluestein ? 16 : 0);
 }
 
 // Bluestein: the transform length L >= 2 M - 1.  Any 2-3-5-smooth L the stage radices (16, 8, 4, 2, 25, 5, 3) cover will do;
@@ -307,7 +313,7 @@ int melspec_generic_bluestein_L(int M, int compute_dtype) {
 #ifdef AUD_TUNE_BLUESTEIN  // (tuning builds only: pick the length by hand)
     if (const char* env = getenv("AUD_BLUESTEIN_L")) {
         const int forced = atoi(env);
-        if (forced >= need && melspec_generic_lds_bytes(forced, 1, compute_dtype) <= 160 * 1024) return forced;
+        if (forced >= need && melspec_generic_lds_bytes(forced, 1, compute_dtype, true) <= 160 * 1024) return forced;
     }
 #endif
     int best = 0;
@@ -316,7 +322,7 @@ int melspec_generic_bluestein_L(int M, int compute_dtype) {
         for (int64_t p3 = p5; p3 <= 4 * need; p3 *= 3)
             for (int64_t L = p3; L <= 4 * need; L *= 2) {
                 if (L < need || L > (int64_t(1) << 20)) continue;
-                if (melspec_generic_lds_bytes(int(L), 1, compute_dtype) > 160 * 1024) continue;
+                if (melspec_generic_lds_bytes(int(L), 1, compute_dtype, true) > 160 * 1024) continue;
                 double stages = 0;  // as capi.hip's factorize() will cut it; a radix-25 stage weighs 1.75 of the others
                 int64_t m = L;
                 for (int r : {16, 8, 4, 2, 25, 5, 3})
@@ -326,7 +332,7 @@ int melspec_generic_bluestein_L(int M, int compute_dtype) {
                     }
                 // two workgroups per CU when the buffers fit twice.  Fitted to N = 1103 in float64 on an MI355X (us per 256
                 // segments of 14 frames): L 2304 101, 2560 106, 2400 120, 2500 122, 3072 191, 4096 194
-                const double fit2 = 2 * melspec_generic_lds_bytes(int(L), 1, compute_dtype) <= 160 * 1024 ? 0.55 : 1.0;
+                const double fit2 = 2 * melspec_generic_lds_bytes(int(L), 1, compute_dtype, true) <= 160 * 1024 ? 0.55 : 1.0;
                 const double cost = double(L) * stages * fit2;
                 if (best == 0 || cost < best_cost) {
                     best = int(L);
@@ -349,14 +355,14 @@ hipError_t melspec_generic_prepare(size_t lds_bytes) {
 
 int melspec_generic_pick_F(int M, int compute_dtype) {
     for (int F = 16; F >= 1; F >>= 1)
-        if (melspec_generic_lds_bytes(M, F, compute_dtype) <= 64 * 1024) return F;
+        if (melspec_generic_lds_bytes(M, F, compute_dtype, false) <= 64 * 1024) return F;
     return 0;
 }
 
 hipError_t launch_melspec_generic(const MelspecArgs& a, int compute_dtype, hipStream_t st) {
     const int tiles = (a.T + a.F - 1) / a.F;
     const dim3 grid(unsigned(a.n_items) * unsigned(tiles));
-    const size_t lds = a.bl_L ? melspec_generic_lds_bytes(a.bl_L, 1, compute_dtype) : melspec_generic_lds_bytes(a.M, a.F, compute_dtype);
+    const size_t lds = a.bl_L ? melspec_generic_lds_bytes(a.bl_L, 1, compute_dtype, true) : melspec_generic_lds_bytes(a.M, a.F, compute_dtype, false);
     if (compute_dtype == AUD_F64)
         hipLaunchKernelGGL(k_melspec_generic<double>, grid, dim3(256), lds, st, a);
     else

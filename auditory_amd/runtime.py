@@ -72,7 +72,7 @@ class Plan:
     """aud_plan: immutable tables (twiddles, mel triangles, gabor taps) resident on the device."""
 
     def __init__(self, ctx, win_samples, step_samples, segment_steps, border_steps, dft, fbank,
-                 bin_pts, mel_filters, gabor_set=None, gabor_filters=None, compute_dtype=capi.AUD_F32,
+                 bin_pts, mel_filters, gabor_set=None, gabor_filters=None, compute_dtype=capi.AUD_F64,
                  mfcc_coefs=0):
         self.ctx = ctx
         self.lib = ctx.lib

@@ -148,7 +148,7 @@ class Params:
 class SndEnv:
     """sound.SndEnv, sound/sndenv.go:73-182 (hot-path fields only)"""
 
-    def __init__(self, device=0, compute_dtype=capi.AUD_F32):
+    def __init__(self, device=0, compute_dtype=capi.AUD_F64):
         self.Params = Params()
         self.Sound = Wave()
         self.SampleRate = 0                 # se.Sound.SampleRate()

@@ -99,7 +99,7 @@ class Workload:
             fs.SizeX, fs.SizeY, fs.StrideX, fs.StrideY, fs.Gain = 9, 9, 3, 3, 2.0
             agabor.ToTensor([agabor.Filter(**s) for s in GABOR_SPECS], fs)
             gset, gk = fs.to_c(), fs.Filters
-        cdt = capi.AUD_F64 if compute == "f64" else capi.AUD_F32
+        cdt = capi.AUD_F64 if compute == "f64" else capi.AUD_FAST_F32
         return runtime.Plan(runtime.get_ctx(device), self.N, self.S, self.T, self.border, dftp, self.mp.FBank.to_c(),
                             self.mp.BinPts, self.filt, gset, gk, cdt, mfcc_coefs=mfcc)
 
@@ -181,6 +181,7 @@ def cpu_baseline(wl, pcm, target_s=12.0, max_threads=16, chunk=8):
         n = sum(ex.map(worker, range(cores)))
     dt = time.perf_counter() - t0
     return {"value": round(n * wl.dur_s / dt, 2), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+            "affinity_cores": avail, "box_cores_online": os.cpu_count(),   # threads used = min(affinity, 16): SURVEY 8d asks for the box's count
             "sample": "%d utterance passes over the first %d utterances of the bench ring (%s), oracle/auditory_oracle.c "
                       "float64, %d threads x %d calls x %d utterances, FFT plan cached per segment"
                       % (n, n_rows, wl.name, cores, calls, chunk),
@@ -382,7 +383,7 @@ def main():  # noqa: C901
             per_batch = nb * wl.L * (2 if args.sig_dtype == "i16" else 4)
             R = max(2, int(math.ceil(args.ring_mb * 1e6 / per_batch)))
             rings[key] = Ring(torch, wl, nb, R, rank, dev, args.sig_dtype, stereo=args.stereo,
-                              distinct=64 if wl.dur_s > 1.0 else None)
+                              distinct=64 if wl.dur_s > 1.0 else (1024 if nb > 1024 else None))
         return rings[key]
 
     cur = lambda: torch.cuda.current_stream(dev).cuda_stream  # noqa: E731
@@ -772,6 +773,15 @@ def main():  # noqa: C901
             "n512": "BASELINE configs[1] as worded (512-point FFT: WinMs 32): ",
             "cfg5": "BASELINE configs[4]: "}[args.workload]
     top = cfg3 if cfg3 is not None else head      # several GPUs: configs[2] as stated is the line's value
+    # the SAME kernel as ONE launch of 4096 utterances, one stream: the steady-state rate without the two-stream overlap (what the
+    # committed rocprofv3 row profiles/*_b4096_* measures with counters); side by side with `pipelined` in `roofline`
+    big = None
+    if args.workload == "headline" and not multi and not args.only_headline and B == 256:
+        big = time_mode(head_wl, args.compute, check=False, n_streams=1, nb=4096, min_seconds=args.also_seconds if args.min_seconds > 0 else 0.0)
+        for key in list(rings):
+            if key[1] == 4096:
+                del rings[key]
+        torch.cuda.empty_cache()
     # ---- roofline of the dominant kernel (the frame -> mel kernel alone: the one-stream region)
     read_gbps, read_info = (None, "skipped") if (args.no_stream_read or rank != 0) else measured_stream_read(torch, dev)
     flops = head["batch"] * head_wl.T * frame_flops(head_wl)
@@ -789,6 +799,11 @@ def main():  # noqa: C901
                           "frac_of_%s_vector_peak" % args.compute: round(
                               flops / (head["us_per_step_device"]["mean"] * 1e-6) / 1e12 / peak_tf, 4),
                           "us_per_launch": head["us_per_step_device"]["mean"], "streams": head["streams"]},
+            "one_launch_of_4096": None if big is None else {
+                "us_per_launch": big["us_per_step_device"]["mean"], "us_per_256": round(big["us_per_step_device"]["mean"] / 16.0, 3),
+                "GBps": big["achieved_GBps"], "frac": round(big["achieved_GBps"] / HBM_PEAK_GBPS, 5),
+                "frac_of_measured": round(big["achieved_GBps"] / read_gbps, 5) if read_gbps else None, "streams": 1,
+                "note": "live, HIP events, one stream; the counter-backed rocprofv3 row of the same launch is under profiles/ (ROOFLINE.md, b4096)"},
             "kernel": "frame->FFT->power->mel (%s, %s)" % (head["kernel"], args.compute),
             "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"],
             "avg_launch_us": solo["us_per_step_device"]["mean"], "rocprofv3_avg_launch_us": rocprof_us,
@@ -801,14 +816,21 @@ def main():  # noqa: C901
                     "kernel over 2 GiB in this process: SURVEY 8d's denominator); achieved_TFLOPs = SURVEY 8d's algorithmic flops "
                     "(2.5 N log2 N + 3 H + 2 sum of widths + nf per frame) / the same time; rocprofv3_avg_launch_us = the average "
                     "duration rocprofv3 --kernel-trace --stats gave the same kernel in the committed profile (profiles/"
-                    "pmc_traffic.json); pipelined = the same bytes and flops / time per step of the %d-stream region (`value`)"
+                    "pmc_traffic.json); pipelined = the same bytes and flops / time per step of the %d-stream region (`value`); "
+                    "one_launch_of_4096 = the same kernel as one launch of 4096 utterances on one stream (steady state without the overlap).  "
+                    "Why not 0.9 of the read roof: the float64 transform alone needs >= ~400 perfectly packed v_fma_f64 per 6-frame wave tile "
+                    "against ~350 vector-instruction slots for 0.9 of the roof, v_mfma_f32 issues at the vector rate and does not overlap "
+                    "float64 vector work (profiles/round4_mfma_beside_valu.txt), and even the all-float32 plan stops at ~0.31"
                     % ("%.2f" % (flops / (head["us_per_step_device"]["mean"] * 1e-6) / 1e12 / peak_tf),
                        "%.2f" % (head["achieved_GBps"] / HBM_PEAK_GBPS), B, head["streams"])}
     line = {
         "metric": METRIC, "value": top["value"], "unit": "audio-seconds/sec",
         "n_gpus": world, "steps": top["steps"], "warmup": args.warmup, "ms_per_step": top["ms_per_step"],
         "higher_is_better": True, "scaling": "strong" if cfg3 is not None else "weak", "vs_baseline": None,
-        "dtype": args.compute, "data": "synthetic",
+        "dtype": args.compute, "epilogue": "f32", "data": "synthetic",
+        "dtype_note": ("float64 plan: samples -> FFT -> real-FFT split in float64; the power spectrum is parked as float32 behind a per-frame "
+                       "power-of-two scale, mel sums and the final log are float32 (DESIGN.md 5); the strict criterion is checked on every "
+                       "timed element (`parity`)" if args.compute == "f64" else "float32 throughout (explicit opt-in AUD_FAST_F32; never the default)"),
         "steps_note": "the %d steps asked for are captured %d x into one hipGraph, replayed %d x" % (
             K, top["graph_steps"] // K, top["repeats"]),
         "config": {"workload": (("BASELINE configs[2] as stated: %d synthetic 16 kHz mono utterances of 1 s per step in total, "

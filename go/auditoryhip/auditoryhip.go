@@ -455,9 +455,9 @@ func planDesc(n, s, t, border int, d DftParams, m MelFBank, f64 bool, mfcc int) 
 	desc.dft = C.aud_dft_params{comp_log_pow: b2i(d.CompLogPow), log_min: C.double(d.LogMin), log_offset: C.double(d.LogOffSet),
 		prev_smooth: C.double(d.PrevSmooth), cur_smooth: C.double(d.CurSmooth)}
 	desc.mel = m.c()
-	desc.compute_dtype = C.AUD_F32
-	if f64 {
-		desc.compute_dtype = C.AUD_F64
+	desc.compute_dtype = C.AUD_F64 // == 0: the zero value is the plan that computes as the reference does
+	if !f64 {
+		desc.compute_dtype = C.AUD_FAST_F32 // explicit opt-in (SndEnv.ComputeF32)
 	}
 	return desc
 }

@@ -271,7 +271,7 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
     kwta::KWTA Kwta;
     bool KwtaPool = false;
     bool ByTime = false;
-    int ComputeDtype = AUD_F32;
+    int ComputeDtype = AUD_F64;  // the reference's arithmetic; AUD_FAST_F32 is the explicit opt-in
     PlanHandle plan;
     aud_plan_desc plan_desc_{};  // what `plan` was created from (ensure_plan)
     aud_signal* dev_sig_ = nullptr;  // SignalToDevice: the resident copy of Signal ProcessSegment reads (null: upload per call)

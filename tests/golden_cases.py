@@ -48,7 +48,7 @@ def check_library_against_golden(name, compute_dtype):
             py, px = G.GABOR[gab]
             out = np.zeros((len(items), py, px, 2, 8), np.float32)
             plan.gabor_host(mel, out)            # gabor of the library's own mel, as SndEnv does
-            ok, msg = W.feature_close(out, gold["gabor"], compute_dtype, tol_f64=W.TOL_F64_DERIVED)
+            ok, msg = W.feature_close(out, gold["gabor"], compute_dtype, tol_f64=W.TOL_F64_GABOR)
             assert ok, (name, "gabor", msg)
         if gab and compute_dtype == capi.AUD_F32:
             # k-WTA of the STORED gabor tensor: float32 in the reference's order whatever the plan computes in, so

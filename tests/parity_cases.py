@@ -352,9 +352,10 @@ def case_gabor_4d_and_2d_vs_oracle(orc, cdt):
     mel[1, 0, :] = np.nan                               # NaN -> 0.5
     mel[2] = 3.25                                       # constant -> fSum ~ 0
     mel = mel.astype(np.float32).astype(np.float64)     # what the GPU mel stage hands over
-    # float64 plans: the default LDS-staged kernel sums a row of taps in float32 (gabor_tile.h): ~1e-6 of the all-float64
-    # sum; the one-thread-per-position kernel (option gabor_kernel = 1) sums everything in float64: 3e-7
-    tol = 1e-5 if cdt == capi.AUD_F32 else 2.5e-6
+    # float64 plans DEFAULT to the one-thread-per-position kernel, float64 taps and sums as gabor.go:268-283 has them: 3e-7 (the
+    # float32 store of the result); the LDS-staged kernel (option gabor_kernel = 0 for them: float32 taps, a row summed in
+    # float32, gabor_tile.h) ~1e-6 of the all-float64 sum.  float32 plans default to the LDS-staged kernel.
+    tol = 1e-5 if cdt == capi.AUD_F32 else 3e-7
     # 4-D pooled output, processspeech default filter set
     k = orc.gabor_to_tensor(W.DEFAULT_GABOR_SPECS, 9, 9)
     plan = W.product_plan(oc, cdt, GABOR_DEFAULT)
@@ -365,12 +366,15 @@ def case_gabor_4d_and_2d_vs_oracle(orc, cdt):
     plan.gabor_host(mel, out)
     ok, msg = W.close_enough(out, ref, tol)
     assert ok, msg
-    plan.set_option("gabor_kernel", 1)
-    out1 = np.full((5, 11, 32, 2, 8), 7.0, np.float32)
-    plan.gabor_host(mel, out1)
-    ok, msg = W.close_enough(out1, ref, 1e-5 if cdt == capi.AUD_F32 else 3e-7)
-    assert ok, "per-position kernel: " + msg
-    plan.set_option("gabor_kernel", 0)
+    for gk, tol_k in ((1, 1e-5 if cdt == capi.AUD_F32 else 3e-7), (0, 1e-5 if cdt == capi.AUD_F32 else W.TOL_F64_DERIVED)):
+        plan.set_option("gabor_kernel", gk)
+        out1 = np.full((5, 11, 32, 2, 8), 7.0, np.float32)
+        plan.gabor_host(mel, out1)
+        ok, msg = W.close_enough(out1, ref, tol_k)
+        assert ok, "gabor_kernel %d: %s" % (gk, msg)
+        if cdt == capi.AUD_F64 and gk == 1:
+            assert np.array_equal(out1, out)             # the float64 plan's default IS the all-float64 kernel
+    plan.set_option("gabor_kernel", -1)
     # wider units than the kernel fills + fewer pools than the mel allows:
     # untouched cells keep their contents (the reference never zeroes rawOut)
     out = np.full((5, 9, 20, 3, 10), 7.0, np.float32)
@@ -542,6 +546,54 @@ def case_random_any_n(orc, seed, windows):
     return what
 
 
+def case_generic_lds_limits(orc, run=((4096, capi.AUD_F64), (8192, capi.AUD_FAST_F32))):
+    """Window lengths whose two complex buffers fill the 64 KB of a plain launch TO THE BYTE: N = 4096 in float64 (M = 2048 x 16 B
+    x 2) and N = 8192 in float32 must still get a plan (one frame per workgroup) -- the pair-route's two exponent words are the
+    Bluestein launch's business only -- and the power-of-two lengths below them keep their frames per workgroup.  `run`: the
+    (N, compute type) pairs also driven against the oracle on a two-step segment."""
+    dftp = capi.DftParams()
+    capi.load().aud_dft_defaults(dftp)
+    ctx = runtime.get_ctx(0)
+    want = {(4096, capi.AUD_F64): 1, (8192, capi.AUD_FAST_F32): 1, (2048, capi.AUD_F64): 2, (1024, capi.AUD_F64): 4,
+            (4096, capi.AUD_FAST_F32): 2, (2048, capi.AUD_FAST_F32): 4, (256, capi.AUD_F64): 16}
+    from auditory_amd import mel as melmod
+    for (N, cdt), F in want.items():
+        sr = 16000
+        for hi in (8000.0, 4000.0, 2000.0, 1000.0, 500.0, 250.0, 120.0, 60.0):   # the widest triangle must fit [nf, nf+2] (Q4)
+            mp = melmod.Params()
+            mp.Defaults()
+            mp.FBank.NFilters, mp.FBank.LoHz, mp.FBank.HiHz = 24, 0.0, hi
+            try:
+                filt = mp.InitFilters(N, sr)
+                break
+            except capi.AuditoryError:
+                continue
+        else:
+            raise AssertionError("no mel table for N=%d" % N)
+        S, T, border = N // 2, 2, 1
+        plan = runtime.Plan(ctx, N, S, T, border, dftp, mp.FBank.to_c(), mp.BinPts, filt, compute_dtype=cdt)
+        try:
+            plan.set_option("kernel", 1)
+            assert plan.kernel_name == "generic" and plan.info("generic_frames_per_wg") == F, (N, cdt, plan.info("generic_frames_per_wg"))
+            if (N, cdt) not in run:
+                continue
+            L = N + S
+            sig, _ = synth.batch(4096 + N, 1, L, sr)
+            mel, pw, _ = plan.melspec_host(sig.ravel(), runtime.make_items([0], [L], [0]), True, False)
+        finally:
+            plan.close()
+        sp = orc.SndParams(sr, N, S, S, T, border)
+        d, m = orc.dft_defaults(), orc.mel_defaults()
+        m.n_filters, m.lo_hz, m.hi_hz = 24, 0.0, hi
+        rc, bins, hz, ofilt = orc.mel_init_filters(m, N, sr)
+        assert rc == 0 and np.array_equal(bins, mp.BinPts)
+        o = orc.process_segment(sp, d, m, bins, ofilt, sig[0], segment=0)
+        ok, msg = W.feature_close(mel[0], o["mel_seg"], cdt, lin_axis=0)
+        assert ok, "N=%d: mel %s" % (N, msg)
+        ok, msg = W.spectrum_close(pw[:1], o["power_seg"][None], 4e-6 if cdt == capi.AUD_F32 else 3e-7)
+        assert ok, "N=%d: power %s" % (N, msg)
+
+
 def case_gabor_fuzz(orc, seed, cdt):
     """agabor.Convolve on a seeded random geometry -- matrix shape, filter size, strides, filter count (not a multiple of 4:
     zero-padded quads), NaN cells, rank-4 pools of any width and rank-2 outputs in both orders -- through BOTH kernels
@@ -648,14 +700,14 @@ def case_process_fused_vs_oracle(orc, cdt, mem, name="cfg2_16k_n400_nf40", n=3, 
         outs = {}
         # fused (one launch, option item_kernel = 1); the default two launches (tile kernel + LDS-staged gabor kernel); the two
         # launches with the one-thread-per-position gabor kernel (all-float64 sums in float64 plans)
-        for mode, (ik, gk) in {"fused": (1, 0), "lds": (-1, 0), "per_position": (-1, 1)}.items():
+        for mode, (ik, gk) in {"fused": (1, 0), "lds": (-1, 0), "per_position": (-1, 1), "default": (-1, -1)}.items():
             plan.set_option("item_kernel", ik)
             plan.set_option("gabor_kernel", gk)
             d_mel = mem.put(np.full((n, oc.nf, oc.T), 3.0, np.float32))
             d_gab = mem.put(np.full((n, py, px, 2, 8), 7.0, np.float32))
             plan.process_dev(mem.ptr(d_sig), capi.AUD_F32, mem.ptr(d_items), n, mem.ptr(d_mel), py, px, mem.ptr(d_gab), mem.stream)
             outs[mode] = (np.array(mem.get(d_mel)), np.array(mem.get(d_gab)))
-        plan.set_option("gabor_kernel", 0)
+        plan.set_option("gabor_kernel", -1)
         # mel-only through the item kernel (option 1), with the optional spectrum outputs
         plan.set_option("item_kernel", 1)
         d_mel = mem.put(np.zeros((n, oc.nf, oc.T), np.float32))
@@ -674,6 +726,9 @@ def case_process_fused_vs_oracle(orc, cdt, mem, name="cfg2_16k_n400_nf40", n=3, 
     assert np.array_equal(mel_f, mel_u, equal_nan=True) and np.array_equal(mel_f, item_mel, equal_nan=True)
     assert np.array_equal(mel_p, mel_u, equal_nan=True)
     assert np.array_equal(gab_f, gab_u)            # the same device function on the same float32 matrix: bit for bit
+    # what a caller gets without touching an option: float64 plans the all-float64 Convolve, float32 plans the LDS-staged one
+    assert np.array_equal(outs["default"][1], gab_p if cdt == capi.AUD_F64 else gab_u)
+    assert np.array_equal(outs["default"][0], mel_u, equal_nan=True)
     x64 = sig32.astype(np.float64)
     # float64 plans: the LDS-staged forms sum a row of taps in float32 (gabor_tile.h): ~1e-6; the per-position kernel 3e-7
     tol_lds, tol_pp = (1e-5, 1e-5) if cdt == capi.AUD_F32 else (2.5e-6, 1e-6)

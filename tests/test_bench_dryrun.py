@@ -196,14 +196,19 @@ def test_device_api_tests_dry_run(monkeypatch, orc):
     monkeypatch.setattr(torch, "empty", lambda *a, **k: real_empty(*a, **{**k, "device": "cpu"}))
     monkeypatch.setattr(torch, "zeros", lambda *a, **k: real_zeros(*a, **{**k, "device": "cpu"}))
     with backend.emulated("plain"):
-        G.test_input_dtypes_agree(orc, torch, "cfg2_16k_n512_nf40", 300.0)
-        G.test_int16_normalisation_exhaustive(orc, torch)
-        G.test_input_dtypes_agree(orc, torch, "cfg2_16k_n400_nf40", 200.0)
-        G.test_input_dtypes_agree(orc, torch, "cfg5_44k_n2048_nf128", 80.0)
-        G.test_input_dtypes_agree(orc, torch, "cfg1_44k_n1103_nf32", None)
-        G.test_process_batch_mel_plus_gabor(orc, torch)
-        G.test_process_then_kwta_device_resident(orc, torch, n=1)
-        G.test_full_size_properties_cfg2(orc, torch, B=4)
+        F32, F64 = G.capi.AUD_FAST_F32, G.capi.AUD_F64
+        G.test_input_dtypes_agree(orc, torch, "cfg2_16k_n512_nf40", 300.0, F32)
+        G.test_input_dtypes_agree(orc, torch, "cfg2_16k_n512_nf40", 300.0, F64)
+        G.test_int16_normalisation_exhaustive(orc, torch, F32)
+        G.test_int16_normalisation_exhaustive(orc, torch, F64)
+        G.test_input_dtypes_agree(orc, torch, "cfg2_16k_n400_nf40", 200.0, F64)
+        G.test_input_dtypes_agree(orc, torch, "cfg5_44k_n2048_nf128", 80.0, F32)
+        G.test_input_dtypes_agree(orc, torch, "cfg1_44k_n1103_nf32", None, F64)
+        G.test_process_batch_mel_plus_gabor(orc, torch, F64)
+        G.test_process_batch_mel_plus_gabor(orc, torch, F32)
+        G.test_process_then_kwta_device_resident(orc, torch, F64, n=1)
+        G.test_full_size_properties_cfg2(orc, torch, F64, B=4)
+        G.test_zeroed_plan_desc_is_the_conforming_plan(orc, torch)
 
 
 def test_rocprof_summary_on_synthetic_csvs(tmp_path):

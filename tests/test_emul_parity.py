@@ -70,6 +70,11 @@ def test_emul_zero_signal_and_empty_batch(orc, emu):
     PC.case_zero_signal_and_empty_batch(orc)
 
 
+def test_emul_generic_lds_limits(orc, emu):
+    # (the two 64 KB-exact plans are created here; their transforms run on the GPU tier -- 4096-point stages are slow to emulate)
+    PC.case_generic_lds_limits(orc, run=())
+
+
 def test_emul_plan_rejects_unsupported(orc, emu):
     PC.case_plan_rejects_unsupported(orc)
 

@@ -67,6 +67,10 @@ def test_zero_signal_and_empty_batch(orc, torch_cuda):
     PC.case_zero_signal_and_empty_batch(orc)
 
 
+def test_generic_lds_limits(orc, torch_cuda):
+    PC.case_generic_lds_limits(orc)
+
+
 def test_plan_rejects_unsupported(orc, torch_cuda):
     PC.case_plan_rejects_unsupported(orc)
 
@@ -149,58 +153,71 @@ def test_recreated_tone_fixtures_f64(orc, torch_cuda):
 @pytest.mark.parametrize("name,seg_ms", [("cfg2_16k_n512_nf40", None), ("cfg2_16k_n400_nf40", None),
                                          ("cfg5_44k_n2048_nf128", 300.0), ("cfg1_44k_n1103_nf32", None)],
                          ids=["n512", "n400", "n2048", "n1103"])
-def test_input_dtypes_agree(orc, torch_cuda, name, seg_ms):
+@pytest.mark.parametrize("cdt", [capi.AUD_F64, capi.AUD_FAST_F32], ids=["f64", "f32"])
+def test_input_dtypes_agree(orc, torch_cuda, name, seg_ms, cdt):
     """float32, float64 and int16 PCM samples (sound.go:116-141 normalisation on the device) through every
     kernel family; int16 takes the 4-byte-per-pair route when a frame's pairs are aligned and the guarded
-    route when they are not -- the results must not depend on which"""
+    route when they are not -- the results must not depend on which.  float32 plans see PCM / 0x7FFF rounded to float32 whichever
+    way it arrives (int16 == float32 samples, bit for bit); float64 plans see the reference's float64 quotient from int16 and
+    from float64 samples alike (int16 == float64 samples, bit for bit), float32 samples being the rounded ones."""
     torch = torch_cuda
     from auditory_amd.batch import BatchProcessor
     oc = W.OracleCfg(orc, name, seg_ms)
     L = oc.full_len()
     sig, pcm = synth.batch(12, 4, L - oc.N // 2, oc.sr, row_len=L)
-    plan = W.product_plan(oc)
+    plan = W.product_plan(oc, cdt)
     bp = BatchProcessor(plan, "cuda:0")
     items = bp.upload_items(runtime.make_items(np.arange(4) * L, [L] * 4, [0] * 4))
     outs = []
     for t in (torch.from_numpy(sig.astype(np.float32)), torch.from_numpy(sig), torch.from_numpy(pcm)):
         outs.append(bp.melspec(t.cuda().contiguous().view(-1), items, 4).cpu().numpy())
     torch.cuda.synchronize()
-    assert np.array_equal(outs[0], outs[2], equal_nan=True)   # i16/0x7FFF in f32 == f32(round(f64 value))
-    ok, msg = W.close_enough(outs[1], outs[0], 2e-6)
+    f32 = cdt == capi.AUD_FAST_F32
+    twin = 0 if f32 else 1                             # the sample type that must match int16 PCM bit for bit
+    assert np.array_equal(outs[twin], outs[2], equal_nan=True)
+    # (float32 samples are OTHER numbers than PCM / 0x7FFF -- rounded at 6e-8 relative; a one-bin mel filter 60 dB under the frame's
+    # peak moves by a few 1e-6 with them: a sanity bound only, each input's own parity is checked against the oracle below)
+    ok, msg = W.close_enough(outs[1], outs[0], 1e-5)
     assert ok, msg
     ref, _, _ = PC.oracle_items(orc, oc, sig, [(r, 0) for r in range(4)])
-    ok, msg = W.feature_close(outs[0], ref, capi.AUD_F32, lin_axis=1)
+    ok, msg = W.feature_close(outs[2], ref, cdt, lin_axis=1)
     assert ok, msg
+    if not f32:   # the float32 samples are other numbers than PCM / 0x7FFF: against the oracle on exactly those
+        ref32, _, _ = PC.oracle_items(orc, oc, sig.astype(np.float32).astype(np.float64), [(r, 0) for r in range(4)])
+        ok, msg = W.feature_close(outs[0], ref32, cdt, lin_axis=1)
+        assert ok, msg
     assert not (ref[:, :, -1] == 0).all()              # zero tail keeps every frame in bounds
     # the same streams at an odd row pitch: rows 1 and 3 start at odd sample offsets (unaligned pairs)
     Lo = L + 1 if L % 2 == 0 else L + 2
-    for arr in (pcm, sig.astype(np.float32)):
+    for arr, want in ((pcm, outs[2]), (sig.astype(np.float32), outs[0])):
         wide = np.zeros((4, Lo), arr.dtype)
         wide[:, :L] = arr
         items_o = bp.upload_items(runtime.make_items(np.arange(4) * Lo, [L] * 4, [0] * 4))
         got = bp.melspec(torch.from_numpy(wide).cuda().contiguous().view(-1), items_o, 4).cpu().numpy()
-        assert np.array_equal(got, outs[0], equal_nan=True)
+        assert np.array_equal(got, want, equal_nan=True)
     # and as the channels of two interleaved stereo clips (rows 0 | 1 and 2 | 3): strided work items over one buffer
-    for arr in (pcm, sig.astype(np.float32)):
+    for arr, want in ((pcm, outs[2]), (sig.astype(np.float32), outs[0])):
         inter = np.ascontiguousarray(arr.reshape(2, 2, L).transpose(0, 2, 1))        # [clip, sample, channel]
         items_s = bp.upload_items(runtime.make_items((np.arange(4) // 2) * (2 * L) + np.arange(4) % 2, [L] * 4, [0] * 4,
                                                      sig_stride=2))
         got = bp.melspec(torch.from_numpy(inter).cuda().contiguous().view(-1), items_s, 4).cpu().numpy()
-        assert np.array_equal(got, outs[0], equal_nan=True)
+        assert np.array_equal(got, want, equal_nan=True)
     plan.close()
 
 
-def test_int16_normalisation_exhaustive(orc, torch_cuda):
+@pytest.mark.parametrize("cdt", [capi.AUD_F64, capi.AUD_FAST_F32], ids=["f64", "f32"])
+def test_int16_normalisation_exhaustive(orc, torch_cuda, cdt):
     """every int16 value once: the 4-byte-per-pair int16 route (x * RN(1/32767) + one residual step) must give
-    what the correctly rounded float32 division gives -- numpy's float32 quotient fed in as float samples"""
+    what the correctly rounded division gives in the plan's compute type -- numpy's float32 / float64 quotient fed in as
+    float32 / float64 samples (sound.go:138: float64(v) / float64(0x7FFF))"""
     torch = torch_cuda
     from auditory_amd.batch import BatchProcessor
     oc = W.OracleCfg(orc, "cfg2_16k_n512_nf40")
     pcm = np.arange(-32768, 32768, dtype=np.int64)
     pcm = np.concatenate([pcm[::2], pcm[1::2][::-1], np.zeros(oc.N, np.int64)]).astype(np.int16)  # not a ramp
-    f32 = pcm.astype(np.float32) / np.float32(32767.0)
+    f32 = pcm.astype(np.float32) / np.float32(32767.0) if cdt == capi.AUD_FAST_F32 else pcm.astype(np.float64) / 32767.0
     n_seg = (65536 + oc.sp.stride_samples - 1) // oc.sp.stride_samples
-    plan = W.product_plan(oc)
+    plan = W.product_plan(oc, cdt)
     bp = BatchProcessor(plan, "cuda:0")
     items = bp.upload_items(runtime.make_items([0] * n_seg, [len(pcm)] * n_seg,
                                                [s * oc.sp.stride_samples for s in range(n_seg)]))
@@ -212,8 +229,11 @@ def test_int16_normalisation_exhaustive(orc, torch_cuda):
     plan.close()
 
 
-def test_process_batch_mel_plus_gabor(orc, torch_cuda):
-    """cfg 4: fused API, default FilterSet, 4-D [11, 32, 2, 8] pools"""
+@pytest.mark.parametrize("cdt", [capi.AUD_F64, capi.AUD_FAST_F32], ids=["f64_strict", "f32_relaxed"])
+def test_process_batch_mel_plus_gabor(orc, torch_cuda, cdt):
+    """BASELINE configs[3] (N = 512 + agabor.Convolve): fused API, default FilterSet, 4-D [11, 32, 2, 8] pools.  The float64
+    plan -- what every default selects -- under the STRICT criterion |d| <= 1e-5 max(1, |ref|) on every element of both tensors
+    (and the tighter float64 tolerances); the float32 opt-in under its relaxed one."""
     torch = torch_cuda
     from auditory_amd.batch import BatchProcessor
     oc = W.OracleCfg(orc, "cfg2_16k_n512_nf40")
@@ -222,19 +242,67 @@ def test_process_batch_mel_plus_gabor(orc, torch_cuda):
     sig, _ = synth.batch(4, n, 16000, oc.sr, row_len=L)
     k = orc.gabor_to_tensor(W.DEFAULT_GABOR_SPECS, 9, 9)
     g = dict(k=k, stride_x=3, stride_y=3, gain=2.0, py=11, px=32)
-    rc, ref_mel, ref_g = orc.process_batch(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig.ravel(),
+    sig32 = sig.astype(np.float32)                      # what the device sees
+    rc, ref_mel, ref_g = orc.process_batch(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig32.astype(np.float64).ravel(),
                                            np.arange(n) * L, np.full(n, L), np.zeros(n), gabor=g)
     assert rc == 0
-    plan = W.product_plan(oc, capi.AUD_F32, PC.GABOR_DEFAULT)
+    plan = W.product_plan(oc, cdt, PC.GABOR_DEFAULT)
     bp = BatchProcessor(plan, "cuda:0")
     items = bp.upload_items(runtime.make_items(np.arange(n) * L, [L] * n, [0] * n))
     mel, gab = bp.process(torch.from_numpy(sig.astype(np.float32)).cuda().view(-1), items, n, 11, 32)
     torch.cuda.synchronize()
-    ok, msg = W.feature_close(mel.cpu().numpy(), ref_mel, capi.AUD_F32, lin_axis=1)
+    if cdt == capi.AUD_F64:
+        for what, got, ref in (("mel", mel, ref_mel), ("gabor", gab, ref_g)):
+            ok, msg = W.close_enough(got.cpu().numpy(), ref, 1e-5)
+            assert ok, "strict criterion, %s: %s" % (what, msg)
+    ok, msg = W.feature_close(mel.cpu().numpy(), ref_mel, cdt, lin_axis=1)
     assert ok, "mel " + msg
-    ok, msg = W.feature_close(gab.cpu().numpy(), ref_g, capi.AUD_F32)
+    ok, msg = W.feature_close(gab.cpu().numpy(), ref_g, cdt, tol_f64=W.TOL_F64_GABOR)
     assert ok, "gabor " + msg
     plan.close()
+
+
+def test_zeroed_plan_desc_is_the_conforming_plan(orc, torch_cuda):
+    """A memset-0 aud_plan_desc with only the geometry and the parameter blocks filled in -- compute_dtype left at its zero
+    value, as a C caller's `aud_plan_desc d = {0}` or a Go zero value leaves it -- must give the float64 plan and pass the
+    north star's criterion on EVERY element (the reference is float64 throughout: dft.go:42-85, mel.go:120-153)."""
+    import ctypes as C
+    torch = torch_cuda
+    lib = capi.load()
+    ctx = runtime.get_ctx(0)
+    oc = W.OracleCfg(orc, "cfg2_16k_n400_nf40")
+    d = capi.PlanDesc()
+    C.memset(C.byref(d), 0, C.sizeof(d))
+    d.win_samples, d.step_samples, d.segment_steps, d.border_steps = oc.N, oc.S, oc.T, oc.sp.border_steps
+    lib.aud_dft_defaults(C.byref(d.dft))
+    fb = capi.MelFBank()
+    lib.aud_mel_defaults(C.byref(fb))
+    fb.n_filters, fb.lo_hz, fb.hi_hz = oc.nf, oc.m.lo_hz, oc.m.hi_hz
+    bins, filt = np.zeros(oc.nf + 2, np.int32), np.zeros((oc.nf, oc.nf + 2))
+    assert lib.aud_mel_init_filters(C.byref(fb), oc.N, oc.sr, bins.ctypes.data_as(C.c_void_p), None, filt.ctypes.data_as(C.c_void_p)) == 0
+    d.mel = fb
+    assert d.compute_dtype == 0 == capi.AUD_F64
+    h = C.c_void_p()
+    ctx.check(lib.aud_plan_create(ctx.handle, C.byref(d), bins.ctypes.data_as(C.POINTER(C.c_int32)),
+                                  filt.ctypes.data_as(C.POINTER(C.c_double)), None, C.byref(h)))
+    try:
+        assert lib.aud_plan_kernel_name(h).decode() == "w20x10"
+        n, L = 8, oc.full_len()
+        sig, _ = synth.batch(77, n, 16000, oc.sr, row_len=L)
+        sig32 = sig.astype(np.float32)
+        dsig = torch.from_numpy(sig32).cuda().view(-1)
+        items = torch.from_numpy(np.frombuffer(runtime.make_items(np.arange(n) * L, [L] * n, [0] * n).tobytes(), np.uint8).copy()).cuda()
+        mel = torch.from_numpy(np.full((n, oc.nf, oc.T), 3.0, np.float32)).cuda()
+        ctx.check(lib.aud_melspec_batch_dev(h, dsig.data_ptr(), capi.AUD_F32, items.data_ptr(), n, mel.data_ptr(), None, None,
+                                            torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        ref, _, _ = PC.oracle_items(orc, oc, sig32.astype(np.float64), [(r, 0) for r in range(n)])
+        ok, msg = W.close_enough(mel.cpu().numpy(), ref, 1e-5)
+        assert ok, "zero-initialised descriptor: " + msg
+        ok, msg = W.close_enough(mel.cpu().numpy(), ref, W.TOL_F64)      # and it really is the float64 arithmetic
+        assert ok, msg
+    finally:
+        lib.aud_plan_destroy(h)
 
 
 @pytest.mark.parametrize("name", ["cfg2_16k_n400_nf40", "cfg2_16k_n512_nf40", "cfg1_44k_n1103_nf32"])
@@ -283,20 +351,30 @@ def test_segment_device_resident(orc, torch_cuda, name):
         plan.close()
 
 
-def test_process_then_kwta_device_resident(orc, torch_cuda, n=6):
+@pytest.mark.parametrize("cdt", [capi.AUD_F64, capi.AUD_FAST_F32], ids=["f64", "f32"])
+def test_process_then_kwta_device_resident(orc, torch_cuda, cdt, n=6):
     """SndEnv.ApplyGabor with Kwta.On (sndenv.go:481-497) on device-resident tensors: mel + gabor, then the
-    k-WTA stage on the gabor tensor where it lies in HBM; bit-exact against the oracle run on that tensor"""
+    k-WTA stage on the gabor tensor where it lies in HBM; bit-exact against the oracle run on that tensor.  The float64 plan's
+    gabor tensor is also held to the strict criterion against the oracle's own mel + Convolve."""
     torch = torch_cuda
     from auditory_amd import kwta
     from auditory_amd.batch import BatchProcessor
     oc = W.OracleCfg(orc, "cfg2_16k_n512_nf40")
     L = oc.full_len()
     sig, _ = synth.batch(9, n, 16000, oc.sr, row_len=L)
-    plan = W.product_plan(oc, capi.AUD_F32, PC.GABOR_DEFAULT)
+    plan = W.product_plan(oc, cdt, PC.GABOR_DEFAULT)
     bp = BatchProcessor(plan, "cuda:0")
     items = bp.upload_items(runtime.make_items(np.arange(n) * L, [L] * n, [0] * n))
     dsig = torch.from_numpy(sig.astype(np.float32)).cuda().view(-1)
     _, gab = bp.process(dsig, items, n, 11, 32)
+    if cdt == capi.AUD_F64:
+        gk = orc.gabor_to_tensor(W.DEFAULT_GABOR_SPECS, 9, 9)
+        rc, _, ref_g = orc.process_batch(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig.astype(np.float32).astype(np.float64).ravel(),
+                                         np.arange(n) * L, np.full(n, L), np.zeros(n),
+                                         gabor=dict(k=gk, stride_x=3, stride_y=3, gain=2.0, py=11, px=32))
+        assert rc == 0
+        ok, msg = W.close_enough(gab.cpu().numpy(), ref_g, 1e-5)
+        assert ok, "strict criterion, gabor: " + msg
     k, ko = PC._kwta_pair(orc)
     _, gab2, act2 = bp.process_sndenv(dsig, items, n, 11, 32, k)     # the one-call form
     act = torch.empty(gab.shape, dtype=torch.float32, device=gab.device)
@@ -369,9 +447,12 @@ def _full_size_properties(orc, torch, name, B, dur, cdt, spot_step, parseval_ste
     return mel
 
 
-def test_full_size_properties_cfg2(orc, torch_cuda, B=256):
-    """BASELINE configs[1] at full size (B = 256 x 1 s @16 kHz, N = 512, 40 mel), float32 plan"""
-    mel = _full_size_properties(orc, torch_cuda, "cfg2_16k_n512_nf40", B, 16000, capi.AUD_F32, 17, (0, 1, 2, 50, 103), 2e-6)
+@pytest.mark.parametrize("cdt", [capi.AUD_F64, capi.AUD_FAST_F32], ids=["f64_strict", "f32_relaxed"])
+def test_full_size_properties_cfg2(orc, torch_cuda, cdt, B=256):
+    """BASELINE configs[1] as worded at full size (B = 256 x 1 s @16 kHz, N = 512, 40 mel): the float64 plan every default
+    selects (spot streams under the float64 tolerance, i.e. well inside the strict 1e-5), and the float32 opt-in"""
+    mel = _full_size_properties(orc, torch_cuda, "cfg2_16k_n512_nf40", B, 16000, cdt, 17, (0, 1, 2, 50, 103),
+                                1e-6 if cdt == capi.AUD_F64 else 2e-6)
     assert (mel == -10.0).any()
 
 

@@ -29,7 +29,7 @@ def main():
         print("%-90s %8s %12s %14s %6s" % (name, r.get("Calls", "?"), r.get("AverageNs", r.get("Average", "?")),
                                              r.get("TotalDurationNs", r.get("TotalDuration", "?")),
                                              r.get("Percentage", "?")))
-    for ctr in ("fetch", "write", "sqa", "sqb"):
+    for ctr in ("fetch", "write", "sqa", "sqb", "sqc", "ta", "tcc"):
         per = {}
         for r in rows(os.path.join(out, ctr, "**", "*counter_collection.csv")):
             k = r.get("Kernel_Name", r.get("Kernel Name", "?"))
@@ -39,7 +39,7 @@ def main():
             d[0] += 1
             d[1] += v
         print("## %s pass: counter sums per kernel (rows, mean per dispatch)" % ctr.upper())
-        for (k, n), (cnt, tot) in sorted(per.items(), key=lambda kv: -kv[1][1])[:8]:
+        for (k, n), (cnt, tot) in sorted(per.items(), key=lambda kv: -kv[1][1])[:10]:
             mean = tot / max(cnt, 1)
             note = ""
             if n == "FETCH_SIZE":
@@ -62,7 +62,7 @@ def main():
     avg_ns = {r.get("Name", ""): float(r.get("AverageNs", r.get("Average", 0)) or 0) for r in stats}
     calls = {r.get("Name", ""): int(float(r.get("Calls", 0) or 0)) for r in stats}
     sq = {}
-    for ctr in ("sqa", "sqb"):
+    for ctr in ("sqa", "sqb", "sqc", "ta", "tcc"):
         for r in rows(os.path.join(out, ctr, "**", "*counter_collection.csv")):
             k = r.get("Kernel_Name", r.get("Kernel Name", "?"))
             d = sq.setdefault(k, {}).setdefault(r.get("Counter_Name", r.get("Counter Name", "?")), [0, 0.0])
