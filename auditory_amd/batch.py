@@ -130,20 +130,22 @@ def allgather_features(local, world_size, group=None, n_total=None):
 
 class DirectGather:
     """The path's reassembly as direct device-to-device copies (aud_gather_*, include/auditory_hip.h): every rank pushes
-    its slab into slot `rank` of every rank's receive buffer, one copy per peer on its own stream -- on a fully connected
-    xGMI node one link each, where a ring all-gather is per-link bound over G - 1 serial hops.  The
-    receive buffer [n_ranks, slab_floats] float32 belongs to the library (it must be exportable between processes);
+    its slab into slot `rank` of every rank's receive area, one copy per peer on its own stream -- on a fully connected
+    xGMI node one link each, where a ring all-gather is per-link bound over G - 1 serial hops -- and stores
+    its step number into the peer's arrival flag behind the copy; `wait` queues the poll for every peer's flag, behind which
+    the step's slab is complete (what ncclAllGather's return means).  The receive area [2, n_ranks, slab_floats] float32 --
+    consecutive steps alternate between its two slabs -- belongs to the library (it must be exportable between processes);
     `recv` is a torch view of it."""
 
     def __init__(self, ctx, n_ranks, rank, slab_floats):
         import ctypes as C
         self.ctx, self.lib, self.n_ranks, self.rank, self.slab = ctx, ctx.lib, int(n_ranks), int(rank), int(slab_floats)
-        ptr, handle = C.c_void_p(), C.create_string_buffer(64)
+        ptr, handle = C.c_void_p(), C.create_string_buffer(128)
         ctx.check(self.lib.aud_gather_create(ctx.handle, self.n_ranks, self.rank, self.slab, C.byref(ptr), handle))
         self.recv_ptr, self.handle = ptr.value, handle.raw
 
     def open_peers(self, handles):
-        """handles[p] = rank p's 64-byte handle (this rank's own entry is ignored)"""
+        """handles[p] = rank p's 128-byte handle pair (this rank's own entry is ignored)"""
         for p, h in enumerate(handles):
             if p != self.rank:
                 self.ctx.check(self.lib.aud_gather_open_peer(self.ctx.handle, p, bytes(h)))
@@ -156,22 +158,38 @@ class DirectGather:
         self.open_peers(handles)
 
     def allgather(self, send_ptr, count, stream=0):
-        """push `count` floats at device address send_ptr into every rank's buffer; when `stream` has passed the call this
-        rank's pushes are done -- the receive buffer is complete once every rank's call has (barrier, or the next step)"""
-        self.ctx.check(self.lib.aud_allgather_direct_dev(self.ctx.handle, send_ptr, int(count), stream))
+        """push `count` floats at device address send_ptr into the step's slab of every rank and signal each peer; returns the
+        slab index (0 / 1) this step uses.  When `stream` has passed the call this rank's pushes are done; `wait` is the
+        arrival side"""
+        import ctypes as C
+        which = C.c_int(-1)
+        self.ctx.check(self.lib.aud_allgather_direct_dev(self.ctx.handle, send_ptr, int(count), C.byref(which), stream))
+        return which.value
+
+    def wait(self, stream=0):
+        """queue the (bounded) poll for every peer's arrival flag of the last step on `stream`: behind it the step's slab is
+        complete on this rank"""
+        self.ctx.check(self.lib.aud_gather_wait_dev(self.ctx.handle, stream))
+
+    def timeouts(self):
+        """waits that ran into their poll bound so far (synchronises the device)"""
+        import ctypes as C
+        n = C.c_int(0)
+        self.ctx.check(self.lib.aud_gather_timeouts(self.ctx.handle, C.byref(n)))
+        return n.value
 
     def recv(self, device):
-        """the receive buffer as a [n_ranks, slab_floats] float32 tensor (no copy)"""
+        """the receive area as a [2, n_ranks, slab_floats] float32 tensor (no copy): slab `allgather()` returned"""
         if torch.device(device).type == "cpu":  # (tests' CPU thread-emulator build: "device" memory is host memory)
             import ctypes as C
             return torch.from_numpy(np.ctypeslib.as_array(C.cast(self.recv_ptr, C.POINTER(C.c_float)),
-                                                          shape=(self.n_ranks, self.slab)))
+                                                          shape=(2, self.n_ranks, self.slab)))
 
         class _View:
             pass
 
         v = _View()
-        v.__cuda_array_interface__ = {"shape": (self.n_ranks, self.slab), "typestr": "<f4", "data": (self.recv_ptr, False),
+        v.__cuda_array_interface__ = {"shape": (2, self.n_ranks, self.slab), "typestr": "<f4", "data": (self.recv_ptr, False),
                                       "version": 2}
         self._keep = v
         return torch.as_tensor(v, device=device)

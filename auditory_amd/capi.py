@@ -140,7 +140,9 @@ SYMBOLS = {
     "aud_allgather_dev": (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP]),
     "aud_gather_create": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int64, C.POINTER(_VP), _VP]),
     "aud_gather_open_peer": (C.c_int, [_VP, C.c_int, _VP]),
-    "aud_allgather_direct_dev": (C.c_int, [_VP, _VP, C.c_int64, _VP]),
+    "aud_allgather_direct_dev": (C.c_int, [_VP, _VP, C.c_int64, C.POINTER(C.c_int), _VP]),
+    "aud_gather_wait_dev": (C.c_int, [_VP, _VP]),
+    "aud_gather_timeouts": (C.c_int, [_VP, C.POINTER(C.c_int)]),
     "aud_gather_destroy": (C.c_int, [_VP]),
 }
 

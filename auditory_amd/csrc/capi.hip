@@ -401,6 +401,8 @@ int aud_melspec_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
     // one workgroup per (item, frame tile): keep the 1-D grid inside what a launch accepts
     if (int64_t(n_items) * int64_t(p->d.segment_steps) > (int64_t(1) << 30))
         return fail(c, AUD_EINVAL, "n_items x segment_steps too large for one launch; split the batch");
+    if ((power || log_power) && int64_t(p->H) * int64_t(p->d.segment_steps) >= (int64_t(1) << 29))
+        return fail(c, AUD_EINVAL, "an item's [H, T] spectrum tensor must stay below 2 GB (it sits behind a buffer descriptor)");
     AUD_HIP(c, make_current(c));
     aud::MelspecArgs a;
     fill_melspec_args(p, &a);
@@ -528,6 +530,8 @@ int aud_segment_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
     if (sig_dtype != AUD_F32 && sig_dtype != AUD_F64 && sig_dtype != AUD_I16) return fail(c, AUD_EINVAL, "bad sig_dtype");
     if (int64_t(n_items) * int64_t(p->d.segment_steps) > (int64_t(1) << 30))
         return fail(c, AUD_EINVAL, "n_items x segment_steps too large for one launch; split the batch");
+    if ((power || log_power) && int64_t(p->H) * int64_t(p->d.segment_steps) >= (int64_t(1) << 29))
+        return fail(c, AUD_EINVAL, "an item's [H, T] spectrum tensor must stay below 2 GB (it sits behind a buffer descriptor)");
     AUD_HIP(c, make_current(c));
     const size_t T = size_t(p->d.segment_steps), tsz = p->d.compute_dtype == AUD_F64 ? 8 : 4;
     aud::MelspecArgs a;

@@ -38,11 +38,17 @@ struct aud_ctx {
     struct Gather {
         int n_ranks = 0, rank = 0;
         int64_t slab = 0;
-        float* recv = nullptr;
+        float* recv = nullptr;             // [2][n_ranks][slab]: consecutive steps alternate between the two slabs
+        unsigned* flags = nullptr;         // kFlagPitch words per rank: [p] = the last step rank p pushed here; behind them
+                                           // this rank's own step counter and its count of timed-out waits
+        bool flags_fine = false;           // the flag block is fine-grained memory (else plain hipMalloc)
         std::vector<float*> peer;          // [n_ranks], peer[rank] = recv
+        std::vector<unsigned*> peer_flags; // [n_ranks], peer_flags[rank] = flags
         std::vector<hipStream_t> streams;  // [n_ranks], null at `rank`
         std::vector<hipEvent_t> done;      // [n_ranks]
         hipEvent_t fork = nullptr;
+        unsigned calls = 0;                // host side: steps issued (slab = calls & 1)
+        long long max_polls = 0;
     } gather;
 };
 

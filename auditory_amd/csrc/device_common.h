@@ -647,6 +647,140 @@ __device__ __forceinline__ void wave_spectrum_range(const MelspecArgs& a, const 
     }
 }
 
+// ---- the same outputs for the several-frames-per-wave kernels (FPW = 4 / 6): a lane keeps ONE BIN and HALF the tile's frames ----
+// lane = 2 b + h: bin 32 i + b in pass i, frames HF h .. HF h + HF - 1 (HF = FPW / 2).  Against the one-frame-per-lane walk above:
+//   * a lane's HF values of a bin are consecutive steps of one PowerSegment row -- ONE 8- / 12-byte store per tensor and pass
+//     instead of HF 4-byte ones (whole-ProcessSegment kernel: 65 -> 18 store instructions per wave; the two lanes of a bin are
+//     neighbours, so their halves of the 16- / 24-byte run reach the texture addresser in the same quarter-wave);
+//   * one output address per pass instead of one per value, no per-value clamp / select chains: the loop body is the
+//     logarithm and little else;
+//   * the Energy sums of the fused segment tail (bin s < T summed over the tile's frames, sndenv.go:360-366) are the
+//     lane's own HF values plus its neighbour's: one lane swap (no second lane geometry, no zero-padded 8-lane blocks).
+// MODE as above.  `full` (wave-uniform): all FPW steps of the tile exist (t0 + FPW <= T) -- the vector stores; the last tile of a
+// segment whose length is not a multiple of FPW takes per-value stores under its column masks.
+// HF consecutive float32 values as ONE buffer store (8 or 12 bytes per lane) through a descriptor over the item's tensor:
+// `voffset` in bytes; a run at or beyond the descriptor's range is dropped by the hardware (bins k >= H of the last pass need
+// no branch).  A 12-byte run written as two instructions (what the compiler makes of a 4-byte-aligned struct store) costs the
+// vector-memory path two passes over the same cache lines -- and that path, not vector issue, is what bounds the
+// whole-ProcessSegment kernel (profiles/round5_sndenv_b4096_*: SQ_VMEM_TA_ADDR_FIFO_FULL).
+template <int HF>
+__device__ __forceinline__ void store_run(const __amdgpu_buffer_rsrc_t& r, int voffset, const float (&v)[HF]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (HF == 3) {
+        typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+        __builtin_amdgcn_raw_buffer_store_b96(u32x3{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2])}, r, voffset, 0, 0);
+    } else {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])}, r, voffset, 0, 0);
+    }
+#else  // (the CPU thread emulator: dword by dword, each under the descriptor's range check)
+#pragma unroll
+    for (int u = 0; u < HF; ++u) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[u]), r, voffset + 4 * u, 0, 0);
+#endif
+}
+template <typename TT, int FPW, int MODE>
+__device__ __forceinline__ void wave_spectrum_halves(const MelspecArgs& a, const float* P, int Hp, const int* exps, const aud_item& it,
+                                                     int item, int t0, int lane, TT* esum) {
+    constexpr int HF = FPW / 2;
+    static_assert(FPW == 2 * HF && (HF == 2 || HF == 3), "half a tile per lane");
+    const int T = a.T, H = a.H;
+    const int h = lane & 1, b = lane >> 1;
+    const bool full = t0 + FPW <= T;  // wave-uniform
+    bool col_on[HF], live[HF];
+    int sc[HF];
+    float scale_f[HF];     // 2^(sc - 2) where that is a float32 (MODE 1 promises it)
+    double scale_d[HF];
+#pragma unroll
+    for (int u = 0; u < HF; ++u) {
+        const int ff = HF * h + u, sstep = t0 + ff;
+        const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
+        col_on[u] = sstep < T;
+        live[u] = start + a.N <= int64_t(it.sig_len);
+        sc[u] = sizeof(TT) == 8 ? frame_scale_of(exps + ff) : 0;
+        scale_d[u] = MODE == 1 ? ldexp(1.0, sc[u] - 2) : 1.0;
+        scale_f[u] = MODE == 1 ? float(scale_d[u]) : 1.f;
+    }
+    const float* prow = P + (HF * h) * Hp;
+    // the item's [H][T] tensors behind buffer descriptors (wave-uniform: one item per tile)
+#ifdef AUD_EXP_SPEC_DROP  // (experiment, profiles/round5_sndenv_store_bound.txt: every spectrum store issued, all dropped by the
+    const int tensor_bytes = 0;  //  range check -- the kernel without its PowerSegment / LogPowerSegment memory traffic)
+#else
+    const int tensor_bytes = H * T * 4;
+#endif
+    const __amdgpu_buffer_rsrc_t rpw = __builtin_amdgcn_make_buffer_rsrc(a.power ? a.power + size_t(item) * H * T : nullptr, 0,
+                                                                         a.power ? tensor_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rlp = __builtin_amdgcn_make_buffer_rsrc(a.log_power ? a.log_power + size_t(item) * H * T : nullptr, 0,
+                                                                         a.log_power ? tensor_bytes : 0, 0x00020000);
+    const int obase = (t0 + HF * h) * 4;
+    const int n_e = esum ? (T + 31) >> 5 : 0;  // passes that hold a bin s < T (fused tail only)
+    const int n_it = (a.power || a.log_power) ? (H + 31) >> 5 : n_e;  // (a lean segment call keeps no spectrum tensors)
+    for (int i = 0; i < n_it; ++i) {
+        const int k = 32 * i + b;
+        const int kc = k < H ? k : H - 1;  // (reads past the last bin are clamped, not skipped)
+        float pwv[HF], lpv[HF];
+        TT wsum = TT(0);
+#pragma unroll
+        for (int u = 0; u < HF; ++u) {
+            const float p4 = prow[u * Hp + kc];
+            float pw, m = 1.f;
+            int ex = 0;
+            bool none = false;
+            if constexpr (sizeof(TT) == 8 && MODE == 0) {
+                pw = ldexpf(p4, sc[u] - 2);
+                m = frexpf(p4, &ex);
+                ex += sc[u] - 2;
+                none = p4 == 0.f;
+            } else if constexpr (sizeof(TT) == 8 && MODE == 1) {
+                pw = p4 * scale_f[u];  // = ldexpf(p4, sc - 2): an exact power of two within float32's range
+                m = frexpf(float(mad(double(p4), scale_d[u], a.dft_log_off)), &ex);  // > 0: never the LogMin case
+            } else if constexpr (sizeof(TT) == 8) {
+                const double pd = ldexp(double(p4), sc[u] - 2);
+                pw = float(pd);
+                const double vv = pd + a.dft_log_off;
+                m = float(frexp(vv, &ex));
+                none = vv == 0.0;
+            } else {
+                pw = 0.25f * p4;
+                const float vv = pw + float(a.dft_log_off);
+                m = frexpf(vv, &ex);
+                none = vv == 0.f;
+            }
+            const bool want_lp = live[u] && a.comp_log_pow;
+            const float lp = !want_lp ? 0.f : none ? float(a.dft_log_min) : mantissa_log(m, ex);
+            pwv[u] = live[u] ? pw : 0.f;
+            lpv[u] = lp;
+            if (i < n_e) {  // wave-uniform
+                TT wide;
+                if constexpr (sizeof(TT) == 8) wide = none ? a.dft_log_min : mantissa_log_wide(m, ex);
+                else wide = lp;
+                wsum += (want_lp && col_on[u]) ? wide : TT(0);  // frames in step order: ((w0 + w1) + w2)
+            }
+        }
+        {
+            const int o = obase + k * T * 4;  // (k >= H: beyond the descriptor's range, dropped)
+            if (full) {
+                if (a.power) store_run<HF>(rpw, o, pwv);
+                if (a.log_power) store_run<HF>(rlp, o, lpv);
+            } else {
+#pragma unroll
+                for (int u = 0; u < HF; ++u) {
+                    const int ou = col_on[u] ? o + 4 * u : 0x7FFFFFF0;  // a step beyond the segment: out of range
+                    if (a.power) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pwv[u]), rpw, ou, 0, 0);
+                    if (a.log_power) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lpv[u]), rlp, ou, 0, 0);
+                }
+            }
+        }
+        if (i < n_e) {
+            // the other half's sum from the neighbouring lane (quad_perm [1,0,3,2]); first half + second half on both lanes
+            TT other;
+            if constexpr (sizeof(TT) == 8) other = dpp_move(wsum, 0);
+            else other = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, wsum), 0xB1, 0xF, 0xF, false));
+            const TT tot = h == 0 ? wsum + other : other + wsum;
+            if (h == 0 && k < T) esum[k] = tot;
+        }
+    }
+}
+
 template <typename TT, int FPW, int W>
 __device__ __forceinline__ void wave_spectrum_pick(const MelspecArgs& a, const float* P, int Hp, const int* exps, int sc1,
                                                    const aud_item& it, int item, int t0, int lane, int k_lo, int k_hi,
@@ -664,23 +798,38 @@ __device__ __forceinline__ void wave_spectrum_pick(const MelspecArgs& a, const f
         wave_spectrum_range<TT, FPW, W, 2>(a, P, Hp, exps, sc1, it, item, t0, lane, k_lo, k_hi, esum);
     }
 }
+template <typename TT, int FPW>
+__device__ __forceinline__ void wave_spectrum_halves_pick(const MelspecArgs& a, const float* P, int Hp, const int* exps,
+                                                          const aud_item& it, int item, int t0, int lane, TT* esum) {
+    if constexpr (sizeof(TT) == 8) {
+        const double off = a.dft_log_off;
+        // MODE 1 multiplies by 2^(sc - 2) in float32 and adds in float64: every frame's scale must keep both normal
+        const int sc = frame_scale_of(exps + lane % FPW);
+        const bool small = __builtin_amdgcn_ballot_w64(sc >= 96 || sc < -100) == 0;
+        if (off == 0.0) wave_spectrum_halves<TT, FPW, 0>(a, P, Hp, exps, it, item, t0, lane, esum);
+        else if (small && off >= 1e-30 && off <= 1e30) wave_spectrum_halves<TT, FPW, 1>(a, P, Hp, exps, it, item, t0, lane, esum);
+        else wave_spectrum_halves<TT, FPW, 2>(a, P, Hp, exps, it, item, t0, lane, esum);
+    } else {
+        wave_spectrum_halves<TT, FPW, 2>(a, P, Hp, exps, it, item, t0, lane, esum);
+    }
+}
 
 template <typename TT, int FPW, bool FUSE>
 __device__ __forceinline__ void wave_spectrum_outputs(const MelspecArgs& a, const float* P, int Hp, const int* exps, int sc1,
                                                       const aud_item& it, int item, int t0, int lane) {
     if (!a.power && !a.log_power && !(FUSE && a.energy_part)) return;
-    if constexpr (FUSE && (FPW == 4 || FPW == 6)) {
-        if (a.energy_part) {  // fused segment tail (T <= H: plan-time check)
-            constexpr int W = FPW == 4 ? 4 : 8;
-            const int tiles = (a.T + FPW - 1) / FPW;
-            TT* esum = static_cast<TT*>(a.energy_part) + (size_t(item) * tiles + t0 / FPW) * a.T;
-            wave_spectrum_pick<TT, FPW, W>(a, P, Hp, exps, sc1, it, item, t0, lane, 0, a.T, esum);
-            if (a.power || a.log_power)
-                wave_spectrum_pick<TT, FPW, FPW>(a, P, Hp, exps, sc1, it, item, t0, lane, a.T, a.H, static_cast<TT*>(nullptr));
-            return;
+    if constexpr (FPW == 4 || FPW == 6) {
+        TT* esum = nullptr;
+        if constexpr (FUSE) {
+            if (a.energy_part) {  // fused segment tail (T <= H: plan-time check): this tile's row of per-bin Energy sums
+                const int tiles = (a.T + FPW - 1) / FPW;
+                esum = static_cast<TT*>(a.energy_part) + (size_t(item) * tiles + t0 / FPW) * a.T;
+            }
         }
+        wave_spectrum_halves_pick<TT, FPW>(a, P, Hp, exps, it, item, t0, lane, esum);
+    } else {
+        wave_spectrum_pick<TT, FPW, FPW>(a, P, Hp, exps, sc1, it, item, t0, lane, 0, a.H, static_cast<TT*>(nullptr));
     }
-    wave_spectrum_pick<TT, FPW, FPW>(a, P, Hp, exps, sc1, it, item, t0, lane, 0, a.H, static_cast<TT*>(nullptr));
 }
 
 // `sc` = the scale of the frame THIS lane reduces (lane % FPW); `exps` = the frames' scale words (null: one frame per wave).

@@ -323,6 +323,10 @@ def main():  # noqa: C901
                          "fallback if RCCL picks a ring for these 8.5 MB slabs")
     ap.add_argument("--no-direct-alt", action="store_true",
                     help="N > 1: do not also time the step with the direct-pattern reassembly (side key `direct_gather`)")
+    ap.add_argument("--dist-timeout", type=float, default=180.0,
+                    help="seconds: torch.distributed's process-group timeout AND the bound on the first (eager) step with the "
+                         "collective in it -- a rank that never arrives makes every other rank exit non-zero with the reason "
+                         "instead of hanging in a captured collective")
     ap.add_argument("--dist-single", action="store_true",
                     help="validation only: run the multi-GPU code path (shard + RCCL all-gather inside the graph) on ONE rank")
     ap.add_argument("--only-headline", action="store_true", help="skip `modes` and `also`")
@@ -351,10 +355,12 @@ def main():  # noqa: C901
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=args.dist_timeout)
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world, timeout=pg_timeout)
     B, K = args.batch, max(1, args.steps)
     sig_code = capi.AUD_I16 if args.sig_dtype == "i16" else capi.AUD_F32
 
@@ -388,13 +394,32 @@ def main():  # noqa: C901
 
     cur = lambda: torch.cuda.current_stream(dev).cuda_stream  # noqa: E731
 
-    def timed_region(launch, n_streams, min_seconds, audio_s_per_step, extra_streams=(), reset=None):
+    def bounded_first_step(launch, what):
+        """ONE eager step with the collective in it, waited for with a deadline (an event polled from the host): a peer that
+        died or never reached this point leaves the collective's kernel spinning for ever -- inside a captured graph that is a
+        hang nobody can attribute.  On the deadline every surviving rank prints the reason and leaves with a non-zero status;
+        os._exit, because a normal exit would wait for the stuck queue."""
+        launch(0, cur())
+        ev = torch.cuda.Event()
+        ev.record()
+        t0 = time.perf_counter()
+        while not ev.query():
+            if time.perf_counter() - t0 > args.dist_timeout:
+                print("FATAL: rank %d: the first step with %s did not complete within %.0f s (a peer missing or stuck?); "
+                      "library says: %r" % (rank, what, args.dist_timeout,
+                                            capi.load().aud_last_error(runtime.get_ctx(local_rank).handle)), file=sys.stderr, flush=True)
+                os._exit(5)
+            time.sleep(0.002)
+
+    def timed_region(launch, n_streams, min_seconds, audio_s_per_step, extra_streams=(), reset=None, even=False):
         """K x repeats steps of launch(i, stream handle); the steps dealt over n_streams streams inside one hipGraph.
         extra_streams: streams launch() itself puts work on (forked from / joined to the capturing stream with the lanes);
         reset(): forget cross-step state (events) recorded outside the graph that is about to be captured"""
         n_streams = max(1, n_streams)
         side = [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
         GK = K * max(1, -(-args.graph_steps // K)) if args.launch == "graph" else K   # steps per replay: a multiple of K
+        if even and GK % 2:   # (the direct gather's two receive slabs must keep alternating across replays)
+            GK *= 2
         for i in range(args.warmup):
             launch(i, cur())
         sync_all()
@@ -604,8 +629,8 @@ def main():  # noqa: C901
                 direct.close()
                 plan.close()
                 raise RuntimeError("direct gather: mapping a peer's buffer failed on a rank (%s)" % err)
-            recv = direct.recv(dev).view(total, wl.nf, wl.T)   # one receive buffer: consecutive steps overwrite it
-            full = [recv, recv]
+            recv = direct.recv(dev).view(2, total, wl.nf, wl.T)   # two receive slabs: consecutive steps alternate between them
+            full = [recv[0], recv[1]]
         else:
             full = [torch.empty((total,) + tuple(mel3[0].shape[1:]), dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
         # RCCL through the library's OWN communicator (aud_comm_* / aud_allgather_dev: ncclAllGather on the stream it is
@@ -625,10 +650,12 @@ def main():  # noqa: C901
                 dist.broadcast_object_list(uid, src=0)
             plan.ctx.check(lib.aud_comm_init(plan.ctx.handle, world, rank, uid[0]))
         done = [None, None]
+        slab_of = [0, 1]   # direct pattern: which receive slab the step with output buffer s used at its last (captured) call
 
         def collect(s, st):
             if direct is not None:
-                direct.allgather(mel3[s].data_ptr(), nb * wl.nf * wl.T, st)
+                slab_of[s] = direct.allgather(mel3[s].data_ptr(), nb * wl.nf * wl.T, st)   # pushes + arrival signals ...
+                direct.wait(st)   # ... and the wait for every peer's: behind it the step's slab is complete HERE (like ncclAllGather)
             elif own_comm:
                 plan.ctx.check(lib.aud_allgather_dev(plan.ctx.handle, mel3[s].data_ptr(), full[s].data_ptr(), nb * wl.nf * wl.T, st))
             elif even:
@@ -659,22 +686,34 @@ def main():  # noqa: C901
         def reset():
             done[0] = done[1] = None
 
+        if gather and world > 1:
+            bounded_first_step(launch, "the direct-pattern gather" if direct is not None else "the all-gather")
         # the gather's stream handling lives in launch(): one lane, the comm stream is the second
         res = timed_region(launch, 1 if gather else 2, min_seconds, total * wl.dur_s,
-                           extra_streams=[comm] if use_streams else (), reset=reset)
+                           extra_streams=[comm] if use_streams else (), reset=reset, even=direct is not None)
         if use_streams:
             torch.cuda.current_stream(dev).wait_stream(comm)
             torch.cuda.synchronize(dev)
         res.update({"workload": wl.name, "compute": compute, "kernel": plan.kernel_name, "total_batch": total,
                     "streams_this_rank": nb, "rccl_ranks": world if gather else 0,
                     "collective": (("direct pattern (aud_allgather_direct_dev: one device-to-device push per peer on its own "
-                                    "stream)" if direct is not None else
+                                    "stream with its arrival signal behind it, then a bounded wait for every peer's signal; two receive "
+                                    "slabs alternate)" if direct is not None else
                                     "ncclAllGather (RCCL, on the library's own communicator: aud_comm_* / aud_allgather_dev)" if own_comm else
                                     "all_gather_into_tensor (torch.distributed)") +
                                    " of this rank's [%d, %d, %d] float32 slab, on a second stream, overlapped with the next "
                                    "step's kernel" % (nb, wl.nf, wl.T)) if gather else "none (one rank)"})
         if gather:
             res["gathered_shape"] = list(full[0].shape)
+            # the direct pattern's floor on a fully connected xGMI node: every rank must RECEIVE world - 1 slabs, one per link
+            # and per step.  AMD quotes 153.6 GB/s per link BIDIRECTIONAL, i.e. 76.8 GB/s per direction -- the figure a push
+            # can use; the bound at the bidirectional figure is printed beside it (what round 4's DESIGN used)
+            slab_bytes = nb * wl.nf * wl.T * 4
+            res["xgmi_bound_us"] = None if world == 1 else {
+                "per_step": round(slab_bytes / 76.8e9 * 1e6, 1), "assumes": "one slab of %d bytes per link and step at 76.8 GB/s per "
+                "direction (153.6 GB/s per link bidirectional)" % slab_bytes, "at_153.6_GBps_per_direction": round(slab_bytes / 153.6e9 * 1e6, 1)}
+        if direct is not None:
+            res["arrival_timeouts"] = int(max_over_ranks(float(direct.timeouts())))
         if rank == 0:  # the (gathered) tensors of the last two steps against the oracle, strict: rows of EVERY rank's block
             from auditory_amd import synth
             osd = OracleSide(wl)
@@ -682,8 +721,8 @@ def main():  # noqa: C901
             for r in range(world if gather else 1):
                 rlo, rhi = shard_range(total, r, world)
                 idx = np.arange(0, rhi - rlo, max(1, (rhi - rlo) // per_rank))[:per_rank]
-                for s in ((0, 1) if direct is None else ((res["graph_steps"] - 1) % 2,)):
-                    src = full[s][rlo:rhi] if gather else mel3[s]
+                for s in (0, 1):
+                    src = (full[slab_of[s] if direct is not None else s][rlo:rhi]) if gather else mel3[s]
                     got.append(src.cpu().numpy()[idx])
                     if r == 0:
                         pcm = ring.pcm[ring_row[s][idx]]
@@ -703,6 +742,9 @@ def main():  # noqa: C901
             sync_all()
             plan.ctx.check(lib.aud_comm_destroy(plan.ctx.handle))
         plan.close()
+        if res.get("arrival_timeouts"):   # (the same count on every rank: max over ranks)
+            raise RuntimeError("direct gather: %d arrival waits ran into their poll bound (AUD_GATHER_WAIT_MS): a peer's slab "
+                               "never arrived -- the numbers of this region mean nothing" % res["arrival_timeouts"])
         return res
 
     # ---------------------------------------------------------------------------------------------------
@@ -854,20 +896,23 @@ def main():  # noqa: C901
     }
     if cfg3 is not None:
         line["rccl_ranks"] = cfg3["rccl_ranks"]
+        line["xgmi_bound_us"] = cfg3.get("xgmi_bound_us")
+        if "arrival_timeouts" in cfg3:
+            line["arrival_timeouts"] = cfg3["arrival_timeouts"]
         line["collective"] = cfg3["collective"]
         line["gathered_shape"] = cfg3.get("gathered_shape")
         line["no_collective"] = {k: head[k] for k in ("value", "steps", "ms_per_step", "us_per_step_device", "launch", "streams",
                                                       "batch", "parity") if k in head}
         if direct_alt is not None:
             line["direct_gather"] = ({k: direct_alt[k] for k in ("value", "steps", "ms_per_step", "us_per_step_device", "launch",
-                                                                 "collective", "parity") if k in direct_alt}
+                                                                 "collective", "parity", "arrival_timeouts", "xgmi_bound_us")
+                                      if k in direct_alt}
                                      if "error" not in direct_alt else direct_alt)
             if "error" not in direct_alt:
                 line["direct_gather"]["note"] = (
-                    "pushes only: every step writes the ONE receive buffer, a rank's graph joins its own pushes but never waits "
-                    "for its peers' data to ARRIVE (no per-step arrival flag), while ncclAllGather returns with every rank's slab "
-                    "in place -- so this side key flatters the direct pattern by the cross-rank completion a consumer needs; "
-                    "parity is checked on the last step's buffer after a barrier")
+                    "like for like with ncclAllGather: every step ends, inside the graph, with the wait for every peer's arrival "
+                    "flag (stored by the peer behind its push, system scope), two receive slabs alternate; parity is checked on "
+                    "both slabs; arrival_timeouts counts waits that ran into their poll bound (must be 0)")
         line["no_collective"]["note"] = "the sharded step without the collective: %d utterances per rank and step (weak scaling)" % B
     if modes:
         line["modes"] = modes

@@ -424,19 +424,32 @@ int aud_allgather_dev(aud_ctx* ctx, const float* send, float* recv, int64_t coun
 /* The same reassembly as DIRECT device-to-device copies (the 8 GPUs of a node are fully connected, 7 xGMI
  * links per GPU, so an all-gather is one push per peer, each on its own link and its own stream -- what a ring collective,
  * per-link bound with 7 serial hops, cannot do for messages of a few MB).  Set-up, once per (context, shape):
- *   aud_gather_create   allocates this rank's receive buffer [n_ranks][slab_floats] float32 on the device and exports
- *                       its 64-byte inter-process handle; the host program distributes the handles (any channel)
- *   aud_gather_open_peer  maps peer `peer`'s receive buffer from its handle (not needed, and refused, for peer == rank)
- * Per batch:
- *   aud_allgather_direct_dev  copies send[0 .. count) into slot `rank` of EVERY rank's receive buffer (its own included):
- *                       n_ranks - 1 peer copies on n_ranks - 1 internal streams forked from and joined back into `stream`
- *                       (capturable into a hipGraph).  count <= slab_floats.  When `stream` has passed the call, THIS
- *                       rank's pushes are done; a rank's receive buffer is complete once EVERY rank's call has completed --
- *                       the host program orders that (a barrier, or the next step's own synchronisation).
- *   aud_gather_destroy  unmaps the peers, frees the buffer. */
-int aud_gather_create(aud_ctx* ctx, int n_ranks, int rank, int64_t slab_floats, float** recv, char handle[64]);
-int aud_gather_open_peer(aud_ctx* ctx, int peer, const char handle[64]);
-int aud_allgather_direct_dev(aud_ctx* ctx, const float* send, int64_t count, void* stream);
+ *   aud_gather_create   allocates this rank's receive area -- TWO slabs [2][n_ranks][slab_floats] float32 that consecutive
+ *                       steps alternate between -- and a block of arrival flags on the device, and exports their two 64-byte
+ *                       inter-process handles (128 bytes); the host program distributes the handles (any channel)
+ *   aud_gather_open_peer  maps peer `peer`'s receive area and flags from its handles (not needed, and refused, for peer == rank)
+ * Per step (every rank makes the same sequence of calls):
+ *   aud_allgather_direct_dev  copies send[0 .. count) into slot `rank` of the step's slab of EVERY rank (its own included):
+ *                       n_ranks - 1 peer copies on n_ranks - 1 internal streams forked from and joined back into `stream`, each
+ *                       followed by a one-thread kernel that stores this rank's step number into the peer's flag for it
+ *                       (system-scope release).  count <= slab_floats.  *slab_index (may be NULL) = the slab this step
+ *                       uses: 0, 1, 0, ... per call.  When `stream` has passed the call THIS rank's pushes are done.
+ *   aud_gather_wait_dev  the ARRIVAL side of the same step: a kernel on `stream` polls this rank's flags until every peer's
+ *                       has reached this rank's step number, i.e. every peer's slab of the step has landed -- behind it the
+ *                       step's slab is complete and kernels queued on `stream` may read it (what ncclAllGather's return means).
+ *                       The poll is bounded (AUD_GATHER_WAIT_MS, default 2000 ms of polling): a peer that never arrives ends
+ *                       the kernel with the time-out counted, never a hung queue; aud_gather_timeouts reads the count.
+ *   Both are capturable into a hipGraph (step numbers live in device memory and advance per replay; a captured sequence
+ *   must hold an EVEN number of steps so that the slabs keep alternating across replays).  Reuse: the peers' step i + 2
+ *   overwrites the slab of step i, and a peer cannot start step i + 2 before this rank has signalled step i + 1 -- so
+ *   everything that reads the slab of step i must be ordered on `stream` before this rank's call of step i + 1.
+ *   aud_gather_destroy  unmaps the peers, frees the buffers. */
+int aud_gather_create(aud_ctx* ctx, int n_ranks, int rank, int64_t slab_floats, float** recv, char handle[128]);
+int aud_gather_open_peer(aud_ctx* ctx, int peer, const char handle[128]);
+int aud_allgather_direct_dev(aud_ctx* ctx, const float* send, int64_t count, int* slab_index, void* stream);
+int aud_gather_wait_dev(aud_ctx* ctx, void* stream);
+/* waits that ended on their poll bound since aud_gather_create (synchronises `ctx`'s device first) */
+int aud_gather_timeouts(aud_ctx* ctx, int* n);
 int aud_gather_destroy(aud_ctx* ctx);
 
 #ifdef __cplusplus

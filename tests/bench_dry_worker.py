@@ -15,6 +15,10 @@ import test_bench_dryrun as T  # noqa: E402
 
 mp = pytest.MonkeyPatch()
 T._patch(mp)
+if os.environ.get("AUD_DRY_DIE_IN_COLLECTIVE") == os.environ.get("RANK"):
+    # fault injection for test_bench_dry_run_peer_dies: this rank vanishes at the moment it would enter the path's collective
+    import torch.distributed as dist  # noqa: E402
+    mp.setattr(dist, "all_gather_into_tensor", lambda *a, **k: os._exit(9))
 with backend.emulated("plain"):
     bench.main()
 mp.undo()

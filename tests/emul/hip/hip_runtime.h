@@ -149,6 +149,16 @@ enum { hipHostMallocDefault = 0 };
 inline hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
 inline hipError_t hipHostFree(void* p) { return hipFree(p); }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
+// the direct all-gather's arrival flags (capi_comm.hip): fine-grained memory is ordinary memory here, system-scope atomics are
+// the compiler's, and the bounded poll's sleep is nothing
+enum { hipDeviceMallocFinegrained = 1 };
+inline hipError_t hipExtMallocWithFlags(void** p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
+inline hipError_t hipMemset(void* dst, int value, size_t bytes) { std::memset(dst, value, bytes); return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
+inline void __builtin_amdgcn_s_sleep(int) {}
 // (the handle also carries the exporting process: "device" memory here is a process's own heap, so a handle of ANOTHER
 // process cannot be mapped -- opening it fails the way a box without IPC support fails, instead of handing out a wild pointer)
 inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) {

@@ -7,6 +7,8 @@ import time
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.dirname(HERE), HERE]
 
+os.environ.setdefault("AUD_GATHER_WAIT_MS", "30000")   # (process start-up skew between the two workers, not link time)
+
 import torch  # noqa: E402
 
 from auditory_amd import runtime  # noqa: E402
@@ -40,24 +42,41 @@ def main():
     torch.cuda.synchronize()
     open(os.path.join(d, "ready%d" % rank), "w").close()               # buffers initialised on both sides before any push
     wait_for(os.path.join(d, "ready%d" % other))
-    send = torch.arange(slab, dtype=torch.float32, device=dev) + 1000.0 * (rank + 1)
+    sends = [torch.arange(slab, dtype=torch.float32, device=dev) + 1000.0 * (rank + 1) + 7.0 * step for step in range(2)]
     count = slab if rank == 0 else slab - 7
-    if rank == 0:   # the fork / join of the per-peer streams is capturable
+    # four steps, NO host-side barrier between the ranks: every step = pushes + arrival signal, then the (bounded) wait for the
+    # peer's flag, behind which a kernel of THIS rank reads the step's slab (`seen`).  Rank 0 runs them as a captured pair of
+    # steps replayed twice (the fork / join of the per-peer streams, the signal and the wait are capturable; the step numbers
+    # live on the device and advance per replay), rank 1 eagerly.
+    seen = torch.zeros((4, 2, slab), dtype=torch.float32, device=dev)
+
+    def step(i, out):
+        st = torch.cuda.current_stream(dev).cuda_stream
+        which = g.allgather(sends[i % 2].data_ptr(), count, st)
+        assert which == i % 2
+        g.wait(st)
+        out.copy_(recv[which])          # on the same stream, behind the wait: the slab must be complete here
+
+    if rank == 0:
         graph = torch.cuda.CUDAGraph()
+        pair = torch.zeros((2, 2, slab), dtype=torch.float32, device=dev)
         with torch.cuda.graph(graph):
-            g.allgather(send.data_ptr(), count, torch.cuda.current_stream(dev).cuda_stream)
-        graph.replay()
+            for i in range(2):
+                step(i, pair[i])
+        for rep in range(2):
+            graph.replay()
+            seen[2 * rep:2 * rep + 2].copy_(pair)
     else:
-        g.allgather(send.data_ptr(), count, torch.cuda.current_stream(dev).cuda_stream)
+        for i in range(4):
+            step(i, seen[i])
     torch.cuda.synchronize()
-    open(os.path.join(d, "pushed%d" % rank), "w").close()              # the host-side barrier the contract asks for
-    wait_for(os.path.join(d, "pushed%d" % other))
-    torch.cuda.synchronize()
-    got = recv.cpu()
-    for r, n in ((0, slab), (1, slab - 7)):
-        want = torch.arange(n, dtype=torch.float32) + 1000.0 * (r + 1)
-        assert torch.equal(got[r, :n], want), (rank, r)
-        assert bool((got[r, n:] == -1.0).all()), (rank, r)
+    assert g.timeouts() == 0, "an arrival wait ran into its poll bound"
+    got = seen.cpu()
+    for i in range(4):
+        for r, n in ((0, slab), (1, slab - 7)):
+            want = torch.arange(n, dtype=torch.float32) + 1000.0 * (r + 1) + 7.0 * (i % 2)
+            assert torch.equal(got[i, r, :n], want), (rank, i, r)
+            assert bool((got[i, r, n:] == -1.0).all()), (rank, i, r)
     open(os.path.join(d, "checked%d" % rank), "w").close()             # keep the buffers alive until both have read them
     wait_for(os.path.join(d, "checked%d" % other))
     g.close()

@@ -30,6 +30,9 @@ class _Event:
     def elapsed_time(self, other):
         return max(1e-6, (other._t - self._t) * 1e3)
 
+    def query(self):
+        return True   # (the emulator's launches are synchronous)
+
 
 class _Graph:
     def __init__(self):
@@ -183,6 +186,33 @@ def test_smoke_dry_run(monkeypatch, capsys):
         G.smoke()
     out = capsys.readouterr().out
     assert "smoke ok: strict float64 w20x10" in out and "smoke strict float64 w20x10 mel" in out and "RELAXED float32 w16x16" in out
+
+
+def test_bench_dry_run_peer_dies(tmp_path):
+    """a rank that dies at the collective must not leave the other one hanging: the survivor exits NON-ZERO within the
+    --dist-timeout it was given (process-group timeout + the bounded first step of bench.py's collective region)"""
+    import socket
+    import subprocess
+    import time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = os.path.join(HERE, "bench_dry_worker.py")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", AUD_DRY_DIE_IN_COLLECTIVE="1")
+        procs.append(subprocess.Popen([sys.executable, worker, "--gpus", "2", "--steps", "2", "--warmup", "1",
+                                       "--batch", "2", "--ring-mb", "0.2", "--min-seconds", "0", "--cfg3-total", "6",
+                                       "--dist-backend", "gloo", "--dist-timeout", "20"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    t0 = time.time()
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert procs[1].returncode == 9, outs[1][1][-1500:]                       # the injected death
+    assert procs[0].returncode not in (0, None), "the survivor reported success: " + outs[0][0][-500:]
+    assert time.time() - t0 < 200
+    assert not any(ln.startswith("{") for ln in outs[0][0].splitlines()), "no JSON line from a broken job"
 
 
 def test_device_api_tests_dry_run(monkeypatch, orc):

@@ -72,16 +72,27 @@ def test_direct_allgather_indexing_emulated():
             g.open_peers([x.handle for x in gs])
         with pytest.raises(capi.AuditoryError):
             gs[0].open_peers([x.handle for x in gs])                  # twice
-        bufs = [np.ctypeslib.as_array(C.cast(g.recv_ptr, C.POINTER(C.c_float)), shape=(G, slab)) for g in gs]
-        for rnd, counts in enumerate(([1000, 700, 1], [5, 1000, 999])):
+        bufs = [np.ctypeslib.as_array(C.cast(g.recv_ptr, C.POINTER(C.c_float)), shape=(2, G, slab)) for g in gs]
+        for rnd, counts in enumerate(([1000, 700, 1], [5, 1000, 999], [1, 2, 3])):
             for b in bufs:
-                b[:] = -1.0
+                b[rnd & 1] = -1.0
             sends = [np.arange(counts[r], dtype=np.float32) + 1000.0 * (r + 1) + rnd for r in range(G)]
             for r in range(G):
-                gs[r].allgather(sends[r].ctypes.data, counts[r])
+                assert gs[r].allgather(sends[r].ctypes.data, counts[r]) == rnd & 1     # the slabs alternate per step
+            for r in range(G):
+                gs[r].wait()                                                            # every peer's flag has reached this step
+            assert [g.timeouts() for g in gs] == [0] * G
             for b in bufs:
                 for r in range(G):
-                    assert np.array_equal(b[r, :counts[r]], sends[r]) and (b[r, counts[r]:] == -1.0).all()
+                    assert np.array_equal(b[rnd & 1, r, :counts[r]], sends[r]) and (b[rnd & 1, r, counts[r]:] == -1.0).all()
+            if rnd == 1:      # the previous step's slab is untouched by this one
+                assert bufs[0][0, 0, 0] == 1000.0 and bufs[0][0, 1, 0] == 2000.0
+        # a peer that never arrives: the wait ENDS at its poll bound and is counted (never a hung queue)
+        gs[0].allgather(sends[0].ctypes.data, 1)
+        gs[0].wait()
+        assert gs[0].timeouts() == G - 1
+        for r in range(1, G):
+            gs[r].allgather(sends[r].ctypes.data, 1)
         with pytest.raises(capi.AuditoryError):
             gs[1].allgather(sends[1].ctypes.data, slab + 1)           # more than the slab
         for g in gs:

@@ -48,6 +48,11 @@ for step in "$@"; do
                 run mfma 120 /tmp/mfma_beside_valu ;;
         stream) (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -DSTREAM_READ_MAIN -o /tmp/stream_read stream_read.hip) &&
                 run stream 120 /tmp/stream_read ;;
+        runlib:*) args=$(echo "${step#runlib:}" | tr ',' ' ')   # runlib:TAG,script.py,args...  (an experimental build, tools/run_with_lib.py)
+               run runlib$i 400 python tools/run_with_lib.py $args
+               grep '^{' "gpurun_out/${TAG}_runlib$i.log" | tail -1 > "gpurun_out/${TAG}_runlib$i.json" ;;
+        wstream) (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/stream_write stream_write.hip) &&
+                run wstream 120 /tmp/stream_write ;;
         two_ranks) run two_ranks 500 bash tools/two_ranks_one_gpu.sh "${TAG}_two" ;;
         hostcall) run hostcall 300 python tools/host_call_time.py ;;
         dispatch) (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/dispatch_rate dispatch_rate.hip) &&
