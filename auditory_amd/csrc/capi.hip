@@ -132,6 +132,17 @@ int aud_shutdown(aud_ctx* c) {
     (void)hipSetDevice(c->device);
     aud_comm_destroy(c);
     aud_gather_destroy(c);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    {  // resident signals of this context: their memory goes with it, the handles stay valid for aud_signal_destroy
+        SignalRegistry& reg = SignalRegistry::get();
+        std::lock_guard<std::mutex> lk(reg.m);
+        for (aud_signal* s : reg.live)
+            if (s->ctx == c) {
+                if (s->d) (void)hipFree(s->d);
+                s->d = nullptr;
+                s->ctx = nullptr;
+            }
+    }
     for (int i = 0; i < 4; ++i)
         if (c->ws[i]) (void)hipFree(c->ws[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);

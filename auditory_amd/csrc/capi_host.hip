@@ -114,15 +114,29 @@ int aud_signal_upload(aud_ctx* c, const void* samples, int sample_dtype, int64_t
         delete s;
         return hip_fail(c, e, "aud_signal_upload");
     }
+    {
+        SignalRegistry& reg = SignalRegistry::get();
+        std::lock_guard<std::mutex> lk(reg.m);
+        reg.live.push_back(s);
+    }
     *out = s;
     return AUD_OK;
 }
 
 int aud_signal_destroy(aud_signal* s) {
     if (!s) return AUD_EINVAL;
-    (void)hipSetDevice(s->ctx->device);
+    aud_ctx* c = nullptr;
     {
-        HostCallGuard guard(s->ctx);  // (drains the context's stream: no call still reads the buffer)
+        SignalRegistry& reg = SignalRegistry::get();
+        std::lock_guard<std::mutex> lk(reg.m);
+        auto it = std::find(reg.live.begin(), reg.live.end(), s);
+        if (it == reg.live.end()) return AUD_EINVAL;  // not a live handle (destroyed twice?)
+        reg.live.erase(it);
+        c = s->ctx;  // null: the context was shut down first and took the device memory with it
+    }
+    if (c) {
+        (void)hipSetDevice(c->device);
+        HostCallGuard guard(c);  // (drains the context's stream: no call still reads the buffer)
         if (s->d) (void)hipFree(s->d);
     }
     delete s;
@@ -135,7 +149,7 @@ int aud_melspec_batch_sig(aud_plan* p, const aud_signal* s, const aud_item* item
                           double* log_power) {
     if (!p) return AUD_EINVAL;
     aud_ctx* c = p->ctx;
-    if (!s || s->ctx != c) return fail(c, AUD_EINVAL, "signal of another context (or null)");
+    if (!s || s->ctx != c) return fail(c, AUD_EINVAL, "signal of another (or a shut-down) context, or null");
     if (n_items < 0 || (n_items > 0 && (!items || !mel))) return fail(c, AUD_EINVAL, "null buffer");
     if (n_items == 0) return AUD_OK;
     int rc = check_items(c, items, n_items, s->n);

@@ -52,12 +52,23 @@ struct aud_ctx {
     } gather;
 };
 
-// a signal resident on the device between calls (aud_signal_upload)
+// a signal resident on the device between calls (aud_signal_upload).  The context keeps a list of its live signals:
+// aud_shutdown frees their device memory and detaches them (ctx = nullptr), so that an aud_signal_destroy BEHIND the shutdown
+// -- a destructor running late -- frees the handle and touches nothing of the dead context
 struct aud_signal {
     aud_ctx* ctx = nullptr;
     void* d = nullptr;
     int dtype = 0;
     int64_t n = 0;
+};
+// every handle that is alive and the context it belongs to (a destroy on a detached handle must not touch a dead context's mutex)
+struct SignalRegistry {
+    std::mutex m;
+    std::vector<aud_signal*> live;
+    static SignalRegistry& get() {
+        static SignalRegistry r;
+        return r;
+    }
 };
 
 struct aud_plan {
@@ -164,11 +175,12 @@ inline int ensure_pin(aud_ctx* c, size_t bytes) {
         c->pin = nullptr;
         c->pin_cap = 0;
     }
+    // (the events first: a failure here must not leave pin_cap saying "ready" with null events behind it)
+    for (auto& e : c->pin_ev)
+        if (!e) AUD_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const size_t cap = bytes + bytes / 4 + 4096;
     AUD_HIP(c, hipHostMalloc(&c->pin, cap, hipHostMallocDefault));
     c->pin_cap = cap;
-    for (auto& e : c->pin_ev)
-        if (!e) AUD_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return AUD_OK;
 }
 

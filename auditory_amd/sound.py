@@ -185,12 +185,17 @@ class SndEnv:
         self._device = device
         self._compute_dtype = compute_dtype
         self._plan = None
-        self._dev_sig = self._dev_sig_of = None
+        # ProcessSegment runs once per segment on the SAME Signal (sndenv.go:342-359): the device keeps a copy of it between
+        # calls (aud_signal_upload), re-taken when the tensor is another one (ToTensor, AdjustForSilence, an assignment), has
+        # another length, or differs in a sampled fingerprint; SignalChanged() after an in-place edit.  False: copy per call.
+        self.ResidentSignal = True
+        self._dev_sig = self._dev_sig_key = None
 
     def ToTensor(self):
         """sound/sndenv.go:297-300: Signal <- Sound.SoundToTensor()"""
         self.Signal = self.Sound.SoundToTensor()
         self.SampleRate, self.Channels = self.Sound.SampleRate(), self.Sound.Channels()
+        self.SignalChanged()
         return True
 
     def ParamDefaults(self):
@@ -249,9 +254,7 @@ class SndEnv:
         self.SegCnt = lib.aud_seg_cnt(len(self.Signal), p.SegmentSamples, p.StrideSamples,
                                       self.Channels)
         self._plan_key = None
-        if self._dev_sig is not None:      # (a resident copy belongs to the Signal it was taken from)
-            self._dev_sig.close()
-            self._dev_sig = None
+        self._drop_resident()              # (a resident copy belongs to the Signal it was taken from)
         self._ensure_plan()
         return None
 
@@ -279,18 +282,37 @@ class SndEnv:
                                   self.GaborFilters.Filters if has_g else None, self._compute_dtype,
                                   mfcc_coefs=self.Mel.NCoefs if self.Mel.MFCC else 0)
 
-    def SignalToDevice(self):
-        """New, opt-in: keep a copy of self.Signal on the device (aud_signal_upload) so that ProcessSegment(s) send only the
-        work items and fetch only the results -- the reference's loop calls ProcessSegment once per segment on the same
-        Signal.  A SNAPSHOT: call it again whenever self.Signal changes; Init drops it."""
+    def _drop_resident(self):
         if self._dev_sig is not None:
             self._dev_sig.close()
+        self._dev_sig = self._dev_sig_key = None
+
+    def _signal_key(self):
+        """what the resident copy is valid for: the tensor's memory, its length and type, and a fingerprint of <= 64 samples
+        spread over it (an in-place edit that touches none of them needs SignalChanged())"""
+        sig = self.Signal
+        n = len(sig)
+        probe = np.ascontiguousarray(sig[::max(1, n // 61)][:63]).tobytes() + (np.asarray(sig[-1:]).tobytes() if n else b"")
+        return (sig.__array_interface__["data"][0], n, sig.dtype.str, sig.strides, hash(probe))
+
+    def SignalChanged(self):
+        """New: call after changing samples of self.Signal IN PLACE -- the next ProcessSegment uploads the tensor again.
+        (ToTensor, AdjustForSilence, Init and assigning another array are noticed without it.)"""
+        self._dev_sig_key = None
+
+    def SignalToDevice(self):
+        """New: (re)take the device's copy of self.Signal NOW (aud_signal_upload); ProcessSegment(s) then send only the work
+        items and fetch only the results.  With ResidentSignal (the default) the first ProcessSegment does this itself."""
+        self._drop_resident()
         self._dev_sig = runtime.Signal(runtime.get_ctx(self._device), np.ascontiguousarray(self.Signal, np.float64))
-        self._dev_sig_of = self.Signal
+        self._dev_sig_key = self._signal_key()
 
     def _resident(self):
-        ok = self._dev_sig is not None and self._dev_sig_of is self.Signal and self._dev_sig.n == len(self.Signal)
-        return self._dev_sig if ok else None
+        if not self.ResidentSignal or len(self.Signal) == 0:
+            return None
+        if self._dev_sig is None or self._dev_sig_key != self._signal_key():
+            self.SignalToDevice()
+        return self._dev_sig
 
     def _item(self, segment, add):
         start0 = segment * self.Params.StrideSamples + MSecToSamples(add, self.SampleRate)
@@ -400,6 +422,7 @@ class SndEnv:
             self.Signal = self.Signal[-delta.value:]
         elif delta.value > 0:
             self.Signal = np.concatenate([np.zeros(delta.value), self.Signal])
+        self.SignalChanged()
         return off
 
     def Tail(self, signal):

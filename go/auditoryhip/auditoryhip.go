@@ -20,6 +20,7 @@ import (
 	"github.com/emer/vision/kwta"
 	"errors"
 	"fmt"
+	"math"
 	"sync"
 	"unsafe"
 )
@@ -35,6 +36,7 @@ type Plan struct {
 	Steps    int // SegmentSteps (T)
 	Bins     int // WinSamples/2 + 1 (H)
 	NGabor   int
+	NCoefs   int // mfcc_coefs of the plan (0: no MFCC tail)
 }
 
 // Item is one segment of one mono stream: see aud_item in auditory_hip.h (same layout, 24 bytes).
@@ -97,7 +99,7 @@ func GaborToTensor(specs []C.aud_gabor_spec, set *C.aud_gabor_set, out []float64
 // gaborFilters: FilterSet.Filters.Values [nG*SizeY*SizeX] or nil.
 func (c *Ctx) NewPlan(desc *C.aud_plan_desc, binPts []int32, melFilters, gaborFilters []float64) (*Plan, error) {
 	p := &Plan{ctx: c, NFilters: int(desc.mel.n_filters), Steps: int(desc.segment_steps),
-		Bins: int(desc.win_samples)/2 + 1, NGabor: int(desc.n_gabor)}
+		Bins: int(desc.win_samples)/2 + 1, NGabor: int(desc.n_gabor), NCoefs: int(desc.mfcc_coefs)}
 	var gk *C.double
 	if len(gaborFilters) > 0 {
 		gk = (*C.double)(unsafe.Pointer(&gaborFilters[0]))
@@ -525,10 +527,37 @@ func (p *Plan) MelSpecMFCC(sig []float64, items []Item, mel, power, logPower, mf
 
 // Signal is a signal kept resident on the device between calls (aud_signal_upload): SndEnv.ProcessSegment runs once per
 // segment on the SAME Signal tensor (sound/sndenv.go:342-359), so the host-buffer calls above move the whole tensor over
-// the link again for every segment.  A snapshot: upload again after changing the samples.
+// the link again for every segment.  A snapshot: upload again after changing the samples (SndEnv does, keyed on SignalKey).
 type Signal struct {
 	h   *C.aud_signal
 	ctx *Ctx
+}
+
+// SignalKey is what a resident copy of a []float64 is valid for: the slice's memory, its length, and a fingerprint of up
+// to 64 samples spread over it (an in-place edit that touches none of them needs SndEnv.SignalChanged).
+type SignalKey struct {
+	Data  unsafe.Pointer
+	N     int
+	Probe uint64
+}
+
+// KeyOf computes the SignalKey of sig (FNV-1a over the probed samples' bits; a few dozen loads whatever the length).
+func KeyOf(sig []float64) SignalKey {
+	k := SignalKey{N: len(sig), Probe: 1469598103934665603}
+	if len(sig) == 0 {
+		return k
+	}
+	k.Data = unsafe.Pointer(&sig[0])
+	step := len(sig) / 61
+	if step == 0 {
+		step = 1
+	}
+	mix := func(v float64) { k.Probe = (k.Probe ^ math.Float64bits(v)) * 1099511628211 }
+	for i, c := 0, 0; i < len(sig) && c < 63; i, c = i+step, c+1 {
+		mix(sig[i])
+	}
+	mix(sig[len(sig)-1])
+	return k
 }
 
 // UploadSignal copies SndEnv.Signal.Values to the device once.
@@ -587,6 +616,29 @@ func (p *Plan) MelSpecSig(sig *Signal, items []Item, mel, power, logPower []floa
 
 // MelSpecMFCCSig is MelSpecMFCC on a resident signal.
 func (p *Plan) MelSpecMFCCSig(sig *Signal, items []Item, mel, power, logPower, mfcc, deltas, deltaDeltas, energy []float64) error {
+	if len(items) == 0 {
+		return nil
+	}
+	if sig == nil || sig.h == nil {
+		return errors.New("auditory_hip: nil signal")
+	}
+	n, h := len(items), p.Bins
+	if len(mel) < n*p.NFilters*p.Steps || len(mfcc) < n*p.NCoefs*p.Steps {
+		return errors.New("auditory_hip: mel / mfcc buffer too small")
+	}
+	for _, b := range [][]float64{power, logPower} {
+		if len(b) != 0 && len(b) < n*h*p.Steps {
+			return errors.New("auditory_hip: spectrum buffer too small")
+		}
+	}
+	for _, b := range [][]float64{deltas, deltaDeltas} {
+		if len(b) != 0 && len(b) < n*p.NCoefs*p.Steps {
+			return errors.New("auditory_hip: delta buffer too small")
+		}
+	}
+	if len(energy) != 0 && len(energy) < n*p.Steps {
+		return errors.New("auditory_hip: energy buffer too small")
+	}
 	ptr := func(s []float64) *C.double {
 		if len(s) == 0 {
 			return nil

@@ -87,7 +87,13 @@ type SndEnv struct {
 	plan    *auditoryhip.Plan       // device plan of planKey's parameters (segmentPlan rebuilds it when they change)
 	planKey planKey
 	derived auditoryhip.SoundParams // what Init derived (sample counts, steps)
-	devSig  *auditoryhip.Signal     // SignalToDevice: the resident copy of Signal ProcessSegment reads (nil: upload per call)
+	// ProcessSegment runs once per segment on the SAME Signal (sndenv.go:342-359): the device keeps a copy of it between
+	// calls, re-taken when Signal.Values is other memory, has another length or differs in a sampled fingerprint
+	// (auditoryhip.KeyOf); SignalChanged() after an in-place edit that may miss the probed samples.
+	// HostSignalPerCall = true: copy the tensor on every call instead (the zero value keeps it resident).
+	HostSignalPerCall bool
+	devSig            *auditoryhip.Signal
+	devSigKey         auditoryhip.SignalKey
 }
 
 // ParamDefaults: sound/sndenv.go:64-71.
@@ -175,8 +181,7 @@ func (se *SndEnv) Init() (err error) {
 		se.plan.Close()
 		se.plan = nil
 	}
-	se.devSig.Close() // (a resident copy belongs to the Signal it was taken from)
-	se.devSig = nil
+	se.dropResident() // (a resident copy belongs to the Signal it was taken from)
 	se.derived = d
 	_, err = se.segmentPlan()
 	return err
@@ -228,19 +233,42 @@ func (se *SndEnv) segmentPlan() (*auditoryhip.Plan, error) {
 	return p, nil
 }
 
-// SignalToDevice (new, opt-in): keep a copy of se.Signal on the device so that ProcessSegment / ProcessSegments send only
-// the work items and fetch only the results -- the reference's loop calls ProcessSegment once per segment on the same
-// Signal, and without this every call moves the whole tensor over the link again.  The copy is a SNAPSHOT: call it after
-// ToTensor / Pad / AdjustForSilence, and again whenever se.Signal.Values changes; Init drops it.
+func (se *SndEnv) dropResident() {
+	se.devSig.Close()
+	se.devSig, se.devSigKey = nil, auditoryhip.SignalKey{}
+}
+
+// SignalChanged (new): call after changing samples of se.Signal.Values IN PLACE -- the next ProcessSegment uploads the
+// tensor again.  (ToTensor, AdjustForSilence, Init, another slice or another length are noticed without it.)
+func (se *SndEnv) SignalChanged() { se.devSigKey = auditoryhip.SignalKey{} }
+
+// SignalToDevice (new): (re)take the device's copy of se.Signal NOW, so that ProcessSegment / ProcessSegments send only the
+// work items and fetch only the results.  The first ProcessSegment after Init does this by itself unless HostSignalPerCall.
 func (se *SndEnv) SignalToDevice() (err error) {
 	if se.ctx == nil {
 		if se.ctx, err = auditoryhip.Default(); err != nil {
 			return err
 		}
 	}
-	se.devSig.Close()
-	se.devSig, err = se.ctx.UploadSignal(se.Signal.Values)
+	se.dropResident()
+	if se.devSig, err = se.ctx.UploadSignal(se.Signal.Values); err == nil {
+		se.devSigKey = auditoryhip.KeyOf(se.Signal.Values)
+	}
 	return err
+}
+
+// resident: the device copy ProcessSegment may read, taken or re-taken as needed (nil: copy per call)
+func (se *SndEnv) resident() *auditoryhip.Signal {
+	if se.HostSignalPerCall || len(se.Signal.Values) == 0 {
+		return nil
+	}
+	if se.devSig == nil || se.devSigKey != auditoryhip.KeyOf(se.Signal.Values) {
+		if err := se.SignalToDevice(); err != nil {
+			fmt.Println(err)
+			return nil
+		}
+	}
+	return se.devSig
 }
 
 func (se *SndEnv) item(segment, add int) auditoryhip.Item {
@@ -261,10 +289,11 @@ func (se *SndEnv) ProcessSegment(segment, add int) {
 		fmt.Println(err)
 		return
 	}
-	resident := se.devSig != nil && se.devSig.Len() == len(se.Signal.Values)
+	dev := se.resident()
+	resident := dev != nil
 	if se.Mel.MFCC {
 		if resident {
-			err = plan.MelSpecMFCCSig(se.devSig, items, se.MelFBankSegment.Values, se.PowerSegment.Values,
+			err = plan.MelSpecMFCCSig(dev, items, se.MelFBankSegment.Values, se.PowerSegment.Values,
 				se.LogPowerSegment.Values, se.MFCCSegment.Values, se.MFCCDeltas.Values, se.MFCCDeltaDeltas.Values, se.Energy.Values)
 		} else {
 			err = plan.MelSpecMFCC(se.Signal.Values, items, se.MelFBankSegment.Values, se.PowerSegment.Values,
@@ -272,7 +301,7 @@ func (se *SndEnv) ProcessSegment(segment, add int) {
 		}
 	} else {
 		if resident {
-			err = plan.MelSpecSig(se.devSig, items, se.MelFBankSegment.Values, se.PowerSegment.Values, se.LogPowerSegment.Values)
+			err = plan.MelSpecSig(dev, items, se.MelFBankSegment.Values, se.PowerSegment.Values, se.LogPowerSegment.Values)
 		} else {
 			err = plan.MelSpec(se.Signal.Values, items, se.MelFBankSegment.Values, se.PowerSegment.Values, se.LogPowerSegment.Values)
 		}
@@ -301,8 +330,8 @@ func (se *SndEnv) ProcessSegments(first, n, add int, mel []float64) error {
 	if err != nil {
 		return err
 	}
-	if se.devSig != nil && se.devSig.Len() == len(se.Signal.Values) {
-		return plan.MelSpecSig(se.devSig, items, mel, nil, nil)
+	if dev := se.resident(); dev != nil {
+		return plan.MelSpecSig(dev, items, mel, nil, nil)
 	}
 	return plan.MelSpec(se.Signal.Values, items, mel, nil, nil)
 }
@@ -389,7 +418,10 @@ func (se *SndEnv) ApplyKwta() {
 }
 
 // ToTensor: sound/sndenv.go:297-300.
-func (se *SndEnv) ToTensor() bool { return se.Sound.SoundToTensor(&se.Signal) }
+func (se *SndEnv) ToTensor() bool {
+	se.SignalChanged()
+	return se.Sound.SoundToTensor(&se.Signal)
+}
 
 // AdjustForSilence / Tail / Pad: sound/sndenv.go:274-294, :503-519.
 func (se *SndEnv) AdjustForSilence(add, existing float64) (offset int) {
@@ -400,6 +432,7 @@ func (se *SndEnv) AdjustForSilence(add, existing float64) (offset int) {
 	case delta > 0:
 		se.Signal.Values = append(make([]float64, delta), se.Signal.Values...)
 	}
+	se.SignalChanged()
 	return off
 }
 

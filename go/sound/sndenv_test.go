@@ -67,3 +67,52 @@ func TestPrevSmoothSetAfterInitReachesProcessSegment(t *testing.T) {
 		t.Fatal("PrevSmooth had no effect on ProcessSegment")
 	}
 }
+
+// The device keeps se.Signal between ProcessSegment calls by default and must never serve a stale copy: a replaced slice of
+// the same length, an in-place overwrite (the sampled fingerprint sees it), a one-sample edit announced by SignalChanged,
+// AdjustForSilence -- each compared with the copy-per-call route (HostSignalPerCall) on the same samples.
+func TestResidentSignalNeverStale(t *testing.T) {
+	sr := 16000
+	mk := func(f float64) []float64 {
+		s := make([]float64, sr/2)
+		for i := range s {
+			s[i] = 0.3 * math.Sin(2*math.Pi*f*float64(i)/float64(sr))
+		}
+		return s
+	}
+	se := &SndEnv{}
+	se.Defaults()
+	se.Mel.MFCC = false
+	se.Signal.SetShape([]int{sr / 2}, nil, nil)
+	copy(se.Signal.Values, mk(440))
+	se.Sound.Buf = &audio.IntBuffer{Format: &audio.Format{NumChannels: 1, SampleRate: sr}, Data: make([]int, sr/2), SourceBitDepth: 16}
+	if err := se.Init(); err != nil {
+		t.Fatal(err)
+	}
+	mel := func(perCall bool) []float64 {
+		se.HostSignalPerCall = perCall
+		se.ProcessSegment(1, 0)
+		return append([]float64(nil), se.MelFBankSegment.Values...)
+	}
+	check := func(what string) {
+		res, host := mel(false), mel(true)
+		for i := range res {
+			if res[i] != host[i] {
+				t.Fatalf("%s: resident %g, copy per call %g at %d", what, res[i], host[i], i)
+			}
+		}
+	}
+	check("first call")
+	if se.devSig == nil {
+		t.Fatal("the first ProcessSegment did not keep the Signal on the device")
+	}
+	se.Signal.Values = mk(880) // another slice of the same length
+	check("replaced slice")
+	copy(se.Signal.Values, mk(1320)) // in place, every sample
+	check("in-place overwrite")
+	se.Signal.Values[1] += 0.25 // in place, one sample the fingerprint does not probe
+	se.SignalChanged()
+	check("one-sample edit + SignalChanged")
+	se.AdjustForSilence(30, 10) // prepends 20 ms
+	check("AdjustForSilence")
+}

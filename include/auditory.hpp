@@ -19,6 +19,7 @@
 #include <complex>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -274,16 +275,53 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
     int ComputeDtype = AUD_F64;  // the reference's arithmetic; AUD_FAST_F32 is the explicit opt-in
     PlanHandle plan;
     aud_plan_desc plan_desc_{};  // what `plan` was created from (ensure_plan)
-    aud_signal* dev_sig_ = nullptr;  // SignalToDevice: the resident copy of Signal ProcessSegment reads (null: upload per call)
-    ~SndEnv() { if (dev_sig_) aud_signal_destroy(dev_sig_); }
-
-    // New, opt-in: keep a copy of Signal on the device (aud_signal_upload) so that ProcessSegment sends only the work item and
-    // fetches only the results -- the reference's loop calls ProcessSegment once per segment on the same Signal.  A SNAPSHOT:
-    // call it again whenever Signal.Values changes; Init drops it.
+    // ProcessSegment runs once per segment on the SAME Signal (sndenv.go:342-359): the device keeps a copy of it between calls
+    // (aud_signal_upload), re-taken when Signal.Values is other memory, has another length or differs in a fingerprint of <= 64
+    // samples spread over it; SignalChanged() after an in-place edit that may miss those.  ResidentSignal = false: copy per call.
+    bool ResidentSignal = true;
+    aud_signal* dev_sig_ = nullptr;
+    struct SignalKey {
+        const double* data = nullptr;
+        size_t n = 0;
+        uint64_t probe = 0;
+        bool operator==(const SignalKey& o) const { return data == o.data && n == o.n && probe == o.probe; }
+    } dev_sig_key_;
+    ~SndEnv() { drop_resident(); }
+    void drop_resident() {
+        if (dev_sig_) aud_signal_destroy(dev_sig_);
+        dev_sig_ = nullptr;
+        dev_sig_key_ = SignalKey();
+    }
+    SignalKey signal_key() const {
+        SignalKey k;
+        k.data = Signal.Values.data();
+        k.n = Signal.Values.size();
+        const size_t step = k.n / 61 ? k.n / 61 : 1;
+        uint64_t h = 1469598103934665603ull;  // FNV-1a over the probed samples' bits
+        auto mix = [&h](double v) {
+            uint64_t b;
+            std::memcpy(&b, &v, 8);
+            h = (h ^ b) * 1099511628211ull;
+        };
+        for (size_t i = 0, c = 0; i < k.n && c < 63; i += step, ++c) mix(Signal.Values[i]);
+        if (k.n) mix(Signal.Values[k.n - 1]);
+        k.probe = h;
+        return k;
+    }
+    // New: call after changing samples of Signal.Values IN PLACE (the next ProcessSegment uploads the tensor again)
+    void SignalChanged() { dev_sig_key_ = SignalKey(); }
+    // New: (re)take the device's copy of Signal NOW; with ResidentSignal (the default) the first ProcessSegment does it itself
     bool SignalToDevice() {
         if (ensure_ctx() != AUD_OK) return false;
-        if (dev_sig_) { aud_signal_destroy(dev_sig_); dev_sig_ = nullptr; }
-        return aud_signal_upload(default_ctx(), Signal.Values.data(), AUD_F64, int64_t(Signal.Values.size()), &dev_sig_) == AUD_OK;
+        drop_resident();
+        if (aud_signal_upload(default_ctx(), Signal.Values.data(), AUD_F64, int64_t(Signal.Values.size()), &dev_sig_) != AUD_OK) return false;
+        dev_sig_key_ = signal_key();
+        return true;
+    }
+    bool resident() {
+        if (!ResidentSignal || Signal.Values.empty()) return false;
+        if (!dev_sig_ || !(dev_sig_key_ == signal_key())) return SignalToDevice();
+        return true;
     }
 
     void ParamDefaults() {  // sndenv.go:64-71
@@ -341,7 +379,7 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
 
         if (ensure_ctx() != AUD_OK) return "no HIP device (libauditory_hip has no CPU fallback)";
         if (plan.p) { aud_plan_destroy(plan.p); plan.p = nullptr; }
-        if (dev_sig_) { aud_signal_destroy(dev_sig_); dev_sig_ = nullptr; }  // (belongs to the Signal it was taken from)
+        drop_resident();  // (a resident copy belongs to the Signal it was taken from)
         return ensure_plan() ? "" : aud_last_error(default_ctx());
     }
 
@@ -386,7 +424,7 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
             std::printf("%s\n", aud_last_error(default_ctx()));
             return;
         }
-        const bool resident = dev_sig_ && aud_signal_len(dev_sig_) == int64_t(Signal.Values.size());
+        const bool resident = this->resident();
         double* lp = DFT.CompLogPow ? LogPowerSegment.Values.data() : nullptr;
         if (Mel.MFCC && DFT.CompLogPow) {  // the MFCC tail of the loop too: CepstrumDct, Energy, deltas (:360-432)
             double* dl = Mel.Deltas ? MFCCDeltas.Values.data() : nullptr;

@@ -48,7 +48,27 @@ int main(int argc, char** argv) {
     const int32_t hdr[4] = {se.SegCnt, se.Mel.FBank.NFilters, se.Params_.SegmentSteps, se.Params_.WinSamples / 2 + 1};
     std::fwrite(hdr, 4, 4, o);
     for (int seg = 0; seg < se.SegCnt; ++seg) {
-        if (seg == 2 && !se.SignalToDevice()) return 7;  // from here on the segments run on the resident copy (same results)
+        // the device keeps the Signal between calls by default; segment 2 takes the copy-per-call route (same results), and
+        // an in-place edit announced by SignalChanged() must reach the device (undone again before the segment is computed)
+        se.ResidentSignal = seg != 2;
+        if (seg == 1 && !se.dev_sig_) return 7;
+        if (seg == 3) {
+            const size_t at = size_t(3 * se.Params_.StrideSamples + 101);  // (inside segment 3, not a probed sample)
+            const double keep = se.Signal.Values[at];
+            se.Signal.Values[at] = keep + 0.5;
+            se.SignalChanged();
+            se.ProcessSegment(seg, 0);
+            auto total = [&se] {
+                double t = 0.0;
+                for (double v : se.MelFBankSegment.Values) t += v;
+                return t;
+            };
+            const double moved = total();
+            se.Signal.Values[at] = keep;
+            se.SignalChanged();
+            se.ProcessSegment(seg, 0);
+            if (moved == total()) return 11;  // the edit never reached the device
+        }
         se.ProcessSegment(seg, 0);
         Float32* g = se.ApplyGabor();
         if (g != &se.GborKwta) return 6;  // Defaults() leaves Kwta.On (sndenv.go:189, :492-494)

@@ -769,9 +769,12 @@ def case_sndenv_mirror_reads_like_the_reference(orc):
     kw, kw_state = orc.kwta_defaults(), np.zeros((8 * 2, 2), np.float32)
     for seg in range(se.SegCnt):
         if seg == 2:
-            se.SignalToDevice()                # from here on the segments run on the resident copy (same results)
-            assert se._resident() is not None
+            se.ResidentSignal = False          # the copy-per-call route gives the same results
+            assert se._resident() is None
+        if seg == 3:
+            se.ResidentSignal = True
         se.ProcessSegment(seg, 0)
+        assert (se._dev_sig is not None) == (seg != 2 or se._dev_sig is not None)
         tsr = se.ApplyGabor()
         assert tsr is se.GborKwta              # :492-494
         # the k-WTA stage is float32 in the reference's operation order: bit-exact against the oracle run
@@ -789,6 +792,56 @@ def case_sndenv_mirror_reads_like_the_reference(orc):
         assert orc.gabor_convolve(o["mel_seg"], k, 3, 3, 2.0, ref) == 0
         ok, msg = W.feature_close(tsr, ref, capi.AUD_F32)
         assert ok, "gabor " + msg
+
+
+def case_sndenv_resident_signal_staleness(orc):
+    """The device keeps SndEnv.Signal between ProcessSegment calls BY DEFAULT (the reference's loop runs once per segment on the
+    same tensor, sndenv.go:342-359) -- and must never serve a stale copy: another array of the same length, AdjustForSilence,
+    an in-place edit announced by SignalChanged(), an in-place edit that the sampled fingerprint sees, Init."""
+    from auditory_amd import sound
+    oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
+    sig, _ = synth.batch(21, 3, 8000, 16000)
+
+    def mel_of(se, seg=1):
+        se.ProcessSegment(seg, 0)
+        return np.array(se.MelFBankSegment)
+
+    def ref_of(x, seg=1):
+        return orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, np.ascontiguousarray(x, np.float64), segment=seg)["mel_seg"]
+
+    def check(se, x, what):
+        ok, msg = W.feature_close(mel_of(se), ref_of(x), capi.AUD_F64, lin_axis=0)
+        assert ok, what + ": " + msg
+
+    se = sound.SndEnv()
+    se.Defaults()
+    se.Mel.MFCC = False
+    se.SampleRate, se.Signal = 16000, sig[0].copy()
+    assert se.Init() is None and se._dev_sig is None
+    check(se, sig[0], "first call")
+    first = se._dev_sig
+    assert first is not None                            # taken by the first call, without opting in
+    check(se, sig[0], "second call")
+    assert se._dev_sig is first                         # ... and kept
+    se.Signal = sig[1].copy()                           # another tensor of the SAME length
+    check(se, sig[1], "replaced tensor")
+    assert se._dev_sig is not first
+    se.Signal[:] = sig[2]                               # in place: every sample changes, the fingerprint sees it
+    check(se, sig[2], "in-place overwrite")
+    keep = se._dev_sig
+    se.Signal[1] += 0.25                                # in place, ONE sample the fingerprint does not probe ...
+    se.SignalChanged()                                  # ... so the caller says so
+    check(se, se.Signal, "in-place edit + SignalChanged")
+    assert se._dev_sig is not keep
+    off = se.AdjustForSilence(30.0, 10.0)               # prepends 20 ms of zeros: another tensor, another length
+    assert off == 20 and len(se.Signal) == 8000 + 320
+    check(se, se.Signal, "AdjustForSilence")
+    assert se.Init() is None and se._dev_sig is None    # Init drops the copy (SegCnt etc. are re-derived)
+    check(se, se.Signal, "after Init")
+    se.ResidentSignal = False
+    se._drop_resident()
+    check(se, se.Signal, "copy per call")
+    assert se._dev_sig is None
 
 
 def case_sndenv_mirror_2d_gabor_kwta_layer(orc):

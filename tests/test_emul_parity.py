@@ -161,6 +161,10 @@ def test_emul_kwta_shapes(orc, emu):
     PC.case_kwta_shapes(orc)
 
 
+def test_emul_sndenv_resident_signal_staleness(orc, emu):
+    PC.case_sndenv_resident_signal_staleness(orc)
+
+
 def test_emul_sndenv_mirror_2d_gabor_kwta_layer(orc, emu):
     PC.case_sndenv_mirror_2d_gabor_kwta_layer(orc)
 

@@ -113,6 +113,10 @@ def test_per_step_api(orc, torch_cuda, cdt):
     PC.case_per_step_api(orc, cdt)
 
 
+def test_sndenv_resident_signal_staleness(orc, torch_cuda):
+    PC.case_sndenv_resident_signal_staleness(orc)
+
+
 def test_sndenv_mirror_2d_gabor_kwta_layer(orc, torch_cuda):
     PC.case_sndenv_mirror_2d_gabor_kwta_layer(orc)
 
