@@ -35,6 +35,7 @@ void fill_melspec_args(const aud_plan* p, aud::MelspecArgs* a) {
     a->bl_chirp = p->d_bl_chirp;
     a->bl_bhat = p->d_bl_bhat;
     a->bl_tw = p->d_bl_tw;
+    a->bl_inplace = p->bl_inplace ? 1 : 0;
     a->xcd_remap = p->xcd_remap;
     a->stamps = reinterpret_cast<unsigned long long*>(p->stamps);
 }
@@ -98,6 +99,7 @@ void factorize(int m, int* fac, int* nfac) {
     while (m % 2 == 0) { fac[n++] = 2; m /= 2; }
     while (m % 25 == 0) { fac[n++] = 25; m /= 25; }
     while (m % 5 == 0) { fac[n++] = 5; m /= 5; }
+    while (m % 9 == 0) { fac[n++] = 9; m /= 9; }
     while (m % 3 == 0) { fac[n++] = 3; m /= 3; }
     for (int p = 7; int64_t(p) * p <= m; p += 2)
         while (m % p == 0) { fac[n++] = p; m /= p; }
@@ -267,6 +269,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
             if (rc == AUD_OK) {
                 p->bl_L = L;
                 factorize(L, p->bl_fac, &p->bl_nfac);
+                p->bl_inplace = aud::melspec_generic_bluestein_inplace(L);  // one padded buffer, stages through registers
                 // odd window lengths, float64 plans: two real frames per complex transform (float32 transforms keep one frame
                 // each: separating a pair adds the partner's rounding floor, 4.2e-6 of the frame peak against 3e-6 measured)
                 p->F_generic = (p->ratio == 1 && d->compute_dtype == AUD_F64) ? 2 : 1;
@@ -347,6 +350,7 @@ int aud_plan_get_info(const aud_plan* p, const char* name, int64_t* value) {
     else if (key == "waves_per_wg") *value = wave ? p->wv.waves : 4;
     else if (key == "wgs_per_cu") *value = wave ? p->wv.wgs_per_cu : 0;
     else if (key == "bluestein_L") *value = wave ? 0 : p->bl_L;
+    else if (key == "bluestein_inplace") *value = !wave && p->bl_L && p->bl_inplace ? 1 : 0;
     else if (key == "generic_frames_per_wg") *value = p->F_generic;  // frames a workgroup of the any-N kernel transforms at once
     else if (key == "item_kernel") *value = wave && p->has_item ? 1 : 0;        // the workgroup-per-item variant exists for this plan
     else if (key == "item_waves") *value = wave && p->has_item ? p->itm.waves : 0;

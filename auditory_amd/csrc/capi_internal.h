@@ -80,6 +80,7 @@ struct aud_plan {
     int F_generic = 0;
     // generic kernel, Bluestein route (kernels.h MelspecArgs::bl_*): 0 = not used
     int bl_L = 0, bl_nfac = 0;
+    bool bl_inplace = false;
     int bl_fac[aud::kMaxFactors] = {0};
     void* d_bl_chirp = nullptr;
     void* d_bl_bhat = nullptr;

@@ -116,6 +116,34 @@ struct SmallDft<TT, 5> {
         dft5(v[0], v[1], v[2], v[3], v[4]);
     }
 };
+// exp(-2 pi i m / 9), m = 1, 2, 4 (the inner twiddles of the 3 x 3 factorisation, m = b k1)
+template <typename TT>
+__device__ __forceinline__ C2<TT> w9_literal(int m) {
+    return m == 1 ? C2<TT>{TT(0.76604444311897803520L), TT(-0.64278760968653932632L)}
+         : m == 2 ? C2<TT>{TT(0.17364817766693034885L), TT(-0.98480775301220805937L)}
+                  : C2<TT>{TT(-0.93969262078590838405L), TT(-0.34202014332566873304L)};
+}
+template <typename TT>
+struct SmallDft<TT, 9> {  // 9 = 3 x 3, inner twiddles W9^(b k1)
+    static __device__ __forceinline__ void run(C2<TT> (&v)[9], const C2<TT>*, int) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) dft3(v[b], v[3 + b], v[6 + b]);
+        v[4] = cmul(v[4], w9_literal<TT>(1));
+        v[5] = cmul(v[5], w9_literal<TT>(2));
+        v[7] = cmul(v[7], w9_literal<TT>(2));
+        v[8] = cmul(v[8], w9_literal<TT>(4));
+#pragma unroll
+        for (int k1 = 0; k1 < 3; ++k1) dft3(v[3 * k1], v[3 * k1 + 1], v[3 * k1 + 2]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = i + 1; j < 3; ++j) {
+                const C2<TT> t = v[3 * i + j];
+                v[3 * i + j] = v[3 * j + i];
+                v[3 * j + i] = t;
+            }
+    }
+};
 template <typename TT>
 struct SmallDft<TT, 8> {  // 8 = 4 x 2: two 4-point DFTs (even / odd samples), then one radix-2 layer
     static __device__ __forceinline__ void run(C2<TT> (&v)[8], const C2<TT>*, int) {

@@ -59,6 +59,7 @@ struct MelspecArgs {
     const void* bl_chirp;  // [M] complex<TT>: exp(-i pi n^2 / M)
     const void* bl_bhat;   // [L] complex<TT>: FFT_L of the wrapped conjugate chirp, / L
     const void* bl_tw;     // [L] complex<TT>: exp(-2 pi i k / L)
+    int bl_inplace;        // 1: ONE padded LDS buffer, stages through registers (melspec_generic.hip stage_inplace)
     int xcd_remap;     // 1: tile_of_workgroup() order (plan option "xcd_remap", default on)
     // wave kernels: wave tiles per item (N = 2048: frames per item) and its reciprocal, set by launch_melspec_wave -- a
     // wave finds its item with one scalar multiply (tile_div) instead of the 64-bit division's twenty vector instructions
@@ -244,6 +245,7 @@ hipError_t launch_mfcc_dct(const MfccArgs& a, int compute_dtype, hipStream_t st)
 
 // generic any-N kernel (Stockham in LDS, radix 2/4 + per-output generic radix)
 size_t melspec_generic_lds_bytes(int M, int F, int compute_dtype, bool bluestein);
+bool melspec_generic_bluestein_inplace(int L);
 int melspec_generic_pick_F(int M, int compute_dtype);
 int melspec_generic_bluestein_L(int M, int compute_dtype);
 hipError_t melspec_generic_prepare(size_t lds_bytes);

@@ -60,6 +60,7 @@ __device__ __forceinline__ void smooth_fft(C2<TT>*& src, C2<TT>*& dst, const Mel
             case 4: stage<TT, 4>(src, dst, tw, 1, L, L, 1, ncur, s, tid); break;
             case 25: stage<TT, 25>(src, dst, tw, 1, L, L, 1, ncur, s, tid); break;
             case 5: stage<TT, 5>(src, dst, tw, 1, L, L, 1, ncur, s, tid); break;
+            case 9: stage<TT, 9>(src, dst, tw, 1, L, L, 1, ncur, s, tid); break;
             case 3: stage<TT, 3>(src, dst, tw, 1, L, L, 1, ncur, s, tid); break;
             default: stage<TT, 2>(src, dst, tw, 1, L, L, 1, ncur, s, tid); break;
         }
@@ -72,11 +73,131 @@ __device__ __forceinline__ void smooth_fft(C2<TT>*& src, C2<TT>*& dst, const Mel
     }
 }
 
-template <typename TT>
-__global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
+// ---- the Bluestein route IN PLACE (round 5) ---------------------------------------------------------------------------------
+// One complex buffer of L points instead of the autosort's two: a thread reads the inputs of ALL its butterflies of a stage into
+// registers, the workgroup meets at a barrier, and the outputs go back into the same buffer at the autosort's positions -- twice
+// the barriers, half the LDS: the 2304-point transform of N = 1103 in float64 takes 39 KB per workgroup, FOUR workgroups (16
+// waves) per CU where the two-buffer form had two -- and this kernel waits (barriers, LDS round trips) for most of its life.
+// The buffer is padded by one element per 16 (padx): the first stages store with a stride of 16 elements = 256 bytes, i.e.
+// sixteen lanes of a 16-byte store on the same four banks; with the pad the stride is 17 elements and the lanes fan out.
+__host__ __device__ __forceinline__ int padx(int i) { return i + (i >> 4); }
+
+// `pre(i, z)`: what element i of the buffer stands for when a stage LOADS it -- the identity, or (first stage of a transform) the
+// chirp / bhat multiplication that would otherwise be a pass of its own over the buffer with a barrier behind it
+struct PreNone {
+    template <typename Z>
+    __device__ __forceinline__ Z operator()(int, Z z) const { return z; }
+};
+// LIN (chosen per stage by stage_inplace_any): equally spaced padded positions on both sides
+template <typename TT, int P, int R, bool LIN, typename PRE>
+__device__ __forceinline__ void stage_inplace(C2<TT>* buf, const C2<TT>* __restrict__ tw, int L, int ncur, int s, int tid, PRE pre) {
+    const int m = ncur / P, nb = L / P, sm = s * m;
+    // wave-uniform facts that keep the per-element index arithmetic off the vector unit: s is a power of two in every stage
+    // but those behind a radix 3 / 5 / 9 one (shift instead of a division); with a stride that is a multiple of 16 the padded
+    // positions of a butterfly's elements are equally spaced (padx(x + i d) = padx(x) + i (d + d / 16))
+    const int s_log = (s & (s - 1)) == 0 ? 31 - __builtin_clz(unsigned(s)) : -1;
+    constexpr bool lin_in = LIN, lin_out = LIN;
+    const int din = sm + (sm >> 4), dout = s == 1 ? 1 : s + (s >> 4);
+    C2<TT> v[R][P];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int b = tid + 256 * r;
+        if (b < nb) {
+            const int q = s_log >= 0 ? b >> s_log : b / s, k = b - q * s;
+            const int x0 = k + s * q;
+            const C2<TT>* in = buf + padx(x0);
+#pragma unroll
+            for (int i = 0; i < P; ++i) v[r][i] = pre(x0 + i * sm, lin_in ? in[i * din] : buf[padx(x0 + i * sm)]);
+        }
+    }
+    __syncthreads();  // every input of the stage is in registers
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int b = tid + 256 * r;
+        if (b < nb) {
+            const int q = s_log >= 0 ? b >> s_log : b / s, k = b - q * s;
+            SmallDft<TT, P>::run(v[r], tw, L);
+            const unsigned tq = unsigned(q * s);
+            const int y0 = k + s * P * q;
+            C2<TT>* out = buf + padx(y0);
+            out[0] = v[r][0];
+            if (s * P == L) {  // the last stage (wave-uniform): q = 0 everywhere, no twiddles
+#pragma unroll
+                for (int j = 1; j < P; ++j) (lin_out ? out[j * dout] : buf[padx(y0 + j * s)]) = v[r][j];
+            } else {
+#pragma unroll
+                for (int j = 1; j < P; ++j) (lin_out ? out[j * dout] : buf[padx(y0 + j * s)]) = cmul<TT>(v[r][j], tw[unsigned(j) * tq]);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// a stage's butterflies L / P over 256 threads: R rounds held in registers at once, P x R <= 16 complex values
+__host__ __device__ inline int inplace_rounds(int L, int p) { return (L / p + 255) / 256; }
+__host__ __device__ inline bool inplace_radix_ok(int L, int p) {
+    const int r = inplace_rounds(L, p);
+    switch (p) {
+        case 16: return r <= 1;
+        case 9: return r <= 1;
+        case 8: return r <= 2;
+        case 5: return r <= 3;
+        case 4: return r <= 4;
+        case 3: return r <= 5;
+        case 2: return r <= 8;
+        default: return false;  // (25 and the O(p) pass: the two-buffer route)
+    }
+}
+
+template <typename TT, typename PRE>
+__device__ __forceinline__ void stage_inplace_any(int p, C2<TT>* buf, const C2<TT>* __restrict__ tw, int L, int ncur, int s, int tid, PRE pre) {
+    // equally spaced padded positions: inputs sm apart with sm a multiple of 16; outputs s apart with s a multiple of 16, or
+    // s = 1 under radix 16 (y0 = 16 q: the 16 outputs share one pad group)
+    const int sm = s * (ncur / p);
+    const bool lin = (sm & 15) == 0 && ((s & 15) == 0 || (s == 1 && p == 16));
+    switch (p) {
+        case 16:
+            if (lin) stage_inplace<TT, 16, 1, true>(buf, tw, L, ncur, s, tid, pre);
+            else stage_inplace<TT, 16, 1, false>(buf, tw, L, ncur, s, tid, pre);
+            break;
+        case 9:
+            if (lin) stage_inplace<TT, 9, 1, true>(buf, tw, L, ncur, s, tid, pre);
+            else stage_inplace<TT, 9, 1, false>(buf, tw, L, ncur, s, tid, pre);
+            break;
+        case 8: stage_inplace<TT, 8, 2, false>(buf, tw, L, ncur, s, tid, pre); break;
+        case 5: stage_inplace<TT, 5, 3, false>(buf, tw, L, ncur, s, tid, pre); break;
+        case 4: stage_inplace<TT, 4, 4, false>(buf, tw, L, ncur, s, tid, pre); break;
+        case 3: stage_inplace<TT, 3, 5, false>(buf, tw, L, ncur, s, tid, pre); break;
+        default: stage_inplace<TT, 2, 8, false>(buf, tw, L, ncur, s, tid, pre); break;
+    }
+}
+// the transform in place; `pre` rides on the FIRST stage's loads (the caller's barrier stands before the call)
+template <typename TT, typename PRE>
+__device__ __forceinline__ void smooth_fft_inplace(C2<TT>* buf, const MelspecArgs& a, int tid, PRE pre) {
+    const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.bl_tw);
+    const int L = a.bl_L;
+    int ncur = L, s = 1;
+    stage_inplace_any<TT>(a.bl_fac[0], buf, tw, L, ncur, s, tid, pre);
+    ncur /= a.bl_fac[0];
+    s *= a.bl_fac[0];
+    for (int stg = 1; stg < a.bl_nfac; ++stg) {
+        const int p = a.bl_fac[stg];
+        stage_inplace_any<TT>(p, buf, tw, L, ncur, s, tid, PreNone());
+        ncur /= p;
+        s *= p;
+    }
+}
+
+// INPL: the instantiation of the in-place Bluestein route alone -- without the two-buffer stages (whose radix-25 butterfly
+// holds 25 complex values per thread: 156 registers in float64, three waves per SIMD) it stays within 128 registers, and
+// four workgroups per CU is what the one-buffer layout is for
+template <typename TT, bool INPL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1 + 3 * int(INPL))))
+void k_melspec_generic(const MelspecArgs a) {
     unsigned char* smem = dyn_lds();
     const int tid = threadIdx.x;
     const int F = a.F, M = a.M, N = a.N, H = a.H, T = a.T;
+    constexpr bool inpl = INPL;  // Bluestein in ONE padded buffer (element i at padx(i)); the host launches it for bl_inplace plans
     C2<TT>* src = reinterpret_cast<C2<TT>*>(smem);
     C2<TT>* dst = src + (a.bl_L ? size_t(a.bl_L) : size_t(F) * M);
     const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);
@@ -94,7 +215,7 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
     // from one frame into the other through rounding is then 2^-53 of the frame's OWN peak, as in a transform of its own (a
     // quiet frame beside a loud one would otherwise inherit the loud one's floor); the powers are scaled back exactly, and a
     // frame of exact zeros keeps an exactly zero spectrum (LogMin rule, mel.go:135-137)
-    int* pair_exp = reinterpret_cast<int*>(smem + 2 * size_t(a.bl_L ? a.bl_L : F * M) * sizeof(C2<TT>));  // [2]
+    int* pair_exp = reinterpret_cast<int*>(smem + (inpl ? size_t(padx(a.bl_L)) : 2 * size_t(a.bl_L ? a.bl_L : F * M)) * sizeof(C2<TT>));  // [2]
     if (pair) {
         if (tid < 2) pair_exp[tid] = kNoSignal;
         __syncthreads();
@@ -109,10 +230,14 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
         const int64_t pos = start + n;
         TT v = TT(0);
         if (live && pos >= 0) v = load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + pos * (it.sig_stride > 1 ? it.sig_stride : 1));
-        if (even) {
+        if (inpl && !pair) {  // (one frame per workgroup) z[n / 2] = (x[2j], x[2j+1]) for even N, z[n] = (x[n], 0) for odd N
+            TT* cell = &src[padx(even ? n >> 1 : n)].x;
+            if (even) cell[n & 1] = v;
+            else { cell[0] = v; cell[1] = TT(0); }
+        } else if (even) {
             reinterpret_cast<TT*>(src)[size_t(f) * N + n] = v;  // z[n/2] = (x[2j], x[2j+1])
         } else if (pair) {
-            reinterpret_cast<TT*>(src)[2 * size_t(n) + f] = v;   // frame 0: real parts, frame 1: imaginary parts
+            (&src[inpl ? padx(n) : n].x)[f] = v;   // frame 0: real parts, frame 1: imaginary parts
             // an Inf / NaN sample takes its frame OUT of the pair (sentinel exponent): the frame's bins are NaN, as a transform of
             // its own would leave them, and its partner -- an independent frame in the reference (dft.go:42-50) -- runs alone
             const int ex = (v - v == TT(0)) ? amax_exponent<TT>(v < TT(0) ? -v : v) : kNonFinite;
@@ -133,26 +258,40 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
         const C2<TT>* __restrict__ bhat = static_cast<const C2<TT>*>(a.bl_bhat);
         const int x0 = pair ? pair_exp[0] : 0, x1 = pair ? pair_exp[1] : 0;
         const int e0 = (x0 == kNoSignal || x0 == kNonFinite) ? 0 : x0, e1 = (x1 == kNoSignal || x1 == kNonFinite) ? 0 : x1;
-        for (int i = tid; i < L; i += blockDim.x) {
-            C2<TT> z = i < M ? src[i] : C2<TT>{TT(0), TT(0)};
-            if (pair) z = C2<TT>{x0 == kNonFinite ? TT(0) : scale2(z.x, -e0), x1 == kNonFinite ? TT(0) : scale2(z.y, -e1)};
-            src[i] = i < M ? cmul<TT>(z, chirp[i]) : z;
+        if constexpr (inpl) {
+            // the three multiplications ride on loads: z . chirp and (.) . bhat, conjugated, on the first stage of the two
+            // transforms; the last one, chirp . conj(.), on the power pass below (zat)
+            smooth_fft_inplace<TT>(src, a, tid, [&](int i, C2<TT> z) {
+                if (i >= M) return C2<TT>{TT(0), TT(0)};  // (whatever the buffer holds behind the window)
+                if (pair) z = C2<TT>{x0 == kNonFinite ? TT(0) : scale2(z.x, -e0), x1 == kNonFinite ? TT(0) : scale2(z.y, -e1)};
+                return cmul<TT>(z, chirp[i]);
+            });
+            smooth_fft_inplace<TT>(src, a, tid, [&](int i, C2<TT> z) {
+                const C2<TT> c = cmul<TT>(z, bhat[i]);
+                return C2<TT>{c.x, -c.y};
+            });
+        } else {
+            for (int i = tid; i < L; i += blockDim.x) {
+                C2<TT> z = i < M ? src[i] : C2<TT>{TT(0), TT(0)};
+                if (pair) z = C2<TT>{x0 == kNonFinite ? TT(0) : scale2(z.x, -e0), x1 == kNonFinite ? TT(0) : scale2(z.y, -e1)};
+                src[i] = i < M ? cmul<TT>(z, chirp[i]) : z;
+            }
+            __syncthreads();
+            smooth_fft<TT>(src, dst, a, tid);
+            for (int i = tid; i < L; i += blockDim.x) {
+                const C2<TT> c = cmul<TT>(src[i], bhat[i]);
+                src[i] = C2<TT>{c.x, -c.y};
+            }
+            __syncthreads();
+            smooth_fft<TT>(src, dst, a, tid);
+            for (int k = tid; k < M; k += blockDim.x) src[k] = cmul<TT>(chirp[k], C2<TT>{src[k].x, -src[k].y});
+            __syncthreads();
         }
-        __syncthreads();
-        smooth_fft<TT>(src, dst, a, tid);
-        for (int i = tid; i < L; i += blockDim.x) {
-            const C2<TT> c = cmul<TT>(src[i], bhat[i]);
-            src[i] = C2<TT>{c.x, -c.y};
-        }
-        __syncthreads();
-        smooth_fft<TT>(src, dst, a, tid);
-        for (int k = tid; k < M; k += blockDim.x) src[k] = cmul<TT>(chirp[k], C2<TT>{src[k].x, -src[k].y});
-        __syncthreads();
     }
 
     // ---- Stockham stages: x[k + s(q + m i)] -> y[k + s(p q + j)] * W_ncur^(q j) ---------
     int ncur = M, s = 1;
-    for (int stg = 0; stg < (a.bl_L ? 0 : a.nfac); ++stg) {
+    for (int stg = 0; stg < ((inpl || a.bl_L) ? 0 : a.nfac); ++stg) {
         const int p = a.fac[stg];
         const int m = ncur / p;
         const int nb = M / p;  // butterflies per frame
@@ -163,6 +302,7 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
             case 5: stage<TT, 5>(src, dst, tw, F, M, N, a.ratio, ncur, s, tid); break;
             case 8: stage<TT, 8>(src, dst, tw, F, M, N, a.ratio, ncur, s, tid); break;
             case 16: stage<TT, 16>(src, dst, tw, F, M, N, a.ratio, ncur, s, tid); break;
+            case 9: stage<TT, 9>(src, dst, tw, F, M, N, a.ratio, ncur, s, tid); break;
             case 25: stage<TT, 25>(src, dst, tw, F, M, N, a.ratio, ncur, s, tid); break;
             default: {
                 // any other prime p: one thread per output j of each radix-p butterfly
@@ -202,16 +342,28 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
     }
 
     // ---- power spectrum into the free buffer: P[f][k], row pitch odd -----------------
-    TT* P = reinterpret_cast<TT*>(dst);
+    // (in place: the spectrum Z[0 .. M) sits at the padded positions below padx(M); everything of the buffer behind it is free
+    //  once the last transform is done, and L >= 2 M - 1 leaves room for F rows of H values there)
+    TT* P = inpl ? reinterpret_cast<TT*>(src + padx(M) + 1) : reinterpret_cast<TT*>(dst);
     const int Hp = H | 1;
+    // Z[k] of frame f.  In place (one frame, or a pair in one transform): the buffer still holds the second transform's raw
+    // output -- the convolution's last step, chirp . conj(.), is applied here, on the load
+    const C2<TT>* __restrict__ chirp_z = static_cast<const C2<TT>*>(a.bl_chirp);
+    auto zat = [&](int f, int k) {
+        if constexpr (inpl) {
+            const C2<TT> r = src[padx(k)];
+            return cmul<TT>(chirp_z[k], C2<TT>{r.x, -r.y});
+        } else {
+            return src[size_t(f) * M + k];
+        }
+    };
     for (int w = tid; w < F * H; w += blockDim.x) {
         const int f = w / H, k = w - f * H;
-        const C2<TT>* Z = src + size_t(f) * M;
         TT re, im;
         if (even) {
             // X[k] = (Z[k] + conj Z[M-k])/2 - i W_N^k (Z[k] - conj Z[M-k])/2, Z[M] == Z[0]
-            const C2<TT> A = Z[k == M ? 0 : k];
-            const C2<TT> Bc = Z[k == 0 ? 0 : M - k];
+            const C2<TT> A = zat(f, k == M ? 0 : k);
+            const C2<TT> Bc = zat(f, k == 0 ? 0 : M - k);
             const TT er = (A.x + Bc.x) * TT(0.5), ei = (A.y - Bc.y) * TT(0.5);
             const TT dr = (A.x - Bc.x) * TT(0.5), di = (A.y + Bc.y) * TT(0.5);
             const C2<TT> wk = tw[k];
@@ -219,7 +371,7 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
             re = er + (di * wk.x + dr * wk.y);
             im = ei + (di * wk.y - dr * wk.x);
         } else if (pair) {
-            const C2<TT> A = src[k], B = src[k == 0 ? 0 : M - k];
+            const C2<TT> A = zat(0, k), B = zat(0, k == 0 ? 0 : M - k);
             if (f == 0) {
                 re = (A.x + B.x) * TT(0.5);
                 im = (A.y - B.y) * TT(0.5);
@@ -232,8 +384,9 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
             P[size_t(f) * Hp + k] = p;
             continue;
         } else {
-            re = Z[k].x;
-            im = Z[k].y;
+            const C2<TT> z = zat(f, k);
+            re = z.x;
+            im = z.y;
         }
         P[size_t(f) * Hp + k] = re * re + im * im;  // dft.go:64-66
     }
@@ -267,19 +420,29 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
         const TT* __restrict__ filt = static_cast<const TT*>(a.filt);
         const int cols = a.nf + 2;
         const TT loff = TT(a.mel_log_off), lmin = TT(a.mel_log_min);
-        for (int w = tid; w < F * a.nf; w += blockDim.x) {
+        // FOUR lanes per (frame, filter): the workgroup has few frames (one or two with Bluestein) and a filter's taps are a
+        // serial chain of table loads -- one lane per filter left three of the four waves idle through the kernel's tail.  A
+        // lane takes every fourth tap; the four partial sums meet by two lane exchanges, (p0 + p2) + (p1 + p3) on every lane.
+        const int n_work = F * a.nf;
+        for (int w0 = tid >> 2; w0 < ((n_work + 63) & ~63); w0 += blockDim.x >> 2) {  // (whole waves stay in the exchanges)
+            const int w = w0 < n_work ? w0 : n_work - 1, part = tid & 3;
             const int flt = w / F, f = w - flt * F;
             const int sstep = t0 + f;
-            if (sstep >= T) continue;
             const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
-            const bool live = start + N <= int64_t(it.sig_len);
-            float res = 0.f;
-            if (live) {
+            const bool live = sstep < T && start + N <= int64_t(it.sig_len);
+            TT sum = TT(0);
+            {
                 const int lo = a.bin_pts[flt], hi = a.bin_pts[flt + 2];
                 const TT* wrow = filt + size_t(flt) * cols;
                 const TT* prow = P + size_t(f) * Hp;
-                TT sum = TT(0);
-                for (int bin = lo; bin <= hi; ++bin) sum += wrow[bin - lo] * prow[bin];
+                if (live)
+                    for (int bin = lo + part; bin <= hi; bin += 4) sum += wrow[bin - lo] * prow[bin];
+            }
+            sum += __shfl_xor(sum, 2, 64);
+            sum += __shfl_xor(sum, 1, 64);
+            if (part != 0 || w0 >= n_work || sstep >= T) continue;
+            float res = 0.f;
+            if (live) {
                 sum += loff;
                 TT val = (sum == TT(0)) ? lmin : dev_log(sum);
                 if (a.renorm) {
@@ -297,8 +460,20 @@ __global__ __launch_bounds__(256) void k_melspec_generic(const MelspecArgs a) {
 
 }  // namespace
 
+// the Bluestein route runs in ONE padded buffer where every stage of L fits a thread's registers (stage_inplace)
+bool melspec_generic_bluestein_inplace(int L) {
+    int m = L;
+    for (int p : {16, 8, 4, 2, 25, 5, 9, 3})
+        while (m % p == 0) {
+            if (!inplace_radix_ok(L, p)) return false;
+            m /= p;
+        }
+    return m == 1;
+}
+
 size_t melspec_generic_lds_bytes(int M, int F, int compute_dtype, bool bluestein) {
     const size_t c = compute_dtype == AUD_F64 ? 16 : 8;
+    if (bluestein && melspec_generic_bluestein_inplace(M)) return size_t(padx(M)) * c + 16;
     // two complex buffers; the Bluestein route (M = its transform length L, F = 1) adds the frame pair's two exponent words.
     // Plain Stockham plans stay at exactly 2 F M c: M = 2048 in float64 / 4096 in float32 fill the 64 KB to the byte.
     return size_t(2) * F * M * c + (bluestein ? 16 : 0);
@@ -325,14 +500,18 @@ int melspec_generic_bluestein_L(int M, int compute_dtype) {
                 if (melspec_generic_lds_bytes(int(L), 1, compute_dtype, true) > 160 * 1024) continue;
                 double stages = 0;  // as capi.hip's factorize() will cut it; a radix-25 stage weighs 1.75 of the others
                 int64_t m = L;
-                for (int r : {16, 8, 4, 2, 25, 5, 3})
+                for (int r : {16, 8, 4, 2, 25, 5, 9, 3})
                     while (m % r == 0) {
                         m /= r;
                         stages += r == 25 ? 1.75 : 1.0;
                     }
-                // two workgroups per CU when the buffers fit twice.  Fitted to N = 1103 in float64 on an MI355X (us per 256
-                // segments of 14 frames): L 2304 101, 2560 106, 2400 120, 2500 122, 3072 191, 4096 194
-                const double fit2 = 2 * melspec_generic_lds_bytes(int(L), 1, compute_dtype, true) <= 160 * 1024 ? 0.55 : 1.0;
+                // the kernel waits for most of its life (barriers, LDS round trips): what counts beside length x stages is how
+                // many workgroups a CU's 160 KB of LDS hold at once.  Round 4's fit to N = 1103 in float64 (two buffers, us per
+                // 256 segments of 14 frames: L 2304 101, 2560 106, 2400 120, 2500 122, 3072 191, 4096 194) gave 0.55 for two
+                // against one; the in-place route fits four of L = 2304 (tools/tune_bluestein.sh, profiles/round5_bluestein_*)
+                const size_t lds_l = melspec_generic_lds_bytes(int(L), 1, compute_dtype, true);
+                const int per_cu = int(std::min<size_t>(4, size_t(160 * 1024) / lds_l));
+                const double fit2 = per_cu >= 4 ? 0.35 : per_cu == 3 ? 0.42 : per_cu == 2 ? 0.55 : 1.0;
                 const double cost = double(L) * stages * fit2;
                 if (best == 0 || cost < best_cost) {
                     best = int(L);
@@ -343,8 +522,10 @@ int melspec_generic_bluestein_L(int M, int compute_dtype) {
 }
 
 hipError_t melspec_generic_prepare(size_t lds_bytes) {
-    const void* fns[2] = {reinterpret_cast<const void*>(&k_melspec_generic<double>),
-                          reinterpret_cast<const void*>(&k_melspec_generic<float>)};
+    const void* fns[4] = {reinterpret_cast<const void*>(&k_melspec_generic<double, false>),
+                          reinterpret_cast<const void*>(&k_melspec_generic<float, false>),
+                          reinterpret_cast<const void*>(&k_melspec_generic<double, true>),
+                          reinterpret_cast<const void*>(&k_melspec_generic<float, true>)};
     for (const void* fn : fns) {
         // the attribute belongs to the kernel, not to a plan: only ever raised, to the device's limit
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes > 0 ? 160 * 1024 : 0);
@@ -363,10 +544,14 @@ hipError_t launch_melspec_generic(const MelspecArgs& a, int compute_dtype, hipSt
     const int tiles = (a.T + a.F - 1) / a.F;
     const dim3 grid(unsigned(a.n_items) * unsigned(tiles));
     const size_t lds = a.bl_L ? melspec_generic_lds_bytes(a.bl_L, 1, compute_dtype, true) : melspec_generic_lds_bytes(a.M, a.F, compute_dtype, false);
-    if (compute_dtype == AUD_F64)
-        hipLaunchKernelGGL(k_melspec_generic<double>, grid, dim3(256), lds, st, a);
-    else
-        hipLaunchKernelGGL(k_melspec_generic<float>, grid, dim3(256), lds, st, a);
+    const bool inpl = a.bl_L != 0 && a.bl_inplace != 0;
+    if (compute_dtype == AUD_F64) {
+        if (inpl) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_generic<double, true>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_generic<double, false>), grid, dim3(256), lds, st, a);
+    } else {
+        if (inpl) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_generic<float, true>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_generic<float, false>), grid, dim3(256), lds, st, a);
+    }
     return hipGetLastError();
 }
 

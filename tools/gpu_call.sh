@@ -51,6 +51,7 @@ for step in "$@"; do
         runlib:*) args=$(echo "${step#runlib:}" | tr ',' ' ')   # runlib:TAG,script.py,args...  (an experimental build, tools/run_with_lib.py)
                run runlib$i 400 python tools/run_with_lib.py $args
                grep '^{' "gpurun_out/${TAG}_runlib$i.log" | tail -1 > "gpurun_out/${TAG}_runlib$i.json" ;;
+        tune_bluestein) run tune_bluestein 1000 bash tools/tune_bluestein.sh ;;
         wstream) (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/stream_write stream_write.hip) &&
                 run wstream 120 /tmp/stream_write ;;
         two_ranks) run two_ranks 500 bash tools/two_ranks_one_gpu.sh "${TAG}_two" ;;
