@@ -36,6 +36,7 @@ int melspec_host_run(aud_plan* p, const void* d_sig, int sig_dtype, const aud_it
     rc = aud_melspec_batch_dev(p, d_sig, sig_dtype, static_cast<const aud_item*>(c->ws[1]), n_items, d_mel, d_pow, d_lp, c->stream);
     if (rc != AUD_OK) return rc;
     const WidenPart parts[3] = {{mel, n_mel}, {power, want_p ? n_pow : 0}, {log_power, want_lp ? n_pow : 0}};
+    if (all_parts_pinned(c, parts, 3)) return store_widened(c, d_mel, parts, 3);  // aud_host_alloc tensors: the device writes them
     return fetch_widened(c, d_mel, parts, 3);
 }
 
@@ -69,6 +70,7 @@ int melspec_mfcc_host_run(aud_plan* p, const void* d_sig, int sig_dtype, const a
     if (rc != AUD_OK) return rc;
     const WidenPart parts[7] = {{mel, n_mel}, {power, n_pow}, {log_power, n_pow}, {mfcc, n_cc}, {deltas, n_cc},
                                 {delta_deltas, n_cc}, {energy, n_en}};
+    if (all_parts_pinned(c, parts, 7)) return store_widened(c, d_mel, parts, 7);
     return fetch_widened(c, d_mel, parts, 7);
 }
 
@@ -91,6 +93,31 @@ int aud_melspec_batch_host(aud_plan* p, const double* sig, int64_t sig_total, co
     if ((rc = ensure_ws(c, 0, sig_bytes + 16)) != AUD_OK) return rc;
     AUD_HIP(c, hipMemcpyAsync(c->ws[0], sig, sig_bytes, hipMemcpyHostToDevice, c->stream));
     return melspec_host_run(p, c->ws[0], AUD_F64, items, n_items, mel, power, log_power);
+}
+
+int aud_host_alloc(aud_ctx* c, int64_t bytes, void** ptr) {
+    if (!c || !ptr || bytes <= 0) return AUD_EINVAL;
+    *ptr = nullptr;
+    AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
+    void* p = nullptr;
+    AUD_HIP(c, hipHostMalloc(&p, size_t(bytes), hipHostMallocDefault));
+    c->host_blocks.push_back({static_cast<unsigned char*>(p), size_t(bytes)});
+    *ptr = p;
+    return AUD_OK;
+}
+
+int aud_host_free(aud_ctx* c, void* ptr) {
+    if (!c || !ptr) return AUD_EINVAL;
+    (void)hipSetDevice(c->device);
+    HostCallGuard guard(c);  // (drains the stream: no kernel still writes the block)
+    for (size_t i = 0; i < c->host_blocks.size(); ++i)
+        if (c->host_blocks[i].p == ptr) {
+            c->host_blocks.erase(c->host_blocks.begin() + long(i));
+            (void)hipHostFree(ptr);
+            return AUD_OK;
+        }
+    return fail(c, AUD_EINVAL, "aud_host_free: not a block of aud_host_alloc");
 }
 
 int aud_signal_upload(aud_ctx* c, const void* samples, int sample_dtype, int64_t n_samples, aud_signal** out) {

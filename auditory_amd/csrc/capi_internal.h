@@ -30,6 +30,12 @@ struct aud_ctx {
     void* pin = nullptr;
     size_t pin_cap = 0;
     hipEvent_t pin_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // aud_host_alloc: pinned, device-visible host memory handed to the caller for result tensors (under host_mutex)
+    struct HostBlock {
+        unsigned char* p;
+        size_t bytes;
+    };
+    std::vector<HostBlock> host_blocks;
     // RCCL (loaded lazily)
     void* rccl_lib = nullptr;
     void* comm = nullptr;
@@ -250,6 +256,34 @@ inline int fetch_widened(aud_ctx* c, const float* d_src, const WidenPart* parts,
         }
         part_lo = part_hi;
     }
+    return AUD_OK;
+}
+
+// true if [p, p + bytes) lies inside one aud_host_alloc block of the context (the caller holds host_mutex)
+inline bool in_host_block(const aud_ctx* c, const void* p, size_t bytes) {
+    const unsigned char* q = static_cast<const unsigned char*>(p);
+    for (const auto& b : c->host_blocks)
+        if (q >= b.p && q + bytes <= b.p + b.bytes) return true;
+    return false;
+}
+// every requested (non-null, non-empty) part lies in aud_host_alloc memory
+inline bool all_parts_pinned(const aud_ctx* c, const WidenPart* parts, int n_parts) {
+    bool any = false;
+    for (int i = 0; i < n_parts; ++i) {
+        if (!parts[i].dst || parts[i].n == 0) continue;
+        if (!in_host_block(c, parts[i].dst, parts[i].n * sizeof(double))) return false;
+        any = true;
+    }
+    return any;
+}
+// device float32 results -> float64 in the caller's PINNED tensors, written by the device (smooth_mel.hip launch_widen_to_host)
+inline int store_widened(aud_ctx* c, const float* d_src, const WidenPart* parts, int n_parts) {
+    size_t lo = 0;
+    for (int i = 0; i < n_parts; ++i) {
+        if (parts[i].dst && parts[i].n) AUD_HIP(c, aud::launch_widen_to_host(d_src + lo, parts[i].dst, parts[i].n, c->stream));
+        lo += parts[i].n;
+    }
+    AUD_HIP(c, hipStreamSynchronize(c->stream));
     return AUD_OK;
 }
 

@@ -244,6 +244,8 @@ hipError_t launch_segment_finish(const SegmentFinishArgs& a, int compute_dtype, 
 hipError_t launch_mfcc_dct(const MfccArgs& a, int compute_dtype, hipStream_t st);
 
 // generic any-N kernel (Stockham in LDS, radix 2/4 + per-output generic radix)
+// float32 device results -> float64 in pinned, device-visible host memory (aud_host_alloc), stored over the link by the kernel
+hipError_t launch_widen_to_host(const float* src, double* dst_host, size_t n, hipStream_t st);
 size_t melspec_generic_lds_bytes(int M, int F, int compute_dtype, bool bluestein);
 bool melspec_generic_bluestein_inplace(int L);
 int melspec_generic_pick_F(int M, int compute_dtype);

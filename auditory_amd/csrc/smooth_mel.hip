@@ -155,4 +155,27 @@ hipError_t launch_mel_from_power(const MelspecArgs& a, int compute_dtype, hipStr
     return hipGetLastError();
 }
 
+namespace {
+// four values per thread and trip: one 16-byte load, two 16-byte stores -- whole 64-byte pieces per four lanes on the link
+__global__ __launch_bounds__(256) void k_widen_to_host(const float* __restrict__ src, double* __restrict__ dst, size_t n) {
+    const size_t stride = size_t(gridDim.x) * 256 * 4;
+    for (size_t i = (size_t(blockIdx.x) * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n && ((reinterpret_cast<uintptr_t>(src + i) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dst + i) & 15) == 0)) {
+            const float4 v = *reinterpret_cast<const float4*>(src + i);
+            *reinterpret_cast<double2*>(dst + i) = double2{double(v.x), double(v.y)};
+            *reinterpret_cast<double2*>(dst + i + 2) = double2{double(v.z), double(v.w)};
+        } else {
+            for (size_t u = i; u < n && u < i + 4; ++u) dst[u] = double(src[u]);
+        }
+    }
+}
+}  // namespace
+
+hipError_t launch_widen_to_host(const float* src, double* dst_host, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const size_t wgs = std::min<size_t>(1024, (n + 1023) / 1024);
+    hipLaunchKernelGGL(k_widen_to_host, dim3(unsigned(wgs)), dim3(256), 0, st, src, dst_host, n);
+    return hipGetLastError();
+}
+
 }  // namespace aud

@@ -30,6 +30,24 @@ class Context:
     def check(self, rc):
         _check(self.lib, self.handle, rc)
 
+    def pinned_empty(self, shape, dtype=np.float64):
+        """a numpy array in pinned, device-visible host memory (aud_host_alloc): result tensors given to the _host / _sig
+        calls through `out=` are written by the device itself -- no staging copy, no CPU widening pass.  The memory lives
+        until pinned_free(array) or the context's close()."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self.check(self.lib.aud_host_alloc(self.handle, max(n, 16), C.byref(p)))
+        buf = (C.c_char * max(n, 16)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.__array_interface__["data"][0]] = p.value
+        return arr
+
+    def pinned_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.__array_interface__["data"][0], None)
+        if p is not None:
+            self.check(self.lib.aud_host_free(self.handle, C.c_void_p(p)))
+
     def close(self):
         if self.handle:
             self.lib.aud_shutdown(self.handle)
@@ -56,6 +74,12 @@ class Signal:
         if self.handle:
             self.ctx.lib.aud_signal_destroy(self.handle)
             self.handle = None
+
+    def __del__(self):   # (safe in any order with Context.close(): aud_shutdown detaches the handle, the destroy frees it)
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def get_ctx(device=0):
@@ -163,13 +187,21 @@ class Plan:
                                                        vp(mel), vp(power), vp(logp)))
         return mel, power, logp
 
-    def melspec_sig(self, signal, items, want_power=False, want_log_power=False):
-        """melspec_host on a resident Signal (aud_melspec_batch_sig): only the items go up, only the results come back"""
+    def melspec_sig(self, signal, items, want_power=False, want_log_power=False, out=None):
+        """melspec_host on a resident Signal (aud_melspec_batch_sig): only the items go up, only the results come back.
+        out = (mel, power or None, log_power or None): float64 result arrays to fill -- from Context.pinned_empty the device
+        writes them directly"""
         items = np.ascontiguousarray(items, dtype=ITEM_DTYPE)
         n = len(items)
-        mel = np.zeros((n, self.nf, self.T), np.float64)
-        power = np.zeros((n, self.H, self.T), np.float64) if want_power else None
-        logp = np.zeros((n, self.H, self.T), np.float64) if want_log_power else None
+        if out is not None:
+            mel, power, logp = out
+            assert mel.shape == (n, self.nf, self.T) and mel.dtype == np.float64 and mel.flags.c_contiguous
+            for a in (power, logp):
+                assert a is None or (a.shape == (n, self.H, self.T) and a.dtype == np.float64 and a.flags.c_contiguous)
+        else:
+            mel = np.zeros((n, self.nf, self.T), np.float64)
+            power = np.zeros((n, self.H, self.T), np.float64) if want_power else None
+            logp = np.zeros((n, self.H, self.T), np.float64) if want_log_power else None
         vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
         self.ctx.check(self.lib.aud_melspec_batch_sig(self.handle, signal.handle, vp(items), n, vp(mel), vp(power), vp(logp)))
         return mel, power, logp

@@ -94,6 +94,11 @@ type SndEnv struct {
 	HostSignalPerCall bool
 	devSig            *auditoryhip.Signal
 	devSigKey         auditoryhip.SignalKey
+	// the segment tensors ProcessSegment fills (PowerSegment, LogPowerSegment, MelFBankSegment, Energy, the MFCC tensors) keep
+	// their Values in pinned host memory (auditoryhip.HostFloat64): the device writes them directly.  GoHeapTensors = true
+	// leaves them on the Go heap (results then come through the library's staging buffer and a widening pass).
+	GoHeapTensors bool
+	pinned        [][]float64
 }
 
 // ParamDefaults: sound/sndenv.go:64-71.
@@ -125,6 +130,7 @@ func (se *SndEnv) Init() (err error) {
 	}
 	se.Params.WinSamples, se.Params.StepSamples = d.WinSamples, d.StepSamples
 	se.Params.SegmentSamples, se.Params.StrideSamples, se.Params.SegmentSteps = d.SegmentSamples, d.StrideSamples, d.SegmentSteps
+	se.unpinSegmentTensors() // (before any SetShape: a tensor must not keep, or re-slice, memory that is about to be freed)
 	T, H, nf := se.Params.SegmentSteps, se.Params.WinSamples/2+1, se.Mel.FBank.NFilters
 
 	// the gabor set and the output tensors' shapes (sndenv.go:209-227): active specs -> taps, 2-D or 4-D output
@@ -177,6 +183,7 @@ func (se *SndEnv) Init() (err error) {
 			return err // no HIP device: there is no CPU fallback
 		}
 	}
+	se.pinSegmentTensors()
 	if se.plan != nil {
 		se.plan.Close()
 		se.plan = nil
@@ -231,6 +238,52 @@ func (se *SndEnv) segmentPlan() (*auditoryhip.Plan, error) {
 	}
 	se.plan, se.planKey = p, key
 	return p, nil
+}
+
+// pinSegmentTensors moves the Values of every tensor ProcessSegment fills into pinned host memory (all of them or none: the
+// library writes them from the device only when every output of the call lies there).  The tensors keep their shapes, strides
+// and names; etensor reads and writes Values through the slice, wherever it lives.
+func (se *SndEnv) unpinSegmentTensors() {
+	if len(se.pinned) == 0 {
+		return
+	}
+	for _, t := range []*etensor.Float64{&se.PowerSegment, &se.LogPowerSegment, &se.MelFBankSegment, &se.Energy,
+		&se.MFCCSegment, &se.MFCCDeltas, &se.MFCCDeltaDeltas} {
+		t.Values = nil
+	}
+	for _, s := range se.pinned {
+		se.ctx.HostFree(s)
+	}
+	se.pinned = nil
+}
+
+func (se *SndEnv) pinSegmentTensors() {
+	se.unpinSegmentTensors()
+	if se.GoHeapTensors {
+		return
+	}
+	tensors := []*etensor.Float64{&se.PowerSegment, &se.LogPowerSegment, &se.MelFBankSegment, &se.Energy}
+	if se.Mel.MFCC {
+		tensors = append(tensors, &se.MFCCSegment, &se.MFCCDeltas, &se.MFCCDeltaDeltas)
+	}
+	var got [][]float64
+	for _, t := range tensors {
+		s, err := se.ctx.HostFloat64(len(t.Values))
+		if err != nil || (len(t.Values) > 0 && s == nil) {
+			for _, g := range got {
+				se.ctx.HostFree(g)
+			}
+			return // (the Go-heap tensors of SetShape stay: the staging route)
+		}
+		got = append(got, s)
+	}
+	for i, t := range tensors {
+		for j := range got[i] {
+			got[i][j] = 0
+		}
+		t.Values = got[i]
+	}
+	se.pinned = got
 }
 
 func (se *SndEnv) dropResident() {

@@ -310,6 +310,16 @@ int aud_melspec_batch_host(aud_plan* plan, const double* sig, int64_t sig_total,
  *   samples: host; sample_dtype AUD_F64 (the Signal tensor's values), AUD_F32, or AUD_I16: the WAV's own 16-bit PCM,
  *   normalised /0x7FFF on the device exactly as sound.go:138 does in float64 (2 bytes per sample over the link).
  * The copy is a snapshot: re-upload after changing the samples.  aud_signal_destroy waits for the context's stream. */
+/* Result tensors in PINNED host memory.  The host entry points return float64 tensors (the Go tensors' type): the float32
+ * results cross the link into a staging buffer and this thread widens them into the caller's memory -- for 256 utterances
+ * a third of the call.  Tensors that live in memory from aud_host_alloc are written by the DEVICE instead: a kernel widens
+ * the float32 results and stores the float64 values straight into them over the link (no staging copy, no CPU pass).  Every
+ * _host / _sig entry point takes that route when ALL the output tensors it is given lie in such memory, and the staging route
+ * otherwise; the values are the same.  A Go caller points etensor.Float64.Values at it (unsafe.Slice over C memory is
+ * within the cgo rules; go/sound does).  aud_host_free after the last call that writes the memory; aud_shutdown frees what
+ * is left. */
+int aud_host_alloc(aud_ctx* ctx, int64_t bytes, void** ptr);
+int aud_host_free(aud_ctx* ctx, void* ptr);
 typedef struct aud_signal aud_signal;
 int aud_signal_upload(aud_ctx* ctx, const void* samples, int sample_dtype, int64_t n_samples, aud_signal** out);
 int aud_signal_destroy(aud_signal* sig);

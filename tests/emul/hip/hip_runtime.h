@@ -32,6 +32,9 @@ struct dim3 {
 };
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
+struct alignas(16) double2 {
+    double x, y;
+};
 struct alignas(16) float4 {
     float x, y, z, w;
 };

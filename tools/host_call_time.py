@@ -5,6 +5,8 @@ DESIGN.md 6 and BASELINE.md quote; never bench.py's `value`):
             results back through pinned staging, widened into the caller's float64 tensors
   sig_f64   aud_melspec_batch_sig on a signal uploaded once (aud_signal_upload): items up, results back
   sig_i16   the same on int16 PCM uploaded once (8.5 MB, normalised on the device)
+  *_reuse   ... into a caller-owned result tensor that is reused (no fresh pages per call)
+  *_pinned  ... into a result tensor from aud_host_alloc: the device widens and writes it (no staging copy, no CPU pass)
   upload_*  the one-time uploads themselves"""
 import os
 import sys
@@ -42,10 +44,16 @@ t0 = time.perf_counter(); s64 = runtime.Signal(plan.ctx, flat); res["upload_f64"
 t0 = time.perf_counter(); s16 = runtime.Signal(plan.ctx, pcm.ravel()); res["upload_i16"] = time.perf_counter() - t0
 res["sig_f64"] = timed(lambda: plan.melspec_sig(s64, items))
 res["sig_i16"] = timed(lambda: plan.melspec_sig(s16, items))
+pin_mel = plan.ctx.pinned_empty((n, 40, 104))
+res["sig_f64_pinned"] = timed(lambda: plan.melspec_sig(s64, items, out=(pin_mel, None, None)))
+res["sig_i16_pinned"] = timed(lambda: plan.melspec_sig(s16, items, out=(pin_mel, None, None)))
+keep = np.zeros((n, 40, 104))
+res["sig_f64_reuse"] = timed(lambda: plan.melspec_sig(s64, items, out=(keep, None, None)))
 a, b = plan.melspec_host(flat, items)[0], plan.melspec_sig(s64, items)[0]
 assert np.array_equal(a, b)
 print("256 utterances of 1 s, float64 plan (w20x10), float64 mel %.1f MB out" % (n * 40 * 104 * 8 / 1e6))
-for k in ("host", "sig_f64", "sig_i16"):
-    print("  %-8s %.3f ms per call = %.0f audio-s/s" % (k, res[k] * 1e3, n / res[k]))
+assert np.array_equal(plan.melspec_sig(s64, items, out=(pin_mel, None, None))[0], b)
+for k in ("host", "sig_f64", "sig_i16", "sig_f64_reuse", "sig_f64_pinned", "sig_i16_pinned"):
+    print("  %-15s %.3f ms per call = %.0f audio-s/s" % (k, res[k] * 1e3, n / res[k]))
 print("  one-time uploads: float64 signal (%.1f MB) %.2f ms, int16 PCM (%.1f MB) %.2f ms"
       % (flat.nbytes / 1e6, res["upload_f64"] * 1e3, pcm.nbytes / 1e6, res["upload_i16"] * 1e3))
