@@ -549,7 +549,7 @@ def main():  # noqa: C901
             if rc != 0:
                 raise RuntimeError("hot path launch: %d %s" % (rc, lib.aud_last_error(plan.ctx.handle)))
 
-        # configs[3]: two launches by default (tile kernel, then the LDS-staged k_gabor_lds); ONE launch with --option
+        # configs[3]: two launches by default (tile kernel, then k_gabor / k_gabor_lds by compute type); ONE launch with --option
         # item_kernel=1 (workgroup-per-item kernel: the item's mel matrix stays in LDS between the frame loop and Convolve --
         # measured slower at 256 items per launch)
         one_launch = bool(gabor and plan.info("item_kernel") == 1 and "item_kernel=1" in args.option)
@@ -559,9 +559,12 @@ def main():  # noqa: C901
         if gabor:  # the pooled on/off pairs written; the unfused path also re-reads the mel tensor
             alg += nb * 4 * GABOR_POOLS[0] * GABOR_POOLS[1] * 2 * 8 + (0 if one_launch else nb * 4 * wl.nf * wl.T)
             res["launches_per_step"] = 1 if one_launch else 2
+            lds_gabor = compute == "f32" or "gabor_kernel=0" in args.option
             res["gabor_path"] = ("fused: k_melspec_w20_item (workgroup per item, mel matrix in LDS, Convolve behind one barrier)"
-                                 if one_launch else "two launches: mel kernel (w20x10 tiles), then the LDS-staged gabor kernel "
-                                 "(k_gabor_lds: the item's mel matrix copied to LDS, float32 taps through the scalar path)")
+                                 if one_launch else "two launches: mel kernel (w20x10 tiles), then " +
+                                 ("the LDS-staged gabor kernel (k_gabor_lds: the item's mel matrix copied to LDS, float32 taps through "
+                                  "the scalar path)" if lds_gabor and "gabor_kernel=1" not in args.option else
+                                  "k_gabor (one thread per position, float64 taps and sums as gabor.go:268-283: the float64 plan's default)"))
         if full:   # Power + LogPower and the tail's four small tensors written; the unfused tail also re-reads mel + LogPower
             alg += nb * (2 * 4 * wl.H * wl.T + 4 * (3 * 13 + 1) * wl.T)
             if args.tail != "fused":
