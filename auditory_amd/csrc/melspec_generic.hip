@@ -106,8 +106,18 @@ __device__ __forceinline__ void stage_inplace(C2<TT>* buf, const C2<TT>* __restr
             const int q = s_log >= 0 ? b >> s_log : b / s, k = b - q * s;
             const int x0 = k + s * q;
             const C2<TT>* in = buf + padx(x0);
+            // (in batches of eight: `pre` may bring a table value per element -- sixteen of them in flight beside sixteen
+            //  float64 values do not fit 128 registers)
+            constexpr int kB = sizeof(TT) == 8 ? 8 : (P > 8 ? P : 8);  // (float32: everything at once, 79 registers)
 #pragma unroll
-            for (int i = 0; i < P; ++i) v[r][i] = pre(x0 + i * sm, lin_in ? in[i * din] : buf[padx(x0 + i * sm)]);
+            for (int i0 = 0; i0 < P; i0 += kB) {
+#pragma unroll
+                for (int u = 0; u < kB; ++u)
+                    if (i0 + u < P) v[r][i0 + u] = pre(x0 + (i0 + u) * sm, lin_in ? in[(i0 + u) * din] : buf[padx(x0 + (i0 + u) * sm)]);
+#if defined(__HIP_DEVICE_COMPILE__)
+                if constexpr (sizeof(TT) == 8 && P > 8) __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
         }
     }
     __syncthreads();  // every input of the stage is in registers
@@ -125,8 +135,26 @@ __device__ __forceinline__ void stage_inplace(C2<TT>* buf, const C2<TT>* __restr
 #pragma unroll
                 for (int j = 1; j < P; ++j) (lin_out ? out[j * dout] : buf[padx(y0 + j * s)]) = v[r][j];
             } else {
+                // (twiddles in batches of eight: all fifteen of a radix-16 butterfly in flight beside its sixteen values do
+                //  not fit the 128 registers four waves per SIMD leave a thread)
+                if constexpr (sizeof(TT) == 4) {
 #pragma unroll
-                for (int j = 1; j < P; ++j) (lin_out ? out[j * dout] : buf[padx(y0 + j * s)]) = cmul<TT>(v[r][j], tw[unsigned(j) * tq]);
+                    for (int j = 1; j < P; ++j) (lin_out ? out[j * dout] : buf[padx(y0 + j * s)]) = cmul<TT>(v[r][j], tw[unsigned(j) * tq]);
+                }
+                constexpr int kB = 8;
+#pragma unroll
+                for (int j0 = 1; j0 < (sizeof(TT) == 8 ? P : 0); j0 += kB) {
+                    C2<TT> w8[kB];
+#pragma unroll
+                    for (int u = 0; u < kB; ++u)
+                        if (j0 + u < P) w8[u] = tw[unsigned(j0 + u) * tq];
+#pragma unroll
+                    for (int u = 0; u < kB; ++u)
+                        if (j0 + u < P) (lin_out ? out[(j0 + u) * dout] : buf[padx(y0 + (j0 + u) * s)]) = cmul<TT>(v[r][j0 + u], w8[u]);
+#if defined(__HIP_DEVICE_COMPILE__)
+                    if constexpr (sizeof(TT) == 8 && P > 8) __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
             }
         }
     }

@@ -181,7 +181,12 @@ def test_kernels_use_no_scratch_and_fit_their_occupancy():
     from auditory_amd import build as B
     # waves per SIMD each kernel's launch geometry assumes (its LDS allows no more than this anyway)
     need_occupancy = {"k_melspec_w16IfL": 5, "k_melspec_w20IfL": 5, "k_melspec_w64IfL": 5, "k_melspec_w16IdL": 3,
-                      "k_melspec_w20IdL": 4, "k_melspec_w64IdL": 3, "k_melspec_genericIf": 2}
+                      "k_melspec_w20IdL": 4, "k_melspec_w64IdL": 3, "k_melspec_genericIf": 2,
+                      "k_melspec_genericIdLb1": 4, "k_melspec_genericIfLb1": 4}   # in-place Bluestein: four workgroups per CU
+    # the float64 in-place Bluestein kernel is HELD at four waves per SIMD (amdgpu_waves_per_eu: its one-buffer layout exists for
+    # the occupancy); the allocator parks three registers once per radix-16 stage for that -- three dword spill / reload pairs
+    # in 24 000 instructions, measured 15 % faster than the same kernel at three waves without them
+    scratch_allowed = {"k_melspec_genericIdLb1": 16}
     seen = {}
     for src in ("melspec_w16.hip", "melspec_w20.hip", "melspec_w64.hip", "melspec_generic.hip", "smooth_mel.hip", "mfcc.hip", "gabor.hip", "kwta.hip"):
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17",
@@ -202,7 +207,7 @@ def test_kernels_use_no_scratch_and_fit_their_occupancy():
     assert len(seen) >= 20
     checked = set()
     for name, res in seen.items():
-        assert res["scratch"] == 0, (name, res)
+        assert res["scratch"] <= max([v for k, v in scratch_allowed.items() if k in name] or [0]), (name, res)
         # (the register file is unified on gfx950, so hipcc's occupancy counts accumulation registers too)
         for key, need in need_occupancy.items():
             if key in name:
