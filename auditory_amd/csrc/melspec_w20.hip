@@ -148,8 +148,13 @@ __device__ __forceinline__ void w20_tile_front(const MelspecArgs& a, const WaveA
     AUD_STAMP(7);
 }
 
+#ifdef AUD_EXP_W20_WAVES5
+#define AUD_W20_F64_WAVES 5
+#else
+#define AUD_W20_F64_WAVES 4
+#endif
 template <typename TT, int SRC, int NW, int MAXS>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(sizeof(TT) == 8 ? 4 : 5, sizeof(TT) == 8 ? 4 : 5)))
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(sizeof(TT) == 8 ? AUD_W20_F64_WAVES : 5, sizeof(TT) == 8 ? AUD_W20_F64_WAVES : 5)))
 void k_melspec_w20(const aud_item* items, unsigned total, unsigned tiles, unsigned tile_mul, int tile_shift, const void* blob_ptr,
                    int blob_bytes, unsigned n_wgs, int xcd_remap, const MelspecArgs a, const WaveArgs e) {
     using L = w20::Layout<TT>;
