@@ -39,6 +39,12 @@ def main():
             PC.case_process_fused_vs_oracle(orc, capi.AUD_F64, PC.HostMem(), name="sndenv_16k_n400_nf32", n=2, pools=(8, 4))
             PC.case_resident_signal(orc, capi.AUD_F32)
             PC.case_kwta_quick(orc)
+            # round 5: the in-place Bluestein route (pair transform in float64, one frame per transform in float32; one padded
+            # LDS buffer, stages through registers), the bin-per-lane spectrum outputs, and the direct all-gather's arrival flags
+            # (system-scope atomics polled by one lane per peer: what ThreadSanitizer is for)
+            PC.case_melspec_vs_oracle(orc, ("cfg1_44k_n1103_nf32", 0.12, 1, [0]), capi.AUD_F64)
+            PC.case_melspec_vs_oracle(orc, ("cfg1_44k_n1103_nf32", 0.12, 1, [0]), capi.AUD_F32)
+            PC.case_direct_gather_three_ranks()
         else:
             PC.case_melspec_vs_oracle(orc, by_name[which], capi.AUD_F32)
     print("DRIVE-OK", variant, which)

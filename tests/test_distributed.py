@@ -52,50 +52,10 @@ def test_sharded_melspec_allgather_gloo(world, n_total):
 
 
 def test_direct_allgather_indexing_emulated():
-    """aud_gather_* (the direct-pattern all-gather: one device-to-device push per peer) on the CPU emulator: three ranks as
-    three contexts of one process (the emulator's inter-process handle carries the pointer), uneven counts, two rounds --
-    every rank's receive buffer ends up [slot r] = rank r's slab, nothing beyond a slab's count is touched, and the
-    misuse paths are AUD_EINVAL"""
-    import ctypes as C
-    import numpy as np
+    """aud_gather_* (the direct-pattern all-gather: one device-to-device push per peer, arrival flags, two receive slabs) on the
+    CPU emulator: parity_cases.case_direct_gather_three_ranks"""
     sys.path.insert(0, os.path.join(HERE, "emul"))
     import backend
-    from auditory_amd import capi, runtime
-    from auditory_amd.batch import DirectGather
-    G, slab = 3, 1000
+    import parity_cases as PC
     with backend.emulated("plain"):
-        ctxs = [runtime.Context(0) for _ in range(G)]
-        gs = [DirectGather(ctxs[r], G, r, slab) for r in range(G)]
-        with pytest.raises(capi.AuditoryError):                       # peers not opened yet
-            gs[0].allgather(0, 10)
-        for g in gs:
-            g.open_peers([x.handle for x in gs])
-        with pytest.raises(capi.AuditoryError):
-            gs[0].open_peers([x.handle for x in gs])                  # twice
-        bufs = [np.ctypeslib.as_array(C.cast(g.recv_ptr, C.POINTER(C.c_float)), shape=(2, G, slab)) for g in gs]
-        for rnd, counts in enumerate(([1000, 700, 1], [5, 1000, 999], [1, 2, 3])):
-            for b in bufs:
-                b[rnd & 1] = -1.0
-            sends = [np.arange(counts[r], dtype=np.float32) + 1000.0 * (r + 1) + rnd for r in range(G)]
-            for r in range(G):
-                assert gs[r].allgather(sends[r].ctypes.data, counts[r]) == rnd & 1     # the slabs alternate per step
-            for r in range(G):
-                gs[r].wait()                                                            # every peer's flag has reached this step
-            assert [g.timeouts() for g in gs] == [0] * G
-            for b in bufs:
-                for r in range(G):
-                    assert np.array_equal(b[rnd & 1, r, :counts[r]], sends[r]) and (b[rnd & 1, r, counts[r]:] == -1.0).all()
-            if rnd == 1:      # the previous step's slab is untouched by this one
-                assert bufs[0][0, 0, 0] == 1000.0 and bufs[0][0, 1, 0] == 2000.0
-        # a peer that never arrives: the wait ENDS at its poll bound and is counted (never a hung queue)
-        gs[0].allgather(sends[0].ctypes.data, 1)
-        gs[0].wait()
-        assert gs[0].timeouts() == G - 1
-        for r in range(1, G):
-            gs[r].allgather(sends[r].ctypes.data, 1)
-        with pytest.raises(capi.AuditoryError):
-            gs[1].allgather(sends[1].ctypes.data, slab + 1)           # more than the slab
-        for g in gs:
-            g.close()
-        for c in ctxs:
-            c.close()
+        PC.case_direct_gather_three_ranks()
