@@ -869,7 +869,8 @@ template <typename TT, int FPW, int MAXS, bool COMPACT = false, bool FUSE = fals
 __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const WaveArgs& e, const float* P, int Hp,
                                                   const unsigned char* smem, int sc, const aud_item& it,
                                                   int item, int t0, int lane, const int* exps = nullptr,
-                                                  float* mel_lds = nullptr, float* stash = nullptr, int stash_i = 0) {
+                                                  float* mel_lds = nullptr, float* stash = nullptr, int stash_i = 0,
+                                                  float (*keep)[4] = nullptr) {
     wave_spectrum_outputs<TT, FPW, FUSE>(a, P, Hp, exps, sc, it, item, t0, lane);
     // 64 is not a multiple of FPW = 6: lanes 60..63 have no filter group; they run group n_groups - 1 again and store nothing
     const int T = a.T;
@@ -953,6 +954,13 @@ __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const Wa
                 // one frame per wave (w64x16): a frame's values would be n_filters 4-byte stores into as many cache lines; with a
                 // stash the wave parks them in LDS, [slot][lane][4 frames], and writes 16-byte [filter][4 steps] pieces behind
                 // its fourth frame (wave_mel_flush4)
+#ifdef AUD_EXP_W64_KEEP  // (experiment: the wave's four frames' values of slots 0 / 1 held in REGISTERS instead of an LDS stash)
+                if (keep && k < 2) {
+                    const float val = live ? res : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) keep[k][j] = stash_i == j ? val : keep[k][j];
+                } else
+#endif
                 if (stash) stash[(k * 64 + lane) * 4 + stash_i] = live ? res : 0.f;
                 else if (col_on && flt != 0xFFFF) mel_col[size_t(flt) * T] = live ? res : 0.f;
             } else {
