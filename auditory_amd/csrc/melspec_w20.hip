@@ -300,10 +300,15 @@ size_t w20_region_bytes(bool f64) { return f64 ? size_t(w20::Layout<double>::kRe
 wave_kernel_t w20_kernel(bool, int, int) { return k_melspec_w20<double, AUD_F32, 4, 4>; }
 item_kernel_t w20_item_kernel(bool, int, int, int) { return k_melspec_w20_item<double, AUD_F32, 5, 4>; }
 #else
+#ifdef AUD_EXP_W20_NW  // (experiment: waves per workgroup of the tile kernel; melspec_wave.hip wave_kernel_waves follows)
+#define AUD_W20_NW AUD_EXP_W20_NW
+#else
+#define AUD_W20_NW 4
+#endif
 #define AUD_W20_PICK(TT)                                                                                  \
-    (sig_dtype == AUD_F64   ? (s8 ? k_melspec_w20<TT, AUD_F64, 4, 8> : k_melspec_w20<TT, AUD_F64, 4, 4>)   \
-     : sig_dtype == AUD_I16 ? (s8 ? k_melspec_w20<TT, AUD_I16, 4, 8> : k_melspec_w20<TT, AUD_I16, 4, 4>)   \
-                            : (s8 ? k_melspec_w20<TT, AUD_F32, 4, 8> : k_melspec_w20<TT, AUD_F32, 4, 4>))
+    (sig_dtype == AUD_F64   ? (s8 ? k_melspec_w20<TT, AUD_F64, AUD_W20_NW, 8> : k_melspec_w20<TT, AUD_F64, AUD_W20_NW, 4>)   \
+     : sig_dtype == AUD_I16 ? (s8 ? k_melspec_w20<TT, AUD_I16, AUD_W20_NW, 8> : k_melspec_w20<TT, AUD_I16, AUD_W20_NW, 4>)   \
+                            : (s8 ? k_melspec_w20<TT, AUD_F32, AUD_W20_NW, 8> : k_melspec_w20<TT, AUD_F32, AUD_W20_NW, 4>))
 wave_kernel_t w20_kernel(bool f64, int sig_dtype, int n_slots) {
     const bool s8 = n_slots > 4;
     return f64 ? AUD_W20_PICK(double) : AUD_W20_PICK(float);

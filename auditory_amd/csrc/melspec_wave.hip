@@ -37,7 +37,12 @@ namespace aud {
 // (the N = 2048 kernel's float64 tables + planes fill a CU with ONE workgroup of twelve waves = three per SIMD; two
 // workgroups of six were measured to leave one of them waiting: six waves land 2-2-1-1 on the SIMDs and the second
 // workgroup's pair does not fit beside the first's at 160 VGPRs)
-static int wave_kernel_waves(int kind, int compute_dtype) { return kind == 4 && compute_dtype == AUD_F64 ? 12 : 4; }
+static int wave_kernel_waves(int kind, int compute_dtype) {
+#ifdef AUD_EXP_W20_NW
+    if (kind == 3) return AUD_EXP_W20_NW;
+#endif
+    return kind == 4 && compute_dtype == AUD_F64 ? 12 : 4;
+}
 
 int melspec_wave_kind(int N) { return N == w16::kN ? 1 : N == w20::kN ? 3 : N == w64::kN ? 4 : 0; }
 

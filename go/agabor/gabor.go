@@ -74,6 +74,7 @@ func Convolve(melData *etensor.Float64, filters FilterSet, rawOut *etensor.Float
 		log.Println(err)
 		return
 	}
+	defer p.Close()
 	shp := make([]int32, rawOut.NumDims())
 	for i := range shp {
 		shp[i] = int32(rawOut.Dim(i))
@@ -85,6 +86,6 @@ func Convolve(melData *etensor.Float64, filters FilterSet, rawOut *etensor.Float
 
 // ToTable: agabor/gabor.go:320-327 (GUI helper: the filters as a table of [SizeY, SizeX] cells).
 func (fs *FilterSet) ToTable(set FilterSet, tab *etable.Table) {
-	tab.SetFromSchema(etable.Schema{{"Filter", etensor.FLOAT32, []int{1, set.SizeY, set.SizeX}, []string{"Filter", "Y", "X"}}}, set.Filters.Dim(0))
+	tab.SetFromSchema(etable.Schema{{"Filter", etensor.FLOAT64, []int{1, fs.SizeX, fs.SizeY}, []string{"Filter", "Y", "X"}}}, fs.Filters.Dim(0))
 	tab.Cols[0].SetFloats(set.Filters.Values)
 }

@@ -154,37 +154,11 @@ func SamplesToMSec(samples, rate int) float64 {
 	return float64(C.aud_samples_to_msec(C.int(samples), C.int(rate)))
 }
 
-// Power is dft.Params.Power (dft/dft.go:62-85) for one step on coefficients the caller computed; power is the
-// carry of the previous step on entry.  logPower / logPowerSeg may be nil.
-func (p *Plan) Power(step int, fftCoefs []complex128, power, logPower, powerSeg, logPowerSeg []float64) error {
-	ptr := func(s []float64) *C.double {
-		if len(s) == 0 {
-			return nil
-		}
-		return (*C.double)(unsafe.Pointer(&s[0]))
-	}
-	rc := C.aud_dft_power_host(p.h, C.int(step), (*C.double)(unsafe.Pointer(&fftCoefs[0])), ptr(power), ptr(logPower),
-		ptr(powerSeg), ptr(logPowerSeg))
-	return status(p.ctx, rc)
-}
-
-// CepstrumDct is mel.Params.CepstrumDct (mel/mel.go:192-212) for one step; the plan must have been created with
-// mfcc_coefs = NCoefs.  mfccSeg is [NCoefs][Steps] row-major; mfccDct (may be nil) ends as a copy of fbank.
-func (p *Plan) CepstrumDct(step int, fbank, mfccSeg, mfccDct []float64) error {
-	var work *C.double
-	if len(mfccDct) > 0 {
-		work = (*C.double)(unsafe.Pointer(&mfccDct[0]))
-	}
-	rc := C.aud_cepstrum_dct_host(p.h, C.int(step), (*C.double)(unsafe.Pointer(&fbank[0])),
-		(*C.double)(unsafe.Pointer(&mfccSeg[0])), work)
-	return status(p.ctx, rc)
-}
-
 // KwtaParams copies the exported fields of a kwta.KWTA (github.com/emer/vision/kwta) into the C struct,
 // one for one.  The derived fields (ErevSubThr, ThrSubErev, ActDt, the nxx1 Sig* values, FBDt) are
 // recomputed inside the library, like KWTA.Update() does.
 func KwtaParams(k *kwta.KWTA) C.aud_kwta_params {
-	fffb := func(p *fffb.Params) C.aud_fffb_params {
+	toC := func(p *fffb.Params) C.aud_fffb_params {
 		on := C.int32_t(0)
 		if p.On {
 			on = 1
@@ -198,7 +172,7 @@ func KwtaParams(k *kwta.KWTA) C.aud_kwta_params {
 	}
 	c.iters = C.int32_t(k.Iters)
 	c.del_act_thr = C.float(k.DelActThr)
-	c.lay_fffb, c.pool_fffb = fffb(&k.LayFFFB), fffb(&k.PoolFFFB)
+	c.lay_fffb, c.pool_fffb = toC(&k.LayFFFB), toC(&k.PoolFFFB)
 	x := &k.XX1
 	c.xx1 = C.aud_nxx1_params{thr: C.float(x.Thr), gain: C.float(x.Gain), nvar: C.float(x.NVar),
 		vm_act_thr: C.float(x.VmActThr), sig_mult: C.float(x.SigMult), sig_mult_pow: C.float(x.SigMultPow),

@@ -21,7 +21,7 @@ type Params struct {
 	CurSmooth  float64
 
 	plan    *auditoryhip.Plan // per-step plan (one frame per call), rebuilt when the window length changes
-	planKey [6]float64
+	planKey [7]float64
 }
 
 // Defaults: dft/dft.go:33-39 (LogOffSet is 1.0 there, whatever the struct tag says).
@@ -32,7 +32,11 @@ func (dft *Params) Defaults() {
 }
 
 func (dft *Params) stepPlan(winSamples, steps int) *auditoryhip.Plan {
-	key := [6]float64{float64(winSamples), float64(steps), dft.LogMin, dft.LogOffSet, dft.PrevSmooth, dft.CurSmooth}
+	logPow := 0.0
+	if dft.CompLogPow {
+		logPow = 1
+	}
+	key := [7]float64{float64(winSamples), float64(steps), dft.LogMin, dft.LogOffSet, dft.PrevSmooth, dft.CurSmooth, logPow}
 	if dft.plan == nil || key != dft.planKey {
 		if dft.plan != nil {
 			dft.plan.Close()

@@ -33,7 +33,9 @@ type Params struct {
 	Deltas  bool
 	NCoefs  int
 	plan    *auditoryhip.Plan
-	planKey [4]int
+	planKey stepKey
+	bins    int       // spectrum length and filter table InitFilters / FilterDft last saw: CepstrumDct, which is handed
+	tab     []float64 // neither, runs on the same per-step plan
 }
 
 // Defaults: mel/mel.go:69-74 and :171-180.
@@ -59,12 +61,14 @@ func (mel *Params) InitFilters(dftSize int, sampleRate int, filters *etensor.Flo
 	if err := auditoryhip.MelInitFiltersGo(&fb, dftSize, sampleRate, mel.BinPts, mel.HzPts, filters.Values); err != nil {
 		log.Println(err) // where the reference would index past the table and panic
 	}
+	mel.bins, mel.tab = dftSize/2+1, filters.Values
 	mel.FBank.Renorm = false
 }
 
 // FilterDft: mel/mel.go:120-153, one step.
 func (mel *Params) FilterDft(step int, dftPowerOut *etensor.Float64, segmentData *etensor.Float64, fBankData *etensor.Float64, filters *etensor.Float64) {
-	p := mel.stepPlan(dftPowerOut.Len(), segmentData.Dim(1), filters)
+	mel.bins, mel.tab = dftPowerOut.Len(), filters.Values
+	p := mel.stepPlan(segmentData.Dim(1))
 	if p == nil {
 		return
 	}
@@ -87,7 +91,7 @@ func (mel *Params) FftReal(out []complex128, in *etensor.Float64) {
 
 // CepstrumDct: mel/mel.go:192-212 (DCT-I of the log-mel values, c0 <- ln(1 + c0^2), NCoefs kept).
 func (mel *Params) CepstrumDct(step int, fBankData *etensor.Float64, mfccSegment *etensor.Float64, mfccDct *etensor.Float64) {
-	p := mel.stepPlan(0, mfccSegment.Dim(1), nil)
+	p := mel.stepPlan(mfccSegment.Dim(1)) // (the plan FilterDft runs on when the segment tensors have the same steps)
 	if p == nil {
 		return
 	}
@@ -102,17 +106,28 @@ func (mfb *FilterBank) toC() auditoryhip.MelFBank {
 		RenormScale: mfb.RenormScale}
 }
 
-func (mel *Params) stepPlan(bins, steps int, filters *etensor.Float64) *auditoryhip.Plan {
-	key := [4]int{bins, steps, mel.FBank.NFilters, mel.NCoefs}
+type stepKey struct {
+	bins, steps, nCoefs int
+	fbank               FilterBank
+}
+
+func (mel *Params) stepPlan(steps int) *auditoryhip.Plan {
+	nf := mel.FBank.NFilters
+	if mel.bins < 2 || len(mel.BinPts) != nf+2 || len(mel.tab) < nf*(nf+2) {
+		log.Println("mel: InitFilters has not run for these parameters")
+		return nil
+	}
+	nc := 0
+	if mel.MFCC {
+		nc = mel.NCoefs
+	}
+	key := stepKey{mel.bins, steps, nc, mel.FBank} // FilterDft reads FBank.LogOff / LogMin / Renorm* at call time (mel.go:133-149)
 	if mel.plan == nil || key != mel.planKey {
 		if mel.plan != nil {
 			mel.plan.Close()
+			mel.plan = nil
 		}
-		var tab []float64
-		if filters != nil {
-			tab = filters.Values
-		}
-		p, err := auditoryhip.NewMelStepPlan(2*(bins-1), steps, mel.FBank.toC(), mel.BinPts, tab, mel.NCoefs)
+		p, err := auditoryhip.NewMelStepPlan(2*(mel.bins-1), steps, mel.FBank.toC(), mel.BinPts, mel.tab, nc)
 		if err != nil {
 			log.Println(err)
 			return nil
