@@ -144,6 +144,12 @@ func (p *Plan) Convolve(mel []float64, nItems, rows, cols int, outShape []int32,
 	if byTime {
 		bt = 1
 	}
+	if nItems <= 0 {
+		return nil
+	}
+	if len(mel) < nItems*rows*cols || len(outShape) == 0 || len(out) == 0 {
+		return errors.New("auditory_hip: Convolve: empty or short tensor") // (the reference logs and returns: gabor.go:226-229)
+	}
 	rc := C.aud_gabor_batch_host(p.h, (*C.double)(unsafe.Pointer(&mel[0])), C.int(nItems), C.int(rows), C.int(cols),
 		C.int(len(outShape)), (*C.int32_t)(unsafe.Pointer(&outShape[0])), bt, (*C.float)(unsafe.Pointer(&out[0])))
 	return status(p.ctx, rc)
@@ -488,6 +494,12 @@ func GaborPlan(sx, sy, stx, sty int, gain float64, taps []float64) (*Plan, error
 
 // MelSpecMFCC is ProcessSegment with Mel.MFCC on (sndenv.go:342-435) for all items in one call.
 func (p *Plan) MelSpecMFCC(sig []float64, items []Item, mel, power, logPower, mfcc, deltas, deltaDeltas, energy []float64) error {
+	if len(items) == 0 {
+		return nil
+	}
+	if len(mel) < len(items)*p.NFilters*p.Steps || len(mfcc) < len(items)*p.NCoefs*p.Steps {
+		return errors.New("auditory_hip: mel / mfcc buffer too small")
+	}
 	ptr := func(s []float64) *C.double {
 		if len(s) == 0 {
 			return nil
