@@ -196,3 +196,80 @@ class DirectGather:
 
     def close(self):
         self.ctx.check(self.lib.aud_gather_destroy(self.ctx.handle))
+
+
+class HostGather:
+    """SURVEY 8(e)'s alternative for consumers that want the features on the HOST: no collective -- every rank copies its
+    slab over its own PCIe link into ITS slot of one host buffer that all ranks of the node map.  The buffer
+    [slabs, n_ranks, slab_floats] float32 is POSIX shared memory (`/dev/shm/<name>`: rank 0 creates it, the others map it),
+    registered with the HIP runtime on GPU ranks so that `put` is an asynchronous device-to-host copy on the caller's
+    stream (capturable).  When every rank's stream has passed its `put` (the caller's barrier, or an event per rank), slab
+    `s` of `view()` is the batch's full [B, ...] tensor in rank order -- rank 0 usually being the one that reads it.
+    Floor per step: one slab at the PCIe rate (64 GB/s: 133 us for configs[2]'s 8.5 MB), against one slab per xGMI link for the
+    device all-gather -- this mode is about WHERE the result is wanted, not about speed."""
+
+    def __init__(self, name, n_ranks, rank, slab_floats, device="cpu", slabs=2, timeout=60.0):
+        import os
+        import time
+        self.n_ranks, self.rank, self.slab, self.slabs = int(n_ranks), int(rank), int(slab_floats), int(slabs)
+        if not (0 <= self.rank < self.n_ranks) or self.slab <= 0 or self.slabs <= 0:
+            raise capi.AuditoryError(capi.AUD_EINVAL, "HostGather: bad rank / slab")
+        self.path = os.path.join("/dev/shm", name)
+        floats = self.slabs * self.n_ranks * self.slab
+        self.nbytes = 4 * floats
+        if self.rank == 0:
+            fd = os.open(self.path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+            try:
+                os.ftruncate(fd, self.nbytes)
+            finally:
+                os.close(fd)
+        else:
+            t0 = time.monotonic()
+            while not (os.path.exists(self.path) and os.path.getsize(self.path) == self.nbytes):
+                if time.monotonic() - t0 > timeout:
+                    raise capi.AuditoryError(capi.AUD_EINVAL, "HostGather: rank 0's buffer %s did not appear" % self.path)
+                time.sleep(0.01)
+        self.buf = torch.from_file(self.path, shared=True, size=floats, dtype=torch.float32).view(self.slabs, self.n_ranks, self.slab)
+        self.device = torch.device(device)
+        self.registered = False
+        if self.device.type == "cuda":
+            rc = torch.cuda.cudart().cudaHostRegister(self.buf.data_ptr(), self.nbytes, 0)
+            if int(rc) != 0:
+                self.close()
+                raise capi.AuditoryError(capi.AUD_EHIP, "HostGather: the runtime refused to register the shared buffer (%s)" % rc)
+            self.registered = True
+
+    @classmethod
+    def create(cls, n_ranks, rank, slab_floats, device="cpu", group=None, slabs=2):
+        """agree on the buffer's name over torch.distributed (any backend), map it on every rank, and return when all have"""
+        import os
+        import torch.distributed as dist
+        name = [None]
+        if rank == 0:
+            name[0] = "auditory_hip_gather_%d_%s" % (os.getpid(), os.urandom(4).hex())
+        if n_ranks > 1:
+            dist.broadcast_object_list(name, src=0, group=group)
+        g = cls(name[0], n_ranks, rank, slab_floats, device, slabs)
+        if n_ranks > 1:
+            dist.barrier(group=group)
+        return g
+
+    def put(self, local, slab=0):
+        """queue the copy of this rank's [B_r, ...] float32 tensor into its slot of slab `slab` on the current stream"""
+        flat = local.reshape(-1)
+        if flat.dtype != torch.float32 or flat.numel() > self.slab or not (0 <= slab < self.slabs):
+            raise capi.AuditoryError(capi.AUD_EINVAL, "HostGather.put: float32 tensor of at most %d elements" % self.slab)
+        self.buf[slab, self.rank, :flat.numel()].copy_(flat, non_blocking=True)
+
+    def view(self, slab=0):
+        """[n_ranks, slab_floats] float32 host tensor (no copy): rank r's slab in row r"""
+        return self.buf[slab]
+
+    def close(self):
+        import os
+        if self.registered:
+            torch.cuda.cudart().cudaHostUnregister(self.buf.data_ptr())
+            self.registered = False
+        self.buf = None
+        if self.rank == 0 and os.path.exists(self.path):
+            os.unlink(self.path)

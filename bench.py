@@ -317,7 +317,7 @@ def main():  # noqa: C901
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="aud_plan_set_option switches, e.g. kernel=1 (the generic kernel)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for CPU dry runs)")
-    ap.add_argument("--gather-mode", choices=["rccl", "direct"], default="rccl",
+    ap.add_argument("--gather-mode", choices=["rccl", "direct", "host"], default="rccl",
                     help="the multi-GPU region's collective: rccl = ncclAllGather (the reported default); direct = the library's "
                          "direct pattern (aud_gather_*: one device-to-device push per peer over its own xGMI link, SURVEY 5) -- the "
                          "fallback if RCCL picks a ring for these 8.5 MB slabs")
@@ -608,7 +608,7 @@ def main():  # noqa: C901
         use_streams = gather and args.dist_backend == "nccl"
         comm = torch.cuda.Stream(dev) if use_streams else None
         even = total % world == 0
-        direct = None
+        direct = host = None
         mode = mode or args.gather_mode
         if gather and mode == "direct":
             if not even:
@@ -634,6 +634,21 @@ def main():  # noqa: C901
                 raise RuntimeError("direct gather: mapping a peer's buffer failed on a rank (%s)" % err)
             recv = direct.recv(dev).view(2, total, wl.nf, wl.T)   # two receive slabs: consecutive steps alternate between them
             full = [recv[0], recv[1]]
+        elif gather and mode == "host":
+            # SURVEY 8(e)'s alternative: NO collective -- every rank copies its slab over its own PCIe link into its slot of one
+            # host buffer all ranks map (batch.HostGather); the batch ends on the host in rank order
+            if not even:
+                raise SystemExit("--gather-mode host needs the total batch to divide evenly over the ranks")
+            from auditory_amd.batch import HostGather
+            err = None
+            try:
+                host = HostGather.create(world, rank, nb * wl.nf * wl.T, device=dev)
+            except Exception as ex:
+                err = ex
+            if not all_ranks_ok(err is None):
+                plan.close()
+                raise RuntimeError("host gather: mapping / registering the shared buffer failed on a rank (%s)" % err)
+            full = [host.view(0).view(total, wl.nf, wl.T), host.view(1).view(total, wl.nf, wl.T)]
         else:
             full = [torch.empty((total,) + tuple(mel3[0].shape[1:]), dtype=torch.float32, device=dev) for _ in range(2)] if gather else None
         # RCCL through the library's OWN communicator (aud_comm_* / aud_allgather_dev: ncclAllGather on the stream it is
@@ -641,7 +656,7 @@ def main():  # noqa: C901
         # pulls its internal stream into the capture, and its watchdog thread then queries events of that stream from the
         # side -- "operation not permitted on an event last recorded in a capturing stream" aborts the process when the
         # timing is unlucky (seen once in this round's runs).  torch.distributed stays the control plane (ids, barriers).
-        own_comm = gather and direct is None and even and use_streams
+        own_comm = gather and direct is None and host is None and even and use_streams
         if own_comm:
             import ctypes as C
             uid = [None]
@@ -659,6 +674,8 @@ def main():  # noqa: C901
             if direct is not None:
                 slab_of[s] = direct.allgather(mel3[s].data_ptr(), nb * wl.nf * wl.T, st)   # pushes + arrival signals ...
                 direct.wait(st)   # ... and the wait for every peer's: behind it the step's slab is complete HERE (like ncclAllGather)
+            elif host is not None:
+                host.put(mel3[s], s)      # (asynchronous device-to-host copy on the current stream: the comm stream, or the lane's)
             elif own_comm:
                 plan.ctx.check(lib.aud_allgather_dev(plan.ctx.handle, mel3[s].data_ptr(), full[s].data_ptr(), nb * wl.nf * wl.T, st))
             elif even:
@@ -699,7 +716,9 @@ def main():  # noqa: C901
             torch.cuda.synchronize(dev)
         res.update({"workload": wl.name, "compute": compute, "kernel": plan.kernel_name, "total_batch": total,
                     "streams_this_rank": nb, "rccl_ranks": world if gather else 0,
-                    "collective": (("direct pattern (aud_allgather_direct_dev: one device-to-device push per peer on its own "
+                    "collective": (("none: every rank copies its slab over PCIe into its slot of one host buffer all ranks map "
+                                    "(batch.HostGather, SURVEY 8e's host mode; two slabs alternate)" if host is not None else
+                                    "direct pattern (aud_allgather_direct_dev: one device-to-device push per peer on its own "
                                     "stream with its arrival signal behind it, then a bounded wait for every peer's signal; two receive "
                                     "slabs alternate)" if direct is not None else
                                     "ncclAllGather (RCCL, on the library's own communicator: aud_comm_* / aud_allgather_dev)" if own_comm else
@@ -717,6 +736,10 @@ def main():  # noqa: C901
                 "direction (153.6 GB/s per link bidirectional)" % slab_bytes, "at_153.6_GBps_per_direction": round(slab_bytes / 153.6e9 * 1e6, 1)}
         if direct is not None:
             res["arrival_timeouts"] = int(max_over_ranks(float(direct.timeouts())))
+        if host is not None:
+            torch.cuda.synchronize(dev)
+            sync_all()   # every rank's copies have landed (own device drained, THEN the barrier) before rank 0 reads the host buffer below
+            res["pcie_bound_us"] = {"per_step": round(nb * wl.nf * wl.T * 4 / 64e9 * 1e6, 1), "assumes": "one slab per step over this rank's own PCIe Gen5 x16 link at 64 GB/s"}
         if rank == 0:  # the (gathered) tensors of the last two steps against the oracle, strict: rows of EVERY rank's block
             from auditory_amd import synth
             osd = OracleSide(wl)
@@ -741,6 +764,9 @@ def main():  # noqa: C901
         if direct is not None:
             sync_all()
             direct.close()
+        if host is not None:
+            sync_all()   # (rank 0 unlinks the buffer: not before every rank has stopped using it)
+            host.close()
         if own_comm:
             sync_all()
             plan.ctx.check(lib.aud_comm_destroy(plan.ctx.handle))

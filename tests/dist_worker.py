@@ -16,7 +16,7 @@ import torch.distributed as dist  # noqa: E402
 import backend  # noqa: E402
 import workloads as W  # noqa: E402
 from auditory_amd import capi, runtime, synth  # noqa: E402
-from auditory_amd.batch import allgather_features, shard_range  # noqa: E402
+from auditory_amd.batch import HostGather, allgather_features, shard_range  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 
@@ -45,7 +45,22 @@ def main():
     t = torch.from_numpy(full.copy())
     dist.broadcast(t, 0)
     assert np.array_equal(t.numpy(), full)
+    # SURVEY 8(e)'s alternative: no collective, every rank copies its slab into its slot of ONE host buffer all ranks map;
+    # behind a barrier rank 0 (and everyone else) reads the batch in rank order -- the same values as the all-gather's
+    longest = max(b - a for a, b in (shard_range(n_total, r, world) for r in range(world)))
+    hg = HostGather.create(world, rank, longest * oc.nf * oc.T)
+    for slab in (0, 1):
+        hg.put(torch.from_numpy(mel.astype(np.float32)) + float(slab), slab)
     dist.barrier()
+    for slab in (0, 1):
+        rows = hg.view(slab).view(world, longest, oc.nf, oc.T)
+        got = torch.cat([rows[r, :b - a] for r, (a, b) in enumerate(shard_range(n_total, r, world) for r in range(world))]).numpy()
+        assert np.array_equal(got, full + np.float32(slab), equal_nan=True), slab
+    dist.barrier()          # nobody unmaps (rank 0: unlinks) before everyone has read
+    path = hg.path
+    hg.close()
+    dist.barrier()
+    assert not os.path.exists(path)
     dist.destroy_process_group()
     print("RANK-OK", rank, lo, hi)
 

@@ -59,3 +59,36 @@ def test_direct_allgather_indexing_emulated():
     import parity_cases as PC
     with backend.emulated("plain"):
         PC.case_direct_gather_three_ranks()
+
+
+def test_host_gather_single_process(tmp_path):
+    """batch.HostGather with both ranks in ONE process (two mappings of the same shared buffer): slots, slabs, short slabs,
+    argument checks, and the file is gone after rank 0's close"""
+    import torch
+    from auditory_amd import capi
+    from auditory_amd.batch import HostGather
+    name = "auditory_hip_test_%d" % os.getpid()
+    a = HostGather(name, 2, 0, 12)
+    with pytest.raises(FileExistsError):
+        HostGather(name, 2, 0, 12)                       # the name is taken: a second job must not scribble into it
+    with pytest.raises(capi.AuditoryError):
+        HostGather(name, 2, 1, 13, timeout=0.2)          # another geometry: the sizes do not match, it never "appears"
+    b = HostGather(name, 2, 1, 12)
+    a.put(torch.arange(12, dtype=torch.float32).view(3, 4), 0)
+    b.put(torch.arange(8, dtype=torch.float32) + 100.0, 0)    # a short slab: the tail of the slot is not touched
+    b.put(torch.full((12,), 7.0), 1)
+    for g in (a, b):
+        v = g.view(0)
+        assert v.shape == (2, 12) and torch.equal(v[0], torch.arange(12.0)) and torch.equal(v[1, :8], torch.arange(8.0) + 100.0)
+        assert torch.equal(v[1, 8:], torch.zeros(4)) and torch.equal(g.view(1)[1], torch.full((12,), 7.0))
+        assert torch.equal(g.view(1)[0], torch.zeros(12))
+    with pytest.raises(capi.AuditoryError):
+        a.put(torch.zeros(13), 0)
+    with pytest.raises(capi.AuditoryError):
+        a.put(torch.zeros(4, dtype=torch.float64), 0)
+    with pytest.raises(capi.AuditoryError):
+        a.put(torch.zeros(4), 2)
+    b.close()
+    assert os.path.exists(a.path)
+    a.close()
+    assert not os.path.exists(os.path.join("/dev/shm", name))

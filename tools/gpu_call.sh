@@ -56,6 +56,7 @@ for step in "$@"; do
                 run wstream 120 /tmp/stream_write ;;
         two_ranks) run two_ranks 500 bash tools/two_ranks_one_gpu.sh "${TAG}_two" ;;
         ranks:*) run ranks${step#ranks:} 500 bash tools/two_ranks_one_gpu.sh "${TAG}_ranks${step#ranks:}" "${step#ranks:}" ;;
+        hostranks:*) run hostranks${step#hostranks:} 500 bash tools/two_ranks_one_gpu.sh "${TAG}_hostranks${step#hostranks:}" "${step#hostranks:}" host ;;
         hostcall) run hostcall 300 python tools/host_call_time.py ;;
         dispatch) (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/dispatch_rate dispatch_rate.hip) &&
                 run dispatch 120 /tmp/dispatch_rate ;;

@@ -8,13 +8,14 @@
 set -u
 TAG=${1:-two}
 N=${2:-2}
+MODE=${3:-direct}     # direct | host
 if [ "$N" -lt 2 ] || [ "$N" -gt 4 ]; then echo "RANKS must be 2..4"; exit 2; fi
 mkdir -p gpurun_out
 PORT=$((20000 + RANDOM % 20000))
 pids=()
 for r in $(seq 0 $((N - 1))); do
     RANK=$r LOCAL_RANK=0 WORLD_SIZE=$N MASTER_ADDR=127.0.0.1 MASTER_PORT=$PORT \
-        timeout -k 10 400 python bench.py --gpus "$N" --dist-backend gloo --gather-mode direct --no-cpu-baseline --no-stream-read \
+        timeout -k 10 400 python bench.py --gpus "$N" --dist-backend gloo --gather-mode "$MODE" --no-cpu-baseline --no-stream-read \
         --steps 20 --warmup 5 --min-seconds 0.05 --cfg3-total 1024 > "gpurun_out/${TAG}_rank$r.log" 2>&1 &
     pids+=($!)
 done
