@@ -344,7 +344,7 @@ func (se *SndEnv) ProcessSegment(segment, add int) {
 	}
 	dev := se.resident()
 	resident := dev != nil
-	if se.Mel.MFCC {
+	if se.Mel.MFCC && se.DFT.CompLogPow { // (the MFCC tail reads LogPowerSegment: include/auditory.hpp takes the same branch)
 		if resident {
 			err = plan.MelSpecMFCCSig(dev, items, se.MelFBankSegment.Values, se.PowerSegment.Values,
 				se.LogPowerSegment.Values, se.MFCCSegment.Values, se.MFCCDeltas.Values, se.MFCCDeltaDeltas.Values, se.Energy.Values)
@@ -360,6 +360,9 @@ func (se *SndEnv) ProcessSegment(segment, add int) {
 		}
 		// Energy[s] = sum over f < SegmentSteps of LogPowerSegment row s (the reference's axis, SURVEY Q8)
 		T := se.Params.SegmentSteps
+		if !se.DFT.CompLogPow {
+			T = 0 // no LogPowerSegment: Energy stays zero
+		}
 		for s := 0; s < T; s++ {
 			e := 0.0
 			for f := 0; f < T; f++ {
