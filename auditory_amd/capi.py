@@ -121,6 +121,8 @@ SYMBOLS = {
     "aud_melspec_batch_host": (C.c_int, [_VP, _VP, C.c_int64, _VP, C.c_int, _VP, _VP, _VP]),
     "aud_host_alloc": (C.c_int, [_VP, C.c_int64, C.POINTER(C.c_void_p)]),
     "aud_host_free": (C.c_int, [_VP, _VP]),
+    "aud_host_register": (C.c_int, [_VP, _VP, C.c_int64]),
+    "aud_host_unregister": (C.c_int, [_VP, _VP]),
     "aud_signal_upload": (C.c_int, [_VP, _VP, C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
     "aud_signal_destroy": (C.c_int, [_VP]),
     "aud_signal_len": (C.c_int64, [_VP]),

@@ -149,7 +149,7 @@ int aud_shutdown(aud_ctx* c) {
         if (c->ws[i]) (void)hipFree(c->ws[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->pin) (void)hipHostFree(c->pin);
-    for (auto& b : c->host_blocks) (void)hipHostFree(b.p);
+    for (auto& b : c->host_blocks) (void)(b.registered ? hipHostUnregister(b.p) : hipHostFree(b.p));
     for (auto& e : c->pin_ev)
         if (e) (void)hipEventDestroy(e);
     if (c->rccl_lib) dlclose(c->rccl_lib);

@@ -102,9 +102,39 @@ int aud_host_alloc(aud_ctx* c, int64_t bytes, void** ptr) {
     HostCallGuard guard(c);
     void* p = nullptr;
     AUD_HIP(c, hipHostMalloc(&p, size_t(bytes), hipHostMallocDefault));
-    c->host_blocks.push_back({static_cast<unsigned char*>(p), size_t(bytes)});
+    c->host_blocks.push_back({static_cast<unsigned char*>(p), size_t(bytes), static_cast<unsigned char*>(p), false});
     *ptr = p;
     return AUD_OK;
+}
+
+int aud_host_register(aud_ctx* c, void* ptr, int64_t bytes) {
+    if (!c || !ptr || bytes <= 0) return AUD_EINVAL;
+    AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);
+    if (find_host_block(c, ptr, 1) || find_host_block(c, static_cast<unsigned char*>(ptr) + bytes - 1, 1))
+        return fail(c, AUD_EINVAL, "aud_host_register: the range overlaps a block the context already holds");
+    AUD_HIP(c, hipHostRegister(ptr, size_t(bytes), hipHostRegisterPortable | hipHostRegisterMapped));
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, ptr, 0) != hipSuccess || !dev) {
+        (void)hipGetLastError();
+        (void)hipHostUnregister(ptr);
+        return fail(c, AUD_EHIP, "aud_host_register: no device address for the range");
+    }
+    c->host_blocks.push_back({static_cast<unsigned char*>(ptr), size_t(bytes), static_cast<unsigned char*>(dev), true});
+    return AUD_OK;
+}
+
+int aud_host_unregister(aud_ctx* c, void* ptr) {
+    if (!c || !ptr) return AUD_EINVAL;
+    (void)hipSetDevice(c->device);
+    HostCallGuard guard(c);  // (drains the stream: no kernel still writes the range)
+    for (size_t i = 0; i < c->host_blocks.size(); ++i)
+        if (c->host_blocks[i].p == ptr && c->host_blocks[i].registered) {
+            c->host_blocks.erase(c->host_blocks.begin() + long(i));
+            (void)hipHostUnregister(ptr);
+            return AUD_OK;
+        }
+    return fail(c, AUD_EINVAL, "aud_host_unregister: not a range of aud_host_register");
 }
 
 int aud_host_free(aud_ctx* c, void* ptr) {
@@ -112,7 +142,7 @@ int aud_host_free(aud_ctx* c, void* ptr) {
     (void)hipSetDevice(c->device);
     HostCallGuard guard(c);  // (drains the stream: no kernel still writes the block)
     for (size_t i = 0; i < c->host_blocks.size(); ++i)
-        if (c->host_blocks[i].p == ptr) {
+        if (c->host_blocks[i].p == ptr && !c->host_blocks[i].registered) {
             c->host_blocks.erase(c->host_blocks.begin() + long(i));
             (void)hipHostFree(ptr);
             return AUD_OK;

@@ -30,10 +30,14 @@ struct aud_ctx {
     void* pin = nullptr;
     size_t pin_cap = 0;
     hipEvent_t pin_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    // aud_host_alloc: pinned, device-visible host memory handed to the caller for result tensors (under host_mutex)
+    // aud_host_alloc / aud_host_register: pinned, device-visible host memory the caller keeps result tensors in (under
+    // host_mutex).  `dev` is the address the device uses for `p` (the same for aud_host_alloc memory; what
+    // hipHostGetDevicePointer says for a registered range, e.g. a shared mapping several processes write their shards into)
     struct HostBlock {
         unsigned char* p;
         size_t bytes;
+        unsigned char* dev;
+        bool registered;
     };
     std::vector<HostBlock> host_blocks;
     // RCCL (loaded lazily)
@@ -259,13 +263,14 @@ inline int fetch_widened(aud_ctx* c, const float* d_src, const WidenPart* parts,
     return AUD_OK;
 }
 
-// true if [p, p + bytes) lies inside one aud_host_alloc block of the context (the caller holds host_mutex)
-inline bool in_host_block(const aud_ctx* c, const void* p, size_t bytes) {
+// the aud_host_alloc / aud_host_register block of the context that holds [p, p + bytes), or null (the caller holds host_mutex)
+inline const aud_ctx::HostBlock* find_host_block(const aud_ctx* c, const void* p, size_t bytes) {
     const unsigned char* q = static_cast<const unsigned char*>(p);
     for (const auto& b : c->host_blocks)
-        if (q >= b.p && q + bytes <= b.p + b.bytes) return true;
-    return false;
+        if (q >= b.p && q + bytes <= b.p + b.bytes) return &b;
+    return nullptr;
 }
+inline bool in_host_block(const aud_ctx* c, const void* p, size_t bytes) { return find_host_block(c, p, bytes) != nullptr; }
 // every requested (non-null, non-empty) part lies in aud_host_alloc memory
 inline bool all_parts_pinned(const aud_ctx* c, const WidenPart* parts, int n_parts) {
     bool any = false;
@@ -280,7 +285,12 @@ inline bool all_parts_pinned(const aud_ctx* c, const WidenPart* parts, int n_par
 inline int store_widened(aud_ctx* c, const float* d_src, const WidenPart* parts, int n_parts) {
     size_t lo = 0;
     for (int i = 0; i < n_parts; ++i) {
-        if (parts[i].dst && parts[i].n) AUD_HIP(c, aud::launch_widen_to_host(d_src + lo, parts[i].dst, parts[i].n, c->stream));
+        if (parts[i].dst && parts[i].n) {
+            const aud_ctx::HostBlock* b = find_host_block(c, parts[i].dst, parts[i].n * sizeof(double));
+            if (!b) return fail(c, AUD_EINVAL, "store_widened: a tensor left its pinned block");
+            double* dst = reinterpret_cast<double*>(b->dev + (reinterpret_cast<unsigned char*>(parts[i].dst) - b->p));
+            AUD_HIP(c, aud::launch_widen_to_host(d_src + lo, dst, parts[i].n, c->stream));
+        }
         lo += parts[i].n;
     }
     AUD_HIP(c, hipStreamSynchronize(c->stream));

@@ -48,6 +48,16 @@ class Context:
         if p is not None:
             self.check(self.lib.aud_host_free(self.handle, C.c_void_p(p)))
 
+    def register_host(self, arr):
+        """pin a numpy array the CALLER owns -- typically a mapping several processes share (np.memmap over /dev/shm) -- and
+        make it device-visible (aud_host_register): result tensors that are views of it, given through `out=`, are written by
+        the device like pinned_empty() ones.  One process per GPU, each passing its shard's slice of ONE [B, ...] float64
+        tensor: the batch's features end in one host tensor without a collective.  unregister_host(arr) before unmapping."""
+        self.check(self.lib.aud_host_register(self.handle, C.c_void_p(arr.__array_interface__["data"][0]), int(arr.nbytes)))
+
+    def unregister_host(self, arr):
+        self.check(self.lib.aud_host_unregister(self.handle, C.c_void_p(arr.__array_interface__["data"][0])))
+
     def close(self):
         if self.handle:
             self.lib.aud_shutdown(self.handle)

@@ -569,6 +569,24 @@ func (c *Ctx) HostFree(s []float64) {
 	}
 }
 
+// HostRegister pins memory the caller owns -- a mapping several processes share (syscall.Mmap over /dev/shm), say -- and
+// makes it device-visible: result tensors whose Values are sub-slices of it are written by the device like HostFloat64 ones.
+// One process per GPU, each passing its shard's slice of ONE [B, nf, T] tensor: the batch's features end in one host
+// tensor with no collective.  HostUnregister before unmapping.
+func (c *Ctx) HostRegister(b []float64) error {
+	if len(b) == 0 {
+		return errors.New("auditory_hip: HostRegister: empty slice")
+	}
+	return status(c, C.aud_host_register(c.h, unsafe.Pointer(&b[0]), C.int64_t(8*len(b))))
+}
+
+func (c *Ctx) HostUnregister(b []float64) error {
+	if len(b) == 0 {
+		return nil
+	}
+	return status(c, C.aud_host_unregister(c.h, unsafe.Pointer(&b[0])))
+}
+
 // UploadSignal copies SndEnv.Signal.Values to the device once.
 func (c *Ctx) UploadSignal(sig []float64) (*Signal, error) {
 	s := &Signal{ctx: c}

@@ -320,6 +320,14 @@ int aud_melspec_batch_host(aud_plan* plan, const double* sig, int64_t sig_total,
  * is left. */
 int aud_host_alloc(aud_ctx* ctx, int64_t bytes, void** ptr);
 int aud_host_free(aud_ctx* ctx, void* ptr);
+/* The same for memory the CALLER owns: aud_host_register pins [ptr, ptr + bytes) and makes it device-visible; result tensors
+ * inside it are then written by the device like those of aud_host_alloc.  Meant for a mapping that SEVERAL processes share
+ * (POSIX shared memory): one process per GPU, each registering the mapping and passing its shard's slice of one
+ * [B, ...] float64 tensor as the output of its _host / _sig calls -- the features of the whole batch end in one host tensor
+ * with no collective and no copy on the host (the host mode of the reference's multi-GPU use: sound/sndenv.go has no
+ * counterpart).  aud_host_unregister before unmapping; aud_shutdown unregisters what is left. */
+int aud_host_register(aud_ctx* ctx, void* ptr, int64_t bytes);
+int aud_host_unregister(aud_ctx* ctx, void* ptr);
 typedef struct aud_signal aud_signal;
 int aud_signal_upload(aud_ctx* ctx, const void* samples, int sample_dtype, int64_t n_samples, aud_signal** out);
 int aud_signal_destroy(aud_signal* sig);

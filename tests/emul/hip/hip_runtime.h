@@ -151,6 +151,13 @@ inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }  // (the emulato
 enum { hipHostMallocDefault = 0 };
 inline hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
 inline hipError_t hipHostFree(void* p) { return hipFree(p); }
+enum { hipHostRegisterPortable = 1, hipHostRegisterMapped = 2 };
+inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
+inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
+inline hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) {
+    *dev = host;
+    return hipSuccess;
+}
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 // the direct all-gather's arrival flags (capi_comm.hip): fine-grained memory is ordinary memory here, system-scope atomics are
 // the compiler's, and the bounded poll's sleep is nothing

@@ -534,6 +534,36 @@ def case_resident_signal(orc, cdt):
             plan.ctx.pinned_free(a)
         with pytest.raises(capi.AuditoryError):
             plan.ctx.check(plan.lib.aud_host_free(plan.ctx.handle, 12345))
+        # the same for memory the CALLER owns (aud_host_register): a shared mapping that two "ranks" write their shards of ONE
+        # [n, nf, T] tensor into (here one process; what several processes share is the file) -- SURVEY 8e's host mode for the
+        # host-facing entry points: the batch's features in one host tensor, no collective, no host copy
+        import os
+        import tempfile
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+        fd, path = tempfile.mkstemp(prefix="auditory_hip_reg_", dir=shm)
+        os.close(fd)
+        try:
+            whole = np.memmap(path, dtype=np.float64, mode="w+", shape=(n_it, oc.nf, oc.T))
+            whole[...] = 7.0
+            plan.ctx.register_host(whole)
+            with pytest.raises(capi.AuditoryError):
+                plan.ctx.register_host(whole[1:])               # overlaps a range the context holds
+            half = n_it // 2
+            for lo, hi in ((0, half), (half, n_it)):            # each "rank": its items, its slice of the one tensor
+                got_r = plan.melspec_sig(s64, items[lo:hi], out=(whole[lo:hi], None, None))
+                assert got_r[0].__array_interface__["data"][0] == whole[lo:hi].__array_interface__["data"][0]
+            assert np.array_equal(np.asarray(whole), want[0], equal_nan=True)
+            with pytest.raises(capi.AuditoryError):
+                plan.ctx.check(plan.lib.aud_host_free(plan.ctx.handle, whole.__array_interface__["data"][0]))   # not an alloc block
+            plan.ctx.unregister_host(whole)
+            with pytest.raises(capi.AuditoryError):
+                plan.ctx.unregister_host(whole)
+            whole[...] = 7.0                                     # unregistered again: the staging route, the same values
+            got_u = plan.melspec_sig(s64, items, out=(whole, None, None))
+            assert np.array_equal(np.asarray(got_u[0]), want[0], equal_nan=True)
+            del whole, got_r, got_u
+        finally:
+            os.unlink(path)
         bad = items.copy()
         bad["sig_len"][0] = 2 * L + 1
         with pytest.raises(capi.AuditoryError):
