@@ -7,6 +7,8 @@ DESIGN.md 6 and BASELINE.md quote; never bench.py's `value`):
   sig_i16   the same on int16 PCM uploaded once (8.5 MB, normalised on the device)
   *_reuse   ... into a caller-owned result tensor that is reused (no fresh pages per call)
   *_pinned  ... into a result tensor from aud_host_alloc: the device widens and writes it (no staging copy, no CPU pass)
+  *_shared  ... into a mapping of POSIX shared memory registered with aud_host_register (what several processes, one per GPU,
+            would write their shards of one host tensor into): the device writes it like the pinned one
   upload_*  the one-time uploads themselves"""
 import os
 import sys
@@ -47,13 +49,24 @@ res["sig_i16"] = timed(lambda: plan.melspec_sig(s16, items))
 pin_mel = plan.ctx.pinned_empty((n, 40, 104))
 res["sig_f64_pinned"] = timed(lambda: plan.melspec_sig(s64, items, out=(pin_mel, None, None)))
 res["sig_i16_pinned"] = timed(lambda: plan.melspec_sig(s16, items, out=(pin_mel, None, None)))
+import tempfile  # noqa: E402
+fd, shm_path = tempfile.mkstemp(prefix="auditory_hip_time_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+os.close(fd)
+shared = np.memmap(shm_path, dtype=np.float64, mode="w+", shape=(n, 40, 104))
+shared[...] = 0.0
+plan.ctx.register_host(shared)
+res["sig_f64_shared"] = timed(lambda: plan.melspec_sig(s64, items, out=(shared, None, None)))
 keep = np.zeros((n, 40, 104))
 res["sig_f64_reuse"] = timed(lambda: plan.melspec_sig(s64, items, out=(keep, None, None)))
 a, b = plan.melspec_host(flat, items)[0], plan.melspec_sig(s64, items)[0]
 assert np.array_equal(a, b)
 print("256 utterances of 1 s, float64 plan (w20x10), float64 mel %.1f MB out" % (n * 40 * 104 * 8 / 1e6))
 assert np.array_equal(plan.melspec_sig(s64, items, out=(pin_mel, None, None))[0], b)
-for k in ("host", "sig_f64", "sig_i16", "sig_f64_reuse", "sig_f64_pinned", "sig_i16_pinned"):
+assert np.array_equal(np.asarray(shared), b)
+plan.ctx.unregister_host(shared)
+del shared
+os.unlink(shm_path)
+for k in ("host", "sig_f64", "sig_i16", "sig_f64_reuse", "sig_f64_pinned", "sig_i16_pinned", "sig_f64_shared"):
     print("  %-15s %.3f ms per call = %.0f audio-s/s" % (k, res[k] * 1e3, n / res[k]))
 print("  one-time uploads: float64 signal (%.1f MB) %.2f ms, int16 PCM (%.1f MB) %.2f ms"
       % (flat.nbytes / 1e6, res["upload_f64"] * 1e3, pcm.nbytes / 1e6, res["upload_i16"] * 1e3))
