@@ -148,15 +148,12 @@ __device__ __forceinline__ void w20_tile_front(const MelspecArgs& a, const WaveA
     AUD_STAMP(7);
 }
 
-#ifdef AUD_EXP_W20_WAVES5
-#define AUD_W20_F64_WAVES 5
-#else
-#define AUD_W20_F64_WAVES 4
-#endif
+// The tile kernel's body: the wave's tile from the samples to the stored mel values.  Returns the tile's item, or -1 for a wave
+// without a tile (it has left the workgroup's one barrier behind it and must simply end).
 template <typename TT, int SRC, int NW, int MAXS>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(sizeof(TT) == 8 ? AUD_W20_F64_WAVES : 5, sizeof(TT) == 8 ? AUD_W20_F64_WAVES : 5)))
-void k_melspec_w20(const aud_item* items, unsigned total, unsigned tiles, unsigned tile_mul, int tile_shift, const void* blob_ptr,
-                   int blob_bytes, unsigned n_wgs, int xcd_remap, const MelspecArgs a, const WaveArgs e) {
+__device__ __forceinline__ int w20_wave_tile(const aud_item* items, unsigned total, unsigned tiles, unsigned tile_mul, int tile_shift,
+                                             const void* blob_ptr, int blob_bytes, unsigned n_wgs, int xcd_remap, const MelspecArgs& a,
+                                             const WaveArgs& e) {
     using L = w20::Layout<TT>;
     unsigned char* smem = dyn_lds();
     const int tid = int(threadIdx.x);
@@ -191,7 +188,7 @@ void k_melspec_w20(const aud_item* items, unsigned total, unsigned tiles, unsign
 
     blob_store<64 * NW>(e, smem, tid, blob);
     __syncthreads();  // the one barrier: tables visible to the workgroup's waves
-    if (!active) return;
+    if (!active) return -1;
 
     unsigned char* region = smem + e.xch_off + wave * L::kRegion;
     w20_tile_front<TT, SRC>(a, e, smem, region, it, t0, f, j, pos0, raw AUD_STAMP_ARG);
@@ -203,6 +200,63 @@ void k_melspec_w20(const aud_item* items, unsigned total, unsigned tiles, unsign
     AUD_STAMP(8);
     AUD_STAMP_REAL(10);
     AUD_STAMP_FLUSH(a, wt, lane);
+    return item;
+}
+
+#ifdef AUD_EXP_W20_WAVES5
+#define AUD_W20_F64_WAVES 5
+#else
+#define AUD_W20_F64_WAVES 4
+#endif
+template <typename TT, int SRC, int NW, int MAXS>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(sizeof(TT) == 8 ? AUD_W20_F64_WAVES : 5, sizeof(TT) == 8 ? AUD_W20_F64_WAVES : 5)))
+void k_melspec_w20(const aud_item* items, unsigned total, unsigned tiles, unsigned tile_mul, int tile_shift, const void* blob_ptr,
+                   int blob_bytes, unsigned n_wgs, int xcd_remap, const MelspecArgs a, const WaveArgs e) {
+    (void)w20_wave_tile<TT, SRC, NW, MAXS>(items, total, tiles, tile_mul, tile_shift, blob_ptr, blob_bytes, n_wgs, xcd_remap, a, e);
+}
+
+// ================================================================================================
+// The tile kernel with agabor.Convolve behind a TICKET (sound/sndenv.go:342-359 + :481-497 as ONE launch at tile grain).
+// Every wave, its tile's mel values stored, releases them at device scope and takes a ticket of its item; the wave that draws
+// the item's LAST ticket finds the item's whole [nf][T] mel matrix in memory (the other tiles' stores happened before their
+// tickets), acquires, and runs Convolve on it: 64 lanes over the item's output positions, every position in the plan's compute
+// type throughout (gabor_position, gabor_tile.h: the same code, the same bits as k_gabor).  Against two launches: the
+// convolution's waves do not have to find room beside a kernel that holds 488 of a SIMD's 512 registers -- they ARE that
+// kernel's waves, one in `tiles` of them living ~ 4 500 vector instructions longer, spread over the whole launch (an item's
+// last tile, not the launch's last waves).  The finishing wave puts the ticket back to 0: the array is clean for the next
+// launch on the same stream (the host keeps one array per stream; launches on one stream are ordered).
+// ================================================================================================
+template <typename TT, int SRC, int NW, int MAXS>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(sizeof(TT) == 8 ? 4 : 5, sizeof(TT) == 8 ? 4 : 5)))
+void k_melspec_w20_gabor(const aud_item* items, unsigned total, unsigned tiles, unsigned tile_mul, int tile_shift, const void* blob_ptr,
+                         int blob_bytes, unsigned n_wgs, int xcd_remap, const TT* __restrict__ taps, int* tickets,
+                         const MelspecArgs a, const WaveArgs e, const GaborArgs g) {
+    const int item = w20_wave_tile<TT, SRC, NW, MAXS>(items, total, tiles, tile_mul, tile_shift, blob_ptr, blob_bytes, n_wgs, xcd_remap, a, e);
+    if (item < 0) return;  // wave-uniform
+    const int lane = int(threadIdx.x) & 63;
+    // release: this wave's mel stores (all lanes': the fence is the wave's) before its ticket
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // (the fences around it order the device's memory; the CPU thread emulator's race detector does not model fences, so that
+    //  build orders through the operation itself)
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int kTicketOrder = __ATOMIC_RELAXED;
+#else
+    constexpr int kTicketOrder = __ATOMIC_ACQ_REL;
+#endif
+    int drawn = 0;
+    if (lane == 0) drawn = __hip_atomic_fetch_add(tickets + item, 1, kTicketOrder, __HIP_MEMORY_SCOPE_AGENT);
+    drawn = __builtin_amdgcn_readfirstlane(drawn);
+    if (drawn != int(tiles) - 1) return;  // wave-uniform: not the item's last tile
+    if (lane == 0) __hip_atomic_store(tickets + item, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int per_item = g.nF * g.nT;
+    const float* __restrict__ mel = a.mel + size_t(item) * a.nf * a.T;
+    float* out = g.out + size_t(item) * gabor_out_item_elems(g);
+    for (int r = lane; r < per_item; r += 64) {
+        if (g.SX == 9 && g.SY == 9 && g.nG == 8) gabor_position<TT, 9, 9, 8>(g, taps, mel, out, r);  // processspeech.go:226-253
+        else gabor_position<TT, 0, 0, 0>(g, taps, mel, out, r);
+    }
 }
 
 // ================================================================================================
@@ -299,6 +353,7 @@ size_t w20_region_bytes(bool f64) { return f64 ? size_t(w20::Layout<double>::kRe
 #ifdef AUD_W20_QUICK  // resource experiments: one instantiation of each kernel (tools, never the product build)
 wave_kernel_t w20_kernel(bool, int, int) { return k_melspec_w20<double, AUD_F32, 4, 4>; }
 item_kernel_t w20_item_kernel(bool, int, int, int) { return k_melspec_w20_item<double, AUD_F32, 5, 4>; }
+wave_gabor_kernel_t w20_gabor_kernel(bool, int, int) { return k_melspec_w20_gabor<double, AUD_F32, 4, 4>; }
 #else
 #ifdef AUD_EXP_W20_NW  // (experiment: waves per workgroup of the tile kernel; melspec_wave.hip wave_kernel_waves follows)
 #define AUD_W20_NW AUD_EXP_W20_NW
@@ -314,6 +369,18 @@ wave_kernel_t w20_kernel(bool f64, int sig_dtype, int n_slots) {
     return f64 ? AUD_W20_PICK(double) : AUD_W20_PICK(float);
 }
 #undef AUD_W20_PICK
+
+// the ticket variant: float64 plans (the conforming default; float32 plans keep the two launches)
+#define AUD_W20_GABOR_PICK()                                                                                                   \
+    (sig_dtype == AUD_F64   ? (s8 ? k_melspec_w20_gabor<double, AUD_F64, 4, 8> : k_melspec_w20_gabor<double, AUD_F64, 4, 4>)   \
+     : sig_dtype == AUD_I16 ? (s8 ? k_melspec_w20_gabor<double, AUD_I16, 4, 8> : k_melspec_w20_gabor<double, AUD_I16, 4, 4>)   \
+                            : (s8 ? k_melspec_w20_gabor<double, AUD_F32, 4, 8> : k_melspec_w20_gabor<double, AUD_F32, 4, 4>))
+wave_gabor_kernel_t w20_gabor_kernel(bool f64, int sig_dtype, int n_slots) {
+    const bool s8 = n_slots > 4;
+    if (!f64) return nullptr;
+    return AUD_W20_GABOR_PICK();
+}
+#undef AUD_W20_GABOR_PICK
 
 #define AUD_W20_ITEM_PICK(TT, NW)                                                                                    \
     (sig_dtype == AUD_F64   ? (s8 ? k_melspec_w20_item<TT, AUD_F64, NW, 8> : k_melspec_w20_item<TT, AUD_F64, NW, 4>)   \

@@ -166,6 +166,8 @@ inline hipError_t hipExtMallocWithFlags(void** p, size_t bytes, unsigned) { retu
 inline hipError_t hipMemset(void* dst, int value, size_t bytes) { std::memset(dst, value, bytes); return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
 inline void __builtin_amdgcn_s_sleep(int) {}
