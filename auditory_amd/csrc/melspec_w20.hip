@@ -150,7 +150,7 @@ __device__ __forceinline__ void w20_tile_front(const MelspecArgs& a, const WaveA
 
 // The tile kernel's body: the wave's tile from the samples to the stored mel values.  Returns the tile's item, or -1 for a wave
 // without a tile (it has left the workgroup's one barrier behind it and must simply end).
-template <typename TT, int SRC, int NW, int MAXS>
+template <typename TT, int SRC, int NW, int MAXS, bool SC1 = false>
 __device__ __forceinline__ int w20_wave_tile(const aud_item* items, unsigned total, unsigned tiles, unsigned tile_mul, int tile_shift,
                                              const void* blob_ptr, int blob_bytes, unsigned n_wgs, int xcd_remap, const MelspecArgs& a,
                                              const WaveArgs& e) {
@@ -195,8 +195,8 @@ __device__ __forceinline__ int w20_wave_tile(const aud_item* items, unsigned tot
 
     // ---- optional spectrum outputs and the mel reduction: 6 frames x 10 filter groups on this wave ---------------
     const int* exps = reinterpret_cast<const int*>(region + L::kExpOff);
-    wave_mel_epilogue_pick<TT, w20::kFW, MAXS>(a, e, reinterpret_cast<const float*>(region), w20::kHp, smem,
-                                          sizeof(TT) == 8 ? frame_scale_of(exps + lane % w20::kFW) : 0, it, item, t0, lane, exps);
+    wave_mel_epilogue_pick<TT, w20::kFW, MAXS, false, SC1>(a, e, reinterpret_cast<const float*>(region), w20::kHp, smem,
+                                                      sizeof(TT) == 8 ? frame_scale_of(exps + lane % w20::kFW) : 0, it, item, t0, lane, exps);
     AUD_STAMP(8);
     AUD_STAMP_REAL(10);
     AUD_STAMP_FLUSH(a, wt, lane);
@@ -217,29 +217,32 @@ void k_melspec_w20(const aud_item* items, unsigned total, unsigned tiles, unsign
 
 // ================================================================================================
 // The tile kernel with agabor.Convolve behind a TICKET (sound/sndenv.go:342-359 + :481-497 as ONE launch at tile grain).
-// Every wave, its tile's mel values stored, releases them at device scope and takes a ticket of its item; the wave that draws
-// the item's LAST ticket finds the item's whole [nf][T] mel matrix in memory (the other tiles' stores happened before their
-// tickets), acquires, and runs Convolve on it: 64 lanes over the item's output positions, every position in the plan's compute
-// type throughout (gabor_position, gabor_tile.h: the same code, the same bits as k_gabor).  Against two launches: the
-// convolution's waves do not have to find room beside a kernel that holds 488 of a SIMD's 512 registers -- they ARE that
-// kernel's waves, one in `tiles` of them living ~ 4 500 vector instructions longer, spread over the whole launch (an item's
-// last tile, not the launch's last waves).  The finishing wave puts the ticket back to 0: the array is clean for the next
-// launch on the same stream (the host keeps one array per stream; launches on one stream are ordered).
+// Every wave stores its tile's mel values WRITE-THROUGH (device scope: the XCDs' L2s are not coherent with each other, and a
+// device-scope release fence -- an L2 write-back -- per wave costs microseconds each: measured 304 us per step against 15),
+// waits for its stores, and takes a ticket of its item (device-scope add).  The wave that draws the item's LAST ticket finds the
+// item's whole [nf][T] mel matrix in memory -- every other tile's stores were acknowledged before its ticket --, invalidates its
+// CU's vector cache (device-scope acquire), and runs Convolve on the matrix: 64 lanes over the item's output positions, every
+// position in the plan's compute type throughout (gabor_position, gabor_tile.h: the same code, the same bits as k_gabor).
+// Against two launches: the convolution's waves do not have to find room beside a kernel that holds 488 of a SIMD's 512
+// registers -- they ARE that kernel's waves, one in `tiles` of them living ~ 4 500 vector instructions longer, spread over the
+// whole launch (an item's last tile, not the launch's last waves).  The finishing wave puts the ticket back to 0: the array is
+// clean for the next launch on the same stream (the host keeps one array per stream; launches on one stream are ordered).
 // ================================================================================================
 template <typename TT, int SRC, int NW, int MAXS>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(sizeof(TT) == 8 ? 4 : 5, sizeof(TT) == 8 ? 4 : 5)))
 void k_melspec_w20_gabor(const aud_item* items, unsigned total, unsigned tiles, unsigned tile_mul, int tile_shift, const void* blob_ptr,
                          int blob_bytes, unsigned n_wgs, int xcd_remap, const TT* __restrict__ taps, int* tickets,
                          const MelspecArgs a, const WaveArgs e, const GaborArgs g) {
-    const int item = w20_wave_tile<TT, SRC, NW, MAXS>(items, total, tiles, tile_mul, tile_shift, blob_ptr, blob_bytes, n_wgs, xcd_remap, a, e);
+    const int item = w20_wave_tile<TT, SRC, NW, MAXS, true>(items, total, tiles, tile_mul, tile_shift, blob_ptr, blob_bytes, n_wgs,
+                                                            xcd_remap, a, e);
     if (item < 0) return;  // wave-uniform
     const int lane = int(threadIdx.x) & 63;
-    // release: this wave's mel stores (all lanes': the fence is the wave's) before its ticket
+    // this wave's mel stores (write-through, all lanes') are acknowledged before its ticket.  (The CPU thread emulator's lanes
+    // are threads: they meet at the wave barrier, and the add itself orders the memory there -- its race detector does not
+    // model fences)
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    // (the fences around it order the device's memory; the CPU thread emulator's race detector does not model fences, so that
-    //  build orders through the operation itself)
 #if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     constexpr int kTicketOrder = __ATOMIC_RELAXED;
 #else
     constexpr int kTicketOrder = __ATOMIC_ACQ_REL;
@@ -249,7 +252,10 @@ void k_melspec_w20_gabor(const aud_item* items, unsigned total, unsigned tiles, 
     drawn = __builtin_amdgcn_readfirstlane(drawn);
     if (drawn != int(tiles) - 1) return;  // wave-uniform: not the item's last tile
     if (lane == 0) __hip_atomic_store(tickets + item, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's vector cache may hold lines of the matrix from an earlier launch
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the invalidate completes asynchronously: wait for it)
+#endif
     const int per_item = g.nF * g.nT;
     const float* __restrict__ mel = a.mel + size_t(item) * a.nf * a.T;
     float* out = g.out + size_t(item) * gabor_out_item_elems(g);
