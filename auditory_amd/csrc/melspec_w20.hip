@@ -256,6 +256,9 @@ void k_melspec_w20_gabor(const aud_item* items, unsigned total, unsigned tiles, 
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the invalidate completes asynchronously: wait for it)
 #endif
+#ifdef AUD_EXP_TICKET_NOTAIL
+    return;
+#endif
     const int per_item = g.nF * g.nT;
     const float* __restrict__ mel = a.mel + size_t(item) * a.nf * a.T;
     float* out = g.out + size_t(item) * gabor_out_item_elems(g);
