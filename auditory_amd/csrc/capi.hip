@@ -725,7 +725,8 @@ int aud_process_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
         // ONE launch at tile grain: the item's last tile runs Convolve behind a ticket (melspec_w20.hip k_melspec_w20_gabor)
         if (p->ticket_opt == 1 && p->has_ticket && p->use_wave && p->item_opt != 1 && p->d.dft.prev_smooth == 0.0 && n_items > 0 &&
             n_items <= aud_plan::kTicketItems && int64_t(n_items) * int64_t(p->d.segment_steps) <= (int64_t(1) << 30) &&
-            ga.nT > 0 && ga.nF > 0 && sig && items && mel &&
+            ga.nT > 0 && ga.nF > 0 && sig && items && mel && (reinterpret_cast<uintptr_t>(mel) & 15) == 0 &&
+            aud::melspec_w20_gabor_fits(ga, p->d.compute_dtype) &&
             (sig_dtype == AUD_F32 || sig_dtype == AUD_F64 || sig_dtype == AUD_I16)) {
             int slot = -1;
             {

@@ -222,7 +222,9 @@ void k_melspec_w20(const aud_item* items, unsigned total, unsigned tiles, unsign
 // waits for its stores, and takes a ticket of its item (device-scope add).  The wave that draws the item's LAST ticket finds the
 // item's whole [nf][T] mel matrix in memory -- every other tile's stores were acknowledged before its ticket --, invalidates its
 // CU's vector cache (device-scope acquire), and runs Convolve on the matrix: 64 lanes over the item's output positions, every
-// position in the plan's compute type throughout (gabor_position, gabor_tile.h: the same code, the same bits as k_gabor).
+// position in the plan's compute type throughout (gabor_item_wave, gabor_tile.h: gabor_position's multiply-adds in the same order,
+// the same bits as k_gabor -- but fed from bands of the matrix staged in the wave's LDS region with all of a band's loads in flight
+// at once: read position by position from memory the lone wave waited for every row of taps, 57 us per step against 15).
 // Against two launches: the convolution's waves do not have to find room beside a kernel that holds 488 of a SIMD's 512
 // registers -- they ARE that kernel's waves, one in `tiles` of them living ~ 4 500 vector instructions longer, spread over the
 // whole launch (an item's last tile, not the launch's last waves).  The finishing wave puts the ticket back to 0: the array is
@@ -259,13 +261,10 @@ void k_melspec_w20_gabor(const aud_item* items, unsigned total, unsigned tiles, 
 #ifdef AUD_EXP_TICKET_NOTAIL
     return;
 #endif
-    const int per_item = g.nF * g.nT;
-    const float* __restrict__ mel = a.mel + size_t(item) * a.nf * a.T;
-    float* out = g.out + size_t(item) * gabor_out_item_elems(g);
-    for (int r = lane; r < per_item; r += 64) {
-        if (g.SX == 9 && g.SY == 9 && g.nG == 8) gabor_position<TT, 9, 9, 8>(g, taps, mel, out, r);  // processspeech.go:226-253
-        else gabor_position<TT, 0, 0, 0>(g, taps, mel, out, r);
-    }
+    // the wave's own exchange region is free (its tile is done): the bands of the item's matrix go through it
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
+    float* band = reinterpret_cast<float*>(dyn_lds() + e.xch_off + wave * w20::Layout<TT>::kRegion);
+    gabor_item_wave<TT>(g, taps, a.mel + size_t(item) * a.nf * a.T, g.out + size_t(item) * gabor_out_item_elems(g), band, lane);
 }
 
 // ================================================================================================

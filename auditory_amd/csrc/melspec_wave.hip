@@ -29,6 +29,7 @@
 #include <algorithm>
 
 #include "wave_common.h"
+#include "gabor_tile.h"
 
 namespace aud {
 
@@ -187,6 +188,11 @@ bool melspec_w20_gabor_available(int kind, int compute_dtype, int n_slots) {
     return kind == 3 && w20_gabor_kernel(compute_dtype == AUD_F64, AUD_F32, n_slots) != nullptr;
 }
 
+// the geometry the ticket tail serves (gabor_tile.h gabor_tail_fits: the 9 x 9 x 8 set, bands that fit the wave's exchange region)
+bool melspec_w20_gabor_fits(const GaborArgs& g, int compute_dtype) {
+    return gabor_tail_fits(g, w20_region_bytes(compute_dtype == AUD_F64) - 32) && g.rows * g.cols > 0;
+}
+
 hipError_t launch_melspec_w20_gabor(const MelspecArgs& a, const WaveArgs& e, const GaborArgs& g, const void* taps, int* tickets,
                                     int compute_dtype, hipStream_t st) {
     if (a.n_items <= 0) return hipSuccess;
@@ -195,7 +201,7 @@ hipError_t launch_melspec_w20_gabor(const MelspecArgs& a, const WaveArgs& e, con
     const int64_t wgs64 = (int64_t(a.n_items) * tiles + per_wg - 1) / per_wg;
     if (wgs64 > 0x7FFFFFFF || int64_t(a.n_items) * tiles >= (int64_t(1) << 31) - 64 * per_wg) return hipErrorInvalidValue;
     wave_gabor_kernel_t fn = w20_gabor_kernel(compute_dtype == AUD_F64, a.sig_dtype, e.n_slots);
-    if (!fn || e.waves != 4) return hipErrorInvalidValue;
+    if (!fn || e.waves != 4 || !melspec_w20_gabor_fits(g, compute_dtype)) return hipErrorInvalidValue;
     MelspecArgs b = a;
     b.tiles = int(tiles);
     int l = 0;
