@@ -290,7 +290,11 @@ __device__ __forceinline__ void gabor_item_wave(const GaborArgs& a, const TT* __
         for (int k = 0; k < kGaborBandPieces; ++k) {
             const int o = 4 * (lane + 64 * k);                // float offset inside the band
             float4 v = float4{0.f, 0.f, 0.f, 0.f};
+#if defined(AUD_EXP_TAIL) && AUD_EXP_TAIL == 3
+            if (o < band && start + o < total && a.nT < 0) {
+#else
             if (o < band && start + o < total) {
+#endif
                 const float* src = mel + start + o;
                 if (vec && start + o + 3 < total) v = *reinterpret_cast<const float4*>(src);
                 else {
@@ -319,6 +323,9 @@ __device__ __forceinline__ void gabor_item_wave(const GaborArgs& a, const TT* __
         TT acc[kGaborChunk];
 #pragma unroll
         for (int c = 0; c < kGaborChunk; ++c) acc[c] = TT(0);
+#if defined(AUD_EXP_TAIL) && AUD_EXP_TAIL == 1
+        if (a.nT < 0)
+#endif
 #pragma unroll 1  // (a row at a time: unrolled, the rows' values and the prefetched band want more registers than four waves per SIMD leave)
         for (int ff = 0; ff < 9; ++ff) {
             float mv[9];
@@ -334,7 +341,12 @@ __device__ __forceinline__ void gabor_item_wave(const GaborArgs& a, const TT* __
                 for (int c = 0; c < kGaborChunk; ++c) acc[c] = mad(tap[c * 81], v, acc[c]);
             }
         }
-        if (has) gabor_emit<TT>(a, out, f0 + fi, ti, 0, 8, 8, acc);
+#if defined(AUD_EXP_TAIL) && AUD_EXP_TAIL == 2
+        if (has && a.nT < 0)
+#else
+        if (has)
+#endif
+            gabor_emit<TT>(a, out, f0 + fi, ti, 0, 8, 8, acc);
     }
 }
 
