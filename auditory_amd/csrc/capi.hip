@@ -315,13 +315,6 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
             for (size_t t = 0; t < area; ++t) k32[((size_t(gi) / 4) * area + t) * 4 + size_t(gi) % 4] = float(gabor_filters[size_t(gi) * area + t]);
         rc = upload(c, reinterpret_cast<void**>(&p->d_gabor32), k32.data(), k32.size() * 4);
     }
-    if (rc == AUD_OK && d->n_gabor > 0 && p->wave_kind == 3 &&
-        aud::melspec_w20_gabor_available(p->wave_kind, d->compute_dtype, p->wv.n_slots)) {
-        const size_t bytes = size_t(aud_plan::kTicketStreams) * aud_plan::kTicketItems * sizeof(int);
-        if (hipMalloc(reinterpret_cast<void**>(&p->d_tickets), bytes) == hipSuccess && hipMemset(p->d_tickets, 0, bytes) == hipSuccess)
-            p->has_ticket = true;
-        else (void)hipGetLastError();  // (the two launches serve every call)
-    }
     if (rc != AUD_OK) {
         aud_plan_destroy(p);
         return rc;
@@ -341,7 +334,6 @@ int aud_plan_destroy(aud_plan* p) {
     if (p->d_bin_pts) (void)hipFree(p->d_bin_pts);
     if (p->d_gabor) (void)hipFree(p->d_gabor);
     if (p->d_gabor32) (void)hipFree(p->d_gabor32);
-    if (p->d_tickets) (void)hipFree(p->d_tickets);
     if (p->d_dct) (void)hipFree(p->d_dct);
     if (p->d_blob) (void)hipFree(p->d_blob);
     if (p->d_gtab) (void)hipFree(p->d_gtab);
@@ -362,7 +354,6 @@ int aud_plan_get_info(const aud_plan* p, const char* name, int64_t* value) {
     else if (key == "bluestein_inplace") *value = !wave && p->bl_L && p->bl_inplace ? 1 : 0;
     else if (key == "generic_frames_per_wg") *value = p->F_generic;  // frames a workgroup of the any-N kernel transforms at once
     else if (key == "item_kernel") *value = wave && p->has_item ? 1 : 0;        // the workgroup-per-item variant exists for this plan
-    else if (key == "gabor_ticket") *value = wave && p->has_ticket ? 1 : 0;     // the tile kernel with Convolve behind a ticket exists
     else if (key == "item_waves") *value = wave && p->has_item ? p->itm.waves : 0;
     else if (key == "item_lds_bytes") *value = wave && p->has_item ? int64_t(p->itm.lds_bytes) : 0;
     else if (key == "item_wgs_per_cu") *value = wave && p->has_item ? p->itm.wgs_per_cu : 0;
@@ -396,13 +387,6 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
     if (key == "gabor_kernel") {
         if (value < -1 || value > 1) return fail(c, AUD_EINVAL, "gabor_kernel: -1 (auto), 0 (LDS-staged, float32 taps) or 1 (one thread per position)");
         p->gabor_opt = value;
-        return AUD_OK;
-    }
-    // 1: aud_process_batch_dev runs the N = 400 tile kernel with Convolve behind a per-item ticket (ONE launch at tile grain)
-    // wherever the plan has it (float64 plans, "gabor_ticket" info key); 0: the two launches
-    if (key == "gabor_ticket") {
-        if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "gabor_ticket: 0 or 1");
-        p->ticket_opt = value;
         return AUD_OK;
     }
     if (key == "xcd_remap") {  // 1 (default): every XCD walks a contiguous run of tiles; 0: tiles in workgroup-id order
@@ -722,38 +706,6 @@ int aud_process_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
         const int rc = gabor_geometry(p, n_items, p->d.mel.n_filters, p->d.segment_steps, 4, shape, 0, &ga);
         if (rc != AUD_OK) return rc;
         if (n_items > 0 && ga.nT > 0 && ga.nF > 0 && !gabor) return fail(c, AUD_EINVAL, "null buffer");
-        // ONE launch at tile grain: the item's last tile runs Convolve behind a ticket (melspec_w20.hip k_melspec_w20_gabor)
-        if (p->ticket_opt == 1 && p->has_ticket && p->use_wave && p->item_opt != 1 && p->d.dft.prev_smooth == 0.0 && n_items > 0 &&
-            n_items <= aud_plan::kTicketItems && int64_t(n_items) * int64_t(p->d.segment_steps) <= (int64_t(1) << 30) &&
-            ga.nT > 0 && ga.nF > 0 && sig && items && mel && (reinterpret_cast<uintptr_t>(mel) & 15) == 0 &&
-            aud::melspec_w20_gabor_fits(ga, p->d.compute_dtype) &&
-            (sig_dtype == AUD_F32 || sig_dtype == AUD_F64 || sig_dtype == AUD_I16)) {
-            int slot = -1;
-            {
-                std::lock_guard<std::mutex> lock(p->ticket_mutex);
-                for (size_t i = 0; i < p->ticket_streams.size(); ++i)
-                    if (p->ticket_streams[i] == stream) slot = int(i);
-                if (slot < 0 && int(p->ticket_streams.size()) < aud_plan::kTicketStreams) {
-                    slot = int(p->ticket_streams.size());
-                    p->ticket_streams.push_back(stream);
-                }
-            }
-            if (slot >= 0) {  // (a ninth stream: the two launches)
-                AUD_HIP(c, make_current(c));
-                aud::MelspecArgs a;
-                fill_melspec_args(p, &a);
-                a.sig = sig;
-                a.sig_dtype = sig_dtype;
-                a.items = items;
-                a.n_items = n_items;
-                a.mel = mel;
-                ga.mel = mel;
-                ga.out = gabor;
-                AUD_HIP(c, aud::launch_melspec_w20_gabor(a, p->wv, ga, p->d_gabor, p->d_tickets + size_t(slot) * aud_plan::kTicketItems,
-                                                         p->d.compute_dtype, static_cast<hipStream_t>(stream)));
-                return AUD_OK;
-            }
-        }
     }
     int rc = aud_melspec_batch_dev(p, sig, sig_dtype, items, n_items, mel, nullptr, nullptr, stream);
     if (rc != AUD_OK) return rc;

@@ -114,16 +114,6 @@ struct aud_plan {
     bool has_item = false;
     int item_opt = -1;
     int gabor_opt = -1;  // plan option "gabor_kernel" (kernels.h GaborArgs::mode): -1 = by compute type
-    // Convolve behind a per-item ticket inside the N = 400 tile kernel (melspec_w20.hip k_melspec_w20_gabor; plan option
-    // "gabor_ticket"): the ticket arrays -- all zero between launches -- come from a pool made with the plan, ONE PER STREAM
-    // (launches on one stream are ordered; two streams' launches may overlap and must not share counters).  Handing a stream
-    // its array is host bookkeeping only, so it works while the stream is being captured.
-    static constexpr int kTicketStreams = 8, kTicketItems = 16384;
-    int ticket_opt = 0;
-    bool has_ticket = false;
-    int* d_tickets = nullptr;  // [kTicketStreams][kTicketItems]
-    std::mutex ticket_mutex;
-    std::vector<void*> ticket_streams;  // stream handle of pool entry i
     void* d_dct = nullptr;  // [mfcc_coefs][nf] DCT-I rows
     unsigned long long stamps = 0;  // diagnostic builds (-DAUD_STAMPS): device buffer for the phase stamps
     const char* family = "generic";

@@ -865,10 +865,7 @@ __device__ __forceinline__ void wave_spectrum_outputs(const MelspecArgs& a, cons
 // it once per wave (wave_mel_epilogue_pick), so the plain path pays nothing for it.
 // TOLDS: the workgroup-per-item kernel also keeps every mel value in the item's LDS matrix mel_lds [nf][T] (what the fused
 // agabor.Convolve reads: a NaN value is stored as 0.5 there, gabor.go:278-280; the tensor in memory keeps the NaN).
-// SC1: the mel values leave as WRITE-THROUGH stores (device scope: `global_store_dword ... sc1`), for a kernel in which another
-// workgroup -- possibly on another XCD, whose L2 is not coherent with this one's -- reads them before the launch ends
-// (melspec_w20.hip k_melspec_w20_gabor); the same values.
-template <typename TT, int FPW, int MAXS, bool COMPACT = false, bool FUSE = false, bool TOLDS = false, bool SC1 = false>
+template <typename TT, int FPW, int MAXS, bool COMPACT = false, bool FUSE = false, bool TOLDS = false>
 __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const WaveArgs& e, const float* P, int Hp,
                                                   const unsigned char* smem, int sc, const aud_item& it,
                                                   int item, int t0, int lane, const int* exps = nullptr,
@@ -966,8 +963,6 @@ __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const Wa
 #endif
                 if (stash) stash[(k * 64 + lane) * 4 + stash_i] = live ? res : 0.f;
                 else if (col_on && flt != 0xFFFF) mel_col[size_t(flt) * T] = live ? res : 0.f;
-            } else if constexpr (SC1) {
-                if (col_on && flt != 0xFFFF) __hip_atomic_store(mel_col + size_t(flt) * T, live ? res : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 if (col_on && flt != 0xFFFF) mel_col[size_t(flt) * T] = live ? res : 0.f;  // MelFBankSegment[item][flt][sstep]
             }
@@ -1037,20 +1032,16 @@ __device__ __forceinline__ void wave_mel_flush4(const MelspecArgs& a, const Wave
     }
 }
 
-template <typename TT, int FPW, int MAXS, bool TOLDS = false, bool SC1 = false>
+template <typename TT, int FPW, int MAXS, bool TOLDS = false>
 __device__ __forceinline__ void wave_mel_epilogue_pick(const MelspecArgs& a, const WaveArgs& e, const float* P, int Hp,
                                                        const unsigned char* smem, int sc, const aud_item& it,
                                                        int item, int t0, int lane, const int* exps, float* mel_lds = nullptr) {
     if constexpr (TOLDS) {
         wave_mel_epilogue<TT, FPW, MAXS, false, false, true>(a, e, P, Hp, smem, sc, it, item, t0, lane, exps, mel_lds);
     } else {
-        if constexpr (SC1) {
-            wave_mel_epilogue<TT, FPW, MAXS, false, false, false, true>(a, e, P, Hp, smem, sc, it, item, t0, lane, exps);
-        } else {
-            if (a.mfcc_acc != nullptr && e.dct_off >= 0)  // wave-uniform
-                wave_mel_epilogue<TT, FPW, MAXS, false, true>(a, e, P, Hp, smem, sc, it, item, t0, lane, exps);
-            else wave_mel_epilogue<TT, FPW, MAXS, false, false>(a, e, P, Hp, smem, sc, it, item, t0, lane, exps);
-        }
+        if (a.mfcc_acc != nullptr && e.dct_off >= 0)  // wave-uniform
+            wave_mel_epilogue<TT, FPW, MAXS, false, true>(a, e, P, Hp, smem, sc, it, item, t0, lane, exps);
+        else wave_mel_epilogue<TT, FPW, MAXS, false, false>(a, e, P, Hp, smem, sc, it, item, t0, lane, exps);
     }
 }
 

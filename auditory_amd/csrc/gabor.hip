@@ -10,13 +10,41 @@
 
 #include "gabor_tile.h"
 
-// (gabor_tile.h pulls in device_common.h: `fp contract(off)`, every fused multiply-add spelled out -- gabor_position's too, so
-// that k_gabor and the ticket tail of melspec_w20.hip give the same bits)
+// (gabor_tile.h pulls in device_common.h, whose kernels spell their fused multiply-adds out under `fp contract(off)`;
+// k_gabor below keeps the compiler's contraction -- acc += tap * v is one v_fma, as in the builds before the tile kernel)
+#pragma clang fp contract(fast)
 
 namespace aud {
 namespace {
 
-// One thread owns one output position (item, fIdx, tIdx): gabor_position (gabor_tile.h), taps behind the kernel's argument struct.
+constexpr int kChunk = 8;
+
+// four floats at 4-byte alignment
+struct __attribute__((packed, aligned(4))) F4u {
+    float x, y, z, w;
+};
+
+// rank-4 output [PY, PX, 2, 8] with exactly 2 x 8 units per pool and 8 filters in the chunk: the on / off values of one
+// position are 16 consecutive floats, 64-byte aligned when the tensor is
+template <typename TT>
+__device__ __forceinline__ void store_pair_block(float* cell, const TT (&acc)[8], TT gain) {
+    float on[8], off[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const bool pos = acc[c] >= TT(0);
+        const float act = float(gain * (acc[c] < TT(0) ? -acc[c] : acc[c]));
+        on[c] = pos ? act : 0.f;
+        off[c] = pos ? 0.f : act;
+    }
+    float4* c4 = reinterpret_cast<float4*>(cell);
+    c4[0] = float4{on[0], on[1], on[2], on[3]};
+    c4[1] = float4{on[4], on[5], on[6], on[7]};
+    c4[2] = float4{off[0], off[1], off[2], off[3]};
+    c4[3] = float4{off[4], off[5], off[6], off[7]};
+}
+
+// KSX, KSY, KNG > 0: compile-time filter geometry (the reference's default 9 x 9 x 8 set gets fully
+// unrolled taps and no group loop); 0: taken from the arguments at run time.
 template <typename TT, int KSX, int KSY, int KNG>
 __global__ __launch_bounds__(256) void k_gabor(const GaborArgs a) {
     const int per_item = a.nF * a.nT;
@@ -24,8 +52,77 @@ __global__ __launch_bounds__(256) void k_gabor(const GaborArgs a) {
     if (gid >= int64_t(a.n_items) * per_item) return;
     const int item = int(gid / per_item);
     const int r = int(gid - int64_t(item) * per_item);
-    gabor_position<TT, KSX, KSY, KNG>(a, static_cast<const TT*>(a.k), a.mel + size_t(item) * a.rows * a.cols,
-                                      a.out + size_t(item) * gabor_out_item_elems(a), r);
+    const int f_idx = r / a.nT, t_idx = r - f_idx * a.nT;
+    const int f = f_idx * a.sty, t = t_idx * a.stx;
+    const int SX = KSX > 0 ? KSX : a.SX, SY = KSY > 0 ? KSY : a.SY, NG = KNG > 0 ? KNG : a.nG;
+
+    const float* __restrict__ mel = a.mel + size_t(item) * a.rows * a.cols;
+    const TT* __restrict__ kf = static_cast<const TT*>(a.k);
+    const int area = SX * SY;
+    const TT gain = TT(a.gain);
+
+    size_t out_item;
+    if (a.rank == 2)
+        out_item = size_t(a.d0) * a.d1;
+    else
+        out_item = size_t(a.d0) * a.d1 * a.d2 * a.d3;
+    float* out = a.out + size_t(item) * out_item;
+
+    for (int g0 = 0; g0 < NG; g0 += kChunk) {
+        TT acc[kChunk];
+#pragma unroll
+        for (int c = 0; c < kChunk; ++c) acc[c] = TT(0);
+        const int gc = min(kChunk, NG - g0);
+        auto tap_val = [&](float mv, int ff, int ft) {
+            if (mv != mv) mv = 0.5f;  // math.IsNaN -> .5
+            const TT v = TT(mv);
+            const TT* tap = kf + size_t(g0) * area + ff * SX + ft;
+#pragma unroll
+            for (int c = 0; c < kChunk; ++c)
+                if (c < gc) acc[c] += tap[size_t(c) * area] * v;
+        };
+        auto tap_row = [&](const float* row, int ff, int ft) { tap_val(row[ft], ff, ft); };
+        for (int ff = 0; ff < SY; ++ff) {
+            const float* row = mel + size_t(f + ff) * a.cols + t;
+            if constexpr (KSX == 9) {
+                // nine consecutive floats as two 16-byte loads (4-byte aligned: the hardware takes unaligned vector loads)
+                // and one 4-byte load: a third of the load instructions, the same cache lines
+                const F4u lo4 = *reinterpret_cast<const F4u*>(row), hi4 = *reinterpret_cast<const F4u*>(row + 4);
+                const float mv[9] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w, row[8]};
+#pragma unroll
+                for (int ft = 0; ft < 9; ++ft) tap_val(mv[ft], ff, ft);
+            } else if constexpr (KSX > 0) {
+#pragma unroll
+                for (int ft = 0; ft < KSX; ++ft) tap_row(row, ff, ft);
+            } else {
+                for (int ft = 0; ft < SX; ++ft) tap_row(row, ff, ft);
+            }
+        }
+        if (a.rank == 4 && a.d2 == 2 && a.d3 == 8 && NG == 8 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
+            store_pair_block<TT>(out + (size_t(f_idx) * a.d1 + t_idx) * 16, acc, gain);
+            continue;
+        }
+#pragma unroll
+        for (int c = 0; c < kChunk; ++c) {
+            if (c >= gc) break;
+            const int flt = g0 + c;
+            const bool pos = acc[c] >= TT(0);
+            const float act = float(gain * (acc[c] < TT(0) ? -acc[c] : acc[c]));
+            size_t o_on, o_off;
+            if (a.rank == 2) {
+                const int y = f_idx * 2;
+                const int x = a.by_time ? t_idx + a.t_max_strides * flt : flt + t_idx * NG;
+                o_on = size_t(y) * a.d1 + x;
+                o_off = size_t(y + 1) * a.d1 + x;
+            } else {
+                const size_t cell = (size_t(f_idx) * a.d1 + t_idx) * a.d2;
+                o_on = cell * a.d3 + flt;
+                o_off = (cell + 1) * a.d3 + flt;
+            }
+            out[o_on] = pos ? act : 0.f;
+            out[o_off] = pos ? 0.f : act;
+        }
+    }
 }
 
 // The LDS-staged form (the default wherever an item's mel matrix and the taps fit 64 KB of LDS): one workgroup per item

@@ -148,210 +148,4 @@ __device__ __forceinline__ void gabor_from_lds(const ItemArgs& g, const float* m
     }
 }
 
-// ---- one output position in the plan's compute type throughout (what k_gabor runs per thread, gabor.hip; and what the last
-// tile of an item runs per lane behind its ticket, melspec_w20.hip k_melspec_w20_gabor) --------------------------------------
-// The position keeps up to 8 filter sums in registers, so every mel value it loads feeds 8 multiply-adds.  The taps are
-// indexed only by loop counters, i.e. wave-uniform: `kf` must be a KERNEL PARAMETER (or derived from one by constants) for
-// them to come through the scalar path.  The mel matrix is addressed by the reference's flat offset (f + ff) * cols + (t + ft)
-// (etensor has no per-dimension bounds check), NaN inputs read as 0.5 (gabor.go:278-280), and the result is rectified into
-// the on / off pair with the 2-D / 4-D index maps of :286-309.  Every multiply-add is spelled as a fused one: the same bits
-// under any contraction setting of the including file.
-constexpr int kGaborChunk = 8;
-
-// four floats at 4-byte alignment
-struct __attribute__((packed, aligned(4))) GaborF4u {
-    float x, y, z, w;
-};
-
-// rank-4 output [PY, PX, 2, 8] with exactly 2 x 8 units per pool and 8 filters in the chunk: the on / off values of one
-// position are 16 consecutive floats, 64-byte aligned when the tensor is
-template <typename TT>
-__device__ __forceinline__ void gabor_store_pair_block(float* cell, const TT (&acc)[8], TT gain) {
-    float on[8], off[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const bool pos = acc[c] >= TT(0);
-        const float act = float(gain * (acc[c] < TT(0) ? -acc[c] : acc[c]));
-        on[c] = pos ? act : 0.f;
-        off[c] = pos ? 0.f : act;
-    }
-    float4* c4 = reinterpret_cast<float4*>(cell);
-    c4[0] = float4{on[0], on[1], on[2], on[3]};
-    c4[1] = float4{on[4], on[5], on[6], on[7]};
-    c4[2] = float4{off[0], off[1], off[2], off[3]};
-    c4[3] = float4{off[4], off[5], off[6], off[7]};
-}
-
-// gabor.go:283-309: the sums of filters g0 .. g0 + gc - 1 at position (f_idx, t_idx), rectified into the on / off pair and
-// stored with the 2-D / 4-D index maps
-template <typename TT>
-__device__ __forceinline__ void gabor_emit(const GaborArgs& a, float* out, int f_idx, int t_idx, int g0, int gc, int NG,
-                                           const TT (&acc)[kGaborChunk]) {
-    const TT gain = TT(a.gain);
-    if (a.rank == 4 && a.d2 == 2 && a.d3 == 8 && NG == 8 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
-        gabor_store_pair_block<TT>(out + (size_t(f_idx) * a.d1 + t_idx) * 16, acc, gain);
-        return;
-    }
-#pragma unroll
-    for (int c = 0; c < kGaborChunk; ++c) {
-        if (c >= gc) break;
-        const int flt = g0 + c;
-        const bool pos = acc[c] >= TT(0);
-        const float act = float(gain * (acc[c] < TT(0) ? -acc[c] : acc[c]));
-        size_t o_on, o_off;
-        if (a.rank == 2) {
-            const int y = f_idx * 2;
-            const int x = a.by_time ? t_idx + a.t_max_strides * flt : flt + t_idx * NG;
-            o_on = size_t(y) * a.d1 + x;
-            o_off = size_t(y + 1) * a.d1 + x;
-        } else {
-            const size_t cell = (size_t(f_idx) * a.d1 + t_idx) * a.d2;
-            o_on = cell * a.d3 + flt;
-            o_off = (cell + 1) * a.d3 + flt;
-        }
-        out[o_on] = pos ? act : 0.f;
-        out[o_off] = pos ? 0.f : act;
-    }
-}
-
-// KSX, KSY, KNG > 0: compile-time filter geometry (the reference's default 9 x 9 x 8 set gets fully unrolled taps and no
-// group loop); 0: taken from the arguments at run time.  `mel` / `out`: the ITEM's matrix and output tensor; r: the
-// position's index f_idx * nT + t_idx.
-template <typename TT, int KSX, int KSY, int KNG>
-__device__ __forceinline__ void gabor_position(const GaborArgs& a, const TT* __restrict__ kf, const float* __restrict__ mel,
-                                               float* out, int r) {
-    const int f_idx = r / a.nT, t_idx = r - f_idx * a.nT;
-    const int f = f_idx * a.sty, t = t_idx * a.stx;
-    const int SX = KSX > 0 ? KSX : a.SX, SY = KSY > 0 ? KSY : a.SY, NG = KNG > 0 ? KNG : a.nG;
-    const int area = SX * SY;
-    for (int g0 = 0; g0 < NG; g0 += kGaborChunk) {
-        TT acc[kGaborChunk];
-#pragma unroll
-        for (int c = 0; c < kGaborChunk; ++c) acc[c] = TT(0);
-        const int gc = min(kGaborChunk, NG - g0);
-        auto tap_val = [&](float mv, int ff, int ft) {
-            if (mv != mv) mv = 0.5f;  // math.IsNaN -> .5
-            const TT v = TT(mv);
-            const TT* tap = kf + size_t(g0) * area + ff * SX + ft;
-#pragma unroll
-            for (int c = 0; c < kGaborChunk; ++c)
-                if (c < gc) acc[c] = mad(tap[size_t(c) * area], v, acc[c]);
-        };
-        auto tap_row = [&](const float* row, int ff, int ft) { tap_val(row[ft], ff, ft); };
-        for (int ff = 0; ff < SY; ++ff) {
-            const float* row = mel + size_t(f + ff) * a.cols + t;
-            if constexpr (KSX == 9) {
-                // nine consecutive floats as two 16-byte loads (4-byte aligned: the hardware takes unaligned vector loads)
-                // and one 4-byte load: a third of the load instructions, the same cache lines
-                const GaborF4u lo4 = *reinterpret_cast<const GaborF4u*>(row), hi4 = *reinterpret_cast<const GaborF4u*>(row + 4);
-                const float mv[9] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w, row[8]};
-#pragma unroll
-                for (int ft = 0; ft < 9; ++ft) tap_val(mv[ft], ff, ft);
-            } else if constexpr (KSX > 0) {
-#pragma unroll
-                for (int ft = 0; ft < KSX; ++ft) tap_row(row, ff, ft);
-            } else {
-                for (int ft = 0; ft < SX; ++ft) tap_row(row, ff, ft);
-            }
-        }
-        gabor_emit<TT>(a, out, f_idx, t_idx, g0, gc, NG, acc);
-    }
-}
-
-// ONE WAVE runs Convolve for a whole item (the ticket tail of melspec_w20.hip): 9 x 9 taps, 8 filters, float64 or float32 sums as
-// gabor_position's (the same order of fused multiply-adds: the same bits).  A lone wave cannot hide memory latency behind other
-// waves, so it does not read the matrix position by position: per step it takes the BAND of mel rows that `fpi` = 64 / nT
-// consecutive fIdx need -- (fpi - 1) stY + 9 rows, flat, plus the 9 values a window may wrap into -- with all its
-// loads in flight at once (16-byte pieces, kGaborBandPieces per lane), parks it in `lds` (the wave's own exchange region: its
-// tile is done), and every lane computes one position (fIdx, tIdx) of the band from there while the next band's loads are in
-// flight.  The caller has checked gabor_tail_fits().
-constexpr int kGaborBandPieces = 5;  // 16-byte pieces per lane and band: 5 x 64 x 4 = 1280 floats (the default set: 12 x 104 + 9)
-__host__ __device__ inline int gabor_tail_fpi(const GaborArgs& a) { return a.nT >= 64 ? 1 : 64 / a.nT; }
-__host__ __device__ inline int gabor_tail_band_floats(const GaborArgs& a) {
-    return ((gabor_tail_fpi(a) - 1) * a.sty + a.SY) * a.cols + a.SX;
-}
-__host__ __device__ inline bool gabor_tail_fits(const GaborArgs& a, size_t lds_bytes) {
-    return a.SX == 9 && a.SY == 9 && a.nG == 8 && a.nT >= 1 && a.nT <= 64 && a.nF >= 1 &&
-           gabor_tail_band_floats(a) <= kGaborBandPieces * 64 * 4 && size_t(gabor_tail_band_floats(a) + 4) * 4 <= lds_bytes &&
-           (a.cols & 3) == 0 && ((size_t(a.rows) * a.cols) & 3) == 0;  // (bands and items start on 16-byte pieces when the tensor does)
-}
-
-template <typename TT>
-__device__ __forceinline__ void gabor_item_wave(const GaborArgs& a, const TT* __restrict__ kf, const float* __restrict__ mel,
-                                                float* out, float* lds, int lane) {
-    const int fpi = gabor_tail_fpi(a);
-    const int total = a.rows * a.cols;                       // floats of the item's matrix
-    const int band = gabor_tail_band_floats(a);
-    const bool vec = (reinterpret_cast<uintptr_t>(mel) & 15) == 0;
-    float4 pre[kGaborBandPieces];
-    auto fetch = [&](int f0) {                               // the band of fIdx f0 .. f0 + fpi - 1 into registers
-        const int start = f0 * a.sty * a.cols;
-#pragma unroll
-        for (int k = 0; k < kGaborBandPieces; ++k) {
-            const int o = 4 * (lane + 64 * k);                // float offset inside the band
-            float4 v = float4{0.f, 0.f, 0.f, 0.f};
-#if defined(AUD_EXP_TAIL) && AUD_EXP_TAIL == 3
-            if (o < band && start + o < total && a.nT < 0) {
-#else
-            if (o < band && start + o < total) {
-#endif
-                const float* src = mel + start + o;
-                if (vec && start + o + 3 < total) v = *reinterpret_cast<const float4*>(src);
-                else {
-                    v.x = src[0];
-                    if (start + o + 1 < total) v.y = src[1];
-                    if (start + o + 2 < total) v.z = src[2];
-                    if (start + o + 3 < total) v.w = src[3];
-                }
-            }
-            pre[k] = v;
-        }
-    };
-    fetch(0);
-    for (int f0 = 0; f0 < a.nF; f0 += fpi) {                 // wave-uniform
-        wave_lds_fence();                                     // every lane is done with the previous band
-#pragma unroll
-        for (int k = 0; k < kGaborBandPieces; ++k) {
-            const int o = 4 * (lane + 64 * k);
-            if (o < band) *reinterpret_cast<float4*>(lds + o) = pre[k];  // (the last piece may end up to 3 floats past the band)
-        }
-        wave_lds_fence();
-        if (f0 + fpi < a.nF) fetch(f0 + fpi);                // in flight behind this band's arithmetic
-        const int fi = lane / a.nT, ti = lane - fi * a.nT;
-        const bool has = fi < fpi && f0 + fi < a.nF;
-        const float* win = lds + (has ? (fi * a.sty) * a.cols + ti * a.stx : 0);
-        TT acc[kGaborChunk];
-#pragma unroll
-        for (int c = 0; c < kGaborChunk; ++c) acc[c] = TT(0);
-#if defined(AUD_EXP_TAIL) && AUD_EXP_TAIL == 1
-        if (a.nT < 0)
-#endif
-#pragma unroll 1  // (a row at a time: unrolled, the rows' values and the prefetched band want more registers than four waves per SIMD leave)
-        for (int ff = 0; ff < 9; ++ff) {
-            float mv[9];
-#pragma unroll
-            for (int ft = 0; ft < 9; ++ft) mv[ft] = win[ff * a.cols + ft];
-#pragma unroll
-            for (int ft = 0; ft < 9; ++ft) {
-                float m = mv[ft];
-                if (m != m) m = 0.5f;  // math.IsNaN -> .5
-                const TT v = TT(m);
-                const TT* tap = kf + ff * 9 + ft;
-#pragma unroll
-                for (int c = 0; c < kGaborChunk; ++c) acc[c] = mad(tap[c * 81], v, acc[c]);
-            }
-        }
-#if defined(AUD_EXP_TAIL) && AUD_EXP_TAIL == 2
-        if (has && a.nT < 0)
-#else
-        if (has)
-#endif
-            gabor_emit<TT>(a, out, f0 + fi, ti, 0, 8, 8, acc);
-    }
-}
-
-__host__ __device__ inline size_t gabor_out_item_elems(const GaborArgs& a) {
-    return a.rank == 2 ? size_t(a.d0) * a.d1 : size_t(a.d0) * a.d1 * a.d2 * a.d3;
-}
-
 }  // namespace aud

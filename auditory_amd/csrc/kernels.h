@@ -268,10 +268,6 @@ hipError_t launch_melspec_wave(int kind, const MelspecArgs& a, const WaveArgs& e
 int melspec_wave_frames_per_wave(int kind);
 // workgroup-per-item variant (N = 400 only): carve LDS behind the plan's blob for `nf x T` mel values, false if it cannot fit;
 // `it` keeps the launch shape; the launch
-bool melspec_w20_gabor_available(int kind, int compute_dtype, int n_slots);
-bool melspec_w20_gabor_fits(const GaborArgs& g, int compute_dtype);
-hipError_t launch_melspec_w20_gabor(const MelspecArgs& a, const WaveArgs& e, const GaborArgs& g, const void* taps, int* tickets,
-                                    int compute_dtype, hipStream_t st);
 bool melspec_item_finish(int kind, int compute_dtype, const WaveArgs& e, int nf, int T, ItemArgs* it);
 hipError_t melspec_item_prepare(int kind, int compute_dtype, const WaveArgs& e, ItemArgs* it);
 hipError_t launch_melspec_item(int kind, const MelspecArgs& a, const WaveArgs& e, const ItemArgs& it, int compute_dtype, hipStream_t st);

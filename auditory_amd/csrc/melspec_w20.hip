@@ -148,12 +148,15 @@ __device__ __forceinline__ void w20_tile_front(const MelspecArgs& a, const WaveA
     AUD_STAMP(7);
 }
 
-// The tile kernel's body: the wave's tile from the samples to the stored mel values.  Returns the tile's item, or -1 for a wave
-// without a tile (it has left the workgroup's one barrier behind it and must simply end).
-template <typename TT, int SRC, int NW, int MAXS, bool SC1 = false>
-__device__ __forceinline__ int w20_wave_tile(const aud_item* items, unsigned total, unsigned tiles, unsigned tile_mul, int tile_shift,
-                                             const void* blob_ptr, int blob_bytes, unsigned n_wgs, int xcd_remap, const MelspecArgs& a,
-                                             const WaveArgs& e) {
+#ifdef AUD_EXP_W20_WAVES5
+#define AUD_W20_F64_WAVES 5
+#else
+#define AUD_W20_F64_WAVES 4
+#endif
+template <typename TT, int SRC, int NW, int MAXS>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(sizeof(TT) == 8 ? AUD_W20_F64_WAVES : 5, sizeof(TT) == 8 ? AUD_W20_F64_WAVES : 5)))
+void k_melspec_w20(const aud_item* items, unsigned total, unsigned tiles, unsigned tile_mul, int tile_shift, const void* blob_ptr,
+                   int blob_bytes, unsigned n_wgs, int xcd_remap, const MelspecArgs a, const WaveArgs e) {
     using L = w20::Layout<TT>;
     unsigned char* smem = dyn_lds();
     const int tid = int(threadIdx.x);
@@ -188,83 +191,18 @@ __device__ __forceinline__ int w20_wave_tile(const aud_item* items, unsigned tot
 
     blob_store<64 * NW>(e, smem, tid, blob);
     __syncthreads();  // the one barrier: tables visible to the workgroup's waves
-    if (!active) return -1;
+    if (!active) return;
 
     unsigned char* region = smem + e.xch_off + wave * L::kRegion;
     w20_tile_front<TT, SRC>(a, e, smem, region, it, t0, f, j, pos0, raw AUD_STAMP_ARG);
 
     // ---- optional spectrum outputs and the mel reduction: 6 frames x 10 filter groups on this wave ---------------
     const int* exps = reinterpret_cast<const int*>(region + L::kExpOff);
-    wave_mel_epilogue_pick<TT, w20::kFW, MAXS, false, SC1>(a, e, reinterpret_cast<const float*>(region), w20::kHp, smem,
-                                                      sizeof(TT) == 8 ? frame_scale_of(exps + lane % w20::kFW) : 0, it, item, t0, lane, exps);
+    wave_mel_epilogue_pick<TT, w20::kFW, MAXS>(a, e, reinterpret_cast<const float*>(region), w20::kHp, smem,
+                                          sizeof(TT) == 8 ? frame_scale_of(exps + lane % w20::kFW) : 0, it, item, t0, lane, exps);
     AUD_STAMP(8);
     AUD_STAMP_REAL(10);
     AUD_STAMP_FLUSH(a, wt, lane);
-    return item;
-}
-
-#ifdef AUD_EXP_W20_WAVES5
-#define AUD_W20_F64_WAVES 5
-#else
-#define AUD_W20_F64_WAVES 4
-#endif
-template <typename TT, int SRC, int NW, int MAXS>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(sizeof(TT) == 8 ? AUD_W20_F64_WAVES : 5, sizeof(TT) == 8 ? AUD_W20_F64_WAVES : 5)))
-void k_melspec_w20(const aud_item* items, unsigned total, unsigned tiles, unsigned tile_mul, int tile_shift, const void* blob_ptr,
-                   int blob_bytes, unsigned n_wgs, int xcd_remap, const MelspecArgs a, const WaveArgs e) {
-    (void)w20_wave_tile<TT, SRC, NW, MAXS>(items, total, tiles, tile_mul, tile_shift, blob_ptr, blob_bytes, n_wgs, xcd_remap, a, e);
-}
-
-// ================================================================================================
-// The tile kernel with agabor.Convolve behind a TICKET (sound/sndenv.go:342-359 + :481-497 as ONE launch at tile grain).
-// Every wave stores its tile's mel values WRITE-THROUGH (device scope: the XCDs' L2s are not coherent with each other, and a
-// device-scope release fence -- an L2 write-back -- per wave costs microseconds each: measured 304 us per step against 15),
-// waits for its stores, and takes a ticket of its item (device-scope add).  The wave that draws the item's LAST ticket finds the
-// item's whole [nf][T] mel matrix in memory -- every other tile's stores were acknowledged before its ticket --, invalidates its
-// CU's vector cache (device-scope acquire), and runs Convolve on the matrix: 64 lanes over the item's output positions, every
-// position in the plan's compute type throughout (gabor_item_wave, gabor_tile.h: gabor_position's multiply-adds in the same order,
-// the same bits as k_gabor -- but fed from bands of the matrix staged in the wave's LDS region with all of a band's loads in flight
-// at once: read position by position from memory the lone wave waited for every row of taps, 57 us per step against 15).
-// Against two launches: the convolution's waves do not have to find room beside a kernel that holds 488 of a SIMD's 512
-// registers -- they ARE that kernel's waves, one in `tiles` of them living ~ 4 500 vector instructions longer, spread over the
-// whole launch (an item's last tile, not the launch's last waves).  The finishing wave puts the ticket back to 0: the array is
-// clean for the next launch on the same stream (the host keeps one array per stream; launches on one stream are ordered).
-// ================================================================================================
-template <typename TT, int SRC, int NW, int MAXS>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(sizeof(TT) == 8 ? 4 : 5, sizeof(TT) == 8 ? 4 : 5)))
-void k_melspec_w20_gabor(const aud_item* items, unsigned total, unsigned tiles, unsigned tile_mul, int tile_shift, const void* blob_ptr,
-                         int blob_bytes, unsigned n_wgs, int xcd_remap, const TT* __restrict__ taps, int* tickets,
-                         const MelspecArgs a, const WaveArgs e, const GaborArgs g) {
-    const int item = w20_wave_tile<TT, SRC, NW, MAXS, true>(items, total, tiles, tile_mul, tile_shift, blob_ptr, blob_bytes, n_wgs,
-                                                            xcd_remap, a, e);
-    if (item < 0) return;  // wave-uniform
-    const int lane = int(threadIdx.x) & 63;
-    // this wave's mel stores (write-through, all lanes') are acknowledged before its ticket.  (The CPU thread emulator's lanes
-    // are threads: they meet at the wave barrier, and the add itself orders the memory there -- its race detector does not
-    // model fences)
-    __builtin_amdgcn_wave_barrier();
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    constexpr int kTicketOrder = __ATOMIC_RELAXED;
-#else
-    constexpr int kTicketOrder = __ATOMIC_ACQ_REL;
-#endif
-    int drawn = 0;
-    if (lane == 0) drawn = __hip_atomic_fetch_add(tickets + item, 1, kTicketOrder, __HIP_MEMORY_SCOPE_AGENT);
-    drawn = __builtin_amdgcn_readfirstlane(drawn);
-    if (drawn != int(tiles) - 1) return;  // wave-uniform: not the item's last tile
-    if (lane == 0) __hip_atomic_store(tickets + item, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's vector cache may hold lines of the matrix from an earlier launch
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the invalidate completes asynchronously: wait for it)
-#endif
-#ifdef AUD_EXP_TICKET_NOTAIL
-    return;
-#endif
-    // the wave's own exchange region is free (its tile is done): the bands of the item's matrix go through it
-    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
-    float* band = reinterpret_cast<float*>(dyn_lds() + e.xch_off + wave * w20::Layout<TT>::kRegion);
-    gabor_item_wave<TT>(g, taps, a.mel + size_t(item) * a.nf * a.T, g.out + size_t(item) * gabor_out_item_elems(g), band, lane);
 }
 
 // ================================================================================================
@@ -361,7 +299,6 @@ size_t w20_region_bytes(bool f64) { return f64 ? size_t(w20::Layout<double>::kRe
 #ifdef AUD_W20_QUICK  // resource experiments: one instantiation of each kernel (tools, never the product build)
 wave_kernel_t w20_kernel(bool, int, int) { return k_melspec_w20<double, AUD_F32, 4, 4>; }
 item_kernel_t w20_item_kernel(bool, int, int, int) { return k_melspec_w20_item<double, AUD_F32, 5, 4>; }
-wave_gabor_kernel_t w20_gabor_kernel(bool, int, int) { return k_melspec_w20_gabor<double, AUD_F32, 4, 4>; }
 #else
 #ifdef AUD_EXP_W20_NW  // (experiment: waves per workgroup of the tile kernel; melspec_wave.hip wave_kernel_waves follows)
 #define AUD_W20_NW AUD_EXP_W20_NW
@@ -377,18 +314,6 @@ wave_kernel_t w20_kernel(bool f64, int sig_dtype, int n_slots) {
     return f64 ? AUD_W20_PICK(double) : AUD_W20_PICK(float);
 }
 #undef AUD_W20_PICK
-
-// the ticket variant: float64 plans (the conforming default; float32 plans keep the two launches)
-#define AUD_W20_GABOR_PICK()                                                                                                   \
-    (sig_dtype == AUD_F64   ? (s8 ? k_melspec_w20_gabor<double, AUD_F64, 4, 8> : k_melspec_w20_gabor<double, AUD_F64, 4, 4>)   \
-     : sig_dtype == AUD_I16 ? (s8 ? k_melspec_w20_gabor<double, AUD_I16, 4, 8> : k_melspec_w20_gabor<double, AUD_I16, 4, 4>)   \
-                            : (s8 ? k_melspec_w20_gabor<double, AUD_F32, 4, 8> : k_melspec_w20_gabor<double, AUD_F32, 4, 4>))
-wave_gabor_kernel_t w20_gabor_kernel(bool f64, int sig_dtype, int n_slots) {
-    const bool s8 = n_slots > 4;
-    if (!f64) return nullptr;
-    return AUD_W20_GABOR_PICK();
-}
-#undef AUD_W20_GABOR_PICK
 
 #define AUD_W20_ITEM_PICK(TT, NW)                                                                                    \
     (sig_dtype == AUD_F64   ? (s8 ? k_melspec_w20_item<TT, AUD_F64, NW, 8> : k_melspec_w20_item<TT, AUD_F64, NW, 4>)   \

@@ -29,7 +29,6 @@
 #include <algorithm>
 
 #include "wave_common.h"
-#include "gabor_tile.h"
 
 namespace aud {
 
@@ -179,38 +178,6 @@ hipError_t launch_melspec_wave(int kind, const MelspecArgs& a, const WaveArgs& e
     hipLaunchKernelGGL(wave_kernel(kind, compute_dtype == AUD_F64, a.sig_dtype, e.n_slots), dim3(unsigned(wgs64)),
                        dim3(64 * e.waves), e.lds_bytes, st, b.items, unsigned(a.n_items) * unsigned(tiles), unsigned(tiles),
                        b.tile_mul, b.tile_shift, e.blob, e.blob_bytes, unsigned(wgs64), a.xcd_remap, b, e);
-    return hipGetLastError();
-}
-
-// the N = 400 tile kernel with Convolve behind a per-item ticket (melspec_w20.hip k_melspec_w20_gabor): float64 plans.  `taps`:
-// the plan's taps in the compute type; `tickets`: n_items ints, all zero between launches (the kernel leaves them so).
-bool melspec_w20_gabor_available(int kind, int compute_dtype, int n_slots) {
-    return kind == 3 && w20_gabor_kernel(compute_dtype == AUD_F64, AUD_F32, n_slots) != nullptr;
-}
-
-// the geometry the ticket tail serves (gabor_tile.h gabor_tail_fits: the 9 x 9 x 8 set, bands that fit the wave's exchange region)
-bool melspec_w20_gabor_fits(const GaborArgs& g, int compute_dtype) {
-    return gabor_tail_fits(g, w20_region_bytes(compute_dtype == AUD_F64) - 32) && g.rows * g.cols > 0;
-}
-
-hipError_t launch_melspec_w20_gabor(const MelspecArgs& a, const WaveArgs& e, const GaborArgs& g, const void* taps, int* tickets,
-                                    int compute_dtype, hipStream_t st) {
-    if (a.n_items <= 0) return hipSuccess;
-    const int64_t tiles = (int64_t(a.T) + w20::kFW - 1) / w20::kFW;
-    const int64_t per_wg = e.waves;
-    const int64_t wgs64 = (int64_t(a.n_items) * tiles + per_wg - 1) / per_wg;
-    if (wgs64 > 0x7FFFFFFF || int64_t(a.n_items) * tiles >= (int64_t(1) << 31) - 64 * per_wg) return hipErrorInvalidValue;
-    wave_gabor_kernel_t fn = w20_gabor_kernel(compute_dtype == AUD_F64, a.sig_dtype, e.n_slots);
-    if (!fn || e.waves != 4 || !melspec_w20_gabor_fits(g, compute_dtype)) return hipErrorInvalidValue;
-    MelspecArgs b = a;
-    b.tiles = int(tiles);
-    int l = 0;
-    while ((int64_t(1) << l) < tiles) ++l;
-    b.tile_shift = l - 1;
-    b.tile_mul = l == 0 ? 0u : unsigned(((uint64_t(1) << (31 + l)) + uint64_t(tiles) - 1) / uint64_t(tiles));
-    hipLaunchKernelGGL(fn, dim3(unsigned(wgs64)), dim3(64 * e.waves), e.lds_bytes, st, b.items, unsigned(a.n_items) * unsigned(tiles),
-                       unsigned(tiles), b.tile_mul, b.tile_shift, e.blob, e.blob_bytes, unsigned(wgs64), a.xcd_remap,
-                       static_cast<const double*>(taps), tickets, b, e, g);
     return hipGetLastError();
 }
 

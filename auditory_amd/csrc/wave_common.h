@@ -22,11 +22,6 @@ typedef void (*wave_kernel_t)(const aud_item*, unsigned, unsigned, unsigned, int
 typedef void (*item_kernel_t)(const aud_item*, unsigned, unsigned, const void*, int, const float*, const MelspecArgs, const WaveArgs,
                               const ItemArgs);
 item_kernel_t w20_item_kernel(bool f64, int sig_dtype, int n_slots, int waves);  // waves: 5, else null
-// the tile kernel with Convolve behind a ticket (melspec_w20.hip k_melspec_w20_gabor): the tile kernel's arguments, the taps in the
-// compute type (a direct restrict parameter: the scalar path), the per-item ticket array, the three argument structs
-typedef void (*wave_gabor_kernel_t)(const aud_item*, unsigned, unsigned, unsigned, int, const void*, int, unsigned, int, const double*, int*,
-                                    const MelspecArgs, const WaveArgs, const GaborArgs);
-wave_gabor_kernel_t w20_gabor_kernel(bool f64, int sig_dtype, int n_slots);  // float64 plans; else null
 __device__ __forceinline__ unsigned tile_div(unsigned mul, int shift, unsigned n) { return shift < 0 ? n : __umulhi(n, mul) >> shift; }
 wave_kernel_t w16_kernel(bool f64, int sig_dtype, int n_slots);
 wave_kernel_t w20_kernel(bool f64, int sig_dtype, int n_slots);

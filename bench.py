@@ -552,18 +552,15 @@ def main():  # noqa: C901
         # configs[3]: two launches by default (tile kernel, then k_gabor / k_gabor_lds by compute type); ONE launch with --option
         # item_kernel=1 (workgroup-per-item kernel: the item's mel matrix stays in LDS between the frame loop and Convolve --
         # measured slower at 256 items per launch)
-        ticket = bool(gabor and plan.info("gabor_ticket") == 1 and "gabor_ticket=1" in args.option and "item_kernel=1" not in args.option)
-        one_launch = ticket or bool(gabor and plan.info("item_kernel") == 1 and "item_kernel=1" in args.option)
+        one_launch = bool(gabor and plan.info("item_kernel") == 1 and "item_kernel=1" in args.option)
         res = timed_region(launch, n_streams, args.min_seconds if min_seconds is None else min_seconds,
                            nb * world * wl.dur_s)
         alg = nb * (ring.sample_bytes * wl.dur + 4 * wl.nf * wl.T)      # each sample read once + each mel value written once
         if gabor:  # the pooled on/off pairs written; the unfused path also re-reads the mel tensor
-            alg += nb * 4 * GABOR_POOLS[0] * GABOR_POOLS[1] * 2 * 8 + (0 if one_launch and not ticket else nb * 4 * wl.nf * wl.T)
+            alg += nb * 4 * GABOR_POOLS[0] * GABOR_POOLS[1] * 2 * 8 + (0 if one_launch else nb * 4 * wl.nf * wl.T)
             res["launches_per_step"] = 1 if one_launch else 2
             lds_gabor = compute == "f32" or "gabor_kernel=0" in args.option
-            res["gabor_path"] = ("one launch at tile grain: k_melspec_w20_gabor (the item's last tile runs Convolve -- float64 taps and sums -- on "
-                                 "the item's stored mel matrix behind a per-item ticket)" if ticket else
-                                 "fused: k_melspec_w20_item (workgroup per item, mel matrix in LDS, Convolve behind one barrier)"
+            res["gabor_path"] = ("fused: k_melspec_w20_item (workgroup per item, mel matrix in LDS, Convolve behind one barrier)"
                                  if one_launch else "two launches: mel kernel (w20x10 tiles), then " +
                                  ("the LDS-staged gabor kernel (k_gabor_lds: the item's mel matrix copied to LDS, float32 taps through "
                                   "the scalar path)" if lds_gabor and "gabor_kernel=1" not in args.option else

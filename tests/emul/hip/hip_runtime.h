@@ -166,22 +166,8 @@ inline hipError_t hipExtMallocWithFlags(void** p, size_t bytes, unsigned) { retu
 inline hipError_t hipMemset(void* dst, int value, size_t bytes) { std::memset(dst, value, bytes); return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
-#define __HIP_MEMORY_SCOPE_AGENT 4
-#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
-// (generic forms: the kernels also store floats this way -- write-through stores on the device, plain atomics here)
-template <typename T, typename V>
-inline void emul_atomic_store(T* p, V v, int order) {
-    T tmp = T(v);
-    __atomic_store(p, &tmp, order);
-}
-template <typename T>
-inline T emul_atomic_load(const T* p, int order) {
-    T out;
-    __atomic_load(const_cast<T*>(p), &out, order);
-    return out;
-}
-#define __hip_atomic_store(p, v, order, scope) emul_atomic_store((p), (v), (order))
-#define __hip_atomic_load(p, order, scope) emul_atomic_load((p), (order))
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
 inline void __builtin_amdgcn_s_sleep(int) {}
 // (the handle also carries the exporting process: "device" memory here is a process's own heap, so a handle of ANOTHER
 // process cannot be mapped -- opening it fails the way a box without IPC support fails, instead of handing out a wild pointer)

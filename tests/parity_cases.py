@@ -800,20 +800,6 @@ def case_process_fused_vs_oracle(orc, cdt, mem, name="cfg2_16k_n400_nf40", n=3, 
             plan.process_dev(mem.ptr(d_sig), capi.AUD_F32, mem.ptr(d_items), n, mem.ptr(d_mel), py, px, mem.ptr(d_gab), mem.stream)
             outs[mode] = (np.array(mem.get(d_mel)), np.array(mem.get(d_gab)))
         plan.set_option("gabor_kernel", -1)
-        # Convolve behind a per-item ticket inside the tile kernel (option gabor_ticket = 1, float64 plans): ONE launch at tile grain,
-        # the item's last tile runs gabor_position on the item's stored mel matrix -- the bits of the two launches with k_gabor.
-        # Three calls in a row on one stream (the counters must be back at zero after each), the last with another batch size.
-        assert plan.info("gabor_ticket") == (1 if cdt == capi.AUD_F64 else 0)
-        plan.set_option("item_kernel", -1)
-        plan.set_option("gabor_ticket", 1)
-        for rep, m in enumerate((n, n, max(1, n - 1))):
-            d_mel = mem.put(np.full((m, oc.nf, oc.T), 3.0, np.float32))
-            d_gab = mem.put(np.full((m, py, px, 2, 8), 7.0, np.float32))
-            plan.process_dev(mem.ptr(d_sig), capi.AUD_F32, mem.ptr(d_items), m, mem.ptr(d_mel), py, px, mem.ptr(d_gab), mem.stream)
-            t_mel, t_gab = np.array(mem.get(d_mel)), np.array(mem.get(d_gab))
-            assert np.array_equal(t_mel, outs["default"][0][:m], equal_nan=True), rep
-            assert np.array_equal(t_gab, outs["default"][1][:m]), rep
-        plan.set_option("gabor_ticket", 0)
         # mel-only through the item kernel (option 1), with the optional spectrum outputs
         plan.set_option("item_kernel", 1)
         d_mel = mem.put(np.zeros((n, oc.nf, oc.T), np.float32))
