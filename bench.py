@@ -279,6 +279,42 @@ class Ring:
         return blk if self.sample_bytes == 2 else blk.astype(np.float32).astype(np.float64)
 
 
+class LineGuard:
+    """Rank 0 of a multi-GPU run: a child process, forked BEFORE anything touches the GPU, that holds a copy of the JSON line
+    while an optional measurement runs.  The parent sends the finished line down a pipe (`stash`), runs the measurement, and
+    says `done` before it prints the final line itself; if the parent ends without saying so -- a GPU fault aborts the process,
+    the launcher kills it because another rank died -- the child prints the stashed line (its stdout is the parent's).
+    The child never imports or calls anything: it reads a pipe and writes one line."""
+
+    def __init__(self):
+        r, w = os.pipe()
+        pid = os.fork()
+        if pid == 0:
+            try:
+                os.close(w)
+                data = b""
+                while True:
+                    chunk = os.read(r, 1 << 16)
+                    if not chunk:
+                        break
+                    data += chunk
+                msgs = [m for m in data.split(b"\n") if m]
+                if msgs and msgs[-1] != b"DONE":
+                    os.write(1, msgs[-1] + b"\n")
+            finally:
+                os._exit(0)
+        os.close(r)
+        self.w, self.pid = w, pid
+
+    def stash(self, line):
+        os.write(self.w, json.dumps(line).encode() + b"\n")
+
+    def done(self):
+        os.write(self.w, b"DONE\n")
+        os.close(self.w)
+        os.waitpid(self.pid, 0)
+
+
 def main():  # noqa: C901
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -337,6 +373,11 @@ def main():  # noqa: C901
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream-read", action="store_true", help="skip roofline.measured_read_GBps (2 GiB read kernel)")
     args = ap.parse_args()
+
+    guard = None   # (forked before torch is imported or the GPU touched: LineGuard)
+    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) == 0 and args.workload == "headline"
+            and args.gather_mode == "rccl" and not args.no_direct_alt):
+        guard = LineGuard()
 
     import torch
     import torch.distributed as dist
@@ -817,13 +858,6 @@ def main():  # noqa: C901
             print("FATAL: the gathered tensor fails the parity criterion: %s" % cfg3["parity"], file=sys.stderr)
             dist.destroy_process_group()
             raise SystemExit(3)
-        # the same step with the OTHER reassembly (side key, never `value`): xGMI is point to point, so whether RCCL's
-        # schedule or one push per peer moves the 8.5 MB slabs faster is a measurement
-        if args.gather_mode == "rccl" and args.cfg3_total % world == 0 and not args.no_direct_alt:
-            try:
-                direct_alt = cfg3_region(head_wl, args.compute, args.cfg3_total, args.also_seconds, mode="direct")
-            except Exception as ex:
-                direct_alt = {"error": str(ex).splitlines()[0][:300]}
 
     # roofline.traffic: HBM bytes per launch from the PMC passes (tools/profile_bench.sh), if they were taken for this
     # kernel and batch; null otherwise (it cannot be measured inside this process)
@@ -932,16 +966,6 @@ def main():  # noqa: C901
         line["gathered_shape"] = cfg3.get("gathered_shape")
         line["no_collective"] = {k: head[k] for k in ("value", "steps", "ms_per_step", "us_per_step_device", "launch", "streams",
                                                       "batch", "parity") if k in head}
-        if direct_alt is not None:
-            line["direct_gather"] = ({k: direct_alt[k] for k in ("value", "steps", "ms_per_step", "us_per_step_device", "launch",
-                                                                 "collective", "parity", "arrival_timeouts", "xgmi_bound_us")
-                                      if k in direct_alt}
-                                     if "error" not in direct_alt else direct_alt)
-            if "error" not in direct_alt:
-                line["direct_gather"]["note"] = (
-                    "like for like with ncclAllGather: every step ends, inside the graph, with the wait for every peer's arrival "
-                    "flag (stored by the peer behind its push, system scope), two receive slabs alternate; parity is checked on "
-                    "both slabs; arrival_timeouts counts waits that ran into their poll bound (must be 0)")
         line["no_collective"]["note"] = "the sharded step without the collective: %d utterances per rank and step (weak scaling)" % B
     if modes:
         line["modes"] = modes
@@ -949,8 +973,33 @@ def main():  # noqa: C901
         line["also"] = also
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(head_wl, ring_for(head_wl).pcm)
+    # the same step with the OTHER reassembly (side key `direct_gather`, never `value`): xGMI is point to point, so whether RCCL's
+    # schedule or one push per peer moves the 8.5 MB slabs faster is a measurement.  It runs LAST, behind a copy of
+    # the finished line held by the guard process: a fault in this optional measurement (device-to-device pushes into buffers
+    # mapped from other processes: the one part of the flow no single-GPU box can rehearse) cannot take the line with it
+    if cfg3 is not None and args.gather_mode == "rccl" and args.cfg3_total % world == 0 and not args.no_direct_alt:
+        if guard is not None:
+            guard.stash(dict(line, direct_gather={"error": "the process ended during the direct-pattern side measurement; "
+                                                           "every other key of this line was measured before it"}))
+        try:
+            if os.environ.get("AUD_BENCH_TEST_DIE_IN_SIDE_MEASUREMENT") == "1":   # (tests/test_bench_dryrun.py: what a GPU fault does)
+                os._exit(7)
+            direct_alt = cfg3_region(head_wl, args.compute, args.cfg3_total, args.also_seconds, mode="direct")
+        except Exception as ex:
+            direct_alt = {"error": str(ex).splitlines()[0][:300]}
+        line["direct_gather"] = ({k: direct_alt[k] for k in ("value", "steps", "ms_per_step", "us_per_step_device", "launch",
+                                                             "collective", "parity", "arrival_timeouts", "xgmi_bound_us")
+                                  if k in direct_alt}
+                                 if "error" not in direct_alt else direct_alt)
+        if "error" not in direct_alt:
+            line["direct_gather"]["note"] = (
+                "like for like with ncclAllGather: every step ends, inside the graph, with the wait for every peer's arrival "
+                "flag (stored by the peer behind its push, system scope), two receive slabs alternate; parity is checked on "
+                "both slabs; arrival_timeouts counts waits that ran into their poll bound (must be 0)")
+    if guard is not None:
+        guard.done()
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if multi:
         dist.destroy_process_group()
 

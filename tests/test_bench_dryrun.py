@@ -85,6 +85,34 @@ def test_bench_dry_run_two_ranks(tmp_path):
     assert "error" in line["direct_gather"] and "peer" in line["direct_gather"]["error"]
 
 
+def test_bench_dry_run_line_survives_a_dead_side_measurement(tmp_path):
+    """Two gloo ranks; both processes end abruptly (os._exit: what a GPU fault's abort does) inside the optional direct-pattern
+    side measurement, the last thing the run does.  Rank 0's guard process -- forked before the GPU was touched, holding a copy
+    of the finished line -- must print that line: every key measured before the fault, and the reason in `direct_gather`."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = os.path.join(HERE, "bench_dry_worker.py")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", AUD_BENCH_TEST_DIE_IN_SIDE_MEASUREMENT="1")
+        procs.append(subprocess.Popen([sys.executable, worker, "--gpus", "2", "--steps", "2", "--warmup", "1",
+                                       "--batch", "2", "--ring-mb", "0.2", "--min-seconds", "0", "--cfg3-total", "6",
+                                       "--dist-backend", "gloo"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert [p.returncode for p in procs] == [7, 7], outs[0][1][-2000:] + outs[1][1][-2000:]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["parity"]["pass"] and line["value"] > 0
+    assert "ended during" in line["direct_gather"]["error"]
+
+
 class _SideStream(_Stream):
     def __init__(self, dev=None):
         pass
