@@ -111,8 +111,12 @@ int aud_host_register(aud_ctx* c, void* ptr, int64_t bytes) {
     if (!c || !ptr || bytes <= 0) return AUD_EINVAL;
     AUD_HIP(c, make_current(c));
     HostCallGuard guard(c);
-    if (find_host_block(c, ptr, 1) || find_host_block(c, static_cast<unsigned char*>(ptr) + bytes - 1, 1))
-        return fail(c, AUD_EINVAL, "aud_host_register: the range overlaps a block the context already holds");
+    {
+        const unsigned char* lo = static_cast<const unsigned char*>(ptr);
+        for (const auto& b : c->host_blocks)
+            if (lo < b.p + b.bytes && b.p < lo + bytes)
+                return fail(c, AUD_EINVAL, "aud_host_register: the range overlaps a block the context already holds");
+    }
     AUD_HIP(c, hipHostRegister(ptr, size_t(bytes), hipHostRegisterPortable | hipHostRegisterMapped));
     void* dev = nullptr;
     if (hipHostGetDevicePointer(&dev, ptr, 0) != hipSuccess || !dev) {
