@@ -291,6 +291,9 @@ class LineGuard:
         pid = os.fork()
         if pid == 0:
             try:
+                import signal
+                for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):   # (a launcher that ends the ranks of a failed job
+                    signal.signal(sig, signal.SIG_IGN)                       #  signals their whole group: outlive the parent)
                 os.close(w)
                 data = b""
                 while True:
