@@ -77,6 +77,67 @@ def main():
         report("w64 %s pass-1 row stores       plane[k1*68 + l]" % name, wr, lambda l, k1: (k1 * 68 + l) * sz, range(16))
         report("w64 %s pass-2 column reads     plane[(l>>2)*68 + (l&3) + 4 n2]" % name, "read_b64" if sz == 8 else "read_b32",
                lambda l, n2: ((l >> 2) * 68 + (l & 3) + 4 * n2) * sz, range(16))
+    generic_inplace()
+
+
+def group_cycles(kind, addrs):
+    """(LDS group-cycles, of which conflict cycles) of ONE wave instruction: every lane group costs as many cycles as its
+    busiest bank has distinct addresses"""
+    groups, mod, width = GROUPS[kind]
+    tot = conf = 0
+    for g in groups:
+        per = {}
+        for lane in g:
+            a = addrs[lane]
+            if a is None:
+                continue
+            for w in range(width):
+                per.setdefault((a // 4 + w) % mod, set()).add(a // 4 + w)
+        if per:
+            n = max(len(v) for v in per.values())
+            tot += n
+            conf += n - 1
+    return tot, conf
+
+
+def generic_inplace(L=2304):
+    """The in-place Bluestein transform of melspec_generic.hip (N = 1103: L = 2304 = 16 x 16 x 9, float64: 16-byte elements, 256
+    threads): every stage's 16-byte reads and writes of the four waves, under candidate placements of element i.
+      stage A (radix 16, s = 1):   144 butterflies; reads q + 144 i, writes 16 q + j
+      stage B (radix 16, s = 16):  144 butterflies, q = b >> 4, k = b & 15; reads k + 16 q + 144 i, writes k + 256 q + 16 j
+      stage C (radix 9, s = 256):  256 butterflies; reads and writes tid + 256 i
+    Result (group-cycles per transform, conflicts): linear 3344 / 2016 (stage A's writes: 16 lanes on one slot); the kernel's
+    padx (i + i / 16) 1728 / 400 -- the pad that spreads those writes costs every LINEAR read a 2-way conflict per lane group
+    (ds_read_b128's groups {0-3, 12-15, 20-27}: lanes 12 and 27 meet); a row-XOR swizzle (slot ^= row & 15) 1360 / 32.  The
+    swizzle is not in the kernel: its positions are not equally spaced, so every access needs ~3 vector instructions of address
+    arithmetic where padx's are immediate offsets -- ~490 per thread on 2 560, in a kernel whose vector ALUs and LDS pipe are
+    both ~70 % busy."""
+    def patterns(pos):
+        for wave in range(4):
+            tids = [wave * 64 + lane for lane in range(64)]
+            for i in range(16):
+                yield "read_b128", [pos(t + 144 * i) * 16 if t < 144 else None for t in tids]
+            for j in range(16):
+                yield "write_b128", [pos(16 * t + j) * 16 if t < 144 else None for t in tids]
+            for i in range(16):
+                yield "read_b128", [pos((t & 15) + 16 * (t >> 4) + 144 * i) * 16 if t < 144 else None for t in tids]
+            for j in range(16):
+                yield "write_b128", [pos((t & 15) + 256 * (t >> 4) + 16 * j) * 16 if t < 144 else None for t in tids]
+            for i in range(9):
+                yield "read_b128", [pos(t + 256 * i) * 16 for t in tids]
+            for j in range(9):
+                yield "write_b128", [pos(t + 256 * j) * 16 for t in tids]
+    for name, pos in (("linear", lambda i: i), ("padx: i + i / 16 (the kernel)", lambda i: i + (i >> 4)),
+                      ("row-XOR swizzle: slot ^= row & 15", lambda i: (i & ~15) | ((i & 15) ^ ((i >> 4) & 15)))):
+        tot = conf = 0
+        by = {"read_b128": 0, "write_b128": 0}
+        for kind, addrs in patterns(pos):
+            c = group_cycles(kind, addrs)
+            tot += c[0]
+            conf += c[1]
+            by[kind] += c[1]
+        print("generic in-place L = %d, %-36s group-cycles %5d, conflicts %4d (reads %d, writes %d)" % (
+            L, name, tot, conf, by["read_b128"], by["write_b128"]))
 
 
 if __name__ == "__main__":
