@@ -45,8 +45,13 @@ __device__ __forceinline__ void store_pair_block(float* cell, const TT (&acc)[8]
 
 // KSX, KSY, KNG > 0: compile-time filter geometry (the reference's default 9 x 9 x 8 set gets fully
 // unrolled taps and no group loop); 0: taken from the arguments at run time.
+#ifdef AUD_EXP_GABOR_BLOCK
+constexpr int kGaborBlock = AUD_EXP_GABOR_BLOCK;
+#else
+constexpr int kGaborBlock = 256;
+#endif
 template <typename TT, int KSX, int KSY, int KNG>
-__global__ __launch_bounds__(256) void k_gabor(const GaborArgs a) {
+__global__ __launch_bounds__(kGaborBlock) void k_gabor(const GaborArgs a) {
     const int per_item = a.nF * a.nT;
     const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (gid >= int64_t(a.n_items) * per_item) return;
@@ -202,14 +207,14 @@ hipError_t launch_gabor(const GaborArgs& a, int compute_dtype, hipStream_t st) {
         else hipLaunchKernelGGL(k_gabor_lds<float>, dim3(unsigned(a.n_items)), dim3(kLdsThreads), lds, st, a, g, a.k32);
         return hipGetLastError();
     }
-    const dim3 grid(unsigned((total + 255) / 256));
+    const dim3 grid(unsigned((total + kGaborBlock - 1) / kGaborBlock));
     const bool dflt = a.SX == 9 && a.SY == 9 && a.nG == 8;  // processspeech.go:226-253
     if (compute_dtype == AUD_F64) {
-        if (dflt) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor<double, 9, 9, 8>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor<double, 0, 0, 0>), grid, dim3(256), 0, st, a);
+        if (dflt) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor<double, 9, 9, 8>), grid, dim3(kGaborBlock), 0, st, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor<double, 0, 0, 0>), grid, dim3(kGaborBlock), 0, st, a);
     } else {
-        if (dflt) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor<float, 9, 9, 8>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor<float, 0, 0, 0>), grid, dim3(256), 0, st, a);
+        if (dflt) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor<float, 9, 9, 8>), grid, dim3(kGaborBlock), 0, st, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor<float, 0, 0, 0>), grid, dim3(kGaborBlock), 0, st, a);
     }
     return hipGetLastError();
 }
