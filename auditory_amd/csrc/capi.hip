@@ -42,7 +42,14 @@ void fill_melspec_args(const aud_plan* p, aud::MelspecArgs* a) {
 
 // the plan's frame -> power -> mel kernel (whatever family it selected), raw power, no smoothing
 hipError_t launch_frames(const aud_plan* p, const aud::MelspecArgs& a, hipStream_t st) {
-    if (p->use_wave && p->wave_kind) return aud::launch_melspec_wave(p->wave_kind, a, p->wv, p->d.compute_dtype, st);
+    if (p->use_wave && p->wave_kind) {
+        if (p->lds_pad > 0 && p->wv.lds_bytes + unsigned(p->lds_pad) <= 64u * 1024u) {  // (plan option "lds_pad": fewer workgroups per CU)
+            aud::WaveArgs e = p->wv;
+            e.lds_bytes += unsigned(p->lds_pad);
+            return aud::launch_melspec_wave(p->wave_kind, a, e, p->d.compute_dtype, st);
+        }
+        return aud::launch_melspec_wave(p->wave_kind, a, p->wv, p->d.compute_dtype, st);
+    }
     return aud::launch_melspec_generic(a, p->d.compute_dtype, st);
 }
 
@@ -387,6 +394,13 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
     if (key == "gabor_kernel") {
         if (value < -1 || value > 1) return fail(c, AUD_EINVAL, "gabor_kernel: -1 (auto), 0 (LDS-staged, float32 taps) or 1 (one thread per position)");
         p->gabor_opt = value;
+        return AUD_OK;
+    }
+    // extra dynamic LDS per workgroup of the wave kernels (bytes, the total stays <= 64 KB): lowers the workgroups a CU holds --
+    // and with them the registers the kernel's waves take -- so that a second kernel's waves find room beside them
+    if (key == "lds_pad") {
+        if (value < 0 || value > 64 * 1024) return fail(c, AUD_EINVAL, "lds_pad: 0 .. 65536 bytes");
+        p->lds_pad = value;
         return AUD_OK;
     }
     if (key == "xcd_remap") {  // 1 (default): every XCD walks a contiguous run of tiles; 0: tiles in workgroup-id order
