@@ -221,6 +221,14 @@ const char* aud_plan_kernel_name(const aud_plan* plan);
  *               kernel (the A/B and parity baseline of the wave kernels)
  *   "xcd_remap" 1 (default) workgroups that share an XCD take one contiguous run of tiles (L2 reuse of the
  *               samples neighbouring tiles share), 0 tiles in workgroup-id order
+ *   "item_kernel"  -1 / 0 (default) the tile kernel; 1 the workgroup-per-item kernel where the plan has one (N = 400): a
+ *               aud_process_batch_dev call becomes ONE launch with Convolve behind the frame loop (measured slower at 256 items per
+ *               launch: DESIGN.md 4.5)
+ *   "gabor_kernel" -1 (default) by compute type: float64 plans the all-float64 one-thread-per-position kernel (gabor.go:268-283 as
+ *               written), float32 plans the LDS-staged kernel; 0 the LDS-staged kernel (float32 taps and row sums: for a float64
+ *               plan an explicit opt-in, ~1e-6 of the all-float64 sum); 1 one thread per position
+ *   "lds_pad"   extra dynamic LDS per workgroup of the wave kernels, bytes (total <= 64 KB): fewer workgroups per CU, i.e. registers
+ *               left free for another kernel's waves (occupancy experiments); 0 (default) none
  *   "stamps_lo" / "stamps_hi"  the two halves of a device address for the s_memtime stamps of the DIAGNOSTIC build
  *               (-DAUD_STAMPS, tools/stamp_profile.py); unknown to the product build
  * AUD_EINVAL for an unknown name. */
@@ -232,7 +240,10 @@ int aud_plan_set_option(aud_plan* plan, const char* name, int value);
  *   "wgs_per_cu"       workgroups resident per compute unit (the runtime's occupancy answer at plan time)
  *   "frames_per_wave"  frames one wave transforms together (0: the generic kernel)
  *   "epilogue_steps"   wave kernels: filter steps of the mel epilogue, summed over its slots (padding included)
- *   "bluestein_L"      generic kernel: length of the power-of-two FFTs of its Bluestein route (0: direct factorisation)
+ *   "bluestein_L"      generic kernel: length of the transforms of its Bluestein route (0: direct factorisation)
+ *   "bluestein_inplace" 1 if that route runs in one padded buffer (stages through registers)
+ *   "generic_frames_per_wg"  frames a workgroup of the generic kernel transforms at once
+ *   "item_kernel"      1 if the plan has the workgroup-per-item kernel ("item_waves", "item_lds_bytes": its launch shape)
  * AUD_EINVAL for an unknown name. */
 int aud_plan_get_info(const aud_plan* plan, const char* name, int64_t* value);
 
