@@ -398,13 +398,6 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
     }
     // extra dynamic LDS per workgroup of the wave kernels (bytes, the total stays <= 64 KB): lowers the workgroups a CU holds --
     // and with them the registers the kernel's waves take -- so that a second kernel's waves find room beside them
-    // 1 (default): the one-thread-per-position kernel takes TWO neighbouring positions per thread where the set is the reference's
-    // default (9 x 9 taps, 8 filters, time stride 3) -- the same bits, a quarter fewer vector instructions; 0: one position per thread
-    if (key == "gabor_pair") {
-        if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "gabor_pair: 0 or 1");
-        p->gabor_pair = value;
-        return AUD_OK;
-    }
     if (key == "lds_pad") {
         if (value < 0 || value > 64 * 1024) return fail(c, AUD_EINVAL, "lds_pad: 0 .. 65536 bytes");
         p->lds_pad = value;
@@ -645,7 +638,6 @@ int gabor_geometry(aud_plan* p, int n_items, int rows, int cols, int out_rank, c
     a.k = p->d_gabor;
     a.k32 = p->d_gabor32;
     a.mode = p->gabor_opt;
-    a.pair = p->gabor_pair;
     a.nG = nG;
     a.SX = g.size_x;
     a.SY = g.size_y;

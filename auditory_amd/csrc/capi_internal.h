@@ -113,7 +113,6 @@ struct aud_plan {
     aud::ItemArgs itm{};
     bool has_item = false;
     int item_opt = -1;
-    int gabor_pair = 1;  // plan option "gabor_pair"
     int lds_pad = 0;     // plan option "lds_pad": extra dynamic LDS per workgroup of the wave kernels (occupancy experiments)
     int gabor_opt = -1;  // plan option "gabor_kernel" (kernels.h GaborArgs::mode): -1 = by compute type
     void* d_dct = nullptr;  // [mfcc_coefs][nf] DCT-I rows

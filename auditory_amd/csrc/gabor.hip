@@ -43,37 +43,6 @@ __device__ __forceinline__ void store_pair_block(float* cell, const TT (&acc)[8]
     c4[3] = float4{off[4], off[5], off[6], off[7]};
 }
 
-// gabor.go:283-309: the sums of filters g0 .. g0 + gc - 1 at position (fIdx, tIdx), rectified into the on / off pair, stored with the
-// 2-D / 4-D index maps
-template <typename TT>
-__device__ __forceinline__ void gabor_emit(const GaborArgs& a, float* out, int f_idx, int t_idx, int g0, int gc, int NG,
-                                           const TT (&acc)[kChunk], TT gain) {
-    if (a.rank == 4 && a.d2 == 2 && a.d3 == 8 && NG == 8 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
-        store_pair_block<TT>(out + (size_t(f_idx) * a.d1 + t_idx) * 16, acc, gain);
-        return;
-    }
-#pragma unroll
-    for (int c = 0; c < kChunk; ++c) {
-        if (c >= gc) break;
-        const int flt = g0 + c;
-        const bool pos = acc[c] >= TT(0);
-        const float act = float(gain * (acc[c] < TT(0) ? -acc[c] : acc[c]));
-        size_t o_on, o_off;
-        if (a.rank == 2) {
-            const int y = f_idx * 2;
-            const int x = a.by_time ? t_idx + a.t_max_strides * flt : flt + t_idx * NG;
-            o_on = size_t(y) * a.d1 + x;
-            o_off = size_t(y + 1) * a.d1 + x;
-        } else {
-            const size_t cell = (size_t(f_idx) * a.d1 + t_idx) * a.d2;
-            o_on = cell * a.d3 + flt;
-            o_off = (cell + 1) * a.d3 + flt;
-        }
-        out[o_on] = pos ? act : 0.f;
-        out[o_off] = pos ? 0.f : act;
-    }
-}
-
 // KSX, KSY, KNG > 0: compile-time filter geometry (the reference's default 9 x 9 x 8 set gets fully
 // unrolled taps and no group loop); 0: taken from the arguments at run time.
 #ifdef AUD_EXP_GABOR_BLOCK
@@ -134,62 +103,31 @@ __global__ __launch_bounds__(kGaborBlock) void k_gabor(const GaborArgs a) {
                 for (int ft = 0; ft < SX; ++ft) tap_row(row, ff, ft);
             }
         }
-        gabor_emit<TT>(a, out, f_idx, t_idx, g0, gc, NG, acc, gain);
-    }
-}
-
-// The reference's default set (9 x 9 taps, 8 filters, time stride 3: processspeech.go:226-253) with TWO neighbouring positions
-// per thread, (fIdx, 2u) and (fIdx, 2u + 1): their windows share 6 of 9 columns, so a row is 12 values instead of 18 to load,
-// to convert and to test for NaN -- and the NaN test itself (gabor.go:278-280) is one sum per row: the sum of a row's values is
-// NaN or infinite only if one of them is (or they overflow), and only then are the values tested one by one.  The multiply-adds
-// are k_gabor's, in k_gabor's order: the same bits.  1 570 instead of 2 x 1 049 vector instructions per pair of positions --
-// the stage costs what its instructions cost beside a vector-issue-bound mel kernel.
-template <typename TT>
-__global__ __launch_bounds__(256) void k_gabor_pair(const GaborArgs a) {
-    const int half = (a.nT + 1) >> 1;
-    const int per_item = a.nF * half;
-    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (gid >= int64_t(a.n_items) * per_item) return;
-    const int item = int(gid / per_item);
-    const int r = int(gid - int64_t(item) * per_item);
-    const int f_idx = r / half, u = r - f_idx * half;
-    const int t_idx = 2 * u;
-    const bool two = t_idx + 1 < a.nT;  // (an odd nT leaves the last position of a row alone)
-    const int f = f_idx * a.sty, t = t_idx * 3;
-    const float* __restrict__ mel = a.mel + size_t(item) * a.rows * a.cols;
-    const TT* __restrict__ kf = static_cast<const TT*>(a.k);
-    const TT gain = TT(a.gain);
-    float* out = a.out + size_t(item) * (a.rank == 2 ? size_t(a.d0) * a.d1 : size_t(a.d0) * a.d1 * a.d2 * a.d3);
-    TT acc0[kChunk], acc1[kChunk];
-#pragma unroll
-    for (int c = 0; c < kChunk; ++c) acc0[c] = acc1[c] = TT(0);
-    for (int ff = 0; ff < 9; ++ff) {
-        const float* row = mel + size_t(f + ff) * a.cols + t;
-        const F4u q0 = *reinterpret_cast<const F4u*>(row), q1 = *reinterpret_cast<const F4u*>(row + 4);
-        F4u q2 = {row[8], 0.f, 0.f, 0.f};
-        if (two) q2 = *reinterpret_cast<const F4u*>(row + 8);  // (the second position's last read is inside the matrix: the host checked)
-        float mv[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-        const float sum = ((mv[0] + mv[1]) + (mv[2] + mv[3])) + ((mv[4] + mv[5]) + (mv[6] + mv[7])) + ((mv[8] + mv[9]) + (mv[10] + mv[11]));
-        if (!(__builtin_fabsf(sum) <= 3.402823466e38f)) {  // a NaN (or an infinity) somewhere in the row: math.IsNaN -> .5, value by value
-#pragma unroll
-            for (int i = 0; i < 12; ++i)
-                if (mv[i] != mv[i]) mv[i] = 0.5f;
+        if (a.rank == 4 && a.d2 == 2 && a.d3 == 8 && NG == 8 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
+            store_pair_block<TT>(out + (size_t(f_idx) * a.d1 + t_idx) * 16, acc, gain);
+            continue;
         }
-        TT v[12];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) v[i] = TT(mv[i]);
-#pragma unroll
-        for (int ft = 0; ft < 9; ++ft) {
-            const TT* tap = kf + ff * 9 + ft;
-#pragma unroll
-            for (int c = 0; c < kChunk; ++c) {
-                acc0[c] += tap[c * 81] * v[ft];
-                acc1[c] += tap[c * 81] * v[ft + 3];
+        for (int c = 0; c < kChunk; ++c) {
+            if (c >= gc) break;
+            const int flt = g0 + c;
+            const bool pos = acc[c] >= TT(0);
+            const float act = float(gain * (acc[c] < TT(0) ? -acc[c] : acc[c]));
+            size_t o_on, o_off;
+            if (a.rank == 2) {
+                const int y = f_idx * 2;
+                const int x = a.by_time ? t_idx + a.t_max_strides * flt : flt + t_idx * NG;
+                o_on = size_t(y) * a.d1 + x;
+                o_off = size_t(y + 1) * a.d1 + x;
+            } else {
+                const size_t cell = (size_t(f_idx) * a.d1 + t_idx) * a.d2;
+                o_on = cell * a.d3 + flt;
+                o_off = (cell + 1) * a.d3 + flt;
             }
+            out[o_on] = pos ? act : 0.f;
+            out[o_off] = pos ? 0.f : act;
         }
     }
-    gabor_emit<TT>(a, out, f_idx, t_idx, 0, 8, 8, acc0, gain);
-    if (two) gabor_emit<TT>(a, out, f_idx, t_idx + 1, 0, 8, 8, acc1, gain);
 }
 
 // The LDS-staged form (the default wherever an item's mel matrix and the taps fit 64 KB of LDS): one workgroup per item
@@ -271,13 +209,6 @@ hipError_t launch_gabor(const GaborArgs& a, int compute_dtype, hipStream_t st) {
     }
     const dim3 grid(unsigned((total + kGaborBlock - 1) / kGaborBlock));
     const bool dflt = a.SX == 9 && a.SY == 9 && a.nG == 8;  // processspeech.go:226-253
-    if (dflt && a.stx == 3 && a.pair != 0) {  // two neighbouring positions per thread (plan option "gabor_pair", default on)
-        const int64_t threads = int64_t(a.n_items) * a.nF * ((a.nT + 1) / 2);
-        const dim3 pgrid(unsigned((threads + 255) / 256));
-        if (compute_dtype == AUD_F64) hipLaunchKernelGGL(k_gabor_pair<double>, pgrid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(k_gabor_pair<float>, pgrid, dim3(256), 0, st, a);
-        return hipGetLastError();
-    }
     if (compute_dtype == AUD_F64) {
         if (dflt) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor<double, 9, 9, 8>), grid, dim3(kGaborBlock), 0, st, a);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gabor<double, 0, 0, 0>), grid, dim3(kGaborBlock), 0, st, a);

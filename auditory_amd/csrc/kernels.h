@@ -144,7 +144,6 @@ struct GaborArgs {
     int by_time;
     int nT, nF, t_max_strides;
     float* out;
-    int pair;  // plan option "gabor_pair": 1 = the default set (9 x 9 x 8, time stride 3) takes two positions per thread
     int mode;  // plan option "gabor_kernel": -1 = float64 plans k_gabor, float32 plans LDS-staged; 0 = LDS-staged where it fits; 1 = k_gabor
 };
 

@@ -419,33 +419,6 @@ def case_gabor_4d_and_2d_vs_oracle(orc, cdt):
         assert ok, "gabor_kernel %d: %s" % (gk, msg)
         if cdt == capi.AUD_F64 and gk == 1:
             assert np.array_equal(out1, out)             # the float64 plan's default IS the all-float64 kernel
-    # two neighbouring positions per thread (option gabor_pair, the default for this set) against one: the same multiply-adds in the
-    # same order -- bit for bit, also where a row holds NaN or infinite cells (the pair kernel screens a row by its SUM before it
-    # tests values one by one) and with 33 pools (an odd count: the last position of a row stands alone)
-    mel_x = mel.copy()
-    mel_x[3, 5, 17] = np.inf
-    mel_x[3, 9, 40] = -np.inf
-    mel_x[3, 9, 41] = np.inf           # +inf and -inf in one row: their sum is NaN, neither value is
-    mel_x[4, 20, 3] = np.nan
-    mel_x[4, 21, 100:] = 3.0e38        # finite values whose row sum overflows
-    plan.set_option("gabor_kernel", 1)
-    for shape in ((5, 11, 32, 2, 8), (5, 11, 33, 2, 8), (5, 9, 20, 3, 10)):
-        got = {}
-        for pair in (1, 0):
-            plan.set_option("gabor_pair", pair)
-            o = np.full(shape, 7.0, np.float32)
-            plan.gabor_host(mel_x, o)
-            got[pair] = o
-        assert np.array_equal(got[0], got[1], equal_nan=True), shape
-    r2 = np.full((5, 11, 32, 2, 8), 7.0, np.float32)
-    for i in (0, 1, 2, 4):             # (item 3 holds infinities: NaN sums on both sides, compared above)
-        assert orc.gabor_convolve(mel_x[i], k, 3, 3, 2.0, r2[i]) == 0
-    o = np.full((5, 11, 32, 2, 8), 7.0, np.float32)
-    plan.gabor_host(mel_x, o)
-    with np.errstate(invalid="ignore", over="ignore"):
-        ok, msg = W.close_enough(o[[0, 1, 2]], r2[[0, 1, 2]], 1e-5 if cdt == capi.AUD_F32 else 3e-7)
-    assert ok, msg
-    plan.set_option("gabor_pair", 1)
     plan.set_option("gabor_kernel", -1)
     # wider units than the kernel fills + fewer pools than the mel allows:
     # untouched cells keep their contents (the reference never zeroes rawOut)
