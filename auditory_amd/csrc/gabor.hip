@@ -87,6 +87,9 @@ __global__ __launch_bounds__(kGaborBlock) void k_gabor(const GaborArgs a) {
                 if (c < gc) acc[c] += tap[size_t(c) * area] * v;
         };
         auto tap_row = [&](const float* row, int ff, int ft) { tap_val(row[ft], ff, ft); };
+#ifdef AUD_EXP_GABOR_UNROLL
+#pragma unroll AUD_EXP_GABOR_UNROLL
+#endif
         for (int ff = 0; ff < SY; ++ff) {
             const float* row = mel + size_t(f + ff) * a.cols + t;
             if constexpr (KSX == 9) {
