@@ -87,8 +87,12 @@ __global__ __launch_bounds__(kGaborBlock) void k_gabor(const GaborArgs a) {
                 if (c < gc) acc[c] += tap[size_t(c) * area] * v;
         };
         auto tap_row = [&](const float* row, int ff, int ft) { tap_val(row[ft], ff, ft); };
+        // three rows at a time: the next rows' loads are in flight behind a row's multiply-adds (rolled: every row's loads are
+        // waited for in full, 15.47-15.55 us per configs[3] step; by three 15.35-15.39; all nine 15.96-16.14: round 5, one box)
 #ifdef AUD_EXP_GABOR_UNROLL
 #pragma unroll AUD_EXP_GABOR_UNROLL
+#else
+#pragma unroll 3
 #endif
         for (int ff = 0; ff < SY; ++ff) {
             const float* row = mel + size_t(f + ff) * a.cols + t;
