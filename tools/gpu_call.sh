@@ -3,7 +3,9 @@
 #   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/gpu_call.sh TAG step [step ...]'
 # Every step is bounded by its own `timeout -k`, writes gpurun_out/TAG_<step>.log, and a step that times out or dies by a
 # signal ends the sequence (no GPU step after it); an ordinary failure (rc 1) does not.
-# Steps: smoke | pytest | bench | bench:<extra bench.py args joined by ','> | ab | profile[:<bench args>] | stamps | mfma | stream | two_ranks | hostcall
+# Steps: smoke | pytest | pytest_all | bench | bench:<extra bench.py args joined by ','> | ab | profile[:<bench args>] | stamps | mfma |
+#        stream | wstream | dispatch | ubench | two_ranks | ranks:<2..4> | hostranks:<2..4> | hostcall | tune_bluestein |
+#        runlib:<tag>,<script.py>,<args...>  (the script against an experimental build: python -m auditory_amd.build --tag <tag> -D...)
 set -u
 TAG=${1:?tag}; shift
 mkdir -p gpurun_out
