@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libauditory_hip.so")
 
 AUD_OK, AUD_EINVAL, AUD_EHIP, AUD_ERCCL, AUD_ENOMEM, AUD_ESHORT = 0, 1, 2, 3, 4, 5
+AUD_RESIDENT_AUTO_BYTES = 8 << 20   # include/auditory_hip.h
 AUD_F64, AUD_F32, AUD_I16 = 0, 1, 2   # AUD_F64 == 0: a zeroed PlanDesc is the float64 (conforming) plan
 AUD_FAST_F32 = AUD_F32                # compute_dtype opt-in: the float32 kernels (never a default)
 
@@ -124,6 +125,7 @@ SYMBOLS = {
     "aud_host_register": (C.c_int, [_VP, _VP, C.c_int64]),
     "aud_host_unregister": (C.c_int, [_VP, _VP]),
     "aud_signal_upload": (C.c_int, [_VP, _VP, C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
+    "aud_signal_sync": (C.c_int, [_VP, C.POINTER(C.c_void_p), _VP, C.c_int, C.c_int64, C.POINTER(C.c_int64)]),
     "aud_signal_destroy": (C.c_int, [_VP]),
     "aud_signal_len": (C.c_int64, [_VP]),
     "aud_melspec_batch_sig": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP]),

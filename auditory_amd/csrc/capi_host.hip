@@ -206,6 +206,75 @@ int aud_signal_destroy(aud_signal* s) {
 
 int64_t aud_signal_len(const aud_signal* s) { return s ? s->n : -1; }
 
+int aud_signal_sync(aud_ctx* c, aud_signal** sig, const void* samples, int sample_dtype, int64_t n_samples,
+                    int64_t* uploaded_bytes) {
+    if (uploaded_bytes) *uploaded_bytes = 0;
+    if (!c || !sig) return AUD_EINVAL;
+    if (sample_dtype != AUD_F64 && sample_dtype != AUD_F32 && sample_dtype != AUD_I16) return fail(c, AUD_EINVAL, "bad sample_dtype");
+    if (n_samples < 0 || (n_samples > 0 && !samples)) return fail(c, AUD_EINVAL, "null buffer");
+    aud_signal* s = *sig;
+    if (s) {  // a handle of THIS context that is still alive
+        SignalRegistry& reg = SignalRegistry::get();
+        std::lock_guard<std::mutex> lk(reg.m);
+        if (std::find(reg.live.begin(), reg.live.end(), s) == reg.live.end() || s->ctx != c)
+            return fail(c, AUD_EINVAL, "signal of another (or a shut-down) context");
+    }
+    AUD_HIP(c, make_current(c));
+    HostCallGuard guard(c);  // (its drain on exit is what lets the caller touch `samples` again)
+    if (!s) {
+        s = new (std::nothrow) aud_signal();
+        if (!s) return AUD_ENOMEM;
+        s->ctx = c;
+        SignalRegistry& reg = SignalRegistry::get();
+        std::lock_guard<std::mutex> lk(reg.m);
+        reg.live.push_back(s);
+        *sig = s;
+    }
+    const unsigned char* src = static_cast<const unsigned char*>(samples);
+    const size_t bytes = size_t(n_samples) * sample_bytes(sample_dtype);
+    size_t lo = 0, hi = bytes;  // the span to upload
+    const bool same_shape = s->shadow_ok && s->dtype == sample_dtype && s->n == n_samples;
+    if (same_shape) {  // byte for byte against what the device holds
+        constexpr size_t kBlock = 4096;
+        lo = bytes;
+        hi = 0;
+        for (size_t b = 0; b < bytes; b += kBlock) {
+            const size_t len = std::min(kBlock, bytes - b);
+            if (std::memcmp(src + b, s->shadow + b, len) != 0) {
+                if (lo == bytes) lo = b;
+                hi = b + len;
+            }
+        }
+        if (lo >= hi) return AUD_OK;  // equal: the resident copy IS the caller's tensor
+    } else {
+        s->shadow_ok = false;
+        if (s->cap < bytes + 16) {
+            if (s->d) AUD_HIP(c, hipFree(s->d));
+            s->d = nullptr;
+            s->cap = 0;
+            AUD_HIP(c, hipMalloc(&s->d, bytes + 16));
+            s->cap = bytes + 16;
+        }
+        if (s->shadow_cap < bytes) {
+            std::free(s->shadow);
+            s->shadow = static_cast<unsigned char*>(std::malloc(bytes ? bytes : 1));
+            s->shadow_cap = s->shadow ? bytes : 0;
+            if (!s->shadow) return fail(c, AUD_ENOMEM, "aud_signal_sync: no memory for the shadow");
+        }
+        s->dtype = sample_dtype;
+        s->n = n_samples;
+    }
+    s->shadow_ok = false;
+    if (hi > lo) {
+        AUD_HIP(c, hipMemcpyAsync(static_cast<unsigned char*>(s->d) + lo, src + lo, hi - lo, hipMemcpyHostToDevice, c->stream));
+        std::memcpy(s->shadow + lo, src + lo, hi - lo);
+        AUD_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    s->shadow_ok = true;
+    if (uploaded_bytes) *uploaded_bytes = int64_t(hi - lo);
+    return AUD_OK;
+}
+
 int aud_melspec_batch_sig(aud_plan* p, const aud_signal* s, const aud_item* items, int n_items, double* mel, double* power,
                           double* log_power) {
     if (!p) return AUD_EINVAL;

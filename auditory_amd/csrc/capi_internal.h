@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <climits>
 #include <cstring>
 #include <new>
@@ -70,6 +71,13 @@ struct aud_signal {
     void* d = nullptr;
     int dtype = 0;
     int64_t n = 0;
+    // aud_signal_sync: capacity of `d`, and the host SHADOW of what `d` holds (malloc; valid only while shadow_ok: an upload
+    // that failed half-way leaves the device copy undefined, and the next sync uploads everything)
+    size_t cap = 0;
+    unsigned char* shadow = nullptr;
+    size_t shadow_cap = 0;
+    bool shadow_ok = false;
+    ~aud_signal() { std::free(shadow); }
 };
 // every handle that is alive and the context it belongs to (a destroy on a detached handle must not touch a dead context's mutex)
 struct SignalRegistry {

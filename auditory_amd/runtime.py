@@ -70,15 +70,31 @@ class Signal:
 
     _DT = {np.dtype(np.float64): capi.AUD_F64, np.dtype(np.float32): capi.AUD_F32, np.dtype(np.int16): capi.AUD_I16}
 
-    def __init__(self, ctx, samples):
+    def __init__(self, ctx, samples=None):
+        """samples given: a SNAPSHOT of them (aud_signal_upload).  None: an empty handle for sync()."""
+        self.ctx, self.n, self.handle = ctx, 0, C.c_void_p()
+        self.uploaded_bytes = 0
+        if samples is None:
+            return
         samples = np.ascontiguousarray(samples)
         if samples.dtype not in self._DT:
             raise TypeError("samples must be float64, float32 or int16")
-        self.ctx, self.n = ctx, int(samples.size)
-        h = C.c_void_p()
+        self.n = int(samples.size)
         ctx.check(ctx.lib.aud_signal_upload(ctx.handle, samples.ctypes.data_as(C.c_void_p), self._DT[samples.dtype],
-                                            samples.size, C.byref(h)))
-        self.handle = h
+                                            samples.size, C.byref(self.handle)))
+        self.uploaded_bytes = samples.nbytes
+
+    def sync(self, samples):
+        """aud_signal_sync: make the device copy EQUAL to `samples` -- compared byte for byte with the handle's host shadow of
+        what the device holds; only a differing span (everything the first time) crosses the link.  Returns the bytes uploaded."""
+        samples = np.ascontiguousarray(samples)
+        if samples.dtype not in self._DT:
+            raise TypeError("samples must be float64, float32 or int16")
+        up = C.c_int64(0)
+        self.ctx.check(self.ctx.lib.aud_signal_sync(self.ctx.handle, C.byref(self.handle), samples.ctypes.data_as(C.c_void_p),
+                                                    self._DT[samples.dtype], samples.size, C.byref(up)))
+        self.n, self.uploaded_bytes = int(samples.size), int(up.value)
+        return self.uploaded_bytes
 
     def close(self):
         if self.handle:

@@ -185,11 +185,17 @@ class SndEnv:
         self._device = device
         self._compute_dtype = compute_dtype
         self._plan = None
-        # ProcessSegment runs once per segment on the SAME Signal (sndenv.go:342-359): the device keeps a copy of it between
-        # calls (aud_signal_upload), re-taken when the tensor is another one (ToTensor, AdjustForSilence, an assignment), has
-        # another length, or differs in a sampled fingerprint; SignalChanged() after an in-place edit.  False: copy per call.
-        self.ResidentSignal = True
+        # ProcessSegment runs once per segment on the SAME Signal, and the reference reads the LIVE tensor at every step
+        # (sndenv.go:455-478): the device keeps a copy of it between calls that is validated EXACTLY on every call.
+        #   ResidentSignal = None (default): a Signal of up to AUD_RESIDENT_AUTO_BYTES is compared byte for byte with the host
+        #       shadow of the device copy (aud_signal_sync) -- any in-place edit is seen, only the differing span is uploaded;
+        #       a larger Signal is copied per call, as if there were no residency.
+        #   ResidentSignal = True, or an explicit SignalToDevice(): the caller opts in to a SNAPSHOT it keeps current itself --
+        #       re-taken when Signal is another array, length or type; SignalChanged() after an in-place edit.
+        #   ResidentSignal = False: copy per call.
+        self.ResidentSignal = None
         self._dev_sig = self._dev_sig_key = None
+        self._snapshot = False      # the resident copy is an opted-in snapshot (validated by identity only)
 
     def ToTensor(self):
         """sound/sndenv.go:297-300: Signal <- Sound.SoundToTensor()"""
@@ -286,32 +292,44 @@ class SndEnv:
         if self._dev_sig is not None:
             self._dev_sig.close()
         self._dev_sig = self._dev_sig_key = None
+        self._snapshot = False
 
     def _signal_key(self):
-        """what the resident copy is valid for: the tensor's memory, its length and type, and a fingerprint of <= 64 samples
-        spread over it (an in-place edit that touches none of them needs SignalChanged())"""
+        """what an opted-in SNAPSHOT is valid for: the tensor's memory, length, type and strides (its contents are the
+        caller's business: SignalChanged())"""
         sig = self.Signal
-        n = len(sig)
-        probe = np.ascontiguousarray(sig[::max(1, n // 61)][:63]).tobytes() + (np.asarray(sig[-1:]).tobytes() if n else b"")
-        return (sig.__array_interface__["data"][0], n, sig.dtype.str, sig.strides, hash(probe))
+        return (sig.__array_interface__["data"][0], len(sig), sig.dtype.str, sig.strides)
 
     def SignalChanged(self):
-        """New: call after changing samples of self.Signal IN PLACE -- the next ProcessSegment uploads the tensor again.
-        (ToTensor, AdjustForSilence, Init and assigning another array are noticed without it.)"""
+        """New: after changing samples of self.Signal IN PLACE while a snapshot is resident (ResidentSignal = True or
+        SignalToDevice()): the next ProcessSegment uploads the tensor again.  Not needed in the default mode, which compares
+        the whole tensor on every call."""
         self._dev_sig_key = None
 
     def SignalToDevice(self):
-        """New: (re)take the device's copy of self.Signal NOW (aud_signal_upload); ProcessSegment(s) then send only the work
-        items and fetch only the results.  With ResidentSignal (the default) the first ProcessSegment does this itself."""
+        """New: opt in to a resident SNAPSHOT of self.Signal, taken NOW (aud_signal_upload); ProcessSegment(s) then send only
+        the work items and fetch only the results, whatever the Signal's size.  The snapshot is re-taken when Signal is
+        another array / length / type; an in-place edit must be announced with SignalChanged()."""
         self._drop_resident()
         self._dev_sig = runtime.Signal(runtime.get_ctx(self._device), np.ascontiguousarray(self.Signal, np.float64))
         self._dev_sig_key = self._signal_key()
+        self._snapshot = True
 
     def _resident(self):
-        if not self.ResidentSignal or len(self.Signal) == 0:
+        """the device copy this call may read (None: copy per call)"""
+        if self.ResidentSignal is False or len(self.Signal) == 0:
             return None
-        if self._dev_sig is None or self._dev_sig_key != self._signal_key():
-            self.SignalToDevice()
+        if self.ResidentSignal or self._snapshot:                       # opted-in snapshot (until Init, or ResidentSignal = False)
+            if self._dev_sig is None or self._dev_sig_key != self._signal_key():
+                self.SignalToDevice()
+            return self._dev_sig
+        sig = np.ascontiguousarray(self.Signal, np.float64)
+        if sig.nbytes > capi.AUD_RESIDENT_AUTO_BYTES:
+            self._drop_resident()
+            return None
+        if self._dev_sig is None:
+            self._dev_sig = runtime.Signal(runtime.get_ctx(self._device))
+        self._dev_sig.sync(sig)                                         # exact: memcmp against the shadow, upload what differs
         return self._dev_sig
 
     def _item(self, segment, add):

@@ -20,7 +20,6 @@ import (
 	"github.com/emer/vision/kwta"
 	"errors"
 	"fmt"
-	"math"
 	"sync"
 	"unsafe"
 )
@@ -511,39 +510,36 @@ func (p *Plan) MelSpecMFCC(sig []float64, items []Item, mel, power, logPower, mf
 	return status(p.ctx, rc)
 }
 
-// Signal is a signal kept resident on the device between calls (aud_signal_upload): SndEnv.ProcessSegment runs once per
-// segment on the SAME Signal tensor (sound/sndenv.go:342-359), so the host-buffer calls above move the whole tensor over
-// the link again for every segment.  A snapshot: upload again after changing the samples (SndEnv does, keyed on SignalKey).
+// Signal is a signal kept resident on the device between calls: SndEnv.ProcessSegment runs once per segment on the SAME Signal
+// tensor (sound/sndenv.go:342-359), so the host-buffer calls above move the whole tensor over the link again for every
+// segment.  Two forms: UploadSignal is a SNAPSHOT (the caller keeps it current); SyncSignal is EXACT -- the library keeps a
+// host shadow of what the device holds and compares the caller's slice with it byte for byte on every call.
 type Signal struct {
 	h   *C.aud_signal
 	ctx *Ctx
 }
 
-// SignalKey is what a resident copy of a []float64 is valid for: the slice's memory, its length, and a fingerprint of up
-// to 64 samples spread over it (an in-place edit that touches none of them needs SndEnv.SignalChanged).
-type SignalKey struct {
-	Data  unsafe.Pointer
-	N     int
-	Probe uint64
-}
+// ResidentAutoBytes is the size up to which SndEnv validates its resident Signal exactly on every call (SyncSignal); a
+// larger Signal is copied per call unless the caller opts in to a snapshot.
+const ResidentAutoBytes = C.AUD_RESIDENT_AUTO_BYTES
 
-// KeyOf computes the SignalKey of sig (FNV-1a over the probed samples' bits; a few dozen loads whatever the length).
-func KeyOf(sig []float64) SignalKey {
-	k := SignalKey{N: len(sig), Probe: 1469598103934665603}
-	if len(sig) == 0 {
-		return k
+// SyncSignal makes the device copy s (nil: created) EQUAL to sig: aud_signal_sync compares sig with the shadow in 4 KB blocks
+// and uploads the span from the first to the last differing block -- nothing when they are equal, everything the first time or
+// when the length changed.  Returns the signal and the bytes that crossed the link.  The reference reads the live tensor at
+// every step (sound/sndenv.go:455-478); this is what lets a resident copy do the same.
+func (c *Ctx) SyncSignal(s *Signal, sig []float64) (*Signal, int64, error) {
+	if s == nil {
+		s = &Signal{ctx: c}
 	}
-	k.Data = unsafe.Pointer(&sig[0])
-	step := len(sig) / 61
-	if step == 0 {
-		step = 1
+	var p unsafe.Pointer
+	if len(sig) > 0 {
+		p = unsafe.Pointer(&sig[0])
 	}
-	mix := func(v float64) { k.Probe = (k.Probe ^ math.Float64bits(v)) * 1099511628211 }
-	for i, c := 0, 0; i < len(sig) && c < 63; i, c = i+step, c+1 {
-		mix(sig[i])
+	var up C.int64_t
+	if err := status(c, C.aud_signal_sync(c.h, &s.h, p, C.AUD_F64, C.int64_t(len(sig)), &up)); err != nil {
+		return s, 0, err
 	}
-	mix(sig[len(sig)-1])
-	return k
+	return s, int64(up), nil
 }
 
 // HostFloat64 returns n float64 in pinned, device-visible host memory (aud_host_alloc) as a Go slice over C memory.  Result

@@ -12,6 +12,7 @@ import (
 	"errors"
 	"fmt"
 	"log"
+	"runtime"
 
 	"github.com/emer/auditory/go/agabor"
 	"github.com/emer/auditory/go/auditoryhip"
@@ -87,18 +88,50 @@ type SndEnv struct {
 	plan    *auditoryhip.Plan       // device plan of planKey's parameters (segmentPlan rebuilds it when they change)
 	planKey planKey
 	derived auditoryhip.SoundParams // what Init derived (sample counts, steps)
-	// ProcessSegment runs once per segment on the SAME Signal (sndenv.go:342-359): the device keeps a copy of it between
-	// calls, re-taken when Signal.Values is other memory, has another length or differs in a sampled fingerprint
-	// (auditoryhip.KeyOf); SignalChanged() after an in-place edit that may miss the probed samples.
-	// HostSignalPerCall = true: copy the tensor on every call instead (the zero value keeps it resident).
+	// ProcessSegment runs once per segment on the SAME Signal, and the reference reads the LIVE tensor at every step
+	// (sndenv.go:455-478): the device keeps a copy between calls that is validated EXACTLY on every call.
+	//   zero values (default): a Signal of up to auditoryhip.ResidentAutoBytes is compared byte for byte with the host shadow
+	//       of the device copy (aud_signal_sync) -- any in-place edit is seen, only the differing span is uploaded; a larger
+	//       Signal is copied per call.
+	//   ResidentSnapshot = true, or an explicit SignalToDevice(): the caller opts in to a SNAPSHOT it keeps current itself --
+	//       re-taken when Signal.Values is other memory or another length, SignalChanged() after an in-place edit.
+	//   HostSignalPerCall = true: copy per call, no resident copy at all.
 	HostSignalPerCall bool
+	ResidentSnapshot  bool
+	LastUploadedBytes int64 // what the last ProcessSegment moved of the Signal (diagnostic)
 	devSig            *auditoryhip.Signal
-	devSigKey         auditoryhip.SignalKey
-	// the segment tensors ProcessSegment fills (PowerSegment, LogPowerSegment, MelFBankSegment, Energy, the MFCC tensors) keep
-	// their Values in pinned host memory (auditoryhip.HostFloat64): the device writes them directly.  GoHeapTensors = true
-	// leaves them on the Go heap (results then come through the library's staging buffer and a widening pass).
-	GoHeapTensors bool
-	pinned        [][]float64
+	snapshot          bool // devSig is an opted-in snapshot of (snapData, snapN)
+	snapData          *float64
+	snapN             int
+	// PinnedTensors = true (opt-in): the segment tensors ProcessSegment fills (PowerSegment, LogPowerSegment, MelFBankSegment,
+	// Energy, the MFCC tensors) keep their Values in pinned host memory (auditoryhip.HostFloat64) and the device writes them
+	// directly: 0.20 instead of 0.29 ms per 256 utterances.  LIFETIME: such Values are C memory -- the next Init, Close, or the
+	// SndEnv's finalizer frees them, so a caller must not keep a slice of tensor.Values beyond that (copy it).  The zero value
+	// leaves every tensor on the Go heap, as the reference's are: results then come through the library's staging buffer.
+	PinnedTensors bool
+	pinned        []pinnedTensor
+	guard         *pinGuard
+}
+
+// pinnedTensor: a segment tensor whose Values currently live in C memory
+type pinnedTensor struct {
+	t *etensor.Float64
+	s []float64
+}
+
+// pinGuard owns the pinned blocks of one SndEnv.  It is a heap object of its own, so that it can carry a finalizer wherever
+// the SndEnv itself lives (embedded by value in a sim's struct, a global, the stack: runtime.SetFinalizer on such a SndEnv
+// would panic): when the last SndEnv (copy) that points to it is garbage-collected without Close, the blocks are freed.
+type pinGuard struct {
+	ctx    *auditoryhip.Ctx
+	blocks [][]float64
+}
+
+func (g *pinGuard) free() {
+	for _, b := range g.blocks {
+		g.ctx.HostFree(b)
+	}
+	g.blocks = nil
 }
 
 // ParamDefaults: sound/sndenv.go:64-71.
@@ -240,63 +273,83 @@ func (se *SndEnv) segmentPlan() (*auditoryhip.Plan, error) {
 	return p, nil
 }
 
-// pinSegmentTensors moves the Values of every tensor ProcessSegment fills into pinned host memory (all of them or none: the
-// library writes them from the device only when every output of the call lies there).  The tensors keep their shapes, strides
-// and names; etensor reads and writes Values through the slice, wherever it lives.
+// unpinSegmentTensors gives every tensor that was pinned a Go-heap slice of the same length again (the shape stays valid, the
+// values are kept) and frees the C memory.  Tensors that were never pinned are not touched.
 func (se *SndEnv) unpinSegmentTensors() {
-	if len(se.pinned) == 0 {
-		return
-	}
-	for _, t := range []*etensor.Float64{&se.PowerSegment, &se.LogPowerSegment, &se.MelFBankSegment, &se.Energy,
-		&se.MFCCSegment, &se.MFCCDeltas, &se.MFCCDeltaDeltas} {
-		t.Values = nil
-	}
-	for _, s := range se.pinned {
-		se.ctx.HostFree(s)
+	for _, p := range se.pinned {
+		if len(p.t.Values) == len(p.s) && len(p.s) > 0 && &p.t.Values[0] == &p.s[0] { // still the pinned slice
+			heap := make([]float64, len(p.s))
+			copy(heap, p.s)
+			p.t.Values = heap
+		}
 	}
 	se.pinned = nil
+	if se.guard != nil {
+		se.guard.free()
+	}
 }
 
+// pinSegmentTensors (PinnedTensors only) moves the Values of every tensor ProcessSegment fills into pinned host memory -- all of
+// them or none: the library writes them from the device only when every output of the call lies there.  The tensors keep their
+// shapes, strides and names; etensor reads and writes Values through the slice, wherever it lives.
 func (se *SndEnv) pinSegmentTensors() {
 	se.unpinSegmentTensors()
-	if se.GoHeapTensors {
+	if !se.PinnedTensors {
 		return
 	}
 	tensors := []*etensor.Float64{&se.PowerSegment, &se.LogPowerSegment, &se.MelFBankSegment, &se.Energy}
 	if se.Mel.MFCC {
 		tensors = append(tensors, &se.MFCCSegment, &se.MFCCDeltas, &se.MFCCDeltaDeltas)
 	}
-	var got [][]float64
+	var got []pinnedTensor
 	for _, t := range tensors {
 		s, err := se.ctx.HostFloat64(len(t.Values))
 		if err != nil || (len(t.Values) > 0 && s == nil) {
 			for _, g := range got {
-				se.ctx.HostFree(g)
+				se.ctx.HostFree(g.s)
 			}
 			return // (the Go-heap tensors of SetShape stay: the staging route)
 		}
-		got = append(got, s)
+		got = append(got, pinnedTensor{t, s})
 	}
-	for i, t := range tensors {
-		for j := range got[i] {
-			got[i][j] = 0
+	if se.guard == nil { // a SndEnv that is garbage-collected without Close must not leak its pinned blocks
+		se.guard = &pinGuard{ctx: se.ctx}
+		runtime.SetFinalizer(se.guard, (*pinGuard).free)
+	}
+	for _, g := range got {
+		for j := range g.s {
+			g.s[j] = 0
 		}
-		t.Values = got[i]
+		g.t.Values = g.s
+		se.guard.blocks = append(se.guard.blocks, g.s)
 	}
 	se.pinned = got
 }
 
-func (se *SndEnv) dropResident() {
-	se.devSig.Close()
-	se.devSig, se.devSigKey = nil, auditoryhip.SignalKey{}
+// Close (new) releases what the SndEnv holds outside the Go heap: the device plan, the resident Signal and -- with
+// PinnedTensors -- the pinned blocks (the tensors get Go-heap copies of their values back, so they stay readable).  A SndEnv
+// without PinnedTensors may simply be dropped; Init after Close works.
+func (se *SndEnv) Close() {
+	se.unpinSegmentTensors()
+	se.dropResident()
+	if se.plan != nil {
+		se.plan.Close()
+		se.plan = nil
+	}
 }
 
-// SignalChanged (new): call after changing samples of se.Signal.Values IN PLACE -- the next ProcessSegment uploads the
-// tensor again.  (ToTensor, AdjustForSilence, Init, another slice or another length are noticed without it.)
-func (se *SndEnv) SignalChanged() { se.devSigKey = auditoryhip.SignalKey{} }
+func (se *SndEnv) dropResident() {
+	se.devSig.Close()
+	se.devSig, se.snapshot, se.snapData, se.snapN = nil, false, nil, 0
+}
 
-// SignalToDevice (new): (re)take the device's copy of se.Signal NOW, so that ProcessSegment / ProcessSegments send only the
-// work items and fetch only the results.  The first ProcessSegment after Init does this by itself unless HostSignalPerCall.
+// SignalChanged (new): after changing samples of se.Signal.Values IN PLACE while a snapshot is resident (ResidentSnapshot or
+// SignalToDevice) -- the next ProcessSegment takes the snapshot again.  Not needed in the default mode, which compares the
+// whole tensor on every call.
+func (se *SndEnv) SignalChanged() { se.snapData = nil }
+
+// SignalToDevice (new): opt in to a resident SNAPSHOT of se.Signal, taken NOW, whatever its size; ProcessSegment /
+// ProcessSegments then send only the work items and fetch only the results.  The opt-in lasts until Init.
 func (se *SndEnv) SignalToDevice() (err error) {
 	if se.ctx == nil {
 		if se.ctx, err = auditoryhip.Default(); err != nil {
@@ -305,23 +358,47 @@ func (se *SndEnv) SignalToDevice() (err error) {
 	}
 	se.dropResident()
 	if se.devSig, err = se.ctx.UploadSignal(se.Signal.Values); err == nil {
-		se.devSigKey = auditoryhip.KeyOf(se.Signal.Values)
+		se.snapshot, se.snapN = true, len(se.Signal.Values)
+		if se.snapN > 0 {
+			se.snapData = &se.Signal.Values[0]
+		}
+		se.LastUploadedBytes = int64(8 * se.snapN)
 	}
 	return err
 }
 
-// resident: the device copy ProcessSegment may read, taken or re-taken as needed (nil: copy per call)
+// resident: the device copy this call may read, holding exactly what se.Signal.Values holds (nil: copy per call)
 func (se *SndEnv) resident() *auditoryhip.Signal {
-	if se.HostSignalPerCall || len(se.Signal.Values) == 0 {
+	se.LastUploadedBytes = 0
+	n := len(se.Signal.Values)
+	if se.HostSignalPerCall || n == 0 {
 		return nil
 	}
-	if se.devSig == nil || se.devSigKey != auditoryhip.KeyOf(se.Signal.Values) {
-		if err := se.SignalToDevice(); err != nil {
-			fmt.Println(err)
-			return nil
+	if se.ResidentSnapshot || se.snapshot { // the opt-in: validated by identity only
+		if se.devSig == nil || se.snapData != &se.Signal.Values[0] || se.snapN != n {
+			if err := se.SignalToDevice(); err != nil {
+				fmt.Println(err)
+				return nil
+			}
 		}
+		return se.devSig
 	}
-	return se.devSig
+	if 8*n > auditoryhip.ResidentAutoBytes {
+		se.dropResident()
+		return nil
+	}
+	if se.ctx == nil {
+		return nil
+	}
+	sig, up, err := se.ctx.SyncSignal(se.devSig, se.Signal.Values) // exact: memcmp against the shadow, upload what differs
+	if err != nil {
+		fmt.Println(err)
+		sig.Close()
+		se.devSig = nil
+		return nil
+	}
+	se.devSig, se.LastUploadedBytes = sig, up
+	return sig
 }
 
 func (se *SndEnv) item(segment, add int) auditoryhip.Item {

@@ -68,9 +68,11 @@ func TestPrevSmoothSetAfterInitReachesProcessSegment(t *testing.T) {
 	}
 }
 
-// The device keeps se.Signal between ProcessSegment calls by default and must never serve a stale copy: a replaced slice of
-// the same length, an in-place overwrite (the sampled fingerprint sees it), a one-sample edit announced by SignalChanged,
-// AdjustForSilence -- each compared with the copy-per-call route (HostSignalPerCall) on the same samples.
+// The device keeps se.Signal between ProcessSegment calls by default and must never serve a stale copy.  The reference reads
+// the live tensor at every step (sound/sndenv.go:455-478), so the resident copy is validated EXACTLY on every call
+// (aud_signal_sync: memcmp against a host shadow): a replaced slice of the same length, an in-place overwrite, a ONE-sample
+// edit that nobody announces, AdjustForSilence -- each compared with the copy-per-call route (HostSignalPerCall) on the same
+// samples.  Then the opt-in snapshot (SignalToDevice) and its SignalChanged contract.
 func TestResidentSignalNeverStale(t *testing.T) {
 	sr := 16000
 	mk := func(f float64) []float64 {
@@ -94,25 +96,107 @@ func TestResidentSignalNeverStale(t *testing.T) {
 		se.ProcessSegment(1, 0)
 		return append([]float64(nil), se.MelFBankSegment.Values...)
 	}
-	check := func(what string) {
+	check := func(what string) []float64 {
 		res, host := mel(false), mel(true)
 		for i := range res {
 			if res[i] != host[i] {
 				t.Fatalf("%s: resident %g, copy per call %g at %d", what, res[i], host[i], i)
 			}
 		}
+		return res
 	}
 	check("first call")
 	if se.devSig == nil {
 		t.Fatal("the first ProcessSegment did not keep the Signal on the device")
 	}
+	mel(false)
+	if se.LastUploadedBytes != 0 {
+		t.Fatalf("an unchanged Signal moved %d bytes", se.LastUploadedBytes)
+	}
 	se.Signal.Values = mk(880) // another slice of the same length
 	check("replaced slice")
 	copy(se.Signal.Values, mk(1320)) // in place, every sample
-	check("in-place overwrite")
-	se.Signal.Values[1] += 0.25 // in place, one sample the fingerprint does not probe
-	se.SignalChanged()
-	check("one-sample edit + SignalChanged")
+	before := check("in-place overwrite")
+	se.Signal.Values[1601] += 0.25 // in place, ONE sample inside segment 1, NOT announced
+	after := check("one-sample edit without SignalChanged")
+	same := true
+	for i := range after {
+		same = same && after[i] == before[i]
+	}
+	if same {
+		t.Fatal("the one-sample edit did not reach the device")
+	}
+	mel(false)
+	se.Signal.Values[3000] -= 0.125
+	mel(false)
+	if se.LastUploadedBytes != 4096 {
+		t.Fatalf("a one-sample edit moved %d bytes, not its 4 KB compare block", se.LastUploadedBytes)
+	}
 	se.AdjustForSilence(30, 10) // prepends 20 ms
 	check("AdjustForSilence")
+
+	// the opt-in snapshot: identity-keyed; an unannounced in-place edit is the caller's business, SignalChanged() retakes it
+	if err := se.SignalToDevice(); err != nil {
+		t.Fatal(err)
+	}
+	clean := mel(false)
+	se.Signal.Values[2000] += 0.25
+	stale := mel(false)
+	for i := range stale {
+		if stale[i] != clean[i] {
+			t.Fatal("a snapshot changed without SignalChanged()")
+		}
+	}
+	se.SignalChanged()
+	check("snapshot + SignalChanged")
+	se.Close()
+}
+
+// PinnedTensors is an opt-in: by default every segment tensor lives on the Go heap, like the reference's.  With it, Init points
+// their Values at pinned C memory; the next Init or Close gives the tensors Go-heap copies back (never nil Values under a
+// non-empty shape) and frees the blocks.
+func TestPinnedTensorsOptInAndLifetime(t *testing.T) {
+	sr := 16000
+	se := &SndEnv{}
+	se.Defaults()
+	se.Signal.SetShape([]int{sr / 2}, nil, nil)
+	for i := range se.Signal.Values {
+		se.Signal.Values[i] = 0.3 * math.Sin(2*math.Pi*440*float64(i)/float64(sr))
+	}
+	se.Sound.Buf = &audio.IntBuffer{Format: &audio.Format{NumChannels: 1, SampleRate: sr}, Data: make([]int, sr/2), SourceBitDepth: 16}
+	if err := se.Init(); err != nil {
+		t.Fatal(err)
+	}
+	if len(se.pinned) != 0 {
+		t.Fatal("tensors were pinned without PinnedTensors")
+	}
+	se.ProcessSegment(1, 0)
+	heap := append([]float64(nil), se.MelFBankSegment.Values...)
+	se.PinnedTensors = true
+	if err := se.Init(); err != nil {
+		t.Fatal(err)
+	}
+	if len(se.pinned) != 7 {
+		t.Fatalf("%d tensors pinned, want 7", len(se.pinned))
+	}
+	se.ProcessSegment(1, 0)
+	for i := range heap {
+		if heap[i] != se.MelFBankSegment.Values[i] {
+			t.Fatalf("pinned route differs at %d", i)
+		}
+	}
+	se.Mel.MFCC = false // the MFCC tensors are not SetShape'd again by this Init: they must keep valid Go-heap Values
+	if err := se.Init(); err != nil {
+		t.Fatal(err)
+	}
+	if len(se.MFCCSegment.Values) != se.MFCCSegment.Len() {
+		t.Fatal("MFCCSegment lost its Values")
+	}
+	se.Close()
+	if len(se.pinned) != 0 || len(se.MelFBankSegment.Values) != se.MelFBankSegment.Len() {
+		t.Fatal("Close left pinned tensors behind")
+	}
+	for i := range heap {
+		_ = se.MelFBankSegment.Values[i] // Go heap again: readable after Close
+	}
 }

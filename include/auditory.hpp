@@ -275,53 +275,56 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
     int ComputeDtype = AUD_F64;  // the reference's arithmetic; AUD_FAST_F32 is the explicit opt-in
     PlanHandle plan;
     aud_plan_desc plan_desc_{};  // what `plan` was created from (ensure_plan)
-    // ProcessSegment runs once per segment on the SAME Signal (sndenv.go:342-359): the device keeps a copy of it between calls
-    // (aud_signal_upload), re-taken when Signal.Values is other memory, has another length or differs in a fingerprint of <= 64
-    // samples spread over it; SignalChanged() after an in-place edit that may miss those.  ResidentSignal = false: copy per call.
-    bool ResidentSignal = true;
+    // ProcessSegment runs once per segment on the SAME Signal, and the reference reads the LIVE tensor at every step
+    // (sndenv.go:455-478): the device keeps a copy between calls that is validated EXACTLY on every call.
+    //   Residency = Auto (default): a Signal of up to AUD_RESIDENT_AUTO_BYTES is compared byte for byte with the host shadow of
+    //       the device copy (aud_signal_sync) -- any in-place edit is seen, only the differing span is uploaded; a larger one
+    //       is copied per call.
+    //   Residency = Snapshot, or an explicit SignalToDevice(): the caller opts in to a snapshot it keeps current itself --
+    //       re-taken when Signal.Values is other memory or another length, SignalChanged() after an in-place edit.
+    //   Residency = PerCall: copy per call.
+    enum ResidencyMode { Auto = 0, Snapshot = 1, PerCall = 2 };
+    ResidencyMode Residency = Auto;
     aud_signal* dev_sig_ = nullptr;
-    struct SignalKey {
-        const double* data = nullptr;
-        size_t n = 0;
-        uint64_t probe = 0;
-        bool operator==(const SignalKey& o) const { return data == o.data && n == o.n && probe == o.probe; }
-    } dev_sig_key_;
+    bool snapshot_ = false;        // dev_sig_ is an opted-in snapshot of (snap_data_, snap_n_)
+    const double* snap_data_ = nullptr;
+    size_t snap_n_ = 0;
+    int64_t last_uploaded_bytes = 0;  // what the last ProcessSegment moved of the Signal (diagnostic)
     ~SndEnv() { drop_resident(); }
     void drop_resident() {
         if (dev_sig_) aud_signal_destroy(dev_sig_);
         dev_sig_ = nullptr;
-        dev_sig_key_ = SignalKey();
+        snapshot_ = false;
+        snap_data_ = nullptr;
+        snap_n_ = 0;
     }
-    SignalKey signal_key() const {
-        SignalKey k;
-        k.data = Signal.Values.data();
-        k.n = Signal.Values.size();
-        const size_t step = k.n / 61 ? k.n / 61 : 1;
-        uint64_t h = 1469598103934665603ull;  // FNV-1a over the probed samples' bits
-        auto mix = [&h](double v) {
-            uint64_t b;
-            std::memcpy(&b, &v, 8);
-            h = (h ^ b) * 1099511628211ull;
-        };
-        for (size_t i = 0, c = 0; i < k.n && c < 63; i += step, ++c) mix(Signal.Values[i]);
-        if (k.n) mix(Signal.Values[k.n - 1]);
-        k.probe = h;
-        return k;
-    }
-    // New: call after changing samples of Signal.Values IN PLACE (the next ProcessSegment uploads the tensor again)
-    void SignalChanged() { dev_sig_key_ = SignalKey(); }
-    // New: (re)take the device's copy of Signal NOW; with ResidentSignal (the default) the first ProcessSegment does it itself
+    // New: after changing samples of Signal.Values IN PLACE while a snapshot is resident (not needed in the default mode)
+    void SignalChanged() { snap_data_ = nullptr; }
+    // New: opt in to a resident SNAPSHOT of Signal, taken NOW (aud_signal_upload), whatever its size
     bool SignalToDevice() {
         if (ensure_ctx() != AUD_OK) return false;
         drop_resident();
         if (aud_signal_upload(default_ctx(), Signal.Values.data(), AUD_F64, int64_t(Signal.Values.size()), &dev_sig_) != AUD_OK) return false;
-        dev_sig_key_ = signal_key();
+        snapshot_ = true;
+        snap_data_ = Signal.Values.data();
+        snap_n_ = Signal.Values.size();
+        last_uploaded_bytes = int64_t(snap_n_ * 8);
         return true;
     }
-    bool resident() {
-        if (!ResidentSignal || Signal.Values.empty()) return false;
-        if (!dev_sig_ || !(dev_sig_key_ == signal_key())) return SignalToDevice();
-        return true;
+    bool resident() {  // true: dev_sig_ holds exactly what this call must read
+        last_uploaded_bytes = 0;
+        if (Residency == PerCall || Signal.Values.empty()) return false;
+        if (Residency == Snapshot || snapshot_) {
+            if (!dev_sig_ || snap_data_ != Signal.Values.data() || snap_n_ != Signal.Values.size()) return SignalToDevice();
+            return true;
+        }
+        if (Signal.Values.size() * sizeof(double) > size_t(AUD_RESIDENT_AUTO_BYTES)) {
+            drop_resident();
+            return false;
+        }
+        if (ensure_ctx() != AUD_OK) return false;
+        return aud_signal_sync(default_ctx(), &dev_sig_, Signal.Values.data(), AUD_F64, int64_t(Signal.Values.size()),
+                               &last_uploaded_bytes) == AUD_OK;
     }
 
     void ParamDefaults() {  // sndenv.go:64-71

@@ -343,6 +343,20 @@ typedef struct aud_signal aud_signal;
 int aud_signal_upload(aud_ctx* ctx, const void* samples, int sample_dtype, int64_t n_samples, aud_signal** out);
 int aud_signal_destroy(aud_signal* sig);
 int64_t aud_signal_len(const aud_signal* sig);
+/* The EXACT form of residency -- what the host mirrors of SndEnv use by default.  The reference reads the live tensor at every
+ * step (sound/sndenv.go:455-478: SndToWindow slices se.Signal.Values), so a caller may edit samples in place between two
+ * ProcessSegment calls and must get the edited signal's features.  aud_signal_sync makes the device copy equal to `samples`:
+ * the handle keeps a host SHADOW of what the device holds, the caller's tensor is compared with it byte for byte
+ * (memcmp over 4 KB blocks: 20 us for a 3 s sound), and the span from the first to the last differing block -- nothing when
+ * they are equal, everything on the first call or when type or length changed -- is uploaded and copied into the shadow.
+ *   *sig: NULL on the first call (the handle is created), the handle afterwards; uploaded_bytes (may be NULL): what crossed
+ *   the link.  No probability involved: any edit, anywhere, is seen.
+ * The compare costs host time in proportion to the tensor and the shadow doubles its host memory, so the mirrors use it up
+ * to AUD_RESIDENT_AUTO_BYTES of samples; above that they copy per call unless the caller opts in to a resident copy it
+ * keeps current itself (SndEnv.SignalToDevice / SignalChanged: aud_signal_upload, a snapshot). */
+#define AUD_RESIDENT_AUTO_BYTES (8 << 20)
+int aud_signal_sync(aud_ctx* ctx, aud_signal** sig, const void* samples, int sample_dtype, int64_t n_samples,
+                    int64_t* uploaded_bytes);
 /* aud_melspec_batch_host / aud_melspec_mfcc_batch_host on a resident signal (items index ITS samples) */
 int aud_melspec_batch_sig(aud_plan* plan, const aud_signal* sig, const aud_item* items, int n_items, double* mel,
                           double* power, double* log_power);

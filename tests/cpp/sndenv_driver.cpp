@@ -48,26 +48,44 @@ int main(int argc, char** argv) {
     const int32_t hdr[4] = {se.SegCnt, se.Mel.FBank.NFilters, se.Params_.SegmentSteps, se.Params_.WinSamples / 2 + 1};
     std::fwrite(hdr, 4, 4, o);
     for (int seg = 0; seg < se.SegCnt; ++seg) {
-        // the device keeps the Signal between calls by default; segment 2 takes the copy-per-call route (same results), and
-        // an in-place edit announced by SignalChanged() must reach the device (undone again before the segment is computed)
-        se.ResidentSignal = seg != 2;
+        // the device keeps the Signal between calls by default, validated exactly on every call (aud_signal_sync); segment 2
+        // takes the copy-per-call route (same results).  Segment 3: ONE sample edited in place and NOT announced must reach the
+        // device (the reference reads the live tensor, sndenv.go:455-478) -- and only its 4 KB compare block crosses the link.
+        // Segment 4: the opted-in snapshot (SignalToDevice) serves what it holds until SignalChanged().
+        se.Residency = seg == 2 ? sound::SndEnv::PerCall : sound::SndEnv::Auto;
         if (seg == 1 && !se.dev_sig_) return 7;
-        if (seg == 3) {
-            const size_t at = size_t(3 * se.Params_.StrideSamples + 101);  // (inside segment 3, not a probed sample)
+        auto total = [&se] {
+            double t = 0.0;
+            for (double v : se.MelFBankSegment.Values) t += v;
+            return t;
+        };
+        if (seg == 3 || seg == 4) {
+            const size_t at = size_t(seg * se.Params_.StrideSamples + 101);  // (inside the segment)
             const double keep = se.Signal.Values[at];
-            se.Signal.Values[at] = keep + 0.5;
-            se.SignalChanged();
+            if (seg == 4 && !se.SignalToDevice()) return 12;
             se.ProcessSegment(seg, 0);
-            auto total = [&se] {
-                double t = 0.0;
-                for (double v : se.MelFBankSegment.Values) t += v;
-                return t;
-            };
-            const double moved = total();
+            if (se.last_uploaded_bytes != 0) return 13;  // the copy was current: nothing moved
+            const double clean = total();
+            se.Signal.Values[at] = keep + 0.5;  // no SignalChanged()
+            se.ProcessSegment(seg, 0);
+            if (seg == 3) {
+                if (total() == clean) return 11;  // the edit never reached the device
+                if (se.last_uploaded_bytes != 4096) return 14;
+            } else {
+                if (total() != clean) return 15;  // a snapshot is a snapshot ...
+                se.SignalChanged();
+                se.ProcessSegment(seg, 0);
+                if (total() == clean) return 16;  // ... until the caller says so
+            }
             se.Signal.Values[at] = keep;
-            se.SignalChanged();
-            se.ProcessSegment(seg, 0);
-            if (moved == total()) return 11;  // the edit never reached the device
+            if (seg == 4) {
+                se.SignalChanged();
+                se.ProcessSegment(seg, 0);
+                se.drop_resident();  // end of the opt-in: the default mode again
+            } else {
+                se.ProcessSegment(seg, 0);
+            }
+            if (total() != clean) return 17;
         }
         se.ProcessSegment(seg, 0);
         Float32* g = se.ApplyGabor();

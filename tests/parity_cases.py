@@ -888,8 +888,11 @@ def case_sndenv_mirror_reads_like_the_reference(orc):
 
 def case_sndenv_resident_signal_staleness(orc):
     """The device keeps SndEnv.Signal between ProcessSegment calls BY DEFAULT (the reference's loop runs once per segment on the
-    same tensor, sndenv.go:342-359) -- and must never serve a stale copy: another array of the same length, AdjustForSilence,
-    an in-place edit announced by SignalChanged(), an in-place edit that the sampled fingerprint sees, Init."""
+    same tensor, sndenv.go:342-359) and the reference reads the LIVE tensor at every step (:455-478), so the copy is validated
+    EXACTLY on every call (aud_signal_sync: memcmp against a host shadow): an edit of ONE sample anywhere, with no
+    SignalChanged(), must give the edited signal's features.  Also: another array of the same length, an in-place overwrite,
+    AdjustForSilence, Init; a Signal above AUD_RESIDENT_AUTO_BYTES is copied per call unless the caller opts in to a
+    snapshot (ResidentSignal = True / SignalToDevice()), which SignalChanged() keeps current."""
     from auditory_amd import sound
     oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
     sig, _ = synth.batch(21, 3, 8000, 16000)
@@ -901,38 +904,84 @@ def case_sndenv_resident_signal_staleness(orc):
     def ref_of(x, seg=1):
         return orc.process_segment(oc.sp, oc.d, oc.m, oc.bins, oc.filt, np.ascontiguousarray(x, np.float64), segment=seg)["mel_seg"]
 
-    def check(se, x, what):
-        ok, msg = W.feature_close(mel_of(se), ref_of(x), capi.AUD_F64, lin_axis=0)
+    def check(se, x, what, seg=1):
+        got, ref = mel_of(se, seg), ref_of(x, seg)
+        ok, msg = W.feature_close(got, ref, capi.AUD_F64, lin_axis=0)
         assert ok, what + ": " + msg
+        return got
 
     se = sound.SndEnv()
     se.Defaults()
     se.Mel.MFCC = False
     se.SampleRate, se.Signal = 16000, sig[0].copy()
+    assert se.ResidentSignal is None                    # the default: exact residency
     assert se.Init() is None and se._dev_sig is None
     check(se, sig[0], "first call")
     first = se._dev_sig
-    assert first is not None                            # taken by the first call, without opting in
+    assert first is not None and first.uploaded_bytes == 8000 * 8   # taken by the first call, without opting in
     check(se, sig[0], "second call")
-    assert se._dev_sig is first                         # ... and kept
+    assert se._dev_sig is first and first.uploaded_bytes == 0       # ... kept, and nothing crossed the link
     se.Signal = sig[1].copy()                           # another tensor of the SAME length
     check(se, sig[1], "replaced tensor")
-    assert se._dev_sig is not first
-    se.Signal[:] = sig[2]                               # in place: every sample changes, the fingerprint sees it
+    assert first.uploaded_bytes == 8000 * 8
+    se.Signal[:] = sig[2]                               # in place: every sample changes
     check(se, sig[2], "in-place overwrite")
-    keep = se._dev_sig
-    se.Signal[1] += 0.25                                # in place, ONE sample the fingerprint does not probe ...
-    se.SignalChanged()                                  # ... so the caller says so
-    check(se, se.Signal, "in-place edit + SignalChanged")
-    assert se._dev_sig is not keep
+    # ---- the case the sampled fingerprint of round 5 missed: ONE sample, in place, NOT announced.  Segment 1 of this
+    # parameter set covers samples 1280 .. 3759: edit one inside it, one in its first frame's left neighbourhood, the last
+    # sample of a 4 KB compare block and the first of the next
+    before = check(se, se.Signal, "before the edits")
+    for pos, delta in ((1601, 0.25), (3000, -0.125), (511, 0.5), (512, 0.5), (7999, 0.25)):
+        se.Signal[pos] += delta
+        got = check(se, se.Signal, "one-sample edit at %d without SignalChanged()" % pos)
+        assert first.uploaded_bytes in (4096, 8000 * 8 % 4096), (pos, first.uploaded_bytes)   # one compare block went up
+        if 1280 <= pos < 3760:
+            assert not np.array_equal(got, before), "the edit at %d did not reach the device" % pos
+            before = got
+    z = se.Signal[4000]
+    se.Signal[4000] = 0.0
+    check(se, se.Signal, "zeroed sample")
+    se.Signal[4000] = -0.0                              # equal as a value, different bytes: re-uploaded all the same
+    check(se, se.Signal, "minus zero")
+    assert first.uploaded_bytes == 4096
+    se.Signal[4000] = z
     off = se.AdjustForSilence(30.0, 10.0)               # prepends 20 ms of zeros: another tensor, another length
     assert off == 20 and len(se.Signal) == 8000 + 320
     check(se, se.Signal, "AdjustForSilence")
+    assert first.uploaded_bytes == 8320 * 8
     assert se.Init() is None and se._dev_sig is None    # Init drops the copy (SegCnt etc. are re-derived)
     check(se, se.Signal, "after Init")
+    # ---- the opt-in snapshot: identity-keyed, SignalChanged() for in-place edits
+    se.SignalToDevice()
+    snap = se._dev_sig
+    assert se._snapshot and snap.uploaded_bytes == 8320 * 8
+    check(se, se.Signal, "snapshot")
+    assert se._dev_sig is snap
+    old = se.Signal.copy()
+    se.Signal[2000] += 0.25                             # NOT announced: the snapshot is what the caller asked for
+    check(se, old, "snapshot, unannounced edit (the caller's contract)")
+    se.SignalChanged()
+    check(se, se.Signal, "snapshot + SignalChanged")
+    assert se._dev_sig is not snap and se._snapshot
+    se.Signal = se.Signal.copy()                        # another array: re-taken by identity
+    snap = se._dev_sig
+    check(se, se.Signal, "snapshot, replaced tensor")
+    assert se._dev_sig is not snap
+    assert se.Init() is None and not se._snapshot       # Init ends the opt-in
+    # ---- above AUD_RESIDENT_AUTO_BYTES the default is a copy per call; ResidentSignal = True opts in
+    big = np.zeros(capi.AUD_RESIDENT_AUTO_BYTES // 8 + 16)
+    big[:8320] = se.Signal
+    se.Signal = big
+    assert se.Init() is None
+    check(se, big, "large signal: copy per call")
+    assert se._dev_sig is None
+    big[1700] += 0.25
+    check(se, big, "large signal, edited in place")
+    se.ResidentSignal = True
+    check(se, big, "large signal, opted in")
+    assert se._dev_sig is not None and se._snapshot
     se.ResidentSignal = False
+    check(se, big, "copy per call")
     se._drop_resident()
-    check(se, se.Signal, "copy per call")
     assert se._dev_sig is None
 
 

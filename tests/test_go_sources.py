@@ -146,7 +146,7 @@ def test_calls_into_the_binding_package():
     code = _code(bind)
     funcs = GL.go_funcs(code)
     declared = {n for (_, n) in funcs if True} | {n for k, _, n, _ in GL.declarations(code) if k == "type"}
-    declared |= set(re.findall(r"^var\s+(\w+)", code, flags=re.M)) | set(re.findall(r"^\t(\w+)\s+(?:\*|error|sync)", code, flags=re.M))
+    declared |= set(re.findall(r"^(?:var|const)\s+(\w+)", code, flags=re.M)) | set(re.findall(r"^\t(\w+)\s+(?:\*|error|sync)", code, flags=re.M))
     plain = {n: t for (r, n), t in funcs.items() if not r}
     others = collections.Counter()
     for path in FILES:

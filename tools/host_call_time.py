@@ -9,7 +9,14 @@ DESIGN.md 6 and BASELINE.md quote; never bench.py's `value`):
   *_pinned  ... into a result tensor from aud_host_alloc: the device widens and writes it (no staging copy, no CPU pass)
   *_shared  ... into a mapping of POSIX shared memory registered with aud_host_register (what several processes, one per GPU,
             would write their shards of one host tensor into): the device writes it like the pinned one
-  upload_*  the one-time uploads themselves"""
+  upload_*  the one-time uploads themselves
+and, round 6, what the DEFAULT of the SndEnv mirrors costs per sound -- the resident copy validated exactly on every call
+(aud_signal_sync: memcmp against a host shadow) -- one ProcessSegment call on one 3 s sound (SndEnv defaults: 100 ms segments):
+  sound_snapshot   the _sig call alone on a snapshot (round 5's default minus its 64-sample fingerprint)
+  sound_sync       aud_signal_sync on the unchanged tensor + the same call: the round-6 default
+  sound_sync_edit  ... with one sample edited before every call (one 4 KB block goes up)
+  sound_per_call   the tensor copied in on every call
+  sync_8MB         aud_signal_sync alone on an unchanged tensor of AUD_RESIDENT_AUTO_BYTES (the largest the default validates)"""
 import os
 import sys
 import time
@@ -70,3 +77,48 @@ for k in ("host", "sig_f64", "sig_i16", "sig_f64_reuse", "sig_f64_pinned", "sig_
     print("  %-15s %.3f ms per call = %.0f audio-s/s" % (k, res[k] * 1e3, n / res[k]))
 print("  one-time uploads: float64 signal (%.1f MB) %.2f ms, int16 PCM (%.1f MB) %.2f ms"
       % (flat.nbytes / 1e6, res["upload_f64"] * 1e3, pcm.nbytes / 1e6, res["upload_i16"] * 1e3))
+
+
+# ---- per sound: the SndEnv default (one segment per call on a 3 s sound)
+oc1 = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
+plan1 = W.product_plan(oc1, capi.AUD_F64)
+snd = np.ascontiguousarray(synth.batch(5, 1, 48000, 16000)[0][0])
+one = runtime.make_items([0], [len(snd)], [16000])
+snap, live = runtime.Signal(plan1.ctx, snd), runtime.Signal(plan1.ctx)
+live.sync(snd)
+out1 = (np.zeros((1, plan1.nf, plan1.T)), np.zeros((1, plan1.H, plan1.T)), np.zeros((1, plan1.H, plan1.T)))
+r1 = {}
+r1["sound_snapshot"] = timed(lambda: plan1.melspec_sig(snap, one, out=out1), reps=200, warm=20)
+
+
+def synced():
+    live.sync(snd)
+    plan1.melspec_sig(live, one, out=out1)
+
+
+r1["sound_sync"] = timed(synced, reps=200, warm=20)
+assert live.uploaded_bytes == 0
+k = [0]
+
+
+def edited():
+    k[0] += 1
+    snd[17000 + k[0]] += 1e-3
+    synced()
+
+
+r1["sound_sync_edit"] = timed(edited, reps=200, warm=20)
+assert live.uploaded_bytes in (4096, 8192)
+ref1 = plan1.melspec_host(snd, one, True, True)
+plan1.melspec_sig(live, one, out=out1)
+assert all(np.array_equal(a, b) for a, b in zip(ref1, out1))       # the edited tensor's features, without any announcement
+r1["sound_per_call"] = timed(lambda: plan1.melspec_host(snd, one, True, True), reps=200, warm=20)
+big = np.zeros(capi.AUD_RESIDENT_AUTO_BYTES // 8)
+big[::7] = 0.25
+bsig = runtime.Signal(plan1.ctx)
+bsig.sync(big)
+r1["sync_8MB"] = timed(lambda: bsig.sync(big), reps=50, warm=5)
+print("one 3 s sound (384 KB of float64), one 100 ms segment per call (mel + PowerSegment + LogPowerSegment out):")
+for k_ in ("sound_snapshot", "sound_sync", "sound_sync_edit", "sound_per_call", "sync_8MB"):
+    print("  %-16s %.1f us per call" % (k_, r1[k_] * 1e6))
+print("  exact residency costs %+.1f %% of the per-sound call" % (100.0 * (r1["sound_sync"] / r1["sound_snapshot"] - 1.0)))
