@@ -26,15 +26,26 @@ FIXTURES = {
     "cfg2_16k_n512_nf40": ("cfg2_16k_n512_nf40", None, 1.0, 2, [0], 23, "pool11x32"),
     "cfg1_44k_n1103_nf32": ("cfg1_44k_n1103_nf32", None, 0.3, 1, [0, 1], 24, "pool8x2"),
     "cfg5_44k_n2048_nf128": ("cfg5_44k_n2048_nf128", 300.0, 0.4, 2, [0], 25, None),
+    # SURVEY 8d's cfg-1 input (configs[0]: examples/processspeech on one speech WAV, processspeech.go:190-283): 3 s of
+    # synth.speech_like -- shaped noise / pulse trains under a 4 Hz envelope with exact-zero gaps -- at 16 kHz (N = 400) and at
+    # the shipped WAVs' 44.1 kHz (N = 1103), SndEnv defaults, gabor through the 4-D shape [8,2,2,8] (Q9), with the MFCC tail.
+    # Segments: 0 (left pad + leading gap), 1 (first syllable), 2 (a gap: all-zero frames), 5 (voiced), 12, 29 (the last).
+    "speech_16k_n400_nf32": ("sndenv_16k_n400_nf32", None, 3.0, 1, [0, 1, 2, 5, 12, 29], 31, "pool8x2"),
+    "speech_44k_n1103_nf32": ("cfg1_44k_n1103_nf32", None, 3.0, 1, [0, 1, 2, 5, 12, 29], 32, "pool8x2"),
 }
 GABOR = {"pool8x2": (8, 2), "pool11x32": (11, 32)}
+SPEECH = ("speech_16k_n400_nf32", "speech_44k_n1103_nf32")   # inputs from synth.speech_like; fixtures carry the MFCC tail
 
 
 def inputs(name):
     cfg, seg_ms, dur, rows, segs, seed, gab = FIXTURES[name]
     oc = W.OracleCfg(orc, cfg, seg_ms)
     L = int(dur * oc.sr)
-    sig, pcm = synth.batch(seed, rows, L, oc.sr)
+    if name in SPEECH:
+        sig, pcm = synth.speech_like(seed, L, oc.sr)
+        sig, pcm = sig[None], pcm[None]
+    else:
+        sig, pcm = synth.batch(seed, rows, L, oc.sr)
     return oc, sig, pcm, [(r, s) for r in range(rows) for s in segs], gab
 
 
@@ -47,6 +58,11 @@ def compute(name):
         lp.append(o["log_power_seg"])
     out = dict(mel=np.stack(mel), log_power=np.stack(lp).astype(np.float32),
                bin_pts=oc.bins, pcm_crc=np.array([int(pcm.astype(np.int64).sum())]))
+    if name in SPEECH:   # the rest of ProcessSegment (sndenv.go:360-432): Energy, MFCC with row 0 <- Energy, deltas, delta-deltas
+        tail = [orc.process_segment_mfcc(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig[r], segment=s) for r, s in items]
+        for k in ("mfcc", "deltas", "delta_deltas", "energy"):
+            out[k] = np.stack([t[k] for t in tail])
+        assert all(np.array_equal(t["mel_seg"], m) for t, m in zip(tail, mel))
     if gab:
         py, px = GABOR[gab]
         k = orc.gabor_to_tensor(W.DEFAULT_GABOR_SPECS, 9, 9)

@@ -50,6 +50,18 @@ def check_library_against_golden(name, compute_dtype):
             plan.gabor_host(mel, out)            # gabor of the library's own mel, as SndEnv does
             ok, msg = W.feature_close(out, gold["gabor"], compute_dtype, tol_f64=W.TOL_F64_GABOR)
             assert ok, (name, "gabor", msg)
+        if "mfcc" in gold.files and compute_dtype == capi.AUD_F64:
+            # the speech fixtures carry the rest of ProcessSegment (sndenv.go:360-432): one call of the MFCC entry point
+            tplan = W.product_plan(oc, compute_dtype, mfcc_coefs=13)
+            try:
+                o = tplan.melspec_mfcc_host(sig.ravel(), its)
+            finally:
+                tplan.close()
+            fused = tplan.kernel_name in ("w20x10", "w16x16")
+            tols = dict(mel=1e-5, energy=1e-5, mfcc=1e-5, deltas=1e-5 if fused else 2e-5, delta_deltas=5e-5 if fused else 2e-4)
+            for key, tol in tols.items():
+                ok, msg = W.close_enough(o[key], gold[key], tol)
+                assert ok, (name, key, msg)
         if gab and compute_dtype == capi.AUD_F32:
             # k-WTA of the STORED gabor tensor: float32 in the reference's order whatever the plan computes in, so
             # exact (checked once, with the float32 plans)

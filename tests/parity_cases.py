@@ -5,6 +5,8 @@ Tolerances (BASELINE.json north_star: 1e-5 relative on the float32 tensors):
   f32 compute : |got - ref| <= 1e-5 * max(1, |ref|)  on broadband inputs
   f64 compute : |got - ref| <= 3e-7 * max(1, |ref|)  (float32 output rounding only)
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -983,6 +985,78 @@ def case_sndenv_resident_signal_staleness(orc):
     check(se, big, "copy per call")
     se._drop_resident()
     assert se._dev_sig is None
+
+
+SPEECH_STRICT = 1e-5   # the north star's criterion: |d| <= 1e-5 max(1, |ref|) on every element
+
+
+def case_speech_like_sndenv(orc, sr, tmp_dir, segments=None, report=None):
+    """BASELINE configs[0] as worded, on SURVEY 8d's cfg-1 input: one TIMIT-style WAV -- 3 s of synth.speech_like (speech-band
+    shaped noise / pulse trains, 4 Hz syllables, exact-zero gaps, > 60 dB of spectral tilt), 16 kHz (N = 400) or the shipped
+    WAVs' 44.1 kHz (N = 1103, prime) -- WRITTEN as a 16-bit WAV and taken through the reference's own sequence:
+    Sound.Load -> ToTensor -> Init -> ProcessSegment x SegCnt -> ApplyGabor, processspeech's parameters and filter set
+    (processspeech.go:190-283), gabor through the 4-D shape [8,2,2,8] (its own 5-D tensor makes Convolve a no-op: Q9),
+    float64 plan.  Every segment against the oracle under the STRICT criterion: mel, log-power, Energy, MFCC and gabor at
+    1e-5; deltas at 1e-5 (2e-5 at N = 1103, whose tail runs on the float32-stored tensors) and delta-deltas, which difference
+    running sums carried over all 13 coefficients, at 5e-5 / 2e-4.  All-zero frames must give mel = LogMin and
+    log-power = ln(LogOffSet) EXACTLY (Q2)."""
+    from auditory_amd import agabor, sound
+    cfg = {16000: "sndenv_16k_n400_nf32", 44100: "cfg1_44k_n1103_nf32"}[sr]
+    oc = W.OracleCfg(orc, cfg)
+    sig, pcm = synth.speech_like({16000: 31, 44100: 32}[sr], 3 * sr, sr)
+    fn = os.path.join(str(tmp_dir), "speech_%d.wav" % sr)
+    w = sound.Wave()
+    w.Data, w.SourceBitDepth, w._rate, w._channels = pcm.astype(np.int64), 16, sr, 1
+    assert w.WriteWave(fn) is None
+    se = sound.SndEnv()
+    se.Defaults()
+    assert se.Sound.Load(fn) is None and se.ToTensor()
+    assert se.SampleRate == sr and se.Channels == 1 and np.array_equal(se.Signal, sig)
+    se.GaborSpecs = [agabor.Filter(WaveLen=2.0, Orientation=o, SigmaWidth=0.5, SigmaLength=0.5, PhaseOffset=ph, CircleEdge=True)
+                     for o in (0, 45, 90, 135) for ph in (0, 1.5708)]
+    gf = se.GaborFilters
+    gf.SizeX = gf.SizeY = 9
+    gf.StrideX = gf.StrideY = 3
+    gf.Gain = 2.0
+    se.GborOutPoolsY, se.GborOutPoolsX, se.GborOutUnitsY, se.GborOutUnitsX = 8, 2, 2, 8
+    se.Kwta.On = False                                   # processspeech has no k-WTA stage
+    assert se.Init() is None
+    assert se.Params.WinSamples == oc.N and se.Params.SegmentSteps == 14 and se.SegCnt == 30
+    assert se._plan.kernel_name == ("w20x10" if sr == 16000 else "generic")
+    fused = sr == 16000
+    tols = dict(mel=SPEECH_STRICT, log_power=SPEECH_STRICT, energy=SPEECH_STRICT, mfcc=SPEECH_STRICT, gabor=SPEECH_STRICT,
+                deltas=1e-5 if fused else 2e-5, delta_deltas=5e-5 if fused else 2e-4)
+    k = orc.gabor_to_tensor(W.DEFAULT_GABOR_SPECS, 9, 9)
+    worst = dict.fromkeys(tols, 0.0)
+    zero_frames = 0
+    for seg in (range(se.SegCnt) if segments is None else segments):
+        se.ProcessSegment(seg, 0)
+        tsr = se.ApplyGabor()
+        assert tsr is se.GborOutput and tsr.shape == (8, 2, 2, 8)
+        o = orc.process_segment_mfcc(oc.sp, oc.d, oc.m, oc.bins, oc.filt, sig, segment=seg)
+        ref_g = np.zeros((8, 2, 2, 8), np.float32)
+        assert orc.gabor_convolve(o["mel_seg"], k, 3, 3, 2.0, ref_g) == 0
+        got = dict(mel=se.MelFBankSegment, log_power=se.LogPowerSegment, energy=se.Energy, mfcc=se.MFCCSegment,
+                   deltas=se.MFCCDeltas, delta_deltas=se.MFCCDeltaDeltas, gabor=tsr)
+        ref = dict(mel=o["mel_seg"], log_power=o["log_power_seg"], energy=o["energy"], mfcc=o["mfcc"], deltas=o["deltas"],
+                   delta_deltas=o["delta_deltas"], gabor=ref_g)
+        for key, tol in tols.items():
+            g, r = np.asarray(got[key], np.float64), np.asarray(ref[key], np.float64)
+            assert g.shape == r.shape, (seg, key, g.shape, r.shape)
+            err = float((np.abs(g - r) / np.maximum(1.0, np.abs(r))).max())
+            worst[key] = max(worst[key], err)
+            assert err <= tol, "segment %d %s: max scaled err %.3g (tol %.1g)" % (seg, key, err, tol)
+        # frames of exact zeros (the gaps; the left pad of segment 0): LogMin and ln(LogOffSet) exactly, not approximately
+        for t in range(14):
+            start = seg * se.Params.StrideSamples + se.Params.Steps[t]
+            if start + oc.N <= len(sig) and not np.any(sig[max(start, 0):start + oc.N]):
+                zero_frames += 1
+                assert np.all(se.MelFBankSegment[:, t] == -10.0), (seg, t)       # mel.go:136-139, LogMin
+                assert np.all(se.LogPowerSegment[:, t] == 0.0), (seg, t)         # dft.go:75-80: ln(0 + 1.0)
+    assert zero_frames > 0 or segments is not None
+    if report is not None:
+        report.update(worst=worst, zero_frames=zero_frames, seg_cnt=se.SegCnt)
+    return worst
 
 
 def case_sndenv_mirror_2d_gabor_kwta_layer(orc):

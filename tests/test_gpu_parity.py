@@ -592,3 +592,17 @@ def test_random_any_n_configs(orc, torch_cuda):
         except pytest.skip.Exception:
             pass
     assert "generic" in seen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sr", [16000, 44100])
+def test_speech_like_sndenv(orc, torch_cuda, tmp_path, sr):
+    """BASELINE configs[0] as worded, on hardware: SURVEY 8d's cfg-1 WAV (3 s of speech-like audio, written by the test)
+    through Sound.Load -> ToTensor -> Init -> ProcessSegment x SegCnt -> ApplyGabor with processspeech's parameters,
+    float64 plan, every one of the 30 segments against the oracle under the strict criterion -- at 16 kHz (w20x10 with the
+    fused tail) and at the shipped WAVs' 44.1 kHz (N = 1103: Bluestein in place)."""
+    rep = {}
+    PC.case_speech_like_sndenv(orc, sr, tmp_path, None, rep)
+    assert rep["seg_cnt"] == 30 and rep["zero_frames"] >= 60
+    print("speech-like %d Hz: worst scaled errors %s; %d all-zero frames exact" % (
+        sr, {k: "%.2g" % v for k, v in rep["worst"].items()}, rep["zero_frames"]))
