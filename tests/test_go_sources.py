@@ -139,6 +139,35 @@ def test_reference_signatures_present():
             assert have[key] == types, "%s: %s takes %s, the reference %s" % (rel, key, have[key], types)
 
 
+def test_refdump_writes_what_the_golden_hook_reads():
+    """go/cmd/refdump (the program that pins the oracle where Go exists) and tests/golden_cases.py (the reader) must agree on
+    every file kind, and refdump may only touch what the REFERENCE's SndEnv exports (sound/sndenv.go:73-182, :185-497; the
+    list below was read off those lines, and is checked against the file itself where /root/reference is present)."""
+    import golden_cases as GC
+    src = open(os.path.join(GL.ROOT, "go", "cmd", "refdump", "main.go")).read()
+    code = GL.blank_go(src)
+    for kind, ext in GC.REF_KINDS:
+        stem, suffix = ext.rsplit(".", 1)
+        assert ('_%s.%s"' % (stem, suffix)) in src or ('"%s"' % stem) in src, "refdump never writes *_%s" % ext
+    assert "_kwta_params.txt" in src and "%+v" in src
+    ref_fields = {"Sound", "Params", "Signal", "Mel", "DFT", "Kwta", "KwtaPool", "GaborFilters", "GaborSpecs", "GborOutPoolsX",
+                  "GborOutPoolsY", "GborOutUnitsX", "GborOutUnitsY", "GborOutput", "GborKwta", "MelFBankSegment",
+                  "LogPowerSegment", "PowerSegment", "Energy", "MFCCSegment", "MFCCDeltas", "MFCCDeltaDeltas", "Inhibs", "ByTime"}
+    ref_methods = {"Defaults", "ToTensor", "Init", "ProcessSegment", "ApplyGabor"}
+    used = set(re.findall(r"\bse\.([A-Z]\w*)", code))
+    assert used <= ref_fields | ref_methods, "refdump uses SndEnv members the reference does not export: %s" % sorted(
+        used - ref_fields - ref_methods)
+    assert {"Energy", "MFCCDeltas", "MFCCDeltaDeltas", "GborKwta", "Kwta", "KwtaPool"} <= used   # f-1 and f-4 are dumped
+    assert "se.Kwta.On = false" in src and "se.KwtaPool = pool" in src                          # both passes exist
+    ref = "/root/reference/sound/sndenv.go"
+    if os.path.exists(ref):
+        text = open(ref).read()
+        for name in used & ref_fields:
+            assert re.search(r"^\t%s\s" % name, text, flags=re.M), "the reference's SndEnv has no field %s" % name
+        for name in used & ref_methods:
+            assert re.search(r"^func \(se \*SndEnv\) %s\(" % name, text, flags=re.M), "the reference's SndEnv has no method %s" % name
+
+
 def test_calls_into_the_binding_package():
     """every auditoryhip.X the drop-in packages name is declared there, function calls pass as many arguments as the
     declaration has parameters, and so do calls of the binding's methods whose names no other package declares"""
