@@ -140,7 +140,7 @@ class OracleSide:
         return (mel, gab) if gabor else mel
 
 
-def cpu_baseline(wl, pcm, target_s=12.0, max_threads=16, chunk=8):
+def cpu_baseline(wl, pcm, target_s=12.0, max_threads=16, chunk=8, all_seconds=5.0):
     """The oracle (C float64 restatement of the reference, FFT plan cached per segment) timed on this box's host cores,
     `chunk` utterances per call, one call per thread at a time (ctypes releases the GIL).
 
@@ -180,7 +180,33 @@ def cpu_baseline(wl, pcm, target_s=12.0, max_threads=16, chunk=8):
     with ThreadPoolExecutor(cores) as ex:
         n = sum(ex.map(worker, range(cores)))
     dt = time.perf_counter() - t0
-    return {"value": round(n * wl.dur_s / dt, 2), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+
+    # SURVEY 8d's "all host cores" flavour: one thread per CPU of the affinity mask, every thread running chunks until a
+    # DEADLINE (bounded by wall time, not by a call count: where a CPU quota holds the process to fewer cores than the mask
+    # shows, 256 threads x a fixed amount of work would run for minutes)
+    all_cores = None
+    if all_seconds > 0 and avail > cores:
+        def until(t):
+            end, c, done = t_start[0] + all_seconds, 0, 0
+            while time.perf_counter() < end:
+                done += run_chunk(t * 131 + c * chunk)
+                c += 1
+            return done
+        t_start = [time.perf_counter()]
+        with ThreadPoolExecutor(avail) as ex:
+            n_all = sum(ex.map(until, range(avail)))
+        dt_all = time.perf_counter() - t_start[0]
+        quota = None
+        try:
+            q = open("/sys/fs/cgroup/cpu.max").read().split()
+            quota = None if q[0] == "max" else round(float(q[0]) / float(q[1]), 2)
+        except (OSError, ValueError, IndexError):
+            pass
+        all_cores = {"value": round(n_all * wl.dur_s / dt_all, 2), "threads": avail, "seconds": round(dt_all, 2),
+                     "cgroup_cpu_quota": quota,
+                     "note": "one thread per CPU of the affinity mask, each running %d-utterance calls until a %g s deadline; "
+                             "cgroup_cpu_quota = CPUs the container may use at once (null: no quota)" % (chunk, all_seconds)}
+    return {"value": round(n * wl.dur_s / dt, 2), "unit": "audio-seconds/sec", "cores": cores, "kind": "port", "all_cores": all_cores,
             "affinity_cores": avail, "box_cores_online": os.cpu_count(),   # threads used = min(affinity, 16): SURVEY 8d asks for the box's count
             "sample": "%d utterance passes over the first %d utterances of the bench ring (%s), oracle/auditory_oracle.c "
                       "float64, %d threads x %d calls x %d utterances, FFT plan cached per segment"
@@ -408,13 +434,29 @@ def main():  # noqa: C901
     B, K = args.batch, max(1, args.steps)
     sig_code = capi.AUD_I16 if args.sig_dtype == "i16" else capi.AUD_F32
 
+    alone = [False]   # rank0_alone(): the collectives inside a timed region become local
+
     def sync_all():
-        if world > 1:
+        if world > 1 and not alone[0]:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def rank0_alone(fn):
+        """rank 0 runs fn() while every other rank waits at the barrier behind it: the one-GPU rate of THIS run, on this node
+        (the denominator of weak_scaling.x_of_1gpu)"""
+        out = None
+        if rank == 0:
+            alone[0] = True
+            try:
+                out = fn()
+            finally:
+                alone[0] = False
+        if world > 1:
+            dist.barrier()
+        return out
+
     def max_over_ranks(x):
-        if world == 1:
+        if world == 1 or alone[0]:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -486,11 +528,19 @@ def main():  # noqa: C901
                 graph.replay()
                 torch.cuda.synchronize(dev)
                 launch_mode = "hipGraph of %d steps" % GK + (" (%d x the %d requested)" % (GK // K, K) if GK != K else "")
-            except Exception as ex:  # capture unsupported here (CPU dry run): say so and time eager launches
-                print("WARNING: hipGraph capture failed (%s); timing eager launches" % str(ex).splitlines()[0], file=sys.stderr)
+            except Exception as ex:
+                # capture unsupported here (CPU dry run), or refused for this region (a collective that will not be captured
+                # at N > 1): the region is finished with EAGER launches in this same process -- never a re-exec of a process
+                # that has touched the GPU -- and `launch` says so with the reason
+                why = str(ex).splitlines()[0][:160] if str(ex) else type(ex).__name__
+                print("WARNING: hipGraph capture failed (%s); timing eager launches" % why, file=sys.stderr)
                 graph = None
                 GK = K
-                torch.cuda.synchronize(dev)
+                launch_mode = "eager (hipGraph capture failed: %s)" % why
+                try:
+                    torch.cuda.synchronize(dev)
+                except Exception:     # (a capture that died half-way can leave an error behind: clear it and go on)
+                    torch.cuda.synchronize(dev)
                 if reset:
                     reset()
 
@@ -598,7 +648,7 @@ def main():  # noqa: C901
         # measured slower at 256 items per launch)
         one_launch = bool(gabor and plan.info("item_kernel") == 1 and "item_kernel=1" in args.option)
         res = timed_region(launch, n_streams, args.min_seconds if min_seconds is None else min_seconds,
-                           nb * world * wl.dur_s)
+                           nb * (1 if alone[0] else world) * wl.dur_s)
         alg = nb * (ring.sample_bytes * wl.dur + 4 * wl.nf * wl.T)      # each sample read once + each mel value written once
         if gabor:  # the pooled on/off pairs written; the unfused path also re-reads the mel tensor
             alg += nb * 4 * GABOR_POOLS[0] * GABOR_POOLS[1] * 2 * 8 + (0 if one_launch else nb * 4 * wl.nf * wl.T)
@@ -638,12 +688,17 @@ def main():  # noqa: C901
         ring = ring_for(wl)
         lo, hi = shard_range(total, rank, world)
         nb = hi - lo
-        reps3 = (nb + B - 1) // B
         # this rank's shard of the batch: ring buffers back to back (rank-seeded streams); two input copies so that
         # consecutive steps do not read the same HBM lines
-        bufs = [[(r + o * reps3) % ring.R for r in range(reps3)] for o in (0, 1)]
+        def shard_rows(n_rows):
+            """shard row -> row of the ring, for the two input copies of a rank whose shard has n_rows rows (every rank lays its
+            shard out by this rule over ITS ring; rank 0 replays it for the other ranks' blocks in the parity check)"""
+            reps = (n_rows + B - 1) // B
+            bl2 = [[(r + o * reps) % ring.R for r in range(reps)] for o in (0, 1)]
+            return bl2, [np.concatenate([np.arange(B) + b * B for b in bl])[:n_rows] for bl in bl2]
+
+        bufs, ring_row = shard_rows(nb)
         sig3 = [torch.cat([ring.sig[b] for b in bl])[:nb * wl.L].contiguous() for bl in bufs]
-        ring_row = [np.concatenate([np.arange(B) + b * B for b in bl])[:nb] for bl in bufs]   # shard row -> row of the ring
         items3 = upload_items(nb, wl.L)
         mel3 = [torch.empty((nb, wl.nf, wl.T), dtype=torch.float32, device=dev) for _ in range(2)]
         plan = wl.plan(compute, local_rank)
@@ -750,6 +805,14 @@ def main():  # noqa: C901
         def reset():
             done[0] = done[1] = None
 
+        def launch_kernel_only(i, st):
+            rc = lib.aud_melspec_batch_dev(ph, sig3[i % 2].data_ptr(), sig_code, items3.data_ptr(), nb, mel3[i % 2].data_ptr(), None, None, st)
+            if rc != 0:
+                raise RuntimeError("hot path launch: %d" % rc)
+
+        kernel_only = None
+        if gather:   # this rank's shard through the kernel WITHOUT the collective (two streams, like the one-GPU regions)
+            kernel_only = timed_region(launch_kernel_only, 2, min(min_seconds, 0.1), total * wl.dur_s)
         if gather and world > 1:
             bounded_first_step(launch, "the direct-pattern gather" if direct is not None else "the all-gather")
         # the gather's stream handling lives in launch(): one lane, the comm stream is the second
@@ -769,6 +832,7 @@ def main():  # noqa: C901
                                     "all_gather_into_tensor (torch.distributed)") +
                                    " of this rank's [%d, %d, %d] float32 slab, on a second stream, overlapped with the next "
                                    "step's kernel" % (nb, wl.nf, wl.T)) if gather else "none (one rank)"})
+        res["shard_sizes"] = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
         if gather:
             res["gathered_shape"] = list(full[0].shape)
             # the direct pattern's floor on a fully connected xGMI node: every rank must RECEIVE world - 1 slabs, one per link
@@ -778,6 +842,20 @@ def main():  # noqa: C901
             res["xgmi_bound_us"] = None if world == 1 else {
                 "per_step": round(slab_bytes / 76.8e9 * 1e6, 1), "assumes": "one slab of %d bytes per link and step at 76.8 GB/s per "
                 "direction (153.6 GB/s per link bidirectional)" % slab_bytes, "at_153.6_GBps_per_direction": round(slab_bytes / 153.6e9 * 1e6, 1)}
+            # what the links allow for configs[2] AS STATED, in the line itself: one GPU takes ~ world x kernel_us for
+            # the whole batch (the kernel is linear in the items); G ranks cannot finish a step before the slower of the shard's
+            # kernel and the slab's way over a link
+            k_us = kernel_only["us_per_step_device"]["mean"]
+            x_us = res["xgmi_bound_us"]["per_step"] if res["xgmi_bound_us"] else None
+            res["scaling_bound"] = {
+                "xgmi_us": x_us, "kernel_us": round(k_us, 2), "one_gpu_us_for_total_batch": round(k_us * world, 1),
+                "max_x_of_1gpu": round(world * k_us / max(k_us, x_us or 0.0), 2),
+                "bound_by": "kernel" if not x_us or k_us >= x_us else "xgmi",
+                "note": "kernel_us: this rank's shard of %d utterances through the kernel alone, measured in this run (two streams, "
+                        "no collective); xgmi_us: its %d-byte slab over one link at 76.8 GB/s per direction; the step of "
+                        "configs[2] as stated cannot be shorter than the larger of the two, so %d ranks can be at most "
+                        "max_x_of_1gpu times one GPU (which takes ~ ranks x kernel_us for the whole batch) whatever the collective's "
+                        "implementation; the measured ratio is `value` against a 1-GPU run's also.cfg3" % (nb, slab_bytes, world)}
         if direct is not None:
             res["arrival_timeouts"] = int(max_over_ranks(float(direct.timeouts())))
         if host is not None:
@@ -798,7 +876,7 @@ def main():  # noqa: C901
                         pcm = ring.pcm[ring_row[s][idx]]
                     else:  # another rank's input streams, regenerated from that rank's seeds (Ring: rank * R * B + row)
                         pcm = np.zeros((len(idx), wl.L), np.int16)
-                        for q, row in enumerate(ring_row[s][idx]):
+                        for q, row in enumerate(shard_rows(rhi - rlo)[1][s][idx]):
                             pcm[q, :wl.dur] = synth.utterance_pcm(2, r * ring.R * B + int(row), wl.dur, wl.sr)
                     r64 = pcm.astype(np.float64) / 32767.0
                     ref.append(osd.mel(r64 if ring.sample_bytes == 2 else r64.astype(np.float32).astype(np.float64)))
@@ -854,8 +932,16 @@ def main():  # noqa: C901
             if key[0] == "cfg5":
                 del rings[key]
         torch.cuda.empty_cache()
-    direct_alt = None
+    direct_alt = one_gpu = None
     if multi and args.workload == "headline":
+        if world > 1:   # the one-GPU rate of the collective-free step, rank 0 alone on the node (weak_scaling.x_of_1gpu)
+            one_gpu = rank0_alone(lambda: time_mode(head_wl, args.compute, kind=kind, check=False,
+                                                    min_seconds=min(args.min_seconds, args.also_seconds)))
+            one_gpu = [one_gpu]
+            dist.broadcast_object_list(one_gpu, src=0)
+            one_gpu = one_gpu[0]
+        else:
+            one_gpu = head
         cfg3 = cfg3_region(head_wl, args.compute, args.cfg3_total, args.min_seconds)
         if rank == 0 and not cfg3["parity"]["pass"] and not args.report_anyway:
             print("FATAL: the gathered tensor fails the parity criterion: %s" % cfg3["parity"], file=sys.stderr)
@@ -918,29 +1004,26 @@ def main():  # noqa: C901
             "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"],
             "avg_launch_us": solo["us_per_step_device"]["mean"], "rocprofv3_avg_launch_us": rocprof_us,
             "pipelined_GBps": head["achieved_GBps"],
-            "note": "limited_by: what limits the kernel -- vector-ALU issue in the compute type (DESIGN.md 4.1: %s of the vector peak at "
-                    "the pipelined rate with HBM at %s of 8 TB/s), not HBM; `achieved` / `peak` / `frac` still price it against HBM as "
-                    "the contract asks: algorithmic bytes (every sample read once, every mel value written once) / mean device time per "
-                    "launch between HIP events in a ONE-stream region of %d utterances per launch (the kernel alone on the chip, "
-                    "kernel-to-kernel boundary included); frac_of_measured = the same over measured_read_GBps (a plain float32 read "
-                    "kernel over 2 GiB in this process: SURVEY 8d's denominator); achieved_TFLOPs = SURVEY 8d's algorithmic flops "
-                    "(2.5 N log2 N + 3 H + 2 sum of widths + nf per frame) / the same time; rocprofv3_avg_launch_us = the average "
-                    "duration rocprofv3 --kernel-trace --stats gave the same kernel in the committed profile (profiles/"
-                    "pmc_traffic.json); pipelined = the same bytes and flops / time per step of the %d-stream region (`value`); "
-                    "one_launch_of_4096 = the same kernel as one launch of 4096 utterances on one stream (steady state without the overlap).  "
-                    "Why not 0.9 of the read roof: the float64 transform alone needs >= ~400 perfectly packed v_fma_f64 per 6-frame wave tile "
-                    "against ~350 vector-instruction slots for 0.9 of the roof, v_mfma_f32 issues at the vector rate and does not overlap "
-                    "float64 vector work (profiles/round4_mfma_beside_valu.txt), and even the all-float32 plan stops at ~0.31"
-                    % ("%.2f" % (flops / (head["us_per_step_device"]["mean"] * 1e-6) / 1e12 / peak_tf),
-                       "%.2f" % (head["achieved_GBps"] / HBM_PEAK_GBPS), B, head["streams"])}
+            "note": ("float64 VALU floor: 1.1 vector instructions per algorithmic flop, v_fma_f64 at 4.4-4.6 cycles, vector ALUs ~86 %% busy "
+                     "at the pipelined rate (%s of the %s vector peak with HBM at %s of 8 TB/s): not HBM-bound.  achieved / peak / frac "
+                     "price the kernel ALONE (one stream, %d utterances per launch, HIP events) against HBM as the contract asks; "
+                     "pipelined = the %d-stream rate (`value`); one_launch_of_4096 = steady state without the overlap; "
+                     "rocprofv3_avg_launch_us / traffic = the committed rocprofv3 passes of this command (profiles/pmc_traffic.json); "
+                     "DESIGN.md 4.1 has the account"
+                     % ("%.2f" % (flops / (head["us_per_step_device"]["mean"] * 1e-6) / 1e12 / peak_tf), args.compute,
+                        "%.2f" % (head["achieved_GBps"] / HBM_PEAK_GBPS), B, head["streams"]))
+                    if args.compute == "f64" else
+                    ("float32 plan: vector-issue bound as well (DESIGN.md 4.1); achieved / peak / frac price the kernel alone (one stream, "
+                     "%d utterances per launch) against HBM; pipelined = the %d-stream rate" % (B, head["streams"]))}
     line = {
         "metric": METRIC, "value": top["value"], "unit": "audio-seconds/sec",
         "n_gpus": world, "steps": top["steps"], "warmup": args.warmup, "ms_per_step": top["ms_per_step"],
         "higher_is_better": True, "scaling": "strong" if cfg3 is not None else "weak", "vs_baseline": None,
         "dtype": args.compute, "epilogue": "f32", "data": "synthetic",
-        "dtype_note": ("float64 plan: samples -> FFT -> real-FFT split in float64; the power spectrum is parked as float32 behind a per-frame "
-                       "power-of-two scale, mel sums and the final log are float32 (DESIGN.md 5); the strict criterion is checked on every "
-                       "timed element (`parity`)" if args.compute == "f64" else "float32 throughout (explicit opt-in AUD_FAST_F32; never the default)"),
+        "dtype_note": ("float64 plan: FFT and real-FFT split in float64; the spectrum / mel / log epilogue is float32 behind a per-frame "
+                       "power-of-two scale and passes the strict criterion (1e-5 on every timed element, `parity`) by >= 25x: max "
+                       "scaled error %.2g" % (top.get("parity") or head.get("parity") or {"max_scaled_err": float("nan")})["max_scaled_err"]
+                       if args.compute == "f64" else "float32 throughout (explicit opt-in AUD_FAST_F32; never the default)"),
         "steps_note": "the %d steps asked for are captured %d x into one hipGraph, replayed %d x" % (
             K, top["graph_steps"] // K, top["repeats"]),
         "config": {"workload": (("BASELINE configs[2] as stated: %d synthetic 16 kHz mono utterances of 1 s per step in total, "
@@ -969,9 +1052,20 @@ def main():  # noqa: C901
             line["arrival_timeouts"] = cfg3["arrival_timeouts"]
         line["collective"] = cfg3["collective"]
         line["gathered_shape"] = cfg3.get("gathered_shape")
+        line["shard_sizes"] = cfg3.get("shard_sizes")
         line["no_collective"] = {k: head[k] for k in ("value", "steps", "ms_per_step", "us_per_step_device", "launch", "streams",
                                                       "batch", "parity") if k in head}
         line["no_collective"]["note"] = "the sharded step without the collective: %d utterances per rank and step (weak scaling)" % B
+        line["scaling_bound"] = cfg3.get("scaling_bound")
+        # the collective-free step as a first-class key: every rank its own %d utterances per step, no exchange -- and the SAME step
+        # on rank 0 alone while the other ranks wait, so that the ratio is measured on this node in this run
+        line["weak_scaling"] = {"value": head["value"], "unit": "audio-seconds/sec", "batch_per_gpu": B,
+                                "rank0_alone_value": None if one_gpu is None else one_gpu["value"],
+                                "x_of_1gpu": None if one_gpu is None else round(head["value"] / one_gpu["value"], 3),
+                                "ms_per_step": head["ms_per_step"], "parity": head.get("parity"),
+                                "note": "no collective in the path: the batch shards over utterances (SURVEY 8e), each rank keeps its "
+                                        "features; `value` above adds the all-gather that configs[2] asks for, which the links bound "
+                                        "(scaling_bound)"}
     if modes:
         line["modes"] = modes
     if also:

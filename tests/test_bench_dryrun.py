@@ -85,6 +85,46 @@ def test_bench_dry_run_two_ranks(tmp_path):
     assert "error" in line["direct_gather"] and "peer" in line["direct_gather"]["error"]
 
 
+@pytest.mark.parametrize("total", [16, 19], ids=["even", "uneven"])
+def test_bench_dry_run_eight_ranks(tmp_path, total):
+    """The target world size: EIGHT gloo ranks through bench.py's N > 1 flow (configs[2] shrunk to `total` utterances) -- shard
+    sizes, the gathered tensor's shape, rank 0's parity check over all eight blocks, and the keys that make the first real
+    8-GPU run tell the whole story in one line: weak_scaling (with the same step on rank 0 alone) and scaling_bound."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = os.path.join(HERE, "bench_dry_worker.py")
+    procs = []
+    for r in range(8):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, worker, "--gpus", "8", "--steps", "2", "--warmup", "1",
+                                       "--batch", "2", "--ring-mb", "0.2", "--min-seconds", "0", "--cfg3-total", str(total),
+                                       "--dist-backend", "gloo", "--no-direct-alt"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "".join(o[1][-800:] for o in outs)
+    line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    for o in outs[1:]:
+        assert not [l for l in o[0].splitlines() if l.startswith("{")]            # only rank 0 prints
+    assert line["n_gpus"] == 8 and line["rccl_ranks"] == 8 and line["scaling"] == "strong"
+    assert line["gathered_shape"] == [total, 40, 104]
+    sizes = line["shard_sizes"]
+    assert len(sizes) == 8 and sum(sizes) == total and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    assert line["config"]["batch_per_gpu"] == sizes[0]
+    assert line["parity"]["pass"] and "(8 ranks)" in line["parity"]["checked"] and line["parity"]["elements"] >= 8 * 2 * 40 * 104
+    ws, sb = line["weak_scaling"], line["scaling_bound"]
+    assert ws["value"] == line["no_collective"]["value"] and ws["batch_per_gpu"] == 2 and ws["rank0_alone_value"] > 0
+    assert ws["x_of_1gpu"] == pytest.approx(ws["value"] / ws["rank0_alone_value"], rel=1e-2)
+    assert sb["kernel_us"] > 0 and sb["xgmi_us"] == pytest.approx(sizes[0] * 40 * 104 * 4 / 76.8e9 * 1e6, abs=0.06)
+    assert sb["max_x_of_1gpu"] == pytest.approx(8 * sb["kernel_us"] / max(sb["kernel_us"], sb["xgmi_us"]), rel=1e-2)
+    assert sb["bound_by"] in ("kernel", "xgmi") and line["xgmi_bound_us"]["per_step"] == sb["xgmi_us"]
+    assert line["launch" if "launch" in line else "config"] and "eager (hipGraph capture failed" in line["config"]["launch"]
+
+
 def test_bench_dry_run_line_survives_a_dead_side_measurement(tmp_path):
     """Two gloo ranks; both processes end abruptly (os._exit: what a GPU fault's abort does) inside the optional direct-pattern
     side measurement, the last thing the run does.  Rank 0's guard process -- forked before the GPU was touched, holding a copy
@@ -154,7 +194,7 @@ def test_bench_dry_run(monkeypatch, capsys, extra):
     import bench
     _patch(monkeypatch)
     monkeypatch.setattr(bench, "cpu_baseline",
-                        lambda wl, pcm: bench.__dict__["_real_cpu_baseline"](wl, pcm, target_s=0.2))
+                        lambda wl, pcm: bench.__dict__["_real_cpu_baseline"](wl, pcm, target_s=0.2, max_threads=2, all_seconds=0.3))
     monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--batch", "2", "--ring-mb", "0.2",
                                       "--min-seconds", "0", "--cfg3-total", "4", "--cfg5-batch", "2"] + extra)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
@@ -173,6 +213,13 @@ def test_bench_dry_run(monkeypatch, capsys, extra):
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
     assert line["cpu_baseline"]["cores"] <= 16 and line["cpu_baseline"]["kind"] == "port"
+    ac = line["cpu_baseline"]["all_cores"]      # SURVEY 8d's all-host-cores flavour beside the bounded one
+    if line["cpu_baseline"]["affinity_cores"] > line["cpu_baseline"]["cores"]:
+        assert ac["threads"] == line["cpu_baseline"]["affinity_cores"] and ac["value"] > 0 and ac["seconds"] < 30
+    else:
+        assert ac is None
+    assert ("1e-5" in line["dtype_note"]) == (line["dtype"] == "f64")       # the contract, in the line: float32 epilogue, margin
+    assert line["roofline"]["note"].startswith("float64 VALU floor" if line["dtype"] == "f64" else "float32 plan")
     assert "workload" in line["config"] and "model" not in line["config"]
     assert line["value"] > 0 and line["roofline"]["achieved"] >= 0
     if not extra:   # the default line nests the other BASELINE configurations, each with its own strict parity object
