@@ -730,11 +730,7 @@ __device__ __forceinline__ void wave_spectrum_halves(const MelspecArgs& a, const
     }
     const float* prow = P + (HF * h) * Hp;
     // the item's [H][T] tensors behind buffer descriptors (wave-uniform: one item per tile)
-#ifdef AUD_EXP_SPEC_DROP  // (experiment, profiles/round5_sndenv_store_bound.txt: every spectrum store issued, all dropped by the
-    const int tensor_bytes = 0;  //  range check -- the kernel without its PowerSegment / LogPowerSegment memory traffic)
-#else
     const int tensor_bytes = H * T * 4;
-#endif
     const __amdgpu_buffer_rsrc_t rpw = __builtin_amdgcn_make_buffer_rsrc(a.power ? a.power + size_t(item) * H * T : nullptr, 0,
                                                                          a.power ? tensor_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rlp = __builtin_amdgcn_make_buffer_rsrc(a.log_power ? a.log_power + size_t(item) * H * T : nullptr, 0,
@@ -869,8 +865,7 @@ template <typename TT, int FPW, int MAXS, bool COMPACT = false, bool FUSE = fals
 __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const WaveArgs& e, const float* P, int Hp,
                                                   const unsigned char* smem, int sc, const aud_item& it,
                                                   int item, int t0, int lane, const int* exps = nullptr,
-                                                  float* mel_lds = nullptr, float* stash = nullptr, int stash_i = 0,
-                                                  float (*keep)[4] = nullptr) {
+                                                  float* mel_lds = nullptr, float* stash = nullptr, int stash_i = 0) {
     wave_spectrum_outputs<TT, FPW, FUSE>(a, P, Hp, exps, sc, it, item, t0, lane);
     // 64 is not a multiple of FPW = 6: lanes 60..63 have no filter group; they run group n_groups - 1 again and store nothing
     const int T = a.T;
@@ -954,13 +949,6 @@ __device__ __forceinline__ void wave_mel_epilogue(const MelspecArgs& a, const Wa
                 // one frame per wave (w64x16): a frame's values would be n_filters 4-byte stores into as many cache lines; with a
                 // stash the wave parks them in LDS, [slot][lane][4 frames], and writes 16-byte [filter][4 steps] pieces behind
                 // its fourth frame (wave_mel_flush4)
-#ifdef AUD_EXP_W64_KEEP  // (experiment: the wave's four frames' values of slots 0 / 1 held in REGISTERS instead of an LDS stash)
-                if (keep && k < 2) {
-                    const float val = live ? res : 0.f;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) keep[k][j] = stash_i == j ? val : keep[k][j];
-                } else
-#endif
                 if (stash) stash[(k * 64 + lane) * 4 + stash_i] = live ? res : 0.f;
                 else if (col_on && flt != 0xFFFF) mel_col[size_t(flt) * T] = live ? res : 0.f;
             } else {

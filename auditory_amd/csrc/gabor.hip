@@ -45,11 +45,7 @@ __device__ __forceinline__ void store_pair_block(float* cell, const TT (&acc)[8]
 
 // KSX, KSY, KNG > 0: compile-time filter geometry (the reference's default 9 x 9 x 8 set gets fully
 // unrolled taps and no group loop); 0: taken from the arguments at run time.
-#ifdef AUD_EXP_GABOR_BLOCK
-constexpr int kGaborBlock = AUD_EXP_GABOR_BLOCK;
-#else
 constexpr int kGaborBlock = 256;
-#endif
 template <typename TT, int KSX, int KSY, int KNG>
 __global__ __launch_bounds__(kGaborBlock) void k_gabor(const GaborArgs a) {
     const int per_item = a.nF * a.nT;
@@ -89,11 +85,7 @@ __global__ __launch_bounds__(kGaborBlock) void k_gabor(const GaborArgs a) {
         auto tap_row = [&](const float* row, int ff, int ft) { tap_val(row[ft], ff, ft); };
         // three rows at a time: the next rows' loads are in flight behind a row's multiply-adds (rolled: every row's loads are
         // waited for in full, 15.47-15.55 us per configs[3] step; by three 15.35-15.39; all nine 15.96-16.14: round 5, one box)
-#ifdef AUD_EXP_GABOR_UNROLL
-#pragma unroll AUD_EXP_GABOR_UNROLL
-#else
 #pragma unroll 3
-#endif
         for (int ff = 0; ff < SY; ++ff) {
             const float* row = mel + size_t(f + ff) * a.cols + t;
             if constexpr (KSX == 9) {

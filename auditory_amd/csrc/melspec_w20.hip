@@ -148,13 +148,9 @@ __device__ __forceinline__ void w20_tile_front(const MelspecArgs& a, const WaveA
     AUD_STAMP(7);
 }
 
-#ifdef AUD_EXP_W20_WAVES5
-#define AUD_W20_F64_WAVES 5
-#else
-#define AUD_W20_F64_WAVES 4
-#endif
+// float64: four waves per SIMD (122 registers are the kernel's working set: DESIGN.md 4.1); float32: five
 template <typename TT, int SRC, int NW, int MAXS>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(sizeof(TT) == 8 ? AUD_W20_F64_WAVES : 5, sizeof(TT) == 8 ? AUD_W20_F64_WAVES : 5)))
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(sizeof(TT) == 8 ? 4 : 5, sizeof(TT) == 8 ? 4 : 5)))
 void k_melspec_w20(const aud_item* items, unsigned total, unsigned tiles, unsigned tile_mul, int tile_shift, const void* blob_ptr,
                    int blob_bytes, unsigned n_wgs, int xcd_remap, const MelspecArgs a, const WaveArgs e) {
     using L = w20::Layout<TT>;
@@ -266,9 +262,6 @@ void k_melspec_w20_item(const aud_item* items, unsigned n_items, unsigned tiles,
         const int t0 = tile * w20::kFW;
         w20_tile_front<TT, SRC>(a, e, smem, region, it, t0, f, j, tile_pos0(tile, f, j), raw AUD_STAMP_ARG);
         const int next = tile + NW;
-#ifdef AUD_EXP_PREFETCH  // in flight through the epilogue: 35 spilled registers at the four-wave budget (float64), not adopted
-        if (next < int(tiles)) pairs_issue<SRC, 20, 10>(tile_window(next), tile_pos0(next, f, j), raw);
-#endif
         if (g.nG > 0)
             wave_mel_epilogue_pick<TT, w20::kFW, MAXS, true>(a, e, reinterpret_cast<const float*>(region), w20::kHp, smem,
                                                         sizeof(TT) == 8 ? frame_scale_of(exps + ln % w20::kFW) : 0, it, item, t0,
@@ -278,9 +271,7 @@ void k_melspec_w20_item(const aud_item* items, unsigned n_items, unsigned tiles,
                                                          sizeof(TT) == 8 ? frame_scale_of(exps + ln % w20::kFW) : 0, it, item, t0,
                                                          ln, exps);
         wave_lds_fence();  // the region is free for the next tile's transposes
-#ifndef AUD_EXP_PREFETCH
         if (next < int(tiles)) pairs_issue<SRC, 20, 10>(tile_window(next), tile_pos0(next, f, j), raw);
-#endif
         tile = next;
     }
     AUD_STAMP(8);
@@ -300,11 +291,7 @@ size_t w20_region_bytes(bool f64) { return f64 ? size_t(w20::Layout<double>::kRe
 wave_kernel_t w20_kernel(bool, int, int) { return k_melspec_w20<double, AUD_F32, 4, 4>; }
 item_kernel_t w20_item_kernel(bool, int, int, int) { return k_melspec_w20_item<double, AUD_F32, 5, 4>; }
 #else
-#ifdef AUD_EXP_W20_NW  // (experiment: waves per workgroup of the tile kernel; melspec_wave.hip wave_kernel_waves follows)
-#define AUD_W20_NW AUD_EXP_W20_NW
-#else
 #define AUD_W20_NW 4
-#endif
 #define AUD_W20_PICK(TT)                                                                                  \
     (sig_dtype == AUD_F64   ? (s8 ? k_melspec_w20<TT, AUD_F64, AUD_W20_NW, 8> : k_melspec_w20<TT, AUD_F64, AUD_W20_NW, 4>)   \
      : sig_dtype == AUD_I16 ? (s8 ? k_melspec_w20<TT, AUD_I16, AUD_W20_NW, 8> : k_melspec_w20<TT, AUD_I16, AUD_W20_NW, 4>)   \

@@ -47,8 +47,7 @@ __device__ __forceinline__ void w64_issue(const MelspecArgs& a, int lane, int it
 // (the load phase was 38 % of a wave's life without it: profiles/r05e_stamps_n46.44_f64_b64.txt).
 template <typename TT, int SRC, int MAXS>
 __device__ __forceinline__ void w64_tile(const MelspecArgs& a, const WaveArgs& e, unsigned char* smem, unsigned char* region,
-                                         int lane_in, int item, int sstep, bool more, PairRaw<16>& raw, float* stash, int stash_i,
-                                         float (*keep)[4] = nullptr) {
+                                         int lane_in, int item, int sstep, bool more, PairRaw<16>& raw, float* stash, int stash_i) {
     TT* xw = reinterpret_cast<TT*>(region);
     int lane = lane_in;  // opaque per frame: otherwise the compiler hoists what only depends on it out of the frame loop
     asm volatile("" : "+v"(lane));
@@ -214,7 +213,7 @@ __device__ __forceinline__ void w64_tile(const MelspecArgs& a, const WaveArgs& e
             const bool wrap = sstep + 1 == a.T;
             w64_issue<SRC>(a, lane, wrap ? item + 1 : item, wrap ? 0 : sstep + 1, raw);
         }
-    wave_mel_epilogue<TT, 1, MAXS, true>(a, e, P, w64::kHp, smem, sc, it, item, sstep, lane, nullptr, nullptr, stash, stash_i, keep);
+    wave_mel_epilogue<TT, 1, MAXS, true>(a, e, P, w64::kHp, smem, sc, it, item, sstep, lane, nullptr, nullptr, stash, stash_i);
     AUD_STAMP(8);
     AUD_STAMP_REAL(10);
     AUD_STAMP_FLUSH(a, wt, lane);
@@ -249,34 +248,15 @@ __global__ __launch_bounds__(64 * NW) void k_melspec_w64(const aud_item*, unsign
     const bool quad = e.stash_off >= 0 && (a.T & 3) == 0 && wt0 + w64::kFPW <= total && (reinterpret_cast<uintptr_t>(a.mel) & 15) == 0;
     float* stash = quad ? reinterpret_cast<float*>(smem + e.stash_off) + size_t(wave) * e.n_slots * 64 * 4 : nullptr;
     const int item0 = item, t0 = sstep;
-#ifdef AUD_EXP_W64_KEEP
-    float keepr[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    const bool keepq = sizeof(TT) == 8 && e.n_slots <= 2 && (a.T & 3) == 0 && wt0 + w64::kFPW <= total && (reinterpret_cast<uintptr_t>(a.mel) & 15) == 0;
-    float (*keep)[4] = keepq ? keepr : nullptr;
-#else
-    float (*keep)[4] = nullptr;
-#endif
 #pragma unroll 1
     for (int i = 0; i < w64::kFPW; ++i) {
         if (wt0 + i >= total) break;
-        w64_tile<TT, SRC, MAXS>(a, e, smem, region, lane, item, sstep, i + 1 < w64::kFPW && wt0 + i + 1 < total, raw, stash, i, keep);
+        w64_tile<TT, SRC, MAXS>(a, e, smem, region, lane, item, sstep, i + 1 < w64::kFPW && wt0 + i + 1 < total, raw, stash, i);
         if (++sstep == a.T) {
             sstep = 0;
             ++item;
         }
     }
-#ifdef AUD_EXP_W64_KEEP
-    if (keep) {  // MelFBankSegment[item][flt][t0 .. t0 + 3] as one 16-byte store per slot
-        const unsigned* recs = reinterpret_cast<const unsigned*>(smem + e.slots_off) + lane * e.n_slots * 2;
-        float* base = a.mel + size_t(item0) * a.nf * a.T + t0;
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-            if (k < e.n_slots) {
-                const int flt = int(recs[2 * k] >> 16);
-                if (flt != 0xFFFF) *reinterpret_cast<float4*>(base + size_t(flt) * a.T) = float4{keepr[k][0], keepr[k][1], keepr[k][2], keepr[k][3]};
-            }
-    }
-#endif
     if (quad) {
         wave_lds_fence();
         wave_mel_flush4<MAXS>(a, e, smem, stash, item0, t0, lane);

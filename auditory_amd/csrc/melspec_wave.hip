@@ -38,9 +38,6 @@ namespace aud {
 // workgroups of six were measured to leave one of them waiting: six waves land 2-2-1-1 on the SIMDs and the second
 // workgroup's pair does not fit beside the first's at 160 VGPRs)
 static int wave_kernel_waves(int kind, int compute_dtype) {
-#ifdef AUD_EXP_W20_NW
-    if (kind == 3) return AUD_EXP_W20_NW;
-#endif
     return kind == 4 && compute_dtype == AUD_F64 ? 12 : 4;
 }
 

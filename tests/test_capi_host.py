@@ -50,6 +50,17 @@ def test_no_oracle_in_product():
                 assert "oracle" not in src.lower().replace("no oracle", ""), f
 
 
+def test_no_experiment_switches_in_product():
+    """one code path per kernel: closed experiments live as patches under profiles/ (round5_*_experiment.patch,
+    round6_retired_experiment_switches.patch), not as AUD_EXP_* branches in the shipped sources.  (AUD_STAMPS and
+    AUD_TUNE_BLUESTEIN are diagnostic BUILDS of the same code path and stay.)"""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "auditory_amd", "csrc")):
+        for f in files:
+            src = open(os.path.join(dirpath, f), errors="ignore").read()
+            assert "AUD_EXP_" not in src, "%s still carries an experiment switch" % f
+    assert os.path.exists(os.path.join(ROOT, "profiles", "round6_retired_experiment_switches.patch"))
+
+
 def test_init_without_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():

@@ -2,7 +2,7 @@
 """Interleaved A/B timing of kernel builds / plan options in ONE process (run on the GPU box).
 
 A variant is a library build (--libs: comma-separated tags of auditory_amd/libauditory_hip_<tag>.so, "" = the shipped
-library; experimental builds come from `python -m auditory_amd.build --tag T -DAUD_EXP_...`) and an option set.  The
+library; experimental builds come from `python -m auditory_amd.build --tag T -D<SWITCH> on a patched tree: profiles/*_experiment.patch, round6_retired_experiment_switches.patch`) and an option set.  The
 variants are timed round-robin for --rounds rounds of --launches back-to-back launches each inside one hipGraph (HIP
 events on the launch stream; --streams 2 deals the launches over two streams as bench.py does), in a fresh order every
 round, and the per-launch median / min over rounds is printed.  Variance between processes or devices never enters.
