@@ -130,6 +130,9 @@ SYMBOLS = {
     "aud_signal_len": (C.c_int64, [_VP]),
     "aud_melspec_batch_sig": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP]),
     "aud_melspec_mfcc_batch_sig": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "aud_melspec_batch_live": (C.c_int, [_VP, C.POINTER(C.c_void_p), _VP, C.c_int64, _VP, C.c_int, _VP, _VP, _VP, C.POINTER(C.c_int64)]),
+    "aud_melspec_mfcc_batch_live": (C.c_int, [_VP, C.POINTER(C.c_void_p), _VP, C.c_int64, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
+                                            C.POINTER(C.c_int64)]),
     "aud_snd_to_window": (C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int, _VP]),
     "aud_dft_filter_host": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, _VP, _VP]),
     "aud_mel_filter_dft_host": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP]),

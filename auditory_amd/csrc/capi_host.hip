@@ -206,22 +206,27 @@ int aud_signal_destroy(aud_signal* s) {
 
 int64_t aud_signal_len(const aud_signal* s) { return s ? s->n : -1; }
 
-int aud_signal_sync(aud_ctx* c, aud_signal** sig, const void* samples, int sample_dtype, int64_t n_samples,
-                    int64_t* uploaded_bytes) {
-    if (uploaded_bytes) *uploaded_bytes = 0;
-    if (!c || !sig) return AUD_EINVAL;
-    if (sample_dtype != AUD_F64 && sample_dtype != AUD_F32 && sample_dtype != AUD_I16) return fail(c, AUD_EINVAL, "bad sample_dtype");
-    if (n_samples < 0 || (n_samples > 0 && !samples)) return fail(c, AUD_EINVAL, "null buffer");
+namespace {
+
+constexpr size_t kSyncBlock = 4096;  // compare / upload grain of a synced signal
+
+// a handle of THIS context that is still alive (or null: to be created)
+int check_live_signal(aud_ctx* c, aud_signal* s) {
+    if (!s) return AUD_OK;
+    SignalRegistry& reg = SignalRegistry::get();
+    std::lock_guard<std::mutex> lk(reg.m);
+    if (std::find(reg.live.begin(), reg.live.end(), s) == reg.live.end() || s->ctx != c)
+        return fail(c, AUD_EINVAL, "signal of another (or a shut-down) context");
+    return AUD_OK;
+}
+
+// The body of aud_signal_sync; the caller holds c->host_mutex.  `need` (may be null: every block) marks the kSyncBlock-byte
+// blocks the coming call reads: only those are compared with the shadow, and what is uploaded is the span from the first to the
+// last of them that differs.  Blocks outside stay as they are on BOTH sides (device copy == shadow always holds), so a later call
+// that needs them finds their edits then.  Unchanged tensor: not a single runtime call.
+int signal_sync_locked(aud_ctx* c, aud_signal** sig, const void* samples, int sample_dtype, int64_t n_samples,
+                       const std::vector<unsigned char>* need, int64_t* uploaded_bytes) {
     aud_signal* s = *sig;
-    if (s) {  // a handle of THIS context that is still alive
-        SignalRegistry& reg = SignalRegistry::get();
-        std::lock_guard<std::mutex> lk(reg.m);
-        if (std::find(reg.live.begin(), reg.live.end(), s) == reg.live.end() || s->ctx != c)
-            return fail(c, AUD_EINVAL, "signal of another (or a shut-down) context");
-    }
-    // The compare needs the context's lock (the handle's shadow is shared state) but nothing of the device: an unchanged
-    // tensor -- every call but the first of a sound -- returns without a single runtime call.
-    std::unique_lock<std::mutex> lock(c->host_mutex);
     if (!s) {
         s = new (std::nothrow) aud_signal();
         if (!s) return AUD_ENOMEM;
@@ -236,17 +241,17 @@ int aud_signal_sync(aud_ctx* c, aud_signal** sig, const void* samples, int sampl
     size_t lo = 0, hi = bytes;  // the span to upload
     const bool same_shape = s->shadow_ok && s->dtype == sample_dtype && s->n == n_samples;
     if (same_shape) {  // byte for byte against what the device holds
-        constexpr size_t kBlock = 4096;
         lo = bytes;
         hi = 0;
-        for (size_t b = 0; b < bytes; b += kBlock) {
-            const size_t len = std::min(kBlock, bytes - b);
+        for (size_t b = 0, k = 0; b < bytes; b += kSyncBlock, ++k) {
+            if (need && !(*need)[k]) continue;
+            const size_t len = std::min(kSyncBlock, bytes - b);
             if (std::memcmp(src + b, s->shadow + b, len) != 0) {
                 if (lo == bytes) lo = b;
                 hi = b + len;
             }
         }
-        if (lo >= hi) return AUD_OK;  // equal: the resident copy IS the caller's tensor
+        if (lo >= hi) return AUD_OK;  // equal where it matters: the resident copy IS the caller's tensor there
     } else {
         s->shadow_ok = false;
         AUD_HIP(c, make_current(c));
@@ -277,6 +282,81 @@ int aud_signal_sync(aud_ctx* c, aud_signal** sig, const void* samples, int sampl
     s->shadow_ok = true;
     if (uploaded_bytes) *uploaded_bytes = int64_t(hi - lo);
     return AUD_OK;
+}
+
+// the blocks of a float64 signal the frames of `items` read under plan p: frame s of an item covers stream positions
+// [start0 + S (s - border), + N) clipped to [0, sig_len) (sndenv.go:438-478), i.e. buffer elements sig_off + pos * stride
+void mark_needed_blocks(const aud_plan* p, const aud_item* items, int n_items, size_t elem_bytes, size_t total_bytes,
+                        std::vector<unsigned char>* need) {
+    need->assign((total_bytes + kSyncBlock - 1) / kSyncBlock, 0);
+    const int64_t S = p->d.step_samples, N = p->d.win_samples, T = p->d.segment_steps, border = p->d.border_steps;
+    for (int i = 0; i < n_items; ++i) {
+        const aud_item& it = items[i];
+        const int64_t stride = it.sig_stride > 1 ? it.sig_stride : 1;
+        int64_t first = int64_t(it.start0) - S * border, last = int64_t(it.start0) + S * (T - 1 - border) + N;  // [first, last)
+        first = std::max<int64_t>(first, 0);
+        last = std::min<int64_t>(last, it.sig_len);
+        if (last <= first) continue;
+        const size_t b0 = size_t(it.sig_off + first * stride) * elem_bytes / kSyncBlock;
+        const size_t b1 = (size_t(it.sig_off + (last - 1) * stride) * elem_bytes + elem_bytes - 1) / kSyncBlock;
+        for (size_t b = b0; b <= b1 && b < need->size(); ++b) (*need)[b] = 1;
+    }
+}
+
+}  // namespace
+
+int aud_signal_sync(aud_ctx* c, aud_signal** sig, const void* samples, int sample_dtype, int64_t n_samples,
+                    int64_t* uploaded_bytes) {
+    if (uploaded_bytes) *uploaded_bytes = 0;
+    if (!c || !sig) return AUD_EINVAL;
+    if (sample_dtype != AUD_F64 && sample_dtype != AUD_F32 && sample_dtype != AUD_I16) return fail(c, AUD_EINVAL, "bad sample_dtype");
+    if (n_samples < 0 || (n_samples > 0 && !samples)) return fail(c, AUD_EINVAL, "null buffer");
+    int rc = check_live_signal(c, *sig);
+    if (rc != AUD_OK) return rc;
+    // The compare needs the context's lock (the handle's shadow is shared state) but nothing of the device
+    std::lock_guard<std::mutex> lock(c->host_mutex);
+    return signal_sync_locked(c, sig, samples, sample_dtype, n_samples, nullptr, uploaded_bytes);
+}
+
+int aud_melspec_batch_live(aud_plan* p, aud_signal** sig, const double* samples, int64_t n_samples, const aud_item* items,
+                           int n_items, double* mel, double* power, double* log_power, int64_t* uploaded_bytes) {
+    if (uploaded_bytes) *uploaded_bytes = 0;
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    if (!sig || n_samples < 0 || n_items < 0 || (n_items > 0 && (!samples || !items || !mel))) return fail(c, AUD_EINVAL, "null buffer");
+    if (n_items == 0) return AUD_OK;
+    int rc = check_items(c, items, n_items, n_samples);
+    if (rc == AUD_OK) rc = check_live_signal(c, *sig);
+    if (rc != AUD_OK) return rc;
+    std::vector<unsigned char> need;
+    mark_needed_blocks(p, items, n_items, sizeof(double), size_t(n_samples) * sizeof(double), &need);
+    HostCallGuard guard(c);
+    if ((rc = signal_sync_locked(c, sig, samples, AUD_F64, n_samples, &need, uploaded_bytes)) != AUD_OK) return rc;
+    AUD_HIP(c, make_current(c));
+    return melspec_host_run(p, (*sig)->d, AUD_F64, items, n_items, mel, power, log_power);
+}
+
+int aud_melspec_mfcc_batch_live(aud_plan* p, aud_signal** sig, const double* samples, int64_t n_samples, const aud_item* items,
+                                int n_items, double* mel, double* power, double* log_power, double* mfcc, double* deltas,
+                                double* delta_deltas, double* energy, int64_t* uploaded_bytes) {
+    if (uploaded_bytes) *uploaded_bytes = 0;
+    if (!p) return AUD_EINVAL;
+    aud_ctx* c = p->ctx;
+    if (p->d.mfcc_coefs <= 0) return fail(c, AUD_EINVAL, "plan was created without mfcc_coefs");
+    if (!p->d.dft.comp_log_pow) return fail(c, AUD_EINVAL, "the MFCC tail reads LogPowerSegment: needs CompLogPow");
+    if (!sig || n_samples < 0 || n_items < 0 || (n_items > 0 && (!samples || !items || !mel || !mfcc)))
+        return fail(c, AUD_EINVAL, "null buffer");
+    if (delta_deltas && !deltas) return fail(c, AUD_EINVAL, "delta_deltas needs deltas");
+    if (n_items == 0) return AUD_OK;
+    int rc = check_items(c, items, n_items, n_samples);
+    if (rc == AUD_OK) rc = check_live_signal(c, *sig);
+    if (rc != AUD_OK) return rc;
+    std::vector<unsigned char> need;
+    mark_needed_blocks(p, items, n_items, sizeof(double), size_t(n_samples) * sizeof(double), &need);
+    HostCallGuard guard(c);
+    if ((rc = signal_sync_locked(c, sig, samples, AUD_F64, n_samples, &need, uploaded_bytes)) != AUD_OK) return rc;
+    AUD_HIP(c, make_current(c));
+    return melspec_mfcc_host_run(p, (*sig)->d, AUD_F64, items, n_items, mel, power, log_power, mfcc, deltas, delta_deltas, energy);
 }
 
 int aud_melspec_batch_sig(aud_plan* p, const aud_signal* s, const aud_item* items, int n_items, double* mel, double* power,

@@ -232,6 +232,43 @@ class Plan:
         self.ctx.check(self.lib.aud_melspec_batch_sig(self.handle, signal.handle, vp(items), n, vp(mel), vp(power), vp(logp)))
         return mel, power, logp
 
+    def melspec_live(self, signal, sig, items, want_power=False, want_log_power=False, out=None):
+        """aud_melspec_batch_live: melspec_host's result on the float64 array `sig` as it is NOW, from the resident copy
+        `signal` (a runtime.Signal, created empty) -- the 4 KB blocks the items' frames read are compared with the copy's host
+        shadow and uploaded where they differ, then the call runs on the device copy.  signal.uploaded_bytes says what moved."""
+        sig = np.ascontiguousarray(sig, np.float64)
+        items = np.ascontiguousarray(items, dtype=ITEM_DTYPE)
+        n = len(items)
+        if out is not None:
+            mel, power, logp = out
+        else:
+            mel = np.zeros((n, self.nf, self.T), np.float64)
+            power = np.zeros((n, self.H, self.T), np.float64) if want_power else None
+            logp = np.zeros((n, self.H, self.T), np.float64) if want_log_power else None
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        up = C.c_int64(0)
+        self.ctx.check(self.lib.aud_melspec_batch_live(self.handle, C.byref(signal.handle), vp(sig), sig.size, vp(items), n, vp(mel),
+                                                       vp(power), vp(logp), C.byref(up)))
+        signal.n, signal.uploaded_bytes = int(sig.size), int(up.value)
+        return mel, power, logp
+
+    def melspec_mfcc_live(self, signal, sig, items, deltas=True):
+        """aud_melspec_mfcc_batch_live: melspec_mfcc_host's result on `sig` as it is now, from the resident copy `signal`"""
+        sig = np.ascontiguousarray(sig, np.float64)
+        items = np.ascontiguousarray(items, dtype=ITEM_DTYPE)
+        n, nc = len(items), self.mfcc_coefs
+        out = dict(mel=np.zeros((n, self.nf, self.T)), power=np.zeros((n, self.H, self.T)),
+                   log_power=np.zeros((n, self.H, self.T)), mfcc=np.zeros((n, nc, self.T)),
+                   deltas=np.zeros((n, nc, self.T)) if deltas else None,
+                   delta_deltas=np.zeros((n, nc, self.T)) if deltas else None, energy=np.zeros((n, self.T)))
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        up = C.c_int64(0)
+        self.ctx.check(self.lib.aud_melspec_mfcc_batch_live(
+            self.handle, C.byref(signal.handle), vp(sig), sig.size, vp(items), n, vp(out["mel"]), vp(out["power"]),
+            vp(out["log_power"]), vp(out["mfcc"]), vp(out["deltas"]), vp(out["delta_deltas"]), vp(out["energy"]), C.byref(up)))
+        signal.n, signal.uploaded_bytes = int(sig.size), int(up.value)
+        return out
+
     def melspec_mfcc_sig(self, signal, items, deltas=True):
         """melspec_mfcc_host on a resident Signal (aud_melspec_mfcc_batch_sig)"""
         items = np.ascontiguousarray(items, dtype=ITEM_DTYPE)

@@ -187,8 +187,9 @@ class SndEnv:
         self._plan = None
         # ProcessSegment runs once per segment on the SAME Signal, and the reference reads the LIVE tensor at every step
         # (sndenv.go:455-478): the device keeps a copy of it between calls that is validated EXACTLY on every call.
-        #   ResidentSignal = None (default): a Signal of up to AUD_RESIDENT_AUTO_BYTES is compared byte for byte with the host
-        #       shadow of the device copy (aud_signal_sync) -- any in-place edit is seen, only the differing span is uploaded;
+        #   ResidentSignal = None (default): for a Signal of up to AUD_RESIDENT_AUTO_BYTES every call compares what ITS frames read
+        #       (4 KB blocks) byte for byte with the host shadow of the device copy and uploads what differs
+        #       (aud_melspec_batch_live / aud_melspec_mfcc_batch_live) -- any in-place edit is seen by the call that reads it;
         #       a larger Signal is copied per call, as if there were no residency.
         #   ResidentSignal = True, or an explicit SignalToDevice(): the caller opts in to a SNAPSHOT it keeps current itself --
         #       re-taken when Signal is another array, length or type; SignalChanged() after an in-place edit.
@@ -323,14 +324,12 @@ class SndEnv:
             if self._dev_sig is None or self._dev_sig_key != self._signal_key():
                 self.SignalToDevice()
             return self._dev_sig
-        sig = np.ascontiguousarray(self.Signal, np.float64)
-        if sig.nbytes > capi.AUD_RESIDENT_AUTO_BYTES:
+        if len(self.Signal) * 8 > capi.AUD_RESIDENT_AUTO_BYTES:
             self._drop_resident()
             return None
         if self._dev_sig is None:
             self._dev_sig = runtime.Signal(runtime.get_ctx(self._device))
-        self._dev_sig.sync(sig)                                         # exact: memcmp against the shadow, upload what differs
-        return self._dev_sig
+        return self._dev_sig            # (the default: the _live calls validate what they read, exactly, as part of the call)
 
     def _item(self, segment, add):
         start0 = segment * self.Params.StrideSamples + MSecToSamples(add, self.SampleRate)
@@ -374,8 +373,10 @@ class SndEnv:
         items = runtime.make_items([i[0] for i in its], [i[1] for i in its], [i[2] for i in its])
         self._ensure_plan()
         res = self._resident()
+        live = res is not None and not self._snapshot      # default residency: aud_*_live compares what the call reads
         if self.Mel.MFCC and self.DFT.CompLogPow:
-            o = (self._plan.melspec_mfcc_sig(res, items, deltas=bool(self.Mel.Deltas)) if res is not None else
+            o = (self._plan.melspec_mfcc_live(res, self.Signal, items, deltas=bool(self.Mel.Deltas)) if live else
+                 self._plan.melspec_mfcc_sig(res, items, deltas=bool(self.Mel.Deltas)) if res is not None else
                  self._plan.melspec_mfcc_host(self.Signal, items, deltas=bool(self.Mel.Deltas)))
             m, pw, lp = o["mel"], o["power"], o["log_power"]
             self.MFCCSegment, self.Energy = o["mfcc"][-1], o["energy"][-1]
@@ -383,7 +384,8 @@ class SndEnv:
                 self.MFCCDeltas, self.MFCCDeltaDeltas = o["deltas"][-1], o["delta_deltas"][-1]
             self._last_mfcc = o
         else:
-            m, pw, lp = (self._plan.melspec_sig(res, items, True, bool(self.DFT.CompLogPow)) if res is not None else
+            m, pw, lp = (self._plan.melspec_live(res, self.Signal, items, True, bool(self.DFT.CompLogPow)) if live else
+                         self._plan.melspec_sig(res, items, True, bool(self.DFT.CompLogPow)) if res is not None else
                          self._plan.melspec_host(self.Signal, items, True, bool(self.DFT.CompLogPow)))
         self.MelFBankSegment = m[-1]
         self.PowerSegment = pw[-1]

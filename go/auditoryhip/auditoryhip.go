@@ -672,3 +672,52 @@ func (p *Plan) MelSpecMFCCSig(sig *Signal, items []Item, mel, power, logPower, m
 		ptr(power), ptr(logPower), ptr(mfcc), ptr(deltas), ptr(deltaDeltas), ptr(energy))
 	return status(p.ctx, rc)
 }
+
+
+// MelSpecLive is MelSpec on the LIVE tensor sig through its resident copy dev (nil: created): aud_melspec_batch_live compares the
+// 4 KB blocks the items' frames read with the copy's host shadow, uploads what differs and runs on the device copy -- the result
+// is MelSpec's on sig as it is now.  Returns the (possibly new) Signal and the bytes that crossed the link.
+func (p *Plan) MelSpecLive(dev *Signal, sig []float64, items []Item, mel, power, logPower []float64) (*Signal, int64, error) {
+	if dev == nil {
+		dev = &Signal{ctx: p.ctx}
+	}
+	if len(items) == 0 {
+		return dev, 0, nil
+	}
+	if len(mel) < len(items)*p.NFilters*p.Steps || len(sig) == 0 {
+		return dev, 0, errors.New("auditory_hip: mel buffer too small, or empty signal")
+	}
+	ptr := func(s []float64) *C.double {
+		if len(s) == 0 {
+			return nil
+		}
+		return (*C.double)(unsafe.Pointer(&s[0]))
+	}
+	var up C.int64_t
+	rc := C.aud_melspec_batch_live(p.h, &dev.h, ptr(sig), C.int64_t(len(sig)), (*C.aud_item)(unsafe.Pointer(&items[0])),
+		C.int(len(items)), ptr(mel), ptr(power), ptr(logPower), &up)
+	return dev, int64(up), status(p.ctx, rc)
+}
+
+// MelSpecMFCCLive is MelSpecMFCC on the live tensor sig through its resident copy (aud_melspec_mfcc_batch_live).
+func (p *Plan) MelSpecMFCCLive(dev *Signal, sig []float64, items []Item, mel, power, logPower, mfcc, deltas, deltaDeltas, energy []float64) (*Signal, int64, error) {
+	if dev == nil {
+		dev = &Signal{ctx: p.ctx}
+	}
+	if len(items) == 0 {
+		return dev, 0, nil
+	}
+	if len(mel) < len(items)*p.NFilters*p.Steps || len(mfcc) < len(items)*p.NCoefs*p.Steps || len(sig) == 0 {
+		return dev, 0, errors.New("auditory_hip: mel / mfcc buffer too small, or empty signal")
+	}
+	ptr := func(s []float64) *C.double {
+		if len(s) == 0 {
+			return nil
+		}
+		return (*C.double)(unsafe.Pointer(&s[0]))
+	}
+	var up C.int64_t
+	rc := C.aud_melspec_mfcc_batch_live(p.h, &dev.h, ptr(sig), C.int64_t(len(sig)), (*C.aud_item)(unsafe.Pointer(&items[0])),
+		C.int(len(items)), ptr(mel), ptr(power), ptr(logPower), ptr(mfcc), ptr(deltas), ptr(deltaDeltas), ptr(energy), &up)
+	return dev, int64(up), status(p.ctx, rc)
+}

@@ -90,9 +90,10 @@ type SndEnv struct {
 	derived auditoryhip.SoundParams // what Init derived (sample counts, steps)
 	// ProcessSegment runs once per segment on the SAME Signal, and the reference reads the LIVE tensor at every step
 	// (sndenv.go:455-478): the device keeps a copy between calls that is validated EXACTLY on every call.
-	//   zero values (default): a Signal of up to auditoryhip.ResidentAutoBytes is compared byte for byte with the host shadow
-	//       of the device copy (aud_signal_sync) -- any in-place edit is seen, only the differing span is uploaded; a larger
-	//       Signal is copied per call.
+	//   zero values (default): for a Signal of up to auditoryhip.ResidentAutoBytes every call compares what ITS frames read
+	//       (4 KB blocks) byte for byte with the host shadow of the device copy and uploads what differs
+	//       (aud_melspec_batch_live / aud_melspec_mfcc_batch_live) -- any in-place edit is seen by the call that reads it; a
+	//       larger Signal is copied per call.
 	//   ResidentSnapshot = true, or an explicit SignalToDevice(): the caller opts in to a SNAPSHOT it keeps current itself --
 	//       re-taken when Signal.Values is other memory or another length, SignalChanged() after an in-place edit.
 	//   HostSignalPerCall = true: copy per call, no resident copy at all.
@@ -367,38 +368,29 @@ func (se *SndEnv) SignalToDevice() (err error) {
 	return err
 }
 
-// resident: the device copy this call may read, holding exactly what se.Signal.Values holds (nil: copy per call)
-func (se *SndEnv) resident() *auditoryhip.Signal {
+// resident: how this call reads the Signal -- a snapshot (dev != nil, live false), the default live route (live true: the
+// aud_*_live calls compare what they read with the resident copy's shadow and upload what differs, as part of the call), or a
+// copy per call (nil, false)
+func (se *SndEnv) resident() (dev *auditoryhip.Signal, live bool) {
 	se.LastUploadedBytes = 0
 	n := len(se.Signal.Values)
 	if se.HostSignalPerCall || n == 0 {
-		return nil
+		return nil, false
 	}
 	if se.ResidentSnapshot || se.snapshot { // the opt-in: validated by identity only
 		if se.devSig == nil || se.snapData != &se.Signal.Values[0] || se.snapN != n {
 			if err := se.SignalToDevice(); err != nil {
 				fmt.Println(err)
-				return nil
+				return nil, false
 			}
 		}
-		return se.devSig
+		return se.devSig, false
 	}
 	if 8*n > auditoryhip.ResidentAutoBytes {
 		se.dropResident()
-		return nil
+		return nil, false
 	}
-	if se.ctx == nil {
-		return nil
-	}
-	sig, up, err := se.ctx.SyncSignal(se.devSig, se.Signal.Values) // exact: memcmp against the shadow, upload what differs
-	if err != nil {
-		fmt.Println(err)
-		sig.Close()
-		se.devSig = nil
-		return nil
-	}
-	se.devSig, se.LastUploadedBytes = sig, up
-	return sig
+	return se.devSig, true // (devSig may still be nil: the first live call creates it)
 }
 
 func (se *SndEnv) item(segment, add int) auditoryhip.Item {
@@ -419,10 +411,14 @@ func (se *SndEnv) ProcessSegment(segment, add int) {
 		fmt.Println(err)
 		return
 	}
-	dev := se.resident()
+	dev, live := se.resident()
 	resident := dev != nil
 	if se.Mel.MFCC && se.DFT.CompLogPow { // (the MFCC tail reads LogPowerSegment: include/auditory.hpp takes the same branch)
-		if resident {
+		if live {
+			se.devSig, se.LastUploadedBytes, err = plan.MelSpecMFCCLive(dev, se.Signal.Values, items, se.MelFBankSegment.Values,
+				se.PowerSegment.Values, se.LogPowerSegment.Values, se.MFCCSegment.Values, se.MFCCDeltas.Values,
+				se.MFCCDeltaDeltas.Values, se.Energy.Values)
+		} else if resident {
 			err = plan.MelSpecMFCCSig(dev, items, se.MelFBankSegment.Values, se.PowerSegment.Values,
 				se.LogPowerSegment.Values, se.MFCCSegment.Values, se.MFCCDeltas.Values, se.MFCCDeltaDeltas.Values, se.Energy.Values)
 		} else {
@@ -430,7 +426,10 @@ func (se *SndEnv) ProcessSegment(segment, add int) {
 				se.LogPowerSegment.Values, se.MFCCSegment.Values, se.MFCCDeltas.Values, se.MFCCDeltaDeltas.Values, se.Energy.Values)
 		}
 	} else {
-		if resident {
+		if live {
+			se.devSig, se.LastUploadedBytes, err = plan.MelSpecLive(dev, se.Signal.Values, items, se.MelFBankSegment.Values,
+				se.PowerSegment.Values, se.LogPowerSegment.Values)
+		} else if resident {
 			err = plan.MelSpecSig(dev, items, se.MelFBankSegment.Values, se.PowerSegment.Values, se.LogPowerSegment.Values)
 		} else {
 			err = plan.MelSpec(se.Signal.Values, items, se.MelFBankSegment.Values, se.PowerSegment.Values, se.LogPowerSegment.Values)
@@ -463,7 +462,12 @@ func (se *SndEnv) ProcessSegments(first, n, add int, mel []float64) error {
 	if err != nil {
 		return err
 	}
-	if dev := se.resident(); dev != nil {
+	dev, live := se.resident()
+	if live {
+		se.devSig, se.LastUploadedBytes, err = plan.MelSpecLive(dev, se.Signal.Values, items, mel, nil, nil)
+		return err
+	}
+	if dev != nil {
 		return plan.MelSpecSig(dev, items, mel, nil, nil)
 	}
 	return plan.MelSpec(se.Signal.Values, items, mel, nil, nil)

@@ -277,9 +277,9 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
     aud_plan_desc plan_desc_{};  // what `plan` was created from (ensure_plan)
     // ProcessSegment runs once per segment on the SAME Signal, and the reference reads the LIVE tensor at every step
     // (sndenv.go:455-478): the device keeps a copy between calls that is validated EXACTLY on every call.
-    //   Residency = Auto (default): a Signal of up to AUD_RESIDENT_AUTO_BYTES is compared byte for byte with the host shadow of
-    //       the device copy (aud_signal_sync) -- any in-place edit is seen, only the differing span is uploaded; a larger one
-    //       is copied per call.
+    //   Residency = Auto (default): for a Signal of up to AUD_RESIDENT_AUTO_BYTES every call compares what ITS frames read (4 KB
+    //       blocks) byte for byte with the host shadow of the device copy and uploads what differs (aud_melspec_batch_live /
+    //       aud_melspec_mfcc_batch_live) -- any in-place edit is seen by the call that reads it; a larger one is copied per call.
     //   Residency = Snapshot, or an explicit SignalToDevice(): the caller opts in to a snapshot it keeps current itself --
     //       re-taken when Signal.Values is other memory or another length, SignalChanged() after an in-place edit.
     //   Residency = PerCall: copy per call.
@@ -311,8 +311,9 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
         last_uploaded_bytes = int64_t(snap_n_ * 8);
         return true;
     }
-    bool resident() {  // true: dev_sig_ holds exactly what this call must read
+    bool resident() {  // true: dev_sig_ holds (snapshot) or will hold (live_) exactly what this call must read
         last_uploaded_bytes = 0;
+        live_ = false;
         if (Residency == PerCall || Signal.Values.empty()) return false;
         if (Residency == Snapshot || snapshot_) {
             if (!dev_sig_ || snap_data_ != Signal.Values.data() || snap_n_ != Signal.Values.size()) return SignalToDevice();
@@ -322,10 +323,10 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
             drop_resident();
             return false;
         }
-        if (ensure_ctx() != AUD_OK) return false;
-        return aud_signal_sync(default_ctx(), &dev_sig_, Signal.Values.data(), AUD_F64, int64_t(Signal.Values.size()),
-                               &last_uploaded_bytes) == AUD_OK;
+        live_ = true;  // the aud_*_live calls validate what they read, exactly, as part of the call
+        return true;
     }
+    bool live_ = false;  // set by resident(): this call goes through aud_melspec_batch_live / aud_melspec_mfcc_batch_live
 
     void ParamDefaults() {  // sndenv.go:64-71
         aud_sound_params c{};
@@ -432,13 +433,18 @@ struct SndEnv {  // sound/sndenv.go:73-182 (hot-path fields)
         if (Mel.MFCC && DFT.CompLogPow) {  // the MFCC tail of the loop too: CepstrumDct, Energy, deltas (:360-432)
             double* dl = Mel.Deltas ? MFCCDeltas.Values.data() : nullptr;
             double* ddl = Mel.Deltas ? MFCCDeltaDeltas.Values.data() : nullptr;
-            rc = resident ? aud_melspec_mfcc_batch_sig(plan.p, dev_sig_, &it, 1, MelFBankSegment.Values.data(), PowerSegment.Values.data(),
+            rc = live_ ? aud_melspec_mfcc_batch_live(plan.p, &dev_sig_, Signal.Values.data(), int64_t(Signal.Values.size()), &it, 1,
+                                                     MelFBankSegment.Values.data(), PowerSegment.Values.data(), lp,
+                                                     MFCCSegment.Values.data(), dl, ddl, Energy.Values.data(), &last_uploaded_bytes)
+                 : resident ? aud_melspec_mfcc_batch_sig(plan.p, dev_sig_, &it, 1, MelFBankSegment.Values.data(), PowerSegment.Values.data(),
                                                        lp, MFCCSegment.Values.data(), dl, ddl, Energy.Values.data())
                           : aud_melspec_mfcc_batch_host(plan.p, Signal.Values.data(), int64_t(Signal.Values.size()), &it, 1,
                                                         MelFBankSegment.Values.data(), PowerSegment.Values.data(), lp,
                                                         MFCCSegment.Values.data(), dl, ddl, Energy.Values.data());
         } else {
-            rc = resident ? aud_melspec_batch_sig(plan.p, dev_sig_, &it, 1, MelFBankSegment.Values.data(), PowerSegment.Values.data(), lp)
+            rc = live_ ? aud_melspec_batch_live(plan.p, &dev_sig_, Signal.Values.data(), int64_t(Signal.Values.size()), &it, 1,
+                                                MelFBankSegment.Values.data(), PowerSegment.Values.data(), lp, &last_uploaded_bytes)
+                 : resident ? aud_melspec_batch_sig(plan.p, dev_sig_, &it, 1, MelFBankSegment.Values.data(), PowerSegment.Values.data(), lp)
                           : aud_melspec_batch_host(plan.p, Signal.Values.data(), int64_t(Signal.Values.size()), &it, 1,
                                                    MelFBankSegment.Values.data(), PowerSegment.Values.data(), lp);
         }

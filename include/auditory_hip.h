@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AUD_VERSION 200 /* 0.2.0: AUD_F64 is 0 (a zero-initialised aud_plan_desc is the float64 plan), AUD_F32 is 1 */
+#define AUD_VERSION 210 /* 0.2.1: + aud_signal_sync, aud_melspec_batch_live, aud_melspec_mfcc_batch_live (0.2.0: AUD_F64 is 0 -- a zero-initialised aud_plan_desc is the float64 plan --, AUD_F32 is 1) */
 
 /* status codes */
 #define AUD_OK 0
@@ -357,6 +357,17 @@ int64_t aud_signal_len(const aud_signal* sig);
 #define AUD_RESIDENT_AUTO_BYTES (8 << 20)
 int aud_signal_sync(aud_ctx* ctx, aud_signal** sig, const void* samples, int sample_dtype, int64_t n_samples,
                     int64_t* uploaded_bytes);
+/* SndEnv.ProcessSegment on the LIVE Signal tensor (sound/sndenv.go:342-359, :455-478) in ONE call: aud_signal_sync restricted to
+ * the 4 KB blocks the frames of `items` read under this plan (start0 - S Border ... start0 + S (T - 1 - Border) + N of each
+ * stream), then aud_melspec_batch_sig / aud_melspec_mfcc_batch_sig on the resident copy.  The result is exactly what the
+ * copy-per-call entries give on `samples` as they are NOW; the cost of being exact is a compare of what the call reads -- 16 KB
+ * for one 100 ms segment of a sound, whatever the sound's length -- and an edit elsewhere in the tensor is found by the call
+ * that reads it.  *sig as in aud_signal_sync (NULL at first); samples: float64 [n_samples], the Signal tensor's Values. */
+int aud_melspec_batch_live(aud_plan* plan, aud_signal** sig, const double* samples, int64_t n_samples, const aud_item* items,
+                           int n_items, double* mel, double* power, double* log_power, int64_t* uploaded_bytes);
+int aud_melspec_mfcc_batch_live(aud_plan* plan, aud_signal** sig, const double* samples, int64_t n_samples,
+                                const aud_item* items, int n_items, double* mel, double* power, double* log_power,
+                                double* mfcc, double* deltas, double* delta_deltas, double* energy, int64_t* uploaded_bytes);
 /* aud_melspec_batch_host / aud_melspec_mfcc_batch_host on a resident signal (items index ITS samples) */
 int aud_melspec_batch_sig(aud_plan* plan, const aud_signal* sig, const aud_item* items, int n_items, double* mel,
                           double* power, double* log_power);

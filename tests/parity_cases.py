@@ -923,33 +923,56 @@ def case_sndenv_resident_signal_staleness(orc):
     assert first is not None and first.uploaded_bytes == 8000 * 8   # taken by the first call, without opting in
     check(se, sig[0], "second call")
     assert se._dev_sig is first and first.uploaded_bytes == 0       # ... kept, and nothing crossed the link
+    # a call compares the 4 KB blocks ITS frames read: segment 1 of this parameter set reads samples 1280 .. 3759 = bytes
+    # 10240 .. 30079 = blocks 2 .. 7
     se.Signal = sig[1].copy()                           # another tensor of the SAME length
     check(se, sig[1], "replaced tensor")
-    assert first.uploaded_bytes == 8000 * 8
+    assert first.uploaded_bytes == 6 * 4096
     se.Signal[:] = sig[2]                               # in place: every sample changes
     check(se, sig[2], "in-place overwrite")
-    # ---- the case the sampled fingerprint of round 5 missed: ONE sample, in place, NOT announced.  Segment 1 of this
-    # parameter set covers samples 1280 .. 3759: edit one inside it, one in its first frame's left neighbourhood, the last
-    # sample of a 4 KB compare block and the first of the next
+    assert first.uploaded_bytes == 6 * 4096
+    # ---- the case the sampled fingerprint of round 5 missed: ONE sample, in place, NOT announced
     before = check(se, se.Signal, "before the edits")
-    for pos, delta in ((1601, 0.25), (3000, -0.125), (511, 0.5), (512, 0.5), (7999, 0.25)):
+    assert first.uploaded_bytes == 0
+    for pos, delta in ((1601, 0.25), (3000, -0.125), (1280, 0.5), (3759, 0.5)):       # inside the segment, first and last sample too
         se.Signal[pos] += delta
         got = check(se, se.Signal, "one-sample edit at %d without SignalChanged()" % pos)
-        assert first.uploaded_bytes in (4096, 8000 * 8 % 4096), (pos, first.uploaded_bytes)   # one compare block went up
-        if 1280 <= pos < 3760:
-            assert not np.array_equal(got, before), "the edit at %d did not reach the device" % pos
-            before = got
-    z = se.Signal[4000]
-    se.Signal[4000] = 0.0
+        assert first.uploaded_bytes == 4096, (pos, first.uploaded_bytes)              # its compare block went up, nothing else
+        assert not np.array_equal(got, before), "the edit at %d did not reach the device" % pos
+        before = got
+    # edits OUTSIDE the blocks segment 1 reads (blocks 2 .. 7 = samples 1024 .. 4095) cost this call nothing and change nothing ...
+    for pos in (511, 512, 1023, 4097, 7999):
+        se.Signal[pos] += 0.375
+    got = check(se, se.Signal, "edits outside the segment's blocks")
+    assert first.uploaded_bytes == 0 and np.array_equal(got, before)
+    se.Signal[1279] += 0.375                            # not read by the segment, but in its first block: uploaded, no effect
+    got = check(se, se.Signal, "edit beside the segment")
+    assert first.uploaded_bytes == 4096 and np.array_equal(got, before)
+    # ... and are found by the calls that read them -- as is the rest of the in-place overwrite above, of which segment 1's calls
+    # took only blocks 2 .. 7: segment 0 reads blocks 0 .. 4, segment 2 blocks 5 .. 10, segment 4 blocks 11 .. 15 (the last partial)
+    check(se, se.Signal, "segment 0 after edits in its span", seg=0)
+    assert first.uploaded_bytes == 2 * 4096             # blocks 0 and 1
+    check(se, se.Signal, "segment 2", seg=2)
+    assert first.uploaded_bytes == 3 * 4096             # blocks 8 .. 10
+    check(se, se.Signal, "segment 4 (the signal's tail)", seg=4)
+    assert first.uploaded_bytes == 64000 - 11 * 4096    # blocks 11 .. 15, sample 7999 in the last, partial one
+    se.Signal[4096] += 0.375                            # (first sample of block 8)
+    check(se, se.Signal, "segment 2 again", seg=2)
+    assert first.uploaded_bytes == 4096
+    for seg in range(5):
+        check(se, se.Signal, "everything current", seg=seg)
+        assert first.uploaded_bytes == 0
+    z = se.Signal[2000]
+    se.Signal[2000] = 0.0
     check(se, se.Signal, "zeroed sample")
-    se.Signal[4000] = -0.0                              # equal as a value, different bytes: re-uploaded all the same
+    se.Signal[2000] = -0.0                              # equal as a value, different bytes: re-uploaded all the same
     check(se, se.Signal, "minus zero")
     assert first.uploaded_bytes == 4096
-    se.Signal[4000] = z
+    se.Signal[2000] = z
     off = se.AdjustForSilence(30.0, 10.0)               # prepends 20 ms of zeros: another tensor, another length
     assert off == 20 and len(se.Signal) == 8000 + 320
     check(se, se.Signal, "AdjustForSilence")
-    assert first.uploaded_bytes == 8320 * 8
+    assert first.uploaded_bytes == 8320 * 8             # another length: everything
     assert se.Init() is None and se._dev_sig is None    # Init drops the copy (SegCnt etc. are re-derived)
     check(se, se.Signal, "after Init")
     # ---- the opt-in snapshot: identity-keyed, SignalChanged() for in-place edits

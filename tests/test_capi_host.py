@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     nm = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH]).decode()
     exported = set(re.findall(r" T (aud_[a-z0-9_]+)", nm))
     assert set(declared) <= exported
-    assert lib.aud_version() == 200
+    assert lib.aud_version() == 210
     assert lib.aud_status_string(capi.AUD_EINVAL).decode().startswith("invalid")
 
 
@@ -254,7 +254,7 @@ int main(void) {
     subprocess.check_call(["gcc", "-std=c99", "-I" + inc, str(src), "-o", exe, "-L" + libdir, "-lauditory_hip",
                            "-Wl,-rpath," + libdir])
     out = subprocess.run([exe], capture_output=True, text=True)
-    assert out.returncode == 0 and out.stdout.startswith("C-ABI-OK 200 200"), out.stdout + out.stderr
+    assert out.returncode == 0 and out.stdout.startswith("C-ABI-OK 210 210"), out.stdout + out.stderr
 
 
 @pytest.mark.parametrize("depth", [8, 16, 24, 32])

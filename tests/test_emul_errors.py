@@ -132,6 +132,56 @@ def test_resident_signal_argument_errors(orc, emu):
     plan.close()
 
 
+def test_signal_sync_and_live_argument_errors(orc, emu):
+    """aud_signal_sync / aud_melspec_batch_live / aud_melspec_mfcc_batch_live: misuse is a status code, nothing is written;
+    the handle lives across type and length changes; a destroyed or foreign handle is refused"""
+    oc = W.OracleCfg(orc, "sndenv_16k_n400_nf32")
+    plan = W.product_plan(oc)
+    lib, h, ctx = plan.lib, plan.handle, plan.ctx.handle
+    sig = np.linspace(-0.5, 0.5, 4000)
+    hs, up = C.c_void_p(), C.c_int64(-1)
+    assert lib.aud_signal_sync(ctx, None, _vp(sig), capi.AUD_F64, 4000, C.byref(up)) == capi.AUD_EINVAL      # no handle slot
+    assert lib.aud_signal_sync(None, C.byref(hs), _vp(sig), capi.AUD_F64, 4000, C.byref(up)) == capi.AUD_EINVAL
+    assert lib.aud_signal_sync(ctx, C.byref(hs), _vp(sig), 9, 4000, C.byref(up)) == capi.AUD_EINVAL          # bad sample type
+    assert lib.aud_signal_sync(ctx, C.byref(hs), None, capi.AUD_F64, 4000, C.byref(up)) == capi.AUD_EINVAL   # null samples
+    assert lib.aud_signal_sync(ctx, C.byref(hs), _vp(sig), capi.AUD_F64, -3, C.byref(up)) == capi.AUD_EINVAL
+    assert not hs.value and up.value == 0
+    assert lib.aud_signal_sync(ctx, C.byref(hs), _vp(sig), capi.AUD_F64, 4000, C.byref(up)) == capi.AUD_OK and hs.value
+    assert up.value == 32000 and lib.aud_signal_len(hs) == 4000
+    assert lib.aud_signal_sync(ctx, C.byref(hs), _vp(sig), capi.AUD_F64, 4000, None) == capi.AUD_OK          # (the count is optional)
+    first = hs.value
+    s32 = sig.astype(np.float32)                                                                             # another type, same handle
+    assert lib.aud_signal_sync(ctx, C.byref(hs), _vp(s32), capi.AUD_F32, 4000, C.byref(up)) == capi.AUD_OK
+    assert hs.value == first and up.value == 16000
+    assert lib.aud_signal_sync(ctx, C.byref(hs), _vp(sig), capi.AUD_F64, 3000, C.byref(up)) == capi.AUD_OK and up.value == 24000
+    assert lib.aud_signal_len(hs) == 3000
+    items = runtime.make_items([0], [3000], [0])
+    mel = np.full((1, 32, 14), 7.0)
+    assert lib.aud_melspec_batch_live(h, None, _vp(sig), 3000, _vp(items), 1, _vp(mel), None, None, None) == capi.AUD_EINVAL
+    assert lib.aud_melspec_batch_live(h, C.byref(hs), None, 3000, _vp(items), 1, _vp(mel), None, None, None) == capi.AUD_EINVAL
+    assert lib.aud_melspec_batch_live(h, C.byref(hs), _vp(sig), 3000, None, 1, _vp(mel), None, None, None) == capi.AUD_EINVAL
+    assert lib.aud_melspec_batch_live(h, C.byref(hs), _vp(sig), 3000, _vp(items), 1, None, None, None, None) == capi.AUD_EINVAL
+    bad = runtime.make_items([1], [3000], [0])                                                               # one sample past the end
+    assert lib.aud_melspec_batch_live(h, C.byref(hs), _vp(sig), 3000, _vp(bad), 1, _vp(mel), None, None, C.byref(up)) == capi.AUD_EINVAL
+    assert b"outside" in lib.aud_last_error(ctx) and up.value == 0
+    # the MFCC form on a plan created without mfcc_coefs
+    assert lib.aud_melspec_mfcc_batch_live(h, C.byref(hs), _vp(sig), 3000, _vp(items), 1, _vp(mel), None, None, _vp(mel), None, None,
+                                           None, None) == capi.AUD_EINVAL
+    assert (mel == 7.0).all()
+    assert lib.aud_melspec_batch_live(h, C.byref(hs), _vp(sig), 3000, _vp(items), 0, None, None, None, None) == capi.AUD_OK   # empty batch
+    assert lib.aud_melspec_batch_live(h, C.byref(hs), _vp(sig), 3000, _vp(items), 1, _vp(mel), None, None, C.byref(up)) == capi.AUD_OK
+    assert up.value == 0 and not (mel == 7.0).any()                                                          # current: nothing moved
+    assert lib.aud_signal_destroy(hs) == capi.AUD_OK
+    dead = C.c_void_p(first)                                                                                 # a destroyed handle is refused
+    assert lib.aud_signal_sync(ctx, C.byref(dead), _vp(sig), capi.AUD_F64, 3000, None) == capi.AUD_EINVAL
+    assert lib.aud_melspec_batch_live(h, C.byref(dead), _vp(sig), 3000, _vp(items), 1, _vp(mel), None, None, None) == capi.AUD_EINVAL
+    # a fresh slot works again, from a live call alone
+    hs = C.c_void_p()
+    assert lib.aud_melspec_batch_live(h, C.byref(hs), _vp(sig), 3000, _vp(items), 1, _vp(mel), None, None, C.byref(up)) == capi.AUD_OK
+    assert hs.value and up.value == 24000 and lib.aud_signal_destroy(hs) == capi.AUD_OK
+    plan.close()
+
+
 def test_process_batch_rejects_before_writing(orc, emu):
     """aud_process_batch_dev with pools that reach past the mel matrix (the Go code would panic in Convolve):
     AUD_EINVAL and NOTHING written -- the mel tensor included -- on the two-launch path and on the fused one"""

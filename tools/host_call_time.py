@@ -14,7 +14,11 @@ and, round 6, what the DEFAULT of the SndEnv mirrors costs per sound -- the resi
 (aud_signal_sync: memcmp against a host shadow) -- one ProcessSegment call on one 3 s sound (SndEnv defaults: 100 ms segments):
   sound_snapshot   the _sig call alone on a snapshot (the opt-in)
   sound_r5_default round 5's default: the 64-sample fingerprint in Python, then the call on the snapshot
-  sound_sync       aud_signal_sync on the unchanged tensor + the same call: the round-6 default
+  sound_live       aud_melspec_batch_live: ONE call that compares the 4 KB blocks the segment's frames read with the resident
+                   copy's shadow, uploads what differs, and runs -- the mirrors' default
+  sound_live_edit  ... with one sample of the segment edited before every call (one block goes up)
+  sound_sync       aud_signal_sync over the WHOLE unchanged tensor + the _sig call (two calls; what a caller gets who wants
+                   every edit uploaded at once)
   sound_sync_edit  ... with one sample edited before every call (one 4 KB block goes up)
   sound_per_call   the tensor copied in on every call
   sync_8MB         aud_signal_sync alone on an unchanged tensor of AUD_RESIDENT_AUTO_BYTES (the largest the default validates)"""
@@ -124,13 +128,32 @@ ref1 = plan1.melspec_host(snd, one, True, True)
 plan1.melspec_sig(live, one, out=out1)
 assert all(np.array_equal(a, b) for a, b in zip(ref1, out1))       # the edited tensor's features, without any announcement
 r1["sound_per_call"] = timed(lambda: plan1.melspec_host(snd, one, True, True), reps=200, warm=20)
+# the default of the mirrors since the second half of round 6: ONE call that compares only the blocks the segment's frames read
+lv = runtime.Signal(plan1.ctx)
+plan1.melspec_live(lv, snd, one, out=out1)
+r1["sound_live"] = timed(lambda: plan1.melspec_live(lv, snd, one, out=out1), reps=200, warm=20)
+assert lv.uploaded_bytes == 0
+
+
+def live_edited():
+    k[0] += 1
+    snd[17000 + k[0]] += 1e-3
+    plan1.melspec_live(lv, snd, one, out=out1)
+
+
+r1["sound_live_edit"] = timed(live_edited, reps=200, warm=20)
+assert lv.uploaded_bytes in (4096, 8192)
+ref1 = plan1.melspec_host(snd, one, True, True)
+assert all(np.array_equal(a, b) for a, b in zip(ref1, out1))
 big = np.zeros(capi.AUD_RESIDENT_AUTO_BYTES // 8)
 big[::7] = 0.25
 bsig = runtime.Signal(plan1.ctx)
 bsig.sync(big)
 r1["sync_8MB"] = timed(lambda: bsig.sync(big), reps=50, warm=5)
 print("one 3 s sound (384 KB of float64), one 100 ms segment per call (mel + PowerSegment + LogPowerSegment out):")
-for k_ in ("sound_snapshot", "sound_r5_default", "sound_sync", "sound_sync_edit", "sound_per_call", "sync_8MB"):
+for k_ in ("sound_snapshot", "sound_r5_default", "sound_live", "sound_live_edit", "sound_sync", "sound_sync_edit", "sound_per_call", "sync_8MB"):
     print("  %-16s %.1f us per call" % (k_, r1[k_] * 1e6))
-print("  exact residency: %+.1f %% against the bare snapshot call, %+.1f %% against round 5's default (sampled fingerprint + call)"
-      % (100.0 * (r1["sound_sync"] / r1["sound_snapshot"] - 1.0), 100.0 * (r1["sound_sync"] / r1["sound_r5_default"] - 1.0)))
+print("  exact residency (sound_live, the mirrors' default): %+.1f %% against the bare snapshot call, %+.1f %% against round 5's default "
+      "(sampled fingerprint + call); comparing the WHOLE tensor per call (sound_sync): %+.1f %% / %+.1f %%"
+      % (100.0 * (r1["sound_live"] / r1["sound_snapshot"] - 1.0), 100.0 * (r1["sound_live"] / r1["sound_r5_default"] - 1.0),
+         100.0 * (r1["sound_sync"] / r1["sound_snapshot"] - 1.0), 100.0 * (r1["sound_sync"] / r1["sound_r5_default"] - 1.0)))
