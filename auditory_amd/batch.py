@@ -178,6 +178,11 @@ class DirectGather:
         self.ctx.check(self.lib.aud_gather_timeouts(self.ctx.handle, C.byref(n)))
         return n.value
 
+    def flags_fine(self):
+        """1: the arrival flags live in fine-grained (coherent) device memory; 0: ordinary device memory (only with
+        AUD_GATHER_COARSE_FLAGS=1 in the environment)"""
+        return int(self.lib.aud_gather_flags_fine(self.ctx.handle))
+
     def recv(self, device):
         """the receive area as a [2, n_ranks, slab_floats] float32 tensor (no copy): slab `allgather()` returned"""
         if torch.device(device).type == "cpu":  # (tests' CPU thread-emulator build: "device" memory is host memory)

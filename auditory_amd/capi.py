@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libauditory_hip.so")
 
-AUD_OK, AUD_EINVAL, AUD_EHIP, AUD_ERCCL, AUD_ENOMEM, AUD_ESHORT = 0, 1, 2, 3, 4, 5
+AUD_OK, AUD_EINVAL, AUD_EHIP, AUD_ERCCL, AUD_ENOMEM, AUD_ESHORT, AUD_EBROKEN = 0, 1, 2, 3, 4, 5, 6
 AUD_RESIDENT_AUTO_BYTES = 8 << 20   # include/auditory_hip.h
 AUD_F64, AUD_F32, AUD_I16 = 0, 1, 2   # AUD_F64 == 0: a zeroed PlanDesc is the float64 (conforming) plan
 AUD_FAST_F32 = AUD_F32                # compute_dtype opt-in: the float32 kernels (never a default)
@@ -152,6 +152,7 @@ SYMBOLS = {
     "aud_allgather_direct_dev": (C.c_int, [_VP, _VP, C.c_int64, C.POINTER(C.c_int), _VP]),
     "aud_gather_wait_dev": (C.c_int, [_VP, _VP]),
     "aud_gather_timeouts": (C.c_int, [_VP, C.POINTER(C.c_int)]),
+    "aud_gather_flags_fine": (C.c_int, [_VP]),
     "aud_gather_destroy": (C.c_int, [_VP]),
 }
 

@@ -39,18 +39,91 @@ __global__ void k_gather_signal(unsigned* peer_flag, const unsigned* step) {
     __hip_atomic_store(peer_flag, *step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// one lane per peer polls that peer's flag until it has reached this rank's step (every rank makes the same calls, so the
-// counters run in lockstep); the poll count is bounded: a peer that never arrives is counted and the kernel ENDS
-__global__ void k_gather_wait(const unsigned* flags, const unsigned* step, unsigned* timeouts, int n_ranks, int rank, long long max_polls) {
+// One lane per peer polls that peer's flag until it has reached this rank's step (every rank makes the same calls, so the
+// counters run in lockstep).  The poll count is bounded: a peer that never arrives is counted and the kernel ENDS -- but not
+// quietly: the late peers' slots of the step's slab are filled with NaN (whatever is queued behind this wait then computes NaN
+// instead of plausible numbers from a stale slab), and a status word in host-mapped memory tells the next library call, which
+// refuses to go on (AUD_EBROKEN) without having to synchronise anything.
+__global__ void k_gather_wait(const unsigned* flags, const unsigned* step, unsigned* timeouts, volatile unsigned* host_status,
+                              float* recv, long long slab, int n_ranks, int rank, long long max_polls) {
+    int* late = reinterpret_cast<int*>(aud::dyn_lds());  // [kMaxGatherRanks] (dynamic LDS: the launch gives it)
     const int p = int(threadIdx.x);
-    if (p >= n_ranks || p == rank) return;
     const unsigned want = *step;
-    for (long long i = 0; i < max_polls; ++i) {
+    const bool mine = p < n_ranks && p != rank;
+    bool arrived = !mine;
+    for (long long i = 0; mine && i < max_polls; ++i) {
         const unsigned v = __hip_atomic_load(flags + size_t(p) * kFlagPitch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (int(v - want) >= 0) return;
+        if (int(v - want) >= 0) {
+            arrived = true;
+            break;
+        }
         __builtin_amdgcn_s_sleep(32);
     }
-    atomicAdd(timeouts, 1u);
+    late[p] = arrived ? 0 : 1;
+    if (!arrived) atomicAdd(timeouts, 1u);
+    __syncthreads();
+    unsigned mask_lo = 0, mask_hi = 0;
+    for (int q = 0; q < n_ranks; ++q)
+        if (late[q]) (q < 32 ? mask_lo : mask_hi) |= 1u << (q & 31);
+    if ((mask_lo | mask_hi) == 0) return;  // the common case: every peer's slab of this step is here
+    const int which = int((want - 1u) & 1u);  // the slab this step uses (aud_allgather_direct_dev: calls & 1 before the increment)
+    const float poison = __builtin_nanf("");
+    for (int q = 0; q < n_ranks; ++q) {
+        if (!late[q]) continue;
+        float* slot = recv + (size_t(which) * size_t(n_ranks) + size_t(q)) * size_t(slab);
+        for (long long i = p; i < slab; i += kMaxGatherRanks) slot[i] = poison;
+    }
+    if (p == 0) {
+        host_status[1] = mask_lo;
+        host_status[2] = mask_hi;
+        __threadfence_system();
+        host_status[0] = want ? want : 1u;  // non-zero: sticky
+        __threadfence_system();
+    }
+}
+
+// the gather's sticky failure state, checked (and refreshed from the host-mapped status word) at the top of every per-step call
+int gather_usable(aud_ctx* c) {
+    aud_ctx::Gather& g = c->gather;
+    if (!g.broken && g.host_status && g.host_status[0] != 0) {
+        g.broken = true;
+        char buf[160];
+        std::snprintf(buf, sizeof(buf), "direct gather: the wait of step %u ran into its poll bound (late peers: mask 0x%08x%08x); their "
+                                        "slots were filled with NaN", g.host_status[0], g.host_status[2], g.host_status[1]);
+        g.broken_why = buf;
+    }
+    if (g.broken) return fail(c, AUD_EBROKEN, g.broken_why + " -- aud_gather_destroy / aud_gather_create to go on");
+    return AUD_OK;
+}
+
+int gather_break(aud_ctx* c, const std::string& why) {
+    c->gather.broken = true;
+    c->gather.broken_why = why;
+    return fail(c, AUD_EBROKEN, why);
+}
+
+// calls of the current stream capture: an odd number in a finished capture breaks the slab alternation across its replays
+int gather_note_capture(aud_ctx* c, hipStream_t st) {
+    aud_ctx::Gather& g = c->gather;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    if (hipStreamGetCaptureInfo(st, &cs, &id) != hipSuccess) {
+        (void)hipGetLastError();
+        cs = hipStreamCaptureStatusNone;
+    }
+    const bool capturing = cs == hipStreamCaptureStatusActive;
+    if (g.cap_id != 0 && (!capturing || id != g.cap_id)) {  // the previous capture sequence is over
+        const unsigned n = g.cap_calls;
+        g.cap_id = 0;
+        g.cap_calls = 0;
+        if (n & 1u) return gather_break(c, "direct gather: a captured sequence held an ODD number of steps (" + std::to_string(n) +
+                                               "): its replays would not alternate between the two receive slabs");
+    }
+    if (capturing) {
+        g.cap_id = id;
+        g.cap_calls += 1;
+    }
+    return AUD_OK;
 }
 }  // namespace
 
@@ -109,13 +182,20 @@ int aud_gather_create(aud_ctx* c, int n_ranks, int rank, int64_t slab_floats, fl
     AUD_HIP(c, make_current(c));
     aud_ctx::Gather& g = c->gather;
     AUD_HIP(c, hipMalloc(reinterpret_cast<void**>(&g.recv), size_t(2) * size_t(n_ranks) * size_t(slab_floats) * sizeof(float)));
-    // the flags are polled by this GPU while peers store into them over xGMI: fine-grained (coherent) memory where the
-    // runtime has it for exportable allocations, plain device memory otherwise (the accesses are system-scope atomics)
+    // the flags are polled by this GPU while peers store into them over xGMI: fine-grained (coherent) memory.  Ordinary device
+    // memory is cached in this GPU's L2, where a peer's store is not guaranteed to become visible to the poll: only on request
     const size_t flag_bytes = size_t(n_ranks + 2) * kFlagPitch * sizeof(unsigned);
     g.flags_fine = hipExtMallocWithFlags(reinterpret_cast<void**>(&g.flags), flag_bytes, hipDeviceMallocFinegrained) == hipSuccess;
     if (!g.flags_fine) {
         (void)hipGetLastError();
         g.flags = nullptr;
+        const char* coarse = getenv("AUD_GATHER_COARSE_FLAGS");
+        if (!coarse || atoi(coarse) != 1) {
+            (void)hipFree(g.recv);
+            g.recv = nullptr;
+            return fail(c, AUD_EHIP, "direct gather: no fine-grained device memory for the arrival flags (hipExtMallocWithFlags "
+                                     "hipDeviceMallocFinegrained failed); AUD_GATHER_COARSE_FLAGS=1 takes ordinary device memory");
+        }
         if (hipMalloc(reinterpret_cast<void**>(&g.flags), flag_bytes) != hipSuccess) {
             (void)hipGetLastError();
             (void)hipFree(g.recv);
@@ -125,25 +205,34 @@ int aud_gather_create(aud_ctx* c, int n_ranks, int rank, int64_t slab_floats, fl
     }
     hipIpcMemHandle_t h[2];
     static_assert(sizeof(h[0]) == 64, "hipIpcMemHandle_t is 64 bytes");
+    const char* what = "hipMemset (flag block)";
     hipError_t e = hipMemset(g.flags, 0, flag_bytes);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipIpcGetMemHandle(&h[0], g.recv);
-    if (e == hipSuccess) e = hipIpcGetMemHandle(&h[1], g.flags);
+    if (e == hipSuccess) { what = "hipDeviceSynchronize"; e = hipDeviceSynchronize(); }
+    if (e == hipSuccess) { what = "hipIpcGetMemHandle (receive area; HSA_ENABLE_IPC_MODE_LEGACY=0 set?)"; e = hipIpcGetMemHandle(&h[0], g.recv); }
+    if (e == hipSuccess) { what = "hipIpcGetMemHandle (flag block; HSA_ENABLE_IPC_MODE_LEGACY=0 set?)"; e = hipIpcGetMemHandle(&h[1], g.flags); }
+    void* hst = nullptr;
+    if (e == hipSuccess) { what = "hipHostMalloc (status word)"; e = hipHostMalloc(&hst, 64, hipHostMallocDefault); }
     if (e != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(g.recv);
         (void)hipFree(g.flags);
         g.recv = nullptr;
         g.flags = nullptr;
-        return fail(c, AUD_EHIP, "hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)");
+        return fail(c, AUD_EHIP, std::string("aud_gather_create: ") + what + ": " + hipGetErrorString(e));
     }
+    std::memset(hst, 0, 64);
+    g.host_status = static_cast<volatile unsigned*>(hst);
+    g.broken = false;
+    g.broken_why.clear();
+    g.cap_id = 0;
+    g.cap_calls = 0;
     std::memcpy(handle, h, 128);
     g.n_ranks = n_ranks;
     g.rank = rank;
     g.slab = slab_floats;
     g.calls = 0;
-    long long ms = 2000;
-    if (const char* env = getenv("AUD_GATHER_WAIT_MS")) ms = std::max(1LL, atoll(env));
+    long long ms = 30000;  // generous: a peer may be loading data, page-faulting or still capturing its graph; the variable
+    if (const char* env = getenv("AUD_GATHER_WAIT_MS")) ms = std::max(1LL, atoll(env));  // is there to SHORTEN it (tests) or lengthen it
     g.max_polls = ms * 400;  // a poll = one system-scope load + s_sleep: 2-3 us
     g.peer.assign(size_t(n_ranks), nullptr);
     g.peer[size_t(rank)] = g.recv;
@@ -199,31 +288,50 @@ int aud_allgather_direct_dev(aud_ctx* c, const float* send, int64_t count, int* 
     for (int p = 0; p < g.n_ranks; ++p)
         if (!g.peer[size_t(p)]) return fail(c, AUD_EINVAL, "a peer's receive buffer has not been opened");
     if (count > 0 && !send) return fail(c, AUD_EINVAL, "null buffer");
+    int rc = gather_usable(c);
+    if (rc != AUD_OK) return rc;
     AUD_HIP(c, make_current(c));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((rc = gather_note_capture(c, st)) != AUD_OK) return rc;
     const int which = int(g.calls & 1u);
-    g.calls += 1;
     if (slab_index) *slab_index = which;
     const size_t bytes = size_t(count) * sizeof(float);
     const size_t slot = (size_t(which) * size_t(g.n_ranks) + size_t(g.rank)) * size_t(g.slab);
     unsigned* step = g.flags + size_t(g.n_ranks) * kFlagPitch;
     // this rank's step number advances ON THE DEVICE (a captured call replays with the next numbers); own slot on the caller's
     // stream; one push per peer, each on its own stream (its own xGMI link) with the arrival signal behind it, forked from and
-    // joined back into the caller's stream
+    // joined back into the caller's stream.  From the first enqueue on a failure leaves the device-side step count (and
+    // possibly some pushes) ahead of the host's and of the peers': the gather is then BROKEN, not quietly out of step.
+    hipError_t e = hipSuccess;
+    const char* what = "k_gather_begin";
     hipLaunchKernelGGL(k_gather_begin, dim3(1), dim3(1), 0, st, step);
-    AUD_HIP(c, hipGetLastError());
-    if (bytes) AUD_HIP(c, hipMemcpyAsync(g.recv + slot, send, bytes, hipMemcpyDeviceToDevice, st));
-    if (g.n_ranks > 1) AUD_HIP(c, hipEventRecord(g.fork, st));
-    for (int p = 0; p < g.n_ranks; ++p) {
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(c, e, "aud_allgather_direct_dev: k_gather_begin");  // (nothing was queued: still usable)
+    auto step_ok = [&](hipError_t r, const char* w) {
+        if (e == hipSuccess && r != hipSuccess) {
+            e = r;
+            what = w;
+        }
+        return e == hipSuccess;
+    };
+    if (bytes) step_ok(hipMemcpyAsync(g.recv + slot, send, bytes, hipMemcpyDeviceToDevice, st), "copy into the own slot");
+    if (g.n_ranks > 1 && e == hipSuccess) step_ok(hipEventRecord(g.fork, st), "hipEventRecord (fork)");
+    for (int p = 0; p < g.n_ranks && e == hipSuccess; ++p) {
         if (p == g.rank) continue;
         hipStream_t sp = g.streams[size_t(p)];
-        AUD_HIP(c, hipStreamWaitEvent(sp, g.fork, 0));
-        if (bytes) AUD_HIP(c, hipMemcpyAsync(g.peer[size_t(p)] + slot, send, bytes, hipMemcpyDeviceToDevice, sp));
+        if (!step_ok(hipStreamWaitEvent(sp, g.fork, 0), "hipStreamWaitEvent (fork)")) break;
+        if (bytes && !step_ok(hipMemcpyAsync(g.peer[size_t(p)] + slot, send, bytes, hipMemcpyDeviceToDevice, sp), "push to a peer")) break;
         hipLaunchKernelGGL(k_gather_signal, dim3(1), dim3(1), 0, sp, g.peer_flags[size_t(p)] + size_t(g.rank) * kFlagPitch, step);
-        AUD_HIP(c, hipGetLastError());
-        AUD_HIP(c, hipEventRecord(g.done[size_t(p)], sp));
-        AUD_HIP(c, hipStreamWaitEvent(st, g.done[size_t(p)], 0));
+        if (!step_ok(hipGetLastError(), "k_gather_signal")) break;
+        if (!step_ok(hipEventRecord(g.done[size_t(p)], sp), "hipEventRecord (join)")) break;
+        step_ok(hipStreamWaitEvent(st, g.done[size_t(p)], 0), "hipStreamWaitEvent (join)");
     }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return gather_break(c, std::string("direct gather: ") + what + " failed behind the step's first enqueue (" + hipGetErrorString(e) +
+                                   "): this rank's step count no longer matches its peers'");
+    }
+    g.calls += 1;  // (only a step that was queued in full counts)
     return AUD_OK;
 }
 
@@ -231,11 +339,13 @@ int aud_gather_wait_dev(aud_ctx* c, void* stream) {
     if (!c) return AUD_EINVAL;
     aud_ctx::Gather& g = c->gather;
     if (!g.recv) return fail(c, AUD_EINVAL, "aud_gather_create has not been called");
+    int rc = gather_usable(c);
+    if (rc != AUD_OK) return rc;
     if (g.n_ranks == 1) return AUD_OK;
     AUD_HIP(c, make_current(c));
     unsigned* step = g.flags + size_t(g.n_ranks) * kFlagPitch;
-    hipLaunchKernelGGL(k_gather_wait, dim3(1), dim3(kMaxGatherRanks), 0, static_cast<hipStream_t>(stream), g.flags, step,
-                       step + kFlagPitch, g.n_ranks, g.rank, g.max_polls);
+    hipLaunchKernelGGL(k_gather_wait, dim3(1), dim3(kMaxGatherRanks), kMaxGatherRanks * sizeof(int), static_cast<hipStream_t>(stream), g.flags, step,
+                       step + kFlagPitch, g.host_status, g.recv, static_cast<long long>(g.slab), g.n_ranks, g.rank, g.max_polls);
     AUD_HIP(c, hipGetLastError());
     return AUD_OK;
 }
@@ -250,6 +360,11 @@ int aud_gather_timeouts(aud_ctx* c, int* n) {
     AUD_HIP(c, hipMemcpy(&v, g.flags + size_t(g.n_ranks + 1) * kFlagPitch, sizeof(v), hipMemcpyDeviceToHost));
     *n = int(v);
     return AUD_OK;
+}
+
+int aud_gather_flags_fine(aud_ctx* c) {
+    if (!c || !c->gather.recv) return -1;
+    return c->gather.flags_fine ? 1 : 0;
 }
 
 int aud_gather_destroy(aud_ctx* c) {
@@ -270,6 +385,7 @@ int aud_gather_destroy(aud_ctx* c) {
     if (g.fork) (void)hipEventDestroy(g.fork);
     (void)hipFree(g.recv);
     if (g.flags) (void)hipFree(g.flags);
+    if (g.host_status) (void)hipHostFree(const_cast<unsigned*>(g.host_status));
     g = aud_ctx::Gather();
     return AUD_OK;
 }

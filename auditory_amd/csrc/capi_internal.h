@@ -60,6 +60,16 @@ struct aud_ctx {
         hipEvent_t fork = nullptr;
         unsigned calls = 0;                // host side: steps issued (slab = calls & 1)
         long long max_polls = 0;
+        // sticky failure state: host_status is host-mapped memory the wait kernel writes on a time-out ([0] = the step that
+        // timed out, [1] / [2] = the late peers' bit mask), read by the next call without synchronising; `broken` once seen,
+        // or after a call that failed behind its first enqueue
+        volatile unsigned* host_status = nullptr;
+        bool broken = false;
+        std::string broken_why;
+        // calls captured into the current capture sequence (its id from hipStreamGetCaptureInfo): an odd count breaks the
+        // slab alternation across replays
+        unsigned long long cap_id = 0;
+        unsigned cap_calls = 0;
     } gather;
 };
 

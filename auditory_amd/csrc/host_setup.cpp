@@ -26,6 +26,7 @@ const char* aud_status_string(int status) {
         case AUD_ERCCL: return "RCCL error";
         case AUD_ENOMEM: return "out of memory";
         case AUD_ESHORT: return "SndToWindow: end beyond signal length!!";
+        case AUD_EBROKEN: return "the direct gather is broken (a peer never arrived, or a call failed half-way): destroy and create it again";
         default: return "unknown status";
     }
 }

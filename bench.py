@@ -858,6 +858,7 @@ def main():  # noqa: C901
                         "implementation; the measured ratio is `value` against a 1-GPU run's also.cfg3" % (nb, slab_bytes, world)}
         if direct is not None:
             res["arrival_timeouts"] = int(max_over_ranks(float(direct.timeouts())))
+            res["flags_memory"] = "fine-grained" if direct.flags_fine() == 1 else "ordinary device memory (AUD_GATHER_COARSE_FLAGS=1)"
         if host is not None:
             torch.cuda.synchronize(dev)
             sync_all()   # every rank's copies have landed (own device drained, THEN the barrier) before rank 0 reads the host buffer below
@@ -1087,7 +1088,7 @@ def main():  # noqa: C901
         except Exception as ex:
             direct_alt = {"error": str(ex).splitlines()[0][:300]}
         line["direct_gather"] = ({k: direct_alt[k] for k in ("value", "steps", "ms_per_step", "us_per_step_device", "launch",
-                                                             "collective", "parity", "arrival_timeouts", "xgmi_bound_us")
+                                                             "collective", "parity", "arrival_timeouts", "flags_memory", "xgmi_bound_us")
                                   if k in direct_alt}
                                  if "error" not in direct_alt else direct_alt)
         if "error" not in direct_alt:

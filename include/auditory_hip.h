@@ -36,6 +36,8 @@ extern "C" {
 #define AUD_ERCCL 3  /* RCCL error */
 #define AUD_ENOMEM 4
 #define AUD_ESHORT 5 /* sndenv.go:458-460 "end beyond signal length" (per-step API only) */
+#define AUD_EBROKEN 6 /* the direct gather is unusable until aud_gather_destroy / aud_gather_create: a peer's slab never arrived
+                       * (the missing slots of the slab were filled with NaN), or a call failed half-way */
 
 /* element types of signal buffers / compute.  AUD_F64 is ZERO on purpose: the reference computes in float64 throughout
  * (dft/dft.go:42-85, mel/mel.go:120-153), so a zero-initialised aud_plan_desc, a memset, a Go zero value all select the plan
@@ -491,12 +493,23 @@ int aud_allgather_dev(aud_ctx* ctx, const float* send, float* recv, int64_t coun
  *   aud_gather_wait_dev  the ARRIVAL side of the same step: a kernel on `stream` polls this rank's flags until every peer's
  *                       has reached this rank's step number, i.e. every peer's slab of the step has landed -- behind it the
  *                       step's slab is complete and kernels queued on `stream` may read it (what ncclAllGather's return means).
- *                       The poll is bounded (AUD_GATHER_WAIT_MS, default 2000 ms of polling): a peer that never arrives ends
- *                       the kernel with the time-out counted, never a hung queue; aud_gather_timeouts reads the count.
+ *                       The poll is bounded (default 30 s; AUD_GATHER_WAIT_MS sets another bound): a peer that never arrives
+ *                       ends the kernel -- never a hung queue -- and the time-out is STICKY and VISIBLE: the kernel fills the
+ *                       missing peers' slots of the step's slab with NaN (what is queued behind the wait computes NaN, not
+ *                       plausible numbers from a stale slab), counts the time-out, and sets a status word in host-mapped memory;
+ *                       the next aud_allgather_direct_dev / aud_gather_wait_dev on this context returns AUD_EBROKEN without
+ *                       queueing anything (no synchronisation needed to notice), and so does every later one until
+ *                       aud_gather_destroy / aud_gather_create.  aud_gather_timeouts reads the count (it synchronises).
  *   Both are capturable into a hipGraph (step numbers live in device memory and advance per replay; a captured sequence
- *   must hold an EVEN number of steps so that the slabs keep alternating across replays).  Reuse: the peers' step i + 2
+ *   must hold an EVEN number of steps so that the slabs keep alternating across replays: the library counts the calls of a
+ *   capture and the first call behind an odd one returns AUD_EBROKEN).  Reuse: the peers' step i + 2
  *   overwrites the slab of step i, and a peer cannot start step i + 2 before this rank has signalled step i + 1 -- so
  *   everything that reads the slab of step i must be ordered on `stream` before this rank's call of step i + 1.
+ *   A call that fails behind its first enqueue leaves this rank's step count out of step with its peers': the gather is
+ *   marked broken (AUD_EBROKEN from then on) instead of running on with slabs and step numbers that no longer match.
+ *   The arrival flags need fine-grained (coherent) device memory that can be exported to other processes; where the runtime has
+ *   none aud_gather_create FAILS (peers' stores into ordinary device memory are not guaranteed to become visible to a kernel
+ *   that polls through its L2) unless AUD_GATHER_COARSE_FLAGS=1 is set; aud_gather_flags_fine says which was taken.
  *   aud_gather_destroy  unmaps the peers, frees the buffers. */
 int aud_gather_create(aud_ctx* ctx, int n_ranks, int rank, int64_t slab_floats, float** recv, char handle[128]);
 int aud_gather_open_peer(aud_ctx* ctx, int peer, const char handle[128]);
@@ -504,6 +517,8 @@ int aud_allgather_direct_dev(aud_ctx* ctx, const float* send, int64_t count, int
 int aud_gather_wait_dev(aud_ctx* ctx, void* stream);
 /* waits that ended on their poll bound since aud_gather_create (synchronises `ctx`'s device first) */
 int aud_gather_timeouts(aud_ctx* ctx, int* n);
+/* 1: the arrival flags live in fine-grained memory; 0: ordinary device memory (AUD_GATHER_COARSE_FLAGS=1); -1: no gather */
+int aud_gather_flags_fine(aud_ctx* ctx);
 int aud_gather_destroy(aud_ctx* ctx);
 
 #ifdef __cplusplus

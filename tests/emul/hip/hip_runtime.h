@@ -159,6 +159,13 @@ inline hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) {
     return hipSuccess;
 }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
+// (nothing is ever captured here: launches are synchronous)
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1, hipStreamCaptureStatusInvalidated = 2 };
+inline hipError_t hipStreamGetCaptureInfo(hipStream_t, hipStreamCaptureStatus* st, unsigned long long* id) {
+    if (st) *st = hipStreamCaptureStatusNone;
+    if (id) *id = 0;
+    return 0;
+}
 // the direct all-gather's arrival flags (capi_comm.hip): fine-grained memory is ordinary memory here, system-scope atomics are
 // the compiler's, and the bounded poll's sleep is nothing
 enum { hipDeviceMallocFinegrained = 1 };
@@ -169,6 +176,7 @@ inline hipError_t hipDeviceSynchronize() { return 0; }
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
 inline void __builtin_amdgcn_s_sleep(int) {}
+inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 // (the handle also carries the exporting process: "device" memory here is a process's own heap, so a handle of ANOTHER
 // process cannot be mapped -- opening it fails the way a box without IPC support fails, instead of handing out a wild pointer)
 inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) {

@@ -312,14 +312,30 @@ def case_direct_gather_three_ranks():
                 assert np.array_equal(b[rnd & 1, r, :counts[r]], sends[r]) and (b[rnd & 1, r, counts[r]:] == -1.0).all()
         if rnd == 1:      # the previous step's slab is untouched by this one
             assert bufs[0][0, 0, 0] == 1000.0 and bufs[0][0, 1, 0] == 2000.0
-    # a peer that never arrives: the wait ENDS at its poll bound and is counted (never a hung queue)
-    gs[0].allgather(sends[0].ctypes.data, 1)
+    # a peer that never arrives: the wait ENDS at its poll bound (never a hung queue) -- and the time-out is sticky and visible:
+    # counted, the late peers' slots of the step's slab filled with NaN, and the next per-step call on this context refused
+    # (AUD_EBROKEN) without anything having been synchronised
+    assert all(g.flags_fine() == 1 for g in gs)
+    which = gs[0].allgather(sends[0].ctypes.data, 1)
     gs[0].wait()
     assert gs[0].timeouts() == G - 1
-    for r in range(1, G):
+    assert bufs[0][which, 0, 0] == sends[0][0]                                 # the own slot is intact
+    assert np.isnan(bufs[0][which, 1]).all() and np.isnan(bufs[0][which, 2]).all()
+    assert not np.isnan(bufs[0][1 - which]).any()                             # the other slab is not touched
+    for call in (lambda: gs[0].allgather(sends[0].ctypes.data, 1), gs[0].wait):
+        with pytest.raises(capi.AuditoryError) as ei:
+            call()
+        assert ei.value.status == capi.AUD_EBROKEN and "poll bound" in str(ei.value) and "0x0000000000000006" in str(ei.value)
+    for r in range(1, G):                                                     # the other ranks are not affected by rank 0's state
         gs[r].allgather(sends[r].ctypes.data, 1)
     with pytest.raises(capi.AuditoryError):
         gs[1].allgather(sends[1].ctypes.data, slab + 1)           # more than the slab
+    # destroy / create makes the context usable again
+    gs[0].close()
+    g0 = DirectGather(ctxs[0], G, 0, slab)
+    assert g0.timeouts() == 0
+    g0.close()
+    gs[0] = DirectGather(ctxs[0], 1, 0, 4)                        # (a one-rank gather for the loop below to close)
     for g in gs:
         g.close()
     for c in ctxs:
