@@ -79,8 +79,49 @@ def main():
             assert bool((got[i, r, n:] == -1.0).all()), (rank, i, r)
     open(os.path.join(d, "checked%d" % rank), "w").close()             # keep the buffers alive until both have read them
     wait_for(os.path.join(d, "checked%d" % other))
+    fine = g.flags_fine()
     g.close()
-    print("GATHER-OK", rank)
+
+    # ---- a peer that never arrives, on hardware: a second gather with a SHORT poll bound; rank 1 maps everything and then
+    # does nothing, rank 0 pushes and waits.  The wait must END (0.3 s), count the time-out, fill rank 1's slot of the step's
+    # slab with NaN, and the next call must be refused (AUD_EBROKEN) without any synchronisation of rank 0's own.
+    import numpy as np
+    from auditory_amd import capi
+    os.environ["AUD_GATHER_WAIT_MS"] = "300"
+    g = DirectGather(ctx, 2, rank, slab)
+    with open(os.path.join(d, "t%d.tmp" % rank), "wb") as fh:
+        fh.write(g.handle)
+    os.rename(os.path.join(d, "t%d.tmp" % rank), os.path.join(d, "t%d" % rank))
+    handles[rank], handles[other] = g.handle, open(wait_for(os.path.join(d, "t%d" % other)), "rb").read()
+    g.open_peers(handles)
+    recv = g.recv(dev)
+    recv.fill_(-1.0)
+    torch.cuda.synchronize()
+    open(os.path.join(d, "tready%d" % rank), "w").close()
+    wait_for(os.path.join(d, "tready%d" % other))
+    if rank == 0:
+        st = torch.cuda.current_stream(dev).cuda_stream
+        t0 = time.time()
+        which = g.allgather(sends[0].data_ptr(), slab, st)
+        g.wait(st)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        assert g.timeouts() == 1 and dt < 20.0, (g.timeouts(), dt)
+        got = recv.cpu().numpy()
+        assert np.array_equal(got[which, 0], sends[0].cpu().numpy()) and np.isnan(got[which, 1]).all()
+        assert (got[1 - which] == -1.0).all()
+        for call in (lambda: g.allgather(sends[0].data_ptr(), slab, st), lambda: g.wait(st)):
+            try:
+                call()
+                raise SystemExit("a broken gather accepted another call")
+            except capi.AuditoryError as ex:
+                assert ex.status == capi.AUD_EBROKEN and "poll bound" in str(ex), str(ex)
+        open(os.path.join(d, "tdone"), "w").close()
+        print("GATHER-TIMEOUT-OK waited %.2f s" % dt)
+    else:
+        wait_for(os.path.join(d, "tdone"))
+    g.close()
+    print("GATHER-OK", rank, "flags_fine", fine)
 
 
 if __name__ == "__main__":

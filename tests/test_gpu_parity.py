@@ -506,6 +506,8 @@ def test_direct_allgather_two_processes_one_gpu(torch_cuda, tmp_path):
     outs = _join_workers(procs, 300)
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0 and "GATHER-OK" in o, (o[-1000:], e[-3000:])
+    assert "GATHER-TIMEOUT-OK" in outs[0][0]        # a peer that never arrives: bounded, counted, NaN-filled, sticky (rank 0's view)
+    print(outs[0][0].strip().splitlines()[-2:])
 
 
 def _join_workers(procs, timeout):
