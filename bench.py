@@ -1051,6 +1051,7 @@ def main():  # noqa: C901
         line["xgmi_bound_us"] = cfg3.get("xgmi_bound_us")
         if "arrival_timeouts" in cfg3:
             line["arrival_timeouts"] = cfg3["arrival_timeouts"]
+            line["flags_memory"] = cfg3.get("flags_memory")
         line["collective"] = cfg3["collective"]
         line["gathered_shape"] = cfg3.get("gathered_shape")
         line["shard_sizes"] = cfg3.get("shard_sizes")

@@ -150,6 +150,20 @@ big[::7] = 0.25
 bsig = runtime.Signal(plan1.ctx)
 bsig.sync(big)
 r1["sync_8MB"] = timed(lambda: bsig.sync(big), reps=50, warm=5)
+# the same three routes at the C ABI with the ctypes arguments built ONCE (what a compiled host -- Go through cgo, C++ -- pays:
+# the rows above include 1-2 us of Python marshalling per pointer argument, and the live call has three more of them)
+import ctypes as C  # noqa: E402
+vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+lib1, up1 = plan1.lib, C.c_int64(0)
+a_sig = (plan1.handle, snap.handle, vp(one), 1, vp(out1[0]), vp(out1[1]), vp(out1[2]))
+a_live = (plan1.handle, C.byref(lv.handle), vp(snd), snd.size, vp(one), 1, vp(out1[0]), vp(out1[1]), vp(out1[2]), C.byref(up1))
+a_sync = (plan1.ctx.handle, C.byref(live.handle), vp(snd), capi.AUD_F64, snd.size, C.byref(up1))
+a_sig2 = (plan1.handle, live.handle, vp(one), 1, vp(out1[0]), vp(out1[1]), vp(out1[2]))
+assert lib1.aud_melspec_batch_live(*a_live) == 0 and lib1.aud_signal_sync(*a_sync) == 0
+r1["abi_snapshot"] = timed(lambda: lib1.aud_melspec_batch_sig(*a_sig), reps=400, warm=40)
+r1["abi_live"] = timed(lambda: lib1.aud_melspec_batch_live(*a_live), reps=400, warm=40)
+r1["abi_sync_whole"] = timed(lambda: (lib1.aud_signal_sync(*a_sync), lib1.aud_melspec_batch_sig(*a_sig2)), reps=400, warm=40)
+r1["abi_snapshot_again"] = timed(lambda: lib1.aud_melspec_batch_sig(*a_sig), reps=400, warm=40)
 print("one 3 s sound (384 KB of float64), one 100 ms segment per call (mel + PowerSegment + LogPowerSegment out):")
 for k_ in ("sound_snapshot", "sound_r5_default", "sound_live", "sound_live_edit", "sound_sync", "sound_sync_edit", "sound_per_call", "sync_8MB"):
     print("  %-16s %.1f us per call" % (k_, r1[k_] * 1e6))
@@ -157,3 +171,7 @@ print("  exact residency (sound_live, the mirrors' default): %+.1f %% against th
       "(sampled fingerprint + call); comparing the WHOLE tensor per call (sound_sync): %+.1f %% / %+.1f %%"
       % (100.0 * (r1["sound_live"] / r1["sound_snapshot"] - 1.0), 100.0 * (r1["sound_live"] / r1["sound_r5_default"] - 1.0),
          100.0 * (r1["sound_sync"] / r1["sound_snapshot"] - 1.0), 100.0 * (r1["sound_sync"] / r1["sound_r5_default"] - 1.0)))
+print("  at the C ABI, arguments prebuilt: snapshot %.1f / %.1f us, live %.1f us (%+.1f %%), sync of the whole tensor + call %.1f us (%+.1f %%)"
+      % (r1["abi_snapshot"] * 1e6, r1["abi_snapshot_again"] * 1e6, r1["abi_live"] * 1e6,
+         100.0 * (r1["abi_live"] / min(r1["abi_snapshot"], r1["abi_snapshot_again"]) - 1.0), r1["abi_sync_whole"] * 1e6,
+         100.0 * (r1["abi_sync_whole"] / min(r1["abi_snapshot"], r1["abi_snapshot_again"]) - 1.0)))
