@@ -45,6 +45,9 @@ def main():
             PC.case_melspec_vs_oracle(orc, ("cfg1_44k_n1103_nf32", 0.12, 1, [0]), capi.AUD_F64)
             PC.case_melspec_vs_oracle(orc, ("cfg1_44k_n1103_nf32", 0.12, 1, [0]), capi.AUD_F32)
             PC.case_direct_gather_three_ranks()
+            # round 6: the exact resident Signal (host shadow, block compares, partial uploads: memcmp / memcpy bounds are what
+            # AddressSanitizer is for; the direct gather case above now ends in the sticky time-out with its NaN fill)
+            PC.case_sndenv_resident_signal_staleness(orc)
         else:
             PC.case_melspec_vs_oracle(orc, by_name[which], capi.AUD_F32)
     print("DRIVE-OK", variant, which)
