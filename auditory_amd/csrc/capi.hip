@@ -403,6 +403,13 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
         p->lds_pad = value;
         return AUD_OK;
     }
+    // -1 / 1 (default): aud_segment_batch_dev lets the plan's mel kernel carry the MFCC tail wherever it can (w20x10, w16x16, the
+    // any-N kernel); 0: always the two launches on the float32-STORED tensors (aud_melspec_batch_dev + aud_mfcc_batch_dev)
+    if (key == "fused_tail") {
+        if (value < -1 || value > 1) return fail(c, AUD_EINVAL, "fused_tail: -1 / 1 (wherever the kernel can) or 0 (never)");
+        p->fused_tail_opt = value;
+        return AUD_OK;
+    }
     if (key == "xcd_remap") {  // 1 (default): every XCD walks a contiguous run of tiles; 0: tiles in workgroup-id order
         if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "xcd_remap: 0 or 1");
         p->xcd_remap = value;
@@ -511,8 +518,17 @@ int aud_mfcc_batch_dev(aud_plan* p, const aud_item* items, int n_items, const fl
 namespace {
 // the plan's mel kernel can carry the tail's DCT and Energy sums itself (kernels.h MelspecArgs::mfcc_acc)
 bool segment_fused(const aud_plan* p) {
-    return p->use_wave && p->wave_kind && p->wv.dct_off >= 0 && p->d.dft.prev_smooth == 0.0 &&
-           aud::segment_finish_lds_bytes(p->d.mfcc_coefs, p->d.segment_steps, p->d.compute_dtype) <= 64 * 1024;
+    if (p->fused_tail_opt == 0 || p->d.dft.prev_smooth != 0.0 || p->d.mfcc_coefs < 1 ||
+        aud::segment_finish_lds_bytes(p->d.mfcc_coefs, p->d.segment_steps, p->d.compute_dtype) > 64 * 1024)
+        return false;
+    if (p->use_wave && p->wave_kind) return p->wv.dct_off >= 0;
+    // the any-N kernel (round 6): DCT and Energy sums from its unrounded values wherever its power buffer has the room
+    return aud::melspec_generic_tail_fits(p->M, p->F_generic, p->H, p->d.mel.n_filters, p->d.compute_dtype, p->bl_L, p->bl_inplace);
+}
+// tiles of an item the fused tail's per-tile Energy sums come in: wave tiles, or the any-N kernel's workgroups of F frames
+int segment_tiles(const aud_plan* p) {
+    const int fw = (p->use_wave && p->wave_kind) ? aud::melspec_wave_frames_per_wave(p->wave_kind) : p->F_generic;
+    return (p->d.segment_steps + fw - 1) / fw;
 }
 size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 }  // namespace
@@ -521,8 +537,7 @@ int aud_segment_workspace_bytes(const aud_plan* p, int n_items, int64_t* bytes) 
     if (!p || !bytes || n_items < 0) return AUD_EINVAL;
     const size_t T = size_t(p->d.segment_steps), n = size_t(n_items);
     if (segment_fused(p)) {
-        const int fw = aud::melspec_wave_frames_per_wave(p->wave_kind);
-        const size_t tiles = (T + fw - 1) / fw, tsz = p->d.compute_dtype == AUD_F64 ? 8 : 4;
+        const size_t tiles = size_t(segment_tiles(p)), tsz = p->d.compute_dtype == AUD_F64 ? 8 : 4;
         *bytes = int64_t(align256(n * p->d.mfcc_coefs * T * tsz) + align256(n * tiles * T * tsz));
     } else {
         // a LogPowerSegment of its own when the caller keeps none, and -- PrevSmooth != 0: the scan runs on the stored
@@ -548,7 +563,7 @@ int aud_segment_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
     if (n_items > 0 && (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15)))
         return fail(c, AUD_EINVAL, "workspace: 16-byte aligned, aud_segment_workspace_bytes() bytes");
     if (n_items == 0) return AUD_OK;
-    if (!segment_fused(p)) {  // (generic kernel, w64x16, PrevSmooth, more than 13 coefficients): the two launches of the parts
+    if (!segment_fused(p)) {  // (w64x16, PrevSmooth, more than 13 coefficients on a wave kernel, option fused_tail = 0): the two launches of the parts
         float* lp = log_power ? log_power : static_cast<float*>(workspace);
         float* pw = power;
         if (!pw && p->d.dft.prev_smooth != 0.0)  // `power` stays optional: the scan's tensor comes out of the workspace
@@ -576,14 +591,14 @@ int aud_segment_batch_dev(aud_plan* p, const void* sig, int sig_dtype, const aud
     a.mfcc_acc = workspace;
     a.energy_part = static_cast<unsigned char*>(workspace) + align256(size_t(n_items) * p->d.mfcc_coefs * T * tsz);
     a.n_coefs = p->d.mfcc_coefs;
+    a.dct_rows = p->d_dct;
     AUD_HIP(c, launch_frames(p, a, static_cast<hipStream_t>(stream)));
     aud::SegmentFinishArgs f;
     std::memset(&f, 0, sizeof(f));
     f.n_items = n_items;
     f.T = p->d.segment_steps;
     f.n_coefs = p->d.mfcc_coefs;
-    const int fw = aud::melspec_wave_frames_per_wave(p->wave_kind);
-    f.tiles = (p->d.segment_steps + fw - 1) / fw;
+    f.tiles = segment_tiles(p);
     f.mfcc_acc = a.mfcc_acc;
     f.energy_part = a.energy_part;
     f.mfcc = mfcc;

@@ -133,6 +133,7 @@ struct aud_plan {
     int item_opt = -1;
     int lds_pad = 0;     // plan option "lds_pad": extra dynamic LDS per workgroup of the wave kernels (occupancy experiments)
     int gabor_opt = -1;  // plan option "gabor_kernel" (kernels.h GaborArgs::mode): -1 = by compute type
+    int fused_tail_opt = -1;  // plan option "fused_tail": 0 = aud_segment_batch_dev always runs the tail on the stored tensors
     void* d_dct = nullptr;  // [mfcc_coefs][nf] DCT-I rows
     unsigned long long stamps = 0;  // diagnostic builds (-DAUD_STAMPS): device buffer for the phase stamps
     const char* family = "generic";

@@ -72,6 +72,7 @@ struct MelspecArgs {
     void* mfcc_acc;      // [n_items][n_coefs][T] compute type (row 0 is not written: ProcessSegment overwrites it with Energy)
     void* energy_part;   // [n_items][tiles][T] compute type: sum over the tile's frames of LogPower[bin s < T][frame] (Q8 axis quirk)
     int n_coefs;
+    const void* dct_rows;  // the any-N kernel's fused tail (round 6): [n_coefs][nf] DCT-I rows, compute type (its tile = the F frames of a workgroup)
     // diagnostic builds only (-DAUD_STAMPS, tools/stamp_profile.py): [waves][16] s_memtime stamps of the wave
     // kernels' phases.  Never read by anything that computes an output.
     unsigned long long* stamps;
@@ -240,6 +241,8 @@ struct SegmentFinishArgs {
     float* energy;             // [n_items, T] or null
 };
 size_t segment_finish_lds_bytes(int n_coefs, int T, int compute_dtype);
+// the any-N kernel can carry the tail: its power buffer has room for the F x nf unrounded log-mel values behind the F spectra
+bool melspec_generic_tail_fits(int M, int F, int H, int nf, int compute_dtype, int bl_L, bool bl_inplace);
 hipError_t launch_segment_finish(const SegmentFinishArgs& a, int compute_dtype, hipStream_t st);
 hipError_t launch_mfcc_dct(const MfccArgs& a, int compute_dtype, hipStream_t st);
 

@@ -443,7 +443,27 @@ void k_melspec_generic(const MelspecArgs a) {
         }
     }
 
+    // ---- fused segment tail, part 1 (aud_segment_batch_dev; sndenv.go:360-366 with its axis quirk): Energy[s] sums
+    // the log-power of BIN s over the steps of the segment -- this workgroup's share, from the UNROUNDED values, for s < T
+    if (a.energy_part) {
+        const TT off = TT(a.dft_log_off), lmin = TT(a.dft_log_min);
+        TT* ep = static_cast<TT*>(a.energy_part) + (size_t(item) * tiles + size_t(t0 / F)) * T;
+        for (int s = tid; s < T; s += blockDim.x) {  // (T <= H: the host checks, the Go code panics otherwise)
+            TT e = TT(0);
+            for (int f = 0; f < F; ++f) {
+                const int sstep = t0 + f;
+                const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
+                if (sstep < T && start + N <= int64_t(it.sig_len)) {  // (a step the loop never reached left LogPowerSegment at 0)
+                    const TT v = P[size_t(f) * Hp + s] + off;
+                    e += v == TT(0) ? lmin : dev_log(v);
+                }
+            }
+            ep[s] = e;
+        }
+    }
+
     // ---- mel triangles + log (mel.go:120-153) ---------------------------------------
+    TT* melL = P + size_t(F) * Hp;  // fused tail: the workgroup's [F][nf] log-mel values before their float32 rounding
     {
         const TT* __restrict__ filt = static_cast<const TT*>(a.filt);
         const int cols = a.nf + 2;
@@ -468,11 +488,12 @@ void k_melspec_generic(const MelspecArgs a) {
             }
             sum += __shfl_xor(sum, 2, 64);
             sum += __shfl_xor(sum, 1, 64);
-            if (part != 0 || w0 >= n_work || sstep >= T) continue;
+            if (part != 0 || w0 >= n_work) continue;
             float res = 0.f;
+            TT val = TT(0);
             if (live) {
                 sum += loff;
-                TT val = (sum == TT(0)) ? lmin : dev_log(sum);
+                val = (sum == TT(0)) ? lmin : dev_log(sum);
                 if (a.renorm) {
                     val -= TT(a.renorm_min);
                     if (val < TT(0)) val = TT(0);
@@ -481,7 +502,25 @@ void k_melspec_generic(const MelspecArgs a) {
                 }
                 res = float(val);
             }
-            a.mel[(size_t(item) * a.nf + flt) * T + sstep] = res;
+            if (a.mfcc_acc) melL[f * a.nf + flt] = val;  // (0 for a step the loop never reached: its MFCC column stays 0)
+            if (sstep < T) a.mel[(size_t(item) * a.nf + flt) * T + sstep] = res;
+        }
+    }
+
+    // ---- fused segment tail, part 2: mel.Params.CepstrumDct (mel.go:192-212) on the unrounded log-mel values, rows 1 .. (row 0 is
+    // overwritten with Energy, sndenv.go:368-372: launch_segment_finish does that and the deltas)
+    if (a.mfcc_acc) {
+        __syncthreads();
+        const TT* __restrict__ D = static_cast<const TT*>(a.dct_rows);
+        TT* acc = static_cast<TT*>(a.mfcc_acc) + size_t(item) * a.n_coefs * T;
+        for (int w = tid; w < F * (a.n_coefs - 1); w += blockDim.x) {
+            const int c = 1 + w / F, f = w - (c - 1) * F, sstep = t0 + f;
+            if (sstep >= T) continue;
+            const TT* drow = D + size_t(c) * a.nf;
+            const TT* mrow = melL + f * a.nf;
+            TT sum = TT(0);
+            for (int j = 0; j < a.nf; ++j) sum = mad(drow[j], mrow[j], sum);
+            acc[size_t(c) * T + sstep] = sum;
         }
     }
 }
@@ -497,6 +536,16 @@ bool melspec_generic_bluestein_inplace(int L) {
             m /= p;
         }
     return m == 1;
+}
+
+// the fused tail parks F x nf log-mel values behind the F power spectra (F x (H | 1) values) in the buffer the spectra live in:
+// the second Stockham buffer (F M complex values; L for a two-buffer Bluestein plan), or -- in place -- what the padded buffer
+// has left behind Z[0 .. M) and one element
+bool melspec_generic_tail_fits(int M, int F, int H, int nf, int compute_dtype, int bl_L, bool bl_inplace) {
+    const size_t tsz = compute_dtype == AUD_F64 ? 8 : 4, c = 2 * tsz;
+    const size_t need = (size_t(F) * size_t(H | 1) + size_t(F) * size_t(nf)) * tsz;
+    if (bl_L && bl_inplace) return size_t(padx(M) + 1) * c + need <= size_t(padx(bl_L)) * c;
+    return need <= (bl_L ? size_t(bl_L) : size_t(F) * size_t(M)) * c;
 }
 
 size_t melspec_generic_lds_bytes(int M, int F, int compute_dtype, bool bluestein) {

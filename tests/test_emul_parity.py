@@ -120,7 +120,9 @@ def test_emul_mfcc_tail(orc, emu, name, cdt):
 
 @pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
 def test_emul_mfcc_tail_from_stored_tensors(orc, emu, cdt):
-    PC.case_mfcc_tail(orc, "sndenv_16k_n400_nf32", cdt, options={"kernel": 1})     # generic kernel: the unfused tail
+    PC.case_mfcc_tail(orc, "sndenv_16k_n400_nf32", cdt, options={"kernel": 1, "fused_tail": 0})     # the tail on the stored tensors
+    PC.case_mfcc_tail(orc, "sndenv_16k_n400_nf32", cdt, options={"kernel": 1})                      # the any-N kernel carries it (round 6)
+    PC.case_mfcc_tail(orc, "cfg1_44k_n1103_nf32", cdt)                                             # ... on the Bluestein route too
 
 
 @pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
