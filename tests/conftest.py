@@ -52,3 +52,14 @@ def orc():
     from oracle import oracle
     oracle.lib()
     return oracle
+
+
+def pytest_collection_modifyitems(config, items):
+    """CPU tier: the few long tests (sanitizer runs of the emulator, hipcc's resource report, the multi-rank dry runs) go FIRST,
+    so that the xdist workers pack the many short ones around them instead of starting a two-minute test at the end"""
+    if (getattr(config.option, "markexpr", "") or "").strip() != "not gpu":
+        return
+    long_ones = ("under_tsan", "under_asan", "no_scratch_and_fit", "device_api_tests_dry_run", "eight_ranks", "test_bench_dry_run[",
+                 "kwta_vs_oracle", "peer_dies", "two_ranks", "single_rank_collective", "workgroup_order")
+    rank = {id(it): (0 if any(k in it.nodeid for k in long_ones) else 1) for it in items}
+    items.sort(key=lambda it: rank[id(it)])

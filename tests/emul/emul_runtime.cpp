@@ -11,9 +11,13 @@
 #define EMUL_UNPOISON(p, n) ((void)0)
 #endif
 
-#include <condition_variable>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <climits>
 #include <cstdio>
-#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -26,34 +30,48 @@ alignas(16) unsigned char aud_dyn_lds[160 * 1024];
 
 namespace {
 
-// barrier whose participant count can shrink when threads leave the kernel early
+// Barrier whose participant count can shrink when threads leave the kernel early.  One 64-bit state word {live, waiting}
+// changed by compare-and-swap -- exactly one thread per generation sees "everyone is here" and becomes the releaser -- and a
+// generation counter the others sleep on through the futex syscall: a wake-up touches no mutex (the condition-variable form
+// woke 255 threads into one lock per barrier, and the CPU tier spent 20 minutes of system time there).  The acquire / release
+// pairs on `gen` are what orders the threads' memory accesses (and what ThreadSanitizer sees).
 struct Barrier {
-    std::mutex m;
-    std::condition_variable cv;
-    int waiting = 0, live = 0;
-    unsigned long gen = 0;
-    void reset(int n) {
-        waiting = 0;
-        live = n;
+    std::atomic<uint64_t> state{0};  // live << 32 | waiting
+    std::atomic<uint32_t> gen{0};
+    static void futex(std::atomic<uint32_t>* addr, int op, uint32_t val) {
+        syscall(SYS_futex, reinterpret_cast<uint32_t*>(addr), op, val, nullptr, nullptr, 0);
+    }
+    void reset(int n) { state.store(uint64_t(uint32_t(n)) << 32, std::memory_order_release); }
+    void release() {
+        gen.fetch_add(1, std::memory_order_acq_rel);
+        futex(&gen, FUTEX_WAKE_PRIVATE, INT_MAX);
     }
     void arrive_and_wait() {
-        std::unique_lock<std::mutex> lk(m);
-        const unsigned long g = gen;
-        if (++waiting >= live) {
-            waiting = 0;
-            ++gen;
-            cv.notify_all();
-        } else {
-            cv.wait(lk, [&] { return gen != g; });
+        const uint32_t g = gen.load(std::memory_order_acquire);
+        uint64_t s = state.load(std::memory_order_relaxed);
+        for (;;) {
+            const uint32_t live = uint32_t(s >> 32), w = uint32_t(s) + 1;
+            const bool last = w >= live;
+            if (state.compare_exchange_weak(s, (uint64_t(live) << 32) | (last ? 0u : w), std::memory_order_acq_rel)) {
+                if (last) return release();
+                break;
+            }
+        }
+        int spins = 0;
+        while (gen.load(std::memory_order_acquire) == g) {
+            if (++spins < 64) std::this_thread::yield();   // (a barrier of a few threads is usually passed within a yield or two)
+            else futex(&gen, FUTEX_WAIT_PRIVATE, g);
         }
     }
     void drop() {
-        std::unique_lock<std::mutex> lk(m);
-        --live;
-        if (live > 0 && waiting >= live) {
-            waiting = 0;
-            ++gen;
-            cv.notify_all();
+        uint64_t s = state.load(std::memory_order_relaxed);
+        for (;;) {
+            const uint32_t live = uint32_t(s >> 32) - 1, w = uint32_t(s);
+            const bool fire = live > 0 && w >= live;
+            if (state.compare_exchange_weak(s, (uint64_t(live) << 32) | (fire ? 0u : w), std::memory_order_acq_rel)) {
+                if (fire) release();
+                return;
+            }
         }
     }
 };
@@ -101,7 +119,12 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
     }
     g_lds_bytes = lds_bytes;
     const unsigned long nblocks = (unsigned long)grid.x * grid.y * grid.z;
-    for (unsigned long b = 0; b < nblocks; ++b) {
+    // the workgroup's threads live for the whole launch and take the blocks one after another: between two blocks they meet
+    // at `turn` (a barrier of their own that never shrinks), thread 0 prepares the next block -- LDS poison, the kernel-visible
+    // barriers back to full strength -- and they meet again
+    Barrier turn;
+    turn.reset(nthr);
+    auto prepare = [&]() {
         // poison LDS so that reads of never-written shared memory show up as NaNs / garbage
         EMUL_UNPOISON(aud::aud_dyn_lds, sizeof(aud::aud_dyn_lds));
         std::memset(aud::aud_dyn_lds, 0xFF, sizeof(aud::aud_dyn_lds));
@@ -111,23 +134,26 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
             EMUL_POISON(aud::aud_dyn_lds + used, sizeof(aud::aud_dyn_lds) - used);
         g_block.reset(nthr);
         for (int w = 0; w * 64 < nthr; ++w) g_wave[w].reset(std::min(64, nthr - w * 64));
-        std::vector<std::thread> pool;
-        pool.reserve(size_t(nthr));
-        for (int t = 0; t < nthr; ++t) {
-            pool.emplace_back([&, t, b]() {
-                threadIdx = dim3(unsigned(t) % block.x, (unsigned(t) / block.x) % block.y,
-                                 unsigned(t) / (block.x * block.y));
-                blockIdx = dim3(unsigned(b % grid.x), unsigned((b / grid.x) % grid.y),
-                                unsigned(b / ((unsigned long)grid.x * grid.y)));
-                blockDim = block;
-                gridDim = grid;
+    };
+    std::vector<std::thread> pool;
+    pool.reserve(size_t(nthr));
+    for (int t = 0; t < nthr; ++t) {
+        pool.emplace_back([&, t]() {
+            blockDim = block;
+            gridDim = grid;
+            threadIdx = dim3(unsigned(t) % block.x, (unsigned(t) / block.x) % block.y, unsigned(t) / (block.x * block.y));
+            for (unsigned long b = 0; b < nblocks; ++b) {
+                turn.arrive_and_wait();  // every thread has left the previous block (its drops included)
+                if (t == 0) prepare();
+                turn.arrive_and_wait();
+                blockIdx = dim3(unsigned(b % grid.x), unsigned((b / grid.x) % grid.y), unsigned(b / ((unsigned long)grid.x * grid.y)));
                 body();
                 g_wave[t >> 6].drop();
                 g_block.drop();
-            });
-        }
-        for (auto& th : pool) th.join();
+            }
+        });
     }
+    for (auto& th : pool) th.join();
     EMUL_UNPOISON(aud::aud_dyn_lds, sizeof(aud::aud_dyn_lds));
 }
 
