@@ -535,6 +535,36 @@ def case_resident_signal(orc, cdt):
         ref32 = plan.melspec_host(sig.ravel().astype(np.float32).astype(np.float64), items)
         if cdt == capi.AUD_F64:
             assert np.array_equal(got32[0], ref32[0], equal_nan=True)
+        # ---- the LIVE route (round 6: what the SndEnv mirrors call by default): several items per call, the MFCC form, and an
+        # interleaved stereo buffer addressed through sig_stride -- the blocks every item's frames read are compared with the
+        # resident copy's shadow; the results are the host route's on the tensor as it is at the call
+        flat = sig.ravel().copy()
+        live = runtime.Signal(plan.ctx)
+        got = plan.melspec_live(live, flat, items, True, True)
+        assert live.uploaded_bytes == flat.nbytes
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b, equal_nan=True)
+        got_m = plan.melspec_mfcc_live(live, flat, items)
+        assert live.uploaded_bytes == 0
+        for key in want_m:
+            assert np.array_equal(got_m[key], want_m[key], equal_nan=True), key
+        flat[L + 1700] += 0.25                                       # row 1, inside its segment 1 (item 2), nowhere near row 0's items
+        got = plan.melspec_live(live, flat, items, True, True)
+        ref = plan.melspec_host(flat, items, True, True)
+        assert live.uploaded_bytes == 4096
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b, equal_nan=True)
+        assert np.array_equal(got[0][:2], want[0][:2]) and not np.array_equal(got[0][2], want[0][2])
+        inter = np.empty(2 * L)                                      # L, R, L, R ...: two strided items over one buffer
+        inter[0::2], inter[1::2] = sig[0], sig[1]
+        st_items = runtime.make_items([0, 1], [L, L], [oc.sp.stride_samples, oc.sp.stride_samples], sig_stride=2)
+        lv2 = runtime.Signal(plan.ctx)
+        assert np.array_equal(plan.melspec_live(lv2, inter, st_items)[0], plan.melspec_host(inter, st_items)[0], equal_nan=True)
+        inter[2 * 1700 + 1] -= 0.125                                 # the RIGHT channel's sample 1700
+        got_s, ref_s = plan.melspec_live(lv2, inter, st_items)[0], plan.melspec_host(inter, st_items)[0]
+        assert lv2.uploaded_bytes == 4096 and np.array_equal(got_s, ref_s, equal_nan=True)
+        live.close()
+        lv2.close()
         # result tensors in aud_host_alloc memory: the device widens and stores them itself -- the same bits as the staging route;
         # a call whose outputs are only partly pinned takes the staging route for all of them
         n_it = len(items)
