@@ -350,13 +350,14 @@ def main():  # noqa: C901
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
-    ap.add_argument("--workload", choices=["headline", "n512", "cfg4", "cfg5", "cfg1", "sndenv"], default="headline",
+    ap.add_argument("--workload", choices=["headline", "n512", "cfg4", "cfg5", "cfg1", "sndenv", "sndenv_cfg1"], default="headline",
                     help="headline: the judged line (N = 400; the other BASELINE configurations nested under `also`).  "
                          "Stand-alone lines for BASELINE.md's table: cfg4 = headline + agabor.Convolve (default FilterSet, "
                          "[11,32,2,8] pools); cfg5 = 44.1 kHz 5 s streams, N = 2048, 128 mel (use --batch 1280 for >= 1 GB "
                          "resident input); cfg1 = configs[0]'s parameters (N = 1103, prime); sndenv = the headline parameters "
                          "with everything the unmodified SndEnv.ProcessSegment loop produces (SURVEY 8 f-1 + f-2): mel + Power "
-                         "+ LogPower tensors + the MFCC tail (13 coefficients, deltas, delta-deltas, Energy)")
+                         "+ LogPower tensors + the MFCC tail (13 coefficients, deltas, delta-deltas, Energy); sndenv_cfg1 = the same "
+                         "on configs[0]'s parameters (N = 1103: what an unmodified SndEnv loop over the shipped 44.1 kHz WAVs runs)")
     ap.add_argument("--compute", choices=["f64", "f32"], default="f64", help="arithmetic of the headline mode")
     ap.add_argument("--sig-dtype", choices=["f32", "i16"], default="f32",
                     help="resident sample format: float32 (the metric's definition) or int16 PCM normalised on the device "
@@ -900,9 +901,9 @@ def main():  # noqa: C901
         return res
 
     # ---------------------------------------------------------------------------------------------------
-    stand_alone = args.workload if args.workload in ("cfg5", "cfg1", "n512") else "n400"
+    stand_alone = args.workload if args.workload in ("cfg5", "cfg1", "n512") else ("cfg1" if args.workload == "sndenv_cfg1" else "n400")
     head_wl = Workload(stand_alone)
-    kind = {"cfg4": "gabor", "sndenv": "full"}.get(args.workload, "mel")
+    kind = {"cfg4": "gabor", "sndenv": "full", "sndenv_cfg1": "full"}.get(args.workload, "mel")
     head = time_mode(head_wl, args.compute, kind=kind)
     solo = head if head["streams"] == 1 else time_mode(head_wl, args.compute, kind=kind, check=False, n_streams=1)  # the kernel alone
     if rank == 0 and "parity" in head and not head["parity"]["pass"] and not args.report_anyway:
@@ -965,6 +966,8 @@ def main():  # noqa: C901
             "sndenv": "the whole unmodified SndEnv.ProcessSegment loop on the metric's parameters (mel + Power + LogPower "
                       "tensors + MFCC tail with deltas and Energy: SURVEY 8 f-1, f-2): ",
             "cfg1": "BASELINE configs[0] parameters (N = 1103), one 100 ms segment per item: ",
+            "sndenv_cfg1": "the whole unmodified SndEnv.ProcessSegment loop on BASELINE configs[0]'s parameters (N = 1103, one 100 ms "
+                           "segment per item: mel + Power + LogPower tensors + MFCC tail; the any-N kernel carries the tail): ",
             "n512": "BASELINE configs[1] as worded (512-point FFT: WinMs 32): ",
             "cfg5": "BASELINE configs[4]: "}[args.workload]
     top = cfg3 if cfg3 is not None else head      # several GPUs: configs[2] as stated is the line's value

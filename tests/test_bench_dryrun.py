@@ -188,7 +188,7 @@ def test_bench_dry_run_single_rank_collective(monkeypatch, capsys, mode):
 
 @pytest.mark.parametrize("extra", [[], ["--only-headline"], ["--workload", "cfg4"], ["--sig-dtype", "i16", "--only-headline"],
                                    ["--compute", "f32", "--launch", "eager", "--only-headline"],
-                                   ["--workload", "sndenv"], ["--stereo", "--only-headline"]])
+                                   ["--workload", "sndenv"], ["--stereo", "--only-headline"], ["--workload", "sndenv_cfg1"]])
 def test_bench_dry_run(monkeypatch, capsys, extra):
     import backend
     import bench
@@ -207,7 +207,7 @@ def test_bench_dry_run(monkeypatch, capsys, extra):
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
     assert line["unit"] == "audio-seconds/sec" and line["n_gpus"] == 1 and line["steps"] == 2 * line["config"]["repeats"]
-    assert "25 ms" in line["metric"] and line["config"]["win_samples"] == 400     # the metric's own parameter set
+    assert "25 ms" in line["metric"] and line["config"]["win_samples"] == (1103 if "sndenv_cfg1" in extra else 400)   # the metric's own parameter set
     assert set(line["parity"]) >= {"criterion", "elements", "max_scaled_err", "n_past_1e-5", "pass"} and line["parity"]["pass"]
     assert line["vs_baseline"] is None and line["scaling"] == "weak" and line["data"] == "synthetic"
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
