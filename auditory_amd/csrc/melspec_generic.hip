@@ -250,28 +250,39 @@ void k_melspec_generic(const MelspecArgs a) {
     }
 
     // ---- gather the F windows (sndenv.go:455-478) -------------------------------------
-    for (int i = tid; i < F * N; i += blockDim.x) {
-        const int f = i / N, n = i - f * N;
+    // frame by frame (what a frame is -- live, where it starts -- is workgroup-uniform), a thread's samples 256 apart; the pair
+    // route's per-frame exponent is the maximum over the thread's own samples first, then over the wave (DPP), then ONE LDS
+    // atomic per wave and frame (round 6: an atomic per sample was 2 206 serialised LDS operations per workgroup, and with
+    // the division of the flat index by N a quarter of the kernel's time: profiles/round6_cfg1_ablation.txt)
+    const int64_t stride = it.sig_stride > 1 ? it.sig_stride : 1;
+    for (int f = 0; f < F; ++f) {
         const int s = t0 + f;
         const int64_t start = int64_t(it.start0) + int64_t(a.S) * (s - a.border);
         const bool live = s < T && start + N <= int64_t(it.sig_len);
-        const int64_t pos = start + n;
-        TT v = TT(0);
-        if (live && pos >= 0) v = load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + pos * (it.sig_stride > 1 ? it.sig_stride : 1));
-        if (inpl && !pair) {  // (one frame per workgroup) z[n / 2] = (x[2j], x[2j+1]) for even N, z[n] = (x[n], 0) for odd N
-            TT* cell = &src[padx(even ? n >> 1 : n)].x;
-            if (even) cell[n & 1] = v;
-            else { cell[0] = v; cell[1] = TT(0); }
-        } else if (even) {
-            reinterpret_cast<TT*>(src)[size_t(f) * N + n] = v;  // z[n/2] = (x[2j], x[2j+1])
-        } else if (pair) {
-            (&src[inpl ? padx(n) : n].x)[f] = v;   // frame 0: real parts, frame 1: imaginary parts
-            // an Inf / NaN sample takes its frame OUT of the pair (sentinel exponent): the frame's bins are NaN, as a transform of
-            // its own would leave them, and its partner -- an independent frame in the reference (dft.go:42-50) -- runs alone
-            const int ex = (v - v == TT(0)) ? amax_exponent<TT>(v < TT(0) ? -v : v) : kNonFinite;
-            if (ex != kNoSignal) atomicMax(pair_exp + f, ex);
-        } else {
-            src[size_t(f) * M + n] = {v, TT(0)};
+        int ex_max = kNoSignal;
+        for (int n = tid; n < N; n += blockDim.x) {
+            const int64_t pos = start + n;
+            TT v = TT(0);
+            if (live && pos >= 0) v = load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + pos * stride);
+            if (inpl && !pair) {  // (one frame per workgroup) z[n / 2] = (x[2j], x[2j+1]) for even N, z[n] = (x[n], 0) for odd N
+                TT* cell = &src[padx(even ? n >> 1 : n)].x;
+                if (even) cell[n & 1] = v;
+                else { cell[0] = v; cell[1] = TT(0); }
+            } else if (even) {
+                reinterpret_cast<TT*>(src)[size_t(f) * N + n] = v;  // z[n/2] = (x[2j], x[2j+1])
+            } else if (pair) {
+                (&src[inpl ? padx(n) : n].x)[f] = v;   // frame 0: real parts, frame 1: imaginary parts
+                // an Inf / NaN sample takes its frame OUT of the pair (sentinel exponent): the frame's bins are NaN, as a transform of
+                // its own would leave them, and its partner -- an independent frame in the reference (dft.go:42-50) -- runs alone
+                const int ex = (v - v == TT(0)) ? amax_exponent<TT>(v < TT(0) ? -v : v) : kNonFinite;
+                ex_max = ex > ex_max ? ex : ex_max;
+            } else {
+                src[size_t(f) * M + n] = {v, TT(0)};
+            }
+        }
+        if (pair) {  // (uniform)
+            ex_max = wave_max_i32(ex_max);
+            if ((tid & 63) == 0 && ex_max != kNoSignal) atomicMax(pair_exp + f, ex_max);
         }
     }
     __syncthreads();
@@ -385,7 +396,21 @@ void k_melspec_generic(const MelspecArgs a) {
             return src[size_t(f) * M + k];
         }
     };
-    for (int w = tid; w < F * H; w += blockDim.x) {
+    if (pair) {  // (uniform) both frames' bins from ONE read of Z[k] and Z[M - k]
+        const int ex0 = pair_exp[0], ex1 = pair_exp[1];
+        for (int k = tid; k < H; k += blockDim.x) {
+            const C2<TT> A = zat(0, k), B = zat(0, k == 0 ? 0 : M - k);
+            {
+                const TT re = (A.x + B.x) * TT(0.5), im = (A.y - B.y) * TT(0.5);
+                P[k] = ex0 == kNoSignal ? TT(0) : ex0 == kNonFinite ? TT(__builtin_nan("")) : scale2(re * re + im * im, 2 * ex0);
+            }
+            {
+                const TT re = (A.y + B.y) * TT(0.5), im = (B.x - A.x) * TT(0.5);
+                P[size_t(Hp) + k] = ex1 == kNoSignal ? TT(0) : ex1 == kNonFinite ? TT(__builtin_nan("")) : scale2(re * re + im * im, 2 * ex1);
+            }
+        }
+    }
+    for (int w = tid; w < (pair ? 0 : F * H); w += blockDim.x) {
         const int f = w / H, k = w - f * H;
         TT re, im;
         if (even) {
@@ -398,19 +423,6 @@ void k_melspec_generic(const MelspecArgs a) {
             // -i * (dr + i di) = di - i dr
             re = er + (di * wk.x + dr * wk.y);
             im = ei + (di * wk.y - dr * wk.x);
-        } else if (pair) {
-            const C2<TT> A = zat(0, k), B = zat(0, k == 0 ? 0 : M - k);
-            if (f == 0) {
-                re = (A.x + B.x) * TT(0.5);
-                im = (A.y - B.y) * TT(0.5);
-            } else {
-                re = (A.y + B.y) * TT(0.5);
-                im = (B.x - A.x) * TT(0.5);
-            }
-            const int ex = pair_exp[f];
-            const TT p = ex == kNoSignal ? TT(0) : ex == kNonFinite ? TT(__builtin_nan("")) : scale2(re * re + im * im, 2 * ex);
-            P[size_t(f) * Hp + k] = p;
-            continue;
         } else {
             const C2<TT> z = zat(f, k);
             re = z.x;
@@ -483,8 +495,25 @@ void k_melspec_generic(const MelspecArgs a) {
                 const int lo = a.bin_pts[flt], hi = a.bin_pts[flt + 2];
                 const TT* wrow = filt + size_t(flt) * cols;
                 const TT* prow = P + size_t(f) * Hp;
-                if (live)
+                constexpr int kJ = 9;  // taps of a lane where a table row has at most 36 columns (nf <= 34: the reference's 32)
+                if (live && cols <= 4 * kJ) {
+                    // every tap's weight requested before the first is used: as a loop with a data-dependent trip count each
+                    // iteration waited for its own table load -- five to nine L2 round trips in a row (round 6).  Same products,
+                    // same order of additions
+                    TT wv[kJ];
+#pragma unroll
+                    for (int j = 0; j < kJ; ++j) {
+                        const int bin = lo + part + 4 * j;
+                        wv[j] = wrow[bin <= hi ? bin - lo : 0];
+                    }
+#pragma unroll
+                    for (int j = 0; j < kJ; ++j) {
+                        const int bin = lo + part + 4 * j;
+                        if (bin <= hi) sum += wv[j] * prow[bin];
+                    }
+                } else if (live) {
                     for (int bin = lo + part; bin <= hi; bin += 4) sum += wrow[bin - lo] * prow[bin];
+                }
             }
             sum += __shfl_xor(sum, 2, 64);
             sum += __shfl_xor(sum, 1, 64);
