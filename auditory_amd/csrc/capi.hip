@@ -36,6 +36,7 @@ void fill_melspec_args(const aud_plan* p, aud::MelspecArgs* a) {
     a->bl_bhat = p->d_bl_bhat;
     a->bl_tw = p->d_bl_tw;
     a->bl_inplace = p->bl_inplace ? 1 : 0;
+    a->bl_fix = (p->chirp_opt && p->d_bl_fix) ? p->d_bl_fix : nullptr;
     a->xcd_remap = p->xcd_remap;
     a->stamps = reinterpret_cast<unsigned long long*>(p->stamps);
 }
@@ -50,6 +51,7 @@ hipError_t launch_frames(const aud_plan* p, const aud::MelspecArgs& a, hipStream
         }
         return aud::launch_melspec_wave(p->wave_kind, a, p->wv, p->d.compute_dtype, st);
     }
+    if (a.bl_fix) return aud::launch_melspec_chirp(a, p->d.compute_dtype, st);
     return aud::launch_melspec_generic(a, p->d.compute_dtype, st);
 }
 
@@ -269,6 +271,11 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
             rc = upload_real(c, &p->d_bl_chirp, chirp.data(), chirp.size(), d->compute_dtype);
             if (rc == AUD_OK) rc = upload_real(c, &p->d_bl_bhat, bhat.data(), bhat.size(), d->compute_dtype);
             if (rc == AUD_OK) rc = upload_real(c, &p->d_bl_tw, twl.data(), twl.size(), d->compute_dtype);
+            if (rc == AUD_OK && aud::melspec_chirp_serves(N, M, L)) {  // the fixed-geometry kernel's tables (melspec_chirp.hip)
+                std::vector<double> fix(size_t(aud::melspec_chirp_table_len()) * 2);
+                aud::melspec_chirp_tables(twl.data(), bhat.data(), fix.data());
+                rc = upload_real(c, &p->d_bl_fix, fix.data(), fix.size(), d->compute_dtype);
+            }
             const size_t lds = aud::melspec_generic_lds_bytes(L, 1, d->compute_dtype, true);
             if (rc == AUD_OK && lds > 64u * 1024u && aud::melspec_generic_prepare(lds) != hipSuccess) {
                 (void)hipGetLastError();
@@ -337,6 +344,7 @@ int aud_plan_destroy(aud_plan* p) {
     if (p->d_bl_chirp) (void)hipFree(p->d_bl_chirp);
     if (p->d_bl_bhat) (void)hipFree(p->d_bl_bhat);
     if (p->d_bl_tw) (void)hipFree(p->d_bl_tw);
+    if (p->d_bl_fix) (void)hipFree(p->d_bl_fix);
     if (p->d_filt) (void)hipFree(p->d_filt);
     if (p->d_bin_pts) (void)hipFree(p->d_bin_pts);
     if (p->d_gabor) (void)hipFree(p->d_gabor);
@@ -359,6 +367,7 @@ int aud_plan_get_info(const aud_plan* p, const char* name, int64_t* value) {
     else if (key == "wgs_per_cu") *value = wave ? p->wv.wgs_per_cu : 0;
     else if (key == "bluestein_L") *value = wave ? 0 : p->bl_L;
     else if (key == "bluestein_inplace") *value = !wave && p->bl_L && p->bl_inplace ? 1 : 0;
+    else if (key == "chirp_kernel") *value = !wave && p->d_bl_fix && p->chirp_opt ? 1 : 0;  // the fixed-geometry kernel of L = 2304 runs this plan
     else if (key == "generic_frames_per_wg") *value = p->F_generic;  // frames a workgroup of the any-N kernel transforms at once
     else if (key == "item_kernel") *value = wave && p->has_item ? 1 : 0;        // the workgroup-per-item variant exists for this plan
     else if (key == "item_waves") *value = wave && p->has_item ? p->itm.waves : 0;
@@ -408,6 +417,11 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
     if (key == "fused_tail") {
         if (value < -1 || value > 1) return fail(c, AUD_EINVAL, "fused_tail: -1 / 1 (wherever the kernel can) or 0 (never)");
         p->fused_tail_opt = value;
+        return AUD_OK;
+    }
+    if (key == "chirp_kernel") {  // 1 (default): the fixed-geometry chirp kernel wherever it serves the plan; 0: the any-N route
+        if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "chirp_kernel: 0 or 1");
+        p->chirp_opt = value;
         return AUD_OK;
     }
     if (key == "xcd_remap") {  // 1 (default): every XCD walks a contiguous run of tiles; 0: tiles in workgroup-id order
@@ -523,6 +537,7 @@ bool segment_fused(const aud_plan* p) {
         return false;
     if (p->use_wave && p->wave_kind) return p->wv.dct_off >= 0;
     // the any-N kernel (round 6): DCT and Energy sums from its unrounded values wherever its power buffer has the room
+    if (p->chirp_opt && p->d_bl_fix) return aud::melspec_chirp_tail_fits(p->F_generic, p->H, p->d.mel.n_filters, p->d.compute_dtype);
     return aud::melspec_generic_tail_fits(p->M, p->F_generic, p->H, p->d.mel.n_filters, p->d.compute_dtype, p->bl_L, p->bl_inplace);
 }
 // tiles of an item the fused tail's per-tile Energy sums come in: wave tiles, or the any-N kernel's workgroups of F frames

@@ -113,6 +113,8 @@ struct aud_plan {
     void* d_bl_chirp = nullptr;
     void* d_bl_bhat = nullptr;
     void* d_bl_tw = nullptr;
+    void* d_bl_fix = nullptr;  // tables of the fixed-geometry chirp kernel (melspec_chirp.hip) where it serves the plan
+    int chirp_opt = 1;         // plan option "chirp_kernel": 1 (default) use it where it serves, 0 the any-N route
     int xcd_remap = 1;         // workgroup -> tile order keeps an XCD on one run of tiles (kernels.h)
     // wave-autonomous kernel of this window length (melspec_wave.hip), the default where it exists
     int wave_kind = 0;         // = the kind number of melspec_wave.hip (0: none)

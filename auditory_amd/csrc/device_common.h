@@ -160,8 +160,37 @@ struct SmallDft<TT, 8> {  // 8 = 4 x 2: two 4-point DFTs (even / odd samples), t
         v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
     }
 };
+// 16 = 4 x 4.  First layer: 4-point DFTs over a of the inputs n = 4 a + b (result k1 at v[4 k1 + b]); then the inner twiddles
+// W16^(b k1); second layer: 4-point DFTs over b (result k2 at v[4 k1 + k2], frequency k = k1 + 4 k2); then the transposition
+// that puts frequency k at v[k].  The layers are separate functions because the fixed-geometry chirp kernel
+// (melspec_chirp.hip) prunes them: a first layer whose inputs n >= 8 are zero, a second layer of which only k < 8 is used.
 template <typename TT>
-struct SmallDft<TT, 16> {  // 16 = 4 x 4
+__device__ __forceinline__ void dft16_twiddle(C2<TT> (&v)[16]) {
+    const TT c1 = TT(0.92387953251128675613L), s1 = TT(0.38268343236508977173L);
+    const TT r2 = TT(0.70710678118654752440L);
+    v[5] = cmul(v[5], C2<TT>{c1, -s1});
+    v[9] = C2<TT>{(v[9].x + v[9].y) * r2, (v[9].y - v[9].x) * r2};
+    v[13] = cmul(v[13], C2<TT>{s1, -c1});
+    v[6] = C2<TT>{(v[6].x + v[6].y) * r2, (v[6].y - v[6].x) * r2};
+    v[10] = mul_mi(v[10]);
+    v[14] = C2<TT>{(v[14].y - v[14].x) * r2, -(v[14].x + v[14].y) * r2};
+    v[7] = cmul(v[7], C2<TT>{s1, -c1});
+    v[11] = C2<TT>{(v[11].y - v[11].x) * r2, -(v[11].x + v[11].y) * r2};
+    v[15] = cmul(v[15], C2<TT>{-c1, s1});
+}
+template <typename TT>
+__device__ __forceinline__ void dft16_transpose(C2<TT> (&v)[16]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) {
+            const C2<TT> t = v[4 * i + j];
+            v[4 * i + j] = v[4 * j + i];
+            v[4 * j + i] = t;
+        }
+}
+template <typename TT>
+struct SmallDft<TT, 16> {
     static __device__ __forceinline__ void run(C2<TT> (&v)[16], const C2<TT>*, int) {
         const TT c1 = TT(0.92387953251128675613L), s1 = TT(0.38268343236508977173L);
         const TT r2 = TT(0.70710678118654752440L);

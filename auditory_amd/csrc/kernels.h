@@ -60,6 +60,7 @@ struct MelspecArgs {
     const void* bl_bhat;   // [L] complex<TT>: FFT_L of the wrapped conjugate chirp, / L
     const void* bl_tw;     // [L] complex<TT>: exp(-2 pi i k / L)
     int bl_inplace;        // 1: ONE padded LDS buffer, stages through registers (melspec_generic.hip stage_inplace)
+    const void* bl_fix;    // the fixed-geometry chirp kernel's tables (melspec_chirp.hip: twiddles of both outer stages, bhat in its digit-reversed order); null: the any-N route
     int xcd_remap;     // 1: tile_of_workgroup() order (plan option "xcd_remap", default on)
     // wave kernels: wave tiles per item (N = 2048: frames per item) and its reciprocal, set by launch_melspec_wave -- a
     // wave finds its item with one scalar multiply (tile_div) instead of the 64-bit division's twenty vector instructions
@@ -255,6 +256,15 @@ int melspec_generic_pick_F(int M, int compute_dtype);
 int melspec_generic_bluestein_L(int M, int compute_dtype);
 hipError_t melspec_generic_prepare(size_t lds_bytes);
 hipError_t launch_melspec_generic(const MelspecArgs& a, int compute_dtype, hipStream_t st);
+
+// the chirp convolution of fixed length 2304 = 16 x 16 x 9 (melspec_chirp.hip): odd window lengths 1024 < N <= 1152 -- the
+// reference's 25 ms at 44.1 kHz = 1103 samples -- with compile-time stage geometry, five LDS round trips instead of six
+bool melspec_chirp_serves(int N, int M, int bl_L);
+size_t melspec_chirp_lds_bytes(int compute_dtype);
+int melspec_chirp_table_len();
+void melspec_chirp_tables(const double* twl, const double* bhat, double* out);
+bool melspec_chirp_tail_fits(int F, int H, int nf, int compute_dtype);
+hipError_t launch_melspec_chirp(const MelspecArgs& a, int compute_dtype, hipStream_t st);
 
 // wave-autonomous kernels (melspec_wave.hip): N = 512 as 16 x 16 (kind 1), N = 400 as 20 x 10 (kind 3), N = 2048 as
 // 16 x 16 x 4 with one frame per wave (kind 4); no workgroup barrier behind the table staging.

@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "device_common.h"
+#include "frames_epilogue.h"
 
 namespace aud {
 namespace {
@@ -432,126 +433,7 @@ void k_melspec_generic(const MelspecArgs a) {
     }
     __syncthreads();
 
-    // ---- optional PowerSegment / LogPowerSegment (dft.go:70-83) -----------------------
-    if (a.power || a.log_power) {
-        const TT off = TT(a.dft_log_off), lmin = TT(a.dft_log_min);
-        for (int w = tid; w < F * H; w += blockDim.x) {
-            const int k = w / F, f = w - k * F;
-            const int sstep = t0 + f;
-            if (sstep >= T) continue;
-            const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
-            const bool live = start + N <= int64_t(it.sig_len);
-            const TT pw = P[size_t(f) * Hp + k];
-            const size_t o = (size_t(item) * H + k) * T + sstep;
-            if (a.power) a.power[o] = live ? float(pw) : 0.f;
-            if (a.log_power) {
-                float lp = 0.f;
-                if (live && a.comp_log_pow) {
-                    const TT v = pw + off;
-                    lp = float(v == TT(0) ? lmin : dev_log(v));
-                }
-                a.log_power[o] = lp;
-            }
-        }
-    }
-
-    // ---- fused segment tail, part 1 (aud_segment_batch_dev; sndenv.go:360-366 with its axis quirk): Energy[s] sums
-    // the log-power of BIN s over the steps of the segment -- this workgroup's share, from the UNROUNDED values, for s < T
-    if (a.energy_part) {
-        const TT off = TT(a.dft_log_off), lmin = TT(a.dft_log_min);
-        TT* ep = static_cast<TT*>(a.energy_part) + (size_t(item) * tiles + size_t(t0 / F)) * T;
-        for (int s = tid; s < T; s += blockDim.x) {  // (T <= H: the host checks, the Go code panics otherwise)
-            TT e = TT(0);
-            for (int f = 0; f < F; ++f) {
-                const int sstep = t0 + f;
-                const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
-                if (sstep < T && start + N <= int64_t(it.sig_len)) {  // (a step the loop never reached left LogPowerSegment at 0)
-                    const TT v = P[size_t(f) * Hp + s] + off;
-                    e += v == TT(0) ? lmin : dev_log(v);
-                }
-            }
-            ep[s] = e;
-        }
-    }
-
-    // ---- mel triangles + log (mel.go:120-153) ---------------------------------------
-    TT* melL = P + size_t(F) * Hp;  // fused tail: the workgroup's [F][nf] log-mel values before their float32 rounding
-    {
-        const TT* __restrict__ filt = static_cast<const TT*>(a.filt);
-        const int cols = a.nf + 2;
-        const TT loff = TT(a.mel_log_off), lmin = TT(a.mel_log_min);
-        // FOUR lanes per (frame, filter): the workgroup has few frames (one or two with Bluestein) and a filter's taps are a
-        // serial chain of table loads -- one lane per filter left three of the four waves idle through the kernel's tail.  A
-        // lane takes every fourth tap; the four partial sums meet by two lane exchanges, (p0 + p2) + (p1 + p3) on every lane.
-        const int n_work = F * a.nf;
-        for (int w0 = tid >> 2; w0 < ((n_work + 63) & ~63); w0 += blockDim.x >> 2) {  // (whole waves stay in the exchanges)
-            const int w = w0 < n_work ? w0 : n_work - 1, part = tid & 3;
-            const int flt = w / F, f = w - flt * F;
-            const int sstep = t0 + f;
-            const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
-            const bool live = sstep < T && start + N <= int64_t(it.sig_len);
-            TT sum = TT(0);
-            {
-                const int lo = a.bin_pts[flt], hi = a.bin_pts[flt + 2];
-                const TT* wrow = filt + size_t(flt) * cols;
-                const TT* prow = P + size_t(f) * Hp;
-                constexpr int kJ = 9;  // taps of a lane where a table row has at most 36 columns (nf <= 34: the reference's 32)
-                if (live && cols <= 4 * kJ) {
-                    // every tap's weight requested before the first is used: as a loop with a data-dependent trip count each
-                    // iteration waited for its own table load -- five to nine L2 round trips in a row (round 6).  Same products,
-                    // same order of additions
-                    TT wv[kJ];
-#pragma unroll
-                    for (int j = 0; j < kJ; ++j) {
-                        const int bin = lo + part + 4 * j;
-                        wv[j] = wrow[bin <= hi ? bin - lo : 0];
-                    }
-#pragma unroll
-                    for (int j = 0; j < kJ; ++j) {
-                        const int bin = lo + part + 4 * j;
-                        if (bin <= hi) sum += wv[j] * prow[bin];
-                    }
-                } else if (live) {
-                    for (int bin = lo + part; bin <= hi; bin += 4) sum += wrow[bin - lo] * prow[bin];
-                }
-            }
-            sum += __shfl_xor(sum, 2, 64);
-            sum += __shfl_xor(sum, 1, 64);
-            if (part != 0 || w0 >= n_work) continue;
-            float res = 0.f;
-            TT val = TT(0);
-            if (live) {
-                sum += loff;
-                val = (sum == TT(0)) ? lmin : dev_log(sum);
-                if (a.renorm) {
-                    val -= TT(a.renorm_min);
-                    if (val < TT(0)) val = TT(0);
-                    val *= TT(a.renorm_scale);
-                    if (val > TT(1)) val = TT(1);
-                }
-                res = float(val);
-            }
-            if (a.mfcc_acc) melL[f * a.nf + flt] = val;  // (0 for a step the loop never reached: its MFCC column stays 0)
-            if (sstep < T) a.mel[(size_t(item) * a.nf + flt) * T + sstep] = res;
-        }
-    }
-
-    // ---- fused segment tail, part 2: mel.Params.CepstrumDct (mel.go:192-212) on the unrounded log-mel values, rows 1 .. (row 0 is
-    // overwritten with Energy, sndenv.go:368-372: launch_segment_finish does that and the deltas)
-    if (a.mfcc_acc) {
-        __syncthreads();
-        const TT* __restrict__ D = static_cast<const TT*>(a.dct_rows);
-        TT* acc = static_cast<TT*>(a.mfcc_acc) + size_t(item) * a.n_coefs * T;
-        for (int w = tid; w < F * (a.n_coefs - 1); w += blockDim.x) {
-            const int c = 1 + w / F, f = w - (c - 1) * F, sstep = t0 + f;
-            if (sstep >= T) continue;
-            const TT* drow = D + size_t(c) * a.nf;
-            const TT* mrow = melL + f * a.nf;
-            TT sum = TT(0);
-            for (int j = 0; j < a.nf; ++j) sum = mad(drow[j], mrow[j], sum);
-            acc[size_t(c) * T + sstep] = sum;
-        }
-    }
+    frames_epilogue<TT>(a, it, item, tiles, t0, P, tid);
 }
 
 }  // namespace

@@ -686,6 +686,94 @@ def case_random_any_n(orc, seed, windows):
     return what
 
 
+def case_chirp_kernel(orc, N, cdt, seed=0, sig_kind="float", quirks=False):
+    """The fixed-geometry chirp kernel (melspec_chirp.hip: odd window lengths 1024 < N <= 1152, L = 2304 = 16 x 16 x 9, the
+    reference's N = 1103) against the oracle AND against the any-N route it replaces (plan option chirp_kernel = 0): mel, Power
+    and log-power of a seeded random parameter set; `quirks`: an all-zero frame beside a loud one, a frame with an Inf sample
+    beside a finite one (its bins NaN, the partner's untouched), segments that run off the signal end, a left zero pad."""
+    rng = np.random.default_rng(7000 + 13 * N + seed)
+    sr = 44100
+    S = int(rng.integers(N // 3, N // 2 + 40))
+    T = int(rng.integers(3, 12))
+    border = int(rng.integers(0, 3))
+    mp, filt = _valid_mel(N, sr, rng)
+    assert mp is not None
+    nf = mp.FBank.NFilters
+    L = int(N + S * (T + rng.integers(0, 3)))
+    sig, pcm = synth.batch(900 + seed, 2, L, sr)
+    if quirks:
+        sig[0, S * 2:S * 2 + N] = 0.0                    # a frame of exact zeros (LogMin rule) between live ones
+        sig[0, :S] *= 1e6                                # ... and a loud neighbour
+        sig[1, S * 3 + 5] = np.inf                       # a non-finite sample: every frame that holds it is NaN, no other
+    sp = orc.SndParams(sr, N, S, S * max(1, T // 2), T, border)
+    d, m = orc.dft_defaults(), orc.mel_defaults()
+    m.n_filters, m.lo_hz, m.hi_hz = nf, mp.FBank.LoHz, mp.FBank.HiHz
+    rc, bins, hz, ofilt = orc.mel_init_filters(m, N, sr)
+    assert rc == 0 and np.array_equal(bins, mp.BinPts)
+    segs = [(r, s) for r in range(2) for s in (0, 1, 2)]  # (the later segments run off the end: masked steps)
+    dsig = sig
+    if sig_kind == "int16":
+        dsig = pcm.astype(np.float64) / 32767.0
+    with np.errstate(invalid="ignore"):
+        ref = [orc.process_segment(sp, d, m, bins, ofilt, dsig[r], segment=s) for r, s in segs]
+    ref_mel = np.stack([o["mel_seg"] for o in ref])
+    ref_pw = np.stack([o["power_seg"] for o in ref])
+    ref_lp = np.stack([o["log_power_seg"] for o in ref])
+    dftp = capi.DftParams()
+    capi.load().aud_dft_defaults(dftp)
+    out = {}
+    for opt in (1, 0):
+        plan = runtime.Plan(runtime.get_ctx(0), N, S, T, border, dftp, mp.FBank.to_c(), mp.BinPts, filt, compute_dtype=cdt)
+        try:
+            plan.set_option("chirp_kernel", opt)
+            assert plan.kernel_name == "generic" and plan.info("bluestein_L") == 2304 and plan.info("chirp_kernel") == opt
+            items = runtime.make_items([r * L for r, s in segs], [L] * len(segs), [s * sp.stride_samples for r, s in segs])
+            if sig_kind == "int16":    # the device normalises the PCM itself (sound.go:138), sample by sample as the window is read
+                dev = runtime.Signal(plan.ctx, pcm.ravel())
+                try:
+                    out[opt] = plan.melspec_sig(dev, items, True, True)
+                finally:
+                    dev.close()
+            else:
+                out[opt] = plan.melspec_host(sig.ravel(), items, True, True)
+        finally:
+            plan.close()
+    what = "N=%d S=%d T=%d border=%d nf=%d" % (N, S, T, border, nf)
+    for opt in (1, 0):
+        mel, pw, lp = out[opt]
+        tag = what + (" chirp kernel" if opt else " any-N route")
+        if quirks:
+            # frames whose OWN window holds the Inf sample: NaN in every bin, here as there.  The reference then keeps the NaN for
+            # the REST of the segment (dft.go:67-69: step > 0 adds PrevSmooth * power[k] = 0 * NaN); the kernels treat frames
+            # independently -- a documented deviation (DESIGN 5) -- so those later steps are left out of the comparison
+            pos = S * 3 + 5
+            own = np.zeros(ref_pw.shape[::2], bool)                   # [items, T]
+            for i, (r, sg) in enumerate(segs):
+                for st in range(T):
+                    a0 = sg * sp.stride_samples + S * (st - border)
+                    own[i, st] = r == 1 and a0 <= pos < a0 + N and a0 + N <= L
+            later = np.maximum.accumulate(own, axis=1) & ~own
+            assert own.any() and np.isnan(ref_pw.transpose(0, 2, 1)[own]).all() and np.isnan(pw.transpose(0, 2, 1)[own]).all(), tag
+            assert not np.isnan(pw.transpose(0, 2, 1)[~own]).any(), tag + ": a NaN outside the frames that hold the Inf sample"
+            keep = ~(own | later)
+            mel, ref_mel_c = np.where(keep[:, None, :], mel, 0), np.where(keep[:, None, :], ref_mel, 0)
+            pw, ref_pw_c = np.where(keep[:, None, :], pw, 0), np.where(keep[:, None, :], ref_pw, 0)
+            lp, ref_lp_c = np.where(keep[:, None, :], lp, 0), np.where(keep[:, None, :], ref_lp, 0)
+        else:
+            ref_mel_c, ref_pw_c, ref_lp_c = ref_mel, ref_pw, ref_lp
+        ok, msg = W.feature_close(mel, ref_mel_c, cdt, lin_axis=1)
+        assert ok, tag + ": mel " + msg
+        ok, msg = W.spectrum_close(pw, ref_pw_c, 4e-6 if cdt == capi.AUD_F32 else 3e-7)
+        assert ok, tag + ": power " + msg
+        if cdt == capi.AUD_F64:
+            ok, msg = W.close_enough(lp, ref_lp_c, TOL_F64)
+            assert ok, tag + ": log_power " + msg
+    # the two routes compute the same convolution: where a frame is silent or dead both leave exact zeros, NaN frames are the same
+    a, b = out[1][1], out[0][1]
+    assert np.array_equal(a == 0, b == 0) and np.array_equal(np.isnan(a), np.isnan(b)), what + ": exact zeros / NaN differ between the routes"
+    return what
+
+
 def case_generic_lds_limits(orc, run=((4096, capi.AUD_F64), (8192, capi.AUD_FAST_F32))):
     """Window lengths whose two complex buffers fill the 64 KB of a plain launch TO THE BYTE: N = 4096 in float64 (M = 2048 x 16 B
     x 2) and N = 8192 in float32 must still get a plan (one frame per workgroup) -- the pair-route's two exponent words are the

@@ -597,6 +597,20 @@ def test_random_any_n_configs(orc, torch_cuda):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,cdt,kind,quirks", [(1103, capi.AUD_F64, "float", True), (1103, capi.AUD_F64, "int16", False),
+                                               (1103, capi.AUD_FAST_F32, "float", True), (1027, capi.AUD_F64, "float", False),
+                                               (1151, capi.AUD_F64, "float", True), (1025, capi.AUD_FAST_F32, "int16", False),
+                                               (1131, capi.AUD_F64, "int16", True)],
+                         ids=["n1103_f64_quirks", "n1103_f64_i16", "n1103_f32_quirks", "n1027_f64", "n1151_f64_quirks", "n1025_f32_i16",
+                              "n1131_f64_i16_quirks"])
+def test_chirp_kernel(orc, torch_cuda, N, cdt, kind, quirks):
+    """the fixed-geometry chirp kernel of L = 2304 (melspec_chirp.hip: the reference's N = 1103 and the other odd window lengths
+    it serves) against the oracle and against the any-N route it replaces, three seeds each"""
+    for seed in range(3):
+        PC.case_chirp_kernel(orc, N, cdt, seed=seed, sig_kind=kind, quirks=quirks)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("sr", [16000, 44100])
 def test_speech_like_sndenv(orc, torch_cuda, tmp_path, sr):
     """BASELINE configs[0] as worded, on hardware: SURVEY 8d's cfg-1 WAV (3 s of speech-like audio, written by the test)
