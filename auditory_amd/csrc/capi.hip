@@ -51,7 +51,7 @@ hipError_t launch_frames(const aud_plan* p, const aud::MelspecArgs& a, hipStream
         }
         return aud::launch_melspec_wave(p->wave_kind, a, p->wv, p->d.compute_dtype, st);
     }
-    if (a.bl_fix) return aud::launch_melspec_chirp(a, p->d.compute_dtype, st);
+    if (a.bl_fix) return aud::launch_melspec_chirp(a, st);
     return aud::launch_melspec_generic(a, p->d.compute_dtype, st);
 }
 
@@ -271,7 +271,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
             rc = upload_real(c, &p->d_bl_chirp, chirp.data(), chirp.size(), d->compute_dtype);
             if (rc == AUD_OK) rc = upload_real(c, &p->d_bl_bhat, bhat.data(), bhat.size(), d->compute_dtype);
             if (rc == AUD_OK) rc = upload_real(c, &p->d_bl_tw, twl.data(), twl.size(), d->compute_dtype);
-            if (rc == AUD_OK && aud::melspec_chirp_serves(N, M, L)) {  // the fixed-geometry kernel's tables (melspec_chirp.hip)
+            if (rc == AUD_OK && aud::melspec_chirp_serves(N, M, L, d->compute_dtype)) {  // the fixed-geometry kernel's tables (melspec_chirp.hip)
                 std::vector<double> fix(size_t(aud::melspec_chirp_table_len()) * 2);
                 aud::melspec_chirp_tables(twl.data(), bhat.data(), fix.data());
                 rc = upload_real(c, &p->d_bl_fix, fix.data(), fix.size(), d->compute_dtype);
@@ -537,7 +537,7 @@ bool segment_fused(const aud_plan* p) {
         return false;
     if (p->use_wave && p->wave_kind) return p->wv.dct_off >= 0;
     // the any-N kernel (round 6): DCT and Energy sums from its unrounded values wherever its power buffer has the room
-    if (p->chirp_opt && p->d_bl_fix) return aud::melspec_chirp_tail_fits(p->F_generic, p->H, p->d.mel.n_filters, p->d.compute_dtype);
+    if (p->chirp_opt && p->d_bl_fix) return aud::melspec_chirp_tail_fits(p->H, p->d.mel.n_filters);
     return aud::melspec_generic_tail_fits(p->M, p->F_generic, p->H, p->d.mel.n_filters, p->d.compute_dtype, p->bl_L, p->bl_inplace);
 }
 // tiles of an item the fused tail's per-tile Energy sums come in: wave tiles, or the any-N kernel's workgroups of F frames

@@ -259,12 +259,12 @@ hipError_t launch_melspec_generic(const MelspecArgs& a, int compute_dtype, hipSt
 
 // the chirp convolution of fixed length 2304 = 16 x 16 x 9 (melspec_chirp.hip): odd window lengths 1024 < N <= 1152 -- the
 // reference's 25 ms at 44.1 kHz = 1103 samples -- with compile-time stage geometry, five LDS round trips instead of six
-bool melspec_chirp_serves(int N, int M, int bl_L);
-size_t melspec_chirp_lds_bytes(int compute_dtype);
+bool melspec_chirp_serves(int N, int M, int bl_L, int compute_dtype);  // (float64 plans: two frames per transform)
+size_t melspec_chirp_lds_bytes();
 int melspec_chirp_table_len();
 void melspec_chirp_tables(const double* twl, const double* bhat, double* out);
-bool melspec_chirp_tail_fits(int F, int H, int nf, int compute_dtype);
-hipError_t launch_melspec_chirp(const MelspecArgs& a, int compute_dtype, hipStream_t st);
+bool melspec_chirp_tail_fits(int H, int nf);
+hipError_t launch_melspec_chirp(const MelspecArgs& a, hipStream_t st);
 
 // wave-autonomous kernels (melspec_wave.hip): N = 512 as 16 x 16 (kind 1), N = 400 as 20 x 10 (kind 3), N = 2048 as
 // 16 x 16 x 4 with one frame per wave (kind 4); no workgroup barrier behind the table staging.

@@ -40,16 +40,42 @@ constexpr int kChirpNonFinite = 1 << 20;  // sentinel exponent of a frame that h
 // (k1 < 16, n2 < 9), bhat_mid[i][thread] = bhat[k0 + 16 k1 + 256 i] for the block (k0, k1) the thread owns in the middle stage
 constexpr int kTw1 = 0, kTw2 = 16 * kBlk, kBhat = kTw2 + 16 * 9, kTabLen = kBhat + 9 * 256;
 
-__device__ __forceinline__ float chirp_scale2(float v, int e) { return ldexpf(v, e); }
 __device__ __forceinline__ double chirp_scale2(double v, int e) { return ldexp(v, e); }
 
-// load_sample (device_common.h) with int16 PCM / 0x7FFF (sound.go:138) by pcm16_to: the correctly rounded quotient for every
-// int16 value without the division sequence (sixteen float64 divisions per thread otherwise)
-template <typename TT>
-__device__ __forceinline__ TT chirp_sample(const void* sig, int dtype, int64_t i) {
-    if (dtype == AUD_F32) return TT(static_cast<const float*>(sig)[i]);
-    if (dtype == AUD_F64) return TT(static_cast<const double*>(sig)[i]);
-    return pcm16_to<TT>(int(static_cast<const int16_t*>(sig)[i]));
+// A thread's eight samples of both frames, n = tid + 144 n0: ALL sixteen loads in flight before the first is used -- the sample
+// type is a launch constant (one straight-line copy per type), and no load sits under a condition: a frame with has[f] is live
+// (start + N <= sig_len) with start + N > 0, so every position clamped to [max(start, 0), start + N - 1] is a sample of the
+// stream; a frame without (dead, or wholly inside the left zero pad of sndenv.go:461-468) reads its partner's positions and
+// discards them.  Slots outside [0, N) of the window or in the pad take 0 -- as integers / raw floats, before the conversion.
+// int16 PCM / 0x7FFF (sound.go:138) by pcm16_to_double: the correctly rounded quotient for every int16 value (device_common.h)
+template <typename S>
+__device__ __forceinline__ void chirp_windows(const S* __restrict__ stream, int64_t stride, const int64_t (&start)[2], const bool (&has)[2],
+                                              int N, int tid, double (&x)[2][8]) {
+    S raw[2][8];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int64_t from = has[f] ? start[f] : start[1 - f];  // (uniform; the caller has checked has[0] || has[1])
+        const int pad = from < 0 ? int(-from) : 0;               // samples of the window inside the left pad (< N)
+        const S* __restrict__ first = stream + (from + pad) * stride;  // the window's first sample that exists
+        const int hi = N - 1 - pad;
+#pragma unroll
+        for (int n0 = 0; n0 < 8; ++n0) {
+            int rel = tid + kBlk * n0 - pad;
+            rel = rel < 0 ? 0 : (rel > hi ? hi : rel);
+            raw[f][n0] = first[int64_t(rel) * stride];
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int lo = !has[f] ? N : start[f] < 0 ? int(-start[f]) : 0;  // first sample of the window that is not pad (has[f]: -start < N)
+#pragma unroll
+        for (int n0 = 0; n0 < 8; ++n0) {
+            const int n = tid + kBlk * n0;
+            const S r = (n >= lo && n < N) ? raw[f][n0] : S(0);
+            if constexpr (sizeof(S) == 2) x[f][n0] = pcm16_to_double(int(r));
+            else x[f][n0] = double(r);
+        }
+    }
 }
 
 // radix-16 butterfly whose inputs 8 .. 15 are zero: the first layer's 4-point DFTs see (u0, u1, 0, 0)
@@ -89,14 +115,20 @@ __device__ __forceinline__ void dft16_out8(C2<TT> (&v)[16]) {
     }
 }
 
-template <typename TT>
+// float64 plans only (two frames per transform: F = 2).  The float32 opt-in stays on the any-N route: its N = 1103 results sit at
+// the float32 criterion's edge on either route (the logarithm's own rounding), and nothing is gained by moving them
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 void k_melspec_chirp(const MelspecArgs a) {
+    using TT = double;
     using Z = C2<TT>;
     Z* buf = reinterpret_cast<Z*>(dyn_lds());                              // 16 blocks of 144 elements, pitch 153
     int* wave_exp = reinterpret_cast<int*>(buf + 16 * kPitch);             // [4 waves][2 frames]
-    const int tid = threadIdx.x;
-    const int F = a.F, M = a.M, N = a.N, H = a.H, T = a.T;
+    // The radix-16 stages keep waves 0 .. 2 of the four busy (144 butterflies), and the hardware deals a workgroup's waves to
+    // the CU's four SIMDs in order: the roles are rotated by the workgroup's number, so that the light wave of the workgroups a
+    // CU holds does not sit on the same SIMD (measured: -2.7 %, profiles/round6_chirp_rotation_ab.txt)
+    const int tid = (int(threadIdx.x) + 64 * int(blockIdx.x & 3)) & 255;
+    constexpr int F = 2;  // (= a.F: the host launches this kernel for pair plans only)
+    const int M = a.M, N = a.N, H = a.H, T = a.T;
     const Z* __restrict__ chirp = static_cast<const Z*>(a.bl_chirp);
     const Z* __restrict__ tab = static_cast<const Z*>(a.bl_fix);
 
@@ -105,7 +137,7 @@ void k_melspec_chirp(const MelspecArgs a) {
     const int item = wg / tiles;
     const int t0 = (wg - item * tiles) * F;
     const aud_item it = a.items[item];
-    const bool pair = F == 2;  // (uniform) float64 plans: TWO real frames ride one complex transform, z[n] = x_0[n] + i x_1[n]
+    // TWO real frames ride one complex transform: z[n] = x_0[n] + i x_1[n]
 
     // ---- the window(s), straight into the first stage's registers (sndenv.go:455-478): thread r < 144 takes the samples
     // n = r + 144 n0, n0 < 8, of both frames
@@ -113,25 +145,26 @@ void k_melspec_chirp(const MelspecArgs a) {
     int ex[2] = {kNoSignal, kNoSignal};
     {
         const int64_t stride = it.sig_stride > 1 ? it.sig_stride : 1;
+        int64_t start[2];
+        bool has[2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             const int s = t0 + f;
-            const int64_t start = int64_t(it.start0) + int64_t(a.S) * (s - a.border);
-            const bool live = f < F && s < T && start + N <= int64_t(it.sig_len);
+            start[f] = int64_t(it.start0) + int64_t(a.S) * (s - a.border);
+            has[f] = s < T && start[f] + N <= int64_t(it.sig_len) && start[f] + N > 0;  // (uniform) live, and not all in the left pad
 #pragma unroll
-            for (int n0 = 0; n0 < 8; ++n0) {
-                const int n = tid + kBlk * n0;
-                const int64_t pos = start + n;
-                TT v = TT(0);
-                if (tid < kBlk && live && n < N && pos >= 0) v = chirp_sample<TT>(a.sig, a.sig_dtype, it.sig_off + pos * stride);
-                xs[f][n0] = v;
-            }
+            for (int n0 = 0; n0 < 8; ++n0) xs[f][n0] = TT(0);
+        }
+        if (tid < kBlk && (has[0] || has[1])) {
+            if (a.sig_dtype == AUD_F32) chirp_windows(static_cast<const float*>(a.sig) + it.sig_off, stride, start, has, N, tid, xs);
+            else if (a.sig_dtype == AUD_F64) chirp_windows(static_cast<const double*>(a.sig) + it.sig_off, stride, start, has, N, tid, xs);
+            else chirp_windows(static_cast<const int16_t*>(a.sig) + it.sig_off, stride, start, has, N, tid, xs);
         }
         // each frame is divided by 2^(exponent of its largest sample) so that both components of z are O(1): what leaks from
         // one frame into the other through rounding is then 2^-53 of the frame's OWN peak; the powers are scaled back exactly
         // and a frame of exact zeros keeps an exactly zero spectrum (LogMin rule, mel.go:135-137).  An Inf / NaN sample takes
         // its frame OUT of the pair (sentinel): its bins are NaN, its partner runs alone (dft.go:42-50: independent frames)
-        if (pair) {
+        {
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
 #pragma unroll
@@ -168,7 +201,7 @@ void k_melspec_chirp(const MelspecArgs a) {
         for (int n0 = 0; n0 < 8; ++n0) {
             const int n = r + kBlk * n0;
             Z z = {xs[0][n0], xs[1][n0]};
-            if (pair) z = Z{x0 == kChirpNonFinite ? TT(0) : chirp_scale2(z.x, -e0), x1 == kChirpNonFinite ? TT(0) : chirp_scale2(z.y, -e1)};
+            z = Z{x0 == kChirpNonFinite ? TT(0) : chirp_scale2(z.x, -e0), x1 == kChirpNonFinite ? TT(0) : chirp_scale2(z.y, -e1)};
             const Z c = chirp[n < M ? n : 0];
             v[n0] = n < M ? cmul<TT>(z, c) : Z{TT(0), TT(0)};
         }
@@ -289,7 +322,7 @@ void k_melspec_chirp(const MelspecArgs a) {
     TT* P = reinterpret_cast<TT*>(buf + 8 * kPitch);
     const int Hp = H | 1;
     auto zat = [&](int k) { return buf[k + 9 * (k / kBlk)]; };
-    if (pair) {
+    {
         for (int k = tid; k < H; k += 256) {
             const Z A = zat(k), B = zat(k == 0 ? 0 : M - k);
             {
@@ -301,11 +334,6 @@ void k_melspec_chirp(const MelspecArgs a) {
                 P[size_t(Hp) + k] = x1 == kNoSignal ? TT(0) : x1 == kChirpNonFinite ? TT(__builtin_nan("")) : chirp_scale2(re * re + im * im, 2 * x1);
             }
         }
-    } else {
-        for (int k = tid; k < H; k += 256) {
-            const Z A = zat(k);
-            P[k] = A.x * A.x + A.y * A.y;
-        }
     }
     __syncthreads();
 
@@ -316,9 +344,11 @@ void k_melspec_chirp(const MelspecArgs a) {
 
 // which plans the fixed-geometry kernel serves: odd window lengths (M = N) whose chirp convolution has the length 2304 the
 // any-N route would pick, and whose window fits the first stage's eight blocks of 144
-bool melspec_chirp_serves(int N, int M, int bl_L) { return bl_L == kL && (N & 1) == 1 && M == N && 2 * M - 1 <= kL && M <= 8 * kBlk; }
+bool melspec_chirp_serves(int N, int M, int bl_L, int compute_dtype) {
+    return compute_dtype == AUD_F64 && bl_L == kL && (N & 1) == 1 && M == N && 2 * M - 1 <= kL && M <= 8 * kBlk;
+}
 
-size_t melspec_chirp_lds_bytes(int compute_dtype) { return size_t(16 * kPitch) * (compute_dtype == AUD_F64 ? 16 : 8) + 32; }
+size_t melspec_chirp_lds_bytes() { return size_t(16 * kPitch) * 16 + 32; }
 int melspec_chirp_table_len() { return kTabLen; }
 
 // the three tables from the plan's long-double ones: twl[k] = exp(-2 pi i k / 2304), bhat[k] (natural order); out: kTabLen complex values
@@ -345,17 +375,16 @@ void melspec_chirp_tables(const double* twl, const double* bhat, double* out) {
 }
 
 // the fused tail parks F x nf log-mel values behind the F power spectra, which start behind block 7 of the buffer
-bool melspec_chirp_tail_fits(int F, int H, int nf, int compute_dtype) {
-    const size_t tsz = compute_dtype == AUD_F64 ? 8 : 4;
+bool melspec_chirp_tail_fits(int H, int nf) {
+    const size_t tsz = 8, F = 2;
     return size_t(8 * kPitch) * 2 * tsz + (size_t(F) * size_t(H | 1) + size_t(F) * size_t(nf)) * tsz <= size_t(16 * kPitch) * 2 * tsz;
 }
 
-hipError_t launch_melspec_chirp(const MelspecArgs& a, int compute_dtype, hipStream_t st) {
-    const int tiles = (a.T + a.F - 1) / a.F;
+hipError_t launch_melspec_chirp(const MelspecArgs& a, hipStream_t st) {
+    if (a.F != 2 || !a.bl_fix) return hipErrorInvalidValue;
+    const int tiles = (a.T + 1) / 2;
     const dim3 grid(unsigned(a.n_items) * unsigned(tiles));
-    const size_t lds = melspec_chirp_lds_bytes(compute_dtype);
-    if (compute_dtype == AUD_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_chirp<double>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_chirp<float>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL(k_melspec_chirp, grid, dim3(256), melspec_chirp_lds_bytes(), st, a);
     return hipGetLastError();
 }
 

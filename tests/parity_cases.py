@@ -691,6 +691,7 @@ def case_chirp_kernel(orc, N, cdt, seed=0, sig_kind="float", quirks=False):
     reference's N = 1103) against the oracle AND against the any-N route it replaces (plan option chirp_kernel = 0): mel, Power
     and log-power of a seeded random parameter set; `quirks`: an all-zero frame beside a loud one, a frame with an Inf sample
     beside a finite one (its bins NaN, the partner's untouched), segments that run off the signal end, a left zero pad."""
+    assert not (quirks and sig_kind == "int16")          # (an int16 stream cannot hold the Inf sample)
     rng = np.random.default_rng(7000 + 13 * N + seed)
     sr = 44100
     S = int(rng.integers(N // 3, N // 2 + 40))

@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--compute", choices=["f32", "f64"], default="f64")
     ap.add_argument("--libs", default="", help="comma-separated build tags; the empty tag is the shipped library")
     ap.add_argument("--generic", action="store_true", help="also time the generic kernel (plan option kernel = 1)")
+    ap.add_argument("--cfg", default="", help="a tests/workloads.py configuration by name instead of --win-ms (e.g. cfg1_44k_n1103_nf32)")
+    ap.add_argument("--opts", default="", help="further variants per library: ';'-separated plan option sets 'name=value,name=value'")
     args = ap.parse_args()
 
     import torch
@@ -42,11 +44,12 @@ def main():
     assert torch.cuda.is_available()
     dev = torch.device("cuda", 0)
     name = {32.0: "cfg2_16k_n512_nf40", 25.0: "cfg2_16k_n400_nf40", 46.44: "cfg5_44k_n2048_nf128"}[args.win_ms]
+    name = args.cfg or name
     oc = W.OracleCfg(orc, name)
     B = args.batch
     L = (oc.full_len() + 63) // 64 * 64
     R = max(2, int(np.ceil(320e6 / (B * L * 4))))   # ring of resident batches beyond the Infinity Cache, as bench.py
-    sig64, _ = synth.batch(2, min(B, 256 if oc.sr == 16000 else 32), int(oc.sr * (1.0 if oc.sr == 16000 else 5.0)), oc.sr, row_len=L)
+    sig64, _ = synth.batch(2, min(B, 256 if oc.sr == 16000 else 32), min(L, int(oc.sr * (1.0 if oc.sr == 16000 else 5.0))), oc.sr, row_len=L)
     reps = (B + sig64.shape[0] - 1) // sig64.shape[0]
     sig = np.tile(sig64.astype(np.float32), (reps, 1))[:B]
     ring = [torch.from_numpy(np.roll(sig, r, axis=0)).to(dev).view(-1) for r in range(R)]
@@ -57,7 +60,8 @@ def main():
         if tag:  # (the empty tag keeps whatever binding the process has: the shipped library, or a test's emulator build)
             capi.LIB_PATH = shipped.replace(".so", "_%s.so" % tag)
             capi._LIB, runtime._CTX = None, {}
-        for oname, opts in [("", {})] + ([("generic", {"kernel": 1})] if args.generic else []):
+        more = [(o, dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in o.split(","))) for o in args.opts.split(";") if o]
+        for oname, opts in [("", {})] + ([("generic", {"kernel": 1})] if args.generic else []) + more:
             p = W.product_plan(oc, cdt)
             for k, v in opts.items():
                 p.set_option(k, v)
