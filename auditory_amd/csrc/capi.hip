@@ -56,7 +56,7 @@ hipError_t launch_frames(const aud_plan* p, const aud::MelspecArgs& a, hipStream
 }
 
 const char* plan_family(const aud_plan* p) {
-    if (!p->use_wave || !p->wave_kind) return "generic";
+    if (!p->use_wave || !p->wave_kind) return (p->chirp_opt && p->d_bl_fix) ? "chirp2304" : "generic";  // (melspec_chirp.hip | any N)
     return p->wave_kind == 1 ? "w16x16" : p->wave_kind == 3 ? "w20x10" : "w64x16";
 }
 
@@ -315,6 +315,7 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
     // kernel family: the wave-autonomous kernel of this window length where one exists and its tables fit, else the
     // generic any-N kernel
     if (rc == AUD_OK) rc = build_wave_tables(p, bin_pts, mel_filters);
+    p->family = plan_family(p);
     if (rc == AUD_OK && p->wave_kind == 3) {  // the workgroup-per-item variant, where the item's mel matrix fits LDS beside the rest
         p->has_item = aud::melspec_item_finish(p->wave_kind, d->compute_dtype, p->wv, nf, d->segment_steps, &p->itm) &&
                       aud::melspec_item_prepare(p->wave_kind, d->compute_dtype, p->wv, &p->itm) == hipSuccess;
@@ -362,12 +363,13 @@ int aud_plan_get_info(const aud_plan* p, const char* name, int64_t* value) {
     if (!p || !name || !value) return AUD_EINVAL;
     const std::string key(name);
     const bool wave = p->use_wave && p->wave_kind;
-    if (key == "lds_bytes") *value = wave ? int64_t(p->wv.lds_bytes) : 0;
+    const bool chirp = !wave && p->d_bl_fix && p->chirp_opt;  // the fixed-geometry kernel of L = 2304 runs this plan
+    if (key == "lds_bytes") *value = wave ? int64_t(p->wv.lds_bytes) : chirp ? int64_t(aud::melspec_chirp_lds_bytes()) : 0;
     else if (key == "waves_per_wg") *value = wave ? p->wv.waves : 4;
-    else if (key == "wgs_per_cu") *value = wave ? p->wv.wgs_per_cu : 0;
+    else if (key == "wgs_per_cu") *value = wave ? p->wv.wgs_per_cu : chirp ? int64_t((160u * 1024u) / aud::melspec_chirp_lds_bytes()) : 0;
     else if (key == "bluestein_L") *value = wave ? 0 : p->bl_L;
     else if (key == "bluestein_inplace") *value = !wave && p->bl_L && p->bl_inplace ? 1 : 0;
-    else if (key == "chirp_kernel") *value = !wave && p->d_bl_fix && p->chirp_opt ? 1 : 0;  // the fixed-geometry kernel of L = 2304 runs this plan
+    else if (key == "chirp_kernel") *value = chirp ? 1 : 0;
     else if (key == "generic_frames_per_wg") *value = p->F_generic;  // frames a workgroup of the any-N kernel transforms at once
     else if (key == "item_kernel") *value = wave && p->has_item ? 1 : 0;        // the workgroup-per-item variant exists for this plan
     else if (key == "item_waves") *value = wave && p->has_item ? p->itm.waves : 0;
@@ -422,6 +424,7 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
     if (key == "chirp_kernel") {  // 1 (default): the fixed-geometry chirp kernel wherever it serves the plan; 0: the any-N route
         if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "chirp_kernel: 0 or 1");
         p->chirp_opt = value;
+        p->family = plan_family(p);
         return AUD_OK;
     }
     if (key == "xcd_remap") {  // 1 (default): every XCD walks a contiguous run of tiles; 0: tiles in workgroup-id order

@@ -987,7 +987,8 @@ def main():  # noqa: C901
     ach_tf, peak_tf = flops / solo_s / 1e12, VECTOR_PEAK_TF[args.compute]
     # `bound`: the roof that achieved / peak / frac are priced against (the contract's "hbm"); `limited_by`: what the counters say
     # holds the kernel (vector-ALU issue in the compute type)
-    roof = {"bound": "hbm", "limited_by": "valu_" + args.compute, "achieved": solo["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+    any_n = head["kernel"] in ("generic", "chirp2304")   # float64 (or float32) throughout, workgroup-level transform through LDS
+    roof = {"bound": "hbm", "limited_by": "lds_round_trips_and_barriers" if any_n else "valu_" + args.compute, "achieved": solo["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(solo["achieved_GBps"] / HBM_PEAK_GBPS, 5), "traffic": traffic,
             "measured_read_GBps": round(read_gbps, 1) if read_gbps else None,
             "frac_of_measured": round(solo["achieved_GBps"] / read_gbps, 5) if read_gbps else None,
@@ -1008,7 +1009,12 @@ def main():  # noqa: C901
             "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"],
             "avg_launch_us": solo["us_per_step_device"]["mean"], "rocprofv3_avg_launch_us": rocprof_us,
             "pipelined_GBps": head["achieved_GBps"],
-            "note": ("float64 VALU floor: 1.1 vector instructions per algorithmic flop, v_fma_f64 at 4.4-4.6 cycles, vector ALUs ~86 %% busy "
+            "note": ("workgroup-level transform through LDS (%s): a wave waits ~half its life (SQ_WAIT_ANY) on workgroup barriers and LDS / "
+                     "table round trips, not on HBM and not on vector issue; achieved / peak / frac price the kernel ALONE (one stream, %d "
+                     "items per launch, HIP events) against HBM as the contract asks; pipelined = the %d-stream rate (`value`); DESIGN.md "
+                     "4.3 has the account and profiles/ROOFLINE.md the rocprofv3 row" % (head["kernel"], B, head["streams"]))
+                    if any_n else
+                    ("float64 VALU floor: 1.1 vector instructions per algorithmic flop, v_fma_f64 at 4.4-4.6 cycles, vector ALUs ~86 %% busy "
                      "at the pipelined rate (%s of the %s vector peak with HBM at %s of 8 TB/s): not HBM-bound.  achieved / peak / frac "
                      "price the kernel ALONE (one stream, %d utterances per launch, HIP events) against HBM as the contract asks; "
                      "pipelined = the %d-stream rate (`value`); one_launch_of_4096 = steady state without the overlap; "
@@ -1023,8 +1029,12 @@ def main():  # noqa: C901
         "metric": METRIC, "value": top["value"], "unit": "audio-seconds/sec",
         "n_gpus": world, "steps": top["steps"], "warmup": args.warmup, "ms_per_step": top["ms_per_step"],
         "higher_is_better": True, "scaling": "strong" if cfg3 is not None else "weak", "vs_baseline": None,
-        "dtype": args.compute, "epilogue": "f32", "data": "synthetic",
-        "dtype_note": ("float64 plan: FFT and real-FFT split in float64; the spectrum / mel / log epilogue is float32 behind a per-frame "
+        "dtype": args.compute, "epilogue": args.compute if any_n else "f32", "data": "synthetic",
+        "dtype_note": ("float64 plan on the any-N route (%s): chirp convolution, power, mel sums and logarithms all in float64, rounded "
+                       "to float32 once at the store; strict criterion (1e-5 on every timed element, `parity`): max scaled error %.2g"
+                       % (head["kernel"], (top.get("parity") or head.get("parity") or {"max_scaled_err": float("nan")})["max_scaled_err"])
+                       if args.compute == "f64" and any_n else
+                       "float64 plan: FFT and real-FFT split in float64; the spectrum / mel / log epilogue is float32 behind a per-frame "
                        "power-of-two scale and passes the strict criterion (1e-5 on every timed element, `parity`) by >= 25x: max "
                        "scaled error %.2g" % (top.get("parity") or head.get("parity") or {"max_scaled_err": float("nan")})["max_scaled_err"]
                        if args.compute == "f64" else "float32 throughout (explicit opt-in AUD_FAST_F32; never the default)"),

@@ -727,7 +727,7 @@ def case_chirp_kernel(orc, N, cdt, seed=0, sig_kind="float", quirks=False):
         plan = runtime.Plan(runtime.get_ctx(0), N, S, T, border, dftp, mp.FBank.to_c(), mp.BinPts, filt, compute_dtype=cdt)
         try:
             plan.set_option("chirp_kernel", opt)
-            assert plan.kernel_name == "generic" and plan.info("bluestein_L") == 2304 and plan.info("chirp_kernel") == opt
+            assert plan.kernel_name == ("chirp2304" if opt else "generic") and plan.info("bluestein_L") == 2304 and plan.info("chirp_kernel") == opt
             items = runtime.make_items([r * L for r, s in segs], [L] * len(segs), [s * sp.stride_samples for r, s in segs])
             if sig_kind == "int16":    # the device normalises the PCM itself (sound.go:138), sample by sample as the window is read
                 dev = runtime.Signal(plan.ctx, pcm.ravel())
@@ -1181,7 +1181,7 @@ def case_speech_like_sndenv(orc, sr, tmp_dir, segments=None, report=None):
     se.Kwta.On = False                                   # processspeech has no k-WTA stage
     assert se.Init() is None
     assert se.Params.WinSamples == oc.N and se.Params.SegmentSteps == 14 and se.SegCnt == 30
-    assert se._plan.kernel_name == ("w20x10" if sr == 16000 else "generic")
+    assert se._plan.kernel_name == ("w20x10" if sr == 16000 else "chirp2304")
     tols = dict(mel=SPEECH_STRICT, log_power=SPEECH_STRICT, energy=SPEECH_STRICT, mfcc=SPEECH_STRICT, gabor=SPEECH_STRICT,
                 deltas=SPEECH_STRICT, delta_deltas=5e-5 if sr == 16000 else SPEECH_STRICT)
     k = orc.gabor_to_tensor(W.DEFAULT_GABOR_SPECS, 9, 9)
@@ -1538,7 +1538,7 @@ def case_mfcc_tail(orc, name, cdt, options=None):
     try:
         for k, v in (options or {}).items():
             plan.set_option(k, v)
-        fused = plan.kernel_name in ("w16x16", "w20x10", "generic") and (options or {}).get("fused_tail", 1) != 0
+        fused = plan.kernel_name in ("w16x16", "w20x10", "generic", "chirp2304") and (options or {}).get("fused_tail", 1) != 0
         got = plan.melspec_mfcc_host(sig.ravel(), make_items(oc, L, segs))
         plain, pw, lp = plan.melspec_host(sig.ravel(), make_items(oc, L, segs), True, True)
     finally:
@@ -1674,7 +1674,7 @@ def case_reference_wav(orc, cdt, wav="bug.wav"):
     se.ToTensor()
     se.GborOutUnitsX = se.GborOutUnitsY = 1
     assert se.Init() is None
-    assert se.SampleRate == 44100 and se.Params.WinSamples == 1103 and se._plan.kernel_name == "generic"
+    assert se.SampleRate == 44100 and se.Params.WinSamples == 1103 and se._plan.kernel_name == "chirp2304"
     sp = orc.sound_params(25, 10, 100, 100, 2, 44100)
     d, m = orc.dft_defaults(), orc.mel_defaults()
     rc, bins, hz, filt = orc.mel_init_filters(m, 1103, 44100)

@@ -189,22 +189,27 @@ def test_emul_plan_info(orc, emu):
     """aud_plan_get_info: the launch facts of the kernel a plan selected, per family; unknown names are AUD_EINVAL"""
     import workloads as W
     expect = {"cfg2_16k_n400_nf40": ("w20x10", 6, 4), "cfg2_16k_n512_nf40": ("w16x16", 4, 4),
-              "cfg5_44k_n2048_nf128": ("w64x16", 1, 12), "cfg1_44k_n1103_nf32": ("generic", 0, 4)}
+              "cfg5_44k_n2048_nf128": ("w64x16", 1, 12), "cfg1_44k_n1103_nf32": ("chirp2304", 0, 4)}
     for name, (fam, fpw, waves) in expect.items():
         oc = W.OracleCfg(orc, name, 100.0)
         plan = W.product_plan(oc, capi.AUD_F64)
         try:
             assert plan.kernel_name == fam
             assert plan.info("frames_per_wave") == fpw and plan.info("waves_per_wg") == waves
-            if fam == "generic":   # the prime window length takes the Bluestein route: L = the cheapest 2-3-5-smooth length
-                assert plan.info("bluestein_L") == 2304 and plan.info("lds_bytes") == 0   # >= 2 N - 1 (16 x 16 x 3 x 3)
+            if fam == "chirp2304":  # the prime window length takes the Bluestein route: L = the cheapest 2-3-5-smooth length
+                assert plan.info("bluestein_L") == 2304 and plan.info("chirp_kernel") == 1   # >= 2 N - 1 (16 x 16 x 3 x 3)
+                assert plan.info("lds_bytes") == 16 * 153 * 16 + 32 and plan.info("wgs_per_cu") == 4
+                plan.set_option("chirp_kernel", 0)   # the any-N route of the same plan
+                assert plan.kernel_name == "generic" and plan.info("bluestein_L") == 2304 and plan.info("lds_bytes") == 0
+                plan.set_option("chirp_kernel", 1)
+                assert plan.kernel_name == "chirp2304"
             else:
                 assert 0 < plan.info("lds_bytes") <= 160 * 1024 and plan.info("wgs_per_cu") >= 1
                 assert plan.info("bluestein_L") == 0
             with pytest.raises(capi.AuditoryError):
                 plan.info("no_such_fact")
             plan.set_option("kernel", 1)          # the generic kernel of a factorable length: no Bluestein
-            if fam != "generic":
+            if fam != "chirp2304":
                 assert plan.kernel_name == "generic" and plan.info("bluestein_L") == 0
         finally:
             plan.close()

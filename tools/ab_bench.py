@@ -117,14 +117,15 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1) * 1e3 / args.launches)   # us per launch (incl. kernel boundaries)
-    alg = B * (4 * int(oc.sr * (1.0 if oc.sr == 16000 else 5.0)) + 4 * oc.nf * oc.T)
+    secs = oc.sp.stride_samples / float(oc.sr)       # audio a work item stands for (the segment stride)
+    alg = B * (4 * oc.sp.stride_samples + 4 * oc.nf * oc.T)
     print("workload: %s, batch %d, %s; %d rounds x %d launches on %d stream(s); algorithmic bytes/launch %.2f MB"
           % (name, B, args.compute, args.rounds, args.launches, args.streams, alg / 1e6))
     for v, ts in times.items():
         med, mn = statistics.median(ts), min(ts)
         print("%-24s kernel=%-8s lds %6d B, %d wg/CU  median %8.2f us  min %8.2f us  -> %6.3f of 8 TB/s, %7.2f M audio-s/s"
               % (v, plans[v].kernel_name, plans[v].info("lds_bytes"), plans[v].info("wgs_per_cu"), med, mn,
-                 alg / (med * 1e-6) / 8e12, B * (1.0 if oc.sr == 16000 else 5.0) / med))
+                 alg / (med * 1e-6) / 8e12, B * secs / med))
     for p in plans.values():
         p.close()
 

@@ -5,6 +5,7 @@
 # signal ends the sequence (no GPU step after it); an ordinary failure (rc 1) does not.
 # Steps: smoke | pytest | pytest_all | bench | bench:<extra bench.py args joined by ','> | ab | profile[:<bench args>] | stamps | mfma |
 #        stream | wstream | dispatch | ubench | two_ranks | ranks:<2..4> | hostranks:<2..4> | hostcall | tune_bluestein |
+#        sweep[:<rate_sweep.py args>] |
 #        runlib:<tag>,<script.py>,<args...>  (the script against an experimental build: python -m auditory_amd.build --tag <tag> -D...)
 set -u
 TAG=${1:?tag}; shift
@@ -60,6 +61,9 @@ for step in "$@"; do
         ranks:*) run ranks${step#ranks:} 500 bash tools/two_ranks_one_gpu.sh "${TAG}_ranks${step#ranks:}" "${step#ranks:}" ;;
         hostranks:*) run hostranks${step#hostranks:} 500 bash tools/two_ranks_one_gpu.sh "${TAG}_hostranks${step#hostranks:}" "${step#hostranks:}" host ;;
         hostcall) run hostcall 300 python tools/host_call_time.py ;;
+        sweep) run sweep 600 python tools/rate_sweep.py --json "gpurun_out/${TAG}_rate_sweep.json" ;;
+        sweep:*) args=$(echo "${step#sweep:}" | tr ',' ' ')
+               run sweep$i 600 python tools/rate_sweep.py --json "gpurun_out/${TAG}_rate_sweep$i.json" $args ;;
         dispatch) (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/dispatch_rate dispatch_rate.hip) &&
                 run dispatch 120 /tmp/dispatch_rate ;;
         *) echo "unknown step $step"; exit 2 ;;

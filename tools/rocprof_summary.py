@@ -57,7 +57,7 @@ def main():
     # per hot kernel: average duration, HBM bytes per launch and the SQ counters per launch -> profiles/<tag>_kernels.json
     # (tools/roofline_table.py builds profiles/ROOFLINE.md from these); the headline kernel's traffic also goes to
     # profiles/pmc_traffic.json, what bench.py reports as roofline.traffic
-    fams = {"k_melspec_w20_item": "w20item", "k_melspec_w20": "w20x10", "k_melspec_w16": "w16x16", "k_melspec_w64": "w64x16", "k_melspec_generic": "generic",
+    fams = {"k_melspec_w20_item": "w20item", "k_melspec_w20": "w20x10", "k_melspec_w16": "w16x16", "k_melspec_w64": "w64x16", "k_melspec_generic": "generic", "k_melspec_chirp": "chirp2304",
             "k_gabor": "gabor", "k_mfcc_fused": "mfcc", "k_segment_finish": "finish", "k_kwta": "kwta"}
     avg_ns = {r.get("Name", ""): float(r.get("AverageNs", r.get("Average", 0)) or 0) for r in stats}
     calls = {r.get("Name", ""): int(float(r.get("Calls", 0) or 0)) for r in stats}
@@ -74,7 +74,7 @@ def main():
         if fam is None:
             continue
         v = traffic.get(k, {})
-        kernels[k] = {"family": fam, "compute": "f64" if "<double" in k else "f32", "calls": calls.get(k), "avg_duration_ns": ns,
+        kernels[k] = {"family": fam, "compute": "f64" if ("<double" in k or fam == "chirp2304") else "f32", "calls": calls.get(k), "avg_duration_ns": ns,
                       "read_bytes": v.get("read_bytes"), "write_bytes": v.get("write_bytes"),
                       "read_bytes_raw_fetch_size": v.get("read_bytes_raw_fetch_size"),
                       "counters_per_launch": {n: round(t / max(c, 1), 1) for n, (c, t) in sq.get(k, {}).items()}}

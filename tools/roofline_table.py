@@ -22,14 +22,14 @@ MEASURED_READ_GBPS = 6047.0
 # workload -> samples per stream, frames per stream, mel filters, bins, kFLOP per frame (2.5 N log2 N + 3 H + 2 sum of
 # the triangles' widths + nf logarithms, evaluated on the product's own mel table: bench.py frame_flops gives the same figure)
 WL = {"headline": (16000, 104, 40, 201, 10.14), "n512": (16000, 104, 40, 257, 13.43), "cfg4": (16000, 104, 40, 201, 10.14),
-      "sndenv": (16000, 104, 40, 201, 10.14), "cfg5": (220500, 504, 128, 1025, 63.7), "cfg1": (4410, 14, 32, 552, 0.0)}
+      "sndenv": (16000, 104, 40, 201, 10.14), "cfg5": (220500, 504, 128, 1025, 63.7), "cfg1": (4410, 14, 32, 552, 30.39)}
 
 
 def algorithmic(fam, wl, B):
     """(bytes, flops) one launch of kernel family `fam` moves / does in workload wl at batch B"""
     dur, T, nf, H, kflop = WL[wl]
     mel_out = 4 * nf * T
-    if fam in ("w20x10", "w16x16", "w64x16", "generic"):
+    if fam in ("w20x10", "w16x16", "w64x16", "generic", "chirp2304"):
         extra = 2 * 4 * H * T if wl == "sndenv" else 0            # Power + LogPower tensors
         return B * (4 * dur + mel_out + extra), B * T * kflop * 1e3
     if fam == "w20item":  # workgroup per item; cfg4: + the fused Convolve (no re-read of mel), [11, 32, 2, 8] written
@@ -65,7 +65,7 @@ def main():
             waves = c.get("SQ_WAVES")
             hbm = (v["read_bytes"] or 0) + (v["write_bytes"] or 0) if v.get("read_bytes") is not None else None
             rows.append({
-                "kernel": k.replace("void aud::(anonymous namespace)::", "").split("(")[0], "tag": tag, "workload": wl, "batch": B,
+                "kernel": k.replace("void ", "").replace("aud::(anonymous namespace)::", "").split("(")[0], "tag": tag, "workload": wl, "batch": B,
                 "avg_us": ns / 1e3, "alg_MB": nbytes / 1e6, "GBps": nbytes / ns, "frac": nbytes / ns / PEAK_GBPS,
                 "frac_meas": nbytes / ns / MEASURED_READ_GBPS, "us_per_256": ns / 1e3 * 256.0 / B,
                 "hbm_MB": hbm / 1e6 if hbm else None, "TF": flops / ns / 1e3 if flops else None,
