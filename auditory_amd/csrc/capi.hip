@@ -37,6 +37,8 @@ void fill_melspec_args(const aud_plan* p, aud::MelspecArgs* a) {
     a->bl_tw = p->d_bl_tw;
     a->bl_inplace = p->bl_inplace ? 1 : 0;
     a->bl_fix = (p->chirp_opt && p->d_bl_fix) ? p->d_bl_fix : nullptr;
+    a->ip_nfac = plain_inplace(p) ? p->ip_nfac : 0;
+    for (int i = 0; i < a->ip_nfac; ++i) a->ip_fac[i] = p->ip_fac[i];
     a->xcd_remap = p->xcd_remap;
     a->stamps = reinterpret_cast<unsigned long long*>(p->stamps);
 }
@@ -53,6 +55,13 @@ hipError_t launch_frames(const aud_plan* p, const aud::MelspecArgs& a, hipStream
     }
     if (a.bl_fix) return aud::launch_melspec_chirp(a, st);
     return aud::launch_melspec_generic(a, p->d.compute_dtype, st);
+}
+
+// smooth window lengths: the any-N kernel's in-place route runs this plan (melspec_generic.hip plain_fft_inplace)
+bool plain_inplace(const aud_plan* p) { return p->bl_L == 0 && p->F_ip > 0 && (p->ip_opt != 0 || p->F_two < 1); }
+// frames per workgroup of the any-N kernel on the route the plan's options select (Bluestein plans set theirs at creation)
+void generic_route(aud_plan* p) {
+    if (p->bl_L == 0) p->F_generic = plain_inplace(p) ? p->F_ip : p->F_two;
 }
 
 const char* plan_family(const aud_plan* p) {
@@ -212,11 +221,8 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
     p->ratio = (N % 2 == 0) ? 2 : 1;
     p->M = N / p->ratio;
     factorize(p->M, p->fac, &p->nfac);
-    p->F_generic = aud::melspec_generic_pick_F(p->M, d->compute_dtype);
-    if (p->F_generic < 1) {
-        delete p;
-        return fail(c, AUD_EINVAL, "win_samples too large for the LDS-resident FFT");
-    }
+    p->F_two = aud::melspec_generic_pick_F(p->M, d->compute_dtype);   // (0: its two buffers do not fit LDS)
+    p->F_generic = p->F_two;
 
     int rc = AUD_OK;
     {  // twiddles exp(-2 pi i k / N), computed in long double
@@ -290,6 +296,19 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
                 p->F_generic = (p->ratio == 1 && d->compute_dtype == AUD_F64) ? 2 : 1;
             }
         }
+    }
+    if (rc == AUD_OK && p->bl_L == 0) {
+        // smooth lengths: the in-place route (one padded buffer, the workgroup's frames as one batched transform) where every
+        // stage fits a thread's registers; the two-buffer route otherwise (radix 25 in one stage, the O(p) pass for 7 .. 23)
+        size_t ip_lds = 0;
+        p->F_ip = aud::melspec_generic_plain_inplace(p->M, H, nf, d->segment_steps, d->compute_dtype, 0, p->ip_fac, &p->ip_nfac, &ip_lds);
+        const size_t two_lds = p->F_two > 0 ? aud::melspec_generic_lds_bytes(p->M, p->F_two, d->compute_dtype, false) : 0;
+        if ((ip_lds > 64u * 1024u || two_lds > 64u * 1024u) && aud::melspec_generic_prepare(std::max(ip_lds, two_lds)) != hipSuccess) {
+            (void)hipGetLastError();
+            rc = fail(c, AUD_EHIP, "the runtime refused the LDS size of the any-N kernel");
+        }
+        if (rc == AUD_OK && p->F_ip < 1 && p->F_two < 1) rc = fail(c, AUD_EINVAL, "win_samples too large for the LDS-resident FFT");
+        generic_route(p);
     }
     if (rc == AUD_OK) rc = upload_real(c, &p->d_filt, mel_filters, size_t(cells), d->compute_dtype);
     if (rc == AUD_OK)
@@ -370,6 +389,7 @@ int aud_plan_get_info(const aud_plan* p, const char* name, int64_t* value) {
     else if (key == "bluestein_L") *value = wave ? 0 : p->bl_L;
     else if (key == "bluestein_inplace") *value = !wave && p->bl_L && p->bl_inplace ? 1 : 0;
     else if (key == "chirp_kernel") *value = chirp ? 1 : 0;
+    else if (key == "plain_inplace") *value = !wave && plain_inplace(p) ? 1 : 0;  // smooth length on the any-N kernel's in-place route
     else if (key == "generic_frames_per_wg") *value = p->F_generic;  // frames a workgroup of the any-N kernel transforms at once
     else if (key == "item_kernel") *value = wave && p->has_item ? 1 : 0;        // the workgroup-per-item variant exists for this plan
     else if (key == "item_waves") *value = wave && p->has_item ? p->itm.waves : 0;
@@ -419,6 +439,27 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
     if (key == "fused_tail") {
         if (value < -1 || value > 1) return fail(c, AUD_EINVAL, "fused_tail: -1 / 1 (wherever the kernel can) or 0 (never)");
         p->fused_tail_opt = value;
+        return AUD_OK;
+    }
+    if (key == "plain_inplace") {  // 1 (default): smooth lengths run the any-N kernel's in-place route where it serves; 0: two buffers
+        if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "plain_inplace: 0 or 1");
+        p->ip_opt = value;
+        generic_route(p);
+        return AUD_OK;
+    }
+    if (key == "plain_frames") {  // frames per workgroup of the in-place route: 0 = the plan's own choice, else 1 / 2 / 4 / 8 / 16
+        if (p->bl_L != 0) return fail(c, AUD_EINVAL, "plain_frames: the plan runs the Bluestein route");
+        int fac[aud::kMaxFactors], nfac = 0;
+        size_t lds = 0;
+        const int F = aud::melspec_generic_plain_inplace(p->M, p->H, p->d.mel.n_filters, p->d.segment_steps, p->d.compute_dtype,
+                                                         value, fac, &nfac, &lds);
+        if (value < 0 || F < 1) return fail(c, AUD_EINVAL, "plain_frames: the in-place route does not run this length with that many frames");
+        if (lds > 64u * 1024u && aud::melspec_generic_prepare(lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(c, AUD_EHIP, "the runtime refused the LDS size of the any-N kernel");
+        }
+        p->F_ip = F;
+        generic_route(p);
         return AUD_OK;
     }
     if (key == "chirp_kernel") {  // 1 (default): the fixed-geometry chirp kernel wherever it serves the plan; 0: the any-N route
@@ -541,6 +582,7 @@ bool segment_fused(const aud_plan* p) {
     if (p->use_wave && p->wave_kind) return p->wv.dct_off >= 0;
     // the any-N kernel (round 6): DCT and Energy sums from its unrounded values wherever its power buffer has the room
     if (p->chirp_opt && p->d_bl_fix) return aud::melspec_chirp_tail_fits(p->H, p->d.mel.n_filters);
+    if (plain_inplace(p)) return true;  // (its launch's LDS is sized with the tail's F x nf values)
     return aud::melspec_generic_tail_fits(p->M, p->F_generic, p->H, p->d.mel.n_filters, p->d.compute_dtype, p->bl_L, p->bl_inplace);
 }
 // tiles of an item the fused tail's per-tile Energy sums come in: wave tiles, or the any-N kernel's workgroups of F frames

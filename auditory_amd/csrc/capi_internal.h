@@ -105,7 +105,11 @@ struct aud_plan {
     int H = 0, M = 0, ratio = 0;
     int nfac = 0;
     int fac[aud::kMaxFactors] = {0};
-    int F_generic = 0;
+    int F_generic = 0;         // frames a workgroup of the any-N kernel takes on the route the plan runs (generic_route())
+    // smooth window lengths in place (kernels.h MelspecArgs::ip_*): F_ip = 0 where the route does not serve the length
+    int F_two = 0, F_ip = 0, ip_nfac = 0;
+    int ip_fac[aud::kMaxFactors] = {0};
+    int ip_opt = 1;            // plan option "plain_inplace": 1 (default) the in-place route where it serves, 0 the two-buffer route
     // generic kernel, Bluestein route (kernels.h MelspecArgs::bl_*): 0 = not used
     int bl_L = 0, bl_nfac = 0;
     bool bl_inplace = false;
@@ -342,6 +346,8 @@ inline int upload_real(aud_ctx* c, void** dst, const double* src, size_t n, int 
 void fill_melspec_args(const aud_plan* p, aud::MelspecArgs* a);
 hipError_t launch_frames(const aud_plan* p, const aud::MelspecArgs& a, hipStream_t st);
 const char* plan_family(const aud_plan* p);
+bool plain_inplace(const aud_plan* p);   // smooth window length on the any-N kernel's in-place route
+void generic_route(aud_plan* p);         // F_generic of the route the plan's options select
 // wave_tables.hip
 int build_wave_tables(aud_plan* p, const int32_t* bin_pts, const double* mel_filters);
 

@@ -60,6 +60,10 @@ struct MelspecArgs {
     const void* bl_bhat;   // [L] complex<TT>: FFT_L of the wrapped conjugate chirp, / L
     const void* bl_tw;     // [L] complex<TT>: exp(-2 pi i k / L)
     int bl_inplace;        // 1: ONE padded LDS buffer, stages through registers (melspec_generic.hip stage_inplace)
+    // generic kernel, smooth window lengths IN PLACE (ip_nfac > 0; bl_L = 0): the F frames of a workgroup as one batched transform
+    // of F M points in one padded buffer (melspec_generic.hip plain_fft_inplace); its radices, powers of two first
+    int ip_nfac;
+    int ip_fac[kMaxFactors];
     const void* bl_fix;    // the fixed-geometry chirp kernel's tables (melspec_chirp.hip: twiddles of both outer stages, bhat in its digit-reversed order); null: the any-N route
     int xcd_remap;     // 1: tile_of_workgroup() order (plan option "xcd_remap", default on)
     // wave kernels: wave tiles per item (N = 2048: frames per item) and its reciprocal, set by launch_melspec_wave -- a
@@ -253,6 +257,9 @@ hipError_t launch_widen_to_host(const float* src, double* dst_host, size_t n, hi
 size_t melspec_generic_lds_bytes(int M, int F, int compute_dtype, bool bluestein);
 bool melspec_generic_bluestein_inplace(int L);
 int melspec_generic_pick_F(int M, int compute_dtype);
+// smooth lengths in place: frames per workgroup F (0: the length has a factor the in-place stages do not run, or nothing fits),
+// the stage radices and the launch's LDS; forced_F > 0 asks for that F (plan option "plain_frames")
+int melspec_generic_plain_inplace(int M, int H, int nf, int T, int compute_dtype, int forced_F, int* fac, int* nfac, size_t* lds);
 int melspec_generic_bluestein_L(int M, int compute_dtype);
 hipError_t melspec_generic_prepare(size_t lds_bytes);
 hipError_t launch_melspec_generic(const MelspecArgs& a, int compute_dtype, hipStream_t st);

@@ -91,7 +91,9 @@ struct PreNone {
 };
 // LIN (chosen per stage by stage_inplace_any): equally spaced padded positions on both sides
 template <typename TT, int P, int R, bool LIN, typename PRE>
-__device__ __forceinline__ void stage_inplace(C2<TT>* buf, const C2<TT>* __restrict__ tw, int L, int ncur, int s, int tid, PRE pre) {
+__device__ __forceinline__ void stage_inplace(C2<TT>* buf, const C2<TT>* __restrict__ tw, int L, int ncur, int s, int tws, int tid, PRE pre) {
+    // (tws: the stage's twiddle W_ncur^(q j) is tw[j q tws] -- s for one transform of length L over the table W_L; the batched
+    //  plain route passes ratio x (product of the radices so far) over the table W_N)
     const int m = ncur / P, nb = L / P, sm = s * m;
     // wave-uniform facts that keep the per-element index arithmetic off the vector unit: s is a power of two in every stage
     // but those behind a radix 3 / 5 / 9 one (shift instead of a division); with a stride that is a multiple of 16 the padded
@@ -128,7 +130,7 @@ __device__ __forceinline__ void stage_inplace(C2<TT>* buf, const C2<TT>* __restr
         if (b < nb) {
             const int q = s_log >= 0 ? b >> s_log : b / s, k = b - q * s;
             SmallDft<TT, P>::run(v[r], tw, L);
-            const unsigned tq = unsigned(q * s);
+            const unsigned tq = unsigned(q) * unsigned(tws);
             const int y0 = k + s * P * q;
             C2<TT>* out = buf + padx(y0);
             out[0] = v[r][0];
@@ -179,25 +181,25 @@ __host__ __device__ inline bool inplace_radix_ok(int L, int p) {
 }
 
 template <typename TT, typename PRE>
-__device__ __forceinline__ void stage_inplace_any(int p, C2<TT>* buf, const C2<TT>* __restrict__ tw, int L, int ncur, int s, int tid, PRE pre) {
+__device__ __forceinline__ void stage_inplace_any(int p, C2<TT>* buf, const C2<TT>* __restrict__ tw, int L, int ncur, int s, int tws, int tid, PRE pre) {
     // equally spaced padded positions: inputs sm apart with sm a multiple of 16; outputs s apart with s a multiple of 16, or
     // s = 1 under radix 16 (y0 = 16 q: the 16 outputs share one pad group)
     const int sm = s * (ncur / p);
     const bool lin = (sm & 15) == 0 && ((s & 15) == 0 || (s == 1 && p == 16));
     switch (p) {
         case 16:
-            if (lin) stage_inplace<TT, 16, 1, true>(buf, tw, L, ncur, s, tid, pre);
-            else stage_inplace<TT, 16, 1, false>(buf, tw, L, ncur, s, tid, pre);
+            if (lin) stage_inplace<TT, 16, 1, true>(buf, tw, L, ncur, s, tws, tid, pre);
+            else stage_inplace<TT, 16, 1, false>(buf, tw, L, ncur, s, tws, tid, pre);
             break;
         case 9:
-            if (lin) stage_inplace<TT, 9, 1, true>(buf, tw, L, ncur, s, tid, pre);
-            else stage_inplace<TT, 9, 1, false>(buf, tw, L, ncur, s, tid, pre);
+            if (lin) stage_inplace<TT, 9, 1, true>(buf, tw, L, ncur, s, tws, tid, pre);
+            else stage_inplace<TT, 9, 1, false>(buf, tw, L, ncur, s, tws, tid, pre);
             break;
-        case 8: stage_inplace<TT, 8, 2, false>(buf, tw, L, ncur, s, tid, pre); break;
-        case 5: stage_inplace<TT, 5, 3, false>(buf, tw, L, ncur, s, tid, pre); break;
-        case 4: stage_inplace<TT, 4, 4, false>(buf, tw, L, ncur, s, tid, pre); break;
-        case 3: stage_inplace<TT, 3, 5, false>(buf, tw, L, ncur, s, tid, pre); break;
-        default: stage_inplace<TT, 2, 8, false>(buf, tw, L, ncur, s, tid, pre); break;
+        case 8: stage_inplace<TT, 8, 2, false>(buf, tw, L, ncur, s, tws, tid, pre); break;
+        case 5: stage_inplace<TT, 5, 3, false>(buf, tw, L, ncur, s, tws, tid, pre); break;
+        case 4: stage_inplace<TT, 4, 4, false>(buf, tw, L, ncur, s, tws, tid, pre); break;
+        case 3: stage_inplace<TT, 3, 5, false>(buf, tw, L, ncur, s, tws, tid, pre); break;
+        default: stage_inplace<TT, 2, 8, false>(buf, tw, L, ncur, s, tws, tid, pre); break;
     }
 }
 // the transform in place; `pre` rides on the FIRST stage's loads (the caller's barrier stands before the call)
@@ -206,14 +208,34 @@ __device__ __forceinline__ void smooth_fft_inplace(C2<TT>* buf, const MelspecArg
     const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.bl_tw);
     const int L = a.bl_L;
     int ncur = L, s = 1;
-    stage_inplace_any<TT>(a.bl_fac[0], buf, tw, L, ncur, s, tid, pre);
+    stage_inplace_any<TT>(a.bl_fac[0], buf, tw, L, ncur, s, s, tid, pre);
     ncur /= a.bl_fac[0];
     s *= a.bl_fac[0];
     for (int stg = 1; stg < a.bl_nfac; ++stg) {
         const int p = a.bl_fac[stg];
-        stage_inplace_any<TT>(p, buf, tw, L, ncur, s, tid, PreNone());
+        stage_inplace_any<TT>(p, buf, tw, L, ncur, s, s, tid, PreNone());
         ncur /= p;
         s *= p;
+    }
+}
+
+// ---- smooth window lengths IN PLACE (round 6): F frames per workgroup as ONE batched transform ---------------------------------
+// The autosort stage x[k + s (q + m i)] -> y[k + s (P q + j)] W_ncur^(q j) treats k < s as a batch index: started at s = F
+// (instead of 1) over a buffer that holds element n of frame f at position f + F n, the stages above run F independent M-point
+// transforms as if they were the tail of one transform of length F M -- same butterflies per thread, same padded buffer, same
+// batched loads as the Bluestein route, one buffer instead of the two-buffer route's two.  X_f[k] ends at position f + F k.
+// Twiddles from the plan's W_N table: W_ncur^(q j) = W_N^(ratio prod q j), prod = the radices so far.
+template <typename TT>
+__device__ __forceinline__ void plain_fft_inplace(C2<TT>* buf, const MelspecArgs& a, int tid) {
+    const C2<TT>* __restrict__ tw = static_cast<const C2<TT>*>(a.tw);
+    const int L = a.F * a.M;
+    int ncur = a.M, s = a.F, tws = a.ratio;
+    for (int stg = 0; stg < a.ip_nfac; ++stg) {
+        const int p = a.ip_fac[stg];
+        stage_inplace_any<TT>(p, buf, tw, L, ncur, s, tws, tid, PreNone());
+        ncur /= p;
+        s *= p;
+        tws *= p;
     }
 }
 
@@ -265,8 +287,8 @@ void k_melspec_generic(const MelspecArgs a) {
             const int64_t pos = start + n;
             TT v = TT(0);
             if (live && pos >= 0) v = load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + pos * stride);
-            if (inpl && !pair) {  // (one frame per workgroup) z[n / 2] = (x[2j], x[2j+1]) for even N, z[n] = (x[n], 0) for odd N
-                TT* cell = &src[padx(even ? n >> 1 : n)].x;
+            if (inpl && !pair) {  // z[n / 2] = (x[2j], x[2j+1]) for even N, z[n] = (x[n], 0) for odd N; element j of frame f at f + F j
+                TT* cell = &src[padx(f + F * (even ? n >> 1 : n))].x;  // (Bluestein without a pair: F = 1)
                 if (even) cell[n & 1] = v;
                 else { cell[0] = v; cell[1] = TT(0); }
             } else if (even) {
@@ -329,6 +351,12 @@ void k_melspec_generic(const MelspecArgs a) {
         }
     }
 
+    // ---- smooth lengths in place: the F frames as one batched transform (plain_fft_inplace) ----
+    const bool plain_ip = inpl && a.ip_nfac > 0;  // (uniform; the host sets ip_nfac only on plans without a Bluestein length)
+    if constexpr (inpl) {
+        if (plain_ip) plain_fft_inplace<TT>(src, a, tid);
+    }
+
     // ---- Stockham stages: x[k + s(q + m i)] -> y[k + s(p q + j)] * W_ncur^(q j) ---------
     int ncur = M, s = 1;
     for (int stg = 0; stg < ((inpl || a.bl_L) ? 0 : a.nfac); ++stg) {
@@ -384,13 +412,15 @@ void k_melspec_generic(const MelspecArgs a) {
     // ---- power spectrum into the free buffer: P[f][k], row pitch odd -----------------
     // (in place: the spectrum Z[0 .. M) sits at the padded positions below padx(M); everything of the buffer behind it is free
     //  once the last transform is done, and L >= 2 M - 1 leaves room for F rows of H values there)
-    TT* P = inpl ? reinterpret_cast<TT*>(src + padx(M) + 1) : reinterpret_cast<TT*>(dst);
+    // (smooth lengths in place: the buffer is full of spectra; the launch's LDS has room for the F rows behind it)
+    TT* P = inpl ? reinterpret_cast<TT*>(src + padx(plain_ip ? F * M : M) + 1) : reinterpret_cast<TT*>(dst);
     const int Hp = H | 1;
     // Z[k] of frame f.  In place (one frame, or a pair in one transform): the buffer still holds the second transform's raw
     // output -- the convolution's last step, chirp . conj(.), is applied here, on the load
     const C2<TT>* __restrict__ chirp_z = static_cast<const C2<TT>*>(a.bl_chirp);
     auto zat = [&](int f, int k) {
         if constexpr (inpl) {
+            if (plain_ip) return src[padx(f + F * k)];
             const C2<TT> r = src[padx(k)];
             return cmul<TT>(chirp_z[k], C2<TT>{r.x, -r.y});
         } else {
@@ -509,6 +539,44 @@ int melspec_generic_bluestein_L(int M, int compute_dtype) {
     return best;
 }
 
+// Smooth window lengths in place (plain_fft_inplace): which F, which radices, how much LDS.  The buffer holds F M complex values
+// (padded), the F power spectra and the fused tail's F x nf log-mel values live behind it.  F is a power of two (the batch index
+// is the low part of every position: shifts) -- the largest that keeps the workgroup at <= 40 KB (four workgroups per CU: this
+// kernel waits for barriers and LDS round trips for most of its life), with fewer workgroups per CU where one
+// frame alone needs more, and never more than the segment has steps (rounded up to a power of two).
+int melspec_generic_plain_inplace(int M, int H, int nf, int T, int compute_dtype, int forced_F, int* fac, int* nfac, size_t* lds) {
+    int n = 0, m = M;
+    for (int p : {16, 8, 4, 2, 9, 5, 3})
+        while (m % p == 0) {
+            if (n >= kMaxFactors) return 0;
+            fac[n++] = p;
+            m /= p;
+        }
+    if (m != 1 || n == 0) return 0;  // (a prime factor above 5: the two-buffer route's O(p) pass, or Bluestein)
+    const size_t tsz = compute_dtype == AUD_F64 ? 8 : 4, c = 2 * tsz;
+    auto bytes = [&](int F) { return size_t(padx(F * M) + 1) * c + (size_t(F) * size_t(H | 1) + size_t(F) * size_t(nf)) * tsz + 16; };
+    auto runs = [&](int F) {
+        for (int i = 0; i < n; ++i)
+            if (!inplace_radix_ok(F * M, fac[i])) return false;
+        return true;
+    };
+    int tcap = 1;
+    while (tcap < T) tcap <<= 1;
+    int best = 0;
+    for (int F = 16; F >= 1; F >>= 1) {
+        if (forced_F > 0 && F != forced_F) continue;
+        if (F > tcap || !runs(F)) continue;
+        const size_t b = bytes(F);
+        if (b > size_t(160) * 1024) continue;
+        best = F;  // (descending: without a break this ends at the smallest F that fits at all -- taken when none fits 40 KB)
+        if (forced_F > 0 || b <= size_t(40) * 1024) break;
+    }
+    if (best == 0) return 0;
+    *nfac = n;
+    *lds = bytes(best);
+    return best;
+}
+
 hipError_t melspec_generic_prepare(size_t lds_bytes) {
     const void* fns[4] = {reinterpret_cast<const void*>(&k_melspec_generic<double, false>),
                           reinterpret_cast<const void*>(&k_melspec_generic<float, false>),
@@ -525,14 +593,18 @@ hipError_t melspec_generic_prepare(size_t lds_bytes) {
 int melspec_generic_pick_F(int M, int compute_dtype) {
     for (int F = 16; F >= 1; F >>= 1)
         if (melspec_generic_lds_bytes(M, F, compute_dtype, false) <= 64 * 1024) return F;
-    return 0;
+    // (one frame per workgroup in up to the CU's whole LDS: the plan raises the kernel's limit, melspec_generic_prepare)
+    return melspec_generic_lds_bytes(M, 1, compute_dtype, false) <= 160 * 1024 ? 1 : 0;
 }
 
 hipError_t launch_melspec_generic(const MelspecArgs& a, int compute_dtype, hipStream_t st) {
     const int tiles = (a.T + a.F - 1) / a.F;
     const dim3 grid(unsigned(a.n_items) * unsigned(tiles));
-    const size_t lds = a.bl_L ? melspec_generic_lds_bytes(a.bl_L, 1, compute_dtype, true) : melspec_generic_lds_bytes(a.M, a.F, compute_dtype, false);
-    const bool inpl = a.bl_L != 0 && a.bl_inplace != 0;
+    const bool plain_ip = a.bl_L == 0 && a.ip_nfac > 0;
+    const size_t tsz = compute_dtype == AUD_F64 ? 8 : 4;
+    const size_t lds = plain_ip ? size_t(padx(a.F * a.M) + 1) * 2 * tsz + (size_t(a.F) * size_t(a.H | 1) + size_t(a.F) * size_t(a.nf)) * tsz + 16
+                       : a.bl_L ? melspec_generic_lds_bytes(a.bl_L, 1, compute_dtype, true) : melspec_generic_lds_bytes(a.M, a.F, compute_dtype, false);
+    const bool inpl = plain_ip || (a.bl_L != 0 && a.bl_inplace != 0);
     if (compute_dtype == AUD_F64) {
         if (inpl) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_generic<double, true>), grid, dim3(256), lds, st, a);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_melspec_generic<double, false>), grid, dim3(256), lds, st, a);

@@ -19,6 +19,13 @@ CONFIGS = {
     # many narrow filters: the filter-group schedule outgrows one / two entries per thread of the staging code
     "many_16k_n512_nf124": (16000, 32.0, 10.0, 100.0, 100.0, 2, 124, 0.0, 8000.0),
     "many_16k_n400_nf64": (16000, 25.0, 10.0, 100.0, 100.0, 2, 64, 0.0, 8000.0),
+    # processspeech's parameters at other common sample rates (tools/rate_sweep.py): smooth window lengths on the any-N kernel
+    "rate_8k_n200_nf32": (8000, 25.0, 10.0, 100.0, 100.0, 2, 32, 0.0, 4000.0),       # 200 = 2^3 * 5^2
+    "rate_22k_n551_nf32": (22050, 25.0, 10.0, 100.0, 100.0, 2, 32, 0.0, 8000.0),     # 551 = 19 * 29: Bluestein, L = 1152
+    "rate_24k_n600_nf32": (24000, 25.0, 10.0, 100.0, 100.0, 2, 32, 0.0, 8000.0),     # 600 = 2^3 * 3 * 5^2
+    "rate_32k_n800_nf32": (32000, 25.0, 10.0, 100.0, 100.0, 2, 32, 0.0, 8000.0),     # 800 = 2^5 * 5^2
+    "rate_48k_n1200_nf32": (48000, 25.0, 10.0, 100.0, 100.0, 2, 32, 0.0, 8000.0),    # 1200 = 2^4 * 3 * 5^2
+    "rate_96k_n2400_nf32": (96000, 25.0, 10.0, 100.0, 100.0, 2, 32, 0.0, 8000.0),    # 2400 = 2^5 * 3 * 5^2
 }
 
 

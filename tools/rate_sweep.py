@@ -40,7 +40,7 @@ def main():
     cdt = capi.AUD_F32 if args.compute == "f32" else capi.AUD_F64
     B = args.batch
     rows = []
-    for sr in [int(r) for r in args.rates.split(",")]:
+    for sr in [int(r) for r in args.rates.replace("/", ",").split(",")]:
         name = "sweep_%d" % sr
         W.CONFIGS[name] = (sr, args.win_ms, 10.0, 100.0, 100.0, 2, 32, 0.0, min(8000.0, sr / 2.0))
         try:
