@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libauditory_hip.so")
-SOURCES = ["host_setup.cpp", "capi.hip", "capi_host.hip", "capi_comm.hip", "wave_tables.hip", "melspec_generic.hip", "melspec_chirp.hip", "melspec_wave.hip", "melspec_w16.hip", "melspec_w20.hip", "melspec_w64.hip", "smooth_mel.hip", "mfcc.hip", "gabor.hip", "kwta.hip"]
+SOURCES = ["host_setup.cpp", "capi.hip", "capi_host.hip", "capi_comm.hip", "wave_tables.hip", "melspec_generic.hip", "melspec_chirp.hip", "melspec_direct.hip", "melspec_wave.hip", "melspec_w16.hip", "melspec_w20.hip", "melspec_w64.hip", "smooth_mel.hip", "mfcc.hip", "gabor.hip", "kwta.hip"]
 
 
 def _hipcc():

@@ -39,6 +39,7 @@ void fill_melspec_args(const aud_plan* p, aud::MelspecArgs* a) {
     a->bl_fix = (p->chirp_opt && p->d_bl_fix) ? p->d_bl_fix : nullptr;
     a->ip_nfac = plain_inplace(p) ? p->ip_nfac : 0;
     for (int i = 0; i < a->ip_nfac; ++i) a->ip_fac[i] = p->ip_fac[i];
+    a->tw64 = p->direct ? p->d_tw64 : nullptr;
     a->xcd_remap = p->xcd_remap;
     a->stamps = reinterpret_cast<unsigned long long*>(p->stamps);
 }
@@ -53,6 +54,7 @@ hipError_t launch_frames(const aud_plan* p, const aud::MelspecArgs& a, hipStream
         }
         return aud::launch_melspec_wave(p->wave_kind, a, p->wv, p->d.compute_dtype, st);
     }
+    if (p->direct) return aud::launch_melspec_direct(a, p->d.compute_dtype, st);
     if (a.bl_fix) return aud::launch_melspec_chirp(a, st);
     return aud::launch_melspec_generic(a, p->d.compute_dtype, st);
 }
@@ -65,6 +67,7 @@ void generic_route(aud_plan* p) {
 }
 
 const char* plan_family(const aud_plan* p) {
+    if (p->direct) return "direct";
     if (!p->use_wave || !p->wave_kind) return (p->chirp_opt && p->d_bl_fix) ? "chirp2304" : "generic";  // (melspec_chirp.hip | any N)
     return p->wave_kind == 1 ? "w16x16" : p->wave_kind == 3 ? "w20x10" : "w64x16";
 }
@@ -307,7 +310,25 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
             (void)hipGetLastError();
             rc = fail(c, AUD_EHIP, "the runtime refused the LDS size of the any-N kernel");
         }
-        if (rc == AUD_OK && p->F_ip < 1 && p->F_two < 1) rc = fail(c, AUD_EINVAL, "win_samples too large for the LDS-resident FFT");
+        if (rc == AUD_OK && p->F_ip < 1 && p->F_two < 1) {
+            // no transform of this length fits a workgroup's LDS: the O(N H) kernel, which keeps only the spectrum there
+            if (aud::melspec_direct_lds_bytes(H, nf, d->compute_dtype) > 160u * 1024u)
+                rc = fail(c, AUD_EINVAL, "win_samples too large: the power spectrum of one frame must fit a workgroup's 160 KB of LDS");
+            else if (aud::melspec_direct_prepare() != hipSuccess) {
+                (void)hipGetLastError();
+                rc = fail(c, AUD_EHIP, "the runtime refused the LDS size of the direct kernel");
+            } else {
+                std::vector<double> tw(size_t(N) * 2);
+                const long double w = -2.0L * 3.14159265358979323846264338327950288L / (long double)N;
+                for (int k = 0; k < N; ++k) {
+                    tw[2 * size_t(k)] = double(cosl(w * k));
+                    tw[2 * size_t(k) + 1] = double(sinl(w * k));
+                }
+                rc = upload(c, &p->d_tw64, tw.data(), tw.size() * sizeof(double));
+                p->direct = rc == AUD_OK;
+                p->F_two = 1;  // (one frame per workgroup: what F_generic, the fused tail's tiles and the launch use)
+            }
+        }
         generic_route(p);
     }
     if (rc == AUD_OK) rc = upload_real(c, &p->d_filt, mel_filters, size_t(cells), d->compute_dtype);
@@ -365,6 +386,7 @@ int aud_plan_destroy(aud_plan* p) {
     if (p->d_bl_bhat) (void)hipFree(p->d_bl_bhat);
     if (p->d_bl_tw) (void)hipFree(p->d_bl_tw);
     if (p->d_bl_fix) (void)hipFree(p->d_bl_fix);
+    if (p->d_tw64) (void)hipFree(p->d_tw64);
     if (p->d_filt) (void)hipFree(p->d_filt);
     if (p->d_bin_pts) (void)hipFree(p->d_bin_pts);
     if (p->d_gabor) (void)hipFree(p->d_gabor);
@@ -582,7 +604,7 @@ bool segment_fused(const aud_plan* p) {
     if (p->use_wave && p->wave_kind) return p->wv.dct_off >= 0;
     // the any-N kernel (round 6): DCT and Energy sums from its unrounded values wherever its power buffer has the room
     if (p->chirp_opt && p->d_bl_fix) return aud::melspec_chirp_tail_fits(p->H, p->d.mel.n_filters);
-    if (plain_inplace(p)) return true;  // (its launch's LDS is sized with the tail's F x nf values)
+    if (plain_inplace(p) || p->direct) return true;  // (their launches' LDS is sized with the tail's F x nf values)
     return aud::melspec_generic_tail_fits(p->M, p->F_generic, p->H, p->d.mel.n_filters, p->d.compute_dtype, p->bl_L, p->bl_inplace);
 }
 // tiles of an item the fused tail's per-tile Energy sums come in: wave tiles, or the any-N kernel's workgroups of F frames

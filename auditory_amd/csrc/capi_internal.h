@@ -109,6 +109,8 @@ struct aud_plan {
     // smooth window lengths in place (kernels.h MelspecArgs::ip_*): F_ip = 0 where the route does not serve the length
     int F_two = 0, F_ip = 0, ip_nfac = 0;
     int ip_fac[aud::kMaxFactors] = {0};
+    bool direct = false;       // no LDS-resident transform fits this window length: the O(N H) kernel (melspec_direct.hip)
+    void* d_tw64 = nullptr;    // its [N] complex<double> table
     int ip_opt = 1;            // plan option "plain_inplace": 1 (default) the in-place route where it serves, 0 the two-buffer route
     // generic kernel, Bluestein route (kernels.h MelspecArgs::bl_*): 0 = not used
     int bl_L = 0, bl_nfac = 0;

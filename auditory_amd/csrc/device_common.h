@@ -94,6 +94,28 @@ __device__ __forceinline__ void dft5(C2<TT>& u0, C2<TT>& u1, C2<TT>& u2, C2<TT>&
     u3 = cadd(m2, mul_pi(n2));
 }
 
+// 7-point DFT (44.1 kHz = 2^2 3^2 5^2 7^2 Hz: its 10 / 20 / 30 / 40 / 50 ms windows are 441, 882, 1323, 1764, 2205 samples): sums and
+// differences of the pairs (j, 7 - j), X[k] = m_k - i n_k, X[7 - k] = m_k + i n_k
+template <typename TT>
+__device__ __forceinline__ void dft7(C2<TT>& u0, C2<TT>& u1, C2<TT>& u2, C2<TT>& u3, C2<TT>& u4, C2<TT>& u5, C2<TT>& u6) {
+    const TT c1 = TT(0.62348980185873353053L), c2 = TT(-0.22252093395631440429L), c3 = TT(-0.90096886790241912624L);
+    const TT s1 = TT(0.78183148246802980871L), s2 = TT(0.97492791218182360702L), s3 = TT(0.43388373911755812048L);
+    const C2<TT> t1 = cadd(u1, u6), t2 = cadd(u2, u5), t3 = cadd(u3, u4), d1 = csub(u1, u6), d2 = csub(u2, u5), d3 = csub(u3, u4);
+    const C2<TT> m1 = {mad(c3, t3.x, mad(c2, t2.x, mad(c1, t1.x, u0.x))), mad(c3, t3.y, mad(c2, t2.y, mad(c1, t1.y, u0.y)))};
+    const C2<TT> m2 = {mad(c1, t3.x, mad(c3, t2.x, mad(c2, t1.x, u0.x))), mad(c1, t3.y, mad(c3, t2.y, mad(c2, t1.y, u0.y)))};
+    const C2<TT> m3 = {mad(c2, t3.x, mad(c1, t2.x, mad(c3, t1.x, u0.x))), mad(c2, t3.y, mad(c1, t2.y, mad(c3, t1.y, u0.y)))};
+    const C2<TT> n1 = {mad(s3, d3.x, mad(s2, d2.x, s1 * d1.x)), mad(s3, d3.y, mad(s2, d2.y, s1 * d1.y))};
+    const C2<TT> n2 = {mad(-s1, d3.x, mad(-s3, d2.x, s2 * d1.x)), mad(-s1, d3.y, mad(-s3, d2.y, s2 * d1.y))};
+    const C2<TT> n3 = {mad(s2, d3.x, mad(-s1, d2.x, s3 * d1.x)), mad(s2, d3.y, mad(-s1, d2.y, s3 * d1.y))};
+    u0 = {u0.x + t1.x + t2.x + t3.x, u0.y + t1.y + t2.y + t3.y};
+    u1 = cadd(m1, mul_mi(n1));
+    u6 = cadd(m1, mul_pi(n1));
+    u2 = cadd(m2, mul_mi(n2));
+    u5 = cadd(m2, mul_pi(n2));
+    u3 = cadd(m3, mul_mi(n3));
+    u4 = cadd(m3, mul_pi(n3));
+}
+
 // P-point DFT of v[0..P-1], natural order in and out.  tw / N give access to W_N^k for the
 // composite sizes whose inner twiddles are not worth spelling out as literals (P = 25).
 template <typename TT, int P>
@@ -114,6 +136,12 @@ template <typename TT>
 struct SmallDft<TT, 5> {
     static __device__ __forceinline__ void run(C2<TT> (&v)[5], const C2<TT>*, int) {
         dft5(v[0], v[1], v[2], v[3], v[4]);
+    }
+};
+template <typename TT>
+struct SmallDft<TT, 7> {
+    static __device__ __forceinline__ void run(C2<TT> (&v)[7], const C2<TT>*, int) {
+        dft7(v[0], v[1], v[2], v[3], v[4], v[5], v[6]);
     }
 };
 // exp(-2 pi i m / 9), m = 1, 2, 4 (the inner twiddles of the 3 x 3 factorisation, m = b k1)

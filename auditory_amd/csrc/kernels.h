@@ -65,6 +65,7 @@ struct MelspecArgs {
     int ip_nfac;
     int ip_fac[kMaxFactors];
     const void* bl_fix;    // the fixed-geometry chirp kernel's tables (melspec_chirp.hip: twiddles of both outer stages, bhat in its digit-reversed order); null: the any-N route
+    const void* tw64;  // the direct kernel (melspec_direct.hip): [N] complex<double> exp(-2 pi i k / N) whatever the plan computes in; null otherwise
     int xcd_remap;     // 1: tile_of_workgroup() order (plan option "xcd_remap", default on)
     // wave kernels: wave tiles per item (N = 2048: frames per item) and its reciprocal, set by launch_melspec_wave -- a
     // wave finds its item with one scalar multiply (tile_div) instead of the 64-bit division's twenty vector instructions
@@ -263,6 +264,11 @@ int melspec_generic_plain_inplace(int M, int H, int nf, int T, int compute_dtype
 int melspec_generic_bluestein_L(int M, int compute_dtype);
 hipError_t melspec_generic_prepare(size_t lds_bytes);
 hipError_t launch_melspec_generic(const MelspecArgs& a, int compute_dtype, hipStream_t st);
+
+// window lengths nothing else runs (melspec_direct.hip): the O(N H) sum, one frame per workgroup, only the spectrum in LDS
+size_t melspec_direct_lds_bytes(int H, int nf, int compute_dtype);
+hipError_t melspec_direct_prepare();
+hipError_t launch_melspec_direct(const MelspecArgs& a, int compute_dtype, hipStream_t st);
 
 // the chirp convolution of fixed length 2304 = 16 x 16 x 9 (melspec_chirp.hip): odd window lengths 1024 < N <= 1152 -- the
 // reference's 25 ms at 44.1 kHz = 1103 samples -- with compile-time stage geometry, five LDS round trips instead of six

@@ -172,6 +172,7 @@ __host__ __device__ inline bool inplace_radix_ok(int L, int p) {
         case 16: return r <= 1;
         case 9: return r <= 1;
         case 8: return r <= 2;
+        case 7: return r <= 2;
         case 5: return r <= 3;
         case 4: return r <= 4;
         case 3: return r <= 5;
@@ -196,6 +197,7 @@ __device__ __forceinline__ void stage_inplace_any(int p, C2<TT>* buf, const C2<T
             else stage_inplace<TT, 9, 1, false>(buf, tw, L, ncur, s, tws, tid, pre);
             break;
         case 8: stage_inplace<TT, 8, 2, false>(buf, tw, L, ncur, s, tws, tid, pre); break;
+        case 7: stage_inplace<TT, 7, 2, false>(buf, tw, L, ncur, s, tws, tid, pre); break;
         case 5: stage_inplace<TT, 5, 3, false>(buf, tw, L, ncur, s, tws, tid, pre); break;
         case 4: stage_inplace<TT, 4, 4, false>(buf, tw, L, ncur, s, tws, tid, pre); break;
         case 3: stage_inplace<TT, 3, 5, false>(buf, tw, L, ncur, s, tws, tid, pre); break;
@@ -371,6 +373,7 @@ void k_melspec_generic(const MelspecArgs a) {
             case 8: stage<TT, 8>(src, dst, tw, F, M, N, a.ratio, ncur, s, tid); break;
             case 16: stage<TT, 16>(src, dst, tw, F, M, N, a.ratio, ncur, s, tid); break;
             case 9: stage<TT, 9>(src, dst, tw, F, M, N, a.ratio, ncur, s, tid); break;
+            case 7: stage<TT, 7>(src, dst, tw, F, M, N, a.ratio, ncur, s, tid); break;
             case 25: stage<TT, 25>(src, dst, tw, F, M, N, a.ratio, ncur, s, tid); break;
             default: {
                 // any other prime p: one thread per output j of each radix-p butterfly
@@ -546,13 +549,13 @@ int melspec_generic_bluestein_L(int M, int compute_dtype) {
 // frame alone needs more, and never more than the segment has steps (rounded up to a power of two).
 int melspec_generic_plain_inplace(int M, int H, int nf, int T, int compute_dtype, int forced_F, int* fac, int* nfac, size_t* lds) {
     int n = 0, m = M;
-    for (int p : {16, 8, 4, 2, 9, 5, 3})
+    for (int p : {16, 8, 4, 2, 9, 7, 5, 3})
         while (m % p == 0) {
             if (n >= kMaxFactors) return 0;
             fac[n++] = p;
             m /= p;
         }
-    if (m != 1 || n == 0) return 0;  // (a prime factor above 5: the two-buffer route's O(p) pass, or Bluestein)
+    if (m != 1 || n == 0) return 0;  // (a prime factor above 7: the two-buffer route's O(p) pass, or Bluestein)
     const size_t tsz = compute_dtype == AUD_F64 ? 8 : 4, c = 2 * tsz;
     auto bytes = [&](int F) { return size_t(padx(F * M) + 1) * c + (size_t(F) * size_t(H | 1) + size_t(F) * size_t(nf)) * tsz + 16; };
     auto runs = [&](int F) {

@@ -40,6 +40,10 @@ CASES = [  # config, seconds of audio, rows, segments to process per row
     ("mixed_16k_n480_nf32", 0.5, 1, [0, 1]),
     ("many_16k_n512_nf124", 0.3, 2, [0, 1]),             # degenerate low triangles (NaN rows), long schedule
     ("many_16k_n400_nf64", 0.3, 2, [0, 1]),
+    ("rate_48k_n1200_nf32", 0.3, 2, [0, 1]),             # smooth lengths on the any-N kernel's in-place route
+    ("rate_8k_n200_nf32", 0.3, 2, [0, 1, 2]),
+    ("win20_44k_n882_nf32", 0.3, 2, [0, 1]),             # radix 7 (in place, two frames per workgroup)
+    ("win50_44k_n2205_nf64", 0.3, 1, [0, 1]),            # radix 7, odd length
 ]
 
 GABOR_DEFAULT = dict(size=(9, 9), stride=(3, 3), gain=2.0, specs=W.DEFAULT_GABOR_SPECS)
@@ -833,6 +837,95 @@ def case_generic_lds_limits(orc, run=((4096, capi.AUD_F64), (8192, capi.AUD_FAST
         assert ok, "N=%d in place: power %s" % (N, msg)
 
 
+def case_smooth_routes(orc, name, cdt):
+    """A smooth window length on BOTH routes of the any-N kernel -- in place (the workgroup's F frames as one batched transform in
+    one padded buffer: the default) and the two-buffer autosort (plan option plain_inplace = 0) -- and in place with every F the
+    plan accepts (plan option plain_frames): each against the oracle; a refused F is AUD_EINVAL and leaves the plan as it was."""
+    oc = W.OracleCfg(orc, name)
+    plan = W.product_plan(oc, cdt)
+    try:
+        plan.set_option("kernel", 1)
+        assert plan.kernel_name == "generic" and plan.info("plain_inplace") == 1 and plan.info("bluestein_L") == 0
+        f_default = plan.info("generic_frames_per_wg")
+    finally:
+        plan.close()
+    case_melspec_vs_oracle(orc, (name, 0.3, 2, [0, 1]), cdt, options={"kernel": 1, "plain_inplace": 0})
+    ran = []
+    for F in (1, 2, 4, 8, 16):
+        try:
+            case_melspec_vs_oracle(orc, (name, 0.3, 2, [0, 1]), cdt, options={"kernel": 1, "plain_frames": F})
+            ran.append(F)
+        except capi.AuditoryError as ex:
+            assert ex.status == capi.AUD_EINVAL, ex
+    assert f_default in ran, (name, f_default, ran)
+    return "%s: F = %d by default, %s accepted" % (name, f_default, ran)
+
+
+def case_direct_kernel(orc, N, cdt, sig_kind="float"):
+    """Window lengths no LDS-resident transform serves (melspec_direct.hip: the O(N H) sum, float64 accumulation whatever the plan
+    computes in): an odd N = 5123 = 47 x 109 (Bluestein's L >= 10 245 does not fit) and a smooth even N = 12 000 (M = 6000: past the
+    in-place stages' 4096 points and the two buffers' 160 KB).  Two streams -- one long enough for both steps, one that ends inside
+    step 1 (masked: zeros) --, step 0 starts in the left zero pad (border 1); mel, PowerSegment and LogPowerSegment against the
+    oracle, the MFCC rows through the fused tail."""
+    from auditory_amd import mel as melmod
+    sr = 16000
+    for hi in (8000.0, 4000.0, 2000.0, 1000.0, 500.0, 250.0, 120.0, 60.0, 30.0):   # the widest triangle must fit [nf, nf+2] (Q4)
+        mp = melmod.Params()
+        mp.Defaults()
+        mp.FBank.NFilters, mp.FBank.LoHz, mp.FBank.HiHz = 24, 0.0, hi
+        try:
+            filt = mp.InitFilters(N, sr)
+            break
+        except capi.AuditoryError:
+            continue
+    else:
+        raise AssertionError("no mel table for N=%d" % N)
+    S, T, border = N // 2, 2, 1
+    dftp = capi.DftParams()
+    capi.load().aud_dft_defaults(dftp)
+    L = N + S
+    sig, _ = synth.batch(77 + N, 2, L, sr)
+    lens = [L, N - 3]                      # stream 1: step 1 (start 0) would end 3 samples behind the signal; step 0 starts in the pad
+    if sig_kind == "int16":
+        pcm = np.clip(np.round(sig * 20000.0), -32768, 32767).astype(np.int16)
+        sig = pcm.astype(np.float64) / 32767.0
+    plan = runtime.Plan(runtime.get_ctx(0), N, S, T, border, dftp, mp.FBank.to_c(), mp.BinPts, filt, compute_dtype=cdt, mfcc_coefs=13)
+    try:
+        assert plan.kernel_name == "direct" and plan.info("generic_frames_per_wg") == 1 and plan.info("bluestein_L") == 0
+        items = runtime.make_items([0, L], lens, [0, 0])
+        if sig_kind == "int16":
+            dev = runtime.Signal(plan.ctx, pcm.ravel())
+            try:
+                mel, pw, lp = plan.melspec_sig(dev, items, True, True)
+            finally:
+                dev.close()
+        else:
+            mel, pw, lp = plan.melspec_host(sig.ravel(), items, True, True)
+        tail = plan.melspec_mfcc_host(sig.ravel(), items)
+    finally:
+        plan.close()
+    sp = orc.SndParams(sr, N, S, S, T, border)
+    d, m = orc.dft_defaults(), orc.mel_defaults()
+    m.n_filters, m.lo_hz, m.hi_hz = 24, 0.0, hi
+    rc, bins, hz, ofilt = orc.mel_init_filters(m, N, sr)
+    assert rc == 0 and np.array_equal(bins, mp.BinPts)
+    ref = [orc.process_segment_mfcc(sp, d, m, bins, ofilt, sig[r][:lens[r]], segment=0) for r in range(2)]
+    what = "direct N=%d %s" % (N, sig_kind)
+    ok, msg = W.feature_close(mel, np.stack([o["mel_seg"] for o in ref]), cdt, lin_axis=1)
+    assert ok, what + ": mel " + msg
+    ok, msg = W.spectrum_close(pw, np.stack([o["power_seg"] for o in ref]), 4e-6 if cdt == capi.AUD_F32 else 3e-7)
+    assert ok, what + ": power " + msg
+    ok, msg = W.close_enough(lp, np.stack([o["log_power_seg"] for o in ref]), TOL_F64 if cdt == capi.AUD_F64 else 2e-5)
+    assert ok, what + ": log_power " + msg
+    assert not mel[1][:, 1].any() and not pw[1][:, 1].any(), what + ": the step behind the signal's end must be zeros"
+    for key, tol in (dict(mfcc=4e-6, deltas=6e-6, delta_deltas=5e-5, energy=3e-7) if cdt == capi.AUD_F64 else
+                     dict(mfcc=5e-5, deltas=2e-4, delta_deltas=1e-3, energy=1e-6)).items():
+        ok, msg = W.close_enough(tail[key], np.stack([o[key] for o in ref]), tol)
+        assert ok, what + ": %s %s" % (key, msg)
+    assert np.array_equal(tail["mel"], mel, equal_nan=True)   # the fused tail does not change the stored tensors
+    return what
+
+
 def case_gabor_fuzz(orc, seed, cdt):
     """agabor.Convolve on a seeded random geometry -- matrix shape, filter size, strides, filter count (not a multiple of 4:
     zero-padded quads), NaN cells, rank-4 pools of any width and rank-2 outputs in both orders -- through BOTH kernels
@@ -1548,7 +1641,7 @@ def case_mfcc_tail(orc, name, cdt, options=None):
     try:
         for k, v in (options or {}).items():
             plan.set_option(k, v)
-        fused = plan.kernel_name in ("w16x16", "w20x10", "generic", "chirp2304") and (options or {}).get("fused_tail", 1) != 0
+        fused = plan.kernel_name in ("w16x16", "w20x10", "generic", "chirp2304", "direct") and (options or {}).get("fused_tail", 1) != 0
         got = plan.melspec_mfcc_host(sig.ravel(), make_items(oc, L, segs))
         plain, pw, lp = plan.melspec_host(sig.ravel(), make_items(oc, L, segs), True, True)
     finally:

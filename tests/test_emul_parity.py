@@ -46,6 +46,19 @@ def test_emul_chirp_kernel(orc, emu, N, cdt, kind, quirks):
     PC.case_chirp_kernel(orc, N, cdt, seed=N % 7, sig_kind=kind, quirks=quirks)
 
 
+@pytest.mark.parametrize("N,cdt,kind", [(5123, capi.AUD_F64, "float"), (10243, capi.AUD_F32, "int16"), (12000, capi.AUD_F64, "float")],
+                         ids=["n5123_f64", "n10243_f32_i16", "n12000_f64"])
+def test_emul_direct_kernel(orc, emu, N, cdt, kind):
+    """window lengths no LDS-resident transform serves run the O(N H) kernel (melspec_direct.hip) instead of being refused"""
+    PC.case_direct_kernel(orc, N, cdt, sig_kind=kind)
+
+
+@pytest.mark.parametrize("name,cdt", [("rate_8k_n200_nf32", capi.AUD_F64), ("win20_44k_n882_nf32", capi.AUD_F64), ("odd_15k_n375_nf32", capi.AUD_F32)],
+                         ids=["n200_f64", "n882_f64", "n375_f32"])
+def test_emul_smooth_routes(orc, emu, name, cdt):
+    PC.case_smooth_routes(orc, name, cdt)
+
+
 def test_emul_melspec_nan_row_config(orc, emu):
     # cfg 5 parameters (N=2048, 128 mel, NaN row) on a short segment to keep the thread count sane
     PC.case_melspec_vs_oracle(orc, ("cfg5_44k_n2048_nf128", 0.25, 1, [0]), capi.AUD_F32, seg_ms=200.0)

@@ -67,6 +67,15 @@ def test_zero_signal_and_empty_batch(orc, torch_cuda):
     PC.case_zero_signal_and_empty_batch(orc)
 
 
+@pytest.mark.parametrize("name", ["rate_8k_n200_nf32", "rate_24k_n600_nf32", "rate_32k_n800_nf32", "rate_48k_n1200_nf32", "rate_96k_n2400_nf32",
+                                  "win20_44k_n882_nf32", "win50_44k_n2205_nf64", "odd_15k_n375_nf32", "mixed_16k_n480_nf32"])
+@pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
+def test_smooth_routes(orc, torch_cuda, name, cdt):
+    """smooth window lengths (processspeech's parameters at the common sample rates; 44.1 kHz windows with factors of 7) on both
+    routes of the any-N kernel and with every accepted number of frames per workgroup"""
+    PC.case_smooth_routes(orc, name, cdt)
+
+
 def test_generic_lds_limits(orc, torch_cuda):
     PC.case_generic_lds_limits(orc)
 
@@ -607,6 +616,15 @@ def test_chirp_kernel(orc, torch_cuda, N, cdt, kind, quirks):
     it serves) against the oracle and against the any-N route it replaces, three seeds each"""
     for seed in range(3):
         PC.case_chirp_kernel(orc, N, cdt, seed=seed, sig_kind=kind, quirks=quirks)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,cdt,kind", [(5123, capi.AUD_F64, "float"), (10243, capi.AUD_F32, "int16"), (12000, capi.AUD_F64, "float"),
+                                        (10241, capi.AUD_F64, "int16")],
+                         ids=["n5123_f64", "n10243_f32_i16", "n12000_f64", "n10241_f64_i16"])
+def test_direct_kernel(orc, torch_cuda, N, cdt, kind):
+    """window lengths no LDS-resident transform serves run the O(N H) kernel (melspec_direct.hip) instead of being refused"""
+    PC.case_direct_kernel(orc, N, cdt, sig_kind=kind)
 
 
 @pytest.mark.gpu

@@ -26,6 +26,9 @@ CONFIGS = {
     "rate_32k_n800_nf32": (32000, 25.0, 10.0, 100.0, 100.0, 2, 32, 0.0, 8000.0),     # 800 = 2^5 * 5^2
     "rate_48k_n1200_nf32": (48000, 25.0, 10.0, 100.0, 100.0, 2, 32, 0.0, 8000.0),    # 1200 = 2^4 * 3 * 5^2
     "rate_96k_n2400_nf32": (96000, 25.0, 10.0, 100.0, 100.0, 2, 32, 0.0, 8000.0),    # 2400 = 2^5 * 3 * 5^2
+    # 44.1 kHz = 2^2 3^2 5^2 7^2 Hz: windows other than the 25 ms default carry factors of 7 (radix-7 stages)
+    "win20_44k_n882_nf32": (44100, 20.0, 10.0, 100.0, 100.0, 2, 32, 0.0, 8000.0),    # 882 = 2 * 3^2 * 7^2
+    "win50_44k_n2205_nf64": (44100, 50.0, 10.0, 100.0, 100.0, 2, 64, 0.0, 8000.0),   # 2205 = 3^2 * 5 * 7^2 (odd: M = N)
 }
 
 
