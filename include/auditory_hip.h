@@ -214,8 +214,9 @@ int aud_device_id(const aud_ctx* ctx);
 int aud_plan_create(aud_ctx* ctx, const aud_plan_desc* desc, const int32_t* bin_pts, const double* mel_filters,
                     const double* gabor_filters, aud_plan** plan);
 int aud_plan_destroy(aud_plan* plan);
-/* which frame->mel kernel family the plan selected: "w16x16" (N = 512), "w20x10" (N = 400), "w64x16" (N = 2048) or
- * "generic" (any other N, and any plan with "kernel" = 1) -- diagnostic */
+/* which frame->mel kernel family the plan selected: "w16x16" (N = 512), "w20x10" (N = 400), "w64x16" (N = 2048),
+ * "chirp2304" (float64 plans with an odd 1024 < N <= 1152: dft.go:42-50 at the reference's own N = 1103), "generic" (any other N
+ * whose transform fits a workgroup's LDS, and any plan with "kernel" = 1) or "direct" (every other N: the O(N H) sum) -- diagnostic */
 const char* aud_plan_kernel_name(const aud_plan* plan);
 /* Tuning / diagnostic switches; results are identical whatever they are set to (up to the last-place effects of a
  * different summation order between the two kernel families).
@@ -229,6 +230,14 @@ const char* aud_plan_kernel_name(const aud_plan* plan);
  *   "gabor_kernel" -1 (default) by compute type: float64 plans the all-float64 one-thread-per-position kernel (gabor.go:268-283 as
  *               written), float32 plans the LDS-staged kernel; 0 the LDS-staged kernel (float32 taps and row sums: for a float64
  *               plan an explicit opt-in, ~1e-6 of the all-float64 sum); 1 one thread per position
+ *   "fused_tail"   -1 / 1 (default) aud_segment_batch_dev lets the plan's mel kernel carry the MFCC tail wherever it can; 0 always
+ *               the two launches on the float32-stored tensors
+ *   "chirp_kernel" 1 (default) the fixed-geometry chirp kernel of L = 2304 where it serves the plan (see aud_plan_kernel_name);
+ *               0 the any-N kernel's Bluestein route (its A/B and parity partner)
+ *   "plain_inplace" 1 (default) smooth window lengths run the any-N kernel IN PLACE (the workgroup's frames as one batched transform
+ *               in one padded LDS buffer) where every stage fits a thread's registers; 0 the two-buffer autosort route
+ *   "plain_frames"  frames per workgroup of that in-place route: 1 / 2 / 4 / 8 / 16 (AUD_EINVAL where the length does not run with
+ *               that many, the plan unchanged); the plan picks the largest that keeps four workgroups per CU
  *   "lds_pad"   extra dynamic LDS per workgroup of the wave kernels, bytes (total <= 64 KB): fewer workgroups per CU, i.e. registers
  *               left free for another kernel's waves (occupancy experiments); 0 (default) none
  *   "stamps_lo" / "stamps_hi"  the two halves of a device address for the s_memtime stamps of the DIAGNOSTIC build
@@ -245,6 +254,8 @@ int aud_plan_set_option(aud_plan* plan, const char* name, int value);
  *   "bluestein_L"      generic kernel: length of the transforms of its Bluestein route (0: direct factorisation)
  *   "bluestein_inplace" 1 if that route runs in one padded buffer (stages through registers)
  *   "generic_frames_per_wg"  frames a workgroup of the generic kernel transforms at once
+ *   "chirp_kernel"     1 if the fixed-geometry chirp kernel runs the plan ("chirp2304")
+ *   "plain_inplace"    1 if the generic kernel runs the plan's smooth window length in place
  *   "item_kernel"      1 if the plan has the workgroup-per-item kernel ("item_waves", "item_lds_bytes": its launch shape)
  * AUD_EINVAL for an unknown name. */
 int aud_plan_get_info(const aud_plan* plan, const char* name, int64_t* value);
