@@ -58,6 +58,8 @@ WORKLOADS = {
     # BASELINE configs[0]'s parameter set (processspeech defaults on the shipped 44.1 kHz WAVs: N = 1103, prime; 100 ms
     # segments of 14 steps, 32 mel): every work item is one segment -- the generic any-N kernel, a stated non-headline row
     "cfg1": (44100, 25.0, 10.0, 100.0, 2, 32, 0.0, 8000.0, 0.1),
+    # processspeech's parameters on 48 kHz audio (N = 1200 = 2^4 3 5^2): the any-N kernel's in-place route for smooth lengths
+    "rate48k": (48000, 25.0, 10.0, 100.0, 2, 32, 0.0, 8000.0, 0.1),
 }
 GABOR_SPECS = [dict(WaveLen=2.0, Orientation=o, SigmaWidth=0.5, SigmaLength=0.5, PhaseOffset=ph, CircleEdge=True)
                for o in (0, 45, 90, 135) for ph in (0, 1.5708)]        # processspeech.go:236-252
@@ -350,7 +352,7 @@ def main():  # noqa: C901
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
-    ap.add_argument("--workload", choices=["headline", "n512", "cfg4", "cfg5", "cfg1", "sndenv", "sndenv_cfg1"], default="headline",
+    ap.add_argument("--workload", choices=["headline", "n512", "cfg4", "cfg5", "cfg1", "rate48k", "sndenv", "sndenv_cfg1"], default="headline",
                     help="headline: the judged line (N = 400; the other BASELINE configurations nested under `also`).  "
                          "Stand-alone lines for BASELINE.md's table: cfg4 = headline + agabor.Convolve (default FilterSet, "
                          "[11,32,2,8] pools); cfg5 = 44.1 kHz 5 s streams, N = 2048, 128 mel (use --batch 1280 for >= 1 GB "
@@ -901,7 +903,7 @@ def main():  # noqa: C901
         return res
 
     # ---------------------------------------------------------------------------------------------------
-    stand_alone = args.workload if args.workload in ("cfg5", "cfg1", "n512") else ("cfg1" if args.workload == "sndenv_cfg1" else "n400")
+    stand_alone = args.workload if args.workload in ("cfg5", "cfg1", "rate48k", "n512") else ("cfg1" if args.workload == "sndenv_cfg1" else "n400")
     head_wl = Workload(stand_alone)
     kind = {"cfg4": "gabor", "sndenv": "full", "sndenv_cfg1": "full"}.get(args.workload, "mel")
     head = time_mode(head_wl, args.compute, kind=kind)
@@ -966,6 +968,7 @@ def main():  # noqa: C901
             "sndenv": "the whole unmodified SndEnv.ProcessSegment loop on the metric's parameters (mel + Power + LogPower "
                       "tensors + MFCC tail with deltas and Energy: SURVEY 8 f-1, f-2): ",
             "cfg1": "BASELINE configs[0] parameters (N = 1103), one 100 ms segment per item: ",
+            "rate48k": "processspeech's parameters on 48 kHz audio (N = 1200: a smooth length on the any-N kernel), one 100 ms segment per item: ",
             "sndenv_cfg1": "the whole unmodified SndEnv.ProcessSegment loop on BASELINE configs[0]'s parameters (N = 1103, one 100 ms "
                            "segment per item: mel + Power + LogPower tensors + MFCC tail; the any-N kernel carries the tail): ",
             "n512": "BASELINE configs[1] as worded (512-point FFT: WinMs 32): ",

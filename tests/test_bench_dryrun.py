@@ -188,7 +188,8 @@ def test_bench_dry_run_single_rank_collective(monkeypatch, capsys, mode):
 
 @pytest.mark.parametrize("extra", [[], ["--only-headline"], ["--workload", "cfg4"], ["--sig-dtype", "i16", "--only-headline"],
                                    ["--compute", "f32", "--launch", "eager", "--only-headline"],
-                                   ["--workload", "sndenv"], ["--stereo", "--only-headline"], ["--workload", "sndenv_cfg1"]])
+                                   ["--workload", "sndenv"], ["--stereo", "--only-headline"], ["--workload", "sndenv_cfg1"],
+                                   ["--workload", "rate48k"]])
 def test_bench_dry_run(monkeypatch, capsys, extra):
     import backend
     import bench
@@ -207,7 +208,7 @@ def test_bench_dry_run(monkeypatch, capsys, extra):
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
     assert line["unit"] == "audio-seconds/sec" and line["n_gpus"] == 1 and line["steps"] == 2 * line["config"]["repeats"]
-    assert "25 ms" in line["metric"] and line["config"]["win_samples"] == (1103 if "sndenv_cfg1" in extra else 400)   # the metric's own parameter set
+    assert "25 ms" in line["metric"] and line["config"]["win_samples"] == (1103 if "sndenv_cfg1" in extra else 1200 if "rate48k" in extra else 400)   # the metric's own parameter set
     assert set(line["parity"]) >= {"criterion", "elements", "max_scaled_err", "n_past_1e-5", "pass"} and line["parity"]["pass"]
     assert line["vs_baseline"] is None and line["scaling"] == "weak" and line["data"] == "synthetic"
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
@@ -219,7 +220,11 @@ def test_bench_dry_run(monkeypatch, capsys, extra):
     else:
         assert ac is None
     assert ("1e-5" in line["dtype_note"]) == (line["dtype"] == "f64")       # the contract, in the line: float32 epilogue, margin
-    assert line["roofline"]["note"].startswith("float64 VALU floor" if line["dtype"] == "f64" else "float32 plan")
+    any_n = line["config"]["kernel"] in ("generic", "chirp2304")    # the any-N rows say what THEY wait for, and that nothing of them is float32
+    assert line["roofline"]["note"].startswith("workgroup-level transform through LDS" if any_n else
+                                               "float64 VALU floor" if line["dtype"] == "f64" else "float32 plan")
+    assert line["epilogue"] == (line["dtype"] if any_n else "f32") and line["roofline"]["limited_by"] == (
+        "lds_round_trips_and_barriers" if any_n else "valu_" + line["dtype"])
     assert "workload" in line["config"] and "model" not in line["config"]
     assert line["value"] > 0 and line["roofline"]["achieved"] >= 0
     if not extra:   # the default line nests the other BASELINE configurations, each with its own strict parity object

@@ -22,7 +22,8 @@ MEASURED_READ_GBPS = 6047.0
 # workload -> samples per stream, frames per stream, mel filters, bins, kFLOP per frame (2.5 N log2 N + 3 H + 2 sum of
 # the triangles' widths + nf logarithms, evaluated on the product's own mel table: bench.py frame_flops gives the same figure)
 WL = {"headline": (16000, 104, 40, 201, 10.14), "n512": (16000, 104, 40, 257, 13.43), "cfg4": (16000, 104, 40, 201, 10.14),
-      "sndenv": (16000, 104, 40, 201, 10.14), "cfg5": (220500, 504, 128, 1025, 63.7), "cfg1": (4410, 14, 32, 552, 30.39)}
+      "sndenv": (16000, 104, 40, 201, 10.14), "cfg5": (220500, 504, 128, 1025, 63.7), "cfg1": (4410, 14, 32, 552, 30.39),
+      "rate48k": (4800, 14, 32, 601, 33.1)}
 
 
 def algorithmic(fam, wl, B):
