@@ -10,7 +10,10 @@
 
 namespace aud {
 
-template <typename TT>
+// WALK: how the mel loop deals its work -- true: a slot of four lanes keeps one filter and walks the workgroup's frames (the any-N
+// and direct kernels: up to sixteen frames per workgroup); false: a slot per (frame, filter) pair (the chirp kernel: two frames,
+// one pass either way, and this form is 3 % faster there: profiles/round6_epilogue_walk_ab.txt)
+template <typename TT, bool WALK = true>
 __device__ __forceinline__ void frames_epilogue(const MelspecArgs& a, const aud_item& it, int item, int tiles, int t0, TT* P, int tid) {
     const int F = a.F, N = a.N, H = a.H, T = a.T;
     const int Hp = H | 1;
@@ -62,59 +65,124 @@ __device__ __forceinline__ void frames_epilogue(const MelspecArgs& a, const aud_
         const TT* __restrict__ filt = static_cast<const TT*>(a.filt);
         const int cols = a.nf + 2;
         const TT loff = TT(a.mel_log_off), lmin = TT(a.mel_log_min);
-        // FOUR lanes per (frame, filter): the workgroup has few frames (one or two with Bluestein) and a filter's taps are a
-        // serial chain of table loads -- one lane per filter left three of the four waves idle through the kernel's tail.  A
-        // lane takes every fourth tap; the four partial sums meet by two lane exchanges, (p0 + p2) + (p1 + p3) on every lane.
-        const int n_work = F * a.nf;
-        for (int w0 = tid >> 2; w0 < ((n_work + 63) & ~63); w0 += blockDim.x >> 2) {  // (whole waves stay in the exchanges)
-            const int w = w0 < n_work ? w0 : n_work - 1, part = tid & 3;
-            const int flt = w / F, f = w - flt * F;
-            const int sstep = t0 + f;
-            const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
-            const bool live = sstep < T && start + N <= int64_t(it.sig_len);
-            TT sum = TT(0);
-            {
+        if constexpr (WALK) {
+            // FOUR lanes per filter, a lane takes every fourth tap; the four partial sums meet by two lane exchanges, (p0 + p2) +
+            // (p1 + p3) on every lane.  A slot (= four lanes) keeps ONE filter and walks the workgroup's frames with it: the filter's
+            // bin range and tap weights are requested once, together, before the first is used -- as a loop over (frame, filter)
+            // pairs every pass waited for its own table loads, two L2 round trips in a row, F / 2 passes (a third of the kernel at
+            // N = 200, F = 8: profiles/round6_plain_inplace_ablation.txt).  With fewer filters than slots the slots split the frames
+            // between them (G groups: 32 filters, 64 slots: even and odd frames).  Same products, same order of additions.
+            const int slots = int(blockDim.x) >> 2, slot = tid >> 2, part = tid & 3;
+            const int G = a.nf < slots ? slots / a.nf : 1;            // frame groups of a pass
+            const int per_group = (F + G - 1) / G;                    // frames a slot walks (uniform trip count: whole waves stay in the exchanges)
+            for (int base = 0; base < a.nf; base += slots) {
+                const int g = G > 1 ? slot / a.nf : 0;
+                const int flt_raw = base + (G > 1 ? slot - g * a.nf : slot);
+                const bool on = flt_raw < a.nf && g < G;
+                const int flt = on ? flt_raw : a.nf - 1;
                 const int lo = a.bin_pts[flt], hi = a.bin_pts[flt + 2];
                 const TT* wrow = filt + size_t(flt) * cols;
-                const TT* prow = P + size_t(f) * Hp;
                 constexpr int kJ = 9;  // taps of a lane where a table row has at most 36 columns (nf <= 34: the reference's 32)
-                if (live && cols <= 4 * kJ) {
-                    // every tap's weight requested before the first is used: as a loop with a data-dependent trip count each
-                    // iteration waited for its own table load -- five to nine L2 round trips in a row (round 6).  Same products,
-                    // same order of additions
-                    TT wv[kJ];
-#pragma unroll
-                    for (int j = 0; j < kJ; ++j) {
-                        const int bin = lo + part + 4 * j;
-                        wv[j] = wrow[bin <= hi ? bin - lo : 0];
+                const bool batched = cols <= 4 * kJ;
+                TT wv[kJ];
+    #pragma unroll
+                for (int j = 0; j < kJ; ++j) {
+                    const int bin = lo + part + 4 * j;
+                    wv[j] = batched ? wrow[bin <= hi ? bin - lo : 0] : TT(0);
+                }
+                for (int i = 0; i < per_group; ++i) {
+                    const int f_raw = g + i * G;
+                    const bool valid = on && f_raw < F;
+                    const int f = f_raw < F ? f_raw : F - 1;
+                    const int sstep = t0 + f;
+                    const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
+                    const bool live = sstep < T && start + N <= int64_t(it.sig_len);
+                    const TT* prow = P + size_t(f) * Hp;
+                    TT sum = TT(0);
+                    if (live && batched) {
+    #pragma unroll
+                        for (int j = 0; j < kJ; ++j) {
+                            const int bin = lo + part + 4 * j;
+                            if (bin <= hi) sum += wv[j] * prow[bin];
+                        }
+                    } else if (live) {
+                        for (int bin = lo + part; bin <= hi; bin += 4) sum += wrow[bin - lo] * prow[bin];
                     }
-#pragma unroll
-                    for (int j = 0; j < kJ; ++j) {
-                        const int bin = lo + part + 4 * j;
-                        if (bin <= hi) sum += wv[j] * prow[bin];
+                    sum += __shfl_xor(sum, 2, 64);
+                    sum += __shfl_xor(sum, 1, 64);
+                    if (part != 0 || !valid) continue;
+                    float res = 0.f;
+                    TT val = TT(0);
+                    if (live) {
+                        sum += loff;
+                        val = (sum == TT(0)) ? lmin : dev_log(sum);
+                        if (a.renorm) {
+                            val -= TT(a.renorm_min);
+                            if (val < TT(0)) val = TT(0);
+                            val *= TT(a.renorm_scale);
+                            if (val > TT(1)) val = TT(1);
+                        }
+                        res = float(val);
                     }
-                } else if (live) {
-                    for (int bin = lo + part; bin <= hi; bin += 4) sum += wrow[bin - lo] * prow[bin];
+                    if (a.mfcc_acc) melL[f * a.nf + flt] = val;  // (0 for a step the loop never reached: its MFCC column stays 0)
+                    if (sstep < T) a.mel[(size_t(item) * a.nf + flt) * T + sstep] = res;
                 }
             }
-            sum += __shfl_xor(sum, 2, 64);
-            sum += __shfl_xor(sum, 1, 64);
-            if (part != 0 || w0 >= n_work) continue;
-            float res = 0.f;
-            TT val = TT(0);
-            if (live) {
-                sum += loff;
-                val = (sum == TT(0)) ? lmin : dev_log(sum);
-                if (a.renorm) {
-                    val -= TT(a.renorm_min);
-                    if (val < TT(0)) val = TT(0);
-                    val *= TT(a.renorm_scale);
-                    if (val > TT(1)) val = TT(1);
+        } else {
+            // FOUR lanes per (frame, filter): the workgroup has few frames (one or two with Bluestein) and a filter's taps are a
+            // serial chain of table loads -- one lane per filter left three of the four waves idle through the kernel's tail.  A
+            // lane takes every fourth tap; the four partial sums meet by two lane exchanges, (p0 + p2) + (p1 + p3) on every lane.
+            const int n_work = F * a.nf;
+            for (int w0 = tid >> 2; w0 < ((n_work + 63) & ~63); w0 += blockDim.x >> 2) {  // (whole waves stay in the exchanges)
+                const int w = w0 < n_work ? w0 : n_work - 1, part = tid & 3;
+                const int flt = w / F, f = w - flt * F;
+                const int sstep = t0 + f;
+                const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
+                const bool live = sstep < T && start + N <= int64_t(it.sig_len);
+                TT sum = TT(0);
+                {
+                    const int lo = a.bin_pts[flt], hi = a.bin_pts[flt + 2];
+                    const TT* wrow = filt + size_t(flt) * cols;
+                    const TT* prow = P + size_t(f) * Hp;
+                    constexpr int kJ = 9;  // taps of a lane where a table row has at most 36 columns (nf <= 34: the reference's 32)
+                    if (live && cols <= 4 * kJ) {
+                        // every tap's weight requested before the first is used: as a loop with a data-dependent trip count each
+                        // iteration waited for its own table load -- five to nine L2 round trips in a row (round 6).  Same products,
+                        // same order of additions
+                        TT wv[kJ];
+    #pragma unroll
+                        for (int j = 0; j < kJ; ++j) {
+                            const int bin = lo + part + 4 * j;
+                            wv[j] = wrow[bin <= hi ? bin - lo : 0];
+                        }
+    #pragma unroll
+                        for (int j = 0; j < kJ; ++j) {
+                            const int bin = lo + part + 4 * j;
+                            if (bin <= hi) sum += wv[j] * prow[bin];
+                        }
+                    } else if (live) {
+                        for (int bin = lo + part; bin <= hi; bin += 4) sum += wrow[bin - lo] * prow[bin];
+                    }
                 }
-                res = float(val);
+                sum += __shfl_xor(sum, 2, 64);
+                sum += __shfl_xor(sum, 1, 64);
+                if (part != 0 || w0 >= n_work) continue;
+                float res = 0.f;
+                TT val = TT(0);
+                if (live) {
+                    sum += loff;
+                    val = (sum == TT(0)) ? lmin : dev_log(sum);
+                    if (a.renorm) {
+                        val -= TT(a.renorm_min);
+                        if (val < TT(0)) val = TT(0);
+                        val *= TT(a.renorm_scale);
+                        if (val > TT(1)) val = TT(1);
+                    }
+                    res = float(val);
+                }
+                if (a.mfcc_acc) melL[f * a.nf + flt] = val;  // (0 for a step the loop never reached: its MFCC column stays 0)
+                if (sstep < T) a.mel[(size_t(item) * a.nf + flt) * T + sstep] = res;
             }
-            if (a.mfcc_acc) melL[f * a.nf + flt] = val;  // (0 for a step the loop never reached: its MFCC column stays 0)
-            if (sstep < T) a.mel[(size_t(item) * a.nf + flt) * T + sstep] = res;
         }
     }
 

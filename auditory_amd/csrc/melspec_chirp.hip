@@ -337,7 +337,7 @@ void k_melspec_chirp(const MelspecArgs a) {
     }
     __syncthreads();
 
-    frames_epilogue<TT>(a, it, item, tiles, t0, P, tid);
+    frames_epilogue<TT, false>(a, it, item, tiles, t0, P, tid);
 }
 
 }  // namespace

@@ -285,10 +285,8 @@ void k_melspec_generic(const MelspecArgs a) {
         const int64_t start = int64_t(it.start0) + int64_t(a.S) * (s - a.border);
         const bool live = s < T && start + N <= int64_t(it.sig_len);
         int ex_max = kNoSignal;
-        for (int n = tid; n < N; n += blockDim.x) {
-            const int64_t pos = start + n;
-            TT v = TT(0);
-            if (live && pos >= 0) v = load_sample<TT>(a.sig, a.sig_dtype, it.sig_off + pos * stride);
+        // what a sample is turned into and where it goes (uniform route flags; positions of frame f)
+        auto put = [&](int n, TT v) {
             if (inpl && !pair) {  // z[n / 2] = (x[2j], x[2j+1]) for even N, z[n] = (x[n], 0) for odd N; element j of frame f at f + F j
                 TT* cell = &src[padx(f + F * (even ? n >> 1 : n))].x;  // (Bluestein without a pair: F = 1)
                 if (even) cell[n & 1] = v;
@@ -304,7 +302,24 @@ void k_melspec_generic(const MelspecArgs a) {
             } else {
                 src[size_t(f) * M + n] = {v, TT(0)};
             }
-        }
+        };
+        // one loop per sample type (a launch constant), the frame's first sample as a pointer, 32-bit positions inside the frame:
+        // the loop had carried a 64-bit position, a 64-bit product with the stride and a three-way type switch per sample
+        const int lo = !live ? N : start < 0 ? int(-start < int64_t(N) ? -start : int64_t(N)) : 0;  // first sample that is not pad (N: none)
+        auto run = [&](auto* stream) {
+            auto* first = stream + it.sig_off + start * stride;   // (dereferenced for lo <= n < N only: samples of the stream)
+            for (int n = tid; n < N; n += blockDim.x) {
+                TT v = TT(0);
+                if (n >= lo) {
+                    if constexpr (sizeof(*stream) == 2) v = pcm16_to<TT>(int(first[int64_t(n) * stride]));
+                    else v = TT(first[int64_t(n) * stride]);
+                }
+                put(n, v);
+            }
+        };
+        if (a.sig_dtype == AUD_F32) run(static_cast<const float*>(a.sig));
+        else if (a.sig_dtype == AUD_F64) run(static_cast<const double*>(a.sig));
+        else run(static_cast<const int16_t*>(a.sig));
         if (pair) {  // (uniform)
             ex_max = wave_max_i32(ex_max);
             if ((tid & 63) == 0 && ex_max != kNoSignal) atomicMax(pair_exp + f, ex_max);
@@ -444,8 +459,9 @@ void k_melspec_generic(const MelspecArgs a) {
             }
         }
     }
+    const float h_inv = 1.0f / float(H);  // (w < F H <= 2^17: (w + 0.5) / H is at least 0.5 / H from an integer, the product's error below 16 x 2^-22)
     for (int w = tid; w < (pair ? 0 : F * H); w += blockDim.x) {
-        const int f = w / H, k = w - f * H;
+        const int f = int((float(w) + 0.5f) * h_inv), k = w - f * H;
         TT re, im;
         if (even) {
             // X[k] = (Z[k] + conj Z[M-k])/2 - i W_N^k (Z[k] - conj Z[M-k])/2, Z[M] == Z[0]
@@ -466,7 +482,8 @@ void k_melspec_generic(const MelspecArgs a) {
     }
     __syncthreads();
 
-    frames_epilogue<TT>(a, it, item, tiles, t0, P, tid);
+    if (a.bl_L) frames_epilogue<TT, false>(a, it, item, tiles, t0, P, tid);  // (uniform) one or two frames: a slot per (frame, filter)
+    else frames_epilogue<TT, true>(a, it, item, tiles, t0, P, tid);           // up to sixteen: a slot per filter walks the frames
 }
 
 }  // namespace
