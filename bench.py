@@ -1033,7 +1033,7 @@ def main():  # noqa: C901
         "n_gpus": world, "steps": top["steps"], "warmup": args.warmup, "ms_per_step": top["ms_per_step"],
         "higher_is_better": True, "scaling": "strong" if cfg3 is not None else "weak", "vs_baseline": None,
         "dtype": args.compute, "epilogue": args.compute if any_n else "f32", "data": "synthetic",
-        "dtype_note": ("float64 plan on the any-N route (%s): chirp convolution, power, mel sums and logarithms all in float64, rounded "
+        "dtype_note": ("float64 plan on the any-N route (%s): transform, power, mel sums and logarithms all in float64, rounded "
                        "to float32 once at the store; strict criterion (1e-5 on every timed element, `parity`): max scaled error %.2g"
                        % (head["kernel"], (top.get("parity") or head.get("parity") or {"max_scaled_err": float("nan")})["max_scaled_err"])
                        if args.compute == "f64" and any_n else
