@@ -55,7 +55,14 @@ hipError_t launch_frames(const aud_plan* p, const aud::MelspecArgs& a, hipStream
         return aud::launch_melspec_wave(p->wave_kind, a, p->wv, p->d.compute_dtype, st);
     }
     if (p->direct) return aud::launch_melspec_direct(a, p->d.compute_dtype, st);
-    if (a.bl_fix) return aud::launch_melspec_chirp(a, st);
+    if (a.bl_fix) {  // the chirp kernel transforms pairs of whole windows: length N whatever the any-N route's packing
+        aud::MelspecArgs b = a;
+        b.M = a.N;
+        b.ratio = 1;
+        b.F = 2;
+        b.bl_chirp = p->d_fix_chirp;
+        return aud::launch_melspec_chirp(b, st);
+    }
     return aud::launch_melspec_generic(a, p->d.compute_dtype, st);
 }
 
@@ -63,7 +70,9 @@ hipError_t launch_frames(const aud_plan* p, const aud::MelspecArgs& a, hipStream
 bool plain_inplace(const aud_plan* p) { return p->bl_L == 0 && p->F_ip > 0 && (p->ip_opt != 0 || p->F_two < 1); }
 // frames per workgroup of the any-N kernel on the route the plan's options select (Bluestein plans set theirs at creation)
 void generic_route(aud_plan* p) {
-    if (p->bl_L == 0) p->F_generic = plain_inplace(p) ? p->F_ip : p->F_two;
+    if (p->chirp_opt && p->d_bl_fix) p->F_generic = 2;   // the chirp kernel: a pair of frames per workgroup
+    else if (p->bl_L) p->F_generic = p->F_bl;
+    else p->F_generic = plain_inplace(p) ? p->F_ip : p->F_two;
 }
 
 const char* plan_family(const aud_plan* p) {
@@ -126,6 +135,44 @@ void factorize(int m, int* fac, int* nfac) {
         while (m % p == 0) { fac[n++] = p; m /= p; }
     if (m > 1) fac[n++] = m;
     *nfac = n;
+}
+
+// Bluestein's tables for a length-M DFT through transforms of length L >= 2 M - 1, in long double: chirp[n] = exp(-i pi n^2 / M)
+// (n^2 reduced mod 2 M), bhat = FFT_L(conj chirp wrapped to length L) / L, twl[k] = exp(-2 pi i k / L)
+void bluestein_tables(int M, int L, std::vector<double>& chirp, std::vector<double>& bhat, std::vector<double>& twl) {
+    const long double pi = 3.14159265358979323846264338327950288L;
+    const size_t Mz = size_t(M), Lz = size_t(L);
+    std::vector<long double> wr(Mz), wi(Mz);
+    for (int n = 0; n < M; ++n) {
+        const long double ang = -pi * (long double)((int64_t(n) * n) % (2 * int64_t(M))) / (long double)M;
+        wr[size_t(n)] = cosl(ang);
+        wi[size_t(n)] = sinl(ang);
+    }
+    // b[m] = conj(w[|m|]) wrapped to length L, bhat = FFT_L(b) / L by a recursive mixed-radix FFT in long double (any L)
+    std::vector<long double> br(Lz, 0.0L), bi(Lz, 0.0L);
+    for (int m = 0; m < M; ++m) {
+        br[size_t(m)] = wr[size_t(m)];
+        bi[size_t(m)] = -wi[size_t(m)];
+        if (m > 0) {
+            br[size_t(L - m)] = wr[size_t(m)];
+            bi[size_t(L - m)] = -wi[size_t(m)];
+        }
+    }
+    fft_long_double(br, bi);
+    chirp.assign(Mz * 2, 0.0);
+    bhat.assign(Lz * 2, 0.0);
+    twl.assign(Lz * 2, 0.0);
+    for (int n = 0; n < M; ++n) {
+        chirp[2 * size_t(n)] = double(wr[size_t(n)]);
+        chirp[2 * size_t(n) + 1] = double(wi[size_t(n)]);
+    }
+    for (int k = 0; k < L; ++k) {
+        bhat[2 * size_t(k)] = double(br[size_t(k)] / (long double)L);
+        bhat[2 * size_t(k) + 1] = double(bi[size_t(k)] / (long double)L);
+        const long double ang = -2.0L * pi * k / (long double)L;
+        twl[2 * size_t(k)] = double(cosl(ang));
+        twl[2 * size_t(k) + 1] = double(sinl(ang));
+    }
 }
 
 }  // namespace
@@ -246,45 +293,11 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
         const int L = awkward ? aud::melspec_generic_bluestein_L(p->M, d->compute_dtype) : 0;
         if (rc == AUD_OK && L > 0) {
             const int M = p->M;
-            const long double pi = 3.14159265358979323846264338327950288L;
-            const size_t Mz = size_t(M), Lz = size_t(L);
-            std::vector<long double> wr(Mz), wi(Mz);
-            for (int n = 0; n < M; ++n) {  // exp(-i pi n^2 / M) with n^2 reduced mod 2 M
-                const long double ang = -pi * (long double)((int64_t(n) * n) % (2 * int64_t(M))) / (long double)M;
-                wr[size_t(n)] = cosl(ang);
-                wi[size_t(n)] = sinl(ang);
-            }
-            // b[m] = conj(w[|m|]) wrapped to length L, bhat = FFT_L(b) / L by a recursive mixed-radix FFT in long double (any L)
-            std::vector<long double> br(Lz, 0.0L), bi(Lz, 0.0L);
-            for (int m = 0; m < M; ++m) {
-                br[size_t(m)] = wr[size_t(m)];
-                bi[size_t(m)] = -wi[size_t(m)];
-                if (m > 0) {
-                    br[size_t(L - m)] = wr[size_t(m)];
-                    bi[size_t(L - m)] = -wi[size_t(m)];
-                }
-            }
-            fft_long_double(br, bi);
-            std::vector<double> chirp(Mz * 2), bhat(Lz * 2), twl(Lz * 2);
-            for (int n = 0; n < M; ++n) {
-                chirp[2 * size_t(n)] = double(wr[size_t(n)]);
-                chirp[2 * size_t(n) + 1] = double(wi[size_t(n)]);
-            }
-            for (int k = 0; k < L; ++k) {
-                bhat[2 * size_t(k)] = double(br[size_t(k)] / (long double)L);
-                bhat[2 * size_t(k) + 1] = double(bi[size_t(k)] / (long double)L);
-                const long double ang = -2.0L * pi * k / (long double)L;
-                twl[2 * size_t(k)] = double(cosl(ang));
-                twl[2 * size_t(k) + 1] = double(sinl(ang));
-            }
+            std::vector<double> chirp, bhat, twl;
+            bluestein_tables(M, L, chirp, bhat, twl);
             rc = upload_real(c, &p->d_bl_chirp, chirp.data(), chirp.size(), d->compute_dtype);
             if (rc == AUD_OK) rc = upload_real(c, &p->d_bl_bhat, bhat.data(), bhat.size(), d->compute_dtype);
             if (rc == AUD_OK) rc = upload_real(c, &p->d_bl_tw, twl.data(), twl.size(), d->compute_dtype);
-            if (rc == AUD_OK && aud::melspec_chirp_serves(N, M, L, d->compute_dtype)) {  // the fixed-geometry kernel's tables (melspec_chirp.hip)
-                std::vector<double> fix(size_t(aud::melspec_chirp_table_len()) * 2);
-                aud::melspec_chirp_tables(twl.data(), bhat.data(), fix.data());
-                rc = upload_real(c, &p->d_bl_fix, fix.data(), fix.size(), d->compute_dtype);
-            }
             const size_t lds = aud::melspec_generic_lds_bytes(L, 1, d->compute_dtype, true);
             if (rc == AUD_OK && lds > 64u * 1024u && aud::melspec_generic_prepare(lds) != hipSuccess) {
                 (void)hipGetLastError();
@@ -296,7 +309,8 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
                 p->bl_inplace = aud::melspec_generic_bluestein_inplace(L);  // one padded buffer, stages through registers
                 // odd window lengths, float64 plans: two real frames per complex transform (float32 transforms keep one frame
                 // each: separating a pair adds the partner's rounding floor, 4.2e-6 of the frame peak against 3e-6 measured)
-                p->F_generic = (p->ratio == 1 && d->compute_dtype == AUD_F64) ? 2 : 1;
+                p->F_bl = (p->ratio == 1 && d->compute_dtype == AUD_F64) ? 2 : 1;
+                p->F_generic = p->F_bl;
             }
         }
     }
@@ -329,6 +343,29 @@ int aud_plan_create(aud_ctx* c, const aud_plan_desc* d, const int32_t* bin_pts, 
                 p->F_two = 1;  // (one frame per workgroup: what F_generic, the fused tail's tiles and the launch use)
             }
         }
+        generic_route(p);
+    }
+    bool chirp_pays = N > 512;
+    if (!chirp_pays && p->F_ip < 1 && N >= 16) {
+        // shorter windows (profiles/round6_rate_sweep.txt, "short awkward lengths"): the any-N kernel's Bluestein route costs 30-45 us per
+        // 256 segments of 14 frames whatever its length -- one frame per workgroup on even windows (N = 254: 44.8 us), a pair on
+        // odd ones (N = 331, L = 720: 30.5; N = 127, L = 256: 24.8) -- against this kernel's 27-29; its two-buffer route runs O(p)
+        // passes for the primes 11 .. 23, over the whole window where N is odd (N = 276 = 4 x 3 x 23: 24.8 us -- kept; 275 = 11 x 25:
+        // 32.3, 221 = 13 x 17: 40.0, 507 = 3 x 13^2: 73.7 -- all three taken over)
+        int64_t odd_primes = 0;
+        for (int i = 0; i < p->nfac; ++i)
+            if (p->fac[i] > 9 && p->fac[i] != 16 && p->fac[i] != 25) odd_primes += p->fac[i];
+        chirp_pays = p->bl_L ? (p->ratio == 2 || p->bl_L >= 512) : int64_t(p->ratio == 1 ? 2 : 1) * p->M * odd_primes > 4000;
+    }
+    if (rc == AUD_OK && !p->direct && p->F_ip < 1 && chirp_pays && aud::melspec_chirp_serves(N, d->compute_dtype)) {
+        // The fixed-geometry chirp kernel (melspec_chirp.hip): every window 512 < N <= 1152 of a float64 plan that the smooth
+        // in-place route does not run -- the reference's N = 1103 first of all -- as pairs of real frames through ONE chirp
+        // convolution of length N on L = 2304, with tables of its own (whatever length the any-N route's Bluestein picked, if any)
+        std::vector<double> chirp, bhat, twl, fix(size_t(aud::melspec_chirp_table_len()) * 2);
+        bluestein_tables(N, 2304, chirp, bhat, twl);
+        aud::melspec_chirp_tables(twl.data(), bhat.data(), fix.data());
+        rc = upload_real(c, &p->d_bl_fix, fix.data(), fix.size(), d->compute_dtype);
+        if (rc == AUD_OK) rc = upload_real(c, &p->d_fix_chirp, chirp.data(), chirp.size(), d->compute_dtype);
         generic_route(p);
     }
     if (rc == AUD_OK) rc = upload_real(c, &p->d_filt, mel_filters, size_t(cells), d->compute_dtype);
@@ -387,6 +424,7 @@ int aud_plan_destroy(aud_plan* p) {
     if (p->d_bl_tw) (void)hipFree(p->d_bl_tw);
     if (p->d_bl_fix) (void)hipFree(p->d_bl_fix);
     if (p->d_tw64) (void)hipFree(p->d_tw64);
+    if (p->d_fix_chirp) (void)hipFree(p->d_fix_chirp);
     if (p->d_filt) (void)hipFree(p->d_filt);
     if (p->d_bin_pts) (void)hipFree(p->d_bin_pts);
     if (p->d_gabor) (void)hipFree(p->d_gabor);
@@ -487,6 +525,7 @@ int aud_plan_set_option(aud_plan* p, const char* name, int value) {
     if (key == "chirp_kernel") {  // 1 (default): the fixed-geometry chirp kernel wherever it serves the plan; 0: the any-N route
         if (value != 0 && value != 1) return fail(c, AUD_EINVAL, "chirp_kernel: 0 or 1");
         p->chirp_opt = value;
+        generic_route(p);
         p->family = plan_family(p);
         return AUD_OK;
     }

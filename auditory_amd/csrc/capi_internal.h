@@ -120,6 +120,8 @@ struct aud_plan {
     void* d_bl_bhat = nullptr;
     void* d_bl_tw = nullptr;
     void* d_bl_fix = nullptr;  // tables of the fixed-geometry chirp kernel (melspec_chirp.hip) where it serves the plan
+    void* d_fix_chirp = nullptr;  // ... and its chirp of length N (the any-N route's, where it has one, is of length M)
+    int F_bl = 0;              // frames per workgroup of the any-N kernel's Bluestein route
     int chirp_opt = 1;         // plan option "chirp_kernel": 1 (default) use it where it serves, 0 the any-N route
     int xcd_remap = 1;         // workgroup -> tile order keeps an XCD on one run of tiles (kernels.h)
     // wave-autonomous kernel of this window length (melspec_wave.hip), the default where it exists

@@ -272,7 +272,7 @@ hipError_t launch_melspec_direct(const MelspecArgs& a, int compute_dtype, hipStr
 
 // the chirp convolution of fixed length 2304 = 16 x 16 x 9 (melspec_chirp.hip): odd window lengths 1024 < N <= 1152 -- the
 // reference's 25 ms at 44.1 kHz = 1103 samples -- with compile-time stage geometry, five LDS round trips instead of six
-bool melspec_chirp_serves(int N, int M, int bl_L, int compute_dtype);  // (float64 plans: two frames per transform)
+bool melspec_chirp_serves(int N, int compute_dtype);  // (float64 plans: two frames per transform)
 size_t melspec_chirp_lds_bytes();
 int melspec_chirp_table_len();
 void melspec_chirp_tables(const double* twl, const double* bhat, double* out);

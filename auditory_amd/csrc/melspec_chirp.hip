@@ -1,5 +1,7 @@
-// Odd window lengths 1024 < N <= 1152 -- N = 1103, what the reference's 25 ms windows are on its shipped 44.1 kHz WAVs -- as a
-// chirp (Bluestein) convolution of the FIXED length L = 2304 = 16 x 16 x 9.
+// Window lengths up to 1152 that no smooth in-place transform serves -- N = 1103 first of all, what the reference's 25 ms windows
+// are on its shipped 44.1 kHz WAVs -- as a chirp (Bluestein) convolution of the FIXED length L = 2304 = 16 x 16 x 9: a pair of
+// real frames (z = x0 + i x1) through ONE length-N DFT, whatever the parity or the factors of N (capi.hip decides which plans:
+// every such float64 plan above 512 samples, shorter ones where the any-N routes would cost more than this kernel's fixed price).
 //
 // The any-N kernel (melspec_generic.hip) runs this length with run-time stage geometry: two autosort transforms of three
 // stages, every stage a load-all / barrier / store-all round trip through LDS -- six round trips and twelve barriers, its
@@ -342,10 +344,12 @@ void k_melspec_chirp(const MelspecArgs a) {
 
 }  // namespace
 
-// which plans the fixed-geometry kernel serves: odd window lengths (M = N) whose chirp convolution has the length 2304 the
-// any-N route would pick, and whose window fits the first stage's eight blocks of 144
-bool melspec_chirp_serves(int N, int M, int bl_L, int compute_dtype) {
-    return compute_dtype == AUD_F64 && bl_L == kL && (N & 1) == 1 && M == N && 2 * M - 1 <= kL && M <= 8 * kBlk;
+// which plans the fixed-geometry kernel CAN serve: float64 (pairs of real frames), windows whose chirp convolution fits L = 2304
+// and the first stage's eight blocks of 144 (N <= 1152).  Whether it SHOULD is the plan's business (capi.hip: every such window
+// above 512 samples without a smooth in-place route; shorter ones where the any-N route would cost more than this kernel's fixed
+// ~29 us per 256 segments of 14 frames)
+bool melspec_chirp_serves(int N, int compute_dtype) {
+    return compute_dtype == AUD_F64 && N >= 2 && 2 * N - 1 <= kL && N <= 8 * kBlk;
 }
 
 size_t melspec_chirp_lds_bytes() { return size_t(16 * kPitch) * 16 + 32; }

@@ -215,7 +215,7 @@ int aud_plan_create(aud_ctx* ctx, const aud_plan_desc* desc, const int32_t* bin_
                     const double* gabor_filters, aud_plan** plan);
 int aud_plan_destroy(aud_plan* plan);
 /* which frame->mel kernel family the plan selected: "w16x16" (N = 512), "w20x10" (N = 400), "w64x16" (N = 2048),
- * "chirp2304" (float64 plans with an odd 1024 < N <= 1152: dft.go:42-50 at the reference's own N = 1103), "generic" (any other N
+ * "chirp2304" (float64 plans with a window up to 1152 samples that has no smooth in-place route: dft.go:42-50 at the reference's own N = 1103, at 551, 1001 ...), "generic" (any other N
  * whose transform fits a workgroup's LDS, and any plan with "kernel" = 1) or "direct" (every other N: the O(N H) sum) -- diagnostic */
 const char* aud_plan_kernel_name(const aud_plan* plan);
 /* Tuning / diagnostic switches; results are identical whatever they are set to (up to the last-place effects of a

@@ -691,8 +691,8 @@ def case_random_any_n(orc, seed, windows):
 
 
 def case_chirp_kernel(orc, N, cdt, seed=0, sig_kind="float", quirks=False):
-    """The fixed-geometry chirp kernel (melspec_chirp.hip: odd window lengths 1024 < N <= 1152, L = 2304 = 16 x 16 x 9, the
-    reference's N = 1103) against the oracle AND against the any-N route it replaces (plan option chirp_kernel = 0): mel, Power
+    """The fixed-geometry chirp kernel (melspec_chirp.hip: windows 512 < N <= 1152 without a smooth in-place route, L = 2304 =
+    16 x 16 x 9, the reference's N = 1103 first of all) against the oracle AND against the any-N route it replaces (plan option chirp_kernel = 0): mel, Power
     and log-power of a seeded random parameter set; `quirks`: an all-zero frame beside a loud one, a frame with an Inf sample
     beside a finite one (its bins NaN, the partner's untouched), segments that run off the signal end, a left zero pad."""
     assert not (quirks and sig_kind == "int16")          # (an int16 stream cannot hold the Inf sample)
@@ -731,7 +731,10 @@ def case_chirp_kernel(orc, N, cdt, seed=0, sig_kind="float", quirks=False):
         plan = runtime.Plan(runtime.get_ctx(0), N, S, T, border, dftp, mp.FBank.to_c(), mp.BinPts, filt, compute_dtype=cdt)
         try:
             plan.set_option("chirp_kernel", opt)
-            assert plan.kernel_name == ("chirp2304" if opt else "generic") and plan.info("bluestein_L") == 2304 and plan.info("chirp_kernel") == opt
+            # (the any-N route behind the option: Bluestein on whatever length IT picks -- 2304 for 1024 < N <= 1152, 1152 for
+            #  N = 551 --, or no Bluestein at all where N's factors are <= 25: N = 1001 = 7 x 11 x 13 runs the O(p) passes)
+            assert plan.kernel_name == ("chirp2304" if opt else "generic") and plan.info("chirp_kernel") == opt
+            assert plan.info("generic_frames_per_wg") == 2 or not opt
             items = runtime.make_items([r * L for r, s in segs], [L] * len(segs), [s * sp.stride_samples for r, s in segs])
             if sig_kind == "int16":    # the device normalises the PCM itself (sound.go:138), sample by sample as the window is read
                 dev = runtime.Signal(plan.ctx, pcm.ravel())

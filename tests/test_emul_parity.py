@@ -38,8 +38,10 @@ def test_emul_melspec_vs_oracle(orc, emu, case, cdt):
 
 @pytest.mark.parametrize("N,cdt,kind,quirks", [(1103, capi.AUD_F64, "float", True), (1103, capi.AUD_F64, "int16", False),
                                                (1027, capi.AUD_F64, "float", False), (1151, capi.AUD_F64, "float", True),
-                                               (1025, capi.AUD_F64, "int16", False)],
-                         ids=["n1103_f64_quirks", "n1103_f64_i16", "n1027_f64", "n1151_f64_quirks", "n1025_f64_i16"])
+                                               (1025, capi.AUD_F64, "int16", False), (551, capi.AUD_F64, "float", True),
+                                               (1014, capi.AUD_F64, "int16", False), (1001, capi.AUD_F64, "float", False), (507, capi.AUD_F64, "float", True)],
+                         ids=["n1103_f64_quirks", "n1103_f64_i16", "n1027_f64", "n1151_f64_quirks", "n1025_f64_i16", "n551_f64_quirks",
+                              "n1014_f64_i16", "n1001_f64", "n507_f64_quirks"])
 def test_emul_chirp_kernel(orc, emu, N, cdt, kind, quirks):
     """the fixed-geometry chirp kernel of L = 2304 (melspec_chirp.hip) vs the oracle and vs the any-N route, at both ends of the
     window lengths it serves"""

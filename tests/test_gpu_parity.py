@@ -608,9 +608,13 @@ def test_random_any_n_configs(orc, torch_cuda):
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,cdt,kind,quirks", [(1103, capi.AUD_F64, "float", True), (1103, capi.AUD_F64, "int16", False),
                                                (1027, capi.AUD_F64, "float", False), (1151, capi.AUD_F64, "float", True),
-                                               (1025, capi.AUD_F64, "int16", False), (1131, capi.AUD_F64, "float", True)],
+                                               (1025, capi.AUD_F64, "int16", False), (1131, capi.AUD_F64, "float", True),
+                                               (551, capi.AUD_F64, "float", True), (1014, capi.AUD_F64, "int16", False),
+                                               (1001, capi.AUD_F64, "float", False), (1126, capi.AUD_F64, "float", True),
+                                               (513, capi.AUD_F64, "int16", False), (1150, capi.AUD_F64, "float", True), (507, capi.AUD_F64, "float", True)],
                          ids=["n1103_f64_quirks", "n1103_f64_i16", "n1027_f64", "n1151_f64_quirks", "n1025_f64_i16",
-                              "n1131_f64_quirks"])
+                              "n1131_f64_quirks", "n551_f64_quirks", "n1014_f64_i16", "n1001_f64", "n1126_f64_quirks", "n513_f64_i16",
+                              "n1150_f64_quirks", "n507_f64_quirks"])
 def test_chirp_kernel(orc, torch_cuda, N, cdt, kind, quirks):
     """the fixed-geometry chirp kernel of L = 2304 (melspec_chirp.hip: the reference's N = 1103 and the other odd window lengths
     it serves) against the oracle and against the any-N route it replaces, three seeds each"""

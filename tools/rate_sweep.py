@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--launches", type=int, default=200)
     ap.add_argument("--compute", choices=["f32", "f64"], default="f64")
     ap.add_argument("--json", default="", help="also write the rows to this file")
+    ap.add_argument("--lengths", default="", help="window lengths N instead of rates: '/'-separated, at 16 kHz (WinMs = N / 16)")
+    ap.add_argument("--option", action="append", default=[], help="plan option name=value (e.g. chirp_kernel=0), repeatable")
     args = ap.parse_args()
 
     import torch
@@ -40,9 +42,11 @@ def main():
     cdt = capi.AUD_F32 if args.compute == "f32" else capi.AUD_F64
     B = args.batch
     rows = []
-    for sr in [int(r) for r in args.rates.replace("/", ",").split(",")]:
-        name = "sweep_%d" % sr
-        W.CONFIGS[name] = (sr, args.win_ms, 10.0, 100.0, 100.0, 2, 32, 0.0, min(8000.0, sr / 2.0))
+    todo = ([(16000, int(n) / 16.0) for n in args.lengths.replace("/", ",").split(",")] if args.lengths else
+            [(int(r), args.win_ms) for r in args.rates.replace("/", ",").split(",")])
+    for sr, win_ms in todo:
+        name = "sweep_%d_%g" % (sr, win_ms)
+        W.CONFIGS[name] = (sr, win_ms, 10.0, 100.0, 100.0, 2, 32, 0.0, min(8000.0, sr / 2.0))
         try:
             oc = W.OracleCfg(orc, name)
         except AssertionError:
@@ -54,6 +58,8 @@ def main():
         except capi.AuditoryError as ex:
             rows.append({"rate": sr, "N": oc.N, "error": str(ex)})
             continue
+        for o in args.option:
+            plan.set_option(o.split("=")[0], int(o.split("=")[1]))
         # ---- parity on two streams x four segments (host entry; the oracle is the checker)
         Lp = oc.sp.stride_samples * 4 + oc.N
         sig64, _ = synth.batch(11 + sr % 97, 2, Lp, sr)
