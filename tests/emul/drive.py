@@ -44,6 +44,12 @@ def main():
             # (system-scope atomics polled by one lane per peer: what ThreadSanitizer is for)
             PC.case_melspec_vs_oracle(orc, ("cfg1_44k_n1103_nf32", 0.12, 1, [0]), capi.AUD_F64)
             PC.case_melspec_vs_oracle(orc, ("cfg1_44k_n1103_nf32", 0.12, 1, [0]), capi.AUD_F32)
+            # round 6, second half: the chirp kernel is what the two cfg1 float64 cases above now run; the any-N kernel's pair route
+            # behind its option, smooth lengths in place (eight frames per workgroup as one batched transform; radix 7), the direct kernel
+            PC.case_melspec_vs_oracle(orc, ("cfg1_44k_n1103_nf32", 0.12, 1, [0]), capi.AUD_F64, options={"chirp_kernel": 0})
+            PC.case_melspec_vs_oracle(orc, ("rate_8k_n200_nf32", 0.25, 1, [0, 1]), capi.AUD_F64)
+            PC.case_melspec_vs_oracle(orc, ("win20_44k_n882_nf32", 0.12, 1, [0]), capi.AUD_F32)
+            PC.case_direct_kernel(orc, 5123, capi.AUD_F64, sig_kind="int16")
             PC.case_direct_gather_three_ranks()
             # round 6: the exact resident Signal (host shadow, block compares, partial uploads: memcmp / memcpy bounds are what
             # AddressSanitizer is for; the direct gather case above now ends in the sticky time-out with its NaN fill)
