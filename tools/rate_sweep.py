@@ -110,7 +110,8 @@ def main():
                 torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1) * 1e3 / args.launches)
             res[n_streams] = statistics.median(ts)
-        rows.append({"rate": sr, "N": oc.N, "S": oc.S, "T": oc.T, "kernel": plan.kernel_name, "bluestein_L": plan.info("bluestein_L"),
+        rows.append({"rate": sr, "N": oc.N, "S": oc.S, "T": oc.T, "kernel": plan.kernel_name,
+                     "bluestein_L": 2304 if plan.kernel_name == "chirp2304" else plan.info("bluestein_L"),   # (the length the kernel in use transforms on)
                      "frames_per_wg": plan.info("generic_frames_per_wg") if plan.kernel_name in ("generic", "chirp2304") else None,
                      "us_one_stream": round(res[1], 2), "us_two_streams": round(res[2], 2),
                      "ns_per_frame": round(res[2] * 1e3 / (B * oc.T), 2),
