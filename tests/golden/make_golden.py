@@ -32,6 +32,12 @@ FIXTURES = {
     # Segments: 0 (left pad + leading gap), 1 (first syllable), 2 (a gap: all-zero frames), 5 (voiced), 12, 29 (the last).
     "speech_16k_n400_nf32": ("sndenv_16k_n400_nf32", None, 3.0, 1, [0, 1, 2, 5, 12, 29], 31, "pool8x2"),
     "speech_44k_n1103_nf32": ("cfg1_44k_n1103_nf32", None, 3.0, 1, [0, 1, 2, 5, 12, 29], 32, "pool8x2"),
+    # round 6: processspeech's parameters at other sample rates -- the any-N kernel's in-place route (8 kHz: eight frames per
+    # workgroup; 48 kHz: two), the chirp kernel beyond N = 1103 (22.05 kHz: N = 551), radix 7 on an odd window (50 ms at 44.1 kHz)
+    "rate_8k_n200_nf32": ("rate_8k_n200_nf32", None, 0.3, 2, [0, 1, 2], 41, "pool8x2"),
+    "rate_22k_n551_nf32": ("rate_22k_n551_nf32", None, 0.3, 2, [0, 1], 42, "pool8x2"),
+    "rate_48k_n1200_nf32": ("rate_48k_n1200_nf32", None, 0.3, 2, [0, 1], 43, "pool8x2"),
+    "win50_44k_n2205_nf64": ("win50_44k_n2205_nf64", None, 0.3, 1, [0, 1], 44, None),
 }
 GABOR = {"pool8x2": (8, 2), "pool11x32": (11, 32)}
 SPEECH = ("speech_16k_n400_nf32", "speech_44k_n1103_nf32")   # inputs from synth.speech_like; fixtures carry the MFCC tail
@@ -78,7 +84,7 @@ def compute(name):
 
 
 if __name__ == "__main__":
-    for name in FIXTURES:
+    for name in (sys.argv[1:] or FIXTURES):   # (names on the command line: only those)
         d = compute(name)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
         print(name, {k: v.shape for k, v in d.items()})
