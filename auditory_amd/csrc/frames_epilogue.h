@@ -10,6 +10,39 @@
 
 namespace aud {
 
+// ln v for the epilogue's values.  float32 plans: logf.  float64 plans: v = m 2^e with sqrt(1/2) <= m < sqrt(2),
+// ln m = 2 atanh(t), t = (m - 1) / (m + 1), |t| <= 0.1716 -- the odd series through t^15 (what is dropped: < 3e-13), the quotient
+// by the hardware's reciprocal with two Newton steps and one residual correction.  ~35 vector instructions against the ~100
+// of the library's log(); absolute error < 1e-12 -- these values are stored as float32 (6e-8) or feed sums that are compared at
+// 3e-7 (Energy, the DCT rows).  v = 0 never arrives (the callers return LogMin for it: dft.go:79, mel.go:135); NaN, negative and
+// infinite arguments take the library's route.  A whole ProcessSegment workgroup at N = 1103 takes 1 104 of these logarithms.
+__device__ __forceinline__ float epi_log(float v) { return logf(v); }
+__device__ __forceinline__ double epi_log(double v) {
+    if (!(v > 0.0) || v > 1.0e308) return log(v);
+    int e = 0;
+    double m = frexp(v, &e);                                    // [1/2, 1)
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;                                        // [sqrt(1/2), sqrt(2))
+    e -= low ? 1 : 0;
+    const double num = m - 1.0, den = m + 1.0;                  // (exact: m has 53 bits in [0.7, 1.42))
+    double r = __builtin_amdgcn_rcp(den);
+    r = fma(fma(-den, r, 1.0), r, r);
+    r = fma(fma(-den, r, 1.0), r, r);
+    double t = num * r;
+    t = fma(fma(-den, t, num), r, t);                           // t = num / den to ~1 ulp
+    const double t2 = t * t;
+    double p = 1.0 / 15.0;
+    p = fma(p, t2, 1.0 / 13.0);
+    p = fma(p, t2, 1.0 / 11.0);
+    p = fma(p, t2, 1.0 / 9.0);
+    p = fma(p, t2, 1.0 / 7.0);
+    p = fma(p, t2, 1.0 / 5.0);
+    p = fma(p, t2, 1.0 / 3.0);
+    const double two_t = t + t;
+    const double lnm = fma(two_t * t2, p, two_t);               // 2 t (1 + t^2 / 3 + ... + t^14 / 15)
+    return fma(double(e), 0.693147180559945309417, lnm);
+}
+
 // WALK: how the mel loop deals its work -- true: a slot of four lanes keeps one filter and walks the workgroup's frames (the any-N
 // and direct kernels: up to sixteen frames per workgroup); false: a slot per (frame, filter) pair (the chirp kernel: two frames,
 // one pass either way, and this form is 3 % faster there: profiles/round6_epilogue_walk_ab.txt)
@@ -33,7 +66,7 @@ __device__ __forceinline__ void frames_epilogue(const MelspecArgs& a, const aud_
                 float lp = 0.f;
                 if (live && a.comp_log_pow) {
                     const TT v = pw + off;
-                    lp = float(v == TT(0) ? lmin : dev_log(v));
+                    lp = float(v == TT(0) ? lmin : epi_log(v));
                 }
                 a.log_power[o] = lp;
             }
@@ -52,7 +85,7 @@ __device__ __forceinline__ void frames_epilogue(const MelspecArgs& a, const aud_
                 const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
                 if (sstep < T && start + N <= int64_t(it.sig_len)) {  // (a step the loop never reached left LogPowerSegment at 0)
                     const TT v = P[size_t(f) * Hp + s] + off;
-                    e += v == TT(0) ? lmin : dev_log(v);
+                    e += v == TT(0) ? lmin : epi_log(v);
                 }
             }
             ep[s] = e;
@@ -115,7 +148,7 @@ __device__ __forceinline__ void frames_epilogue(const MelspecArgs& a, const aud_
                     TT val = TT(0);
                     if (live) {
                         sum += loff;
-                        val = (sum == TT(0)) ? lmin : dev_log(sum);
+                        val = (sum == TT(0)) ? lmin : epi_log(sum);
                         if (a.renorm) {
                             val -= TT(a.renorm_min);
                             if (val < TT(0)) val = TT(0);
@@ -171,7 +204,7 @@ __device__ __forceinline__ void frames_epilogue(const MelspecArgs& a, const aud_
                 TT val = TT(0);
                 if (live) {
                     sum += loff;
-                    val = (sum == TT(0)) ? lmin : dev_log(sum);
+                    val = (sum == TT(0)) ? lmin : epi_log(sum);
                     if (a.renorm) {
                         val -= TT(a.renorm_min);
                         if (val < TT(0)) val = TT(0);

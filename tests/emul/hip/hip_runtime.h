@@ -52,6 +52,7 @@ inline void __builtin_amdgcn_sched_barrier(int) {}
 #define AUD_EMUL_ABSMAX3 1
 inline float absmax3(float m, float x, float y) { return fmaxf(m, fmaxf(fabsf(x), fabsf(y))); }
 inline float __builtin_amdgcn_logf(float v) { return log2f(v); }  // v_log_f32 is a base-2 logarithm
+inline double __builtin_amdgcn_rcp(double v) { return double(float(1.0 / v)); }  // v_rcp_f64: an APPROXIMATION (~2^-26), refined by the caller
 // same-value races the 20 x 10 wave kernel has by design (shadow lanes): ThreadSanitizer is told to look away
 #if defined(__SANITIZE_THREAD__)
 extern "C" void AnnotateIgnoreWritesBegin(const char*, int);
