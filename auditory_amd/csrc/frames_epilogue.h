@@ -53,22 +53,27 @@ __device__ __forceinline__ void frames_epilogue(const MelspecArgs& a, const aud_
     // ---- optional PowerSegment / LogPowerSegment (dft.go:70-83) -----------------------
     if (a.power || a.log_power) {
         const TT off = TT(a.dft_log_off), lmin = TT(a.dft_log_min);
+        const int f_log = 31 - __builtin_clz(unsigned(F));  // (frames per workgroup are a power of two on every route: 1 .. 16)
+        // the item's [H][T] tensors as pointers, 32-bit offsets inside them (the loop had carried two 64-bit products and a
+        // division by F per value)
+        float* __restrict__ pw_out = a.power ? a.power + size_t(item) * H * T : nullptr;
+        float* __restrict__ lp_out = a.log_power ? a.log_power + size_t(item) * H * T : nullptr;
         for (int w = tid; w < F * H; w += blockDim.x) {
-            const int k = w / F, f = w - k * F;
+            const int k = w >> f_log, f = w - (k << f_log);
             const int sstep = t0 + f;
             if (sstep >= T) continue;
             const int64_t start = int64_t(it.start0) + int64_t(a.S) * (sstep - a.border);
             const bool live = start + N <= int64_t(it.sig_len);
-            const TT pw = P[size_t(f) * Hp + k];
-            const size_t o = (size_t(item) * H + k) * T + sstep;
-            if (a.power) a.power[o] = live ? float(pw) : 0.f;
-            if (a.log_power) {
+            const TT pw = P[f * Hp + k];
+            const int o = k * T + sstep;
+            if (pw_out) pw_out[o] = live ? float(pw) : 0.f;
+            if (lp_out) {
                 float lp = 0.f;
                 if (live && a.comp_log_pow) {
                     const TT v = pw + off;
                     lp = float(v == TT(0) ? lmin : epi_log(v));
                 }
-                a.log_power[o] = lp;
+                lp_out[o] = lp;
             }
         }
     }
