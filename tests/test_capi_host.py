@@ -193,14 +193,17 @@ def test_kernels_use_no_scratch_and_fit_their_occupancy():
     # waves per SIMD each kernel's launch geometry assumes (its LDS allows no more than this anyway)
     need_occupancy = {"k_melspec_w16IfL": 5, "k_melspec_w20IfL": 5, "k_melspec_w64IfL": 5, "k_melspec_w16IdL": 3,
                       "k_melspec_w20IdL": 4, "k_melspec_w64IdL": 3, "k_melspec_genericIf": 2,
-                      "k_melspec_genericIdLb1": 4, "k_melspec_genericIfLb1": 4}   # in-place Bluestein: four workgroups per CU
+                      "k_melspec_genericIdLb1": 4, "k_melspec_genericIfLb1": 4,   # in-place routes: four workgroups per CU
+                      "k_melspec_chirp": 4, "k_melspec_direct": 4}
     # the float64 in-place Bluestein kernel is HELD at four waves per SIMD (amdgpu_waves_per_eu: its one-buffer layout exists for
     # the occupancy); the allocator parks three registers once per radix-16 stage for that -- three dword spill / reload pairs
     # in 24 000 instructions, measured 15 % faster than the same kernel at three waves without them
-    scratch_allowed = {"k_melspec_genericIdLb1": 16}
+    # (the chirp kernel, held at four waves the same way: three dword pairs too -- more live registers there cost more than they
+    #  hide, profiles/round6_chirp_taps_prefetch_experiment.patch: 20 bytes and +4 %)
+    scratch_allowed = {"k_melspec_genericIdLb1": 16, "k_melspec_chirp": 12}
     seen = {}
     from concurrent.futures import ThreadPoolExecutor
-    srcs = ("melspec_generic.hip", "melspec_w20.hip", "melspec_w64.hip", "melspec_w16.hip", "smooth_mel.hip", "mfcc.hip", "gabor.hip", "kwta.hip")
+    srcs = ("melspec_generic.hip", "melspec_chirp.hip", "melspec_direct.hip", "melspec_w20.hip", "melspec_w64.hip", "melspec_w16.hip", "smooth_mel.hip", "mfcc.hip", "gabor.hip", "kwta.hip")
 
     def compile_one(src):   # (--cuda-device-only: the resource report is the device pass's; the host pass is half the time)
         return subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "--cuda-device-only",
