@@ -6,7 +6,7 @@ set -eu
 TAG=${1:?gpurun tag}; ROUND=${2:?round name}
 cd "$(dirname "$0")/.."
 specs=""
-for wl in headline n512 cfg4 cfg5 sndenv cfg1 rate48k; do
+for wl in headline n512 cfg4 cfg5 sndenv cfg1 rate48k sndenv_cfg1; do
     [ -f "gpurun_out/${TAG}_${wl}_kernels.json" ] || continue
     for suf in summary.txt kernel_stats.csv kernels.json; do
         cp "gpurun_out/${TAG}_${wl}_${suf}" "profiles/${ROUND}_${wl}_${suf}"

@@ -36,7 +36,7 @@ for step in "$@"; do
                run ab$i 300 python tools/ab_bench.py $args ;;
         profile) run profile_headline 900 bash tools/profile_bench.sh "${TAG}_headline" ;;
         profile:*) args=$(echo "${step#profile:}" | tr ',' ' ')   # tag = TAG_<workload>
-               wl=$(echo " $args " | sed -n -e 's/.* --workload \([a-z0-9]*\) .*/\1/p'); wl=${wl:-headline}
+               wl=$(echo " $args " | sed -n -e 's/.* --workload \([a-z0-9_]*\) .*/\1/p'); wl=${wl:-headline}
                run profile_$wl 900 bash tools/profile_bench.sh "${TAG}_$wl" $args ;;
         stamps:*) args=$(echo "${step#stamps:}" | tr ',' ' ')
                run stamps$i 400 python tools/stamp_profile.py $args ;;

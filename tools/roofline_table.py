@@ -23,7 +23,7 @@ MEASURED_READ_GBPS = 6047.0
 # the triangles' widths + nf logarithms, evaluated on the product's own mel table: bench.py frame_flops gives the same figure)
 WL = {"headline": (16000, 104, 40, 201, 10.14), "n512": (16000, 104, 40, 257, 13.43), "cfg4": (16000, 104, 40, 201, 10.14),
       "sndenv": (16000, 104, 40, 201, 10.14), "cfg5": (220500, 504, 128, 1025, 63.7), "cfg1": (4410, 14, 32, 552, 30.39),
-      "rate48k": (4800, 14, 32, 601, 33.35)}
+      "rate48k": (4800, 14, 32, 601, 33.35), "sndenv_cfg1": (4410, 14, 32, 552, 30.39)}
 
 
 def algorithmic(fam, wl, B):
@@ -31,7 +31,7 @@ def algorithmic(fam, wl, B):
     dur, T, nf, H, kflop = WL[wl]
     mel_out = 4 * nf * T
     if fam in ("w20x10", "w16x16", "w64x16", "generic", "chirp2304"):
-        extra = 2 * 4 * H * T if wl == "sndenv" else 0            # Power + LogPower tensors
+        extra = 2 * 4 * H * T if wl.startswith("sndenv") else 0   # Power + LogPower tensors
         return B * (4 * dur + mel_out + extra), B * T * kflop * 1e3
     if fam == "w20item":  # workgroup per item; cfg4: + the fused Convolve (no re-read of mel), [11, 32, 2, 8] written
         gab = wl == "cfg4"
