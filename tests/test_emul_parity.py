@@ -131,13 +131,15 @@ def test_emul_recreated_tone_fixtures_f64(orc, emu):
     PC.case_recreated_tone_fixtures_f64(orc)
 
 
-@pytest.mark.parametrize("name", ["sndenv_16k_n400_nf32", "cfg2_16k_n512_nf40"])
+@pytest.mark.parametrize("name", ["sndenv_16k_n400_nf32", "cfg2_16k_n512_nf40", "cfg1_44k_n1103_nf32", "rate_48k_n1200_nf32",
+                                  "rate_8k_n200_nf32"])   # wave kernels; the chirp kernel; smooth lengths in place (F = 2, 8)
 @pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
 def test_emul_prev_smooth(orc, emu, name, cdt):
     PC.case_prev_smooth(orc, name, cdt)
 
 
-@pytest.mark.parametrize("name", ["sndenv_16k_n400_nf32", "cfg2_16k_n512_nf40"])
+@pytest.mark.parametrize("name", ["sndenv_16k_n400_nf32", "cfg2_16k_n512_nf40", "rate_48k_n1200_nf32", "rate_8k_n200_nf32",
+                                  "rate_22k_n551_nf32", "win20_44k_n882_nf32"])   # + in place (F = 2, 8), the chirp kernel at N = 551, radix 7
 @pytest.mark.parametrize("cdt", [capi.AUD_F32, capi.AUD_F64], ids=["f32", "f64"])
 def test_emul_mfcc_tail(orc, emu, name, cdt):
     PC.case_mfcc_tail(orc, name, cdt)
